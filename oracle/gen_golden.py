@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  The reference never travels:
+what is written is data -- the inputs handed to the reference (or the seeds that
+regenerate them through ``fast_forward_amd.synth``) and the outputs it produced.
+
+Import recipe: the reference imports ``nanopq`` and ``h5py`` at package
+import time although the re-ranking path uses neither; both are absent here, so empty
+stand-in modules are registered, and ``importlib.metadata.version`` is answered for the
+uninstalled distribution.  Nothing on the measured path is stubbed.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz + manifest.json
+"""
+
+from __future__ import annotations
+
+import hashlib
+import importlib.metadata as _md
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+sys.dont_write_bytecode = True
+
+for _name, _attrs in (("nanopq", ("PQ", "OPQ")), ("h5py", ("File",))):
+    _m = types.ModuleType(_name)
+    for _a in _attrs:
+        setattr(_m, _a, type(_a, (), {}))
+    sys.modules[_name] = _m
+_orig_version = _md.version
+_md.version = lambda n: "0.8.0" if n == "fast-forward-indexes" else _orig_version(n)
+sys.path.insert(0, "/root/reference/src")
+
+from fast_forward import Ranking  # noqa: E402  (the reference)
+from fast_forward.encoder import LambdaEncoder  # noqa: E402
+from fast_forward.index import InMemoryIndex, Mode  # noqa: E402
+
+from fast_forward_amd import synth  # noqa: E402  (the build's generator)
+
+OUT = ROOT / "tests" / "golden"
+MODES = {"PASSAGE": Mode.PASSAGE, "MAXP": Mode.MAXP, "FIRSTP": Mode.FIRSTP, "AVEP": Mode.AVEP}
+ALPHAS = (0.05, 0.1, 0.2, 0.5)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def frame_arrays(r: Ranking) -> dict[str, np.ndarray]:
+    df = r._df
+    return {
+        "q_id": df["q_id"].to_numpy().astype(str),
+        "id": df["id"].to_numpy().astype(str),
+        "score": df["score"].to_numpy().astype(np.float32),
+    }
+
+
+def make_index(vectors, doc_ids, psg_ids, qvecs, mode):
+    enc = LambdaEncoder(lambda t: qvecs[int(t)])
+    idx = InMemoryIndex(query_encoder=enc, mode=mode, init_size=max(1, len(vectors)))
+    idx.add(vectors, doc_ids=doc_ids, psg_ids=psg_ids)
+    return idx
+
+
+def run_frame(q_names, cand_ids, sparse):
+    """Candidate lists -> reference Ranking with queries attached (query text = q_no)."""
+    rows = []
+    for qi, qn in enumerate(q_names):
+        for cid, s in zip(cand_ids[qi], sparse[qi]):
+            rows.append((qn, cid, s))
+    df = pd.DataFrame(rows, columns=["q_id", "id", "score"])
+    return Ranking(df, queries={qn: str(i) for i, qn in enumerate(q_names)})
+
+
+def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, sparse_hi, modes, k_psg=None):
+    """Synthetic corpus: docs with psg_lo..psg_hi passages, stored contiguously."""
+    rng = np.random.default_rng(seed)
+    per_doc = rng.integers(psg_lo, psg_hi + 1, size=n_docs)
+    n_rows = int(per_doc.sum())
+    doc_of_row = np.repeat(np.arange(n_docs), per_doc).astype(np.int32)
+    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    qvecs = synth.rows(seed + 1000, scale, 0, n_q, dim)
+    doc_ids = [f"D{d}" for d in doc_of_row]
+    psg_ids = [f"P{r}" for r in range(n_rows)]
+    q_names = [f"q{i:03d}" for i in range(n_q)]
+    cand_docs = np.stack([rng.choice(n_docs, size=k, replace=False) for _ in range(n_q)]).astype(np.int32)
+    kp = k_psg or k
+    cand_psgs = np.stack([rng.choice(n_rows, size=kp, replace=False) for _ in range(n_q)]).astype(np.int32)
+    sparse_doc = (rng.random((n_q, k)) * sparse_hi).astype(np.float32)
+    sparse_psg = (rng.random((n_q, kp)) * sparse_hi).astype(np.float32)
+    out = {
+        "seed": seed, "dim": dim, "scale": np.float32(scale), "n_rows": n_rows,
+        "doc_of_row": doc_of_row, "cand_docs": cand_docs, "cand_psgs": cand_psgs,
+        "sparse_doc": sparse_doc, "sparse_psg": sparse_psg,
+        "vectors_sha": sha(vectors), "queries_sha": sha(qvecs), "q_names": np.array(q_names),
+    }
+    for mname in modes:
+        mode = MODES[mname]
+        if mode == Mode.PASSAGE:
+            first = run_frame(q_names, [[f"P{c}" for c in row] for row in cand_psgs], sparse_psg)
+        else:
+            first = run_frame(q_names, [[f"D{c}" for c in row] for row in cand_docs], sparse_doc)
+        idx = make_index(vectors, doc_ids, psg_ids, qvecs, mode)
+        dense = idx(first)
+        for key, val in frame_arrays(dense).items():
+            out[f"{mname}_ff_{key}"] = val
+        for a in ALPHAS:
+            inter = first.interpolate(dense, a)
+            for key, val in frame_arrays(inter).items():
+                out[f"{mname}_int{a}_{key}"] = val
+    # batch_size invariance, straight from the reference (index/base.py:445-459)
+    mode = MODES[modes[-1]]
+    idx = make_index(vectors, doc_ids, psg_ids, qvecs, mode)
+    first = run_frame(q_names, [[f"D{c}" for c in row] for row in cand_docs], sparse_doc) \
+        if mode != Mode.PASSAGE else run_frame(q_names, [[f"P{c}" for c in row] for row in cand_psgs], sparse_psg)
+    assert idx(first) == idx(first, batch_size=7)  # (a divisor of Q trips index/base.py:455)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    return {"rows": n_rows, "pairs": int(n_q * k)}
+
+
+def partial_ids_case():
+    """Vectors with only a doc id / only a psg id / both; a doc re-opened by a later add()
+    (non-contiguous rows); candidates shared between queries.  Layout follows
+    tests/test_index.py:59-69 with real-valued data."""
+    dim, seed, scale = 16, 41, 0.5
+    doc_ids = [None, None, "d1", "d2", "d3", "d0", "d0", None, None, "d2", "d1"]
+    psg_ids = ["p0", "p1", "p2", None, None, None, None, "p3", "p4", "p5", None]
+    n = len(doc_ids)
+    vectors = synth.rows(seed, scale, 0, n, dim)
+    qvecs = synth.rows(seed + 1000, scale, 0, 3, dim)
+    out = {"seed": seed, "dim": dim, "scale": np.float32(scale),
+           "doc_ids": np.array([d or "" for d in doc_ids]), "psg_ids": np.array([p or "" for p in psg_ids])}
+    doc_run = {"qa": {"d0": 3.0, "d1": 1.5, "d2": 0.25, "d3": 7.0}, "qb": {"d1": 2.0, "d2": 9.0}, "qc": {"d2": 1.0, "d0": 0.5}}
+    psg_run = {"qa": {"p0": 1.0, "p5": 2.0, "p3": 0.5}, "qb": {"p1": 4.0, "p5": 1.0, "p2": 3.0}, "qc": {"p4": 2.5}}
+    queries = {"qa": "0", "qb": "1", "qc": "2"}
+    out["doc_run"] = json.dumps(doc_run)
+    out["psg_run"] = json.dumps(psg_run)
+    for mname, mode in MODES.items():
+        enc = LambdaEncoder(lambda t: qvecs[int(t)])
+        idx = InMemoryIndex(query_encoder=enc, mode=mode, init_size=64)
+        # three add() calls, as an index grows in practice
+        idx.add(vectors[:5], doc_ids=doc_ids[:5], psg_ids=psg_ids[:5])
+        idx.add(vectors[5:9], doc_ids=doc_ids[5:9], psg_ids=psg_ids[5:9])
+        idx.add(vectors[9:], doc_ids=doc_ids[9:], psg_ids=psg_ids[9:])
+        first = Ranking.from_run(psg_run if mode == Mode.PASSAGE else doc_run, queries=queries)
+        for key, val in frame_arrays(idx(first)).items():
+            out[f"{mname}_ff_{key}"] = val
+    np.savez_compressed(OUT / "partial_ids.npz", **out)
+    return {"rows": n}
+
+
+def interpolate_case():
+    """ranking.py:293-326 on frames that only partly overlap (missing => 0) +- normalize."""
+    rng = np.random.default_rng(5)
+    rows_a, rows_b = [], []
+    for q in range(6):
+        ids = rng.choice(40, size=25, replace=False)
+        for i in ids[:20]:
+            rows_a.append((f"q{q}", f"d{i}", np.float32(rng.random() * 25)))
+        for i in ids[5:]:
+            rows_b.append((f"q{q}", f"d{i}", np.float32(rng.standard_normal() * 3)))
+    rows_b.append(("q9", "d1", np.float32(1.25)))  # query missing from A
+    a = Ranking(pd.DataFrame(rows_a, columns=["q_id", "id", "score"]))
+    b = Ranking(pd.DataFrame(rows_b, columns=["q_id", "id", "score"]))
+    out = {}
+    for key, val in frame_arrays(a).items():
+        out[f"a_{key}"] = val
+    for key, val in frame_arrays(b).items():
+        out[f"b_{key}"] = val
+    for alpha in ALPHAS:
+        for norm in (False, True):
+            for key, val in frame_arrays(a.interpolate(b, alpha, normalize=norm)).items():
+                out[f"int{alpha}_{'norm' if norm else 'raw'}_{key}"] = val
+    np.savez_compressed(OUT / "interpolate.npz", **out)
+    return {"rows_a": len(rows_a), "rows_b": len(rows_b)}
+
+
+def early_stopping_case():
+    """index/base.py:316-387 on passage runs; cut-off, alpha and depths as fixture data."""
+    dim, seed, scale, n_psg, n_q = 32, 77, 0.35, 300, 6
+    vectors = synth.rows(seed, scale, 0, n_psg, dim)
+    qvecs = synth.rows(seed + 1000, scale, 0, n_q, dim)
+    rng = np.random.default_rng(seed)
+    q_names = [f"q{i}" for i in range(n_q)]
+    lens = [300, 250, 120, 300, 40, 9]
+    cands = [rng.choice(n_psg, size=n, replace=False).astype(np.int32) for n in lens]
+    sparse = [np.sort(rng.random(n).astype(np.float32) * 4)[::-1].copy() for n in lens]
+    first = run_frame(q_names, [[f"P{c}" for c in row] for row in cands], sparse)
+    idx = make_index(vectors, None, [f"P{r}" for r in range(n_psg)], qvecs, Mode.PASSAGE)
+    out = {"seed": seed, "dim": dim, "scale": np.float32(scale), "n_psg": n_psg, "q_names": np.array(q_names),
+           "lens": np.array(lens), "cands": np.concatenate(cands), "sparse": np.concatenate(sparse)}
+    configs = [(10, 0.2, (20, 50, 100, 300)), (5, 0.5, (5, 10, 40)), (25, 0.05, (100, 30, 1000)), (10, 0.9, (10, 11, 12, 300))]
+    out["configs"] = json.dumps(configs)
+    for ci, (cutoff, alpha, depths) in enumerate(configs):
+        res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+        for key, val in frame_arrays(res).items():
+            out[f"es{ci}_{key}"] = val
+    np.savez_compressed(OUT / "early_stopping.npz", **out)
+    return {"configs": len(configs)}
+
+
+def known_answers():
+    """The reference tests' own known answers, re-derived by running the reference
+    (tests/test_index.py:19-43,135-200; tests/test_ranking.py:157-188)."""
+    vecs = np.tril(np.ones((5, 5), dtype=np.int64))
+    doc_ids = ["d0", "d0", "d1", "d2", "d3"]
+    psg_ids = ["p0", "p1", "p2", "p3", "p4"]
+    queries = {"q1": "query 1", "q2": "query 2"}
+    doc_run = {"q1": {"d0": 100, "d1": 2, "d2": 3, "d3": 200}, "q2": {"d0": 400, "d1": 5, "d2": 6, "d3": 800}}
+    psg_run = {"q1": {"p0": 100, "p1": 2, "p2": 3, "p3": 4, "p4": 5}, "q2": {"p0": 500, "p1": 6, "p2": 7, "p3": 8, "p4": 9}}
+    got = {}
+    for mname, mode in MODES.items():
+        idx = InMemoryIndex(LambdaEncoder(lambda _: np.array([1, 1, 1, 1, 1])), mode=mode)
+        idx.add(vecs, doc_ids=doc_ids, psg_ids=psg_ids)
+        r = idx(Ranking.from_run(psg_run if mode == Mode.PASSAGE else doc_run, queries=queries))
+        got[mname] = {q: {k: float(v) for k, v in r[q].items()} for q in ("q1", "q2")}
+    assert got["MAXP"]["q1"] == {"d0": 2, "d1": 3, "d2": 4, "d3": 5}
+    assert got["FIRSTP"]["q1"]["d0"] == 1 and got["AVEP"]["q2"]["d0"] == 1.5
+    assert got["PASSAGE"]["q1"] == {f"p{i}": i + 1 for i in range(5)}
+    return {"vectors": vecs.tolist(), "doc_ids": doc_ids, "psg_ids": psg_ids, "queries": queries,
+            "doc_run": doc_run, "psg_run": psg_run, "expected": got}
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    manifest = {"reference": "mrjleo/fast-forward-indexes v0.8.0 (/root/reference)",
+                "numpy": np.__version__, "pandas": pd.__version__, "cases": {}}
+    manifest["cases"]["known_answers"] = known_answers()
+    manifest["cases"]["config1"] = scoring_case(
+        "config1", seed=1, dim=128, n_docs=1000, psg_lo=1, psg_hi=4, n_q=50, k=100, scale=0.15,
+        sparse_hi=20.0, modes=["PASSAGE", "MAXP", "AVEP", "FIRSTP"])
+    manifest["cases"]["d768"] = scoring_case(
+        "d768", seed=3, dim=768, n_docs=64, psg_lo=1, psg_hi=8, n_q=8, k=32, scale=1.0,
+        sparse_hi=25.0, modes=["PASSAGE", "FIRSTP", "AVEP", "MAXP"])
+    manifest["cases"]["s2_sub"] = scoring_case(
+        "s2_sub", seed=9, dim=768, n_docs=4000, psg_lo=1, psg_hi=8, n_q=12, k=400, scale=0.0625,
+        sparse_hi=25.0, modes=["MAXP"])
+    manifest["cases"]["odd_dims"] = {}
+    for dim in (5, 20, 100, 300, 384, 1024):
+        manifest["cases"]["odd_dims"][str(dim)] = scoring_case(
+            f"dim{dim}", seed=100 + dim, dim=dim, n_docs=40, psg_lo=1, psg_hi=3, n_q=4, k=12, scale=1.0,
+            sparse_hi=10.0, modes=["MAXP", "AVEP"])
+    manifest["cases"]["partial_ids"] = partial_ids_case()
+    manifest["cases"]["interpolate"] = interpolate_case()
+    manifest["cases"]["early_stopping"] = early_stopping_case()
+    (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
+    total = sum(f.stat().st_size for f in OUT.iterdir())
+    print(f"wrote {len(list(OUT.iterdir()))} files, {total / 1e6:.2f} MB -> {OUT}")
+
+
+if __name__ == "__main__":
+    main()

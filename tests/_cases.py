@@ -1,0 +1,112 @@
+"""Rebuild the inputs of a golden fixture as integer CSR arrays (shared by CPU and GPU tests)."""
+
+from __future__ import annotations
+
+import hashlib
+import json
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from fast_forward_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+MODE_NO = {"PASSAGE": 1, "MAXP": 2, "FIRSTP": 3, "AVEP": 4}
+ALPHAS = (0.05, 0.1, 0.2, 0.5)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def manifest() -> dict:
+    return json.loads((GOLDEN / "manifest.json").read_text())
+
+
+@dataclass
+class ScoringCase:
+    name: str
+    z: "np.lib.npyio.NpzFile"
+    vectors: np.ndarray
+    queries: np.ndarray
+    doc_off: np.ndarray
+    doc_rows: np.ndarray
+    psg_row: np.ndarray
+    doc_names: list
+    psg_names: list
+    q_names: list
+
+    def pairs(self, mode: str):
+        """(pair_off, pair_ids, sparse, id_names) with queries in fixture order (q_no = i)."""
+        if mode == "PASSAGE":
+            cands, sparse, prefix = self.z["cand_psgs"], self.z["sparse_psg"], "P"
+        else:
+            cands, sparse, prefix = self.z["cand_docs"], self.z["sparse_doc"], "D"
+        n_q, k = cands.shape
+        pair_off = np.arange(n_q + 1, dtype=np.int64) * k
+        ids = cands.reshape(-1).astype(np.int32)
+        names = [f"{prefix}{c}" for c in ids]
+        return pair_off, ids, sparse.reshape(-1).astype(np.float32), names
+
+    def modes(self):
+        return [m for m in MODE_NO if f"{m}_ff_score" in self.z.files]
+
+    def expected(self, key: str) -> dict:
+        """{(q_id, id): fp32 score} of a stored reference frame."""
+        z = self.z
+        return {(q, i): s for q, i, s in zip(z[f"{key}_q_id"].tolist(), z[f"{key}_id"].tolist(), z[f"{key}_score"])}
+
+    def expected_order(self, key: str) -> dict:
+        """{q_id: [(id, score), ...]} in the reference's output order."""
+        z = self.z
+        out: dict = {}
+        for q, i, s in zip(z[f"{key}_q_id"].tolist(), z[f"{key}_id"].tolist(), z[f"{key}_score"]):
+            out.setdefault(q, []).append((i, s))
+        return out
+
+
+def load_scoring_case(name: str) -> ScoringCase:
+    z = np.load(GOLDEN / f"{name}.npz")
+    seed, dim, scale, n_rows = int(z["seed"]), int(z["dim"]), float(z["scale"]), int(z["n_rows"])
+    n_q = z["cand_docs"].shape[0]
+    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    queries = synth.rows(seed + 1000, scale, 0, n_q, dim)
+    assert sha(vectors) == str(z["vectors_sha"]), "synthetic generator drifted from the fixture"
+    assert sha(queries) == str(z["queries_sha"])
+    doc_of_row = z["doc_of_row"]
+    n_docs = int(doc_of_row.max()) + 1
+    counts = np.bincount(doc_of_row, minlength=n_docs)
+    doc_off = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(counts, out=doc_off[1:])
+    doc_rows = np.argsort(doc_of_row, kind="stable").astype(np.int32)
+    return ScoringCase(
+        name=name, z=z, vectors=vectors, queries=queries, doc_off=doc_off, doc_rows=doc_rows,
+        psg_row=np.arange(n_rows, dtype=np.int32),
+        doc_names=[f"D{d}" for d in doc_of_row], psg_names=[f"P{r}" for r in range(n_rows)],
+        q_names=z["q_names"].tolist(),
+    )
+
+
+SCORING_CASES = ["config1", "d768", "s2_sub", "dim5", "dim20", "dim100", "dim300", "dim384", "dim1024"]
+
+
+def bits(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_order_modulo_ties(got_ids, got_scores, exp):
+    """Both lists are sorted by score descending; they may differ only inside runs of
+    exactly equal scores (ranking.py:116 uses an unstable sort)."""
+    exp_ids = [i for i, _ in exp]
+    exp_scores = np.array([s for _, s in exp], dtype=np.float32)
+    got_scores = np.asarray(got_scores, dtype=np.float32)
+    assert np.array_equal(bits(got_scores), bits(exp_scores)), "score sequences differ"
+    start = 0
+    n = len(exp_ids)
+    while start < n:
+        end = start + 1
+        while end < n and exp_scores[end] == exp_scores[start]:
+            end += 1
+        assert sorted(got_ids[start:end]) == sorted(exp_ids[start:end])
+        start = end

@@ -1,0 +1,45 @@
+"""Shared pytest setup: import paths, the ``gpu`` marker, and the GPU probe."""
+
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests", ROOT):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        from fast_forward_amd import native
+
+        return native.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def have_gpu():
+    return _have_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly rather than skip: nothing to do here.
+    # Plain `pytest` (no -m) on the CPU container skips the gpu tests.
+    if config.getoption("-m"):
+        return
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU here; run with -m gpu on the GPU box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,116 @@
+"""The CPU oracle against the golden fixtures produced by running the reference
+(oracle/gen_golden.py) and against the reference tests' own known answers.  CPU only."""
+
+import json
+
+import numpy as np
+import pytest
+
+import ffx_oracle as fo
+from _cases import ALPHAS, GOLDEN, MODE_NO, SCORING_CASES, assert_same_order_modulo_ties, bits, load_scoring_case, manifest
+
+
+@pytest.mark.parametrize("name", SCORING_CASES)
+def test_scores_bit_exact(name):
+    case = load_scoring_case(name)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        ff, _ = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries,
+                         pair_off, pair_ids, MODE_NO[mode])
+        exp = case.expected(f"{mode}_ff")
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+        assert np.array_equal(bits(ff), bits(want)), f"{name}/{mode}: max diff {np.abs(ff - want).max()}"
+
+
+@pytest.mark.parametrize("name", SCORING_CASES)
+def test_numpy_port_matches_c_oracle(name):
+    case = load_scoring_case(name)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, _ = case.pairs(mode)
+        a, ai = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries,
+                         pair_off, pair_ids, MODE_NO[mode], sparse, 0.1)
+        b, bi = fo.numpy_port_score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries,
+                                    pair_off, pair_ids, MODE_NO[mode], sparse, 0.1, batch_queries=3)
+        assert np.array_equal(bits(a), bits(b))
+        assert np.array_equal(bits(ai), bits(bi))
+
+
+@pytest.mark.parametrize("name", ["config1", "d768", "s2_sub"])
+def test_interpolation_and_order(name):
+    case = load_scoring_case(name)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        for alpha in ALPHAS:
+            ff, interp = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries,
+                                  pair_off, pair_ids, MODE_NO[mode], sparse, alpha)
+            exp = case.expected(f"{mode}_int{alpha}")
+            want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+            assert np.array_equal(bits(interp), bits(want)), f"{name}/{mode}/alpha={alpha}"
+            order = fo.order(interp, pair_off)
+            exp_order = case.expected_order(f"{mode}_int{alpha}")
+            for q, qn in enumerate(case.q_names):
+                sel = order[pair_off[q]:pair_off[q + 1]]
+                assert_same_order_modulo_ties([names[i] for i in sel], interp[sel], exp_order[qn])
+
+
+def test_reference_known_answers():
+    """tests/test_index.py:135-200 of the reference, through the oracle."""
+    ka = manifest()["cases"]["known_answers"]
+    vectors = np.array(ka["vectors"], dtype=np.float32)
+    doc_names, psg_names = ka["doc_ids"], ka["psg_ids"]
+    docs = sorted(set(doc_names), key=doc_names.index)
+    doc_rows = [r for d in docs for r, n in enumerate(doc_names) if n == d]
+    doc_off = np.cumsum([0] + [doc_names.count(d) for d in docs])
+    queries = np.ones((2, 5), dtype=np.float32)
+    for mode, exp in ka["expected"].items():
+        run = ka["psg_run"] if mode == "PASSAGE" else ka["doc_run"]
+        names = psg_names if mode == "PASSAGE" else docs
+        pair_ids, pair_off, keys = [], [0], []
+        for q in ("q1", "q2"):
+            for cid in run[q]:
+                pair_ids.append(names.index(cid))
+                keys.append((q, cid))
+            pair_off.append(len(pair_ids))
+        ff, _ = fo.score(vectors, doc_off, doc_rows, np.arange(5), queries, pair_off, pair_ids, MODE_NO[mode])
+        for (q, cid), s in zip(keys, ff):
+            assert s == exp[q][cid]
+    assert ka["expected"]["MAXP"]["q1"]["d0"] == 2 and ka["expected"]["AVEP"]["q1"]["d0"] == 1.5
+
+
+def test_reference_interpolate_known_answers():
+    """tests/test_ranking.py:157-188: alpha=0.5 on integer scores, and missing => 0."""
+    s = np.array([300, 2, 1], dtype=np.float32)
+    t = np.array([4, 5, 6], dtype=np.float32)
+    assert fo.interpolate(s, t, 0.5).tolist() == [152.0, 3.5, 3.5]
+    assert fo.interpolate([1, 1, 0], [1, 0, 1], 0.5).tolist() == [1.0, 0.5, 0.5]
+
+
+def test_interpolate_fixture_pairs_present_on_both_sides():
+    z = np.load(GOLDEN / "interpolate.npz")
+    a = {(q, i): s for q, i, s in zip(z["a_q_id"].tolist(), z["a_id"].tolist(), z["a_score"])}
+    b = {(q, i): s for q, i, s in zip(z["b_q_id"].tolist(), z["b_id"].tolist(), z["b_score"])}
+    for alpha in ALPHAS:
+        keys = list(zip(z[f"int{alpha}_raw_q_id"].tolist(), z[f"int{alpha}_raw_id"].tolist()))
+        assert set(keys) == set(a) | set(b)
+        sa = np.array([a.get(k, 0.0) for k in keys], dtype=np.float32)
+        sb = np.array([b.get(k, 0.0) for k in keys], dtype=np.float32)
+        assert np.array_equal(bits(fo.interpolate(sa, sb, alpha)), bits(z[f"int{alpha}_raw_score"]))
+
+
+def test_not_found_reports_pair():
+    case = load_scoring_case("dim20")
+    pair_off, pair_ids, _, _ = case.pairs("MAXP")
+    bad = pair_ids.copy()
+    bad[7] = len(case.doc_off) + 5
+    with pytest.raises(fo.OracleNotFound) as e:
+        fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, bad, 2)
+    assert e.value.pair == 7
+
+
+def test_synth_c_matches_numpy():
+    from fast_forward_amd import synth
+
+    for seed, scale, first, n, dim in [(1, 1.0, 0, 7, 5), (9, 0.0625, 12345, 4, 768), (2**40 + 3, 0.3, 2**33, 3, 128)]:
+        assert np.array_equal(bits(fo.synth_rows(seed, scale, first, n, dim)), bits(synth.rows(seed, scale, first, n, dim)))
