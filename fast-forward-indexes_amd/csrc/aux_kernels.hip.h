@@ -1,0 +1,171 @@
+// aux_kernels.hip.h -- the small kernels either side of gather_dot (all P- or R-sized streams,
+// <1 % of the bytes of the gather): candidate expansion, segment aggregation + interpolation,
+// row copy-out, synthetic fill.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ffx.h"
+
+namespace ffx {
+
+// ---- get_indices (src/fast_forward/index/util.py:12-42) on ordinals ----------------------
+// cnt[p] = number of index rows candidate p contributes; an ordinal that names no row is the
+// reference's IndexError: the smallest such pair position lands in *bad_pair.
+__global__ void __launch_bounds__(256)
+count_rows_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
+                  const int32_t* __restrict__ doc_off, int64_t n_docs,
+                  const int32_t* __restrict__ psg_row, int64_t n_psgs, int64_t n_index_rows,
+                  int32_t* __restrict__ cnt, unsigned long long* __restrict__ bad_pair) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_pairs) return;
+  if (p == n_pairs) {  // sentinel so that an exclusive scan of n_pairs+1 counts ends with R
+    cnt[p] = 0;
+    return;
+  }
+  const int32_t o = pair_ids[p];
+  int32_t c = 0;
+  if (mode == FFX_MODE_PASSAGE) {
+    if (o >= 0 && o < n_psgs) {
+      const int32_t r = psg_row[o];
+      c = (r >= 0 && r < n_index_rows) ? 1 : 0;
+    }
+  } else if (o >= 0 && o < n_docs) {
+    c = doc_off[o + 1] - doc_off[o];
+    if (mode == FFX_MODE_FIRSTP && c > 1) c = 1;
+  }
+  cnt[p] = c;
+  if (c == 0) atomicMin(bad_pair, (unsigned long long)p);
+}
+
+// desc[seg_off[p] + i] = {i-th row of candidate p, query number of p}
+__global__ void __launch_bounds__(256)
+expand_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
+              const int64_t* __restrict__ pair_off, int n_queries,
+              const int32_t* __restrict__ doc_off, const int32_t* __restrict__ doc_rows,
+              const int32_t* __restrict__ psg_row, const int32_t* __restrict__ seg_off,
+              int2* __restrict__ desc) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  // query of pair p: last q with pair_off[q] <= p
+  int lo = 0, hi = n_queries;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pair_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  const int32_t o = pair_ids[p];
+  const int32_t s = seg_off[p];
+  const int32_t c = seg_off[p + 1] - s;
+  if (mode == FFX_MODE_PASSAGE) {
+    desc[s] = make_int2(psg_row[o], lo);
+  } else {
+    const int32_t* rows = doc_rows + doc_off[o];
+    for (int32_t i = 0; i < c; ++i) desc[s + i] = make_int2(rows[i], lo);
+  }
+}
+
+// single-row candidates (FIRSTP, PASSAGE, or every document has one passage): no scan needed
+__global__ void __launch_bounds__(256)
+expand_single_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
+                     const int64_t* __restrict__ pair_off, int n_queries,
+                     const int32_t* __restrict__ doc_off, const int32_t* __restrict__ doc_rows,
+                     const int32_t* __restrict__ psg_row, int2* __restrict__ desc) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  int lo = 0, hi = n_queries;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pair_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  const int32_t o = pair_ids[p];
+  const int32_t row = (mode == FFX_MODE_PASSAGE) ? psg_row[o] : doc_rows[doc_off[o]];
+  desc[p] = make_int2(row, lo);
+}
+
+// ---- groupby(["id","q_no"]).aggregate(op) (index/base.py:306-312) + ranking.py:319 ----------
+// One thread per candidate; its rows are contiguous in rs, so no atomics.
+//   MAXP  plain fp32 max            AVEP  pandas group_mean: Kahan fp32 sum, one fp32 divide
+//   FIRSTP / PASSAGE  first row
+// interp = f32(f32(alpha)*sparse) + f32(f32(1-alpha)*dense): two rounded multiplies, one add
+// (no FMA: __f*_rn intrinsics are never contracted).
+__device__ __forceinline__ float interp_one(float a, float b, float sparse, float dense) {
+  return __fadd_rn(__fmul_rn(a, sparse), __fmul_rn(b, dense));
+}
+
+__global__ void __launch_bounds__(256)
+reduce_kernel(const float* __restrict__ rs, const int32_t* __restrict__ seg_off, int64_t n_pairs,
+              int mode, const float* __restrict__ sparse, float a, float b,
+              float* __restrict__ ff, float* __restrict__ interp) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int32_t s = seg_off[p], e = seg_off[p + 1];
+  float out;
+  if (mode == FFX_MODE_MAXP) {
+    out = rs[s];
+    for (int32_t i = s + 1; i < e; ++i) {
+      const float x = rs[i];
+      out = x > out ? x : out;
+    }
+  } else if (mode == FFX_MODE_AVEP) {
+    float sum = 0.f, comp = 0.f, cnt = 0.f;
+    for (int32_t i = s; i < e; ++i) {
+      cnt = __fadd_rn(cnt, 1.f);
+      const float y = __fsub_rn(rs[i], comp);
+      const float t = __fadd_rn(sum, y);
+      comp = __fsub_rn(__fsub_rn(t, sum), y);
+      if (comp != comp) comp = 0.f;
+      sum = t;
+    }
+    out = __fdiv_rn(sum, cnt);
+  } else {
+    out = rs[s];
+  }
+  ff[p] = out;
+  if (sparse != nullptr) interp[p] = interp_one(a, b, sparse[p], out);
+}
+
+__global__ void __launch_bounds__(256)
+interp_kernel(const float* __restrict__ ff, const float* __restrict__ sparse, int64_t n_pairs,
+              float a, float b, float* __restrict__ interp) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  interp[p] = interp_one(a, b, sparse[p], ff[p]);
+}
+
+// ---- row copy-out for _get_vectors (index/memory.py:139-140) --------------------------------
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ vectors, int d, const int32_t* __restrict__ rows,
+                   int64_t n, float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float* src = vectors + (size_t)rows[r] * d;
+  float* dst = out + (size_t)r * d;
+  for (int c = threadIdx.x & 63; c < d; c += 64) dst[c] = src[c];
+}
+
+// ---- synthetic rows: same counter-based generator as oracle/ffx_oracle.c and synth.py ---------
+__device__ __forceinline__ uint64_t mix64(uint64_t idx, uint64_t seed) {
+  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+fill_synthetic_kernel(float* __restrict__ dst, int64_t n_elems, uint64_t first_elem, uint64_t seed,
+                      float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
+    const uint32_t m = (uint32_t)(mix64(first_elem + (uint64_t)e, seed) >> 40);
+    const float u = __fsub_rn(__fmul_rn((float)m, 0x1p-23f), 1.0f);
+    dst[e] = __fmul_rn(u, scale);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+iota_kernel(int32_t* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (int32_t)i;
+}
+
+}  // namespace ffx

@@ -1,0 +1,676 @@
+// ffx.hip -- C ABI (include/ffx.h) over the HIP kernels.  gfx950 only.
+//
+// Host side of the re-ranking path: device memory for the index and for one batch of
+// queries, the launch sequence  count -> scan -> expand -> gather_dot -> reduce [-> sort],
+// hipEvent timing of each stage, and status-code error reporting (no exceptions cross the ABI).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>  // before rocprim: its texture iterator calls memset unqualified
+
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ffx.h"
+#include "aux_kernels.hip.h"
+#include "gather_dot.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define FFX_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(e_ == hipErrorOutOfMemory ? FFX_OOM : FFX_HIP_ERROR, "%s: %s (%s:%d)", #expr, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+  } while (0)
+
+#define FFX_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != FFX_OK) return rc_; \
+  } while (0)
+
+// growable device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return FFX_OK;
+    if (p) {
+      FFX_HIP(hipFree(p));
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      want = bytes;
+      e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(FFX_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    cap = want;
+    return FFX_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// leaf boundaries of NumPy's pairwise recursion for a row of n elements (in-order)
+void numpy_leaf_plan(int start, int n, std::vector<int>& bounds) {
+  if (n <= 128) {
+    bounds.push_back(start);
+    return;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  numpy_leaf_plan(start, n2, bounds);
+  numpy_leaf_plan(start + n2, n - n2, bounds);
+}
+
+}  // namespace
+
+struct ffx_index {
+  int device = 0;
+  int32_t dim = 0;
+  int64_t capacity = 0;
+  float* vectors = nullptr;
+  // id structure (device copies)
+  DevBuf doc_off;   // int32[n_docs+1]
+  DevBuf doc_rows;  // int32[n_doc_rows]
+  DevBuf psg_row;   // int32[n_psgs]
+  int64_t n_docs = 0, n_doc_rows = 0, n_psgs = 0;
+  bool single_passage_docs = true;  // every document has exactly one row
+};
+
+struct ffx_plan {
+  ffx_index* idx = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // inputs
+  DevBuf queries, pair_off, pair_ids, sparse;
+  // workspace
+  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags;
+  // outputs
+  DevBuf ff, interp, order;
+  int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
+  int n_queries_set = 0;
+  int mode = 0;
+  bool have_sparse = false, have_pairs = false, ran = false, ran_sort = false;
+  int n_leaves = 0;
+  bool last_interp = false;
+  int32_t variant = 0;
+  std::vector<int64_t> host_pair_off;
+};
+
+// --------------------------------------------------------------------------------------------
+extern "C" {
+
+int ffx_abi_version(void) { return FFX_ABI_VERSION; }
+
+const char* ffx_last_error(void) { return g_last_error.c_str(); }
+
+int ffx_device_count(int* count) {
+  if (!count) return fail(FFX_BAD_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return FFX_OK;
+}
+
+int ffx_device_info(int device, char* name, size_t name_cap, int64_t* total_bytes, int64_t* free_bytes,
+                    int32_t* compute_units) {
+  hipDeviceProp_t prop;
+  FFX_HIP(hipGetDeviceProperties(&prop, device));
+  if (name && name_cap) {
+    snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (total_bytes || free_bytes) {
+    FFX_HIP(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    FFX_HIP(hipMemGetInfo(&f, &t));
+    if (total_bytes) *total_bytes = (int64_t)t;
+    if (free_bytes) *free_bytes = (int64_t)f;
+  }
+  return FFX_OK;
+}
+
+// ---- index ------------------------------------------------------------------------------------
+int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index** out) {
+  if (!out) return fail(FFX_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (capacity_rows < 0 || capacity_rows > INT32_MAX) return fail(FFX_BAD_ARG, "capacity_rows out of range (row ids are int32)");
+  if (dim <= 0) return fail(FFX_BAD_ARG, "dim must be positive");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    return fail(FFX_NO_DEVICE, "no HIP device: libffx has no CPU fallback");
+  }
+  if (device < 0 || device >= n) return fail(FFX_BAD_ARG, "device %d out of range (%d devices)", device, n);
+  FFX_HIP(hipSetDevice(device));
+  ffx_index* idx = new (std::nothrow) ffx_index();
+  if (!idx) return fail(FFX_OOM, "host allocation failed");
+  idx->device = device;
+  idx->dim = dim;
+  idx->capacity = capacity_rows;
+  const size_t bytes = std::max<size_t>((size_t)capacity_rows * dim * sizeof(float), 256);
+  hipError_t e = hipMalloc((void**)&idx->vectors, bytes);
+  if (e != hipSuccess) {
+    delete idx;
+    return fail(FFX_OOM, "hipMalloc of %zu index bytes failed: %s", bytes, hipGetErrorString(e));
+  }
+  *out = idx;
+  return FFX_OK;
+}
+
+int ffx_index_destroy(ffx_index* idx) {
+  if (!idx) return FFX_OK;
+  (void)hipSetDevice(idx->device);
+  if (idx->vectors) (void)hipFree(idx->vectors);
+  idx->doc_off.release();
+  idx->doc_rows.release();
+  idx->psg_row.release();
+  delete idx;
+  return FFX_OK;
+}
+
+int ffx_index_dim(const ffx_index* idx, int32_t* dim) {
+  if (!idx || !dim) return fail(FFX_BAD_ARG, "NULL argument");
+  *dim = idx->dim;
+  return FFX_OK;
+}
+
+int ffx_index_capacity(const ffx_index* idx, int64_t* rows) {
+  if (!idx || !rows) return fail(FFX_BAD_ARG, "NULL argument");
+  *rows = idx->capacity;
+  return FFX_OK;
+}
+
+int ffx_index_upload(ffx_index* idx, const float* host_rows, int64_t row_offset, int64_t n_rows) {
+  if (!idx || (!host_rows && n_rows > 0)) return fail(FFX_BAD_ARG, "NULL argument");
+  if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > idx->capacity)
+    return fail(FFX_BAD_ARG, "rows [%lld, %lld) outside capacity %lld", (long long)row_offset,
+                (long long)(row_offset + n_rows), (long long)idx->capacity);
+  if (n_rows == 0) return FFX_OK;
+  FFX_HIP(hipSetDevice(idx->device));
+  FFX_HIP(hipMemcpy(idx->vectors + (size_t)row_offset * idx->dim, host_rows,
+                    (size_t)n_rows * idx->dim * sizeof(float), hipMemcpyHostToDevice));
+  return FFX_OK;
+}
+
+int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows) {
+  if (!dst || !src) return fail(FFX_BAD_ARG, "NULL argument");
+  if (dst->device != src->device || dst->dim != src->dim) return fail(FFX_BAD_ARG, "indexes differ in device or dim");
+  if (n_rows < 0 || n_rows > src->capacity || n_rows > dst->capacity) return fail(FFX_BAD_ARG, "n_rows out of range");
+  if (n_rows == 0) return FFX_OK;
+  FFX_HIP(hipSetDevice(dst->device));
+  FFX_HIP(hipMemcpy(dst->vectors, src->vectors, (size_t)n_rows * src->dim * sizeof(float), hipMemcpyDeviceToDevice));
+  return FFX_OK;
+}
+
+int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, float* host_out) {
+  if (!idx || (n_rows > 0 && (!rows || !host_out))) return fail(FFX_BAD_ARG, "NULL argument");
+  if (n_rows == 0) return FFX_OK;
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (rows[i] < 0 || rows[i] >= idx->capacity) return fail(FFX_BAD_ARG, "row %d outside the index", rows[i]);
+  FFX_HIP(hipSetDevice(idx->device));
+  DevBuf drows, dout;
+  int rc = drows.ensure((size_t)n_rows * sizeof(int32_t));
+  if (rc == FFX_OK) rc = dout.ensure((size_t)n_rows * idx->dim * sizeof(float));
+  if (rc == FFX_OK) {
+    hipError_t e = hipMemcpy(drows.p, rows, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      ffx::gather_rows_kernel<<<blocks_for(n_rows, 4), 256>>>(idx->vectors, idx->dim, drows.as<int32_t>(), n_rows, dout.as<float>());
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(host_out, dout.p, (size_t)n_rows * idx->dim * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(FFX_HIP_ERROR, "gather failed: %s", hipGetErrorString(e));
+  }
+  drows.release();
+  dout.release();
+  return rc;
+}
+
+int ffx_index_fill_synthetic(ffx_index* idx, uint64_t seed, float scale, int64_t row_offset, int64_t n_rows,
+                             int64_t first_global_row) {
+  if (!idx) return fail(FFX_BAD_ARG, "NULL argument");
+  if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > idx->capacity || first_global_row < 0)
+    return fail(FFX_BAD_ARG, "rows outside capacity");
+  if (n_rows == 0) return FFX_OK;
+  FFX_HIP(hipSetDevice(idx->device));
+  const int64_t n_elems = n_rows * idx->dim;
+  const unsigned grid = (unsigned)std::min<int64_t>((n_elems + 255) / 256, 256 * 32);
+  ffx::fill_synthetic_kernel<<<grid, 256>>>(idx->vectors + (size_t)row_offset * idx->dim, n_elems,
+                                            (uint64_t)first_global_row * (uint64_t)idx->dim, seed, scale);
+  FFX_HIP(hipGetLastError());
+  FFX_HIP(hipDeviceSynchronize());
+  return FFX_OK;
+}
+
+int ffx_index_set_doc_rows(ffx_index* idx, const int64_t* doc_off, int64_t n_docs, const int32_t* doc_rows,
+                           int64_t n_doc_rows) {
+  if (!idx || n_docs < 0 || n_doc_rows < 0 || (n_docs > 0 && !doc_off) || (n_doc_rows > 0 && !doc_rows))
+    return fail(FFX_BAD_ARG, "bad argument");
+  if (n_docs > INT32_MAX - 1 || n_doc_rows > INT32_MAX) return fail(FFX_BAD_ARG, "too many documents/rows for int32 ids");
+  std::vector<int32_t> off32((size_t)n_docs + 1, 0);
+  bool single = true;
+  if (n_docs > 0) {
+    if (doc_off[0] != 0 || doc_off[n_docs] != n_doc_rows) return fail(FFX_BAD_ARG, "doc_off must run from 0 to n_doc_rows");
+    for (int64_t i = 0; i < n_docs; ++i) {
+      const int64_t c = doc_off[i + 1] - doc_off[i];
+      if (c < 0) return fail(FFX_BAD_ARG, "doc_off not monotone at %lld", (long long)i);
+      if (c != 1) single = false;
+      off32[(size_t)i + 1] = (int32_t)doc_off[i + 1];
+    }
+  }
+  for (int64_t i = 0; i < n_doc_rows; ++i)
+    if (doc_rows[i] < 0 || doc_rows[i] >= idx->capacity) return fail(FFX_BAD_ARG, "doc_rows[%lld] outside the index", (long long)i);
+  FFX_HIP(hipSetDevice(idx->device));
+  FFX_TRY(idx->doc_off.ensure(off32.size() * sizeof(int32_t)));
+  FFX_TRY(idx->doc_rows.ensure(std::max<size_t>((size_t)n_doc_rows, 1) * sizeof(int32_t)));
+  FFX_HIP(hipMemcpy(idx->doc_off.p, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n_doc_rows > 0)
+    FFX_HIP(hipMemcpy(idx->doc_rows.p, doc_rows, (size_t)n_doc_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+  idx->n_docs = n_docs;
+  idx->n_doc_rows = n_doc_rows;
+  idx->single_passage_docs = single;
+  return FFX_OK;
+}
+
+int ffx_index_set_psg_rows(ffx_index* idx, const int32_t* psg_row, int64_t n_psgs) {
+  if (!idx || n_psgs < 0 || (n_psgs > 0 && !psg_row)) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_psgs > INT32_MAX) return fail(FFX_BAD_ARG, "too many passages for int32 ids");
+  FFX_HIP(hipSetDevice(idx->device));
+  FFX_TRY(idx->psg_row.ensure(std::max<size_t>((size_t)n_psgs, 1) * sizeof(int32_t)));
+  if (n_psgs > 0) FFX_HIP(hipMemcpy(idx->psg_row.p, psg_row, (size_t)n_psgs * sizeof(int32_t), hipMemcpyHostToDevice));
+  idx->n_psgs = n_psgs;
+  return FFX_OK;
+}
+
+// ---- plan -------------------------------------------------------------------------------------
+int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
+  if (!idx || !out) return fail(FFX_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  FFX_HIP(hipSetDevice(idx->device));
+  ffx_plan* pl = new (std::nothrow) ffx_plan();
+  if (!pl) return fail(FFX_OOM, "host allocation failed");
+  pl->idx = idx;
+  hipError_t e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
+  if (e != hipSuccess) {
+    ffx_plan_destroy(pl);
+    return fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
+  }
+  // leaf plan of the exact generic kernel depends on dim only
+  std::vector<int> bounds;
+  numpy_leaf_plan(0, idx->dim, bounds);
+  bounds.push_back(idx->dim);
+  pl->n_leaves = (int)bounds.size() - 1;
+  int rc = pl->leaf_start.ensure(bounds.size() * sizeof(int));
+  if (rc == FFX_OK && hipMemcpy(pl->leaf_start.p, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(FFX_HIP_ERROR, "leaf plan upload failed");
+  if (rc == FFX_OK) rc = pl->flags.ensure(64);
+  if (rc != FFX_OK) {
+    ffx_plan_destroy(pl);
+    return rc;
+  }
+  *out = pl;
+  return FFX_OK;
+}
+
+int ffx_plan_destroy(ffx_plan* pl) {
+  if (!pl) return FFX_OK;
+  if (pl->idx) (void)hipSetDevice(pl->idx->device);
+  if (pl->stream) (void)hipStreamSynchronize(pl->stream);
+  for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
+                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start,
+                    &pl->flags, &pl->ff, &pl->interp, &pl->order})
+    b->release();
+  for (auto& e : pl->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (pl->stream) (void)hipStreamDestroy(pl->stream);
+  delete pl;
+  return FFX_OK;
+}
+
+int ffx_plan_set_queries(ffx_plan* pl, const float* host_queries, int64_t n_queries) {
+  if (!pl || n_queries < 0 || (n_queries > 0 && !host_queries)) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_queries > INT32_MAX) return fail(FFX_BAD_ARG, "too many queries");
+  FFX_HIP(hipSetDevice(pl->idx->device));
+  const size_t bytes = (size_t)n_queries * pl->idx->dim * sizeof(float);
+  FFX_TRY(pl->queries.ensure(std::max<size_t>(bytes, 16)));
+  if (bytes) FFX_HIP(hipMemcpyAsync(pl->queries.p, host_queries, bytes, hipMemcpyHostToDevice, pl->stream));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  pl->n_queries_set = (int)n_queries;
+  pl->ran = false;
+  return FFX_OK;
+}
+
+static int launch_count_scan(ffx_plan* pl) {
+  const ffx_index* ix = pl->idx;
+  const int64_t P = pl->n_pairs;
+  ffx::count_rows_kernel<<<blocks_for(P + 1, 256), 256, 0, pl->stream>>>(
+      pl->pair_ids.as<int32_t>(), P, pl->mode, ix->doc_off.as<int32_t>(), ix->n_docs, ix->psg_row.as<int32_t>(),
+      ix->n_psgs, ix->capacity, pl->cnt.as<int32_t>(), pl->flags.as<unsigned long long>());
+  FFX_HIP(hipGetLastError());
+  size_t tmp = 0;
+  FFX_HIP(rocprim::exclusive_scan(nullptr, tmp, pl->cnt.as<int32_t>(), pl->seg_off.as<int32_t>(), (int32_t)0,
+                                  (size_t)(P + 1), rocprim::plus<int32_t>(), pl->stream));
+  FFX_TRY(pl->scan_tmp.ensure(std::max<size_t>(tmp, 16)));
+  FFX_HIP(rocprim::exclusive_scan(pl->scan_tmp.p, tmp, pl->cnt.as<int32_t>(), pl->seg_off.as<int32_t>(), (int32_t)0,
+                                  (size_t)(P + 1), rocprim::plus<int32_t>(), pl->stream));
+  return FFX_OK;
+}
+
+int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids,
+                       const float* sparse, int mode, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!pl || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  if (n_queries > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many queries");
+  if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  if (P > 0 && !pair_ids) return fail(FFX_BAD_ARG, "pair_ids is NULL");
+  ffx_index* ix = pl->idx;
+  if (mode == FFX_MODE_PASSAGE ? ix->n_psgs == 0 : ix->n_docs == 0) {
+    if (P > 0) {
+      if (bad_pair) *bad_pair = 0;
+      return fail(FFX_NOT_FOUND, "the index holds no %s ids", mode == FFX_MODE_PASSAGE ? "passage" : "document");
+    }
+  }
+  FFX_HIP(hipSetDevice(ix->device));
+  pl->have_pairs = false;
+  pl->ran = false;
+  pl->n_queries = n_queries;
+  pl->n_pairs = P;
+  pl->mode = mode;
+  pl->have_sparse = sparse != nullptr;
+  pl->host_pair_off.assign(pair_off, pair_off + n_queries + 1);
+  const size_t pb = std::max<size_t>((size_t)P, 1);
+  FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(pl->cnt.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(pl->seg_off.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(pl->ff.ensure(pb * sizeof(float)));
+  if (sparse) {
+    FFX_TRY(pl->sparse.ensure(pb * sizeof(float)));
+    FFX_TRY(pl->interp.ensure(pb * sizeof(float)));
+  }
+  FFX_HIP(hipMemcpyAsync(pl->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice, pl->stream));
+  if (P > 0) {
+    FFX_HIP(hipMemcpyAsync(pl->pair_ids.p, pair_ids, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, pl->stream));
+    if (sparse) FFX_HIP(hipMemcpyAsync(pl->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice, pl->stream));
+  }
+  // validate ordinals and size the row list on the device (get_indices, index/util.py:29-41)
+  FFX_HIP(hipMemsetAsync(pl->flags.p, 0xFF, sizeof(unsigned long long), pl->stream));
+  FFX_TRY(launch_count_scan(pl));
+  unsigned long long bad = ~0ull;
+  int32_t total = 0;
+  FFX_HIP(hipMemcpyAsync(&bad, pl->flags.p, sizeof bad, hipMemcpyDeviceToHost, pl->stream));
+  FFX_HIP(hipMemcpyAsync(&total, pl->seg_off.as<int32_t>() + P, sizeof total, hipMemcpyDeviceToHost, pl->stream));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  if (bad != ~0ull) {
+    if (bad_pair) *bad_pair = (int64_t)bad;
+    return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad);
+  }
+  if (total < 0) return fail(FFX_BAD_ARG, "more than 2^31-1 gathered rows in one batch: split the queries");
+  pl->n_rows = total;
+  const size_t rb = std::max<size_t>((size_t)total, 1);
+  FFX_TRY(pl->desc.ensure(rb * sizeof(int2)));
+  if (pl->n_rows != pl->n_pairs) FFX_TRY(pl->rs.ensure(rb * sizeof(float)));
+  pl->have_pairs = true;
+  return FFX_OK;
+}
+
+// pick and launch the gather_dot instantiation; returns the variant id
+static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
+  const ffx_index* ix = pl->idx;
+  const int d = ix->dim;
+  const int R = (int)pl->n_rows;
+  const float* V = ix->vectors;
+  const float* Q = pl->queries.as<float>();
+  const int2* desc = pl->desc.as<int2>();
+  hipStream_t st = pl->stream;
+#define FFX_EXACT(LEAVES, NPER, U, ID)                                                            \
+  do {                                                                                            \
+    constexpr int RPW_ = 64 / (8 * LEAVES);                                                       \
+    constexpr int PASSES_ = RPW_ == 1 ? 16 : ((64 / RPW_) < 16 ? (64 / RPW_) : 16);               \
+    constexpr int TILE_ = PASSES_ * RPW_;                                                         \
+    ffx::gather_dot_exact_kernel<LEAVES, NPER, U><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R); \
+    pl->variant = ID;                                                                             \
+  } while (0)
+  if (exact) {
+    switch (d) {
+      case 768: FFX_EXACT(8, 12, 4, 101); break;
+      case 1024: FFX_EXACT(8, 16, 2, 102); break;
+      case 512: FFX_EXACT(4, 16, 2, 103); break;
+      case 384: FFX_EXACT(4, 12, 4, 104); break;
+      case 256: FFX_EXACT(2, 16, 2, 105); break;
+      case 128: FFX_EXACT(1, 16, 2, 106); break;
+      case 64: FFX_EXACT(1, 8, 4, 107); break;
+      default:
+        if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
+        ffx::gather_dot_exact_generic_kernel<<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
+            V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
+        pl->variant = 199;
+    }
+  } else {
+    switch (d) {
+      case 768: ffx::gather_dot_fast_kernel<3, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 201; break;
+      case 1024: ffx::gather_dot_fast_kernel<4, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 202; break;
+      case 512: ffx::gather_dot_fast_kernel<2, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 203; break;
+      case 256: ffx::gather_dot_fast_kernel<1, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 204; break;
+      default:
+        if (d % 4 == 0) {
+          ffx::gather_dot_fast_generic_kernel<<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);
+          pl->variant = 298;
+        } else {  // rows are not 16-byte aligned: the exact generic kernel is the only scalar path
+          if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large", d);
+          ffx::gather_dot_exact_generic_kernel<<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
+              V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
+          pl->variant = 199;
+        }
+    }
+  }
+#undef FFX_EXACT
+  FFX_HIP(hipGetLastError());
+  return FFX_OK;
+}
+
+int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
+  if (!pl) return fail(FFX_BAD_ARG, "NULL plan");
+  if (!pl->have_pairs) return fail(FFX_BAD_ARG, "ffx_plan_set_pairs has not succeeded on this plan");
+  if (pl->n_queries_set < pl->n_queries) return fail(FFX_BAD_ARG, "%d query vectors set, %lld queries in the pairs", pl->n_queries_set, (long long)pl->n_queries);
+  ffx_index* ix = pl->idx;
+  FFX_HIP(hipSetDevice(ix->device));
+  const int64_t P = pl->n_pairs, R = pl->n_rows;
+  hipStream_t st = pl->stream;
+  const bool single = (R == P);
+  const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
+  const bool exact = (flags & FFX_FLAG_EXACT_SUM) != 0;
+  pl->ran = false;
+  FFX_HIP(hipEventRecord(pl->ev[0], st));
+  if (P > 0) {
+    // 1. candidates -> row list
+    if (single) {
+      ffx::expand_single_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
+          pl->pair_ids.as<int32_t>(), P, pl->mode, pl->pair_off.as<int64_t>(), (int)pl->n_queries,
+          ix->doc_off.as<int32_t>(), ix->doc_rows.as<int32_t>(), ix->psg_row.as<int32_t>(), pl->desc.as<int2>());
+    } else {
+      FFX_TRY(launch_count_scan(pl));
+      ffx::expand_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
+          pl->pair_ids.as<int32_t>(), P, pl->mode, pl->pair_off.as<int64_t>(), (int)pl->n_queries,
+          ix->doc_off.as<int32_t>(), ix->doc_rows.as<int32_t>(), ix->psg_row.as<int32_t>(),
+          pl->seg_off.as<int32_t>(), pl->desc.as<int2>());
+    }
+    FFX_HIP(hipGetLastError());
+  }
+  FFX_HIP(hipEventRecord(pl->ev[1], st));
+  // 2. gather + inner product (the hot kernel)
+  float* rs = single ? pl->ff.as<float>() : pl->rs.as<float>();
+  if (R > 0) FFX_TRY(launch_gather_dot(pl, exact, rs));
+  FFX_HIP(hipEventRecord(pl->ev[2], st));
+  // 3. segment aggregation + interpolation
+  const float a = (float)alpha;
+  const float b = (float)(1.0 - alpha);
+  if (P > 0) {
+    if (!single) {
+      ffx::reduce_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
+          rs, pl->seg_off.as<int32_t>(), P, pl->mode, pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b,
+          pl->ff.as<float>(), pl->interp.as<float>());
+    } else if (pl->have_sparse) {
+      ffx::interp_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->ff.as<float>(), pl->sparse.as<float>(), P, a, b,
+                                                            pl->interp.as<float>());
+    }
+    FFX_HIP(hipGetLastError());
+  }
+  pl->last_interp = pl->have_sparse;
+  FFX_HIP(hipEventRecord(pl->ev[3], st));
+  // 4. per-query order: score descending, ties by position (stable radix sort)
+  if (do_sort && P > 0) {
+    const size_t pb = (size_t)P;
+    FFX_TRY(pl->order.ensure(pb * sizeof(int32_t)));
+    FFX_TRY(pl->iota.ensure(pb * sizeof(int32_t)));
+    FFX_TRY(pl->sorted_keys.ensure(pb * sizeof(float)));
+    ffx::iota_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->iota.as<int32_t>(), P);
+    FFX_HIP(hipGetLastError());
+    const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
+    const int64_t* offs = pl->pair_off.as<int64_t>();
+    size_t tmp = 0;
+    FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp, keys, pl->sorted_keys.as<float>(),
+                                                     pl->iota.as<int32_t>(), pl->order.as<int32_t>(), (unsigned)P,
+                                                     (unsigned)pl->n_queries, offs, offs + 1, 0, 32, st));
+    FFX_TRY(pl->sort_tmp.ensure(std::max<size_t>(tmp, 16)));
+    FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(pl->sort_tmp.p, tmp, keys, pl->sorted_keys.as<float>(),
+                                                     pl->iota.as<int32_t>(), pl->order.as<int32_t>(), (unsigned)P,
+                                                     (unsigned)pl->n_queries, offs, offs + 1, 0, 32, st));
+  }
+  FFX_HIP(hipEventRecord(pl->ev[4], st));
+  pl->ran = true;
+  pl->ran_sort = do_sort;
+  return FFX_OK;
+}
+
+int ffx_plan_sync(ffx_plan* pl) {
+  if (!pl) return fail(FFX_BAD_ARG, "NULL plan");
+  FFX_HIP(hipSetDevice(pl->idx->device));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  return FFX_OK;
+}
+
+int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_order) {
+  if (!pl) return fail(FFX_BAD_ARG, "NULL plan");
+  if (!pl->ran) return fail(FFX_BAD_ARG, "ffx_plan_run has not completed on this plan");
+  FFX_HIP(hipSetDevice(pl->idx->device));
+  const size_t P = (size_t)pl->n_pairs;
+  if (out_interp && !pl->last_interp) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
+  if (out_order && !pl->ran_sort) return fail(FFX_BAD_ARG, "the last run did not request FFX_FLAG_SORT");
+  if (P > 0) {
+    if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff, pl->ff.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));
+    if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp, pl->interp.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));
+    if (out_order) FFX_HIP(hipMemcpyAsync(out_order, pl->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, pl->stream));
+  }
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  return FFX_OK;
+}
+
+int ffx_plan_stats(ffx_plan* pl, ffx_stats* out) {
+  if (!pl || !out) return fail(FFX_BAD_ARG, "NULL argument");
+  if (!pl->ran) return fail(FFX_BAD_ARG, "ffx_plan_run has not completed on this plan");
+  FFX_HIP(hipSetDevice(pl->idx->device));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  memset(out, 0, sizeof *out);
+  out->n_queries = pl->n_queries;
+  out->n_pairs = pl->n_pairs;
+  out->n_rows = pl->n_rows;
+  const double d = pl->idx->dim;
+  out->algorithmic_bytes = (double)pl->n_rows * (d * 4 + 4) + (double)pl->n_pairs * 4 * (1 + (pl->last_interp ? 2 : 0)) +
+                           (double)pl->n_queries * d * 4 + (double)(pl->n_queries + 1) * 8;
+  FFX_HIP(hipEventElapsedTime(&out->ms_expand, pl->ev[0], pl->ev[1]));
+  FFX_HIP(hipEventElapsedTime(&out->ms_gather_dot, pl->ev[1], pl->ev[2]));
+  FFX_HIP(hipEventElapsedTime(&out->ms_reduce, pl->ev[2], pl->ev[3]));
+  FFX_HIP(hipEventElapsedTime(&out->ms_sort, pl->ev[3], pl->ev[4]));
+  FFX_HIP(hipEventElapsedTime(&out->ms_total, pl->ev[0], pl->ev[4]));
+  out->kernel_variant = pl->variant;
+  return FFX_OK;
+}
+
+int ffx_plan_device_ptr(ffx_plan* pl, int which, void** ptr, int64_t* n_elems) {
+  if (!pl || !ptr) return fail(FFX_BAD_ARG, "NULL argument");
+  const DevBuf* b = nullptr;
+  int64_t n = pl->n_pairs;
+  switch (which) {
+    case FFX_BUF_FF: b = &pl->ff; break;
+    case FFX_BUF_INTERP: b = &pl->interp; break;
+    case FFX_BUF_ORDER: b = &pl->order; break;
+    case FFX_BUF_QUERIES: b = &pl->queries; n = (int64_t)pl->n_queries_set * pl->idx->dim; break;
+    case FFX_BUF_PAIR_IDS: b = &pl->pair_ids; break;
+    case FFX_BUF_SPARSE: b = &pl->sparse; break;
+    default: return fail(FFX_BAD_ARG, "unknown buffer selector %d", which);
+  }
+  *ptr = b->p;
+  if (n_elems) *n_elems = b->p ? n : 0;
+  return FFX_OK;
+}
+
+int ffx_plan_stream(ffx_plan* pl, void** stream) {
+  if (!pl || !stream) return fail(FFX_BAD_ARG, "NULL argument");
+  *stream = (void*)pl->stream;
+  return FFX_OK;
+}
+
+int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
+              const int32_t* pair_ids, const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff,
+              float* out_interp, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
+  ffx_plan* pl = nullptr;
+  FFX_TRY(ffx_plan_create(idx, &pl));
+  int rc = ffx_plan_set_queries(pl, host_queries, n_queries);
+  if (rc == FFX_OK) rc = ffx_plan_set_pairs(pl, pair_off, n_queries, pair_ids, sparse, mode, bad_pair);
+  if (rc == FFX_OK) rc = ffx_plan_run(pl, alpha, flags);
+  if (rc == FFX_OK) rc = ffx_plan_sync(pl);
+  if (rc == FFX_OK) rc = ffx_plan_fetch(pl, out_ff, out_interp, out_order);
+  if (rc == FFX_OK && stats) rc = ffx_plan_stats(pl, stats);
+  const std::string keep = g_last_error;
+  ffx_plan_destroy(pl);
+  if (rc != FFX_OK) g_last_error = keep;
+  return rc;
+}
+
+}  // extern "C"

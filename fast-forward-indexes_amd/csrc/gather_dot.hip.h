@@ -1,0 +1,279 @@
+// gather_dot.hip.h -- the hot kernels: gather index rows by id and take the inner product
+// with the owning query's vector.  gfx950 (MI355X, CDNA4) only; wave = 64 lanes.
+//
+// Replaces src/fast_forward/index/base.py:301-303 of the reference
+//     q_reps = query_vectors[q_no];  d_reps = vectors[id_idx];
+//     ff_score = np.sum(q_reps * d_reps, axis=1)
+// without materialising q_reps / d_reps: one wave streams a row from HBM straight into
+// registers, multiplies by the query it already holds, and reduces across the wave.
+//
+// Work list: `desc[r] = {index row, query number}` for r in [0, R), rows of one query
+// contiguous (built by ffx_expand_kernel).  Output: rs[r] = <query, row>.
+//
+// Two summation orders:
+//   exact  NumPy's order (products rounded to fp32, 8 strided accumulators per leaf of
+//          <=128 elements, leaves combined pairwise).  For d = 8*LEAVES*NPER the 64
+//          partial sums of one row ARE the 64 lanes of a wave: lane (leaf l, accumulator j)
+//          owns elements l*8*NPER + j + 8*i, i = 0..NPER-1, adds them in order of i, and the
+//          combine tree is the xor-butterfly 1,2,4 (inside a leaf) 8,16,32 (across leaves).
+//          Scores are bit-identical to the reference, hence so is the run ordering.
+//   fast   16-byte coalesced loads, FMA chain, butterfly.  |error| ~ d * 2^-24 * |q||v|.
+//
+// Roofline: HBM.  Per row the kernel must move d*4 B of row data + 8 B of descriptor in and
+// 4 B out; 2*d flop.  0.5 flop/B, so MFMA is irrelevant.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffx {
+
+// ---- cross-lane helpers (DPP: no LDS traffic) ------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+// partner value for the xor-butterfly steps; every step is a plain commutative fp32 add, so
+// both partners end with identical bits
+__device__ __forceinline__ float xor1(float x) { return dpp_mov<0xB1>(x); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float xor2(float x) { return dpp_mov<0x4E>(x); }   // quad_perm [2,3,0,1]
+// after xor1/xor2 the 4 lanes of a quad agree, so mirroring 8 (16) lanes pairs quad A with
+// quad B (half-row A with half-row B) exactly as xor 4 (xor 8) would
+__device__ __forceinline__ float xor4(float x) { return dpp_mov<0x141>(x); }  // row_half_mirror
+__device__ __forceinline__ float xor8(float x) { return dpp_mov<0x140>(x); }  // row_mirror
+__device__ __forceinline__ float xor16(float x) { return __shfl_xor(x, 16, 64); }
+__device__ __forceinline__ float xor32(float x) { return __shfl_xor(x, 32, 64); }
+
+// combine the 8*LEAVES partial sums of one row; all lanes of the row end with the total
+template <int LEAVES>
+__device__ __forceinline__ float butterfly(float x) {
+  x = __fadd_rn(x, xor1(x));
+  x = __fadd_rn(x, xor2(x));
+  x = __fadd_rn(x, xor4(x));
+  if constexpr (LEAVES >= 2) x = __fadd_rn(x, xor8(x));
+  if constexpr (LEAVES >= 4) x = __fadd_rn(x, xor16(x));
+  if constexpr (LEAVES >= 8) x = __fadd_rn(x, xor32(x));
+  return x;
+}
+
+// ---- exact kernel, d = 8*LEAVES*NPER, LEAVES in {1,2,4,8}, NPER <= 16 ---------------------
+// A wave owns TILE consecutive work rows.  LPR = 8*LEAVES lanes cooperate on one row, so a
+// wave works on RPW = 64/LPR rows per pass and keeps U passes of loads in flight.
+template <int LEAVES, int NPER, int U>
+__global__ void __launch_bounds__(256)
+gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+                        const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  constexpr int LPR = 8 * LEAVES;
+  constexpr int RPW = 64 / LPR;
+  constexpr int D = LPR * NPER;
+  constexpr int PASSES = (RPW == 1) ? 16 : ((64 / RPW) < 16 ? (64 / RPW) : 16);
+  constexpr int TILE = PASSES * RPW;
+  static_assert(PASSES % U == 0, "PASSES must be a multiple of U");
+
+  const int lane = threadIdx.x & 63;
+  // threadIdx.x >> 6 is wave-uniform; readfirstlane tells the compiler so (scalar addressing)
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long base = (long)wave * TILE;
+  if (base >= n_rows) return;
+  const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+
+  // one coalesced descriptor load per wave; lanes past the end repeat the last valid row so
+  // every load below stays in bounds
+  const int my_t = lane < n_here ? lane : n_here - 1;
+  const int2 my = desc[base + my_t];
+
+  const int sub = lane & (LPR - 1);
+  const int slot = lane / LPR;                          // which row of the pass (0 if LPR == 64)
+  const int lane_off = (sub >> 3) * (8 * NPER) + (sub & 7);
+
+  if constexpr (RPW == 1) {
+    float q[NPER];
+    int cur_q = -1;
+#pragma unroll
+    for (int b = 0; b < PASSES; b += U) {
+      if (b >= n_here) break;
+      float v[U][NPER];
+      int qn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = (b + u) < n_here ? (b + u) : n_here - 1;
+        const int rid = __builtin_amdgcn_readlane(my.x, t);
+        qn[u] = __builtin_amdgcn_readlane(my.y, t);
+        const float* rowp = vectors + (size_t)rid * D + lane_off;
+#pragma unroll
+        for (int i = 0; i < NPER; ++i) v[u][i] = rowp[8 * i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (qn[u] != cur_q) {  // wave-uniform; rare (rows of a query are contiguous)
+          cur_q = qn[u];
+          const float* qp = queries + (size_t)cur_q * D + lane_off;
+#pragma unroll
+          for (int i = 0; i < NPER; ++i) q[i] = qp[8 * i];
+        }
+        float acc = __fmul_rn(q[0], v[u][0]);
+#pragma unroll
+        for (int i = 1; i < NPER; ++i) acc = __fadd_rn(acc, __fmul_rn(q[i], v[u][i]));
+        acc = butterfly<LEAVES>(acc);
+        if (lane == 0 && (b + u) < n_here) rs[base + b + u] = acc;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < PASSES; b += U) {
+      if (b * RPW >= n_here) break;
+      float v[U][NPER], q[U][NPER];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int t = (b + u) * RPW + slot;
+        t = t < n_here ? t : n_here - 1;
+        const int rid = __shfl(my.x, t, 64);
+        const int qn = __shfl(my.y, t, 64);
+        const float* rowp = vectors + (size_t)rid * D + lane_off;
+        const float* qp = queries + (size_t)qn * D + lane_off;
+#pragma unroll
+        for (int i = 0; i < NPER; ++i) v[u][i] = rowp[8 * i];
+#pragma unroll
+        for (int i = 0; i < NPER; ++i) q[u][i] = qp[8 * i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float acc = __fmul_rn(q[u][0], v[u][0]);
+#pragma unroll
+        for (int i = 1; i < NPER; ++i) acc = __fadd_rn(acc, __fmul_rn(q[u][i], v[u][i]));
+        acc = butterfly<LEAVES>(acc);
+        const int t = (b + u) * RPW + slot;
+        if (sub == 0 && t < n_here) rs[base + t] = acc;
+      }
+    }
+  }
+}
+
+// ---- fast kernel, d = 256*NCH: lane holds NCH float4 per row (16-B coalesced loads) --------
+template <int NCH, int U>
+__global__ void __launch_bounds__(256)
+gather_dot_fast_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+                       const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  constexpr int D = 256 * NCH;
+  constexpr int TILE = 16;
+  static_assert(TILE % U == 0, "TILE must be a multiple of U");
+  const int lane = threadIdx.x & 63;
+  // threadIdx.x >> 6 is wave-uniform; readfirstlane tells the compiler so (scalar addressing)
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long base = (long)wave * TILE;
+  if (base >= n_rows) return;
+  const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+  const int my_t = lane < n_here ? lane : n_here - 1;
+  const int2 my = desc[base + my_t];
+
+  float4 q[NCH];
+  int cur_q = -1;
+#pragma unroll
+  for (int b = 0; b < TILE; b += U) {
+    if (b >= n_here) break;
+    float4 v[U][NCH];
+    int qn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (b + u) < n_here ? (b + u) : n_here - 1;
+      const int rid = __builtin_amdgcn_readlane(my.x, t);
+      qn[u] = __builtin_amdgcn_readlane(my.y, t);
+      const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)rid * D) + lane;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) v[u][c] = rowp[64 * c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (qn[u] != cur_q) {
+        cur_q = qn[u];
+        const float4* qp = reinterpret_cast<const float4*>(queries + (size_t)cur_q * D) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) q[c] = qp[64 * c];
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        acc = fmaf(q[c].x, v[u][c].x, acc);
+        acc = fmaf(q[c].y, v[u][c].y, acc);
+        acc = fmaf(q[c].z, v[u][c].z, acc);
+        acc = fmaf(q[c].w, v[u][c].w, acc);
+      }
+      acc = butterfly<8>(acc);
+      if (lane == 0 && (b + u) < n_here) rs[base + b + u] = acc;
+    }
+  }
+}
+
+// ---- fast kernel, any d % 4 == 0 (runtime chunk loop) ----------------------------------------
+__global__ void __launch_bounds__(256)
+gather_dot_fast_generic_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+                               const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
+                               int d) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int2 de = desc[r];
+  const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)de.x * d);
+  const float4* qp = reinterpret_cast<const float4*>(queries + (size_t)de.y * d);
+  float acc = 0.f;
+  for (int c = lane; c < (d >> 2); c += 64) {
+    const float4 a = qp[c], b = rowp[c];
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+  }
+  acc = butterfly<8>(acc);
+  if (lane == 0) rs[r] = acc;
+}
+
+// ---- exact kernel, any d: leaves of NumPy's recursion handed to 8-lane groups -------------
+// leaf_start[0..n_leaves] are the leaf boundaries in in-order (host: numpy_leaf_plan).
+// One wave (= one block) per row; leaf sums go through LDS, lane 0 replays the recursion.
+__device__ inline float combine_leaves(int n, const float* leaf_sum, int& next) {
+  if (n <= 128) return leaf_sum[next++];
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const float a = combine_leaves(n2, leaf_sum, next);
+  const float b = combine_leaves(n - n2, leaf_sum, next);
+  return __fadd_rn(a, b);
+}
+
+__global__ void __launch_bounds__(64)
+gather_dot_exact_generic_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+                                const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
+                                int d, const int* __restrict__ leaf_start, int n_leaves) {
+  extern __shared__ float leaf_sum[];
+  const int lane = threadIdx.x;
+  const long r = blockIdx.x;
+  if (r >= n_rows) return;  // whole block leaves together
+  const int2 de = desc[r];
+  const float* v = vectors + (size_t)de.x * d;
+  const float* q = queries + (size_t)de.y * d;
+  const int g = lane >> 3, j = lane & 7;
+  for (int leaf = g; leaf < n_leaves; leaf += 8) {
+    const int s = leaf_start[leaf];
+    const int len = leaf_start[leaf + 1] - s;
+    float res;
+    if (len < 8) {
+      res = -0.0f;
+      for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], v[s + i]));
+    } else {
+      const int lim = len - (len % 8);
+      float acc = __fmul_rn(q[s + j], v[s + j]);
+      for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q[s + i + j], v[s + i + j]));
+      acc = __fadd_rn(acc, xor1(acc));
+      acc = __fadd_rn(acc, xor2(acc));
+      acc = __fadd_rn(acc, xor4(acc));
+      res = acc;
+      for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], v[s + i]));
+    }
+    if (j == 0) leaf_sum[leaf] = res;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int next = 0;
+    rs[r] = combine_leaves(d, leaf_sum, next);
+  }
+}
+
+}  // namespace ffx

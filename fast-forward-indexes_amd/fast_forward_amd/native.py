@@ -1,0 +1,283 @@
+"""ctypes binding of ``libffx.so`` (C ABI in ``include/ffx.h``).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no
+HIP device is visible when device work is requested, the error is raised to the caller.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libffx.so"
+
+OK, BAD_ARG, OOM, HIP_ERROR, RCCL_ERROR, NOT_FOUND, NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF = 1, 2, 4
+BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 3, 4, 5
+
+# every symbol include/ffx.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
+    "ffx_index_create", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
+    "ffx_index_upload", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
+    "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
+    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
+    "ffx_plan_run", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
+    "ffx_plan_stream", "ffx_score",
+)
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_queries", C.c_int64), ("n_pairs", C.c_int64), ("n_rows", C.c_int64),
+        ("algorithmic_bytes", C.c_double),
+        ("ms_expand", C.c_float), ("ms_gather_dot", C.c_float), ("ms_reduce", C.c_float),
+        ("ms_sort", C.c_float), ("ms_total", C.c_float),
+        ("kernel_variant", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+class FFXError(RuntimeError):
+    """A libffx call failed (status code + the library's message)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libffx error {code}: {message}")
+        self.code = code
+
+
+class NotFound(FFXError):
+    """An ordinal named no row (the reference's IndexError, index/util.py:38-39)."""
+
+    def __init__(self, code: int, message: str, pair: int):
+        super().__init__(code, message)
+        self.pair = pair
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libffx.so (once).  Raises if it has not been built: there is nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C fast-forward-indexes_amd/csrc`).  This package has no CPU fallback."
+        )
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    P = C.POINTER
+    sig = {
+        "ffx_abi_version": ([], C.c_int),
+        "ffx_last_error": ([], C.c_char_p),
+        "ffx_device_count": ([P(C.c_int)], C.c_int),
+        "ffx_device_info": ([C.c_int, C.c_char_p, C.c_size_t, P(i64), P(i64), P(i32)], C.c_int),
+        "ffx_index_create": ([C.c_int, i64, i32, P(vp)], C.c_int),
+        "ffx_index_destroy": ([vp], C.c_int),
+        "ffx_index_dim": ([vp, P(i32)], C.c_int),
+        "ffx_index_capacity": ([vp, P(i64)], C.c_int),
+        "ffx_index_upload": ([vp, vp, i64, i64], C.c_int),
+        "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
+        "ffx_index_gather": ([vp, vp, i64, vp], C.c_int),
+        "ffx_index_fill_synthetic": ([vp, C.c_uint64, f32, i64, i64, i64], C.c_int),
+        "ffx_index_set_doc_rows": ([vp, vp, i64, vp, i64], C.c_int),
+        "ffx_index_set_psg_rows": ([vp, vp, i64], C.c_int),
+        "ffx_plan_create": ([vp, P(vp)], C.c_int),
+        "ffx_plan_destroy": ([vp], C.c_int),
+        "ffx_plan_set_queries": ([vp, vp, i64], C.c_int),
+        "ffx_plan_set_pairs": ([vp, vp, i64, vp, vp, C.c_int, P(i64)], C.c_int),
+        "ffx_plan_run": ([vp, C.c_double, C.c_uint32], C.c_int),
+        "ffx_plan_sync": ([vp], C.c_int),
+        "ffx_plan_fetch": ([vp, vp, vp, vp], C.c_int),
+        "ffx_plan_stats": ([vp, P(Stats)], C.c_int),
+        "ffx_plan_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
+        "ffx_plan_stream": ([vp, P(vp)], C.c_int),
+        "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if L.ffx_abi_version() != 1:
+        raise ImportError(f"libffx ABI {L.ffx_abi_version()} does not match this binding (1)")
+    _lib = L
+    return L
+
+
+def _check(rc: int, bad_pair: int | None = None) -> None:
+    if rc == OK:
+        return
+    msg = (lib().ffx_last_error() or b"").decode("utf-8", "replace")
+    if rc == NOT_FOUND:
+        raise NotFound(rc, msg, -1 if bad_pair is None else bad_pair)
+    if rc == OOM:
+        raise MemoryError(f"libffx: {msg}")
+    raise FFXError(rc, msg)
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().ffx_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(device: int = 0) -> dict:
+    name = C.create_string_buffer(256)
+    total, free, cus = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    _check(lib().ffx_device_info(device, name, 256, C.byref(total), C.byref(free), C.byref(cus)))
+    return {"name": name.value.decode(), "total_bytes": total.value, "free_bytes": free.value, "compute_units": cus.value}
+
+
+def require_device() -> None:
+    if device_count() < 1:
+        raise RuntimeError("no HIP device is visible; fast_forward_amd has no CPU fallback")
+
+
+class DeviceIndex:
+    """Owns one ``ffx_index`` (fp32 rows resident in HBM)."""
+
+    def __init__(self, capacity_rows: int, dim: int, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().ffx_index_create(device, capacity_rows, dim, C.byref(h)))
+        self._h = h
+        self.capacity, self.dim, self.device = int(capacity_rows), int(dim), int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, rows: np.ndarray, row_offset: int) -> None:
+        rows = _arr(rows, np.float32)
+        assert rows.ndim == 2 and rows.shape[1] == self.dim
+        _check(lib().ffx_index_upload(self._h, _ptr(rows), row_offset, rows.shape[0]))
+
+    def copy_rows_from(self, src: "DeviceIndex", n_rows: int) -> None:
+        _check(lib().ffx_index_copy_rows(self._h, src._h, n_rows))
+
+    def gather(self, rows) -> np.ndarray:
+        rows = _arr(rows, np.int32)
+        out = np.empty((rows.shape[0], self.dim), dtype=np.float32)
+        _check(lib().ffx_index_gather(self._h, _ptr(rows), rows.shape[0], _ptr(out)))
+        return out
+
+    def fill_synthetic(self, seed: int, scale: float, row_offset: int, n_rows: int, first_global_row: int | None = None) -> None:
+        g = row_offset if first_global_row is None else first_global_row
+        _check(lib().ffx_index_fill_synthetic(self._h, seed, scale, row_offset, n_rows, g))
+
+    def set_doc_rows(self, doc_off, doc_rows) -> None:
+        doc_off, doc_rows = _arr(doc_off, np.int64), _arr(doc_rows, np.int32)
+        _check(lib().ffx_index_set_doc_rows(self._h, _ptr(doc_off), doc_off.shape[0] - 1, _ptr(doc_rows), doc_rows.shape[0]))
+
+    def set_psg_rows(self, psg_row) -> None:
+        psg_row = _arr(psg_row, np.int32)
+        _check(lib().ffx_index_set_psg_rows(self._h, _ptr(psg_row), psg_row.shape[0]))
+
+
+class _DevArray:
+    """Zero-copy view of a plan buffer for consumers that speak ``__cuda_array_interface__``
+    (``torch.as_tensor(view, device="cuda")``)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class Plan:
+    """Owns one ``ffx_plan``: device workspace and launch sequence for a batch of queries."""
+
+    def __init__(self, index: DeviceIndex):
+        h = C.c_void_p()
+        _check(lib().ffx_plan_create(index._h, C.byref(h)))
+        self._h = h
+        self._index = index  # keep the index alive as long as the plan
+        self.n_pairs = 0
+        self.has_sparse = False
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_queries(self, queries: np.ndarray) -> None:
+        queries = _arr(queries, np.float32)
+        assert queries.ndim == 2 and queries.shape[1] == self._index.dim, "query dimensionality does not match the index"
+        _check(lib().ffx_plan_set_queries(self._h, _ptr(queries), queries.shape[0]))
+
+    def set_pairs(self, pair_off, pair_ids, sparse, mode: int) -> None:
+        pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
+        sp = None if sparse is None else _arr(sparse, np.float32)
+        assert pair_ids.shape[0] == int(pair_off[-1])
+        bad = C.c_int64(-1)
+        rc = lib().ffx_plan_set_pairs(self._h, _ptr(pair_off), pair_off.shape[0] - 1, _ptr(pair_ids), _ptr(sp), int(mode), C.byref(bad))
+        _check(rc, bad.value)
+        self.n_pairs = int(pair_off[-1])
+        self.has_sparse = sp is not None
+
+    def run(self, alpha: float = 0.0, exact_sum: bool = True, sort: bool = False, sort_ff: bool = False) -> None:
+        flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0) | (FLAG_SORT_FF if sort_ff else 0)
+        _check(lib().ffx_plan_run(self._h, float(alpha), flags))
+
+    def sync(self) -> None:
+        _check(lib().ffx_plan_sync(self._h))
+
+    def fetch(self, ff: bool = True, interp: bool = False, order: bool = False):
+        n = self.n_pairs
+        a = np.empty(n, dtype=np.float32) if ff else None
+        b = np.empty(n, dtype=np.float32) if interp else None
+        c = np.empty(n, dtype=np.int32) if order else None
+        _check(lib().ffx_plan_fetch(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        return a, b, c
+
+    def stats(self) -> dict:
+        s = Stats()
+        _check(lib().ffx_plan_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def device_array(self, which: int) -> _DevArray:
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        _check(lib().ffx_plan_device_ptr(self._h, which, C.byref(ptr), C.byref(n)))
+        typestr = "<i4" if which in (BUF_ORDER, BUF_PAIR_IDS) else "<f4"
+        return _DevArray(ptr.value or 0, n.value, typestr, self)
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _check(lib().ffx_plan_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+
+def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0,
+          exact_sum: bool = True, sort: bool = False):
+    """One-shot ``ffx_score``: host arrays in, host arrays out.  Returns (ff, interp, order, stats)."""
+    queries = _arr(queries, np.float32)
+    pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
+    sp = None if sparse is None else _arr(sparse, np.float32)
+    n = int(pair_off[-1])
+    ff = np.empty(n, dtype=np.float32)
+    interp = None if sp is None else np.empty(n, dtype=np.float32)
+    order = np.empty(n, dtype=np.int32) if sort else None
+    bad, st = C.c_int64(-1), Stats()
+    flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0)
+    rc = lib().ffx_score(index._h, _ptr(queries), queries.shape[0], _ptr(pair_off), _ptr(pair_ids), _ptr(sp), int(mode),
+                         float(alpha), flags, _ptr(ff), _ptr(interp), _ptr(order), C.byref(bad), C.byref(st))
+    _check(rc, bad.value)
+    return ff, interp, order, st.as_dict()

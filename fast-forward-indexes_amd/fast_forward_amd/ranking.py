@@ -1,0 +1,236 @@
+"""``Ranking``: a TREC run (query id, document/passage id, score) with the reference's API.
+
+Mirrors ``fast_forward.Ranking`` (reference ``src/fast_forward/ranking.py:64-409``): same
+constructor arguments, methods, exceptions and score arithmetic, so code written against the
+reference runs unchanged.  It stays a host-side container on a pandas frame (``_df`` with
+columns ``q_id``, ``id``, ``score`` and optionally ``query``); the device work of this
+package happens in ``fast_forward_amd.index``.
+
+Arithmetic notes (pinned by tests/golden/interpolate.npz, generated from the reference):
+  * scores are ``dtype`` (float32 by default); ``alpha * a + (1 - alpha) * b`` rounds both
+    products and the sum to float32, with ``1 - alpha`` formed in double (ranking.py:319)
+  * a pair missing from either side of ``interpolate`` / ``+`` counts as score 0 (ranking.py:318)
+  * ordering is query id descending, then score descending; exact ties keep their input
+    order here (the reference leaves tie order unspecified, ranking.py:115-117)
+"""
+
+from __future__ import annotations
+
+import logging
+from collections.abc import Iterator, Mapping
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+LOGGER = logging.getLogger(__name__)
+
+Run = Mapping[str, Mapping[str, float]]
+_KEY = ["q_id", "id"]
+
+
+def _with_queries(df: pd.DataFrame, queries: Mapping[str, str]) -> pd.DataFrame:
+    """Add the ``query`` column; every query id of the frame must be covered (ranking.py:16-28)."""
+    missing = set(df["q_id"].unique()) - set(queries)
+    if missing:
+        raise ValueError("Queries are incomplete.")
+    out = df.drop(columns=["query"], errors="ignore")
+    out["query"] = out["q_id"].map(dict(queries))
+    return out
+
+
+def _scaled_to_unit_range(df: pd.DataFrame) -> pd.DataFrame:
+    """Global (not per-query) min-max scaling of ``score``; constant scores become 0
+    (ranking.py:45-61)."""
+    out = df.copy()
+    lo, hi = out["score"].min(), out["score"].max()
+    if lo == hi:
+        LOGGER.warning("all scores are equal, setting scores to 0")
+        out["score"] = 0
+    else:
+        out["score"] = (out["score"] - lo) / (hi - lo)
+    return out
+
+
+def _ranks_within_query(df: pd.DataFrame) -> pd.Series:
+    """1-based position of every row inside its query, in frame order (ranking.py:31-42)."""
+    return df.groupby("q_id").cumcount() + 1
+
+
+def _sorted_frame(df: pd.DataFrame) -> pd.DataFrame:
+    """q_id descending, score descending, ties in input order (stable)."""
+    q_codes = pd.factorize(df["q_id"], sort=True)[0]
+    order = np.lexsort((-df["score"].to_numpy(dtype=np.float64), -q_codes))
+    return df.iloc[order]
+
+
+class Ranking:
+    """Rankings of documents/passages w.r.t. queries (drop-in for ``fast_forward.Ranking``)."""
+
+    def __init__(
+        self,
+        df: pd.DataFrame,
+        name: str | None = None,
+        queries: Mapping[str, str] | None = None,
+        dtype: np.dtype = np.dtype(np.float32),
+        copy: bool = True,
+        is_sorted: bool = False,
+    ) -> None:
+        """Build a ranking from a frame with columns ``q_id``, ``id``, ``score`` [, ``query``].
+
+        Rows whose score is NaN are dropped.  Raises ``ValueError`` for a repeated
+        (query, id) pair and for incomplete ``queries`` (ranking.py:67-121).
+        """
+        self.name = name
+        if df.duplicated(subset=_KEY).any():
+            raise ValueError("Only one score per query-document/passage pair is allowed.")
+
+        keep = _KEY + ["score"] + (["query"] if "query" in df.columns else [])
+        frame = df.loc[:, keep].dropna()
+        if copy:
+            frame = frame.copy()
+        wanted = {"score": dtype, "q_id": str, "id": str}
+        for col, dt in wanted.items():
+            if frame[col].dtype != dt:
+                frame[col] = frame[col].astype(dt)
+        if not is_sorted:
+            frame = _sorted_frame(frame)
+        self._df = frame.reset_index(drop=True)
+        self._q_ids = set(self._df["q_id"].unique())
+        if queries is not None:
+            self._df = _with_queries(self._df, queries)
+
+    # ---- container protocol ------------------------------------------------------------
+    @property
+    def has_queries(self) -> bool:
+        """Whether query strings are attached."""
+        return "query" in self._df.columns
+
+    @property
+    def q_ids(self) -> set[str]:
+        """Ids of the queries that have at least one scored candidate."""
+        return self._q_ids
+
+    def __getitem__(self, q_id: str) -> dict[str, float]:
+        rows = self._df[self._df["q_id"] == q_id]
+        return dict(zip(rows["id"], rows["score"]))
+
+    def __len__(self) -> int:
+        return len(self._q_ids)
+
+    def __iter__(self) -> Iterator[str]:
+        yield from self._q_ids
+
+    def __contains__(self, key: object) -> bool:
+        return key in self._q_ids
+
+    def __eq__(self, o: object) -> bool:
+        """Same (q_id, id, score) triples, in any order (ranking.py:171-186)."""
+        if not isinstance(o, Ranking):
+            return False
+        cols = _KEY + ["score"]
+        mine = self._df.sort_values(_KEY).reset_index(drop=True)[cols]
+        theirs = o._df.sort_values(_KEY).reset_index(drop=True)[cols]
+        return mine.equals(theirs)
+
+    __hash__ = None  # mutable container, like the reference
+
+    def __repr__(self) -> str:
+        return repr(self._df)
+
+    # ---- score algebra ---------------------------------------------------------------------
+    def _joined(self, other: "Ranking", left: pd.DataFrame | None = None, right: pd.DataFrame | None = None) -> pd.DataFrame:
+        """Outer join on (q_id, id); a side that lacks the pair contributes 0."""
+        a = self._df if left is None else left
+        b = other._df if right is None else right
+        return a.merge(b, on=_KEY, how="outer", suffixes=(None, "_other")).fillna(0)
+
+    def _derived(self, df: pd.DataFrame, is_sorted: bool, copy: bool = False) -> "Ranking":
+        return Ranking(df, name=self.name, dtype=self._df.dtypes["score"], copy=copy, is_sorted=is_sorted)
+
+    def __add__(self, o: "Ranking | float") -> "Ranking":
+        if isinstance(o, Ranking):
+            both = self._joined(o)
+            both["score"] = both["score"] + both["score_other"]
+            return self._derived(both, is_sorted=False)
+        if isinstance(o, (int, float)):
+            shifted = self._df.copy()
+            shifted["score"] += o
+            return self._derived(shifted, is_sorted=True)
+        return NotImplemented
+
+    __radd__ = __add__
+
+    def __mul__(self, o: float) -> "Ranking":
+        if not isinstance(o, (int, float)):
+            return NotImplemented
+        scaled = self._df.copy()
+        scaled["score"] *= o
+        return self._derived(scaled, is_sorted=True)
+
+    __rmul__ = __mul__
+
+    def interpolate(self, other: "Ranking", alpha: float, normalize: bool = False) -> "Ranking":
+        """``alpha * self + (1 - alpha) * other`` per (query, id) pair (ranking.py:293-326).
+
+        When ``other`` was produced by ``Index.__call__(self)`` on the device, prefer
+        ``Index.__call__(..., alpha=...)`` / ``Index.rerank`` which fuse this step into the
+        scoring kernel's epilogue; this method is the general host path and gives the same bits.
+        """
+        left = _scaled_to_unit_range(self._df) if normalize else None
+        right = _scaled_to_unit_range(other._df) if normalize else None
+        both = self._joined(other, left, right)
+        # a Python-float weight on a float32 column multiplies in float32 (ranking.py:319)
+        both["score"] = alpha * both["score"] + (1 - alpha) * both["score_other"]
+        return self._derived(both, is_sorted=False)
+
+    def normalize(self) -> "Ranking":
+        """Min-max scale all scores to [0, 1] (constant scores -> 0)."""
+        return self._derived(_scaled_to_unit_range(self._df), is_sorted=True)
+
+    def rr_scores(self, k: int = 60) -> "Ranking":
+        """Reciprocal-rank scores ``1 / (rank + k)`` (ranking.py:328-346)."""
+        out = self._df.copy()
+        out["score"] = 1 / (_ranks_within_query(out) + k)
+        return self._derived(out, is_sorted=True)
+
+    # ---- reshaping -------------------------------------------------------------------------
+    def attach_queries(self, queries: Mapping[str, str]) -> "Ranking":
+        """Copy of this ranking with query strings attached (``ValueError`` if incomplete)."""
+        return Ranking(self._df, self.name, queries=queries, dtype=self._df.dtypes["score"], copy=True, is_sorted=True)
+
+    def cut(self, cutoff: int) -> "Ranking":
+        """Keep the ``cutoff`` best candidates of every query (frame is sorted by score)."""
+        top = self._df[_ranks_within_query(self._df) <= cutoff]
+        return self._derived(top.reset_index(drop=True), is_sorted=True, copy=True)
+
+    # ---- I/O -----------------------------------------------------------------------------------
+    def save(self, target: Path) -> None:
+        """Write a TREC run file: ``q_id Q0 id rank score name`` (ranking.py:348-366)."""
+        out = self._df[_KEY + ["score"]].copy()
+        out["rank"] = _ranks_within_query(out)
+        out["q0"] = "Q0"
+        out["name"] = str(self.name)
+        target.parent.mkdir(parents=True, exist_ok=True)
+        out.to_csv(target, sep="\t", columns=["q_id", "q0", "id", "rank", "score", "name"], index=False, header=False)
+
+    @classmethod
+    def from_run(cls, run: Run, name: str | None = None, queries: Mapping[str, str] | None = None,
+                 dtype: np.dtype = np.dtype(np.float32)) -> "Ranking":
+        """From ``{q_id: {id: score}}`` (ranking.py:368-386)."""
+        q_col, id_col, s_col = [], [], []
+        for q_id, scored in run.items():
+            q_col.extend([q_id] * len(scored))
+            id_col.extend(scored.keys())
+            s_col.extend(scored.values())
+        df = pd.DataFrame({"q_id": pd.Series(q_col, dtype=object), "id": pd.Series(id_col, dtype=object),
+                           "score": pd.Series(s_col, dtype=np.float64)})
+        return cls(df, name=name, queries=queries, dtype=dtype, copy=False)
+
+    @classmethod
+    def from_file(cls, f: Path, queries: Mapping[str, str] | None = None,
+                  dtype: np.dtype = np.dtype(np.float32)) -> "Ranking":
+        """From a TREC run file; the method name is taken from its last column."""
+        df = pd.read_csv(f, sep=r"\s+", skipinitialspace=True, header=None,
+                         names=["q_id", "q0", "id", "rank", "score", "name"])
+        return cls(df, name=df["name"][0], queries=queries, dtype=dtype, copy=False)

@@ -1,0 +1,147 @@
+/*
+ * ffx.h -- C ABI of libffx: the MI355X (gfx950) Fast-Forward re-ranking path.
+ *
+ * The reference (mrjleo/fast-forward-indexes v0.8.0) is pure Python and has no FFI; its
+ * seam for this path is the abstract `Index` class (src/fast_forward/index/base.py:30):
+ * `Index.__call__` (:389-469) reaches storage through `_get_vectors` (:258-277, :291) and
+ * does the arithmetic in `_compute_scores` (:279-314); `Ranking.interpolate`
+ * (src/fast_forward/ranking.py:293-326) adds the sparse scores.  Every entry point below
+ * names the reference lines it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; no exceptions cross the ABI
+ *   - every function returns an FFX_* status (0 = ok); ffx_last_error() gives the message
+ *     of the calling thread's last failure
+ *   - the caller owns every host buffer for the duration of the call; the library owns
+ *     device memory behind the opaque handles and retains no host pointer after return
+ *   - a handle is not thread-safe; distinct handles are independent
+ *   - ids are integers here: a *document ordinal* names the rows of one document (in
+ *     insertion order), a *passage ordinal* names one row.  String ids stay in the host
+ *     language (reference: the dicts at src/fast_forward/index/memory.py:46-47).
+ */
+#ifndef FFX_H_
+#define FFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFX_ABI_VERSION 1
+
+/* status codes */
+#define FFX_OK 0
+#define FFX_BAD_ARG (-1)
+#define FFX_OOM (-2)
+#define FFX_HIP_ERROR (-3)
+#define FFX_RCCL_ERROR (-4) /* reserved: the score exchange runs above the ABI */
+#define FFX_NOT_FOUND (-5)  /* an ordinal names no row: the reference's IndexError, index/util.py:38-39 */
+#define FFX_NO_DEVICE (-6)
+
+/* ranking modes: values of fast_forward.index.Mode, index/base.py:18-24 */
+#define FFX_MODE_PASSAGE 1
+#define FFX_MODE_MAXP 2
+#define FFX_MODE_FIRSTP 3
+#define FFX_MODE_AVEP 4
+
+/* ffx_plan_run flags */
+#define FFX_FLAG_EXACT_SUM 1u /* NumPy summation order: scores bit-identical to index/base.py:303 */
+#define FFX_FLAG_SORT 2u      /* also produce the per-query order of ranking.py:115-117 */
+#define FFX_FLAG_SORT_FF 4u   /* with SORT: order by the dense score even if sparse scores are set */
+
+/* ffx_plan_device_ptr selectors */
+#define FFX_BUF_FF 0       /* float[P]   aggregated dense scores                         */
+#define FFX_BUF_INTERP 1   /* float[P]   interpolated scores (valid if sparse was given) */
+#define FFX_BUF_ORDER 2    /* int32[P]   per-query order (valid after FFX_FLAG_SORT)     */
+#define FFX_BUF_QUERIES 3  /* float[Q*d] query vectors                                   */
+#define FFX_BUF_PAIR_IDS 4 /* int32[P]   candidate ordinals                              */
+#define FFX_BUF_SPARSE 5   /* float[P]   first-stage scores                              */
+
+typedef struct ffx_index ffx_index;
+typedef struct ffx_plan ffx_plan;
+
+typedef struct ffx_stats {
+  int64_t n_queries;
+  int64_t n_pairs;           /* P: (query, candidate) pairs                                   */
+  int64_t n_rows;            /* R: gathered index rows (= P unless MAXP/AVEP with >1 passage) */
+  double algorithmic_bytes;  /* R*(d*4+4) + P*4*(1+2*interp) + Q*d*4 + (Q+1)*8 */
+  float ms_expand;           /* pairs -> row list (count, scan, expand)                       */
+  float ms_gather_dot;       /* the gather + inner-product kernel                             */
+  float ms_reduce;           /* segment max/first/mean + interpolation                        */
+  float ms_sort;             /* per-query ordering (0 unless FFX_FLAG_SORT)                   */
+  float ms_total;            /* first launch to last completion of ffx_plan_run               */
+  int32_t kernel_variant;    /* which gather_dot instantiation ran            */
+  int32_t reserved;
+} ffx_stats;
+
+/* ---- library / device ------------------------------------------------------------- */
+int ffx_abi_version(void);
+const char* ffx_last_error(void);
+int ffx_device_count(int* count);
+int ffx_device_info(int device, char* name, size_t name_cap, int64_t* total_bytes,
+                    int64_t* free_bytes, int32_t* compute_units);
+
+/* ---- HBM-resident index: replaces InMemoryIndex storage, index/memory.py:23-131 -------
+ * One fp32 matrix of `capacity_rows` x `dim` in device memory, rows in insertion order
+ * (row r of the reference's chunk list, memory.py:100-119, is row r here). */
+int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index** out);
+int ffx_index_destroy(ffx_index* idx);
+int ffx_index_dim(const ffx_index* idx, int32_t* dim);
+int ffx_index_capacity(const ffx_index* idx, int64_t* rows);
+/* copy host rows into rows [row_offset, row_offset+n_rows): InMemoryIndex._add, memory.py:100-119 */
+int ffx_index_upload(ffx_index* idx, const float* host_rows, int64_t row_offset, int64_t n_rows);
+/* device copy between two indexes on the same device (growing an index) */
+int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows);
+/* read rows back: InMemoryIndex._get_vectors, memory.py:139-140 / index/util.py:97-98 */
+int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, float* host_out);
+/* fill rows with the counter-based synthetic generator shared with the oracle
+ * (value of element e of global row g: see fast_forward_amd/synth.py); bench/test data only */
+int ffx_index_fill_synthetic(ffx_index* idx, uint64_t seed, float scale, int64_t row_offset,
+                             int64_t n_rows, int64_t first_global_row);
+/* id structure: the two dicts of memory.py:46-47 as arrays.
+ *   doc ordinal o -> rows doc_rows[doc_off[o] .. doc_off[o+1])   (insertion order)
+ *   psg ordinal o -> row psg_row[o]                               (-1: no such passage) */
+int ffx_index_set_doc_rows(ffx_index* idx, const int64_t* doc_off, int64_t n_docs,
+                           const int32_t* doc_rows, int64_t n_doc_rows);
+int ffx_index_set_psg_rows(ffx_index* idx, const int32_t* psg_row, int64_t n_psgs);
+
+/* ---- scoring plan: replaces Index._compute_scores, index/base.py:279-314, and the
+ * arithmetic of Ranking.interpolate, ranking.py:319 ------------------------------------
+ * A plan owns the device workspace of one batch of queries.  Typical use:
+ *   set_queries, set_pairs  (host -> HBM; validates ordinals; FFX_NOT_FOUND + *bad_pair)
+ *   run                     (device only, asynchronous: expand -> gather_dot -> reduce [-> sort])
+ *   sync, fetch             (HBM -> host)
+ * A plan can be re-run with another alpha / flags without re-uploading. */
+int ffx_plan_create(ffx_index* idx, ffx_plan** out);
+int ffx_plan_destroy(ffx_plan* plan);
+/* query vectors [n_queries, dim] fp32, row q = query number q (q_no of index/base.py:418-421) */
+int ffx_plan_set_queries(ffx_plan* plan, const float* host_queries, int64_t n_queries);
+/* candidate lists in CSR form: pairs pair_off[q] .. pair_off[q+1] belong to query q and name
+ * ordinal pair_ids[p] (document ordinal, or passage ordinal for FFX_MODE_PASSAGE); sparse[p] is
+ * the first-stage score (may be NULL).  get_indices, index/util.py:12-42, runs here. */
+int ffx_plan_set_pairs(ffx_plan* plan, const int64_t* pair_off, int64_t n_queries,
+                       const int32_t* pair_ids, const float* sparse, int mode, int64_t* bad_pair);
+int ffx_plan_run(ffx_plan* plan, double alpha, uint32_t flags);
+int ffx_plan_sync(ffx_plan* plan);
+/* any of the outputs may be NULL */
+int ffx_plan_fetch(ffx_plan* plan, float* out_ff, float* out_interp, int32_t* out_order);
+int ffx_plan_stats(ffx_plan* plan, ffx_stats* out);
+/* raw device pointers (score exchange between ranks, zero-copy consumers); valid until the
+ * next set_* call on the plan */
+int ffx_plan_device_ptr(ffx_plan* plan, int which, void** ptr, int64_t* n_elems);
+/* the plan's HIP stream (hipStream_t) so callers can order their own work after run */
+int ffx_plan_stream(ffx_plan* plan, void** stream);
+
+/* one-shot: set_queries + set_pairs + run + sync + fetch (host buffers in, host buffers out) */
+int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
+              const int64_t* pair_off, const int32_t* pair_ids, const float* sparse, int mode,
+              double alpha, uint32_t flags, float* out_ff, float* out_interp, int32_t* out_order,
+              int64_t* bad_pair, ffx_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFX_H_ */

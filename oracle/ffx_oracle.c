@@ -190,30 +190,33 @@ int ffo_score(const float* vectors, int64_t n_rows, int64_t d, const int64_t* do
     }
   }
   int err = 0;
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int64_t q = 0; q < n_queries; ++q) {
-    const float* qv = queries + q * d;
+#pragma omp parallel
+  {
     float stack_buf[64];
-    for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
-      int32_t o = pair_ids[p];
-      int64_t n;
-      const int32_t* rows;
-      if (mode == FFO_MODE_PASSAGE) {
-        rows = psg_row + o;
-        n = 1;
-      } else {
-        rows = doc_rows + doc_off[o];
-        n = doc_off[o + 1] - doc_off[o];
-        if (mode == FFO_MODE_FIRSTP) n = 1;
+    for (int64_t q = 0; q < n_queries; ++q) {
+      const float* qv = queries + q * d;
+#pragma omp for schedule(static) nowait
+      for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
+        int32_t o = pair_ids[p];
+        int64_t n;
+        const int32_t* rows;
+        if (mode == FFO_MODE_PASSAGE) {
+          rows = psg_row + o;
+          n = 1;
+        } else {
+          rows = doc_rows + doc_off[o];
+          n = doc_off[o + 1] - doc_off[o];
+          if (mode == FFO_MODE_FIRSTP) n = 1;
+        }
+        float* s = n <= 64 ? stack_buf : (float*)malloc((size_t)n * sizeof(float));
+        if (!s) {
+          err = 1;
+          continue;
+        }
+        for (int64_t i = 0; i < n; ++i) s[i] = ffo_pairwise_prod(qv, vectors + (int64_t)rows[i] * d, d);
+        out_ff[p] = ffo_aggregate_one(s, n, mode);
+        if (s != stack_buf) free(s);
       }
-      float* s = n <= 64 ? stack_buf : (float*)malloc((size_t)n * sizeof(float));
-      if (!s) {
-        err = 1;
-        continue;
-      }
-      for (int64_t i = 0; i < n; ++i) s[i] = ffo_pairwise_prod(qv, vectors + (int64_t)rows[i] * d, d);
-      out_ff[p] = ffo_aggregate_one(s, n, mode);
-      if (s != stack_buf) free(s);
     }
   }
   if (err) return FFO_BAD_ARG;

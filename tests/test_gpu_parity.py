@@ -1,0 +1,242 @@
+"""GPU parity: the HIP path through the C ABI (libffx.so) against the CPU oracle and the
+golden fixtures produced by the reference.  Run with ``-m gpu`` on an MI355X.
+
+Bars (BASELINE.json north_star):
+  * exact-sum mode: scores BIT-IDENTICAL to the reference (hence identical run ordering)
+  * fast mode: |score - reference| <= 1e-4 (fp32, unit-scale rows), tolerance written below
+  * aggregation, interpolation, ordering: bit-exact / identical modulo exact ties
+"""
+
+import numpy as np
+import pytest
+
+import ffx_oracle as fo
+from _cases import ALPHAS, MODE_NO, SCORING_CASES, assert_same_order_modulo_ties, bits, load_scoring_case
+from fast_forward_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+FAST_TOL = 1e-4  # north_star: "match the reference NumPy scores to 1e-4 fp32"
+
+
+def device_index(case) -> native.DeviceIndex:
+    idx = native.DeviceIndex(case.vectors.shape[0], case.vectors.shape[1])
+    idx.upload(case.vectors, 0)
+    idx.set_doc_rows(case.doc_off, case.doc_rows)
+    idx.set_psg_rows(case.psg_row)
+    return idx
+
+
+@pytest.fixture(scope="module")
+def cases():
+    return {name: load_scoring_case(name) for name in SCORING_CASES}
+
+
+@pytest.mark.parametrize("name", SCORING_CASES)
+def test_exact_scores_bit_identical_to_reference(cases, name):
+    case = cases[name]
+    idx = device_index(case)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        ff, interp, order, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], sparse, 0.1,
+                                             exact_sum=True, sort=True)
+        exp = case.expected(f"{mode}_ff")
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+        assert np.array_equal(bits(ff), bits(want)), f"{name}/{mode}: max diff {np.abs(ff - want).max()} (variant {st['kernel_variant']})"
+        exp_i = case.expected(f"{mode}_int0.1")
+        want_i = np.array([exp_i[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+        assert np.array_equal(bits(interp), bits(want_i))
+        # device ordering == reference ordering (modulo exact ties)
+        exp_order = case.expected_order(f"{mode}_int0.1")
+        for q, qn in enumerate(case.q_names):
+            sel = order[pair_off[q]:pair_off[q + 1]]
+            assert_same_order_modulo_ties([names[i] for i in sel], interp[sel], exp_order[qn])
+        # and == the oracle's deterministic tie-break (stable: ascending position)
+        assert np.array_equal(order.astype(np.int64), fo.order(interp, pair_off))
+    idx.close()
+
+
+@pytest.mark.parametrize("name", SCORING_CASES)
+def test_fast_scores_within_tolerance(cases, name):
+    case = cases[name]
+    idx = device_index(case)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, _ = case.pairs(mode)
+        ff, _, _, _ = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=False)
+        want, _ = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids, MODE_NO[mode])
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(ff - want).max() <= FAST_TOL * scale, f"{name}/{mode}"
+    idx.close()
+
+
+@pytest.mark.parametrize("alpha", ALPHAS)
+def test_interpolation_all_alphas(cases, alpha):
+    case = cases["d768"]
+    idx = device_index(case)
+    plan = native.Plan(idx)
+    plan.set_queries(case.queries)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        plan.set_pairs(pair_off, pair_ids, sparse, MODE_NO[mode])
+        plan.run(alpha, exact_sum=True)
+        _, interp, _ = plan.fetch(interp=True)
+        exp = case.expected(f"{mode}_int{alpha}")
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+        assert np.array_equal(bits(interp), bits(want))
+    plan.close()
+    idx.close()
+
+
+def test_plan_rerun_and_stats(cases):
+    case = cases["s2_sub"]
+    idx = device_index(case)
+    plan = native.Plan(idx)
+    plan.set_queries(case.queries)
+    pair_off, pair_ids, sparse, _ = case.pairs("MAXP")
+    plan.set_pairs(pair_off, pair_ids, sparse, MODE_NO["MAXP"])
+    outs = []
+    for alpha in (0.1, 0.5, 0.1):
+        plan.run(alpha, exact_sum=True, sort=True)
+        outs.append(plan.fetch(interp=True, order=True))
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])
+    assert np.array_equal(outs[0][2], outs[2][2])
+    assert not np.array_equal(outs[0][1], outs[1][1])
+    st = plan.stats()
+    d = case.vectors.shape[1]
+    assert st["n_pairs"] == pair_ids.shape[0] and st["n_rows"] > st["n_pairs"]
+    want_bytes = st["n_rows"] * (d * 4 + 4) + st["n_pairs"] * 12 + st["n_queries"] * d * 4 + (st["n_queries"] + 1) * 8
+    assert st["algorithmic_bytes"] == want_bytes
+    assert st["ms_gather_dot"] > 0
+    plan.close()
+    idx.close()
+
+
+def test_unknown_ordinal_is_not_found(cases):
+    case = cases["dim20"]
+    idx = device_index(case)
+    pair_off, pair_ids, _, _ = case.pairs("MAXP")
+    bad = pair_ids.copy()
+    bad[5] = 10**6
+    bad[9] = -3
+    with pytest.raises(native.NotFound) as e:
+        native.score(idx, case.queries, pair_off, bad, MODE_NO["MAXP"])
+    assert e.value.pair == 5
+    idx.close()
+
+
+def test_ragged_and_empty_queries():
+    """Queries with 0, 1 and many candidates; a tile boundary inside a query; R not a multiple
+    of the wave tile."""
+    d, n = 768, 700
+    vectors = synth.rows(11, 0.05, 0, n, d)
+    queries = synth.rows(12, 0.05, 0, 6, d)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    doc_off = np.arange(n + 1)
+    idx.set_doc_rows(doc_off, np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    lens = [0, 1, 333, 0, 17, 64]
+    pair_off = np.concatenate([[0], np.cumsum(lens)])
+    rng = np.random.default_rng(0)
+    pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for k in lens]).astype(np.int32)
+    for mode in (1, 2, 3, 4):
+        ff, _, order, _ = native.score(idx, queries, pair_off, pair_ids, mode, sort=True)
+        want, _ = fo.score(vectors, doc_off, np.arange(n), np.arange(n), queries, pair_off, pair_ids, mode)
+        assert np.array_equal(bits(ff), bits(want))
+        assert np.array_equal(order.astype(np.int64), fo.order(want, pair_off))
+    # nothing to score at all
+    ff, _, _, _ = native.score(idx, queries, np.zeros(7, dtype=np.int64), np.zeros(0, dtype=np.int32), 2)
+    assert ff.shape == (0,)
+    idx.close()
+
+
+def test_many_passages_per_document():
+    """MAXP / AVEP segments from 1 to 300 rows, rows of a document NOT contiguous."""
+    d, n_docs = 128, 40
+    rng = np.random.default_rng(3)
+    per_doc = rng.integers(1, 12, size=n_docs)
+    per_doc[7] = 300
+    n = int(per_doc.sum())
+    doc_of_row = rng.permutation(np.repeat(np.arange(n_docs), per_doc))
+    doc_rows = np.argsort(doc_of_row, kind="stable").astype(np.int32)
+    doc_off = np.concatenate([[0], np.cumsum(np.bincount(doc_of_row, minlength=n_docs))])
+    vectors = synth.rows(21, 0.3, 0, n, d)
+    queries = synth.rows(22, 0.3, 0, 5, d)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    idx.set_doc_rows(doc_off, doc_rows)
+    idx.set_psg_rows(np.arange(n))
+    pair_off = np.arange(6) * n_docs
+    pair_ids = np.concatenate([rng.permutation(n_docs) for _ in range(5)]).astype(np.int32)
+    sparse = rng.random(pair_ids.shape[0]).astype(np.float32)
+    for mode in (2, 3, 4):
+        ff, interp, _, _ = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.2)
+        want, want_i = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, pair_ids, mode, sparse, 0.2)
+        assert np.array_equal(bits(ff), bits(want)), mode
+        assert np.array_equal(bits(interp), bits(want_i)), mode
+    idx.close()
+
+
+@pytest.mark.parametrize("d", [64, 128, 256, 384, 512, 768, 1024, 8, 24, 1000, 2048, 4100])
+def test_every_kernel_variant_exact(d):
+    """Each gather_dot instantiation (and the generic kernel) against the oracle, bit for bit."""
+    n, nq, k = 257, 3, 150
+    vectors = synth.rows(31 + d, 1.0, 0, n, d)
+    queries = synth.rows(32 + d, 1.0, 0, nq, d)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    rng = np.random.default_rng(d)
+    pair_off = np.arange(nq + 1) * k
+    pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for _ in range(nq)]).astype(np.int32)
+    ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=True)
+    want, _ = fo.score(vectors, np.arange(n + 1), np.arange(n), np.arange(n), queries, pair_off, pair_ids, 2)
+    assert np.array_equal(bits(ff), bits(want)), f"d={d} variant {st['kernel_variant']}"
+    ref = np.sum(queries[np.repeat(np.arange(nq), k)] * vectors[pair_ids], axis=1)  # NumPy itself
+    assert np.array_equal(bits(ff), bits(ref))
+    ff_fast, _, _, st = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=False)
+    assert np.abs(ff_fast - want).max() <= FAST_TOL * max(1.0, float(np.abs(want).max())), f"d={d} variant {st['kernel_variant']}"
+    idx.close()
+
+
+def test_synthetic_fill_matches_host_generator():
+    d, n = 768, 1000
+    idx = native.DeviceIndex(n, d)
+    idx.fill_synthetic(seed=5, scale=0.0625, row_offset=0, n_rows=n, first_global_row=123456)
+    rows = np.array([0, 1, 77, 999], dtype=np.int32)
+    got = idx.gather(rows)
+    for i, r in enumerate(rows):
+        assert np.array_equal(bits(got[i]), bits(synth.rows(5, 0.0625, 123456 + int(r), 1, d)[0]))
+    idx.close()
+
+
+def test_full_size_properties():
+    """Properties that hold at any size, checked on a few hundred MB: every candidate is a
+    distinct synthetic row, so (a) scoring a query against its own row list twice gives the
+    same bits, (b) scores are invariant to how candidates are split into queries, (c) a
+    sampled subset matches the oracle bit for bit."""
+    d, n, nq, k = 768, 200_000, 64, 2000
+    idx = native.DeviceIndex(n, d)
+    idx.fill_synthetic(seed=9, scale=0.0625, row_offset=0, n_rows=n)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    queries = synth.rows(10, 0.0625, 0, nq, d)
+    pair_ids = (synth.uniform_u32(np.arange(nq * k, dtype=np.uint64), 4) % np.uint32(n)).astype(np.int32)
+    pair_off = np.arange(nq + 1, dtype=np.int64) * k
+    a, _, _, _ = native.score(idx, queries, pair_off, pair_ids, 2)
+    b, _, _, _ = native.score(idx, queries, pair_off, pair_ids, 1)
+    assert np.array_equal(bits(a), bits(b))
+    # split every query in two halves (same query vector twice): same scores
+    q2 = np.repeat(queries, 2, axis=0)
+    off2 = np.arange(2 * nq + 1, dtype=np.int64) * (k // 2)
+    c, _, _, _ = native.score(idx, q2, off2, pair_ids, 2)
+    assert np.array_equal(bits(a), bits(c))
+    # oracle spot check on 2000 sampled pairs
+    sel = np.random.default_rng(0).choice(nq * k, size=2000, replace=False)
+    rows = np.concatenate([synth.rows(9, 0.0625, int(r), 1, d) for r in pair_ids[sel]])  # re-derived on the host
+    want = fo.row_scores(queries, rows, (sel // k).astype(np.int32), np.arange(sel.shape[0], dtype=np.int32))
+    assert np.array_equal(bits(a[sel]), bits(want))
+    idx.close()
