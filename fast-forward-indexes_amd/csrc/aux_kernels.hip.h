@@ -38,48 +38,55 @@ count_rows_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mod
   if (c == 0) atomicMin(bad_pair, (unsigned long long)p);
 }
 
+// query number of pair p: the q with pair_off[q] <= p < pair_off[q+1].  First-stage runs give
+// (nearly) every query the same number of candidates, so the proportional guess is almost
+// always right and costs two independent loads; a miss falls back to binary search.
+__device__ __forceinline__ int query_of_pair(const int64_t* __restrict__ pair_off, int n_queries,
+                                             int64_t p, double queries_per_pair) {
+  int q = (int)((double)p * queries_per_pair);
+  q = q < 0 ? 0 : (q > n_queries - 1 ? n_queries - 1 : q);
+  if (pair_off[q] <= p && p < pair_off[q + 1]) return q;
+  int lo = 0, hi = n_queries;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pair_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // desc[seg_off[p] + i] = {i-th row of candidate p, query number of p}
 __global__ void __launch_bounds__(256)
 expand_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
-              const int64_t* __restrict__ pair_off, int n_queries,
+              const int64_t* __restrict__ pair_off, int n_queries, double queries_per_pair,
               const int32_t* __restrict__ doc_off, const int32_t* __restrict__ doc_rows,
               const int32_t* __restrict__ psg_row, const int32_t* __restrict__ seg_off,
               int2* __restrict__ desc) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
-  // query of pair p: last q with pair_off[q] <= p
-  int lo = 0, hi = n_queries;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (pair_off[mid] <= p) lo = mid; else hi = mid;
-  }
+  const int q = query_of_pair(pair_off, n_queries, p, queries_per_pair);
   const int32_t o = pair_ids[p];
   const int32_t s = seg_off[p];
   const int32_t c = seg_off[p + 1] - s;
   if (mode == FFX_MODE_PASSAGE) {
-    desc[s] = make_int2(psg_row[o], lo);
+    desc[s] = make_int2(psg_row[o], q);
   } else {
     const int32_t* rows = doc_rows + doc_off[o];
-    for (int32_t i = 0; i < c; ++i) desc[s + i] = make_int2(rows[i], lo);
+    for (int32_t i = 0; i < c; ++i) desc[s + i] = make_int2(rows[i], q);
   }
 }
 
-// single-row candidates (FIRSTP, PASSAGE, or every document has one passage): no scan needed
+// single-row candidates (FIRSTP, PASSAGE, or every document has one passage): no scan needed.
+// row_of[o] is the one row of ordinal o (first row of the document / row of the passage);
+// row_of == nullptr means ordinal == row (ids were added one per row, in order).
 __global__ void __launch_bounds__(256)
-expand_single_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
-                     const int64_t* __restrict__ pair_off, int n_queries,
-                     const int32_t* __restrict__ doc_off, const int32_t* __restrict__ doc_rows,
-                     const int32_t* __restrict__ psg_row, int2* __restrict__ desc) {
+expand_single_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs,
+                     const int64_t* __restrict__ pair_off, int n_queries, double queries_per_pair,
+                     const int32_t* __restrict__ row_of, int2* __restrict__ desc) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
-  int lo = 0, hi = n_queries;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (pair_off[mid] <= p) lo = mid; else hi = mid;
-  }
+  const int q = query_of_pair(pair_off, n_queries, p, queries_per_pair);
   const int32_t o = pair_ids[p];
-  const int32_t row = (mode == FFX_MODE_PASSAGE) ? psg_row[o] : doc_rows[doc_off[o]];
-  desc[p] = make_int2(row, lo);
+  desc[p] = make_int2(row_of ? row_of[o] : o, q);
 }
 
 // ---- groupby(["id","q_no"]).aggregate(op) (index/base.py:306-312) + ranking.py:319 ----------
@@ -130,6 +137,17 @@ interp_kernel(const float* __restrict__ ff, const float* __restrict__ sparse, in
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   interp[p] = interp_one(a, b, sparse[p], ff[p]);
+}
+
+// owner-side merge of a row-sharded index: dense score of candidate p sits at recv[slot[p]]
+__global__ void __launch_bounds__(256)
+merge_kernel(const float* __restrict__ recv, const int32_t* __restrict__ slot, const float* __restrict__ sparse,
+             int64_t n_pairs, float a, float b, float* __restrict__ ff, float* __restrict__ interp) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const float dense = recv[slot[p]];
+  ff[p] = dense;
+  if (sparse != nullptr) interp[p] = interp_one(a, b, sparse[p], dense);
 }
 
 // ---- row copy-out for _get_vectors (index/memory.py:139-140) --------------------------------

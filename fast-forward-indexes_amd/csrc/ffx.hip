@@ -108,13 +108,16 @@ struct ffx_index {
   DevBuf doc_off;   // int32[n_docs+1]
   DevBuf doc_rows;  // int32[n_doc_rows]
   DevBuf psg_row;   // int32[n_psgs]
+  DevBuf doc_first; // int32[n_docs]: first row of every document (FIRSTP / single-passage docs)
   int64_t n_docs = 0, n_doc_rows = 0, n_psgs = 0;
-  bool single_passage_docs = true;  // every document has exactly one row
+  bool docs_identity = false;  // document ordinal o owns exactly row o
+  bool psgs_identity = false;  // passage ordinal o is row o
 };
 
 struct ffx_plan {
   ffx_index* idx = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream work is issued on
+  hipStream_t own_stream = nullptr;  // created with the plan; `stream` may point elsewhere
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // inputs
   DevBuf queries, pair_off, pair_ids, sparse;
@@ -204,6 +207,7 @@ int ffx_index_destroy(ffx_index* idx) {
   idx->doc_off.release();
   idx->doc_rows.release();
   idx->psg_row.release();
+  idx->doc_first.release();
   delete idx;
   return FFX_OK;
 }
@@ -286,28 +290,34 @@ int ffx_index_set_doc_rows(ffx_index* idx, const int64_t* doc_off, int64_t n_doc
   if (!idx || n_docs < 0 || n_doc_rows < 0 || (n_docs > 0 && !doc_off) || (n_doc_rows > 0 && !doc_rows))
     return fail(FFX_BAD_ARG, "bad argument");
   if (n_docs > INT32_MAX - 1 || n_doc_rows > INT32_MAX) return fail(FFX_BAD_ARG, "too many documents/rows for int32 ids");
-  std::vector<int32_t> off32((size_t)n_docs + 1, 0);
-  bool single = true;
+  std::vector<int32_t> off32((size_t)n_docs + 1, 0), first((size_t)std::max<int64_t>(n_docs, 1), 0);
+  bool identity = n_docs == n_doc_rows;
   if (n_docs > 0) {
     if (doc_off[0] != 0 || doc_off[n_docs] != n_doc_rows) return fail(FFX_BAD_ARG, "doc_off must run from 0 to n_doc_rows");
     for (int64_t i = 0; i < n_docs; ++i) {
       const int64_t c = doc_off[i + 1] - doc_off[i];
       if (c < 0) return fail(FFX_BAD_ARG, "doc_off not monotone at %lld", (long long)i);
-      if (c != 1) single = false;
       off32[(size_t)i + 1] = (int32_t)doc_off[i + 1];
     }
   }
   for (int64_t i = 0; i < n_doc_rows; ++i)
     if (doc_rows[i] < 0 || doc_rows[i] >= idx->capacity) return fail(FFX_BAD_ARG, "doc_rows[%lld] outside the index", (long long)i);
+  for (int64_t i = 0; i < n_docs; ++i) {
+    const bool has = doc_off[i + 1] > doc_off[i];
+    first[(size_t)i] = has ? doc_rows[doc_off[i]] : -1;
+    if (!has || doc_off[i] != i || doc_rows[i] != i) identity = false;
+  }
   FFX_HIP(hipSetDevice(idx->device));
   FFX_TRY(idx->doc_off.ensure(off32.size() * sizeof(int32_t)));
   FFX_TRY(idx->doc_rows.ensure(std::max<size_t>((size_t)n_doc_rows, 1) * sizeof(int32_t)));
+  FFX_TRY(idx->doc_first.ensure(first.size() * sizeof(int32_t)));
   FFX_HIP(hipMemcpy(idx->doc_off.p, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  FFX_HIP(hipMemcpy(idx->doc_first.p, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (n_doc_rows > 0)
     FFX_HIP(hipMemcpy(idx->doc_rows.p, doc_rows, (size_t)n_doc_rows * sizeof(int32_t), hipMemcpyHostToDevice));
   idx->n_docs = n_docs;
   idx->n_doc_rows = n_doc_rows;
-  idx->single_passage_docs = single;
+  idx->docs_identity = identity && n_docs > 0;
   return FFX_OK;
 }
 
@@ -318,6 +328,9 @@ int ffx_index_set_psg_rows(ffx_index* idx, const int32_t* psg_row, int64_t n_psg
   FFX_TRY(idx->psg_row.ensure(std::max<size_t>((size_t)n_psgs, 1) * sizeof(int32_t)));
   if (n_psgs > 0) FFX_HIP(hipMemcpy(idx->psg_row.p, psg_row, (size_t)n_psgs * sizeof(int32_t), hipMemcpyHostToDevice));
   idx->n_psgs = n_psgs;
+  bool identity = n_psgs > 0 && n_psgs <= idx->capacity;
+  for (int64_t i = 0; i < n_psgs && identity; ++i) identity = psg_row[i] == i;
+  idx->psgs_identity = identity;
   return FFX_OK;
 }
 
@@ -329,7 +342,8 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
   ffx_plan* pl = new (std::nothrow) ffx_plan();
   if (!pl) return fail(FFX_OOM, "host allocation failed");
   pl->idx = idx;
-  hipError_t e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+  hipError_t e = hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking);
+  pl->stream = pl->own_stream;
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
   if (e != hipSuccess) {
     ffx_plan_destroy(pl);
@@ -362,8 +376,16 @@ int ffx_plan_destroy(ffx_plan* pl) {
     b->release();
   for (auto& e : pl->ev)
     if (e) (void)hipEventDestroy(e);
-  if (pl->stream) (void)hipStreamDestroy(pl->stream);
+  if (pl->own_stream) (void)hipStreamDestroy(pl->own_stream);
   delete pl;
+  return FFX_OK;
+}
+
+int ffx_plan_set_stream(ffx_plan* pl, void* stream) {
+  if (!pl) return fail(FFX_BAD_ARG, "NULL plan");
+  FFX_HIP(hipSetDevice(pl->idx->device));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  pl->stream = stream ? (hipStream_t)stream : pl->own_stream;
   return FFX_OK;
 }
 
@@ -514,6 +536,26 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
   return FFX_OK;
 }
 
+// per-query order: key descending, ties by position (the radix sort is stable)
+static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* offs_dev, int64_t n_queries, DevBuf& order,
+                                 DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st) {
+  const size_t pb = (size_t)P;
+  FFX_TRY(order.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(sorted_keys.ensure(pb * sizeof(float)));
+  ffx::iota_kernel<<<blocks_for(P, 256), 256, 0, st>>>(iota.as<int32_t>(), P);
+  FFX_HIP(hipGetLastError());
+  size_t tmp = 0;
+  FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp, keys, sorted_keys.as<float>(), iota.as<int32_t>(),
+                                                   order.as<int32_t>(), (unsigned)P, (unsigned)n_queries, offs_dev,
+                                                   offs_dev + 1, 0, 32, st));
+  FFX_TRY(sort_tmp.ensure(std::max<size_t>(tmp, 16)));
+  FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(sort_tmp.p, tmp, keys, sorted_keys.as<float>(), iota.as<int32_t>(),
+                                                   order.as<int32_t>(), (unsigned)P, (unsigned)n_queries, offs_dev,
+                                                   offs_dev + 1, 0, 32, st));
+  return FFX_OK;
+}
+
 int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (!pl) return fail(FFX_BAD_ARG, "NULL plan");
   if (!pl->have_pairs) return fail(FFX_BAD_ARG, "ffx_plan_set_pairs has not succeeded on this plan");
@@ -529,14 +571,16 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   FFX_HIP(hipEventRecord(pl->ev[0], st));
   if (P > 0) {
     // 1. candidates -> row list
+    const double qpp = (double)pl->n_queries / (double)P;
     if (single) {
+      const int32_t* row_of = pl->mode == FFX_MODE_PASSAGE ? (ix->psgs_identity ? nullptr : ix->psg_row.as<int32_t>())
+                                                           : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
       ffx::expand_single_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
-          pl->pair_ids.as<int32_t>(), P, pl->mode, pl->pair_off.as<int64_t>(), (int)pl->n_queries,
-          ix->doc_off.as<int32_t>(), ix->doc_rows.as<int32_t>(), ix->psg_row.as<int32_t>(), pl->desc.as<int2>());
+          pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of, pl->desc.as<int2>());
     } else {
       FFX_TRY(launch_count_scan(pl));
       ffx::expand_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
-          pl->pair_ids.as<int32_t>(), P, pl->mode, pl->pair_off.as<int64_t>(), (int)pl->n_queries,
+          pl->pair_ids.as<int32_t>(), P, pl->mode, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp,
           ix->doc_off.as<int32_t>(), ix->doc_rows.as<int32_t>(), ix->psg_row.as<int32_t>(),
           pl->seg_off.as<int32_t>(), pl->desc.as<int2>());
     }
@@ -565,22 +609,9 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   FFX_HIP(hipEventRecord(pl->ev[3], st));
   // 4. per-query order: score descending, ties by position (stable radix sort)
   if (do_sort && P > 0) {
-    const size_t pb = (size_t)P;
-    FFX_TRY(pl->order.ensure(pb * sizeof(int32_t)));
-    FFX_TRY(pl->iota.ensure(pb * sizeof(int32_t)));
-    FFX_TRY(pl->sorted_keys.ensure(pb * sizeof(float)));
-    ffx::iota_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->iota.as<int32_t>(), P);
-    FFX_HIP(hipGetLastError());
     const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
-    const int64_t* offs = pl->pair_off.as<int64_t>();
-    size_t tmp = 0;
-    FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp, keys, pl->sorted_keys.as<float>(),
-                                                     pl->iota.as<int32_t>(), pl->order.as<int32_t>(), (unsigned)P,
-                                                     (unsigned)pl->n_queries, offs, offs + 1, 0, 32, st));
-    FFX_TRY(pl->sort_tmp.ensure(std::max<size_t>(tmp, 16)));
-    FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(pl->sort_tmp.p, tmp, keys, pl->sorted_keys.as<float>(),
-                                                     pl->iota.as<int32_t>(), pl->order.as<int32_t>(), (unsigned)P,
-                                                     (unsigned)pl->n_queries, offs, offs + 1, 0, 32, st));
+    FFX_TRY(launch_segmented_sort(keys, P, pl->pair_off.as<int64_t>(), pl->n_queries, pl->order, pl->iota,
+                                  pl->sorted_keys, pl->sort_tmp, st));
   }
   FFX_HIP(hipEventRecord(pl->ev[4], st));
   pl->ran = true;
@@ -653,6 +684,145 @@ int ffx_plan_device_ptr(ffx_plan* pl, int which, void** ptr, int64_t* n_elems) {
 int ffx_plan_stream(ffx_plan* pl, void** stream) {
   if (!pl || !stream) return fail(FFX_BAD_ARG, "NULL argument");
   *stream = (void*)pl->stream;
+  return FFX_OK;
+}
+
+// ---- merge -----------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct ffx_merge {
+  int device = 0;
+  hipStream_t own_stream = nullptr, last_stream = nullptr;
+  DevBuf pair_off, slot, sparse, ff, interp, order, iota, sorted_keys, sort_tmp;
+  int64_t n_queries = 0, n_pairs = 0;
+  bool have_sparse = false, ready = false, ran = false, ran_sort = false;
+};
+
+extern "C" {
+
+int ffx_merge_create(int device, ffx_merge** out) {
+  if (!out) return fail(FFX_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    return fail(FFX_NO_DEVICE, "no HIP device: libffx has no CPU fallback");
+  }
+  if (device < 0 || device >= n) return fail(FFX_BAD_ARG, "device %d out of range (%d devices)", device, n);
+  FFX_HIP(hipSetDevice(device));
+  ffx_merge* m = new (std::nothrow) ffx_merge();
+  if (!m) return fail(FFX_OOM, "host allocation failed");
+  m->device = device;
+  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete m;
+    return fail(FFX_HIP_ERROR, "stream creation failed");
+  }
+  m->last_stream = m->own_stream;
+  *out = m;
+  return FFX_OK;
+}
+
+int ffx_merge_destroy(ffx_merge* m) {
+  if (!m) return FFX_OK;
+  (void)hipSetDevice(m->device);
+  if (m->last_stream) (void)hipStreamSynchronize(m->last_stream);
+  for (DevBuf* b : {&m->pair_off, &m->slot, &m->sparse, &m->ff, &m->interp, &m->order, &m->iota, &m->sorted_keys, &m->sort_tmp})
+    b->release();
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  delete m;
+  return FFX_OK;
+}
+
+int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* recv_slot, const float* sparse) {
+  if (!m || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many pairs");
+  if (P > 0 && !recv_slot) return fail(FFX_BAD_ARG, "recv_slot is NULL");
+  for (int64_t p = 0; p < P; ++p)
+    if (recv_slot[p] < 0 || recv_slot[p] >= P) return fail(FFX_BAD_ARG, "recv_slot[%lld] out of range", (long long)p);
+  FFX_HIP(hipSetDevice(m->device));
+  m->ready = m->ran = false;
+  const size_t pb = std::max<size_t>((size_t)P, 1);
+  FFX_TRY(m->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(m->slot.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(m->ff.ensure(pb * sizeof(float)));
+  FFX_HIP(hipMemcpy(m->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  if (P > 0) FFX_HIP(hipMemcpy(m->slot.p, recv_slot, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice));
+  m->have_sparse = sparse != nullptr;
+  if (sparse) {
+    FFX_TRY(m->sparse.ensure(pb * sizeof(float)));
+    FFX_TRY(m->interp.ensure(pb * sizeof(float)));
+    if (P > 0) FFX_HIP(hipMemcpy(m->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice));
+  }
+  m->n_queries = n_queries;
+  m->n_pairs = P;
+  m->ready = true;
+  return FFX_OK;
+}
+
+int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t flags, void* stream) {
+  if (!m) return fail(FFX_BAD_ARG, "NULL merge");
+  if (!m->ready) return fail(FFX_BAD_ARG, "ffx_merge_set has not succeeded on this handle");
+  if (m->n_pairs > 0 && !recv_dev) return fail(FFX_BAD_ARG, "recv_dev is NULL");
+  FFX_HIP(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->own_stream;
+  m->last_stream = st;
+  const int64_t P = m->n_pairs;
+  const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
+  if (P > 0) {
+    ffx::merge_kernel<<<blocks_for(P, 256), 256, 0, st>>>(recv_dev, m->slot.as<int32_t>(),
+                                                         m->have_sparse ? m->sparse.as<float>() : nullptr, P, (float)alpha,
+                                                         (float)(1.0 - alpha), m->ff.as<float>(), m->interp.as<float>());
+    FFX_HIP(hipGetLastError());
+    if (do_sort) {
+      const float* keys = (m->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? m->interp.as<float>() : m->ff.as<float>();
+      FFX_TRY(launch_segmented_sort(keys, P, m->pair_off.as<int64_t>(), m->n_queries, m->order, m->iota, m->sorted_keys,
+                                    m->sort_tmp, st));
+    }
+  }
+  m->ran = true;
+  m->ran_sort = do_sort;
+  return FFX_OK;
+}
+
+int ffx_merge_sync(ffx_merge* m) {
+  if (!m) return fail(FFX_BAD_ARG, "NULL merge");
+  FFX_HIP(hipSetDevice(m->device));
+  FFX_HIP(hipStreamSynchronize(m->last_stream));
+  return FFX_OK;
+}
+
+int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order) {
+  if (!m) return fail(FFX_BAD_ARG, "NULL merge");
+  if (!m->ran) return fail(FFX_BAD_ARG, "ffx_merge_run has not completed on this handle");
+  if (out_interp && !m->have_sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
+  if (out_order && !m->ran_sort) return fail(FFX_BAD_ARG, "the last run did not request FFX_FLAG_SORT");
+  FFX_HIP(hipSetDevice(m->device));
+  FFX_HIP(hipStreamSynchronize(m->last_stream));
+  const size_t P = (size_t)m->n_pairs;
+  if (P > 0) {
+    if (out_ff) FFX_HIP(hipMemcpy(out_ff, m->ff.p, P * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_interp) FFX_HIP(hipMemcpy(out_interp, m->interp.p, P * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_order) FFX_HIP(hipMemcpy(out_order, m->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return FFX_OK;
+}
+
+int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems) {
+  if (!m || !ptr) return fail(FFX_BAD_ARG, "NULL argument");
+  const DevBuf* b = nullptr;
+  switch (which) {
+    case FFX_BUF_FF: b = &m->ff; break;
+    case FFX_BUF_INTERP: b = &m->interp; break;
+    case FFX_BUF_ORDER: b = &m->order; break;
+    case FFX_BUF_SPARSE: b = &m->sparse; break;
+    default: return fail(FFX_BAD_ARG, "unknown buffer selector %d", which);
+  }
+  *ptr = b->p;
+  if (n_elems) *n_elems = b->p ? m->n_pairs : 0;
   return FFX_OK;
 }
 

@@ -1,0 +1,286 @@
+"""``Mode`` and the abstract ``Index``: the re-ranking entry point ``Index.__call__``.
+
+Mirrors ``fast_forward.index.Index`` (reference ``src/fast_forward/index/base.py:18-513``) for
+the re-ranking path: same constructor and ``__call__`` arguments, same exceptions.  Where the
+reference computes scores with NumPy inside pandas merges (``_compute_scores``,
+base.py:279-314), this class hands integer candidate lists to a device backend
+(``_score_pairs``), implemented by ``InMemoryIndex`` on the HIP kernels of libffx.
+"""
+
+from __future__ import annotations
+
+import abc
+import logging
+from collections.abc import Iterable, Iterator, Sequence
+from enum import Enum
+from time import perf_counter
+
+import numpy as np
+import pandas as pd
+
+from fast_forward_amd.encoder import Encoder
+from fast_forward_amd.ranking import Ranking
+
+LOGGER = logging.getLogger(__name__)
+
+IDSequence = Sequence["str | None"]
+
+
+class Mode(Enum):
+    """Ranking mode of an index (values as in the reference, base.py:18-24)."""
+
+    PASSAGE = 1
+    MAXP = 2
+    FIRSTP = 3
+    AVEP = 4
+
+
+def _grouped_by_query(q_no: np.ndarray, n_queries: int):
+    """CSR over pairs: a permutation that makes every query's pairs contiguous (identity when
+    they already are) and the offsets of each query."""
+    counts = np.bincount(q_no, minlength=n_queries).astype(np.int64)
+    pair_off = np.zeros(n_queries + 1, dtype=np.int64)
+    np.cumsum(counts, out=pair_off[1:])
+    if (np.diff(q_no) >= 0).all():
+        return None, pair_off
+    return np.argsort(q_no, kind="stable"), pair_off
+
+
+class Index(abc.ABC):
+    """Abstract Fast-Forward index."""
+
+    _query_encoder: Encoder | None = None
+    _quantizer = None
+
+    def __init__(self, query_encoder: Encoder | None = None, quantizer=None, mode: Mode = Mode.MAXP,
+                 encoder_batch_size: int = 32) -> None:
+        super().__init__()
+        if query_encoder is not None:
+            self.query_encoder = query_encoder
+        self.mode = mode
+        if quantizer is not None:
+            self.quantizer = quantizer
+        self._encoder_batch_size = encoder_batch_size
+
+    # ---- configuration ---------------------------------------------------------------------
+    @property
+    def query_encoder(self) -> Encoder | None:
+        return self._query_encoder
+
+    @query_encoder.setter
+    def query_encoder(self, encoder: Encoder) -> None:
+        assert isinstance(encoder, Encoder)
+        self._query_encoder = encoder
+
+    @property
+    def quantizer(self):
+        return self._quantizer
+
+    @quantizer.setter
+    def quantizer(self, quantizer) -> None:
+        if len(self) > 0:
+            raise RuntimeError("Quantizers can only be attached to empty indexes.")
+        raise NotImplementedError(
+            "quantized indexes (reference quantizer/, SURVEY.md section 8 row f2) are not part of this build yet"
+        )
+
+    @property
+    def mode(self) -> Mode:
+        return self._mode
+
+    @mode.setter
+    def mode(self, mode: Mode) -> None:
+        assert isinstance(mode, Mode)
+        self._mode = mode
+
+    def encode_queries(self, queries: Sequence[str]) -> np.ndarray:
+        """Encode query texts in batches of ``encoder_batch_size`` (base.py:58-72)."""
+        if self.query_encoder is None:
+            raise RuntimeError("Index does not have a query encoder.")
+        step = self._encoder_batch_size
+        return np.concatenate([self.query_encoder(queries[i:i + step]) for i in range(0, len(queries), step)])
+
+    # ---- storage interface (implemented by subclasses) ------------------------------------------
+    @abc.abstractmethod
+    def _get_internal_dim(self) -> int | None: ...
+
+    @abc.abstractmethod
+    def _get_doc_ids(self) -> set[str]: ...
+
+    @abc.abstractmethod
+    def _get_psg_ids(self) -> set[str]: ...
+
+    @abc.abstractmethod
+    def _get_num_vectors(self) -> int: ...
+
+    @abc.abstractmethod
+    def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None: ...
+
+    @abc.abstractmethod
+    def _get_vectors(self, ids: Iterable[str]) -> tuple[np.ndarray, list[str]]:
+        """Vectors needed to score ``ids`` in the current mode, and the id owning each vector;
+        ``IndexError`` for an unknown id (base.py:258-277)."""
+
+    @abc.abstractmethod
+    def _batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]: ...
+
+    @abc.abstractmethod
+    def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
+        """String ids -> int32 ordinals; ``IndexError`` for an unknown id."""
+
+    @abc.abstractmethod
+    def _score_pairs(self, query_vectors: np.ndarray, pair_off: np.ndarray, pair_ids: np.ndarray, mode: Mode,
+                     sparse: np.ndarray | None = None, alpha: float | None = None,
+                     sort: bool = False) -> tuple[np.ndarray, np.ndarray | None, np.ndarray | None]:
+        """Device scoring of CSR candidate lists: ``(dense, interpolated|None, order|None)``."""
+
+    @property
+    def dim(self) -> int | None:
+        return self._get_internal_dim()
+
+    @property
+    def doc_ids(self) -> set[str]:
+        return self._get_doc_ids()
+
+    @property
+    def psg_ids(self) -> set[str]:
+        return self._get_psg_ids()
+
+    def __len__(self) -> int:
+        return self._get_num_vectors()
+
+    def add(self, vectors: np.ndarray, doc_ids: IDSequence | None = None, psg_ids: IDSequence | None = None) -> None:
+        """Add vectors with their document and/or passage ids (validation of base.py:211-256).
+
+        ``ValueError``: id count mismatch, wrong dimensionality, a vector without any id.
+        ``RuntimeError``: a passage id that already exists."""
+        n, dim = vectors.shape
+        doc_ids = [None] * n if doc_ids is None else doc_ids
+        psg_ids = [None] * n if psg_ids is None else psg_ids
+        if not len(doc_ids) == len(psg_ids) == n:
+            raise ValueError("Number of IDs does not match number of vectors.")
+        if self.dim is not None and dim != self.dim:
+            raise ValueError(f"Input vector dimensionality ({dim}) does not match index dimensionality ({self.dim}).")
+        if any(d is None and p is None for d, p in zip(doc_ids, psg_ids)):
+            raise ValueError("Vector has neither document nor passage ID.")
+        self._add(vectors, doc_ids, psg_ids)
+
+    # ---- scoring -------------------------------------------------------------------------------------
+    def _numbered_queries(self, df: pd.DataFrame) -> tuple[np.ndarray, list[str], list[str]]:
+        """``q_no`` per row = order of first appearance of the query (base.py:418-421), plus the
+        query ids and texts in that order."""
+        q_no, q_ids = pd.factorize(df["q_id"])
+        first_rows = np.full(len(q_ids), -1, dtype=np.int64)
+        first_rows[q_no[::-1]] = np.arange(len(df) - 1, -1, -1)
+        texts = df["query"].to_numpy()[first_rows].tolist()
+        return q_no.astype(np.int64), list(q_ids), texts
+
+    def _compute_scores(self, data: pd.DataFrame, query_vectors: np.ndarray) -> pd.DataFrame:
+        """``data`` (columns ``id``, ``q_no``, ...) plus an ``ff_score`` column: the dense score of
+        every row in the current mode (the contract of base.py:279-314, computed on the device)."""
+        out = data.copy()
+        if len(out) == 0:
+            out["ff_score"] = np.zeros(0, dtype=np.float32)
+            return out
+        q_no = out["q_no"].to_numpy(dtype=np.int64)
+        ordinals = self._resolve_ids(out["id"].to_numpy(), self.mode)
+        perm, pair_off = _grouped_by_query(q_no, query_vectors.shape[0])
+        dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals if perm is None else ordinals[perm], self.mode)
+        if perm is not None:
+            unperm = np.empty_like(dense)
+            unperm[perm] = dense
+            dense = unperm
+        out["ff_score"] = dense
+        return out
+
+    def _early_stopping(self, df: pd.DataFrame, query_vectors: np.ndarray, cutoff: int, alpha: float,
+                        depths: Iterable[int]) -> pd.DataFrame:
+        """Score each query only as deep as needed for its top-``cutoff`` (base.py:316-387).
+
+        Depth intervals ``[a, b)`` over the sorted depths ``>= cutoff``; after the first
+        interval a query continues only while its ``cutoff``-th best interpolated score is below
+        the best it could still reach, ``alpha * s_last + (1 - alpha) * max_dense`` (``s_last``:
+        sparse score of the last scored candidate).  Unscored candidates get no score."""
+        q_no = df["q_no"].to_numpy(dtype=np.int64)
+        sparse = df["score"].to_numpy()
+        n_q = query_vectors.shape[0]
+        rank_in_q = df.groupby("q_no", sort=False).cumcount().to_numpy()
+        # dense scores are float32 (as the reference's np.sum over float32 vectors); the criterion
+        # below then follows NumPy's promotion for `python_float * np.float32` exactly as the
+        # reference's expression does (NEP 50: stays float32 on numpy >= 2, the version the golden
+        # fixtures were generated with)
+        ff = np.full(len(df), np.nan, dtype=np.float32)
+        interp = np.full(len(df), np.nan, dtype=np.result_type(sparse.dtype, np.float32))
+        active = np.ones(n_q, dtype=bool)
+        a = 0
+        for b in sorted(depths):
+            if b < cutoff:
+                continue
+            if a > 0:
+                scored = ~np.isnan(ff)
+                for q in np.flatnonzero(active):
+                    rows = np.flatnonzero(scored & (q_no == q))
+                    if rows.size == 0:
+                        active[q] = False
+                        continue
+                    ints = np.sort(interp[rows])[::-1]
+                    kth = ints[min(cutoff, ints.size) - 1]
+                    bound = alpha * sparse[rows[-1]] + (1 - alpha) * np.max(ff[rows])
+                    active[q] = bool(kth < bound)
+            LOGGER.info("depth %s: %s queries left", b, int(active.sum()))
+            take = np.flatnonzero(active[q_no] & (rank_in_q >= a) & (rank_in_q < b))
+            if take.size == 0:
+                break
+            chunk_ff = self._compute_scores(df.iloc[take][["id", "q_no"]], query_vectors)["ff_score"].to_numpy(dtype=np.float32)
+            ff[take] = chunk_ff
+            interp[take] = alpha * sparse[take] + (1 - alpha) * chunk_ff
+            a = b
+        out = df.copy()
+        out["ff_score"] = ff
+        return out
+
+    def __call__(self, ranking: Ranking, early_stopping: int | None = None, early_stopping_alpha: float | None = None,
+                 early_stopping_depths: Iterable[int] | None = None, batch_size: int | None = None) -> Ranking:
+        """Dense scores for every (query, candidate) of ``ranking`` (base.py:389-469).
+
+        ``ValueError``: ranking without queries; early stopping without alpha/depths.
+        ``IndexError``: a candidate id that is not in the index (raised before any device work).
+        """
+        if not ranking.has_queries:
+            raise ValueError("Input ranking has no queries attached.")
+        if early_stopping is not None and (early_stopping_alpha is None or early_stopping_depths is None):
+            raise ValueError("Early stopping requires alpha and depths.")
+        t0 = perf_counter()
+
+        df = ranking._df
+        q_no, _, texts = self._numbered_queries(df)
+        work = df.assign(q_no=q_no)
+        query_vectors = np.ascontiguousarray(self.encode_queries(texts))
+        n_q = len(texts)
+        # fail on unknown ids up front, for the whole ranking (the reference raises from its
+        # first batch; either way no partial result is returned)
+        self._resolve_ids(df["id"].to_numpy(), self.mode)
+
+        def score(part: pd.DataFrame) -> pd.DataFrame:
+            if early_stopping is None:
+                return self._compute_scores(part, query_vectors)
+            return self._early_stopping(part, query_vectors, early_stopping, early_stopping_alpha, early_stopping_depths)
+
+        if batch_size is None or batch_size >= n_q:
+            result = score(work)
+        else:
+            # bound device workspace: `batch_size` queries per launch; an empty batch is a no-op
+            batch_of = work["q_no"].to_numpy() // batch_size
+            result = pd.concat([score(work[batch_of == b]) for b in range((n_q + batch_size - 1) // batch_size)])
+        result["score"] = result["ff_score"]
+        LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+        return Ranking(result, name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
+
+    # ---- iteration ----------------------------------------------------------------------------------------
+    def batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:
+        """Vectors, document ids and passage ids in insertion order, ``batch_size`` at a time."""
+        yield from self._batch_iter(batch_size)
+
+    def __iter__(self) -> Iterator[tuple[np.ndarray, "str | None", "str | None"]]:
+        for vectors, doc_ids, psg_ids in self.batch_iter(2**9):
+            yield from zip(vectors, doc_ids, psg_ids)

@@ -1,0 +1,186 @@
+"""``InMemoryIndex``: the Fast-Forward index held in HBM, scored by the HIP kernels of libffx.
+
+Drop-in for ``fast_forward.index.InMemoryIndex`` (reference ``src/fast_forward/index/memory.py:20-180``)
+on the re-ranking path.  "Memory" here is the device's: vectors live in one contiguous fp32
+matrix in HBM (288 GB per MI355X; 3 KB per 768-d row => ~93 M rows per GPU), ids live on the
+host as ordinal tables, and ``Index.__call__`` runs
+
+    ids -> ordinals (host)  ->  expand / gather_dot / segment-reduce / interpolate (device)
+
+Differences from the reference, all deliberate:
+  * storage is fp32.  The reference silently switches to float64 for every chunk after the
+    first (memory.py:106) and so returns float64-accumulated scores on large indexes; here
+    scores always follow the fp32 semantics of a single-chunk reference index.
+  * the vector store grows geometrically instead of by a list of chunks; ``init_size`` /
+    ``alloc_size`` keep their meaning as the initial capacity and the minimum growth step.
+  * no CPU fallback: without libffx.so or a HIP device, construction fails.
+"""
+
+from __future__ import annotations
+
+import logging
+from collections.abc import Iterable, Iterator
+
+import numpy as np
+
+from fast_forward_amd import native
+from fast_forward_amd.encoder import Encoder
+from fast_forward_amd.index.api import IDSequence, Index, Mode
+from fast_forward_amd.index.ids import IdTable
+
+LOGGER = logging.getLogger(__name__)
+
+
+class InMemoryIndex(Index):
+    """Fast-Forward index resident in HBM."""
+
+    def __init__(self, query_encoder: Encoder | None = None, quantizer=None, mode: Mode = Mode.MAXP,
+                 encoder_batch_size: int = 32, init_size: int = 2**16, alloc_size: int = 2**16,
+                 device: int = 0, exact_sum: bool = True) -> None:
+        """
+        :param init_size: initial capacity in vectors (allocated on the first ``add``).
+        :param alloc_size: minimum growth step in vectors.
+        :param device: HIP device ordinal holding the index.
+        :param exact_sum: ``True`` (default): scores are bit-identical to the reference's
+            ``np.sum(q * d, axis=1)``, so run orderings are identical too.  ``False``: FMA
+            summation, within 1e-4 of the reference on unit-scale vectors.
+        """
+        native.lib()  # fail now, loudly, if the native library is missing
+        self._ids = IdTable()
+        self._store: native.DeviceIndex | None = None
+        self._plan: native.Plan | None = None
+        self._n = 0
+        self._init_size, self._alloc_size = int(init_size), int(alloc_size)
+        self._device = int(device)
+        self._ids_on_device = -1
+        self.exact_sum = bool(exact_sum)
+        self.last_stats: dict | None = None
+        super().__init__(query_encoder=query_encoder, quantizer=quantizer, mode=mode, encoder_batch_size=encoder_batch_size)
+
+    # ---- storage --------------------------------------------------------------------------------
+    def _get_num_vectors(self) -> int:
+        return self._n
+
+    def _get_internal_dim(self) -> int | None:
+        return None if self._store is None else self._store.dim
+
+    def _get_doc_ids(self) -> set[str]:
+        return self._ids.doc_ids
+
+    def _get_psg_ids(self) -> set[str]:
+        return self._ids.psg_ids
+
+    def _reserve(self, n_total: int, dim: int) -> None:
+        if self._store is not None and n_total <= self._store.capacity:
+            return
+        if self._store is None:
+            cap = max(self._init_size, n_total)
+        else:
+            cap = max(n_total, self._store.capacity + self._alloc_size, int(self._store.capacity * 1.5))
+        LOGGER.debug("growing the device vector store to %s rows", cap)
+        grown = native.DeviceIndex(cap, dim, self._device)
+        if self._store is not None:
+            grown.copy_rows_from(self._store, self._n)
+            if self._plan is not None:
+                self._plan.close()
+                self._plan = None
+            self._store.close()
+        self._store = grown
+        self._ids_on_device = -1
+
+    def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
+        n_new, dim = vectors.shape
+        self._reserve(self._n + n_new, dim)
+        self._ids.add(doc_ids, psg_ids, self._n)  # a duplicate passage id raises before anything is modified
+        self._store.upload(np.ascontiguousarray(vectors, dtype=np.float32), self._n)
+        self._n += n_new
+
+    def consolidate(self) -> None:
+        """Kept for API compatibility: the device store is always one contiguous matrix."""
+
+    def _sync_ids(self) -> None:
+        if self._store is not None and self._ids_on_device != self._ids.version:
+            doc_off, doc_rows = self._ids.doc_csr()
+            self._store.set_doc_rows(doc_off, doc_rows)
+            self._store.set_psg_rows(self._ids.psg_rows())
+            self._ids_on_device = self._ids.version
+
+    def _get_vectors(self, ids: Iterable[str]) -> tuple[np.ndarray, list[str]]:
+        rows, owners = self._ids.rows_for(ids, self.mode.value)
+        if not rows:
+            return np.array([]), []
+        return self._store.gather(np.asarray(rows, dtype=np.int32)), owners
+
+    def _batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:
+        docs, psgs = self._ids.row_ids(self._n)
+        for lo in range(0, self._n, batch_size):
+            hi = min(lo + batch_size, self._n)
+            yield self._store.gather(np.arange(lo, hi, dtype=np.int32)), docs[lo:hi], psgs[lo:hi]
+
+    # ---- scoring ----------------------------------------------------------------------------------
+    def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
+        return self._ids.resolve(ids, mode.value)
+
+    def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False):
+        if self._store is None:
+            raise IndexError("the index is empty")
+        q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self._store.dim:
+            raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.dim}).")
+        self._sync_ids()
+        if self._plan is None:
+            self._plan = native.Plan(self._store)
+        plan = self._plan
+        plan.set_queries(q)
+        plan.set_pairs(pair_off, pair_ids, sparse, mode.value)
+        plan.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
+        ff, interp, order = plan.fetch(ff=True, interp=sparse is not None, order=sort)
+        self.last_stats = plan.stats()
+        return ff, interp, order
+
+    def rerank(self, ranking, alpha: float, cutoff: int | None = None):
+        """Fused device path for the usual pipeline ``first.interpolate(index(first), alpha)``:
+        dense scores, the alpha-interpolation (ranking.py:319) and the per-query ordering
+        (ranking.py:115-117) all happen on the device; returns the interpolated ``Ranking``
+        (optionally cut to the best ``cutoff`` per query).  Same scores, bit for bit."""
+        import pandas as pd
+
+        from fast_forward_amd.index.api import _grouped_by_query
+        from fast_forward_amd.ranking import Ranking
+
+        if not ranking.has_queries:
+            raise ValueError("Input ranking has no queries attached.")
+        df = ranking._df
+        q_no, _, texts = self._numbered_queries(df)
+        query_vectors = np.ascontiguousarray(self.encode_queries(texts))
+        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
+        perm, pair_off = _grouped_by_query(q_no, len(texts))
+        sparse = df["score"].to_numpy(dtype=np.float32)
+        if perm is not None:
+            ordinals, sparse = ordinals[perm], sparse[perm]
+        _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+        src = order if perm is None else perm[order]
+        if cutoff is not None:
+            rank = np.arange(len(src)) - np.repeat(pair_off[:-1], np.diff(pair_off))
+            keep = rank < cutoff
+            src, order = src[keep], order[keep]
+        out = df.iloc[src].reset_index(drop=True)
+        out["score"] = interp[order].astype(df.dtypes["score"])
+        # queries in the order the reference would list them: q_id descending
+        return Ranking(out, name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
+
+    def close(self) -> None:
+        """Release device memory now (otherwise released when the object is collected)."""
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+        if self._store is not None:
+            self._store.close()
+            self._store = None
+        self._n = 0
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -25,7 +25,9 @@ SYMBOLS = (
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
     "ffx_plan_run", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
-    "ffx_plan_stream", "ffx_score",
+    "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
+    "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
+    "ffx_merge_fetch", "ffx_merge_device_ptr",
 )
 
 
@@ -99,6 +101,14 @@ def lib() -> C.CDLL:
         "ffx_plan_stats": ([vp, P(Stats)], C.c_int),
         "ffx_plan_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
         "ffx_plan_stream": ([vp, P(vp)], C.c_int),
+        "ffx_plan_set_stream": ([vp, vp], C.c_int),
+        "ffx_merge_create": ([C.c_int, P(vp)], C.c_int),
+        "ffx_merge_destroy": ([vp], C.c_int),
+        "ffx_merge_set": ([vp, vp, i64, vp, vp], C.c_int),
+        "ffx_merge_run": ([vp, vp, C.c_double, C.c_uint32, vp], C.c_int),
+        "ffx_merge_sync": ([vp], C.c_int),
+        "ffx_merge_fetch": ([vp, vp, vp, vp], C.c_int),
+        "ffx_merge_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
@@ -263,6 +273,56 @@ class Plan:
         s = C.c_void_p()
         _check(lib().ffx_plan_stream(self._h, C.byref(s)))
         return s.value or 0
+
+    def set_stream(self, stream: int | None) -> None:
+        """Issue the plan's work on a caller-owned hipStream_t (``None``: the plan's own)."""
+        _check(lib().ffx_plan_set_stream(self._h, C.c_void_p(stream or 0)))
+
+
+class Merge:
+    """Owns one ``ffx_merge``: owner-side scatter + interpolation + ordering of scores that
+    arrived from the ranks of a row-sharded index."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().ffx_merge_create(device, C.byref(h)))
+        self._h = h
+        self.n_pairs = 0
+        self.has_sparse = False
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_merge_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set(self, pair_off, recv_slot, sparse=None) -> None:
+        pair_off, recv_slot = _arr(pair_off, np.int64), _arr(recv_slot, np.int32)
+        sp = None if sparse is None else _arr(sparse, np.float32)
+        _check(lib().ffx_merge_set(self._h, _ptr(pair_off), pair_off.shape[0] - 1, _ptr(recv_slot), _ptr(sp)))
+        self.n_pairs = int(pair_off[-1])
+        self.has_sparse = sp is not None
+
+    def run(self, recv_dev_ptr: int, alpha: float, sort: bool = False, stream: int | None = None) -> None:
+        flags = FLAG_SORT if sort else 0
+        _check(lib().ffx_merge_run(self._h, C.c_void_p(recv_dev_ptr), float(alpha), flags, C.c_void_p(stream or 0)))
+
+    def sync(self) -> None:
+        _check(lib().ffx_merge_sync(self._h))
+
+    def fetch(self, ff: bool = True, interp: bool = False, order: bool = False):
+        n = self.n_pairs
+        a = np.empty(n, dtype=np.float32) if ff else None
+        b = np.empty(n, dtype=np.float32) if interp else None
+        c = np.empty(n, dtype=np.int32) if order else None
+        _check(lib().ffx_merge_fetch(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        return a, b, c
+
+    def device_array(self, which: int) -> _DevArray:
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        _check(lib().ffx_merge_device_ptr(self._h, which, C.byref(ptr), C.byref(n)))
+        return _DevArray(ptr.value or 0, n.value, "<i4" if which == BUF_ORDER else "<f4", self)
 
 
 def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0,

@@ -135,6 +135,30 @@ int ffx_plan_device_ptr(ffx_plan* plan, int which, void** ptr, int64_t* n_elems)
 /* the plan's HIP stream (hipStream_t) so callers can order their own work after run */
 int ffx_plan_stream(ffx_plan* plan, void** stream);
 
+/* run the plan on a caller-owned HIP stream (hipStream_t; e.g. the stream a collective library
+ * orders its work on) instead of the plan's own; NULL restores the plan's own stream */
+int ffx_plan_set_stream(ffx_plan* plan, void* stream);
+
+/* ---- merge: the owner-side half of a row-sharded index --------------------------------------
+ * With the index row-sharded by document over several GPUs (one process each), every rank scores
+ * the candidates whose documents it holds, and the dense scores of one query arrive at the
+ * query's owner rank from all ranks (an all-to-all done above this ABI, RCCL via
+ * torch.distributed).  The owner then scatters them back into first-stage order, interpolates
+ * (ranking.py:319) and orders (ranking.py:115-117) -- the same arithmetic as ffx_plan_run's
+ * epilogue, on a caller-provided device buffer. */
+typedef struct ffx_merge ffx_merge;
+int ffx_merge_create(int device, ffx_merge** out);
+int ffx_merge_destroy(ffx_merge* m);
+/* pair_off: CSR of the owned queries' candidates in first-stage order; recv_slot[p]: where the
+ * dense score of candidate p sits in the received buffer; sparse may be NULL */
+int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* recv_slot,
+                  const float* sparse);
+/* recv_dev: DEVICE pointer to n_pairs floats.  stream: hipStream_t to run on (NULL: own stream) */
+int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t flags, void* stream);
+int ffx_merge_sync(ffx_merge* m);
+int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order);
+int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems);
+
 /* one-shot: set_queries + set_pairs + run + sync + fetch (host buffers in, host buffers out) */
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               const int64_t* pair_off, const int32_t* pair_ids, const float* sparse, int mode,

@@ -56,6 +56,16 @@ void ffo_synth_rows(uint64_t seed, float scale, int64_t first_row, int64_t n_row
       out[r * dim + c] = ffo_synth_value((uint64_t)((first_row + r) * dim + c), seed, scale);
 }
 
+/* the same generator for an arbitrary list of global rows (bench: rebuild on the host only the
+ * rows a CPU-baseline sample touches) */
+void ffo_synth_row_list(uint64_t seed, float scale, const int64_t* rows, int64_t n_rows, int64_t dim,
+                        float* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n_rows; ++r)
+    for (int64_t c = 0; c < dim; ++c)
+      out[r * dim + c] = ffo_synth_value((uint64_t)(rows[r] * dim + c), seed, scale);
+}
+
 /* ---- row score ------------------------------------------------------------
  * src/fast_forward/index/base.py:303   ff_score = np.sum(q_reps * d_reps, axis=1)
  * fp32 x fp32: every product is rounded to fp32 on its own (no FMA), then the

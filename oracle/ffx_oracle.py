@@ -46,6 +46,8 @@ def lib() -> C.CDLL:
         f32p, i32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         L.ffo_synth_rows.argtypes = [C.c_uint64, C.c_float, C.c_int64, C.c_int64, C.c_int64, f32p]
         L.ffo_synth_rows.restype = None
+        L.ffo_synth_row_list.argtypes = [C.c_uint64, C.c_float, i64p, C.c_int64, C.c_int64, f32p]
+        L.ffo_synth_row_list.restype = None
         L.ffo_dot_f32.argtypes = [f32p, f32p, C.c_int64]
         L.ffo_dot_f32.restype = C.c_float
         L.ffo_row_scores.argtypes = [f32p, f32p, C.c_int64, i32p, i32p, C.c_int64, f32p]
@@ -76,6 +78,13 @@ def _f32(a) -> np.ndarray:
 def synth_rows(seed: int, scale: float, first_row: int, n_rows: int, dim: int) -> np.ndarray:
     out = np.empty((n_rows, dim), dtype=np.float32)
     lib().ffo_synth_rows(seed, scale, first_row, n_rows, dim, _p(out, C.c_float))
+    return out
+
+
+def synth_row_list(seed: int, scale: float, rows, dim: int) -> np.ndarray:
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    out = np.empty((rows.shape[0], dim), dtype=np.float32)
+    lib().ffo_synth_row_list(seed, scale, _p(rows, C.c_int64), rows.shape[0], dim, _p(out, C.c_float))
     return out
 
 

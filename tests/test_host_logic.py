@@ -1,0 +1,124 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol of
+include/ffx.h, id tables, CSR grouping, argument checks that must fire before device work."""
+
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from fast_forward_amd import Ranking, native
+from fast_forward_amd.index import InMemoryIndex, Mode
+from fast_forward_amd.index.api import _grouped_by_query
+from fast_forward_amd.index.ids import AVEP, FIRSTP, MAXP, PASSAGE, IdTable
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "ffx.h").read_text()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ffx_\w+)\s*\(", header, flags=re.M))
+    assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
+    lib = native.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ffx_abi_version() == 1
+
+
+def test_no_cpu_fallback(have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    assert native.device_count() == 0
+    with pytest.raises(native.FFXError) as e:
+        native.DeviceIndex(8, 4)
+    assert e.value.code == native.NO_DEVICE
+    with pytest.raises(RuntimeError):
+        native.require_device()
+    idx = InMemoryIndex()
+    with pytest.raises(native.FFXError):
+        idx.add(np.zeros((2, 4), dtype=np.float32), doc_ids=["a", "b"])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = ROOT / "fast-forward-indexes_amd"
+    for f in pkg.rglob("*"):
+        if f.suffix in (".py", ".hip", ".h"):
+            text = f.read_text()
+            assert "libffx_oracle" not in text, f  # never loads the oracle library
+            assert not re.search(r"^\s*(import|from)\s+\S*oracle", text, flags=re.M), f  # never imports it
+            assert not re.search(r"#include\s+\"[^\"]*oracle", text), f
+
+
+def _table():
+    t = IdTable()
+    # rows:      0     1     2     3     4
+    t.add(["d0", "d0", "d1", None, "d2"], ["p0", "p1", None, "p3", "p4"], 0)
+    t.add(["d1", "d0"], [None, "p6"], 5)  # d1 and d0 re-opened: rows not contiguous
+    return t
+
+
+def test_id_table_csr_and_resolution():
+    t = _table()
+    assert t.doc_ids == {"d0", "d1", "d2"} and t.psg_ids == {"p0", "p1", "p3", "p4", "p6"}
+    off, rows = t.doc_csr()
+    assert off.tolist() == [0, 3, 5, 6] and rows.tolist() == [0, 1, 6, 2, 5, 4]
+    assert t.psg_rows().tolist() == [0, 1, 3, 4, 6]
+    assert t.resolve(np.array(["d2", "d0", "d2", "d1"]), MAXP).tolist() == [2, 0, 2, 1]
+    assert t.resolve(["p6", "p0"], PASSAGE).tolist() == [4, 0]
+    with pytest.raises(IndexError, match="ID dx not found in the index."):
+        t.resolve(["d0", "dx", "dy"], FIRSTP)
+    with pytest.raises(IndexError):
+        t.resolve(["d0"], PASSAGE)  # a doc id is not a passage id
+    docs, psgs = t.row_ids(7)
+    assert docs == ["d0", "d0", "d1", None, "d2", "d1", "d0"]
+    assert psgs == ["p0", "p1", None, "p3", "p4", None, "p6"]
+
+
+def test_id_table_rows_for_follows_get_indices():
+    t = _table()
+    assert t.rows_for(["d0", "d1"], MAXP) == ([0, 1, 6, 2, 5], ["d0", "d0", "d0", "d1", "d1"])
+    assert t.rows_for(["d0", "d1"], AVEP)[0] == [0, 1, 6, 2, 5]
+    assert t.rows_for(["d1", "d0"], FIRSTP) == ([2, 0], ["d1", "d0"])
+    assert t.rows_for(["p3"], PASSAGE) == ([3], ["p3"])
+    with pytest.raises(IndexError):
+        t.rows_for(["p3"], MAXP)
+
+
+def test_duplicate_passage_id_leaves_table_untouched():
+    t = _table()
+    v = t.version
+    with pytest.raises(RuntimeError, match="Passage ID p1 already exists."):
+        t.add(["d9", "d9"], ["p9", "p1"], 7)
+    with pytest.raises(RuntimeError):
+        t.add([None, None], ["p8", "p8"], 7)
+    assert t.version == v and "d9" not in t.doc_ids and "p9" not in t.psg_ids
+
+
+def test_grouping_pairs_by_query():
+    perm, off = _grouped_by_query(np.array([0, 0, 1, 1, 1, 3]), 4)
+    assert perm is None and off.tolist() == [0, 2, 5, 5, 6]
+    perm, off = _grouped_by_query(np.array([2, 0, 2, 1, 0]), 3)
+    assert off.tolist() == [0, 2, 3, 5] and perm.tolist() == [1, 4, 3, 0, 2]
+
+
+def test_argument_checks_fire_before_device_work():
+    idx = InMemoryIndex()
+    no_queries = Ranking.from_run({"q1": {"d0": 1.0}})
+    with pytest.raises(ValueError, match="no queries"):
+        idx(no_queries)
+    with_q = Ranking.from_run({"q1": {"d0": 1.0}}, queries={"q1": "x"})
+    with pytest.raises(ValueError, match="Early stopping"):
+        idx(with_q, early_stopping=10, early_stopping_alpha=None, early_stopping_depths=(10,))
+    with pytest.raises(ValueError, match="Early stopping"):
+        idx(with_q, early_stopping=10, early_stopping_alpha=0.5)
+    with pytest.raises(RuntimeError, match="query encoder"):
+        idx.encode_queries(["x"])
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((2, 3)), doc_ids=None, psg_ids=None)
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((3, 3)), doc_ids=["a"], psg_ids=None)
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((2, 3)), doc_ids=[None, "a"], psg_ids=[None, "p"])
+    assert len(idx) == 0 and idx.dim is None and idx.mode == Mode.MAXP
+    idx.mode = Mode.FIRSTP
+    assert idx.mode == Mode.FIRSTP
