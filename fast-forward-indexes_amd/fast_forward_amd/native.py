@@ -61,13 +61,22 @@ class NotFound(FFXError):
 
 
 _lib = None
+TORCH_LOADED_FIRST = False
 
 
 def lib() -> C.CDLL:
-    """Load libffx.so (once).  Raises if it has not been built: there is nothing to fall back to."""
-    global _lib
+    """Load libffx.so (once).  Raises if it has not been built: there is nothing to fall back to.
+
+    One process can hold only one HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own
+    ``libamdhip64.so.7`` (same soname as /opt/rocm's), so whichever of torch and libffx is loaded
+    first decides which runtime both use.  The single-GPU path never imports torch; the
+    multi-GPU path (``fast_forward_amd.sharded``) imports torch BEFORE the first call in here."""
+    global _lib, TORCH_LOADED_FIRST
     if _lib is not None:
         return _lib
+    import sys
+
+    TORCH_LOADED_FIRST = "torch" in sys.modules
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,161 @@
+"""Row-sharded index over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference is single-process and has no counterpart; this is the multi-GPU form of the same
+path.  The embedding matrix is sharded by *document* (a document's
+passages never straddle ranks, so MaxP/FirstP/AveP stay rank-local), query vectors are
+replicated, and every rank scores the candidates whose documents it holds.  The one exchange
+step is an all-to-all of dense scores: query ``q`` is *owned* by one rank, which receives q's
+scores from every rank, puts them back in first-stage order, interpolates and orders them
+(``ffx_merge_*``).  Per step each rank sends/receives ~P/world * 4 bytes, spread over all
+peers at once -- with 7 point-to-point xGMI links per GPU a full-mesh all-to-all uses every
+link, where a ring all-gather of all scores would be bound by one.
+
+Routing (which rank scores which candidate, where each score lands at the owner) is computed on
+the host once per run by every rank from the same CSR; it is pure NumPy and is covered by the
+world_size-2 gloo tests, which drive exactly these functions with CPU tensors.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+# ---- partitioning ------------------------------------------------------------------------------
+def doc_partition(doc_off: np.ndarray, world: int) -> np.ndarray:
+    """Document boundaries ``b[0..world]`` of contiguous shards with ~equal row counts; shard r
+    holds documents ``b[r]..b[r+1]`` = rows ``doc_off[b[r]]..doc_off[b[r+1]]``."""
+    doc_off = np.asarray(doc_off, dtype=np.int64)
+    n_docs, n_rows = doc_off.shape[0] - 1, int(doc_off[-1])
+    targets = (np.arange(world + 1, dtype=np.int64) * n_rows) // world
+    bounds = np.searchsorted(doc_off, targets, side="left").astype(np.int64)
+    bounds[0], bounds[-1] = 0, n_docs
+    return np.maximum.accumulate(bounds)
+
+
+def query_partition(n_queries: int, world: int) -> np.ndarray:
+    """Owner rank r finalises queries ``b[r]..b[r+1]`` (contiguous blocks of ~equal size)."""
+    return (np.arange(world + 1, dtype=np.int64) * n_queries) // world
+
+
+@dataclass
+class Route:
+    """Everything rank ``rank`` needs for one run (all host arrays)."""
+
+    rank: int
+    world: int
+    # scoring side: the candidates whose documents this rank holds, as a local CSR over ALL queries
+    local_pair_off: np.ndarray  # int64[Q+1]
+    local_pair_ids: np.ndarray  # int32[P_r]  ordinals relative to the shard
+    send_counts: np.ndarray     # int64[world]: local scores going to each owner (contiguous slices)
+    # owner side: the queries this rank finalises
+    q_lo: int
+    q_hi: int
+    own_pair_off: np.ndarray    # int64[Qo+1]: their candidates in first-stage order
+    recv_counts: np.ndarray     # int64[world]: scores arriving from each rank
+    recv_slot: np.ndarray       # int32[P_o]: position of candidate p in the received buffer
+    own_sparse: np.ndarray | None
+    own_first_pair: int         # global position of the first owned pair
+
+
+def route(pair_off, pair_ids, doc_bounds, rank: int, world: int, sparse=None) -> Route:
+    pair_off = np.asarray(pair_off, dtype=np.int64)
+    pair_ids = np.asarray(pair_ids, dtype=np.int64)
+    doc_bounds = np.asarray(doc_bounds, dtype=np.int64)
+    n_q = pair_off.shape[0] - 1
+    holder = (np.searchsorted(doc_bounds, pair_ids, side="right") - 1).astype(np.int32)
+    if pair_ids.size and (pair_ids.min() < 0 or pair_ids.max() >= doc_bounds[-1]):
+        bad = int(np.flatnonzero((pair_ids < 0) | (pair_ids >= doc_bounds[-1]))[0])
+        raise IndexError(f"pair {bad} names document ordinal {int(pair_ids[bad])}, outside the sharded index")
+    pair_q = np.repeat(np.arange(n_q, dtype=np.int64), np.diff(pair_off))
+    mine = holder == rank
+    local_ids = (pair_ids[mine] - doc_bounds[rank]).astype(np.int32)
+    local_off = np.zeros(n_q + 1, dtype=np.int64)
+    np.cumsum(np.bincount(pair_q[mine], minlength=n_q), out=local_off[1:])
+    q_bounds = query_partition(n_q, world)
+    send_counts = np.diff(local_off[q_bounds])
+    q_lo, q_hi = int(q_bounds[rank]), int(q_bounds[rank + 1])
+    lo, hi = int(pair_off[q_lo]), int(pair_off[q_hi])
+    own_holder = holder[lo:hi]
+    recv_counts = np.bincount(own_holder, minlength=world).astype(np.int64)
+    arrival = np.argsort(own_holder, kind="stable")  # arrival order: by source rank, then first-stage order
+    recv_slot = np.empty(hi - lo, dtype=np.int32)
+    recv_slot[arrival] = np.arange(hi - lo, dtype=np.int32)
+    return Route(
+        rank=rank, world=world, local_pair_off=local_off, local_pair_ids=local_ids, send_counts=send_counts,
+        q_lo=q_lo, q_hi=q_hi, own_pair_off=pair_off[q_lo:q_hi + 1] - lo, recv_counts=recv_counts, recv_slot=recv_slot,
+        own_sparse=None if sparse is None else np.ascontiguousarray(sparse[lo:hi], dtype=np.float32), own_first_pair=lo,
+    )
+
+
+def exchange(send, send_counts, recv_counts, group=None):
+    """All-to-all of dense scores (torch tensors, CPU/gloo or GPU/RCCL): slice j of ``send`` goes
+    to rank j; returns the concatenation of what every rank sent here, in rank order."""
+    import torch
+    import torch.distributed as dist
+
+    recv = torch.empty(int(np.sum(recv_counts)), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
+    return recv
+
+
+class ShardedScorer:
+    """One rank of a row-sharded index: local ``gather_dot`` + RCCL all-to-all + owner merge."""
+
+    def __init__(self, shard, doc_bounds, rank: int, world: int, device: int, group=None):
+        import torch  # before the first libffx call: see native.lib() on the one-runtime-per-process rule
+
+        from fast_forward_amd import native
+
+        native.lib()
+        if not native.TORCH_LOADED_FIRST:
+            raise RuntimeError("libffx was loaded before torch in this process; import torch first "
+                               "(two HIP runtimes cannot share a process)")
+        self._torch = torch
+        self._native = native
+        self.shard, self.doc_bounds, self.rank, self.world, self.device, self.group = shard, doc_bounds, rank, world, device, group
+        self.plan = native.Plan(shard)
+        self.merge = native.Merge(device)
+        self.route: Route | None = None
+        # one explicit (non-null) stream orders the kernels, the collective and the merge; the
+        # C ABI reads a NULL stream as "use your own", so torch's default stream (handle 0) is
+        # never used here
+        self._tstream = torch.cuda.Stream(device)
+        self._stream = self._tstream.cuda_stream
+        assert self._stream != 0
+        self.plan.set_stream(self._stream)
+
+    def set_queries(self, queries: np.ndarray) -> None:
+        self.plan.set_queries(queries)  # replicated: Q*d*4 bytes (21 MB at Q=6980, d=768)
+
+    def set_pairs(self, pair_off, pair_ids, sparse, mode: int) -> None:
+        torch, native = self._torch, self._native
+        r = route(pair_off, pair_ids, self.doc_bounds, self.rank, self.world, sparse)
+        self.plan.set_pairs(r.local_pair_off, r.local_pair_ids, None, mode)
+        self.merge.set(r.own_pair_off, r.recv_slot, r.own_sparse)
+        with torch.cuda.stream(self._tstream):
+            self._send = torch.as_tensor(self.plan.device_array(native.BUF_FF), device=f"cuda:{self.device}")
+            self._recv = torch.empty(int(r.recv_counts.sum()), dtype=torch.float32, device=f"cuda:{self.device}")
+        self._in_split = [int(c) for c in r.send_counts]
+        self._out_split = [int(c) for c in r.recv_counts]
+        self.route = r
+
+    def run(self, alpha: float, exact_sum: bool = True, sort: bool = False) -> None:
+        import torch.distributed as dist
+
+        with self._torch.cuda.stream(self._tstream):
+            self.plan.run(0.0, exact_sum=exact_sum)
+            dist.all_to_all_single(self._recv, self._send, self._out_split, self._in_split, group=self.group)
+            self.merge.run(self._recv.data_ptr(), alpha, sort=sort, stream=self._stream)
+
+    def sync(self) -> None:
+        self._torch.cuda.synchronize(self.device)
+
+    def fetch(self, order: bool = False):
+        """(dense, interpolated|None, order|None) of the owned queries, first-stage order."""
+        return self.merge.fetch(ff=True, interp=self.merge.has_sparse, order=order)
+
+    def close(self) -> None:
+        self.plan.close()
+        self.merge.close()

@@ -1,0 +1,46 @@
+"""Single-rank RCCL rehearsal of fast_forward_amd.sharded.ShardedScorer on one GPU
+(launched by tests/test_gpu_parity.py in a fresh interpreter)."""
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch  # first: the process then uses torch's HIP runtime for libffx too
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
+    sys.path.insert(0, str(p))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import ffx_oracle as fo  # noqa: E402
+from _cases import MODE_NO, bits, load_scoring_case  # noqa: E402
+from fast_forward_amd import native  # noqa: E402
+from fast_forward_amd.sharded import ShardedScorer, doc_partition  # noqa: E402
+
+case = load_scoring_case("s2_sub")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+idx = native.DeviceIndex(case.vectors.shape[0], case.vectors.shape[1])
+idx.upload(case.vectors, 0)
+idx.set_doc_rows(case.doc_off, case.doc_rows)
+idx.set_psg_rows(case.psg_row)
+scorer = ShardedScorer(idx, doc_partition(case.doc_off, 1), 0, 1, 0)
+scorer.set_queries(case.queries)
+pair_off, pair_ids, sparse, _ = case.pairs("MAXP")
+scorer.set_pairs(pair_off, pair_ids, sparse, MODE_NO["MAXP"])
+for alpha in (0.1, 0.5):
+    scorer.run(alpha, exact_sum=True, sort=True)
+    scorer.sync()
+    ff, interp, order = scorer.fetch(order=True)
+    want, want_i = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids,
+                            MODE_NO["MAXP"], sparse, alpha)
+    assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i))
+    assert np.array_equal(order.astype(np.int64), fo.order(want_i, pair_off))
+scorer.close()
+idx.close()
+dist.destroy_process_group()
+print("sharded 1-rank ok")

@@ -240,3 +240,19 @@ def test_full_size_properties():
     want = fo.row_scores(queries, rows, (sel // k).astype(np.int32), np.arange(sel.shape[0], dtype=np.int32))
     assert np.array_equal(bits(a[sel]), bits(want))
     idx.close()
+
+
+
+def test_sharded_scorer_single_rank_nccl():
+    """The multi-GPU code path end to end on one GPU: a 1-rank RCCL group, the plan on torch's
+    stream, the all-to-all on plan-owned memory (zero-copy), the owner-side merge kernel.
+    Runs in its own interpreter because torch must be imported before libffx is loaded
+    (fast_forward_amd.native.lib)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    worker = Path(__file__).resolve().parent / "_nccl1_worker.py"
+    out = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "sharded 1-rank ok" in out.stdout
