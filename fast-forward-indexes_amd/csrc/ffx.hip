@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls memset unqualified
 
 #include <rocprim/device/device_scan.hpp>
@@ -498,10 +499,61 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
     ffx::gather_dot_exact_kernel<LEAVES, NPER, U><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R); \
     pl->variant = ID;                                                                             \
   } while (0)
+  // tuning hook (tools/kernel_ab.py): FFX_GATHER_VARIANT selects an experimental d=768 instantiation
+  const char* exp_env = getenv("FFX_GATHER_VARIANT");
+  const int exp_variant = exp_env ? atoi(exp_env) : 0;
+  if (d == 768 && exp_variant >= 900) {
+    const unsigned waves = (unsigned)R;
+    switch (exp_variant) {
+#define FFX_EXP_EXACT(ID, U, PASSES, NT) \
+  case ID: ffx::gather_dot_exact_kernel<8, 12, U, PASSES, NT><<<blocks_for(waves, 4 * PASSES), 256, 0, st>>>(V, Q, desc, rs, R); break
+      FFX_EXP_EXACT(900, 4, 16, false);  // round-1 first shipping form (strided dword loads)
+      FFX_EXP_EXACT(901, 2, 16, false);
+      FFX_EXP_EXACT(902, 8, 16, false);
+      FFX_EXP_EXACT(903, 4, 16, true);
+      FFX_EXP_EXACT(904, 4, 32, false);
+      FFX_EXP_EXACT(905, 4, 64, false);
+      FFX_EXP_EXACT(906, 8, 32, true);
+      FFX_EXP_EXACT(907, 4, 8, false);
+      FFX_EXP_EXACT(908, 4, 32, true);
+      FFX_EXP_EXACT(909, 8, 64, true);
+#undef FFX_EXP_EXACT
+#define FFX_EXP_LDS(ID, U, TILE, NT) \
+  case ID: ffx::gather_dot_exact_lds_kernel<3, U, TILE, NT><<<blocks_for(waves, 4 * TILE), 256, 0, st>>>(V, Q, desc, rs, R); break
+      FFX_EXP_LDS(911, 4, 16, true);
+      FFX_EXP_LDS(912, 2, 8, true);
+      FFX_EXP_LDS(913, 4, 8, true);
+      FFX_EXP_LDS(914, 4, 16, false);
+      FFX_EXP_LDS(915, 2, 16, true);
+      FFX_EXP_LDS(916, 8, 16, true);
+      FFX_EXP_LDS(917, 4, 4, true);
+      FFX_EXP_LDS(918, 2, 4, true);
+#undef FFX_EXP_LDS
+      case 955: ffx::gather_dot_fast_kernel<3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 956: ffx::gather_dot_fast_kernel<3, 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 957: ffx::gather_dot_fast_kernel<3, 4, 4, true><<<blocks_for(R, 16), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 951: ffx::gather_dot_fast_kernel<3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 952: ffx::gather_dot_fast_kernel<3, 8, 16, false><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 953: ffx::gather_dot_fast_kernel<3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 954: ffx::gather_dot_fast_kernel<3, 4, 64, false><<<blocks_for(R, 256), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      default: return fail(FFX_BAD_ARG, "unknown FFX_GATHER_VARIANT %d", exp_variant);
+    }
+    pl->variant = exp_variant;
+    FFX_HIP(hipGetLastError());
+    return FFX_OK;
+  }
+  // d = 768 / 1024 (8 leaves): full-line non-temporal loads + LDS transpose (16.0 ms vs 17.7 ms for
+  // the strided-dword form at 8.8M x 768, k=5000: tools/kernel_ab.py, profiles/r01/kernel_ab.log)
   if (exact) {
     switch (d) {
-      case 768: FFX_EXACT(8, 12, 4, 101); break;
-      case 1024: FFX_EXACT(8, 16, 2, 102); break;
+      case 768:
+        ffx::gather_dot_exact_lds_kernel<3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
+        pl->variant = 111;
+        break;
+      case 1024:
+        ffx::gather_dot_exact_lds_kernel<4, 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
+        pl->variant = 112;
+        break;
       case 512: FFX_EXACT(4, 16, 2, 103); break;
       case 384: FFX_EXACT(4, 12, 4, 104); break;
       case 256: FFX_EXACT(2, 16, 2, 105); break;
@@ -515,10 +567,10 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
     }
   } else {
     switch (d) {
-      case 768: ffx::gather_dot_fast_kernel<3, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 201; break;
-      case 1024: ffx::gather_dot_fast_kernel<4, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 202; break;
-      case 512: ffx::gather_dot_fast_kernel<2, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 203; break;
-      case 256: ffx::gather_dot_fast_kernel<1, 4><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 204; break;
+      case 768: ffx::gather_dot_fast_kernel<3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 211; break;
+      case 1024: ffx::gather_dot_fast_kernel<4, 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 212; break;
+      case 512: ffx::gather_dot_fast_kernel<2, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213; break;
+      case 256: ffx::gather_dot_fast_kernel<1, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214; break;
       default:
         if (d % 4 == 0) {
           ffx::gather_dot_fast_generic_kernel<<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);

@@ -58,16 +58,31 @@ __device__ __forceinline__ float butterfly(float x) {
 // ---- exact kernel, d = 8*LEAVES*NPER, LEAVES in {1,2,4,8}, NPER <= 16 ---------------------
 // A wave owns TILE consecutive work rows.  LPR = 8*LEAVES lanes cooperate on one row, so a
 // wave works on RPW = 64/LPR rows per pass and keeps U passes of loads in flight.
-template <int LEAVES, int NPER, int U>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// row loads: read-once data, optionally marked non-temporal (nt) so it does not displace the
+// query vectors / descriptors in L2
+template <bool NT>
+__device__ __forceinline__ float load_row_f32(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
+constexpr int exact_default_passes(int leaves) {
+  const int rpw = 64 / (8 * leaves);
+  return rpw == 1 ? 16 : ((64 / rpw) < 16 ? (64 / rpw) : 16);
+}
+
+template <int LEAVES, int NPER, int U, int PASSES = exact_default_passes(LEAVES), bool NT = false>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
                         const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
   constexpr int LPR = 8 * LEAVES;
   constexpr int RPW = 64 / LPR;
   constexpr int D = LPR * NPER;
-  constexpr int PASSES = (RPW == 1) ? 16 : ((64 / RPW) < 16 ? (64 / RPW) : 16);
   constexpr int TILE = PASSES * RPW;
   static_assert(PASSES % U == 0, "PASSES must be a multiple of U");
+  static_assert(TILE <= 64, "one descriptor per lane");
 
   const int lane = threadIdx.x & 63;
   // threadIdx.x >> 6 is wave-uniform; readfirstlane tells the compiler so (scalar addressing)
@@ -100,7 +115,7 @@ gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restri
         qn[u] = __builtin_amdgcn_readlane(my.y, t);
         const float* rowp = vectors + (size_t)rid * D + lane_off;
 #pragma unroll
-        for (int i = 0; i < NPER; ++i) v[u][i] = rowp[8 * i];
+        for (int i = 0; i < NPER; ++i) v[u][i] = load_row_f32<NT>(rowp + 8 * i);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -148,13 +163,103 @@ gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restri
   }
 }
 
+// ---- exact kernel with full-line loads, d = 256*NCH with 8 leaves (768, 1024) -----------------
+// Same arithmetic as gather_dot_exact_kernel (bit-identical), different data movement: rows come
+// in with 16-byte coalesced, non-temporal loads (every 128-B line requested once, whole), the
+// products are formed in that layout (a product does not care where it is computed), and a
+// wave-private LDS tile turns them into NumPy's layout: lane (leaf l, accumulator j) reads back
+// products l*LL + j + 8*i, i = 0..NPER-1, and adds them in order.  Leaves are padded from LL to
+// LL+8 floats in LDS so that the 32 lanes of a ds_read_b32 group hit 32 different banks
+// ((LL+8)*l + j mod 32 = 8*l + j for LL a multiple of 32).  LDS operations of one wave execute in
+// order, so the read-after-write and the next row's write-after-read need no s_barrier.
+template <int NCH, int U, int TILE, bool NT>
+__global__ void __launch_bounds__(256)
+gather_dot_exact_lds_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+                            const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  constexpr int D = 256 * NCH;
+  constexpr int LL = D / 8;        // leaf length (96 or 128)
+  constexpr int NPER = LL / 8;     // adds per accumulator
+  constexpr int LPAD = LL + 8;     // padded leaf stride in LDS
+  static_assert(LL % 32 == 0 && LL <= 128, "8 leaves of at most 128 elements");
+  static_assert(TILE % U == 0 && TILE <= 64, "bad tile");
+  __shared__ __attribute__((aligned(16))) float tile[4][8 * LPAD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+  const long base = (long)wave * TILE;
+  if (base >= n_rows) return;
+  const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+  const int my_t = lane < n_here ? lane : n_here - 1;
+  const int2 my = desc[base + my_t];
+
+  float* buf = tile[wave_in_block];
+  // where this lane's NCH float4 of products go, and where its NPER summands come from
+  int woff[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = 4 * lane + 256 * c;
+    woff[c] = (e / LL) * LPAD + (e % LL);
+  }
+  const float* rbuf = buf + (lane >> 3) * LPAD + (lane & 7);
+
+  float4 q[NCH];
+  int cur_q = -1;
+#pragma unroll 1
+  for (int b = 0; b < TILE; b += U) {
+    if (b >= n_here) break;
+    float4 v[U][NCH];
+    int qn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (b + u) < n_here ? (b + u) : n_here - 1;
+      const int rid = __builtin_amdgcn_readlane(my.x, t);
+      qn[u] = __builtin_amdgcn_readlane(my.y, t);
+      const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)rid * D) + lane;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (NT) {
+          const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * c));
+          v[u][c] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        } else {
+          v[u][c] = rowp[64 * c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (qn[u] != cur_q) {
+        cur_q = qn[u];
+        const float4* qp = reinterpret_cast<const float4*>(queries + (size_t)cur_q * D) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) q[c] = qp[64 * c];
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float4 p;
+        p.x = __fmul_rn(q[c].x, v[u][c].x);
+        p.y = __fmul_rn(q[c].y, v[u][c].y);
+        p.z = __fmul_rn(q[c].z, v[u][c].z);
+        p.w = __fmul_rn(q[c].w, v[u][c].w);
+        *reinterpret_cast<float4*>(buf + woff[c]) = p;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float acc = rbuf[0];
+#pragma unroll
+      for (int i = 1; i < NPER; ++i) acc = __fadd_rn(acc, rbuf[8 * i]);
+      __builtin_amdgcn_wave_barrier();
+      acc = butterfly<8>(acc);
+      if (lane == 0 && (b + u) < n_here) rs[base + b + u] = acc;
+    }
+  }
+}
+
 // ---- fast kernel, d = 256*NCH: lane holds NCH float4 per row (16-B coalesced loads) --------
-template <int NCH, int U>
+template <int NCH, int U, int TILE = 16, bool NT = false>
 __global__ void __launch_bounds__(256)
 gather_dot_fast_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
                        const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
   constexpr int D = 256 * NCH;
-  constexpr int TILE = 16;
   static_assert(TILE % U == 0, "TILE must be a multiple of U");
   const int lane = threadIdx.x & 63;
   // threadIdx.x >> 6 is wave-uniform; readfirstlane tells the compiler so (scalar addressing)
@@ -179,7 +284,14 @@ gather_dot_fast_kernel(const float* __restrict__ vectors, const float* __restric
       qn[u] = __builtin_amdgcn_readlane(my.y, t);
       const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)rid * D) + lane;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) v[u][c] = rowp[64 * c];
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (NT) {
+          const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * c));
+          v[u][c] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+          v[u][c] = rowp[64 * c];
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
