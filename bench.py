@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--layout", default="single", choices=["single", "multi"],
                     help="single: 1 passage per document (MS MARCO passage); multi: 1..8 passages per document")
     ap.add_argument("--sum", default="exact", choices=["exact", "fast"], help="summation order of gather_dot")
+    ap.add_argument("--store", default="f32", choices=["f32", "f16"], help="row storage type of the index")
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--sort", action="store_true", help="also order every query's candidates on the device")
     ap.add_argument("--seed", type=int, default=2024)
@@ -108,6 +109,8 @@ def cpu_baseline(args, doc_off, n_docs, scale):
     sub_off = np.concatenate([[0], np.cumsum(counts)])
     rows_global = np.concatenate([np.arange(doc_off[u], doc_off[u + 1]) for u in uniq]) if args.layout == "multi" else doc_off[uniq]
     vecs = fo.synth_row_list(args.seed, scale, rows_global, args.dim)
+    if args.store == "f16":  # the index rounds rows to float16 once; NumPy then widens them back
+        vecs = vecs.astype(np.float16).astype(np.float32)
     queries = synth.rows(args.seed + 3, scale, 0, nq, args.dim)
     sub_rows = np.arange(rows_global.shape[0], dtype=np.int32)
     mode = MODE_NO[args.mode]
@@ -158,7 +161,8 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
     r_lo, r_hi = int(doc_off[d_lo]), int(doc_off[d_hi])
     n_local = r_hi - r_lo
 
-    shard = native.DeviceIndex(max(n_local, 1), args.dim, device=local_rank)
+    store = np.float16 if args.store == "f16" else np.float32
+    shard = native.DeviceIndex(max(n_local, 1), args.dim, device=local_rank, dtype=store)
     shard.fill_synthetic(args.seed, scale, 0, n_local, first_global_row=r_lo)
     shard.set_doc_rows(doc_off[d_lo:d_hi + 1] - r_lo, np.arange(n_local, dtype=np.int32))
     shard.set_psg_rows(np.arange(n_local, dtype=np.int32))
@@ -188,7 +192,7 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
 
     # kernel time of the last step on this rank (HIP events on the stream the kernel ran on)
     st = scorer.plan.stats()
-    row_bytes = args.dim * 4 + 4
+    row_bytes = args.dim * np.dtype(store).itemsize + 4
     mine = torch.tensor([st["ms_gather_dot"], float(st["n_rows"])], dtype=torch.float64, device=f"cuda:{local_rank}")
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
@@ -213,7 +217,7 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} fp32 index row-sharded by document over "
+                "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} {'fp16' if args.store == 'f16' else 'fp32'} index row-sharded by document over "
                             f"{world} GPUs ({n_local} rows on rank 0), {args.queries} queries, k={args.k}, Mode.{args.mode}, "
                             f"alpha={args.alpha}, sum={args.sum}; per step: local gather_dot, RCCL all-to-all of dense scores to "
                             f"the owning rank, owner-side interpolation{' + sort' if args.sort else ''}",
@@ -262,7 +266,8 @@ def main():
     n_docs = doc_off.shape[0] - 1
 
     t_setup = time.perf_counter()
-    index = native.DeviceIndex(args.rows, args.dim, device=0)
+    store = np.float16 if args.store == "f16" else np.float32
+    index = native.DeviceIndex(args.rows, args.dim, device=0, dtype=store)
     index.fill_synthetic(args.seed, scale, 0, args.rows)
     index.set_doc_rows(doc_off, np.arange(args.rows, dtype=np.int32))
     index.set_psg_rows(np.arange(args.rows, dtype=np.int32))
@@ -291,7 +296,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     st = plan.stats()
 
-    row_bytes = args.dim * 4 + 4  # per gathered row, payload + int32 row id
+    row_bytes = args.dim * np.dtype(store).itemsize + 4  # per gathered row, payload + int32 row id
     kern_avg_ms = float(np.mean(kern_ms))
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
     if traffic is None:
@@ -314,13 +319,13 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} fp32 InMemoryIndex in HBM, "
+            "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} {'fp16' if args.store == 'f16' else 'fp32'} InMemoryIndex in HBM, "
                         f"{args.queries} queries, k={args.k}, Mode.{args.mode}, alpha={args.alpha}, "
                         f"{'1 passage/doc' if args.layout == 'single' else '1..8 passages/doc'}, sum={args.sum}"
                         f"{', device sort' if args.sort else ''}",
             "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
             "layout": args.layout, "sum": args.sum, "pairs": st["n_pairs"], "gathered_rows": st["n_rows"],
-            "sharding": "none (1 GPU)", "index_bytes": args.rows * args.dim * 4,
+            "sharding": "none (1 GPU)", "index_bytes": args.rows * args.dim * np.dtype(store).itemsize, "store": args.store,
         },
         "roofline": {
             "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']})",
@@ -332,7 +337,7 @@ def main():
         "stages_ms": {"expand": stage_ms["ms_expand"], "gather_dot": kern_avg_ms, "reduce_interp": stage_ms["ms_reduce"],
                       "sort": stage_ms["ms_sort"], "device_total": stage_ms["ms_total"]},
         "device": dev["name"], "setup_s": t_setup,
-        "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (args.dim * 4)),
+        "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize)),
     }
 
     if args.cpu_sample_queries > 0:

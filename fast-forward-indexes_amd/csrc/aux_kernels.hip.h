@@ -152,12 +152,12 @@ merge_kernel(const float* __restrict__ recv, const int32_t* __restrict__ slot, c
 
 // ---- row copy-out for _get_vectors (index/memory.py:139-140) --------------------------------
 __global__ void __launch_bounds__(256)
-gather_rows_kernel(const float* __restrict__ vectors, int d, const int32_t* __restrict__ rows,
-                   int64_t n, float* __restrict__ out) {
+gather_rows_kernel(const uint16_t* __restrict__ vectors, int d, const int32_t* __restrict__ rows,
+                   int64_t n, uint16_t* __restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= n) return;
-  const float* src = vectors + (size_t)rows[r] * d;
-  float* dst = out + (size_t)r * d;
+  const uint16_t* src = vectors + (size_t)rows[r] * d;
+  uint16_t* dst = out + (size_t)r * d;
   for (int c = threadIdx.x & 63; c < d; c += 64) dst[c] = src[c];
 }
 
@@ -169,14 +169,20 @@ __device__ __forceinline__ uint64_t mix64(uint64_t idx, uint64_t seed) {
   return z ^ (z >> 31);
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-fill_synthetic_kernel(float* __restrict__ dst, int64_t n_elems, uint64_t first_elem, uint64_t seed,
+fill_synthetic_kernel(T* __restrict__ dst, int64_t n_elems, uint64_t first_elem, uint64_t seed,
                       float scale) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
     const uint32_t m = (uint32_t)(mix64(first_elem + (uint64_t)e, seed) >> 40);
     const float u = __fsub_rn(__fmul_rn((float)m, 0x1p-23f), 1.0f);
-    dst[e] = __fmul_rn(u, scale);
+    float x = __fmul_rn(u, scale);
+    // keep the fp32 product as its own value: without this the compiler folds multiply + narrowing
+    // into v_fma_mixlo_f16, and the half result must be round(round32(u*scale)) like NumPy's
+    // float32 product followed by astype(float16)
+    asm volatile("" : "+v"(x));
+    dst[e] = (T)x;
   }
 }
 

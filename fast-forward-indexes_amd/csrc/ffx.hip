@@ -103,8 +103,11 @@ void numpy_leaf_plan(int start, int n, std::vector<int>& bounds) {
 struct ffx_index {
   int device = 0;
   int32_t dim = 0;
+  int32_t dtype = FFX_DTYPE_F32;
+  size_t elem = sizeof(float);  // bytes per stored element
   int64_t capacity = 0;
-  float* vectors = nullptr;
+  void* vectors = nullptr;
+  char* row_ptr(int64_t row) const { return static_cast<char*>(vectors) + (size_t)row * dim * elem; }
   // id structure (device copies)
   DevBuf doc_off;   // int32[n_docs+1]
   DevBuf doc_rows;  // int32[n_doc_rows]
@@ -175,8 +178,19 @@ int ffx_device_info(int device, char* name, size_t name_cap, int64_t* total_byte
 
 // ---- index ------------------------------------------------------------------------------------
 int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index** out) {
+  return ffx_index_create_typed(device, capacity_rows, dim, FFX_DTYPE_F32, out);
+}
+
+int ffx_index_dtype(const ffx_index* idx, int32_t* dtype) {
+  if (!idx || !dtype) return fail(FFX_BAD_ARG, "NULL argument");
+  *dtype = idx->dtype;
+  return FFX_OK;
+}
+
+int ffx_index_create_typed(int device, int64_t capacity_rows, int32_t dim, int32_t dtype, ffx_index** out) {
   if (!out) return fail(FFX_BAD_ARG, "out is NULL");
   *out = nullptr;
+  if (dtype != FFX_DTYPE_F32 && dtype != FFX_DTYPE_F16) return fail(FFX_BAD_ARG, "unknown dtype %d", dtype);
   if (capacity_rows < 0 || capacity_rows > INT32_MAX) return fail(FFX_BAD_ARG, "capacity_rows out of range (row ids are int32)");
   if (dim <= 0) return fail(FFX_BAD_ARG, "dim must be positive");
   int n = 0;
@@ -190,9 +204,11 @@ int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index**
   if (!idx) return fail(FFX_OOM, "host allocation failed");
   idx->device = device;
   idx->dim = dim;
+  idx->dtype = dtype;
+  idx->elem = dtype == FFX_DTYPE_F16 ? 2 : 4;
   idx->capacity = capacity_rows;
-  const size_t bytes = std::max<size_t>((size_t)capacity_rows * dim * sizeof(float), 256);
-  hipError_t e = hipMalloc((void**)&idx->vectors, bytes);
+  const size_t bytes = std::max<size_t>((size_t)capacity_rows * dim * idx->elem, 256);
+  hipError_t e = hipMalloc(&idx->vectors, bytes);
   if (e != hipSuccess) {
     delete idx;
     return fail(FFX_OOM, "hipMalloc of %zu index bytes failed: %s", bytes, hipGetErrorString(e));
@@ -225,29 +241,29 @@ int ffx_index_capacity(const ffx_index* idx, int64_t* rows) {
   return FFX_OK;
 }
 
-int ffx_index_upload(ffx_index* idx, const float* host_rows, int64_t row_offset, int64_t n_rows) {
+int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, int64_t n_rows) {
   if (!idx || (!host_rows && n_rows > 0)) return fail(FFX_BAD_ARG, "NULL argument");
   if (row_offset < 0 || n_rows < 0 || row_offset + n_rows > idx->capacity)
     return fail(FFX_BAD_ARG, "rows [%lld, %lld) outside capacity %lld", (long long)row_offset,
                 (long long)(row_offset + n_rows), (long long)idx->capacity);
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(idx->device));
-  FFX_HIP(hipMemcpy(idx->vectors + (size_t)row_offset * idx->dim, host_rows,
-                    (size_t)n_rows * idx->dim * sizeof(float), hipMemcpyHostToDevice));
+  FFX_HIP(hipMemcpy(idx->row_ptr(row_offset), host_rows, (size_t)n_rows * idx->dim * idx->elem, hipMemcpyHostToDevice));
   return FFX_OK;
 }
 
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows) {
   if (!dst || !src) return fail(FFX_BAD_ARG, "NULL argument");
-  if (dst->device != src->device || dst->dim != src->dim) return fail(FFX_BAD_ARG, "indexes differ in device or dim");
+  if (dst->device != src->device || dst->dim != src->dim || dst->dtype != src->dtype)
+    return fail(FFX_BAD_ARG, "indexes differ in device, dim or dtype");
   if (n_rows < 0 || n_rows > src->capacity || n_rows > dst->capacity) return fail(FFX_BAD_ARG, "n_rows out of range");
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(dst->device));
-  FFX_HIP(hipMemcpy(dst->vectors, src->vectors, (size_t)n_rows * src->dim * sizeof(float), hipMemcpyDeviceToDevice));
+  FFX_HIP(hipMemcpy(dst->vectors, src->vectors, (size_t)n_rows * src->dim * src->elem, hipMemcpyDeviceToDevice));
   return FFX_OK;
 }
 
-int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, float* host_out) {
+int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, void* host_out) {
   if (!idx || (n_rows > 0 && (!rows || !host_out))) return fail(FFX_BAD_ARG, "NULL argument");
   if (n_rows == 0) return FFX_OK;
   for (int64_t i = 0; i < n_rows; ++i)
@@ -255,14 +271,17 @@ int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, float*
   FFX_HIP(hipSetDevice(idx->device));
   DevBuf drows, dout;
   int rc = drows.ensure((size_t)n_rows * sizeof(int32_t));
-  if (rc == FFX_OK) rc = dout.ensure((size_t)n_rows * idx->dim * sizeof(float));
+  const size_t out_bytes = (size_t)n_rows * idx->dim * idx->elem;
+  if (rc == FFX_OK) rc = dout.ensure(out_bytes);
   if (rc == FFX_OK) {
     hipError_t e = hipMemcpy(drows.p, rows, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-      ffx::gather_rows_kernel<<<blocks_for(n_rows, 4), 256>>>(idx->vectors, idx->dim, drows.as<int32_t>(), n_rows, dout.as<float>());
+      // rows are copied as raw 2-byte units, so one kernel serves both element types
+      ffx::gather_rows_kernel<<<blocks_for(n_rows, 4), 256>>>(static_cast<const uint16_t*>(idx->vectors), (int)(idx->dim * idx->elem / 2),
+                                                             drows.as<int32_t>(), n_rows, dout.as<uint16_t>());
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(host_out, dout.p, (size_t)n_rows * idx->dim * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(host_out, dout.p, out_bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(FFX_HIP_ERROR, "gather failed: %s", hipGetErrorString(e));
   }
   drows.release();
@@ -279,8 +298,12 @@ int ffx_index_fill_synthetic(ffx_index* idx, uint64_t seed, float scale, int64_t
   FFX_HIP(hipSetDevice(idx->device));
   const int64_t n_elems = n_rows * idx->dim;
   const unsigned grid = (unsigned)std::min<int64_t>((n_elems + 255) / 256, 256 * 32);
-  ffx::fill_synthetic_kernel<<<grid, 256>>>(idx->vectors + (size_t)row_offset * idx->dim, n_elems,
-                                            (uint64_t)first_global_row * (uint64_t)idx->dim, seed, scale);
+  if (idx->dtype == FFX_DTYPE_F16)
+    ffx::fill_synthetic_kernel<_Float16><<<grid, 256>>>(reinterpret_cast<_Float16*>(idx->row_ptr(row_offset)), n_elems,
+                                                        (uint64_t)first_global_row * (uint64_t)idx->dim, seed, scale);
+  else
+    ffx::fill_synthetic_kernel<float><<<grid, 256>>>(reinterpret_cast<float*>(idx->row_ptr(row_offset)), n_elems,
+                                                     (uint64_t)first_global_row * (uint64_t)idx->dim, seed, scale);
   FFX_HIP(hipGetLastError());
   FFX_HIP(hipDeviceSynchronize());
   return FFX_OK;
@@ -482,22 +505,29 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   return FFX_OK;
 }
 
-// pick and launch the gather_dot instantiation; returns the variant id
-static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
+}  // extern "C" (templates need C++ linkage)
+
+// pick and launch the gather_dot instantiation for rows of type T (float / _Float16); the
+// variant id lands in ffx_stats.kernel_variant (+1000 for half rows)
+template <typename T>
+static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   const ffx_index* ix = pl->idx;
   const int d = ix->dim;
   const int R = (int)pl->n_rows;
-  const float* V = ix->vectors;
+  const T* V = static_cast<const T*>(ix->vectors);
   const float* Q = pl->queries.as<float>();
   const int2* desc = pl->desc.as<int2>();
   hipStream_t st = pl->stream;
+  constexpr int HALF = sizeof(T) == 2 ? 1000 : 0;
+  // half rows carry half the bytes: keep twice the rows in flight
+  constexpr int UL = sizeof(T) == 2 ? 8 : 4;
 #define FFX_EXACT(LEAVES, NPER, U, ID)                                                            \
   do {                                                                                            \
     constexpr int RPW_ = 64 / (8 * LEAVES);                                                       \
     constexpr int PASSES_ = RPW_ == 1 ? 16 : ((64 / RPW_) < 16 ? (64 / RPW_) : 16);               \
     constexpr int TILE_ = PASSES_ * RPW_;                                                         \
-    ffx::gather_dot_exact_kernel<LEAVES, NPER, U><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R); \
-    pl->variant = ID;                                                                             \
+    ffx::gather_dot_exact_kernel<T, LEAVES, NPER, U><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R); \
+    pl->variant = ID + HALF;                                                                      \
   } while (0)
   // tuning hook (tools/kernel_ab.py): FFX_GATHER_VARIANT selects an experimental d=768 instantiation
   const char* exp_env = getenv("FFX_GATHER_VARIANT");
@@ -506,36 +536,26 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
     const unsigned waves = (unsigned)R;
     switch (exp_variant) {
 #define FFX_EXP_EXACT(ID, U, PASSES, NT) \
-  case ID: ffx::gather_dot_exact_kernel<8, 12, U, PASSES, NT><<<blocks_for(waves, 4 * PASSES), 256, 0, st>>>(V, Q, desc, rs, R); break
-      FFX_EXP_EXACT(900, 4, 16, false);  // round-1 first shipping form (strided dword loads)
-      FFX_EXP_EXACT(901, 2, 16, false);
-      FFX_EXP_EXACT(902, 8, 16, false);
+  case ID: ffx::gather_dot_exact_kernel<T, 8, 12, U, PASSES, NT><<<blocks_for(waves, 4 * PASSES), 256, 0, st>>>(V, Q, desc, rs, R); break
+      FFX_EXP_EXACT(900, 4, 16, false);  // round-1 first shipping form (strided element loads)
       FFX_EXP_EXACT(903, 4, 16, true);
-      FFX_EXP_EXACT(904, 4, 32, false);
-      FFX_EXP_EXACT(905, 4, 64, false);
-      FFX_EXP_EXACT(906, 8, 32, true);
       FFX_EXP_EXACT(907, 4, 8, false);
-      FFX_EXP_EXACT(908, 4, 32, true);
-      FFX_EXP_EXACT(909, 8, 64, true);
 #undef FFX_EXP_EXACT
 #define FFX_EXP_LDS(ID, U, TILE, NT) \
-  case ID: ffx::gather_dot_exact_lds_kernel<3, U, TILE, NT><<<blocks_for(waves, 4 * TILE), 256, 0, st>>>(V, Q, desc, rs, R); break
+  case ID: ffx::gather_dot_exact_lds_kernel<T, 3, U, TILE, NT><<<blocks_for(waves, 4 * TILE), 256, 0, st>>>(V, Q, desc, rs, R); break
       FFX_EXP_LDS(911, 4, 16, true);
       FFX_EXP_LDS(912, 2, 8, true);
       FFX_EXP_LDS(913, 4, 8, true);
       FFX_EXP_LDS(914, 4, 16, false);
-      FFX_EXP_LDS(915, 2, 16, true);
       FFX_EXP_LDS(916, 8, 16, true);
-      FFX_EXP_LDS(917, 4, 4, true);
-      FFX_EXP_LDS(918, 2, 4, true);
+      FFX_EXP_LDS(919, 8, 8, true);
+      FFX_EXP_LDS(920, 16, 16, true);
 #undef FFX_EXP_LDS
-      case 955: ffx::gather_dot_fast_kernel<3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 956: ffx::gather_dot_fast_kernel<3, 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 957: ffx::gather_dot_fast_kernel<3, 4, 4, true><<<blocks_for(R, 16), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 951: ffx::gather_dot_fast_kernel<3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 952: ffx::gather_dot_fast_kernel<3, 8, 16, false><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 953: ffx::gather_dot_fast_kernel<3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 954: ffx::gather_dot_fast_kernel<3, 4, 64, false><<<blocks_for(R, 256), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 951: ffx::gather_dot_fast_kernel<T, 3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 953: ffx::gather_dot_fast_kernel<T, 3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 958: ffx::gather_dot_fast_kernel<T, 3, 8, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 959: ffx::gather_dot_fast_kernel<T, 3, 16, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
       default: return fail(FFX_BAD_ARG, "unknown FFX_GATHER_VARIANT %d", exp_variant);
     }
     pl->variant = exp_variant;
@@ -543,16 +563,16 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
     return FFX_OK;
   }
   // d = 768 / 1024 (8 leaves): full-line non-temporal loads + LDS transpose (16.0 ms vs 17.7 ms for
-  // the strided-dword form at 8.8M x 768, k=5000: tools/kernel_ab.py, profiles/r01/kernel_ab.log)
+  // the strided form at 8.8M x 768 fp32, k=5000: tools/kernel_ab.py, profiles/r01/kernel_ab_2.log)
   if (exact) {
     switch (d) {
       case 768:
-        ffx::gather_dot_exact_lds_kernel<3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
-        pl->variant = 111;
+        ffx::gather_dot_exact_lds_kernel<T, 3, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
+        pl->variant = 111 + HALF;
         break;
       case 1024:
-        ffx::gather_dot_exact_lds_kernel<4, 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
-        pl->variant = 112;
+        ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
+        pl->variant = 112 + HALF;
         break;
       case 512: FFX_EXACT(4, 16, 2, 103); break;
       case 384: FFX_EXACT(4, 12, 4, 104); break;
@@ -561,25 +581,25 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
       case 64: FFX_EXACT(1, 8, 4, 107); break;
       default:
         if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
-        ffx::gather_dot_exact_generic_kernel<<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
+        ffx::gather_dot_exact_generic_kernel<T><<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
             V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
-        pl->variant = 199;
+        pl->variant = 199 + HALF;
     }
   } else {
     switch (d) {
-      case 768: ffx::gather_dot_fast_kernel<3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 211; break;
-      case 1024: ffx::gather_dot_fast_kernel<4, 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 212; break;
-      case 512: ffx::gather_dot_fast_kernel<2, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213; break;
-      case 256: ffx::gather_dot_fast_kernel<1, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214; break;
+      case 768: ffx::gather_dot_fast_kernel<T, 3, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 211 + HALF; break;
+      case 1024: ffx::gather_dot_fast_kernel<T, 4, UL / 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 212 + HALF; break;
+      case 512: ffx::gather_dot_fast_kernel<T, 2, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213 + HALF; break;
+      case 256: ffx::gather_dot_fast_kernel<T, 1, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214 + HALF; break;
       default:
         if (d % 4 == 0) {
-          ffx::gather_dot_fast_generic_kernel<<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);
-          pl->variant = 298;
-        } else {  // rows are not 16-byte aligned: the exact generic kernel is the only scalar path
+          ffx::gather_dot_fast_generic_kernel<T><<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);
+          pl->variant = 298 + HALF;
+        } else {  // rows are not 8/16-byte aligned: the exact generic kernel is the only scalar path
           if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large", d);
-          ffx::gather_dot_exact_generic_kernel<<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
+          ffx::gather_dot_exact_generic_kernel<T><<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
               V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
-          pl->variant = 199;
+          pl->variant = 199 + HALF;
         }
     }
   }
@@ -587,6 +607,13 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
   FFX_HIP(hipGetLastError());
   return FFX_OK;
 }
+
+static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
+  return pl->idx->dtype == FFX_DTYPE_F16 ? launch_gather_dot_t<_Float16>(pl, exact, rs)
+                                         : launch_gather_dot_t<float>(pl, exact, rs);
+}
+
+extern "C" {
 
 // per-query order: key descending, ties by position (the radix sort is stable)
 static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* offs_dev, int64_t n_queries, DevBuf& order,
@@ -704,7 +731,7 @@ int ffx_plan_stats(ffx_plan* pl, ffx_stats* out) {
   out->n_pairs = pl->n_pairs;
   out->n_rows = pl->n_rows;
   const double d = pl->idx->dim;
-  out->algorithmic_bytes = (double)pl->n_rows * (d * 4 + 4) + (double)pl->n_pairs * 4 * (1 + (pl->last_interp ? 2 : 0)) +
+  out->algorithmic_bytes = (double)pl->n_rows * (d * (double)pl->idx->elem + 4) + (double)pl->n_pairs * 4 * (1 + (pl->last_interp ? 2 : 0)) +
                            (double)pl->n_queries * d * 4 + (double)(pl->n_queries + 1) * 8;
   FFX_HIP(hipEventElapsedTime(&out->ms_expand, pl->ev[0], pl->ev[1]));
   FFX_HIP(hipEventElapsedTime(&out->ms_gather_dot, pl->ev[1], pl->ev[2]));

@@ -10,6 +10,10 @@
 // Work list: `desc[r] = {index row, query number}` for r in [0, R), rows of one query
 // contiguous (built by ffx_expand_kernel).  Output: rs[r] = <query, row>.
 //
+// Rows are stored as T = float or _Float16 (the reference stores whatever dtype it is given,
+// index/memory.py:80-83; float32 queries times float16 rows promote to float32 products in
+// NumPy, so a half row is converted to fp32 -- exactly -- and everything after is the same).
+//
 // Two summation orders:
 //   exact  NumPy's order (products rounded to fp32, 8 strided accumulators per leaf of
 //          <=128 elements, leaves combined pairwise).  For d = 8*LEAVES*NPER the 64
@@ -17,15 +21,18 @@
 //          owns elements l*8*NPER + j + 8*i, i = 0..NPER-1, adds them in order of i, and the
 //          combine tree is the xor-butterfly 1,2,4 (inside a leaf) 8,16,32 (across leaves).
 //          Scores are bit-identical to the reference, hence so is the run ordering.
-//   fast   16-byte coalesced loads, FMA chain, butterfly.  |error| ~ d * 2^-24 * |q||v|.
+//   fast   coalesced loads, FMA chain, butterfly.  |error| ~ d * 2^-24 * |q||v|.
 //
-// Roofline: HBM.  Per row the kernel must move d*4 B of row data + 8 B of descriptor in and
-// 4 B out; 2*d flop.  0.5 flop/B, so MFMA is irrelevant.
+// Roofline: HBM.  Per row the kernel must move d*sizeof(T) B of row data + 8 B of descriptor in
+// and 4 B out; 2*d flop.  <= 1 flop/B, so MFMA is irrelevant.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace ffx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // ---- cross-lane helpers (DPP: no LDS traffic) ------------------------------------------
 template <int CTRL>
@@ -55,17 +62,31 @@ __device__ __forceinline__ float butterfly(float x) {
   return x;
 }
 
-// ---- exact kernel, d = 8*LEAVES*NPER, LEAVES in {1,2,4,8}, NPER <= 16 ---------------------
-// A wave owns TILE consecutive work rows.  LPR = 8*LEAVES lanes cooperate on one row, so a
-// wave works on RPW = 64/LPR rows per pass and keeps U passes of loads in flight.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// ---- row loads ------------------------------------------------------------------------------
+// read-once data, optionally marked non-temporal (nt) so it does not displace the query vectors
+// and descriptors in L2.  Conversions half -> float are exact.
+template <typename T, bool NT>
+__device__ __forceinline__ float load1(const T* p) {
+  if constexpr (NT) return (float)__builtin_nontemporal_load(p);
+  else return (float)*p;
+}
 
-// row loads: read-once data, optionally marked non-temporal (nt) so it does not displace the
-// query vectors / descriptors in L2
-template <bool NT>
-__device__ __forceinline__ float load_row_f32(const float* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
-  else return *p;
+// 4 consecutive elements (16 B of float / 8 B of half), naturally aligned
+template <typename T, bool NT>
+__device__ __forceinline__ float4 load4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    f32x4 t;
+    if constexpr (NT) t = __builtin_nontemporal_load(q);
+    else t = *q;
+    return make_float4(t.x, t.y, t.z, t.w);
+  } else {
+    const f16x4* q = reinterpret_cast<const f16x4*>(p);
+    f16x4 t;
+    if constexpr (NT) t = __builtin_nontemporal_load(q);
+    else t = *q;
+    return make_float4((float)t.x, (float)t.y, (float)t.z, (float)t.w);
+  }
 }
 
 constexpr int exact_default_passes(int leaves) {
@@ -73,9 +94,14 @@ constexpr int exact_default_passes(int leaves) {
   return rpw == 1 ? 16 : ((64 / rpw) < 16 ? (64 / rpw) : 16);
 }
 
-template <int LEAVES, int NPER, int U, int PASSES = exact_default_passes(LEAVES), bool NT = false>
+// ---- exact kernel, d = 8*LEAVES*NPER, LEAVES in {1,2,4,8}, NPER <= 16 ---------------------
+// A wave owns TILE consecutive work rows.  LPR = 8*LEAVES lanes cooperate on one row, so a
+// wave works on RPW = 64/LPR rows per pass and keeps U passes of loads in flight.  Each lane
+// loads exactly the NPER elements it sums; the four load instructions that share a 128-B line
+// merge in L1 (so no `nt` here: it would bypass L1 and quadruple the L2 traffic).
+template <typename T, int LEAVES, int NPER, int U, int PASSES = exact_default_passes(LEAVES), bool NT = false>
 __global__ void __launch_bounds__(256)
-gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+gather_dot_exact_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                         const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
   constexpr int LPR = 8 * LEAVES;
   constexpr int RPW = 64 / LPR;
@@ -113,9 +139,9 @@ gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restri
         const int t = (b + u) < n_here ? (b + u) : n_here - 1;
         const int rid = __builtin_amdgcn_readlane(my.x, t);
         qn[u] = __builtin_amdgcn_readlane(my.y, t);
-        const float* rowp = vectors + (size_t)rid * D + lane_off;
+        const T* rowp = vectors + (size_t)rid * D + lane_off;
 #pragma unroll
-        for (int i = 0; i < NPER; ++i) v[u][i] = load_row_f32<NT>(rowp + 8 * i);
+        for (int i = 0; i < NPER; ++i) v[u][i] = load1<T, NT>(rowp + 8 * i);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -143,10 +169,10 @@ gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restri
         t = t < n_here ? t : n_here - 1;
         const int rid = __shfl(my.x, t, 64);
         const int qn = __shfl(my.y, t, 64);
-        const float* rowp = vectors + (size_t)rid * D + lane_off;
+        const T* rowp = vectors + (size_t)rid * D + lane_off;
         const float* qp = queries + (size_t)qn * D + lane_off;
 #pragma unroll
-        for (int i = 0; i < NPER; ++i) v[u][i] = rowp[8 * i];
+        for (int i = 0; i < NPER; ++i) v[u][i] = load1<T, false>(rowp + 8 * i);
 #pragma unroll
         for (int i = 0; i < NPER; ++i) q[u][i] = qp[8 * i];
       }
@@ -172,9 +198,9 @@ gather_dot_exact_kernel(const float* __restrict__ vectors, const float* __restri
 // LL+8 floats in LDS so that the 32 lanes of a ds_read_b32 group hit 32 different banks
 // ((LL+8)*l + j mod 32 = 8*l + j for LL a multiple of 32).  LDS operations of one wave execute in
 // order, so the read-after-write and the next row's write-after-read need no s_barrier.
-template <int NCH, int U, int TILE, bool NT>
+template <typename T, int NCH, int U, int TILE, bool NT>
 __global__ void __launch_bounds__(256)
-gather_dot_exact_lds_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                             const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
   constexpr int D = 256 * NCH;
   constexpr int LL = D / 8;        // leaf length (96 or 128)
@@ -215,16 +241,9 @@ gather_dot_exact_lds_kernel(const float* __restrict__ vectors, const float* __re
       const int t = (b + u) < n_here ? (b + u) : n_here - 1;
       const int rid = __builtin_amdgcn_readlane(my.x, t);
       qn[u] = __builtin_amdgcn_readlane(my.y, t);
-      const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)rid * D) + lane;
+      const T* rowp = vectors + (size_t)rid * D + 4 * lane;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if constexpr (NT) {
-          const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * c));
-          v[u][c] = make_float4(t4.x, t4.y, t4.z, t4.w);
-        } else {
-          v[u][c] = rowp[64 * c];
-        }
-      }
+      for (int c = 0; c < NCH; ++c) v[u][c] = load4<T, NT>(rowp + 256 * c);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -255,9 +274,9 @@ gather_dot_exact_lds_kernel(const float* __restrict__ vectors, const float* __re
 }
 
 // ---- fast kernel, d = 256*NCH: lane holds NCH float4 per row (16-B coalesced loads) --------
-template <int NCH, int U, int TILE = 16, bool NT = false>
+template <typename T, int NCH, int U, int TILE = 16, bool NT = false>
 __global__ void __launch_bounds__(256)
-gather_dot_fast_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+gather_dot_fast_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                        const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
   constexpr int D = 256 * NCH;
   static_assert(TILE % U == 0, "TILE must be a multiple of U");
@@ -282,16 +301,9 @@ gather_dot_fast_kernel(const float* __restrict__ vectors, const float* __restric
       const int t = (b + u) < n_here ? (b + u) : n_here - 1;
       const int rid = __builtin_amdgcn_readlane(my.x, t);
       qn[u] = __builtin_amdgcn_readlane(my.y, t);
-      const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)rid * D) + lane;
+      const T* rowp = vectors + (size_t)rid * D + 4 * lane;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if constexpr (NT) {
-          const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * c));
-          v[u][c] = make_float4(t.x, t.y, t.z, t.w);
-        } else {
-          v[u][c] = rowp[64 * c];
-        }
-      }
+      for (int c = 0; c < NCH; ++c) v[u][c] = load4<T, NT>(rowp + 256 * c);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -316,19 +328,20 @@ gather_dot_fast_kernel(const float* __restrict__ vectors, const float* __restric
 }
 
 // ---- fast kernel, any d % 4 == 0 (runtime chunk loop) ----------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
-gather_dot_fast_generic_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+gather_dot_fast_generic_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                                const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
                                int d) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (r >= n_rows) return;
   const int2 de = desc[r];
-  const float4* rowp = reinterpret_cast<const float4*>(vectors + (size_t)de.x * d);
+  const T* rowp = vectors + (size_t)de.x * d;
   const float4* qp = reinterpret_cast<const float4*>(queries + (size_t)de.y * d);
   float acc = 0.f;
   for (int c = lane; c < (d >> 2); c += 64) {
-    const float4 a = qp[c], b = rowp[c];
+    const float4 a = qp[c], b = load4<T, false>(rowp + 4 * c);
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);
     acc = fmaf(a.z, b.z, acc);
@@ -350,8 +363,9 @@ __device__ inline float combine_leaves(int n, const float* leaf_sum, int& next) 
   return __fadd_rn(a, b);
 }
 
+template <typename T>
 __global__ void __launch_bounds__(64)
-gather_dot_exact_generic_kernel(const float* __restrict__ vectors, const float* __restrict__ queries,
+gather_dot_exact_generic_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                                 const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
                                 int d, const int* __restrict__ leaf_start, int n_leaves) {
   extern __shared__ float leaf_sum[];
@@ -359,7 +373,7 @@ gather_dot_exact_generic_kernel(const float* __restrict__ vectors, const float* 
   const long r = blockIdx.x;
   if (r >= n_rows) return;  // whole block leaves together
   const int2 de = desc[r];
-  const float* v = vectors + (size_t)de.x * d;
+  const T* v = vectors + (size_t)de.x * d;
   const float* q = queries + (size_t)de.y * d;
   const int g = lane >> 3, j = lane & 7;
   for (int leaf = g; leaf < n_leaves; leaf += 8) {
@@ -368,16 +382,16 @@ gather_dot_exact_generic_kernel(const float* __restrict__ vectors, const float* 
     float res;
     if (len < 8) {
       res = -0.0f;
-      for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], v[s + i]));
+      for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], (float)v[s + i]));
     } else {
       const int lim = len - (len % 8);
-      float acc = __fmul_rn(q[s + j], v[s + j]);
-      for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q[s + i + j], v[s + i + j]));
+      float acc = __fmul_rn(q[s + j], (float)v[s + j]);
+      for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q[s + i + j], (float)v[s + i + j]));
       acc = __fadd_rn(acc, xor1(acc));
       acc = __fadd_rn(acc, xor2(acc));
       acc = __fadd_rn(acc, xor4(acc));
       res = acc;
-      for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], v[s + i]));
+      for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], (float)v[s + i]));
     }
     if (j == 0) leaf_sum[leaf] = res;
   }

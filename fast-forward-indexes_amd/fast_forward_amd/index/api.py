@@ -183,7 +183,9 @@ class Index(abc.ABC):
             out["ff_score"] = np.zeros(0, dtype=np.float32)
             return out
         q_no = out["q_no"].to_numpy(dtype=np.int64)
-        ordinals = self._resolve_ids(out["id"].to_numpy(), self.mode)
+        # __call__ resolves the whole ranking once and passes the ordinals along
+        ordinals = out.pop("_ord").to_numpy(dtype=np.int32) if "_ord" in out.columns else \
+            self._resolve_ids(out["id"].to_numpy(), self.mode)
         perm, pair_off = _grouped_by_query(q_no, query_vectors.shape[0])
         dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals if perm is None else ordinals[perm], self.mode)
         if perm is not None:
@@ -231,11 +233,12 @@ class Index(abc.ABC):
             take = np.flatnonzero(active[q_no] & (rank_in_q >= a) & (rank_in_q < b))
             if take.size == 0:
                 break
-            chunk_ff = self._compute_scores(df.iloc[take][["id", "q_no"]], query_vectors)["ff_score"].to_numpy(dtype=np.float32)
+            cols = ["id", "q_no"] + (["_ord"] if "_ord" in df.columns else [])
+            chunk_ff = self._compute_scores(df.iloc[take][cols], query_vectors)["ff_score"].to_numpy(dtype=np.float32)
             ff[take] = chunk_ff
             interp[take] = alpha * sparse[take] + (1 - alpha) * chunk_ff
             a = b
-        out = df.copy()
+        out = df.drop(columns=["_ord"], errors="ignore")
         out["ff_score"] = ff
         return out
 
@@ -254,12 +257,11 @@ class Index(abc.ABC):
 
         df = ranking._df
         q_no, _, texts = self._numbered_queries(df)
-        work = df.assign(q_no=q_no)
+        # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
+        # work (the reference raises from its first batch; either way no partial result is returned)
+        work = df.assign(q_no=q_no, _ord=self._resolve_ids(df["id"].to_numpy(), self.mode))
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
-        # fail on unknown ids up front, for the whole ranking (the reference raises from its
-        # first batch; either way no partial result is returned)
-        self._resolve_ids(df["id"].to_numpy(), self.mode)
 
         def score(part: pd.DataFrame) -> pd.DataFrame:
             if early_stopping is None:
@@ -274,7 +276,8 @@ class Index(abc.ABC):
             result = pd.concat([score(work[batch_of == b]) for b in range((n_q + batch_size - 1) // batch_size)])
         result["score"] = result["ff_score"]
         LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-        return Ranking(result, name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
+        # the pairs are those of `ranking`, already known to be unique
+        return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
 
     # ---- iteration ----------------------------------------------------------------------------------------
     def batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:

@@ -8,9 +8,12 @@ host as ordinal tables, and ``Index.__call__`` runs
     ids -> ordinals (host)  ->  expand / gather_dot / segment-reduce / interpolate (device)
 
 Differences from the reference, all deliberate:
-  * storage is fp32.  The reference silently switches to float64 for every chunk after the
-    first (memory.py:106) and so returns float64-accumulated scores on large indexes; here
-    scores always follow the fp32 semantics of a single-chunk reference index.
+  * storage is float32, or float16 when the first ``add`` hands over float16 vectors (the
+    reference likewise keeps the dtype of the first chunk, memory.py:80-83; float32 queries
+    times float16 rows are float32 products in NumPy, which is what the kernels compute).
+    The reference silently switches to float64 for every chunk after the first
+    (memory.py:106) and so returns float64-accumulated scores on large indexes; here scores
+    always follow the semantics of a single-chunk reference index.
   * the vector store grows geometrically instead of by a list of chunks; ``init_size`` /
     ``alloc_size`` keep their meaning as the initial capacity and the minimum growth step.
   * no CPU fallback: without libffx.so or a HIP device, construction fails.
@@ -36,8 +39,12 @@ class InMemoryIndex(Index):
 
     def __init__(self, query_encoder: Encoder | None = None, quantizer=None, mode: Mode = Mode.MAXP,
                  encoder_batch_size: int = 32, init_size: int = 2**16, alloc_size: int = 2**16,
-                 device: int = 0, exact_sum: bool = True) -> None:
+                 device: int = 0, exact_sum: bool = True, dtype=None) -> None:
         """
+        :param dtype: row storage, ``numpy.float32`` or ``numpy.float16``; ``None`` (default)
+            follows the first ``add``: float16 vectors are stored as float16, anything else as
+            float32.  Float16 halves the bytes per row (twice the rows per GPU, ~1.9x the
+            queries/s) at the cost of rounding the embeddings once.
         :param init_size: initial capacity in vectors (allocated on the first ``add``).
         :param alloc_size: minimum growth step in vectors.
         :param device: HIP device ordinal holding the index.
@@ -52,6 +59,7 @@ class InMemoryIndex(Index):
         self._n = 0
         self._init_size, self._alloc_size = int(init_size), int(alloc_size)
         self._device = int(device)
+        self._dtype = None if dtype is None else np.dtype(dtype)
         self._ids_on_device = -1
         self.exact_sum = bool(exact_sum)
         self.last_stats: dict | None = None
@@ -78,7 +86,7 @@ class InMemoryIndex(Index):
         else:
             cap = max(n_total, self._store.capacity + self._alloc_size, int(self._store.capacity * 1.5))
         LOGGER.debug("growing the device vector store to %s rows", cap)
-        grown = native.DeviceIndex(cap, dim, self._device)
+        grown = native.DeviceIndex(cap, dim, self._device, dtype=self._dtype)
         if self._store is not None:
             grown.copy_rows_from(self._store, self._n)
             if self._plan is not None:
@@ -90,9 +98,11 @@ class InMemoryIndex(Index):
 
     def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
         n_new, dim = vectors.shape
+        if self._dtype is None:
+            self._dtype = np.dtype(np.float16) if vectors.dtype == np.float16 else np.dtype(np.float32)
         self._reserve(self._n + n_new, dim)
         self._ids.add(doc_ids, psg_ids, self._n)  # a duplicate passage id raises before anything is modified
-        self._store.upload(np.ascontiguousarray(vectors, dtype=np.float32), self._n)
+        self._store.upload(np.ascontiguousarray(vectors, dtype=self._dtype), self._n)
         self._n += n_new
 
     def consolidate(self) -> None:
@@ -167,7 +177,7 @@ class InMemoryIndex(Index):
         out = df.iloc[src].reset_index(drop=True)
         out["score"] = interp[order].astype(df.dtypes["score"])
         # queries in the order the reference would list them: q_id descending
-        return Ranking(out, name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
+        return Ranking(Ranking._trusted(out), name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
 
     def close(self) -> None:
         """Release device memory now (otherwise released when the object is collected)."""

@@ -20,7 +20,7 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 # every symbol include/ffx.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
-    "ffx_index_create", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
+    "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
     "ffx_index_upload", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
@@ -91,6 +91,8 @@ def lib() -> C.CDLL:
         "ffx_device_count": ([P(C.c_int)], C.c_int),
         "ffx_device_info": ([C.c_int, C.c_char_p, C.c_size_t, P(i64), P(i64), P(i32)], C.c_int),
         "ffx_index_create": ([C.c_int, i64, i32, P(vp)], C.c_int),
+        "ffx_index_create_typed": ([C.c_int, i64, i32, i32, P(vp)], C.c_int),
+        "ffx_index_dtype": ([vp, P(i32)], C.c_int),
         "ffx_index_destroy": ([vp], C.c_int),
         "ffx_index_dim": ([vp, P(i32)], C.c_int),
         "ffx_index_capacity": ([vp, P(i64)], C.c_int),
@@ -167,12 +169,19 @@ def require_device() -> None:
         raise RuntimeError("no HIP device is visible; fast_forward_amd has no CPU fallback")
 
 
-class DeviceIndex:
-    """Owns one ``ffx_index`` (fp32 rows resident in HBM)."""
+DTYPE_F32, DTYPE_F16 = 0, 1
+_DTYPE_CODE = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.float16): DTYPE_F16}
 
-    def __init__(self, capacity_rows: int, dim: int, device: int = 0):
+
+class DeviceIndex:
+    """Owns one ``ffx_index`` (float32 or float16 rows resident in HBM)."""
+
+    def __init__(self, capacity_rows: int, dim: int, device: int = 0, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in _DTYPE_CODE:
+            raise ValueError(f"unsupported row dtype {self.dtype}: float32 or float16")
         h = C.c_void_p()
-        _check(lib().ffx_index_create(device, capacity_rows, dim, C.byref(h)))
+        _check(lib().ffx_index_create_typed(device, capacity_rows, dim, _DTYPE_CODE[self.dtype], C.byref(h)))
         self._h = h
         self.capacity, self.dim, self.device = int(capacity_rows), int(dim), int(device)
 
@@ -184,7 +193,7 @@ class DeviceIndex:
     __del__ = close
 
     def upload(self, rows: np.ndarray, row_offset: int) -> None:
-        rows = _arr(rows, np.float32)
+        rows = _arr(rows, self.dtype)
         assert rows.ndim == 2 and rows.shape[1] == self.dim
         _check(lib().ffx_index_upload(self._h, _ptr(rows), row_offset, rows.shape[0]))
 
@@ -193,7 +202,7 @@ class DeviceIndex:
 
     def gather(self, rows) -> np.ndarray:
         rows = _arr(rows, np.int32)
-        out = np.empty((rows.shape[0], self.dim), dtype=np.float32)
+        out = np.empty((rows.shape[0], self.dim), dtype=self.dtype)
         _check(lib().ffx_index_gather(self._h, _ptr(rows), rows.shape[0], _ptr(out)))
         return out
 

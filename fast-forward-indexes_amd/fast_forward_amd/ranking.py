@@ -82,7 +82,7 @@ class Ranking:
         (query, id) pair and for incomplete ``queries`` (ranking.py:67-121).
         """
         self.name = name
-        if df.duplicated(subset=_KEY).any():
+        if not getattr(df, "_ffx_pairs_unique", False) and df.duplicated(subset=_KEY).any():
             raise ValueError("Only one score per query-document/passage pair is allowed.")
 
         keep = _KEY + ["score"] + (["query"] if "query" in df.columns else [])
@@ -147,6 +147,13 @@ class Ranking:
 
     def _derived(self, df: pd.DataFrame, is_sorted: bool, copy: bool = False) -> "Ranking":
         return Ranking(df, name=self.name, dtype=self._df.dtypes["score"], copy=copy, is_sorted=is_sorted)
+
+    @staticmethod
+    def _trusted(df: pd.DataFrame) -> pd.DataFrame:
+        """Mark a frame whose (q_id, id) pairs are a subset of an existing Ranking's: the
+        constructor then skips the duplicate scan (a string-pair hash of every row)."""
+        object.__setattr__(df, "_ffx_pairs_unique", True)
+        return df
 
     def __add__(self, o: "Ranking | float") -> "Ranking":
         if isinstance(o, Ranking):

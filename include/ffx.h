@@ -47,6 +47,12 @@ extern "C" {
 #define FFX_MODE_FIRSTP 3
 #define FFX_MODE_AVEP 4
 
+/* storage type of index rows.  The reference keeps whatever dtype it is given
+ * (index/memory.py:80-83); float32 queries x float16 rows promote to float32 products in NumPy,
+ * so half rows are widened exactly and scored with the same fp32 arithmetic */
+#define FFX_DTYPE_F32 0
+#define FFX_DTYPE_F16 1
+
 /* ffx_plan_run flags */
 #define FFX_FLAG_EXACT_SUM 1u /* NumPy summation order: scores bit-identical to index/base.py:303 */
 #define FFX_FLAG_SORT 2u      /* also produce the per-query order of ranking.py:115-117 */
@@ -67,7 +73,7 @@ typedef struct ffx_stats {
   int64_t n_queries;
   int64_t n_pairs;           /* P: (query, candidate) pairs                                   */
   int64_t n_rows;            /* R: gathered index rows (= P unless MAXP/AVEP with >1 passage) */
-  double algorithmic_bytes;  /* R*(d*4+4) + P*4*(1+2*interp) + Q*d*4 + (Q+1)*8 */
+  double algorithmic_bytes;  /* R*(d*e+4) + P*4*(1+2*interp) + Q*d*4 + (Q+1)*8, e = bytes/element */
   float ms_expand;           /* pairs -> row list (count, scan, expand)                       */
   float ms_gather_dot;       /* the gather + inner-product kernel                             */
   float ms_reduce;           /* segment max/first/mean + interpolation                        */
@@ -87,16 +93,18 @@ int ffx_device_info(int device, char* name, size_t name_cap, int64_t* total_byte
 /* ---- HBM-resident index: replaces InMemoryIndex storage, index/memory.py:23-131 -------
  * One fp32 matrix of `capacity_rows` x `dim` in device memory, rows in insertion order
  * (row r of the reference's chunk list, memory.py:100-119, is row r here). */
-int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index** out);
+int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index** out); /* fp32 rows */
+int ffx_index_create_typed(int device, int64_t capacity_rows, int32_t dim, int32_t dtype, ffx_index** out);
+int ffx_index_dtype(const ffx_index* idx, int32_t* dtype);
 int ffx_index_destroy(ffx_index* idx);
 int ffx_index_dim(const ffx_index* idx, int32_t* dim);
 int ffx_index_capacity(const ffx_index* idx, int64_t* rows);
 /* copy host rows into rows [row_offset, row_offset+n_rows): InMemoryIndex._add, memory.py:100-119 */
-int ffx_index_upload(ffx_index* idx, const float* host_rows, int64_t row_offset, int64_t n_rows);
+int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, int64_t n_rows); /* rows in the index dtype */
 /* device copy between two indexes on the same device (growing an index) */
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows);
 /* read rows back: InMemoryIndex._get_vectors, memory.py:139-140 / index/util.py:97-98 */
-int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, float* host_out);
+int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, void* host_out); /* in the index dtype */
 /* fill rows with the counter-based synthetic generator shared with the oracle
  * (value of element e of global row g: see fast_forward_amd/synth.py); bench/test data only */
 int ffx_index_fill_synthetic(ffx_index* idx, uint64_t seed, float scale, int64_t row_offset,

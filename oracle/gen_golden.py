@@ -79,13 +79,14 @@ def run_frame(q_names, cand_ids, sparse):
     return Ranking(df, queries={qn: str(i) for i, qn in enumerate(q_names)})
 
 
-def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, sparse_hi, modes, k_psg=None):
-    """Synthetic corpus: docs with psg_lo..psg_hi passages, stored contiguously."""
+def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, sparse_hi, modes, k_psg=None, store=np.float32):
+    """Synthetic corpus: docs with psg_lo..psg_hi passages, stored contiguously.  ``store`` is
+    the dtype handed to ``Index.add`` (the reference keeps it: index/memory.py:80-83)."""
     rng = np.random.default_rng(seed)
     per_doc = rng.integers(psg_lo, psg_hi + 1, size=n_docs)
     n_rows = int(per_doc.sum())
     doc_of_row = np.repeat(np.arange(n_docs), per_doc).astype(np.int32)
-    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    vectors = synth.rows(seed, scale, 0, n_rows, dim).astype(store)
     qvecs = synth.rows(seed + 1000, scale, 0, n_q, dim)
     doc_ids = [f"D{d}" for d in doc_of_row]
     psg_ids = [f"P{r}" for r in range(n_rows)]
@@ -100,6 +101,7 @@ def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, spar
         "doc_of_row": doc_of_row, "cand_docs": cand_docs, "cand_psgs": cand_psgs,
         "sparse_doc": sparse_doc, "sparse_psg": sparse_psg,
         "vectors_sha": sha(vectors), "queries_sha": sha(qvecs), "q_names": np.array(q_names),
+        "store": np.dtype(store).name,
     }
     for mname in modes:
         mode = MODES[mname]
@@ -230,6 +232,20 @@ def known_answers():
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":  # add one case without rewriting the others
+        manifest = json.loads((OUT / "manifest.json").read_text())
+        if sys.argv[2] == "f16":
+            manifest["cases"]["d768_f16"] = scoring_case(
+                "d768_f16", seed=3, dim=768, n_docs=64, psg_lo=1, psg_hi=8, n_q=8, k=32, scale=1.0,
+                sparse_hi=25.0, modes=["PASSAGE", "FIRSTP", "AVEP", "MAXP"], store=np.float16)
+            manifest["cases"]["dim100_f16"] = scoring_case(
+                "dim100_f16", seed=200, dim=100, n_docs=40, psg_lo=1, psg_hi=3, n_q=4, k=12, scale=1.0,
+                sparse_hi=10.0, modes=["MAXP", "AVEP"], store=np.float16)
+            manifest["cases"]["dim128_f16"] = scoring_case(
+                "dim128_f16", seed=201, dim=128, n_docs=60, psg_lo=1, psg_hi=3, n_q=4, k=20, scale=1.0,
+                sparse_hi=10.0, modes=["MAXP"], store=np.float16)
+        (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
+        return
     manifest = {"reference": "mrjleo/fast-forward-indexes v0.8.0 (/root/reference)",
                 "numpy": np.__version__, "pandas": pd.__version__, "cases": {}}
     manifest["cases"]["known_answers"] = known_answers()

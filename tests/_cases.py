@@ -70,7 +70,8 @@ def load_scoring_case(name: str) -> ScoringCase:
     z = np.load(GOLDEN / f"{name}.npz")
     seed, dim, scale, n_rows = int(z["seed"]), int(z["dim"]), float(z["scale"]), int(z["n_rows"])
     n_q = z["cand_docs"].shape[0]
-    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    store = np.dtype(str(z["store"])) if "store" in z.files else np.dtype(np.float32)
+    vectors = synth.rows(seed, scale, 0, n_rows, dim).astype(store)  # dtype handed to Index.add
     queries = synth.rows(seed + 1000, scale, 0, n_q, dim)
     assert sha(vectors) == str(z["vectors_sha"]), "synthetic generator drifted from the fixture"
     assert sha(queries) == str(z["queries_sha"])
@@ -88,7 +89,8 @@ def load_scoring_case(name: str) -> ScoringCase:
     )
 
 
-SCORING_CASES = ["config1", "d768", "s2_sub", "dim5", "dim20", "dim100", "dim300", "dim384", "dim1024"]
+SCORING_CASES = ["config1", "d768", "s2_sub", "dim5", "dim20", "dim100", "dim300", "dim384", "dim1024",
+                 "d768_f16", "dim100_f16", "dim128_f16"]  # *_f16: float16 rows handed to the reference
 
 
 def bits(a) -> np.ndarray:

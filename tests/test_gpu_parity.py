@@ -20,7 +20,7 @@ FAST_TOL = 1e-4  # north_star: "match the reference NumPy scores to 1e-4 fp32"
 
 
 def device_index(case) -> native.DeviceIndex:
-    idx = native.DeviceIndex(case.vectors.shape[0], case.vectors.shape[1])
+    idx = native.DeviceIndex(case.vectors.shape[0], case.vectors.shape[1], dtype=case.vectors.dtype)
     idx.upload(case.vectors, 0)
     idx.set_doc_rows(case.doc_off, case.doc_rows)
     idx.set_psg_rows(case.psg_row)
@@ -179,13 +179,15 @@ def test_many_passages_per_document():
     idx.close()
 
 
+@pytest.mark.parametrize("store", [np.float32, np.float16])
 @pytest.mark.parametrize("d", [64, 128, 256, 384, 512, 768, 1024, 8, 24, 1000, 2048, 4100])
-def test_every_kernel_variant_exact(d):
-    """Each gather_dot instantiation (and the generic kernel) against the oracle, bit for bit."""
+def test_every_kernel_variant_exact(d, store):
+    """Each gather_dot instantiation (and the generic kernel), float32 and float16 rows, against
+    the oracle and against NumPy itself, bit for bit."""
     n, nq, k = 257, 3, 150
-    vectors = synth.rows(31 + d, 1.0, 0, n, d)
+    vectors = synth.rows(31 + d, 1.0, 0, n, d).astype(store)
     queries = synth.rows(32 + d, 1.0, 0, nq, d)
-    idx = native.DeviceIndex(n, d)
+    idx = native.DeviceIndex(n, d, dtype=store)
     idx.upload(vectors, 0)
     idx.set_doc_rows(np.arange(n + 1), np.arange(n))
     idx.set_psg_rows(np.arange(n))
@@ -195,21 +197,28 @@ def test_every_kernel_variant_exact(d):
     ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=True)
     want, _ = fo.score(vectors, np.arange(n + 1), np.arange(n), np.arange(n), queries, pair_off, pair_ids, 2)
     assert np.array_equal(bits(ff), bits(want)), f"d={d} variant {st['kernel_variant']}"
+    assert (st["kernel_variant"] >= 1000) == (store == np.float16)
     ref = np.sum(queries[np.repeat(np.arange(nq), k)] * vectors[pair_ids], axis=1)  # NumPy itself
+    assert ref.dtype == np.float32
     assert np.array_equal(bits(ff), bits(ref))
     ff_fast, _, _, st = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=False)
     assert np.abs(ff_fast - want).max() <= FAST_TOL * max(1.0, float(np.abs(want).max())), f"d={d} variant {st['kernel_variant']}"
     idx.close()
 
 
-def test_synthetic_fill_matches_host_generator():
+@pytest.mark.parametrize("store", [np.float32, np.float16])
+def test_synthetic_fill_matches_host_generator(store):
     d, n = 768, 1000
-    idx = native.DeviceIndex(n, d)
+    idx = native.DeviceIndex(n, d, dtype=store)
     idx.fill_synthetic(seed=5, scale=0.0625, row_offset=0, n_rows=n, first_global_row=123456)
-    rows = np.array([0, 1, 77, 999], dtype=np.int32)
+    rows = np.arange(0, n, dtype=np.int32)  # every element: narrowing to half must round twice, as NumPy does
     got = idx.gather(rows)
-    for i, r in enumerate(rows):
-        assert np.array_equal(bits(got[i]), bits(synth.rows(5, 0.0625, 123456 + int(r), 1, d)[0]))
+    assert got.dtype == store
+    want = synth.rows(5, 0.0625, 123456, n, d).astype(store)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    idx.fill_synthetic(seed=6, scale=float(1 / np.sqrt(768)), row_offset=0, n_rows=n, first_global_row=7)
+    want = synth.rows(6, float(1 / np.sqrt(768)), 7, n, d).astype(store)
+    assert np.array_equal(idx.gather(rows).view(np.uint8), want.view(np.uint8))
     idx.close()
 
 

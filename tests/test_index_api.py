@@ -187,7 +187,7 @@ def test_partial_ids_fixture_all_modes():
             assert np.float32(have[k]).view(np.uint32) == np.float32(want[k]).view(np.uint32), (mname, k)
 
 
-@pytest.mark.parametrize("name", ["config1", "d768", "s2_sub"])
+@pytest.mark.parametrize("name", ["config1", "d768", "s2_sub", "d768_f16"])
 def test_end_to_end_frames_match_reference(name):
     """first_stage -> index(first_stage) -> interpolate, compared frame against frame with the
     reference's output: identical scores (bits) and identical ordering (modulo exact ties)."""
@@ -196,6 +196,7 @@ def test_end_to_end_frames_match_reference(name):
         qvecs = case.queries
         idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mode]))
         idx.add(case.vectors, doc_ids=case.doc_names, psg_ids=case.psg_names)
+        assert idx._store.dtype == case.vectors.dtype  # float16 vectors stay float16, as in the reference
         pair_off, _, sparse, names = case.pairs(mode)
         pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
         df = pd.DataFrame({"q_id": [case.q_names[q] for q in pair_q], "id": names, "score": sparse})

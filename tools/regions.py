@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""The three timed regions of SURVEY.md section 8(d) side by side (bench.py's `value` is region i+):
+  (i+)  HBM-resident inputs -> HBM-resident outputs           plan.run
+  (ii)  host buffers in -> host buffers out (PCIe inclusive)  ffx_score / set_pairs+run+fetch
+  (iii) Ranking frame in -> Ranking frame out                 Index.__call__ + interpolate / rerank
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+sys.path.insert(0, str(ROOT))
+from fast_forward_amd import Ranking, native, synth  # noqa: E402
+from fast_forward_amd.encoder import LambdaEncoder  # noqa: E402
+from fast_forward_amd.index import InMemoryIndex, Mode  # noqa: E402
+import bench as B  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=8_841_823)
+ap.add_argument("--queries", type=int, default=6980)
+ap.add_argument("--k", type=int, default=5000)
+ap.add_argument("--api-rows", type=int, default=1_000_000)
+ap.add_argument("--api-queries", type=int, default=200)
+ap.add_argument("--api-k", type=int, default=1000)
+args = ap.parse_args()
+d, seed = 768, 2024
+scale = float(1 / np.sqrt(d))
+out = {}
+
+idx = native.DeviceIndex(args.rows, d)
+idx.fill_synthetic(seed, scale, 0, args.rows)
+idx.set_doc_rows(np.arange(args.rows + 1, dtype=np.int64), np.arange(args.rows, dtype=np.int32))
+idx.set_psg_rows(np.arange(args.rows, dtype=np.int32))
+ids, sparse = B.candidates(args.rows, args.queries, args.k, seed)
+pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
+queries = synth.rows(seed + 3, scale, 0, args.queries, d)
+plan = native.Plan(idx)
+plan.set_queries(queries)
+plan.set_pairs(pair_off, ids, sparse, 2)
+for _ in range(2):
+    plan.run(0.1)
+plan.sync()
+t0 = time.perf_counter()
+for _ in range(5):
+    plan.run(0.1)
+plan.sync()
+out["i_device_resident_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+# (ii) persistent plan, host buffers each time
+ts = []
+for _ in range(4):
+    t0 = time.perf_counter()
+    plan.set_queries(queries)
+    plan.set_pairs(pair_off, ids, sparse, 2)
+    plan.run(0.1)
+    ff, interp, _ = plan.fetch(interp=True)
+    ts.append(time.perf_counter() - t0)
+out["ii_host_to_host_persistent_plan_ms"] = min(ts) * 1e3
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    native.score(idx, queries, pair_off, ids, 2, sparse, 0.1)
+    ts.append(time.perf_counter() - t0)
+out["ii_host_to_host_one_shot_ffx_score_ms"] = min(ts) * 1e3
+out["ii_bytes_moved"] = int(queries.nbytes + ids.nbytes + sparse.nbytes + pair_off.nbytes + 2 * ff.nbytes)
+out["queries"], out["k"] = args.queries, args.k
+plan.close()
+idx.close()
+
+# (iii) the Python API with string ids, reduced size (host-bound)
+n, nq, k = args.api_rows, args.api_queries, args.api_k
+qv = synth.rows(seed + 3, scale, 0, nq, d)
+index = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=Mode.MAXP, init_size=n)
+t0 = time.perf_counter()
+step = 100_000
+for lo in range(0, n, step):
+    hi = min(n, lo + step)
+    index.add(synth.rows(seed, scale, lo, hi - lo, d), doc_ids=[f"D{i}" for i in range(lo, hi)])
+out["iii_add_s"] = time.perf_counter() - t0
+cid, csp = B.candidates(n, nq, k, seed)
+df = pd.DataFrame({"q_id": np.repeat([f"q{i:05d}" for i in range(nq)], k), "id": [f"D{i}" for i in cid], "score": csp})
+t0 = time.perf_counter()
+first = Ranking(df, queries={f"q{i:05d}": str(i) for i in range(nq)})
+out["iii_ranking_ctor_s"] = time.perf_counter() - t0
+index(first)  # warm
+t0 = time.perf_counter()
+dense = index(first)
+out["iii_index_call_s"] = time.perf_counter() - t0
+t0 = time.perf_counter()
+final = first.interpolate(dense, 0.1)
+out["iii_interpolate_s"] = time.perf_counter() - t0
+t0 = time.perf_counter()
+fused = index.rerank(first, 0.1)
+out["iii_rerank_fused_s"] = time.perf_counter() - t0
+out["iii_pairs"] = nq * k
+out["iii_same_result"] = bool(fused == final)
+out["iii_kernel_ms"] = index.last_stats["ms_gather_dot"]
+print(json.dumps(out, indent=1))
