@@ -519,8 +519,10 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   const int2* desc = pl->desc.as<int2>();
   hipStream_t st = pl->stream;
   constexpr int HALF = sizeof(T) == 2 ? 1000 : 0;
-  // half rows carry half the bytes: keep twice the rows in flight
-  constexpr int UL = sizeof(T) == 2 ? 8 : 4;
+  // 4 rows in flight per wave for both row types (8 is slower: tools/kernel_ab.py,
+  // profiles/r01/kernel_ab_f16.log); half rows run best with 16-row tiles, float rows with 8
+  constexpr int UL = 4;
+  constexpr int TL = sizeof(T) == 2 ? 16 : 8;
 #define FFX_EXACT(LEAVES, NPER, U, ID)                                                            \
   do {                                                                                            \
     constexpr int RPW_ = 64 / (8 * LEAVES);                                                       \
@@ -567,11 +569,11 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   if (exact) {
     switch (d) {
       case 768:
-        ffx::gather_dot_exact_lds_kernel<T, 3, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
+        ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R);
         pl->variant = 111 + HALF;
         break;
       case 1024:
-        ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R);
+        ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R);
         pl->variant = 112 + HALF;
         break;
       case 512: FFX_EXACT(4, 16, 2, 103); break;
@@ -587,10 +589,10 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     }
   } else {
     switch (d) {
-      case 768: ffx::gather_dot_fast_kernel<T, 3, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 211 + HALF; break;
-      case 1024: ffx::gather_dot_fast_kernel<T, 4, UL / 2, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 212 + HALF; break;
-      case 512: ffx::gather_dot_fast_kernel<T, 2, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213 + HALF; break;
-      case 256: ffx::gather_dot_fast_kernel<T, 1, UL, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214 + HALF; break;
+      case 768: ffx::gather_dot_fast_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 211 + HALF; break;
+      case 1024: ffx::gather_dot_fast_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 212 + HALF; break;
+      case 512: ffx::gather_dot_fast_kernel<T, 2, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213 + HALF; break;
+      case 256: ffx::gather_dot_fast_kernel<T, 1, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214 + HALF; break;
       default:
         if (d % 4 == 0) {
           ffx::gather_dot_fast_generic_kernel<T><<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);

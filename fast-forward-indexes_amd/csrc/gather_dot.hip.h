@@ -71,23 +71,26 @@ __device__ __forceinline__ float load1(const T* p) {
   else return (float)*p;
 }
 
-// 4 consecutive elements (16 B of float / 8 B of half), naturally aligned
+// 4 consecutive elements (16 B of float / 8 B of half), naturally aligned.  Loaded values stay
+// in their storage type while they wait in registers (a half row in flight costs half the VGPRs)
+// and are widened where they are used.
+template <typename T> struct raw4 { typedef f32x4 type; };
+template <> struct raw4<_Float16> { typedef f16x4 type; };
+
 template <typename T, bool NT>
-__device__ __forceinline__ float4 load4(const T* p) {
-  if constexpr (sizeof(T) == 4) {
-    const f32x4* q = reinterpret_cast<const f32x4*>(p);
-    f32x4 t;
-    if constexpr (NT) t = __builtin_nontemporal_load(q);
-    else t = *q;
-    return make_float4(t.x, t.y, t.z, t.w);
-  } else {
-    const f16x4* q = reinterpret_cast<const f16x4*>(p);
-    f16x4 t;
-    if constexpr (NT) t = __builtin_nontemporal_load(q);
-    else t = *q;
-    return make_float4((float)t.x, (float)t.y, (float)t.z, (float)t.w);
-  }
+__device__ __forceinline__ typename raw4<T>::type load4raw(const T* p) {
+  const typename raw4<T>::type* q = reinterpret_cast<const typename raw4<T>::type*>(p);
+  if constexpr (NT) return __builtin_nontemporal_load(q);
+  else return *q;
 }
+
+template <typename V>
+__device__ __forceinline__ float4 widen4(V t) {
+  return make_float4((float)t.x, (float)t.y, (float)t.z, (float)t.w);
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ float4 load4(const T* p) { return widen4(load4raw<T, NT>(p)); }
 
 constexpr int exact_default_passes(int leaves) {
   const int rpw = 64 / (8 * leaves);
@@ -234,7 +237,7 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
 #pragma unroll 1
   for (int b = 0; b < TILE; b += U) {
     if (b >= n_here) break;
-    float4 v[U][NCH];
+    typename raw4<T>::type v[U][NCH];
     int qn[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -243,7 +246,7 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
       qn[u] = __builtin_amdgcn_readlane(my.y, t);
       const T* rowp = vectors + (size_t)rid * D + 4 * lane;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) v[u][c] = load4<T, NT>(rowp + 256 * c);
+      for (int c = 0; c < NCH; ++c) v[u][c] = load4raw<T, NT>(rowp + 256 * c);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -255,11 +258,12 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
+        const float4 w = widen4(v[u][c]);
         float4 p;
-        p.x = __fmul_rn(q[c].x, v[u][c].x);
-        p.y = __fmul_rn(q[c].y, v[u][c].y);
-        p.z = __fmul_rn(q[c].z, v[u][c].z);
-        p.w = __fmul_rn(q[c].w, v[u][c].w);
+        p.x = __fmul_rn(q[c].x, w.x);
+        p.y = __fmul_rn(q[c].y, w.y);
+        p.z = __fmul_rn(q[c].z, w.z);
+        p.w = __fmul_rn(q[c].w, w.w);
         *reinterpret_cast<float4*>(buf + woff[c]) = p;
       }
       __builtin_amdgcn_wave_barrier();
@@ -294,7 +298,7 @@ gather_dot_fast_kernel(const T* __restrict__ vectors, const float* __restrict__ 
 #pragma unroll
   for (int b = 0; b < TILE; b += U) {
     if (b >= n_here) break;
-    float4 v[U][NCH];
+    typename raw4<T>::type v[U][NCH];
     int qn[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -303,7 +307,7 @@ gather_dot_fast_kernel(const T* __restrict__ vectors, const float* __restrict__ 
       qn[u] = __builtin_amdgcn_readlane(my.y, t);
       const T* rowp = vectors + (size_t)rid * D + 4 * lane;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) v[u][c] = load4<T, NT>(rowp + 256 * c);
+      for (int c = 0; c < NCH; ++c) v[u][c] = load4raw<T, NT>(rowp + 256 * c);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -316,10 +320,11 @@ gather_dot_fast_kernel(const T* __restrict__ vectors, const float* __restrict__ 
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        acc = fmaf(q[c].x, v[u][c].x, acc);
-        acc = fmaf(q[c].y, v[u][c].y, acc);
-        acc = fmaf(q[c].z, v[u][c].z, acc);
-        acc = fmaf(q[c].w, v[u][c].w, acc);
+        const float4 w = widen4(v[u][c]);
+        acc = fmaf(q[c].x, w.x, acc);
+        acc = fmaf(q[c].y, w.y, acc);
+        acc = fmaf(q[c].z, w.z, acc);
+        acc = fmaf(q[c].w, w.w, acc);
       }
       acc = butterfly<8>(acc);
       if (lane == 0 && (b + u) < n_here) rs[base + b + u] = acc;

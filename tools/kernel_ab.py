@@ -21,12 +21,14 @@ ap.add_argument("--rows", type=int, default=8_841_823)
 ap.add_argument("--queries", type=int, default=6980)
 ap.add_argument("--k", type=int, default=5000)
 ap.add_argument("--rounds", type=int, default=6)
-ap.add_argument("--variants", default="0,901,902,903,904,905,906,907,908,909,fast,951,952,953,954")
+ap.add_argument("--variants", default="0,900,907,911,913,916,919,920,fast,951,953,955,958,959")
+ap.add_argument("--store", default="f32", choices=["f32", "f16"])
 args = ap.parse_args()
 
 d, seed = 768, 2024
 scale = float(1 / np.sqrt(d))
-idx = native.DeviceIndex(args.rows, d)
+store = np.float16 if args.store == "f16" else np.float32
+idx = native.DeviceIndex(args.rows, d, dtype=store)
 idx.fill_synthetic(seed, scale, 0, args.rows)
 idx.set_doc_rows(np.arange(args.rows + 1, dtype=np.int64), np.arange(args.rows, dtype=np.int32))
 idx.set_psg_rows(np.arange(args.rows, dtype=np.int32))
@@ -61,7 +63,8 @@ for rnd in range(args.rounds + 1):
             continue
         times[v].append(st["ms_gather_dot"])
 rows = args.queries * args.k
-out = {v: {"ms_mean": float(np.mean(t)), "ms_min": float(np.min(t)), "GBs_mean": rows * 3076 / np.mean(t) / 1e6} for v, t in times.items()}
+row_bytes = d * np.dtype(store).itemsize + 4
+out = {v: {"ms_mean": float(np.mean(t)), "ms_min": float(np.min(t)), "GBs_mean": rows * row_bytes / np.mean(t) / 1e6} for v, t in times.items()}
 for v, r in sorted(out.items(), key=lambda kv: kv[1]["ms_mean"]):
     print(f"{v:>5}  mean {r['ms_mean']:.3f} ms  min {r['ms_min']:.3f} ms  {r['GBs_mean']:.0f} GB/s")
 print(json.dumps(out))
