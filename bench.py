@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--layout", default="single", choices=["single", "multi"],
                     help="single: 1 passage per document (MS MARCO passage); multi: 1..8 passages per document")
     ap.add_argument("--sum", default="exact", choices=["exact", "fast"], help="summation order of gather_dot")
-    ap.add_argument("--store", default="f32", choices=["f32", "f16"], help="row storage type of the index")
+    ap.add_argument("--store", default="f32", choices=["f32", "f16", "pq"], help="row storage: float32, float16, or PQ codes (M=8, Ks=256)")
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--sort", action="store_true", help="also order every query's candidates on the device")
     ap.add_argument("--seed", type=int, default=2024)
@@ -108,7 +108,14 @@ def cpu_baseline(args, doc_off, n_docs, scale):
     counts = (doc_off[uniq + 1] - doc_off[uniq]).astype(np.int64)
     sub_off = np.concatenate([[0], np.cumsum(counts)])
     rows_global = np.concatenate([np.arange(doc_off[u], doc_off[u + 1]) for u in uniq]) if args.layout == "multi" else doc_off[uniq]
-    vecs = fo.synth_row_list(args.seed, scale, rows_global, args.dim)
+    if args.store == "pq":  # rebuild the decoded rows the device scores: codes -> codewords
+        m, ks, ds = 8, 256, args.dim // 8
+        book = synth.rows(args.seed + 9, scale, 0, m * ks, ds).reshape(m, ks, ds)
+        elem = (rows_global[:, None] * m + np.arange(m)[None, :]).astype(np.uint64)
+        codes = ((synth.mix64(elem.reshape(-1), args.seed) >> np.uint64(32)) % np.uint64(ks)).astype(np.int64).reshape(-1, m)
+        vecs = np.concatenate([book[j][codes[:, j]] for j in range(m)], axis=1)
+    else:
+        vecs = fo.synth_row_list(args.seed, scale, rows_global, args.dim)
     if args.store == "f16":  # the index rounds rows to float16 once; NumPy then widens them back
         vecs = vecs.astype(np.float16).astype(np.float32)
     queries = synth.rows(args.seed + 3, scale, 0, nq, args.dim)
@@ -266,8 +273,11 @@ def main():
     n_docs = doc_off.shape[0] - 1
 
     t_setup = time.perf_counter()
-    store = np.float16 if args.store == "f16" else np.float32
-    index = native.DeviceIndex(args.rows, args.dim, device=0, dtype=store)
+    store = {"f16": np.float16, "pq": np.uint8}.get(args.store, np.float32)
+    pq_m, pq_ks = 8, 256
+    index = native.DeviceIndex(args.rows, pq_m if args.store == "pq" else args.dim, device=0, dtype=store)
+    if args.store == "pq":  # synthetic codebook [M][Ks][Ds] and uniform random codes
+        index.set_codebook(synth.rows(args.seed + 9, scale, 0, pq_m * pq_ks, args.dim // pq_m).reshape(pq_m, pq_ks, -1))
     index.fill_synthetic(args.seed, scale, 0, args.rows)
     index.set_doc_rows(doc_off, np.arange(args.rows, dtype=np.int32))
     index.set_psg_rows(np.arange(args.rows, dtype=np.int32))
@@ -296,7 +306,8 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     st = plan.stats()
 
-    row_bytes = args.dim * np.dtype(store).itemsize + 4  # per gathered row, payload + int32 row id
+    # per gathered row, payload + int32 row id
+    row_bytes = (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize) + 4
     kern_avg_ms = float(np.mean(kern_ms))
     traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
     if traffic is None:
@@ -319,16 +330,18 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} {'fp16' if args.store == 'f16' else 'fp32'} InMemoryIndex in HBM, "
+            "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} { {'f16': 'fp16', 'pq': 'PQ(M=8,Ks=256)'}.get(args.store, 'fp32') } InMemoryIndex in HBM, "
                         f"{args.queries} queries, k={args.k}, Mode.{args.mode}, alpha={args.alpha}, "
                         f"{'1 passage/doc' if args.layout == 'single' else '1..8 passages/doc'}, sum={args.sum}"
                         f"{', device sort' if args.sort else ''}",
             "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
             "layout": args.layout, "sum": args.sum, "pairs": st["n_pairs"], "gathered_rows": st["n_rows"],
-            "sharding": "none (1 GPU)", "index_bytes": args.rows * args.dim * np.dtype(store).itemsize, "store": args.store,
+            "sharding": "none (1 GPU)", "index_bytes": args.rows * (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize), "store": args.store,
         },
         "roofline": {
             "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']})",
+            **({"note": "PQ rows: 12 algorithmic HBM bytes per row; the kernel is bound by L2->CU codeword traffic "
+                        "(d*4 B per row), so the HBM fraction is not the figure of merit here"} if args.store == "pq" else {}),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": st["n_rows"] * row_bytes, "kernel_ms_avg": kern_avg_ms,
@@ -337,7 +350,7 @@ def main():
         "stages_ms": {"expand": stage_ms["ms_expand"], "gather_dot": kern_avg_ms, "reduce_interp": stage_ms["ms_reduce"],
                       "sort": stage_ms["ms_sort"], "device_total": stage_ms["ms_total"]},
         "device": dev["name"], "setup_s": t_setup,
-        "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize)),
+        "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize)),
     }
 
     if args.cpu_sample_queries > 0:

@@ -151,13 +151,14 @@ merge_kernel(const float* __restrict__ recv, const int32_t* __restrict__ slot, c
 }
 
 // ---- row copy-out for _get_vectors (index/memory.py:139-140) --------------------------------
+template <typename W>
 __global__ void __launch_bounds__(256)
-gather_rows_kernel(const uint16_t* __restrict__ vectors, int d, const int32_t* __restrict__ rows,
-                   int64_t n, uint16_t* __restrict__ out) {
+gather_rows_kernel(const W* __restrict__ vectors, int d, const int32_t* __restrict__ rows,
+                   int64_t n, W* __restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= n) return;
-  const uint16_t* src = vectors + (size_t)rows[r] * d;
-  uint16_t* dst = out + (size_t)r * d;
+  const W* src = vectors + (size_t)rows[r] * d;
+  W* dst = out + (size_t)r * d;
   for (int c = threadIdx.x & 63; c < d; c += 64) dst[c] = src[c];
 }
 
@@ -184,6 +185,14 @@ fill_synthetic_kernel(T* __restrict__ dst, int64_t n_elems, uint64_t first_elem,
     asm volatile("" : "+v"(x));
     dst[e] = (T)x;
   }
+}
+
+// synthetic product-quantizer codes: byte e = mix(e) mod Ks
+__global__ void __launch_bounds__(256)
+fill_codes_kernel(uint8_t* __restrict__ dst, int64_t n_elems, uint64_t first_elem, uint64_t seed, int ks) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride)
+    dst[e] = (uint8_t)((mix64(first_elem + (uint64_t)e, seed) >> 32) % (uint64_t)ks);
 }
 
 __global__ void __launch_bounds__(256)

@@ -108,6 +108,11 @@ struct ffx_index {
   int64_t capacity = 0;
   void* vectors = nullptr;
   char* row_ptr(int64_t row) const { return static_cast<char*>(vectors) + (size_t)row * dim * elem; }
+  // what a query vector looks like: dim for float/half rows, M*Ds for product-quantized rows
+  int32_t qdim = 0;
+  DevBuf codebook;    // FFX_DTYPE_PQ8: float[M][Ks][Ds]
+  DevBuf codebook_t;  // the same, transposed to [M][Ds][Ks] (coalesced reads when tabulating ADC)
+  int32_t pq_ks = 0, pq_ds = 0;
   // id structure (device copies)
   DevBuf doc_off;   // int32[n_docs+1]
   DevBuf doc_rows;  // int32[n_doc_rows]
@@ -126,7 +131,7 @@ struct ffx_plan {
   // inputs
   DevBuf queries, pair_off, pair_ids, sparse;
   // workspace
-  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags;
+  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags, lut;
   // outputs
   DevBuf ff, interp, order;
   int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
@@ -190,7 +195,7 @@ int ffx_index_dtype(const ffx_index* idx, int32_t* dtype) {
 int ffx_index_create_typed(int device, int64_t capacity_rows, int32_t dim, int32_t dtype, ffx_index** out) {
   if (!out) return fail(FFX_BAD_ARG, "out is NULL");
   *out = nullptr;
-  if (dtype != FFX_DTYPE_F32 && dtype != FFX_DTYPE_F16) return fail(FFX_BAD_ARG, "unknown dtype %d", dtype);
+  if (dtype != FFX_DTYPE_F32 && dtype != FFX_DTYPE_F16 && dtype != FFX_DTYPE_PQ8) return fail(FFX_BAD_ARG, "unknown dtype %d", dtype);
   if (capacity_rows < 0 || capacity_rows > INT32_MAX) return fail(FFX_BAD_ARG, "capacity_rows out of range (row ids are int32)");
   if (dim <= 0) return fail(FFX_BAD_ARG, "dim must be positive");
   int n = 0;
@@ -205,7 +210,8 @@ int ffx_index_create_typed(int device, int64_t capacity_rows, int32_t dim, int32
   idx->device = device;
   idx->dim = dim;
   idx->dtype = dtype;
-  idx->elem = dtype == FFX_DTYPE_F16 ? 2 : 4;
+  idx->elem = dtype == FFX_DTYPE_F16 ? 2 : (dtype == FFX_DTYPE_PQ8 ? 1 : 4);
+  idx->qdim = dtype == FFX_DTYPE_PQ8 ? 0 : dim;  // PQ: known once the codebook is set
   idx->capacity = capacity_rows;
   const size_t bytes = std::max<size_t>((size_t)capacity_rows * dim * idx->elem, 256);
   hipError_t e = hipMalloc(&idx->vectors, bytes);
@@ -225,6 +231,8 @@ int ffx_index_destroy(ffx_index* idx) {
   idx->doc_rows.release();
   idx->psg_row.release();
   idx->doc_first.release();
+  idx->codebook.release();
+  idx->codebook_t.release();
   delete idx;
   return FFX_OK;
 }
@@ -232,6 +240,34 @@ int ffx_index_destroy(ffx_index* idx) {
 int ffx_index_dim(const ffx_index* idx, int32_t* dim) {
   if (!idx || !dim) return fail(FFX_BAD_ARG, "NULL argument");
   *dim = idx->dim;
+  return FFX_OK;
+}
+
+int ffx_index_query_dim(const ffx_index* idx, int32_t* dim) {
+  if (!idx || !dim) return fail(FFX_BAD_ARG, "NULL argument");
+  *dim = idx->qdim;
+  return FFX_OK;
+}
+
+int ffx_index_set_codebook(ffx_index* idx, const float* codewords, int32_t m, int32_t ks, int32_t ds) {
+  if (!idx || !codewords) return fail(FFX_BAD_ARG, "NULL argument");
+  if (idx->dtype != FFX_DTYPE_PQ8) return fail(FFX_BAD_ARG, "the index does not hold product-quantizer codes");
+  if (m != idx->dim) return fail(FFX_BAD_ARG, "codebook has %d subspaces, rows have %d codes", m, idx->dim);
+  if (ks < 1 || ks > 256 || ds < 1) return fail(FFX_BAD_ARG, "bad codebook shape (Ks must be <= 256 for uint8 codes)");
+  if ((int64_t)m * ds > (1 << 20)) return fail(FFX_BAD_ARG, "decoded dimensionality too large");
+  FFX_HIP(hipSetDevice(idx->device));
+  const size_t bytes = (size_t)m * ks * ds * sizeof(float);
+  FFX_TRY(idx->codebook.ensure(bytes));
+  FFX_HIP(hipMemcpy(idx->codebook.p, codewords, bytes, hipMemcpyHostToDevice));
+  std::vector<float> tr((size_t)m * ks * ds);
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < ks; ++b)
+      for (int c = 0; c < ds; ++c) tr[((size_t)a * ds + c) * ks + b] = codewords[((size_t)a * ks + b) * ds + c];
+  FFX_TRY(idx->codebook_t.ensure(bytes));
+  FFX_HIP(hipMemcpy(idx->codebook_t.p, tr.data(), bytes, hipMemcpyHostToDevice));
+  idx->pq_ks = ks;
+  idx->pq_ds = ds;
+  idx->qdim = m * ds;
   return FFX_OK;
 }
 
@@ -276,9 +312,14 @@ int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, void* 
   if (rc == FFX_OK) {
     hipError_t e = hipMemcpy(drows.p, rows, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-      // rows are copied as raw 2-byte units, so one kernel serves both element types
-      ffx::gather_rows_kernel<<<blocks_for(n_rows, 4), 256>>>(static_cast<const uint16_t*>(idx->vectors), (int)(idx->dim * idx->elem / 2),
-                                                             drows.as<int32_t>(), n_rows, dout.as<uint16_t>());
+      // rows are copied as raw bytes, so one kernel serves every storage type
+      const int row_bytes = (int)(idx->dim * idx->elem);
+      if (row_bytes % 2 == 0)
+        ffx::gather_rows_kernel<uint16_t><<<blocks_for(n_rows, 4), 256>>>(static_cast<const uint16_t*>(idx->vectors), row_bytes / 2,
+                                                                         drows.as<int32_t>(), n_rows, dout.as<uint16_t>());
+      else
+        ffx::gather_rows_kernel<uint8_t><<<blocks_for(n_rows, 4), 256>>>(static_cast<const uint8_t*>(idx->vectors), row_bytes,
+                                                                        drows.as<int32_t>(), n_rows, dout.as<uint8_t>());
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(host_out, dout.p, out_bytes, hipMemcpyDeviceToHost);
@@ -298,7 +339,10 @@ int ffx_index_fill_synthetic(ffx_index* idx, uint64_t seed, float scale, int64_t
   FFX_HIP(hipSetDevice(idx->device));
   const int64_t n_elems = n_rows * idx->dim;
   const unsigned grid = (unsigned)std::min<int64_t>((n_elems + 255) / 256, 256 * 32);
-  if (idx->dtype == FFX_DTYPE_F16)
+  if (idx->dtype == FFX_DTYPE_PQ8)
+    ffx::fill_codes_kernel<<<grid, 256>>>(reinterpret_cast<uint8_t*>(idx->row_ptr(row_offset)), n_elems,
+                                          (uint64_t)first_global_row * (uint64_t)idx->dim, seed, idx->pq_ks > 0 ? idx->pq_ks : 256);
+  else if (idx->dtype == FFX_DTYPE_F16)
     ffx::fill_synthetic_kernel<_Float16><<<grid, 256>>>(reinterpret_cast<_Float16*>(idx->row_ptr(row_offset)), n_elems,
                                                         (uint64_t)first_global_row * (uint64_t)idx->dim, seed, scale);
   else
@@ -373,10 +417,14 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
     ffx_plan_destroy(pl);
     return fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
   }
-  // leaf plan of the exact generic kernel depends on dim only
+  if (idx->qdim <= 0) {
+    ffx_plan_destroy(pl);
+    return fail(FFX_BAD_ARG, "set the codebook (ffx_index_set_codebook) before creating a plan");
+  }
+  // leaf plan of the exact generic kernel depends on the (decoded) dimensionality only
   std::vector<int> bounds;
-  numpy_leaf_plan(0, idx->dim, bounds);
-  bounds.push_back(idx->dim);
+  numpy_leaf_plan(0, idx->qdim, bounds);
+  bounds.push_back(idx->qdim);
   pl->n_leaves = (int)bounds.size() - 1;
   int rc = pl->leaf_start.ensure(bounds.size() * sizeof(int));
   if (rc == FFX_OK && hipMemcpy(pl->leaf_start.p, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
@@ -395,7 +443,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
   if (pl->idx) (void)hipSetDevice(pl->idx->device);
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
-                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start,
+                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut,
                     &pl->flags, &pl->ff, &pl->interp, &pl->order})
     b->release();
   for (auto& e : pl->ev)
@@ -417,7 +465,7 @@ int ffx_plan_set_queries(ffx_plan* pl, const float* host_queries, int64_t n_quer
   if (!pl || n_queries < 0 || (n_queries > 0 && !host_queries)) return fail(FFX_BAD_ARG, "bad argument");
   if (n_queries > INT32_MAX) return fail(FFX_BAD_ARG, "too many queries");
   FFX_HIP(hipSetDevice(pl->idx->device));
-  const size_t bytes = (size_t)n_queries * pl->idx->dim * sizeof(float);
+  const size_t bytes = (size_t)n_queries * pl->idx->qdim * sizeof(float);
   FFX_TRY(pl->queries.ensure(std::max<size_t>(bytes, 16)));
   if (bytes) FFX_HIP(hipMemcpyAsync(pl->queries.p, host_queries, bytes, hipMemcpyHostToDevice, pl->stream));
   FFX_HIP(hipStreamSynchronize(pl->stream));
@@ -610,9 +658,54 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   return FFX_OK;
 }
 
+// product-quantized rows: decode-then-dot (exact, variants 21xx) or ADC (fast, 2300)
+static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
+  const ffx_index* ix = pl->idx;
+  const int d = ix->qdim, M = ix->dim, Ks = ix->pq_ks, Ds = ix->pq_ds;
+  const int R = (int)pl->n_rows;
+  const uint8_t* codes = static_cast<const uint8_t*>(ix->vectors);
+  const float* cb = ix->codebook.as<float>();
+  const float* Q = pl->queries.as<float>();
+  const int2* desc = pl->desc.as<int2>();
+  hipStream_t st = pl->stream;
+  if (exact) {
+    const bool lds_ok = (d == 768 || d == 1024) && Ds % 4 == 0 && (M == 8 || M == 16 || M == 32);
+    if (lds_ok) {
+#define FFX_PQ(NCH, MW) ffx::gather_dot_pq_lds_kernel<NCH, MW, 4, 16><<<blocks_for(R, 64), 256, 0, st>>>(codes, cb, Ks, Ds, Q, desc, rs, R)
+      if (d == 768) {
+        if (M == 8) FFX_PQ(3, 1); else if (M == 16) FFX_PQ(3, 2); else FFX_PQ(3, 4);
+      } else {
+        if (M == 8) FFX_PQ(4, 1); else if (M == 16) FFX_PQ(4, 2); else FFX_PQ(4, 4);
+      }
+#undef FFX_PQ
+      pl->variant = 2100 + M;
+    } else {
+      if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
+      ffx::gather_dot_pq_exact_generic_kernel<<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
+          codes, M, cb, Ks, Ds, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
+      pl->variant = 2199;
+    }
+  } else {
+    const size_t lut_bytes = (size_t)pl->n_queries * M * Ks * sizeof(float);
+    FFX_TRY(pl->lut.ensure(std::max<size_t>(lut_bytes, 16)));
+    if (pl->n_queries > 0) {
+      ffx::pq_lut_kernel<<<dim3((unsigned)pl->n_queries, (unsigned)M), 256, 0, st>>>(Q, ix->codebook_t.as<float>(), M, Ks, Ds,
+                                                                                    pl->lut.as<float>());
+      FFX_HIP(hipGetLastError());
+    }
+    ffx::pq_adc_kernel<<<blocks_for(R, 256), 256, (size_t)M * Ks * sizeof(float), st>>>(codes, M, Ks, pl->lut.as<float>(), desc, rs, R);
+    pl->variant = 2300;
+  }
+  FFX_HIP(hipGetLastError());
+  return FFX_OK;
+}
+
 static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
-  return pl->idx->dtype == FFX_DTYPE_F16 ? launch_gather_dot_t<_Float16>(pl, exact, rs)
-                                         : launch_gather_dot_t<float>(pl, exact, rs);
+  switch (pl->idx->dtype) {
+    case FFX_DTYPE_F16: return launch_gather_dot_t<_Float16>(pl, exact, rs);
+    case FFX_DTYPE_PQ8: return launch_gather_dot_pq(pl, exact, rs);
+    default: return launch_gather_dot_t<float>(pl, exact, rs);
+  }
 }
 
 extern "C" {
@@ -732,8 +825,8 @@ int ffx_plan_stats(ffx_plan* pl, ffx_stats* out) {
   out->n_queries = pl->n_queries;
   out->n_pairs = pl->n_pairs;
   out->n_rows = pl->n_rows;
-  const double d = pl->idx->dim;
-  out->algorithmic_bytes = (double)pl->n_rows * (d * (double)pl->idx->elem + 4) + (double)pl->n_pairs * 4 * (1 + (pl->last_interp ? 2 : 0)) +
+  const double d = pl->idx->qdim;
+  out->algorithmic_bytes = (double)pl->n_rows * ((double)pl->idx->dim * (double)pl->idx->elem + 4) + (double)pl->n_pairs * 4 * (1 + (pl->last_interp ? 2 : 0)) +
                            (double)pl->n_queries * d * 4 + (double)(pl->n_queries + 1) * 8;
   FFX_HIP(hipEventElapsedTime(&out->ms_expand, pl->ev[0], pl->ev[1]));
   FFX_HIP(hipEventElapsedTime(&out->ms_gather_dot, pl->ev[1], pl->ev[2]));
@@ -752,7 +845,7 @@ int ffx_plan_device_ptr(ffx_plan* pl, int which, void** ptr, int64_t* n_elems) {
     case FFX_BUF_FF: b = &pl->ff; break;
     case FFX_BUF_INTERP: b = &pl->interp; break;
     case FFX_BUF_ORDER: b = &pl->order; break;
-    case FFX_BUF_QUERIES: b = &pl->queries; n = (int64_t)pl->n_queries_set * pl->idx->dim; break;
+    case FFX_BUF_QUERIES: b = &pl->queries; n = (int64_t)pl->n_queries_set * pl->idx->qdim; break;
     case FFX_BUF_PAIR_IDS: b = &pl->pair_ids; break;
     case FFX_BUF_SPARSE: b = &pl->sparse; break;
     default: return fail(FFX_BAD_ARG, "unknown buffer selector %d", which);

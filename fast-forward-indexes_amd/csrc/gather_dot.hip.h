@@ -368,18 +368,29 @@ __device__ inline float combine_leaves(int n, const float* leaf_sum, int& next) 
   return __fadd_rn(a, b);
 }
 
+// row accessors for the generic kernels: element i of the (decoded) row as fp32
 template <typename T>
-__global__ void __launch_bounds__(64)
-gather_dot_exact_generic_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
-                                const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
-                                int d, const int* __restrict__ leaf_start, int n_leaves) {
-  extern __shared__ float leaf_sum[];
+struct PlainRow {
+  const T* p;
+  __device__ __forceinline__ float at(int i) const { return (float)p[i]; }
+};
+// product-quantized row: element i = codeword[m][code_m][i % Ds], m = i / Ds
+// (Quantizer.decode of the reference, index/base.py:292-293: concatenated codewords)
+struct PqRow {
+  const uint8_t* codes;   // M code bytes of this row
+  const float* codebook;  // [M][Ks][Ds]
+  int Ks, Ds;
+  __device__ __forceinline__ float at(int i) const {
+    const int m = i / Ds;
+    return codebook[((size_t)m * Ks + codes[m]) * Ds + (i - m * Ds)];
+  }
+};
+
+template <typename Row>
+__device__ __forceinline__ void exact_generic_row(const Row row, const float* __restrict__ q, int d,
+                                                  const int* __restrict__ leaf_start, int n_leaves,
+                                                  float* leaf_sum, float* out) {
   const int lane = threadIdx.x;
-  const long r = blockIdx.x;
-  if (r >= n_rows) return;  // whole block leaves together
-  const int2 de = desc[r];
-  const T* v = vectors + (size_t)de.x * d;
-  const float* q = queries + (size_t)de.y * d;
   const int g = lane >> 3, j = lane & 7;
   for (int leaf = g; leaf < n_leaves; leaf += 8) {
     const int s = leaf_start[leaf];
@@ -387,24 +398,206 @@ gather_dot_exact_generic_kernel(const T* __restrict__ vectors, const float* __re
     float res;
     if (len < 8) {
       res = -0.0f;
-      for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], (float)v[s + i]));
+      for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], row.at(s + i)));
     } else {
       const int lim = len - (len % 8);
-      float acc = __fmul_rn(q[s + j], (float)v[s + j]);
-      for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q[s + i + j], (float)v[s + i + j]));
+      float acc = __fmul_rn(q[s + j], row.at(s + j));
+      for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q[s + i + j], row.at(s + i + j)));
       acc = __fadd_rn(acc, xor1(acc));
       acc = __fadd_rn(acc, xor2(acc));
       acc = __fadd_rn(acc, xor4(acc));
       res = acc;
-      for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], (float)v[s + i]));
+      for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q[s + i], row.at(s + i)));
     }
     if (j == 0) leaf_sum[leaf] = res;
   }
   __syncthreads();
   if (lane == 0) {
     int next = 0;
-    rs[r] = combine_leaves(d, leaf_sum, next);
+    *out = combine_leaves(d, leaf_sum, next);
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+gather_dot_exact_generic_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
+                                const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
+                                int d, const int* __restrict__ leaf_start, int n_leaves) {
+  extern __shared__ float leaf_sum[];
+  const long r = blockIdx.x;
+  if (r >= n_rows) return;  // whole block leaves together
+  const int2 de = desc[r];
+  exact_generic_row(PlainRow<T>{vectors + (size_t)de.x * d}, queries + (size_t)de.y * d, d, leaf_start, n_leaves,
+                    leaf_sum, rs + r);
+}
+
+// ---- product-quantized rows --------------------------------------------------------------------
+// The index stores M code bytes per row; the codebook [M][Ks][Ds] fp32 (768 KB at M=8, Ks=256,
+// Ds=96) stays resident in L2.  "decode-then-dot": the row the reference would build with
+// quantizer.decode (index/base.py:292-293) is never materialised; its elements are fetched from
+// the codebook as they are needed and scored with the same arithmetic as a stored fp32 row, so the
+// scores are bit-identical to decode + np.sum(q * d).  HBM traffic per row drops from d*4 to M
+// bytes; the kernel is bound by L2 -> CU codeword traffic (d*4 bytes per row) and the LDS transpose.
+__global__ void __launch_bounds__(64)
+gather_dot_pq_exact_generic_kernel(const uint8_t* __restrict__ codes, int M, const float* __restrict__ codebook,
+                                   int Ks, int Ds, const float* __restrict__ queries,
+                                   const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int d,
+                                   const int* __restrict__ leaf_start, int n_leaves) {
+  extern __shared__ float leaf_sum[];
+  const long r = blockIdx.x;
+  if (r >= n_rows) return;
+  const int2 de = desc[r];
+  exact_generic_row(PqRow{codes + (size_t)de.x * M, codebook, Ks, Ds}, queries + (size_t)de.y * d, d, leaf_start,
+                    n_leaves, leaf_sum, rs + r);
+}
+
+// d = 256*NCH with 8 leaves (768, 1024), M = 8*MW code bytes per row, Ds % 4 == 0: the float
+// exact_lds kernel with the row loads replaced by codeword loads.  Lane t of a wave holds the
+// codes of work row t (one 8*MW-byte load per tile); for a row, the code words are broadcast with
+// v_readlane and each lane picks the byte of the subspace its 4 elements fall in.
+template <int NCH, int MW, int U, int TILE>
+__global__ void __launch_bounds__(256)
+gather_dot_pq_lds_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ codebook, int Ks, int Ds,
+                         const float* __restrict__ queries, const int2* __restrict__ desc,
+                         float* __restrict__ rs, int n_rows) {
+  constexpr int D = 256 * NCH;
+  constexpr int LL = D / 8;
+  constexpr int NPER = LL / 8;
+  constexpr int LPAD = LL + 8;
+  constexpr int M = 8 * MW;
+  static_assert(TILE % U == 0 && TILE <= 64, "bad tile");
+  __shared__ __attribute__((aligned(16))) float tile[4][8 * LPAD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+  const long base = (long)wave * TILE;
+  if (base >= n_rows) return;
+  const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+  const int my_t = lane < n_here ? lane : n_here - 1;
+  const int2 my = desc[base + my_t];
+  uint32_t mycode[2 * MW];  // the M code bytes of work row `lane`
+  {
+    const uint2* cp = reinterpret_cast<const uint2*>(codes + (size_t)my.x * M);
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+      const uint2 t = cp[w];
+      mycode[2 * w] = t.x;
+      mycode[2 * w + 1] = t.y;
+    }
+  }
+
+  float* buf = tile[wave_in_block];
+  int woff[NCH], wsel[NCH], shift[NCH];
+  const float* cbase[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = 4 * lane + 256 * c;
+    woff[c] = (e / LL) * LPAD + (e % LL);
+    const int m = e / Ds;  // the 4 elements e..e+3 lie in one subspace because Ds % 4 == 0
+    wsel[c] = m >> 2;
+    shift[c] = 8 * (m & 3);
+    cbase[c] = codebook + (size_t)m * Ks * Ds + (e - m * Ds);
+  }
+  const float* rbuf = buf + (lane >> 3) * LPAD + (lane & 7);
+
+  float4 q[NCH];
+  int cur_q = -1;
+#pragma unroll 1
+  for (int b = 0; b < TILE; b += U) {
+    if (b >= n_here) break;
+    float4 v[U][NCH];
+    int qn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (b + u) < n_here ? (b + u) : n_here - 1;
+      qn[u] = __builtin_amdgcn_readlane(my.y, t);
+      uint32_t word[2 * MW];
+#pragma unroll
+      for (int w = 0; w < 2 * MW; ++w) word[w] = __builtin_amdgcn_readlane(mycode[w], t);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        uint32_t sel = word[0];
+#pragma unroll
+        for (int w = 1; w < 2 * MW; ++w) sel = (wsel[c] == w) ? word[w] : sel;
+        const int code = (sel >> shift[c]) & 0xFF;
+        v[u][c] = *reinterpret_cast<const float4*>(cbase[c] + (size_t)code * Ds);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (qn[u] != cur_q) {
+        cur_q = qn[u];
+        const float4* qp = reinterpret_cast<const float4*>(queries + (size_t)cur_q * D) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) q[c] = qp[64 * c];
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float4 p;
+        p.x = __fmul_rn(q[c].x, v[u][c].x);
+        p.y = __fmul_rn(q[c].y, v[u][c].y);
+        p.z = __fmul_rn(q[c].z, v[u][c].z);
+        p.w = __fmul_rn(q[c].w, v[u][c].w);
+        *reinterpret_cast<float4*>(buf + woff[c]) = p;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float acc = rbuf[0];
+#pragma unroll
+      for (int i = 1; i < NPER; ++i) acc = __fadd_rn(acc, rbuf[8 * i]);
+      __builtin_amdgcn_wave_barrier();
+      acc = butterfly<8>(acc);
+      if (lane == 0 && (b + u) < n_here) rs[base + b + u] = acc;
+    }
+  }
+}
+
+// ---- asymmetric distance computation (the "fast" order for PQ rows) --------------------------------
+// <q, decode(codes)> = sum_m <q_m, codeword[m][code_m]>: the M partial products per query are
+// tabulated once (lut[q][m][ks], Q*M*Ks floats), after which a row costs M table look-ups.
+// Different summation order than decode-then-dot, same value to ~1e-6 relative.
+// codebook_t is the codebook transposed to [M][Ds][Ks] so that the Ks threads of a block read
+// consecutive floats.
+__global__ void __launch_bounds__(256)
+pq_lut_kernel(const float* __restrict__ queries, const float* __restrict__ codebook_t, int M, int Ks, int Ds,
+              float* __restrict__ lut) {
+  const int q = blockIdx.x, m = blockIdx.y;
+  const float* qv = queries + ((size_t)q * M + m) * Ds;      // wave-uniform: scalar loads
+  const float* ct = codebook_t + (size_t)m * Ds * Ks;
+  for (int ks = threadIdx.x; ks < Ks; ks += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < Ds; ++i) acc = fmaf(qv[i], ct[(size_t)i * Ks + ks], acc);
+    lut[((size_t)q * M + m) * Ks + ks] = acc;
+  }
+}
+
+// One thread per row.  Rows of a query are contiguous, so almost every block works for a single
+// query: its M*Ks-float table is staged in LDS once and the M look-ups per row hit LDS.
+__global__ void __launch_bounds__(256)
+pq_adc_kernel(const uint8_t* __restrict__ codes, int M, int Ks, const float* __restrict__ lut,
+              const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  extern __shared__ float table[];
+  const long r0 = (long)blockIdx.x * blockDim.x;
+  const long r = r0 + threadIdx.x;
+  const long last = (r0 + blockDim.x - 1) < (long)n_rows ? (r0 + blockDim.x - 1) : (long)n_rows - 1;
+  const int q_first = desc[r0].y, q_last = desc[last].y;   // block-uniform
+  const bool one_query = q_first == q_last;
+  if (one_query) {
+    const float* src = lut + (size_t)q_first * M * Ks;
+    for (int i = threadIdx.x; i < M * Ks; i += blockDim.x) table[i] = src[i];
+  }
+  __syncthreads();
+  if (r >= n_rows) return;
+  const int2 de = desc[r];
+  const uint8_t* c = codes + (size_t)de.x * M;
+  float acc = 0.f;
+  if (one_query) {
+    for (int m = 0; m < M; ++m) acc += table[m * Ks + c[m]];
+  } else {
+    const float* t = lut + (size_t)de.y * M * Ks;
+    for (int m = 0; m < M; ++m) acc += t[(size_t)m * Ks + c[m]];
+  }
+  rs[r] = acc;
 }
 
 }  // namespace ffx

@@ -76,13 +76,20 @@ class Index(abc.ABC):
     def quantizer(self):
         return self._quantizer
 
+    def _on_quantizer_set(self) -> None:
+        """Hook for subclasses (the reference's OnDiskIndex stores the quantizer here)."""
+
     @quantizer.setter
     def quantizer(self, quantizer) -> None:
+        """Attach a trained quantizer; only possible while the index is empty (base.py:104-118)."""
+        from fast_forward_amd.quantizer import Quantizer
+
+        assert isinstance(quantizer, Quantizer)
         if len(self) > 0:
             raise RuntimeError("Quantizers can only be attached to empty indexes.")
-        raise NotImplementedError(
-            "quantized indexes (reference quantizer/, SURVEY.md section 8 row f2) are not part of this build yet"
-        )
+        self._quantizer = quantizer
+        self._on_quantizer_set()
+        quantizer.set_attached()
 
     @property
     def mode(self) -> Mode:
@@ -122,7 +129,8 @@ class Index(abc.ABC):
         ``IndexError`` for an unknown id (base.py:258-277)."""
 
     @abc.abstractmethod
-    def _batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]: ...
+    def _batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:
+        """Stored vectors (codes, if a quantizer is attached) with their ids."""
 
     @abc.abstractmethod
     def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
@@ -136,6 +144,9 @@ class Index(abc.ABC):
 
     @property
     def dim(self) -> int | None:
+        """Dimensionality of the vectors the index takes (before quantization, if any)."""
+        if self._quantizer is not None:
+            return self._quantizer.dims[0]
         return self._get_internal_dim()
 
     @property
@@ -163,7 +174,7 @@ class Index(abc.ABC):
             raise ValueError(f"Input vector dimensionality ({dim}) does not match index dimensionality ({self.dim}).")
         if any(d is None and p is None for d, p in zip(doc_ids, psg_ids)):
             raise ValueError("Vector has neither document nor passage ID.")
-        self._add(vectors, doc_ids, psg_ids)
+        self._add(vectors if self._quantizer is None else self._quantizer.encode(vectors), doc_ids, psg_ids)
 
     # ---- scoring -------------------------------------------------------------------------------------
     def _numbered_queries(self, df: pd.DataFrame) -> tuple[np.ndarray, list[str], list[str]]:
@@ -281,8 +292,13 @@ class Index(abc.ABC):
 
     # ---- iteration ----------------------------------------------------------------------------------------
     def batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:
-        """Vectors, document ids and passage ids in insertion order, ``batch_size`` at a time."""
-        yield from self._batch_iter(batch_size)
+        """Vectors (decoded, if a quantizer is attached), document ids and passage ids in
+        insertion order, ``batch_size`` at a time."""
+        if self._quantizer is None:
+            yield from self._batch_iter(batch_size)
+        else:
+            for codes, doc_ids, psg_ids in self._batch_iter(batch_size):
+                yield self._quantizer.decode(codes), doc_ids, psg_ids
 
     def __iter__(self) -> Iterator[tuple[np.ndarray, "str | None", "str | None"]]:
         for vectors, doc_ids, psg_ids in self.batch_iter(2**9):

@@ -61,6 +61,8 @@ class InMemoryIndex(Index):
         self._device = int(device)
         self._dtype = None if dtype is None else np.dtype(dtype)
         self._ids_on_device = -1
+        self._rotation: np.ndarray | None = None    # OPQ: queries are rotated instead of rows
+        self._host_codes: list[np.ndarray] = []     # codes of a quantizer the device cannot read
         self.exact_sum = bool(exact_sum)
         self.last_stats: dict | None = None
         super().__init__(query_encoder=query_encoder, quantizer=quantizer, mode=mode, encoder_batch_size=encoder_batch_size)
@@ -70,7 +72,16 @@ class InMemoryIndex(Index):
         return self._n
 
     def _get_internal_dim(self) -> int | None:
-        return None if self._store is None else self._store.dim
+        """Length of a stored row: the vector dimensionality, or the code length if quantized."""
+        if self._store is None:
+            return None
+        return self._quantizer.dims[1] if self._quantizer is not None else self._store.dim
+
+    def _stored(self, rows: np.ndarray) -> np.ndarray:
+        """Stored representation of rows: vectors, or codes if a quantizer is attached."""
+        if self._host_codes:
+            return np.concatenate(self._host_codes)[rows]
+        return self._store.gather(rows)
 
     def _get_doc_ids(self) -> set[str]:
         return self._ids.doc_ids
@@ -88,6 +99,8 @@ class InMemoryIndex(Index):
         LOGGER.debug("growing the device vector store to %s rows", cap)
         grown = native.DeviceIndex(cap, dim, self._device, dtype=self._dtype)
         if self._store is not None:
+            if self._store.codebook_shape is not None:
+                grown.set_codebook(self._quantizer.device_codebook()[0])
             grown.copy_rows_from(self._store, self._n)
             if self._plan is not None:
                 self._plan.close()
@@ -97,12 +110,32 @@ class InMemoryIndex(Index):
         self._ids_on_device = -1
 
     def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
-        n_new, dim = vectors.shape
-        if self._dtype is None:
+        """``vectors`` are codes when a quantizer is attached (``Index.add`` encodes first).
+
+        Quantized rows are kept in HBM as uint8 product-quantizer codes when the quantizer exposes
+        a codebook the kernels can read (``Quantizer.device_codebook``); for any other quantizer
+        the codes stay on the host and their decoded vectors are what the device stores -- scoring
+        decoded rows is exactly what the reference does (index/base.py:292-293)."""
+        n_new = vectors.shape[0]
+        codes = None
+        if self._quantizer is not None:
+            book = self._quantizer.device_codebook()
+            if book is None:
+                codes, vectors = vectors, np.ascontiguousarray(self._quantizer.decode(vectors), dtype=np.float32)
+                self._dtype = np.dtype(np.float32)
+            else:
+                self._dtype = np.dtype(np.uint8)
+        elif self._dtype is None:
             self._dtype = np.dtype(np.float16) if vectors.dtype == np.float16 else np.dtype(np.float32)
-        self._reserve(self._n + n_new, dim)
+        fresh = self._store is None
+        self._reserve(self._n + n_new, vectors.shape[1])
+        if (fresh or self._store.codebook_shape is None) and self._dtype == np.uint8:
+            codewords, self._rotation = self._quantizer.device_codebook()
+            self._store.set_codebook(codewords)
         self._ids.add(doc_ids, psg_ids, self._n)  # a duplicate passage id raises before anything is modified
         self._store.upload(np.ascontiguousarray(vectors, dtype=self._dtype), self._n)
+        if codes is not None:
+            self._host_codes.append(np.array(codes, copy=True))
         self._n += n_new
 
     def consolidate(self) -> None:
@@ -119,13 +152,13 @@ class InMemoryIndex(Index):
         rows, owners = self._ids.rows_for(ids, self.mode.value)
         if not rows:
             return np.array([]), []
-        return self._store.gather(np.asarray(rows, dtype=np.int32)), owners
+        return self._stored(np.asarray(rows, dtype=np.int32)), owners
 
     def _batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:
         docs, psgs = self._ids.row_ids(self._n)
         for lo in range(0, self._n, batch_size):
             hi = min(lo + batch_size, self._n)
-            yield self._store.gather(np.arange(lo, hi, dtype=np.int32)), docs[lo:hi], psgs[lo:hi]
+            yield self._stored(np.arange(lo, hi, dtype=np.int32)), docs[lo:hi], psgs[lo:hi]
 
     # ---- scoring ----------------------------------------------------------------------------------
     def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
@@ -135,8 +168,12 @@ class InMemoryIndex(Index):
         if self._store is None:
             raise IndexError("the index is empty")
         q = np.ascontiguousarray(query_vectors, dtype=np.float32)
-        if q.ndim != 2 or q.shape[1] != self._store.dim:
-            raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.dim}).")
+        if q.ndim != 2 or q.shape[1] != self._store.query_dim:
+            raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.query_dim}).")
+        if self._rotation is not None:
+            # OPQ decodes to c @ R.T, and <q, c R^T> = <q R, c>: rotate the Q queries once instead
+            # of every gathered row (equal up to fp32 rounding of the rotation, not bit-identical)
+            q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
         self._sync_ids()
         if self._plan is None:
             self._plan = native.Plan(self._store)

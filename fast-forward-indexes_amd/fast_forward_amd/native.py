@@ -20,7 +20,7 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 # every symbol include/ffx.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
-    "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
+    "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
     "ffx_index_upload", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
         "ffx_index_create": ([C.c_int, i64, i32, P(vp)], C.c_int),
         "ffx_index_create_typed": ([C.c_int, i64, i32, i32, P(vp)], C.c_int),
         "ffx_index_dtype": ([vp, P(i32)], C.c_int),
+        "ffx_index_set_codebook": ([vp, vp, i32, i32, i32], C.c_int),
+        "ffx_index_query_dim": ([vp, P(i32)], C.c_int),
         "ffx_index_destroy": ([vp], C.c_int),
         "ffx_index_dim": ([vp, P(i32)], C.c_int),
         "ffx_index_capacity": ([vp, P(i64)], C.c_int),
@@ -169,21 +171,32 @@ def require_device() -> None:
         raise RuntimeError("no HIP device is visible; fast_forward_amd has no CPU fallback")
 
 
-DTYPE_F32, DTYPE_F16 = 0, 1
-_DTYPE_CODE = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.float16): DTYPE_F16}
+DTYPE_F32, DTYPE_F16, DTYPE_PQ8 = 0, 1, 2
+_DTYPE_CODE = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.float16): DTYPE_F16, np.dtype(np.uint8): DTYPE_PQ8}
 
 
 class DeviceIndex:
-    """Owns one ``ffx_index`` (float32 or float16 rows resident in HBM)."""
+    """Owns one ``ffx_index``: float32 / float16 rows, or uint8 product-quantizer codes (then
+    ``dim`` is the code length M and ``set_codebook`` must follow), resident in HBM."""
 
     def __init__(self, capacity_rows: int, dim: int, device: int = 0, dtype=np.float32):
         self.dtype = np.dtype(dtype)
         if self.dtype not in _DTYPE_CODE:
-            raise ValueError(f"unsupported row dtype {self.dtype}: float32 or float16")
+            raise ValueError(f"unsupported row dtype {self.dtype}: float32, float16 or uint8 (PQ codes)")
         h = C.c_void_p()
         _check(lib().ffx_index_create_typed(device, capacity_rows, dim, _DTYPE_CODE[self.dtype], C.byref(h)))
         self._h = h
         self.capacity, self.dim, self.device = int(capacity_rows), int(dim), int(device)
+        self.query_dim = 0 if self.dtype == np.uint8 else int(dim)
+        self.codebook_shape: tuple[int, int, int] | None = None
+
+    def set_codebook(self, codewords: np.ndarray) -> None:
+        """Codewords ``[M, Ks, Ds]`` float32 of the product quantizer whose codes the rows hold."""
+        codewords = _arr(codewords, np.float32)
+        m, ks, ds = codewords.shape
+        _check(lib().ffx_index_set_codebook(self._h, _ptr(codewords), m, ks, ds))
+        self.query_dim = m * ds
+        self.codebook_shape = (m, ks, ds)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -248,7 +261,7 @@ class Plan:
 
     def set_queries(self, queries: np.ndarray) -> None:
         queries = _arr(queries, np.float32)
-        assert queries.ndim == 2 and queries.shape[1] == self._index.dim, "query dimensionality does not match the index"
+        assert queries.ndim == 2 and queries.shape[1] == self._index.query_dim, "query dimensionality does not match the index"
         _check(lib().ffx_plan_set_queries(self._h, _ptr(queries), queries.shape[0]))
 
     def set_pairs(self, pair_off, pair_ids, sparse, mode: int) -> None:

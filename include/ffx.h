@@ -52,6 +52,11 @@ extern "C" {
  * so half rows are widened exactly and scored with the same fp32 arithmetic */
 #define FFX_DTYPE_F32 0
 #define FFX_DTYPE_F16 1
+/* product-quantizer codes, one uint8 per subspace (the reference's quantized index: add() stores
+ * quantizer.encode(vectors), index/base.py:253, and scoring decodes first, index/base.py:292-293).
+ * Rows have `dim` = M codes; the codebook [M][Ks][Ds] fp32 comes through ffx_index_set_codebook and
+ * query vectors have M*Ds elements. */
+#define FFX_DTYPE_PQ8 2
 
 /* ffx_plan_run flags */
 #define FFX_FLAG_EXACT_SUM 1u /* NumPy summation order: scores bit-identical to index/base.py:303 */
@@ -96,6 +101,10 @@ int ffx_device_info(int device, char* name, size_t name_cap, int64_t* total_byte
 int ffx_index_create(int device, int64_t capacity_rows, int32_t dim, ffx_index** out); /* fp32 rows */
 int ffx_index_create_typed(int device, int64_t capacity_rows, int32_t dim, int32_t dtype, ffx_index** out);
 int ffx_index_dtype(const ffx_index* idx, int32_t* dtype);
+/* codewords of a product quantizer (quantizer/nanopq.py:49-56): float[m][ks][ds], m = row length */
+int ffx_index_set_codebook(ffx_index* idx, const float* codewords, int32_t m, int32_t ks, int32_t ds);
+/* dimensionality of query vectors: dim for float rows, m*ds for product-quantized rows */
+int ffx_index_query_dim(const ffx_index* idx, int32_t* dim);
 int ffx_index_destroy(ffx_index* idx);
 int ffx_index_dim(const ffx_index* idx, int32_t* dim);
 int ffx_index_capacity(const ffx_index* idx, int64_t* rows);

@@ -230,6 +230,93 @@ def known_answers():
             "doc_run": doc_run, "psg_run": psg_run, "expected": got}
 
 
+PQ_CASES = {
+    "pq_d768_m8": dict(seed=11, dim=768, M=8, Ks=16, n_docs=48, n_q=6, k=24),
+    "pq_d768_m16": dict(seed=12, dim=768, M=16, Ks=8, n_docs=40, n_q=4, k=20),
+    "pq_d1024_m32": dict(seed=13, dim=1024, M=32, Ks=4, n_docs=30, n_q=3, k=16),
+    "pq_d60_m5": dict(seed=14, dim=60, M=5, Ks=7, n_docs=30, n_q=3, k=12),
+}
+
+
+def pq_case(name, *, seed, dim, M, Ks, n_docs, n_q, k):
+    """The reference's quantized path (index/base.py:253, :292-293) with a quantizer whose
+    codewords are fixture data.  nanopq itself is absent, so the quantizer handed to the reference
+    is a minimal subclass of ITS Quantizer base class: encode = nearest codeword per subspace,
+    decode = concatenated codewords (what nanopq.PQ.decode does).  Everything the reference then
+    does with it -- encode at add(), decode before scoring, the dot, the aggregation -- is its own
+    code."""
+    from fast_forward.quantizer import Quantizer as RefQuantizer
+
+    Ds = dim // M
+    codewords = synth.rows(seed + 500, 1.0, 0, M * Ks, Ds).reshape(M, Ks, Ds)
+
+    class FixtureQuantizer(RefQuantizer):
+        def _fit(self, vectors, **kw):
+            pass
+
+        def _get_dtype(self):
+            return np.dtype(np.uint8)
+
+        def _get_dims(self):
+            return dim, M
+
+        def _encode(self, vectors):
+            codes = np.empty((len(vectors), M), dtype=np.uint8)
+            for m in range(M):
+                sub = vectors[:, m * Ds:(m + 1) * Ds].astype(np.float64)
+                d2 = ((sub[:, None, :] - codewords[m][None].astype(np.float64)) ** 2).sum(-1)
+                codes[:, m] = d2.argmin(1)
+            return codes
+
+        def _decode(self, codes):
+            return np.concatenate([codewords[m][codes[:, m]] for m in range(M)], axis=1)
+
+        def _get_state(self):
+            return {}, {}
+
+        @classmethod
+        def _from_state(cls, attributes, data):
+            return cls()
+
+    rng = np.random.default_rng(seed)
+    per_doc = rng.integers(1, 5, size=n_docs)
+    n_rows = int(per_doc.sum())
+    doc_of_row = np.repeat(np.arange(n_docs), per_doc).astype(np.int32)
+    vectors = synth.rows(seed, 1.0, 0, n_rows, dim)
+    qvecs = synth.rows(seed + 1000, 1.0, 0, n_q, dim)
+    doc_ids = [f"D{d}" for d in doc_of_row]
+    psg_ids = [f"P{r}" for r in range(n_rows)]
+    q_names = [f"q{i:03d}" for i in range(n_q)]
+    cand_docs = np.stack([rng.choice(n_docs, size=k, replace=False) for _ in range(n_q)]).astype(np.int32)
+    cand_psgs = np.stack([rng.choice(n_rows, size=k, replace=False) for _ in range(n_q)]).astype(np.int32)
+    sparse_doc = (rng.random((n_q, k)) * 10).astype(np.float32)
+    sparse_psg = (rng.random((n_q, k)) * 10).astype(np.float32)
+    quantizer = FixtureQuantizer()
+    quantizer.fit(vectors)
+    out = {"seed": seed, "dim": dim, "scale": np.float32(1.0), "n_rows": n_rows, "M": M, "Ks": Ks,
+           "doc_of_row": doc_of_row, "cand_docs": cand_docs, "cand_psgs": cand_psgs, "sparse_doc": sparse_doc,
+           "sparse_psg": sparse_psg, "vectors_sha": sha(vectors), "queries_sha": sha(qvecs), "q_names": np.array(q_names),
+           "codes": quantizer.encode(vectors), "codewords_sha": sha(codewords), "store": "float32"}
+    for mname, mode in MODES.items():
+        quantizer = FixtureQuantizer()
+        quantizer.fit(vectors)
+        enc = LambdaEncoder(lambda t: qvecs[int(t)])
+        idx = InMemoryIndex(query_encoder=enc, quantizer=quantizer, mode=mode, init_size=n_rows)
+        idx.add(vectors, doc_ids=doc_ids, psg_ids=psg_ids)
+        assert idx._chunks[0].dtype == np.uint8 and idx._chunks[0].shape[1] == M
+        if mode == Mode.PASSAGE:
+            first = run_frame(q_names, [[f"P{c}" for c in row] for row in cand_psgs], sparse_psg)
+        else:
+            first = run_frame(q_names, [[f"D{c}" for c in row] for row in cand_docs], sparse_doc)
+        dense = idx(first)
+        for key, val in frame_arrays(dense).items():
+            out[f"{mname}_ff_{key}"] = val
+        for key, val in frame_arrays(first.interpolate(dense, 0.1)).items():
+            out[f"{mname}_int0.1_{key}"] = val
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    return {"rows": n_rows, "M": M, "Ks": Ks}
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "--only":  # add one case without rewriting the others
@@ -244,6 +331,8 @@ def main():
             manifest["cases"]["dim128_f16"] = scoring_case(
                 "dim128_f16", seed=201, dim=128, n_docs=60, psg_lo=1, psg_hi=3, n_q=4, k=20, scale=1.0,
                 sparse_hi=10.0, modes=["MAXP"], store=np.float16)
+        if sys.argv[2] == "pq":
+            manifest["cases"]["pq"] = {name: pq_case(name, **kw) for name, kw in PQ_CASES.items()}
         (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
         return
     manifest = {"reference": "mrjleo/fast-forward-indexes v0.8.0 (/root/reference)",

@@ -112,3 +112,38 @@ def assert_same_order_modulo_ties(got_ids, got_scores, exp):
             end += 1
         assert sorted(got_ids[start:end]) == sorted(exp_ids[start:end])
         start = end
+
+
+# ---- product-quantized fixtures (oracle/gen_golden.py::pq_case) ------------------------------------
+PQ_CASES = ["pq_d768_m8", "pq_d768_m16", "pq_d1024_m32", "pq_d60_m5"]
+
+
+@dataclass
+class PQCase(ScoringCase):
+    codes: np.ndarray = None       # uint8 [n_rows, M], as the reference's index stored them
+    codewords: np.ndarray = None   # float32 [M, Ks, Ds]
+    raw_vectors: np.ndarray = None  # what was handed to Index.add (before encoding)
+
+
+def load_pq_case(name: str) -> PQCase:
+    """``vectors`` of the returned case are the DECODED rows (what the reference scores)."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    seed, dim, n_rows, M, Ks = int(z["seed"]), int(z["dim"]), int(z["n_rows"]), int(z["M"]), int(z["Ks"])
+    Ds = dim // M
+    codewords = synth.rows(seed + 500, 1.0, 0, M * Ks, Ds).reshape(M, Ks, Ds)
+    assert sha(codewords) == str(z["codewords_sha"])
+    raw = synth.rows(seed, 1.0, 0, n_rows, dim)
+    queries = synth.rows(seed + 1000, 1.0, 0, z["cand_docs"].shape[0], dim)
+    assert sha(raw) == str(z["vectors_sha"]) and sha(queries) == str(z["queries_sha"])
+    codes = z["codes"]
+    decoded = np.concatenate([codewords[m][codes[:, m]] for m in range(M)], axis=1)
+    doc_of_row = z["doc_of_row"]
+    n_docs = int(doc_of_row.max()) + 1
+    doc_off = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(np.bincount(doc_of_row, minlength=n_docs), out=doc_off[1:])
+    return PQCase(
+        name=name, z=z, vectors=decoded, queries=queries, doc_off=doc_off,
+        doc_rows=np.argsort(doc_of_row, kind="stable").astype(np.int32), psg_row=np.arange(n_rows, dtype=np.int32),
+        doc_names=[f"D{d}" for d in doc_of_row], psg_names=[f"P{r}" for r in range(n_rows)], q_names=z["q_names"].tolist(),
+        codes=codes, codewords=codewords, raw_vectors=raw,
+    )

@@ -265,3 +265,47 @@ def test_sharded_scorer_single_rank_nccl():
     out = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "sharded 1-rank ok" in out.stdout
+
+
+# ---- product-quantized rows (decode-then-dot and ADC) ------------------------------------------------
+from _cases import PQ_CASES, load_pq_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", PQ_CASES)
+def test_pq_decode_then_dot_bit_identical_to_reference(name):
+    """uint8 codes in HBM + codebook in L2, scored by the decode-then-dot kernels, against the
+    frames the reference produced with the same codewords (index/base.py:292-293)."""
+    case = load_pq_case(name)
+    m = case.codes.shape[1]
+    idx = native.DeviceIndex(case.codes.shape[0], m, dtype=np.uint8)
+    idx.set_codebook(case.codewords)
+    idx.upload(case.codes, 0)
+    idx.set_doc_rows(case.doc_off, case.doc_rows)
+    idx.set_psg_rows(case.psg_row)
+    assert np.array_equal(idx.gather(np.arange(5, dtype=np.int32)), case.codes[:5])
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        ff, interp, order, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], sparse, 0.1, exact_sum=True, sort=True)
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        for key, got in ((f"{mode}_ff", ff), (f"{mode}_int0.1", interp)):
+            exp = case.expected(key)
+            want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+            assert np.array_equal(bits(got), bits(want)), (name, key, st["kernel_variant"])
+        assert st["kernel_variant"] == (2199 if name == "pq_d60_m5" else 2100 + m)
+        assert np.array_equal(order.astype(np.int64), fo.order(interp, pair_off))
+        # ADC (fast order): same value up to fp32 rounding of a different summation order
+        fast, _, _, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=False)
+        assert st["kernel_variant"] == 2300
+        assert np.abs(fast - ff).max() <= FAST_TOL * max(1.0, float(np.abs(ff).max()))
+    idx.close()
+
+
+def test_pq_synthetic_codes_fill():
+    n, m, ks = 5000, 8, 256
+    idx = native.DeviceIndex(n, m, dtype=np.uint8)
+    idx.set_codebook(synth.rows(3, 1.0, 0, m * ks, 96).reshape(m, ks, 96))
+    idx.fill_synthetic(seed=7, scale=1.0, row_offset=0, n_rows=n, first_global_row=11)
+    got = idx.gather(np.arange(n, dtype=np.int32))
+    want = ((synth.mix64(np.arange(11 * m, (11 + n) * m, dtype=np.uint64), 7) >> np.uint64(32)) % np.uint64(ks)).astype(np.uint8).reshape(n, m)
+    assert np.array_equal(got, want)
+    idx.close()

@@ -85,8 +85,14 @@ def test_error_contract():
         idx(Ranking.from_run({"q1": {"d0": 100, "dx": 2}}, queries=QUERIES))
     with pytest.raises(IndexError):
         idx._get_vectors(["nope"])
+    from fast_forward_amd.quantizer import NanoPQ
+
+    trained = NanoPQ(1, 2)
+    trained.fit(np.random.default_rng(0).normal(size=(8, 5)).astype(np.float32), iter=1)
     with pytest.raises(RuntimeError):
-        idx.quantizer = object()  # non-empty index
+        idx.quantizer = trained  # non-empty index
+    with pytest.raises(RuntimeError):
+        InMemoryIndex(quantizer=NanoPQ(1, 2))  # not fitted yet
 
 
 def test_batch_size_invariance():
@@ -234,3 +240,91 @@ def test_fast_sum_mode_within_tolerance():
     err = max(abs(s - want[(q, i)]) for q, i, s in zip(got["q_id"], got["id"], got["score"]))
     assert 0 < err <= 1e-4 * max(1.0, max(abs(v) for v in want.values()))  # 1e-4: BASELINE.json north_star
     assert idx.last_stats["kernel_variant"] // 100 == 2
+
+
+# ---- quantized indexes (reference tests/test_index.py:389-399 + golden frames) ------------------------
+from _cases import PQ_CASES, load_pq_case  # noqa: E402
+from fast_forward_amd.quantizer import NanoOPQ, NanoPQ, Quantizer  # noqa: E402
+
+
+def test_quantized_index_shapes():
+    """reference test_quantization: internal dim = code length, iteration yields decoded vectors."""
+    pq = NanoPQ(2, 8)
+    pq.fit(np.random.default_rng(0).normal(size=(16, 16)).astype(np.float32))
+    idx = InMemoryIndex(quantizer=pq, mode=Mode.MAXP)
+    idx.add(np.random.default_rng(1).normal(size=(5, 16)).astype(np.float32), doc_ids=DOC_IDS)
+    assert idx.dim == 16 and idx._get_internal_dim() == 2
+    for vec, _, _ in idx:
+        assert vec.shape[0] == 16
+    codes, owners = idx._get_vectors(sorted(set(DOC_IDS)))
+    assert codes.shape == (5, 2) and codes.dtype == np.uint8 and owners == ["d0", "d0", "d1", "d2", "d3"]
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((1, 8), dtype=np.float32), doc_ids=["x"])  # wrong dimensionality
+
+
+@pytest.mark.parametrize("name", PQ_CASES)
+def test_quantized_index_frames_match_reference(name):
+    case = load_pq_case(name)
+    qvecs = case.queries
+    for mode in case.modes():
+        idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), quantizer=NanoPQ.from_codewords(case.codewords), mode=Mode(MODE_NO[mode]),
+                            init_size=8, alloc_size=8)
+        half = len(case.raw_vectors) // 2  # two add() calls: the store grows and keeps its codebook
+        idx.add(case.raw_vectors[:half], doc_ids=case.doc_names[:half], psg_ids=case.psg_names[:half])
+        idx.add(case.raw_vectors[half:], doc_ids=case.doc_names[half:], psg_ids=case.psg_names[half:])
+        assert idx._store.dtype == np.uint8 and np.array_equal(idx._store.gather(np.arange(len(case.codes), dtype=np.int32)), case.codes)
+        pair_off, _, sparse, names = case.pairs(mode)
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        first = Ranking(pd.DataFrame({"q_id": [case.q_names[q] for q in pair_q], "id": names, "score": sparse}),
+                        queries={q: str(i) for i, q in enumerate(case.q_names)})
+        dense = idx(first)
+        exp = case.expected_order(f"{mode}_ff")
+        for qn in case.q_names:
+            rows = dense._df[dense._df["q_id"] == qn]
+            assert_same_order_modulo_ties(rows["id"].tolist(), rows["score"].to_numpy(), exp[qn])
+        exp_i = case.expected_order(f"{mode}_int0.1")
+        fused = idx.rerank(first, 0.1)
+        for qn in case.q_names:
+            rows = fused._df[fused._df["q_id"] == qn]
+            assert_same_order_modulo_ties(rows["id"].tolist(), rows["score"].to_numpy(), exp_i[qn])
+        idx.close()
+
+
+def test_opq_and_generic_quantizers_score_decoded_rows():
+    """OPQ: rows stay codes, queries are rotated (tolerance).  A quantizer the device cannot read:
+    decoded rows are stored and scored bit-exactly."""
+    import ffx_oracle as fo
+
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(400, 64)).astype(np.float32)
+    qv = rng.normal(size=(3, 64)).astype(np.float32)
+    doc_ids = [f"D{i}" for i in range(400)]
+    run = {f"q{q}": {f"D{i}": 1.0 for i in rng.choice(400, size=50, replace=False)} for q in range(3)}
+    first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(3)})
+
+    def oracle_scores(decoded):
+        want = {}
+        for q in range(3):
+            for d in run[f"q{q}"]:
+                want[(f"q{q}", d)] = fo.dot_f32(qv[q], decoded[int(d[1:])])
+        return want
+
+    opq = NanoOPQ(4, 16)
+    opq.fit(x, pq_iter=2, rotation_iter=3)
+    idx = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), quantizer=opq)
+    idx.add(x, doc_ids=doc_ids)
+    assert idx._store.dtype == np.uint8
+    got = idx(first)._df
+    want = oracle_scores(opq.decode(opq.encode(x)).astype(np.float32))
+    err = max(abs(s - want[(q, i)]) for q, i, s in zip(got["q_id"], got["id"], got["score"]))
+    assert err <= 1e-4 * max(1.0, max(abs(v) for v in want.values()))
+
+    wide = NanoPQ(4, 300)  # uint16 codes: not a device codebook
+    wide.fit(x, iter=2)
+    idx2 = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), quantizer=wide)
+    idx2.add(x, doc_ids=doc_ids)
+    assert idx2._store.dtype == np.float32 and idx2._get_vectors(["D7"])[0].dtype == np.uint16
+    got = idx2(first)._df
+    want = oracle_scores(wide.decode(wide.encode(x)))
+    for q, i, s in zip(got["q_id"], got["id"], got["score"]):
+        assert np.float32(s).view(np.uint32) == np.float32(want[(q, i)]).view(np.uint32)
