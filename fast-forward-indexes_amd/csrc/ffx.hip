@@ -22,9 +22,9 @@
 #include "aux_kernels.hip.h"
 #include "gather_dot.hip.h"
 
-namespace {
-
 thread_local std::string g_last_error;
+
+namespace {
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -35,6 +35,21 @@ int fail(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
+
+}  // namespace
+
+// shared with host_io.cpp
+int ffx_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+namespace {
 
 #define FFX_HIP(expr)                                                                         \
   do {                                                                                        \

@@ -1,0 +1,420 @@
+// host_io.cpp -- host-side natives of the re-ranking path: string-id tables and TREC run files.
+//
+// Once the arithmetic runs at HBM speed the reference's host work dominates end to end: the
+// per-id Python loop of get_indices (src/fast_forward/index/util.py:29-41), the pandas string
+// merges (index/base.py:296-298, :422) and read_csv / to_csv of the run
+// (src/fast_forward/ranking.py:348-366, :388-409).  This file replaces those with
+//   ffx_ids_*  an insertion-ordered string -> ordinal table (open addressing, FNV-1a)
+//   ffx_run_*  a TREC run parsed straight into the CSR the kernels take, and written back
+// No device code here; plain C++17.
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "../../include/ffx.h"
+
+int ffx_fail(int code, const char* fmt, ...);  // ffx.hip: records the thread's last error
+
+namespace {
+
+inline uint64_t fnv1a(const char* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= (unsigned char)p[i];
+    h *= 1099511628211ull;
+  }
+  return h ^ (h >> 29);
+}
+
+}  // namespace
+
+// insertion-ordered interning table: ordinal = order of first insertion
+struct ffx_ids {
+  std::vector<char> arena;
+  std::vector<uint64_t> off;   // off[i]..off[i+1] = bytes of string i
+  std::vector<int32_t> slots;  // open addressing, -1 = empty
+  size_t mask = 0;
+
+  ffx_ids() { off.push_back(0); rehash(1024); }
+  int64_t size() const { return (int64_t)off.size() - 1; }
+  std::string_view get(int32_t i) const { return {arena.data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i])}; }
+  void rehash(size_t cap) {
+    slots.assign(cap, -1);
+    mask = cap - 1;
+    for (int32_t i = 0; i < (int32_t)size(); ++i) {
+      const std::string_view s = get(i);
+      size_t h = fnv1a(s.data(), s.size()) & mask;
+      while (slots[h] >= 0) h = (h + 1) & mask;
+      slots[h] = i;
+    }
+  }
+  int32_t find(std::string_view s) const {
+    size_t h = fnv1a(s.data(), s.size()) & mask;
+    while (true) {
+      const int32_t i = slots[h];
+      if (i < 0) return -1;
+      if (get(i) == s) return i;
+      h = (h + 1) & mask;
+    }
+  }
+  int32_t intern(std::string_view s) {
+    size_t h = fnv1a(s.data(), s.size()) & mask;
+    while (true) {
+      const int32_t i = slots[h];
+      if (i < 0) break;
+      if (get(i) == s) return i;
+      h = (h + 1) & mask;
+    }
+    const int32_t id = (int32_t)size();
+    arena.insert(arena.end(), s.begin(), s.end());
+    off.push_back(arena.size());
+    slots[h] = id;
+    if ((size_t)size() * 10 > slots.size() * 6) rehash(slots.size() * 2);
+    return id;
+  }
+};
+
+// one parsed TREC run: rows grouped by query (order of first appearance), rows of a query in file order
+struct ffx_run {
+  ffx_ids qids;                     // query ids in order of first appearance
+  std::vector<int64_t> pair_off;    // [Q+1]
+  std::vector<int32_t> pair_ids;    // ordinal in the id table given to ffx_run_open
+  std::vector<float> score;
+  std::string tag;                  // last column of the first line (Ranking.name, ranking.py:409)
+  const ffx_ids* ids = nullptr;     // borrowed: candidate id strings for writing
+};
+
+namespace {
+
+inline std::string_view fixed_width(const char* base, int32_t width, int64_t i) {
+  const char* p = base + (size_t)i * width;
+  size_t n = 0;
+  while (n < (size_t)width && p[n] != '\0') ++n;
+  return {p, n};
+}
+
+// shortest round-trip decimal of a float, laid out like numpy's str(np.float32), which is
+// what pandas.to_csv writes for a float32 column (ranking.py:360-366)
+void append_float_repr(std::string& out, float v) {
+  if (std::isnan(v)) { out += "nan"; return; }
+  if (std::isinf(v)) { out += v < 0 ? "-inf" : "inf"; return; }
+  char buf[48];
+  auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+  std::string_view s(buf, (size_t)(r.ptr - buf));  // d[.ddd]e[+-]XX
+  bool neg = false;
+  if (!s.empty() && s[0] == '-') { neg = true; s.remove_prefix(1); }
+  const size_t e = s.find('e');
+  std::string digits;
+  for (char c : s.substr(0, e)) if (c != '.') digits.push_back(c);
+  int exp10 = 0;
+  std::from_chars(s.data() + e + 1 + (s[e + 1] == '+' ? 1 : 0), s.data() + s.size(), exp10);
+  if (neg) out.push_back('-');
+  // numpy switches to scientific on the VALUE (|v| < 1e-4 or >= 1e16), not on the decimal exponent
+  // of the shortest digits: float32(1e-4) = 9.99999975e-05 prints as 1e-04
+  const double mag = std::fabs((double)v);
+  if ((mag != 0 && mag < 1e-4) || mag >= 1e16) {
+    out.push_back(digits[0]);
+    if (digits.size() > 1) { out.push_back('.'); out.append(digits, 1, std::string::npos); }
+    char eb[8];
+    snprintf(eb, sizeof eb, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10));
+    out += eb;
+  } else if (exp10 < 0) {
+    out += "0.";
+    out.append((size_t)(-exp10 - 1), '0');
+    out += digits;
+  } else {
+    const size_t int_len = (size_t)exp10 + 1;
+    if (digits.size() <= int_len) {
+      out += digits;
+      out.append(int_len - digits.size(), '0');
+      out += ".0";
+    } else {
+      out.append(digits, 0, int_len);
+      out.push_back('.');
+      out.append(digits, int_len, std::string::npos);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffx_ids_create(ffx_ids** out) {
+  if (!out) return ffx_fail(FFX_BAD_ARG, "out is NULL");
+  *out = new (std::nothrow) ffx_ids();
+  return *out ? FFX_OK : ffx_fail(FFX_OOM, "host allocation failed");
+}
+
+int ffx_ids_destroy(ffx_ids* t) {
+  delete t;
+  return FFX_OK;
+}
+
+int ffx_ids_count(const ffx_ids* t, int64_t* n) {
+  if (!t || !n) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *n = t->size();
+  return FFX_OK;
+}
+
+int ffx_ids_intern(ffx_ids* t, const char* strs, int32_t width, int64_t n, int32_t* out_ordinals) {
+  if (!t || (n > 0 && !strs) || width <= 0 || n < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  try {
+    for (int64_t i = 0; i < n; ++i) {
+      if (t->size() >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many distinct ids for int32 ordinals");
+      const int32_t o = t->intern(fixed_width(strs, width, i));
+      if (out_ordinals) out_ordinals[i] = o;
+    }
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
+  return FFX_OK;
+}
+
+int ffx_ids_lookup(const ffx_ids* t, const char* strs, int32_t width, int64_t n, int32_t* out_ordinals,
+                   int64_t* first_missing) {
+  if (!t || (n > 0 && (!strs || !out_ordinals)) || width <= 0 || n < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  int64_t miss = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t o = t->find(fixed_width(strs, width, i));
+    out_ordinals[i] = o;
+    if (o < 0 && miss < 0) miss = i;
+  }
+  if (first_missing) *first_missing = miss;
+  return miss < 0 ? FFX_OK : FFX_NOT_FOUND;
+}
+
+int ffx_ids_get(const ffx_ids* t, int32_t ordinal, const char** str, int32_t* len) {
+  if (!t || !str || !len) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (ordinal < 0 || ordinal >= t->size()) return ffx_fail(FFX_BAD_ARG, "ordinal %d out of range", ordinal);
+  const std::string_view s = t->get(ordinal);
+  *str = s.data();
+  *len = (int32_t)s.size();
+  return FFX_OK;
+}
+
+// ---- TREC run files ---------------------------------------------------------------------------------
+// Line format (Ranking.from_file, ranking.py:400-409): q_id Q0 id rank score name, any whitespace.
+// Candidate ids are resolved against `ids` while parsing; the first unknown id is FFX_NOT_FOUND with
+// its 1-based line number in *bad_line (the reference's IndexError, index/util.py:38-39).
+// A (query, id) pair that appears twice is FFX_BAD_ARG (ValueError, ranking.py:95-98).
+int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* bad_line) {
+  if (bad_line) *bad_line = -1;
+  if (!path || !ids || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) return ffx_fail(FFX_BAD_ARG, "cannot open %s", path);
+  std::string data;
+  try {
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    data.resize(sz > 0 ? (size_t)sz : 0);
+    if (sz > 0 && fread(data.data(), 1, (size_t)sz, f) != (size_t)sz) {
+      fclose(f);
+      return ffx_fail(FFX_BAD_ARG, "short read on %s", path);
+    }
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    return ffx_fail(FFX_OOM, "run file does not fit in memory");
+  }
+  fclose(f);
+
+  ffx_run* run = new (std::nothrow) ffx_run();
+  if (!run) return ffx_fail(FFX_OOM, "host allocation failed");
+  run->ids = ids;
+  std::vector<int32_t> row_q, row_id;
+  std::vector<float> row_s;
+  int rc = FFX_OK;
+  int64_t line_no = 0;
+  const char* p = data.data();
+  const char* end = p + data.size();
+  auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r'; };
+  try {
+    while (p < end) {
+      const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
+      if (!eol) eol = end;
+      ++line_no;
+      std::string_view field[6];
+      int nf = 0;
+      const char* c = p;
+      while (c < eol && nf < 6) {
+        while (c < eol && is_space(*c)) ++c;
+        if (c >= eol) break;
+        const char* s = c;
+        while (c < eol && !is_space(*c)) ++c;
+        field[nf++] = {s, (size_t)(c - s)};
+      }
+      p = eol + 1;
+      if (nf == 0) continue;  // blank line
+      if (nf < 5) {
+        if (bad_line) *bad_line = line_no;
+        rc = ffx_fail(FFX_BAD_ARG, "%s:%lld: expected 'q_id Q0 id rank score [name]'", path, (long long)line_no);
+        break;
+      }
+      const int32_t o = ids->find(field[2]);
+      if (o < 0) {
+        if (bad_line) *bad_line = line_no;
+        rc = ffx_fail(FFX_NOT_FOUND, "ID %.*s not found in the index.", (int)field[2].size(), field[2].data());
+        break;
+      }
+      double sc = 0;
+      {
+        const std::string tmp(field[4]);
+        char* endp = nullptr;
+        sc = strtod(tmp.c_str(), &endp);
+        if (endp == tmp.c_str()) {
+          if (bad_line) *bad_line = line_no;
+          rc = ffx_fail(FFX_BAD_ARG, "%s:%lld: bad score '%s'", path, (long long)line_no, tmp.c_str());
+          break;
+        }
+      }
+      if (run->tag.empty() && nf >= 6) run->tag.assign(field[5]);
+      row_q.push_back(run->qids.intern(field[0]));
+      row_id.push_back(o);
+      row_s.push_back((float)sc);  // scores become float32 (Ranking dtype, ranking.py:72)
+    }
+    if (rc == FFX_OK) {
+      const int64_t nq = run->qids.size(), n = (int64_t)row_q.size();
+      run->pair_off.assign((size_t)nq + 1, 0);
+      for (int32_t q : row_q) ++run->pair_off[(size_t)q + 1];
+      for (int64_t q = 0; q < nq; ++q) run->pair_off[(size_t)q + 1] += run->pair_off[(size_t)q];
+      run->pair_ids.resize((size_t)n);
+      run->score.resize((size_t)n);
+      std::vector<int64_t> cursor(run->pair_off.begin(), run->pair_off.end() - 1);
+      for (int64_t i = 0; i < n; ++i) {  // stable: rows of a query keep file order
+        const int64_t dst = cursor[(size_t)row_q[(size_t)i]]++;
+        run->pair_ids[(size_t)dst] = row_id[(size_t)i];
+        run->score[(size_t)dst] = row_s[(size_t)i];
+      }
+      // duplicate (query, id) pairs
+      std::vector<int32_t> tmp;
+      for (int64_t q = 0; q < nq && rc == FFX_OK; ++q) {
+        tmp.assign(run->pair_ids.begin() + run->pair_off[(size_t)q], run->pair_ids.begin() + run->pair_off[(size_t)q + 1]);
+        std::sort(tmp.begin(), tmp.end());
+        if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end())
+          rc = ffx_fail(FFX_BAD_ARG, "Only one score per query-document/passage pair is allowed.");
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    rc = ffx_fail(FFX_OOM, "host allocation failed while parsing %s", path);
+  }
+  if (rc != FFX_OK) {
+    delete run;
+    return rc;
+  }
+  *out = run;
+  return FFX_OK;
+}
+
+int ffx_run_close(ffx_run* run) {
+  delete run;
+  return FFX_OK;
+}
+
+int ffx_run_counts(const ffx_run* run, int64_t* n_queries, int64_t* n_pairs) {
+  if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
+  if (n_queries) *n_queries = run->qids.size();
+  if (n_pairs) *n_pairs = (int64_t)run->pair_ids.size();
+  return FFX_OK;
+}
+
+int ffx_run_query_id(const ffx_run* run, int64_t q, const char** str, int32_t* len) {
+  if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
+  return ffx_ids_get(&run->qids, (int32_t)q, str, len);
+}
+
+int ffx_run_tag(const ffx_run* run, const char** str, int32_t* len) {
+  if (!run || !str || !len) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *str = run->tag.data();
+  *len = (int32_t)run->tag.size();
+  return FFX_OK;
+}
+
+// copy out the CSR; with cutoff > 0 only each query's `cutoff` best-scoring candidates are kept
+// (Ranking.cut, ranking.py:279-291: order by score descending, ties in file order)
+int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pair_ids, float* sparse, int64_t* n_pairs_out) {
+  if (!run || !pair_off) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  const int64_t nq = run->qids.size();
+  if (cutoff > 0) {  // trim in place, once
+    std::vector<int64_t> new_off((size_t)nq + 1, 0);
+    std::vector<int32_t> ids2;
+    std::vector<float> sc2;
+    std::vector<int64_t> idx;
+    for (int64_t q = 0; q < nq; ++q) {
+      const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
+      idx.resize((size_t)(hi - lo));
+      std::iota(idx.begin(), idx.end(), lo);
+      if ((int64_t)idx.size() > cutoff) {
+        std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return run->score[(size_t)a] > run->score[(size_t)b]; });
+        idx.resize((size_t)cutoff);
+        std::sort(idx.begin(), idx.end());  // survivors back in file order
+      }
+      for (int64_t i : idx) {
+        ids2.push_back(run->pair_ids[(size_t)i]);
+        sc2.push_back(run->score[(size_t)i]);
+      }
+      new_off[(size_t)q + 1] = (int64_t)ids2.size();
+    }
+    run->pair_off.swap(new_off);
+    run->pair_ids.swap(ids2);
+    run->score.swap(sc2);
+  }
+  const int64_t n = (int64_t)run->pair_ids.size();
+  if (n_pairs_out) *n_pairs_out = n;
+  memcpy(pair_off, run->pair_off.data(), (size_t)(nq + 1) * sizeof(int64_t));
+  if (pair_ids) memcpy(pair_ids, run->pair_ids.data(), (size_t)n * sizeof(int32_t));
+  if (sparse) memcpy(sparse, run->score.data(), (size_t)n * sizeof(float));
+  return FFX_OK;
+}
+
+// write `q_id Q0 id rank score tag` (tab separated; Ranking.save, ranking.py:348-366): queries in
+// descending q_id order, candidates of a query in the order given by `order` (positions into the
+// CSR, e.g. the device sort of ffx_plan_run); keep > 0 writes only the first `keep` of each query.
+int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
+                  const char* tag) {
+  if (!run || !path || !scores || !order) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  FILE* f = fopen(path, "wb");
+  if (!f) return ffx_fail(FFX_BAD_ARG, "cannot create %s", path);
+  const int64_t nq = run->qids.size();
+  std::vector<int64_t> qorder((size_t)nq);
+  std::iota(qorder.begin(), qorder.end(), 0);
+  std::sort(qorder.begin(), qorder.end(), [&](int64_t a, int64_t b) { return run->qids.get((int32_t)a) > run->qids.get((int32_t)b); });
+  const std::string name = tag ? tag : run->tag;
+  std::string out;
+  out.reserve(1 << 20);
+  for (int64_t q : qorder) {
+    const std::string_view qid = run->qids.get((int32_t)q);
+    const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
+    const int64_t n = (keep > 0 && hi - lo > keep) ? keep : hi - lo;
+    for (int64_t r = 0; r < n; ++r) {
+      const int64_t p = order[lo + r];
+      const std::string_view id = run->ids->get(run->pair_ids[(size_t)p]);
+      out.append(qid).append("\tQ0\t").append(id).push_back('\t');
+      out += std::to_string(r + 1);
+      out.push_back('\t');
+      append_float_repr(out, scores[p]);
+      out.push_back('\t');
+      out += name;
+      out.push_back('\n');
+      if (out.size() > (1 << 20) - 256) {
+        fwrite(out.data(), 1, out.size(), f);
+        out.clear();
+      }
+    }
+  }
+  fwrite(out.data(), 1, out.size(), f);
+  const bool ok = fclose(f) == 0;
+  return ok ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+}
+
+}  // extern "C"

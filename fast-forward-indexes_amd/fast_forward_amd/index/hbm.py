@@ -216,6 +216,33 @@ class InMemoryIndex(Index):
         # queries in the order the reference would list them: q_id descending
         return Ranking(Ranking._trusted(out), name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
 
+    def rerank_file(self, run_in, run_out, alpha: float, queries, cutoff: int | None = None, name: str | None = None) -> dict:
+        """The README pipeline of the reference, file to file, with no pandas in between:
+
+            Ranking.from_file(run_in).attach_queries(queries).cut(cutoff)  ->  index(...)  ->
+            first.interpolate(out, alpha).save(run_out)
+
+        The run is parsed natively into the candidate CSR (ids resolved against this index while
+        parsing: an unknown id raises ``IndexError``), scored, interpolated and ordered on the
+        device, and written back as a TREC run.  ``queries`` maps query id -> query text.
+        Returns the device stage times.  Same scores and ordering as the step-by-step API."""
+        from fast_forward_amd import native
+
+        table = self._ids.native_table(self.mode.value)
+        run = native.RunFile(run_in, table)
+        try:
+            q_ids = run.query_ids()
+            missing = [q for q in q_ids if q not in queries]
+            if missing:
+                raise ValueError("Queries are incomplete.")
+            pair_off, ordinals, sparse = run.export(cutoff or 0)
+            query_vectors = np.ascontiguousarray(self.encode_queries([queries[q] for q in q_ids]))
+            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+            run.write(run_out, interp, order, tag=name)
+            return dict(self.last_stats, n_queries=len(q_ids), n_pairs=int(pair_off[-1]))
+        finally:
+            run.close()
+
     def close(self) -> None:
         """Release device memory now (otherwise released when the object is collected)."""
         if self._plan is not None:

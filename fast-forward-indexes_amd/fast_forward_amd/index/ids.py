@@ -25,6 +25,7 @@ class IdTable:
         self._csr: tuple[np.ndarray, np.ndarray] | None = None
         self._doc_lookup: pd.Index | None = None
         self._psg_lookup: pd.Index | None = None
+        self._native: dict[bool, tuple[int, object]] = {}  # passage? -> (version, native IdStrings)
         self.version = 0  # bumped on every change; the device copy is refreshed lazily
 
     # ---- growth ------------------------------------------------------------------------
@@ -109,6 +110,21 @@ class IdTable:
             first_bad = ids[np.flatnonzero(ordinals[codes] < 0)[0]]
             raise IndexError(f"ID {first_bad} not found in the index.")
         return ordinals[codes].astype(np.int32)
+
+    def native_table(self, mode: int):
+        """The native (libffx) mirror of the doc- or passage-id table, rebuilt when ids changed;
+        ordinals agree with ``resolve``.  Used by the file-to-file path (``RunFile``)."""
+        from fast_forward_amd import native
+
+        passage = mode == PASSAGE
+        cached = self._native.get(passage)
+        if cached is None or cached[0] != self.version:
+            table = native.IdStrings()
+            keys = list(self._psg_ordinal if passage else self._doc_ordinal)
+            got = table.intern(keys)
+            assert len(keys) == 0 or (got[-1] == len(keys) - 1 and len(table) == len(keys)), "ids are not unique as bytes"
+            self._native[passage] = cached = (self.version, table)
+        return cached[1]
 
     def rows_for(self, ids: Iterable[str], mode: int) -> tuple[list[int], list[str]]:
         """``get_indices`` of the reference: the rows needed to score each id, and the id

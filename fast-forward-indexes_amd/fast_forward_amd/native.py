@@ -28,6 +28,8 @@ SYMBOLS = (
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
+    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get",
+    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write",
 )
 
 
@@ -122,6 +124,19 @@ def lib() -> C.CDLL:
         "ffx_merge_sync": ([vp], C.c_int),
         "ffx_merge_fetch": ([vp, vp, vp, vp], C.c_int),
         "ffx_merge_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
+        "ffx_ids_create": ([P(vp)], C.c_int),
+        "ffx_ids_destroy": ([vp], C.c_int),
+        "ffx_ids_count": ([vp, P(i64)], C.c_int),
+        "ffx_ids_intern": ([vp, vp, i32, i64, vp], C.c_int),
+        "ffx_ids_lookup": ([vp, vp, i32, i64, vp, P(i64)], C.c_int),
+        "ffx_ids_get": ([vp, i32, P(vp), P(i32)], C.c_int),
+        "ffx_run_open": ([C.c_char_p, vp, P(vp), P(i64)], C.c_int),
+        "ffx_run_close": ([vp], C.c_int),
+        "ffx_run_counts": ([vp, P(i64), P(i64)], C.c_int),
+        "ffx_run_query_id": ([vp, i64, P(vp), P(i32)], C.c_int),
+        "ffx_run_tag": ([vp, P(vp), P(i32)], C.c_int),
+        "ffx_run_export": ([vp, i64, vp, vp, vp, P(i64)], C.c_int),
+        "ffx_run_write": ([vp, C.c_char_p, vp, vp, i64, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
@@ -372,3 +387,119 @@ def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=Non
                          float(alpha), flags, _ptr(ff), _ptr(interp), _ptr(order), C.byref(bad), C.byref(st))
     _check(rc, bad.value)
     return ff, interp, order, st.as_dict()
+
+
+def _as_fixed_bytes(strings) -> np.ndarray:
+    """Strings -> contiguous NUL-padded byte fields (numpy 'S<w>'), the ABI's string-array form."""
+    a = np.asarray(strings)
+    if a.dtype.kind == "S":
+        return np.ascontiguousarray(a)
+    if a.dtype.kind == "U":
+        return np.char.encode(a, "utf-8")
+    return np.array([s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in a.tolist()] or [b""], dtype="S")[: len(a)]
+
+
+class IdStrings:
+    """Owns one ``ffx_ids``: an insertion-ordered string -> ordinal table on the native side."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib().ffx_ids_create(C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_ids_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __len__(self) -> int:
+        n = C.c_int64(0)
+        _check(lib().ffx_ids_count(self._h, C.byref(n)))
+        return n.value
+
+    def intern(self, strings) -> np.ndarray:
+        b = _as_fixed_bytes(strings)
+        out = np.empty(b.shape[0], dtype=np.int32)
+        if b.shape[0]:
+            _check(lib().ffx_ids_intern(self._h, _ptr(b), b.dtype.itemsize, b.shape[0], _ptr(out)))
+        return out
+
+    def lookup(self, strings) -> np.ndarray:
+        """Ordinals of ``strings``; ``IndexError`` naming the first unknown one."""
+        b = _as_fixed_bytes(strings)
+        out = np.empty(b.shape[0], dtype=np.int32)
+        if b.shape[0] == 0:
+            return out
+        miss = C.c_int64(-1)
+        rc = lib().ffx_ids_lookup(self._h, _ptr(b), b.dtype.itemsize, b.shape[0], _ptr(out), C.byref(miss))
+        if rc == NOT_FOUND:
+            raise IndexError(f"ID {b[miss.value].decode('utf-8', 'replace')} not found in the index.")
+        _check(rc)
+        return out
+
+    def get(self, ordinal: int) -> str:
+        p, n = C.c_void_p(), C.c_int32(0)
+        _check(lib().ffx_ids_get(self._h, int(ordinal), C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value).decode("utf-8")
+
+
+class RunFile:
+    """Owns one ``ffx_run``: a TREC run parsed natively into the kernels' CSR (and written back)."""
+
+    def __init__(self, path, ids: IdStrings):
+        h, bad = C.c_void_p(), C.c_int64(-1)
+        rc = lib().ffx_run_open(str(path).encode(), ids._h, C.byref(h), C.byref(bad))
+        if rc == NOT_FOUND:
+            msg = (lib().ffx_last_error() or b"").decode("utf-8", "replace")
+            raise IndexError(msg)
+        if rc == BAD_ARG:
+            raise ValueError((lib().ffx_last_error() or b"").decode("utf-8", "replace"))
+        _check(rc)
+        self._h, self._ids = h, ids
+        nq, npairs = C.c_int64(0), C.c_int64(0)
+        _check(lib().ffx_run_counts(h, C.byref(nq), C.byref(npairs)))
+        self.n_queries, self.n_pairs = nq.value, npairs.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_run_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def query_ids(self) -> list[str]:
+        out = []
+        p, n = C.c_void_p(), C.c_int32(0)
+        for q in range(self.n_queries):
+            _check(lib().ffx_run_query_id(self._h, q, C.byref(p), C.byref(n)))
+            out.append(C.string_at(p.value, n.value).decode("utf-8"))
+        return out
+
+    @property
+    def tag(self) -> str:
+        p, n = C.c_void_p(), C.c_int32(0)
+        _check(lib().ffx_run_tag(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value).decode("utf-8") if n.value else ""
+
+    def export(self, cutoff: int = 0):
+        """(pair_off, pair_ids, sparse); ``cutoff`` > 0 keeps each query's best ``cutoff`` first."""
+        pair_off = np.empty(self.n_queries + 1, dtype=np.int64)
+        n = C.c_int64(0)
+        if cutoff > 0:  # trim inside the run first, then size the outputs
+            _check(lib().ffx_run_export(self._h, cutoff, _ptr(pair_off), None, None, C.byref(n)))
+            self.n_pairs = n.value
+        pair_ids = np.empty(self.n_pairs, dtype=np.int32)
+        sparse = np.empty(self.n_pairs, dtype=np.float32)
+        _check(lib().ffx_run_export(self._h, 0, _ptr(pair_off), _ptr(pair_ids), _ptr(sparse), C.byref(n)))
+        return pair_off, pair_ids, sparse
+
+    def write(self, path, scores: np.ndarray, order: np.ndarray, keep: int = 0, tag: str | None = None) -> None:
+        scores, order = _arr(scores, np.float32), _arr(order, np.int32)
+        assert scores.shape[0] == self.n_pairs == order.shape[0]
+        from pathlib import Path
+
+        Path(path).parent.mkdir(parents=True, exist_ok=True)
+        _check(lib().ffx_run_write(self._h, str(path).encode(), _ptr(scores), _ptr(order), keep,
+                                   None if tag is None else tag.encode()))

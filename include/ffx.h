@@ -176,6 +176,35 @@ int ffx_merge_sync(ffx_merge* m);
 int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order);
 int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems);
 
+/* ---- host natives: id tables and TREC run files ---------------------------------------------
+ * ffx_ids: insertion-ordered string -> ordinal table; replaces the per-id dict look-ups of
+ * get_indices (index/util.py:29-41).  Strings cross the ABI as arrays of fixed-width, NUL-padded
+ * byte fields (numpy dtype 'S<width>'). */
+typedef struct ffx_ids ffx_ids;
+int ffx_ids_create(ffx_ids** out);
+int ffx_ids_destroy(ffx_ids* table);
+int ffx_ids_count(const ffx_ids* table, int64_t* n);
+int ffx_ids_intern(ffx_ids* table, const char* strs, int32_t width, int64_t n, int32_t* out_ordinals);
+/* FFX_NOT_FOUND (+ position of the first unknown string) if any is absent; absent -> -1 */
+int ffx_ids_lookup(const ffx_ids* table, const char* strs, int32_t width, int64_t n, int32_t* out_ordinals,
+                   int64_t* first_missing);
+int ffx_ids_get(const ffx_ids* table, int32_t ordinal, const char** str, int32_t* len);
+
+/* ffx_run: a TREC run file (q_id Q0 id rank score name) parsed straight into the CSR of
+ * ffx_plan_set_pairs, and written back; replaces Ranking.from_file / cut / save
+ * (ranking.py:388-409, :279-291, :348-366) on the file-to-file path.  Candidate ids are resolved
+ * against `ids` (which must outlive the run); an unknown id is FFX_NOT_FOUND (+ its line). */
+typedef struct ffx_run ffx_run;
+int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* bad_line);
+int ffx_run_close(ffx_run* run);
+int ffx_run_counts(const ffx_run* run, int64_t* n_queries, int64_t* n_pairs);
+int ffx_run_query_id(const ffx_run* run, int64_t q, const char** str, int32_t* len);
+int ffx_run_tag(const ffx_run* run, const char** str, int32_t* len);
+/* cutoff > 0: keep each query's `cutoff` best-scoring candidates first (in place) */
+int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pair_ids, float* sparse, int64_t* n_pairs);
+int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
+                  const char* tag);
+
 /* one-shot: set_queries + set_pairs + run + sync + fetch (host buffers in, host buffers out) */
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               const int64_t* pair_off, const int32_t* pair_ids, const float* sparse, int mode,

@@ -1,0 +1,124 @@
+"""The native host side of libffx (no GPU needed): string-id tables and TREC run files against
+what ``Ranking.from_file`` / ``cut`` / ``save`` do (reference ranking.py:279-291, :348-409)."""
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from fast_forward_amd import Ranking, native
+
+
+def test_id_table_interning_and_lookup():
+    t = native.IdStrings()
+    assert t.intern(["d0", "d1", "d0", "doc with spaces", "d2", "d1"]).tolist() == [0, 1, 0, 2, 3, 1]
+    assert len(t) == 4 and t.get(2) == "doc with spaces"
+    assert t.lookup(np.array(["d2", "d0"])).tolist() == [3, 0]
+    assert t.lookup(np.array([b"d1"], dtype="S8")).tolist() == [1]
+    with pytest.raises(IndexError, match="ID nope not found in the index."):
+        t.lookup(["d0", "nope", "also-no"])
+    # growth across many rehashes keeps ordinals stable
+    many = [f"id-{i}" for i in range(50_000)]
+    got = t.intern(many)
+    assert got[0] == 4 and got[-1] == 4 + len(many) - 1 and t.lookup(["id-31415"]).tolist() == [4 + 31415]
+    assert t.intern([]).shape == (0,) and t.lookup([]).shape == (0,)
+
+
+RUN_TEXT = """q1 Q0 d0 1 1.5 bm25
+q1 Q0 d2 2 300 bm25
+q2\tQ0\td3\t1\t7.25\tbm25
+q1   Q0  d1  3  2e0  bm25
+
+q2 Q0 d0 2 4 bm25
+q2 Q0 d2 3 600.125 bm25
+q2 Q0 d1 4 5 bm25
+"""
+
+
+@pytest.fixture
+def run_path(tmp_path):
+    p = tmp_path / "run.tsv"
+    p.write_text(RUN_TEXT)
+    return p
+
+
+def _table(*ids):
+    t = native.IdStrings()
+    t.intern(list(ids))
+    return t
+
+
+def test_run_parse_matches_ranking_from_file(run_path):
+    table = _table("d0", "d1", "d2", "d3")
+    run = native.RunFile(run_path, table)
+    assert (run.n_queries, run.n_pairs, run.tag) == (2, 7, "bm25")
+    assert run.query_ids() == ["q1", "q2"]
+    pair_off, pair_ids, sparse = run.export()
+    assert pair_off.tolist() == [0, 3, 7]
+    assert pair_ids.tolist() == [0, 2, 1, 3, 0, 2, 1]  # grouped by query, file order inside
+    assert sparse.tolist() == [1.5, 300.0, 2.0, 7.25, 4.0, 600.125, 5.0]
+    ref = Ranking.from_file(run_path)
+    for qi, q in enumerate(run.query_ids()):
+        got = {table.get(o): s for o, s in zip(pair_ids[pair_off[qi]:pair_off[qi + 1]], sparse[pair_off[qi]:pair_off[qi + 1]])}
+        assert got == ref[q]
+    run.close()
+
+
+def test_run_cut_keeps_the_best_of_each_query(run_path):
+    table = _table("d0", "d1", "d2", "d3")
+    run = native.RunFile(run_path, table)
+    pair_off, pair_ids, sparse = run.export(cutoff=2)
+    assert pair_off.tolist() == [0, 2, 4] and run.n_pairs == 4
+    ref = Ranking.from_file(run_path).cut(2)
+    for qi, q in enumerate(run.query_ids()):
+        got = {table.get(o): s for o, s in zip(pair_ids[pair_off[qi]:pair_off[qi + 1]], sparse[pair_off[qi]:pair_off[qi + 1]])}
+        assert got == ref[q]
+
+
+def test_run_errors(run_path, tmp_path):
+    with pytest.raises(IndexError, match="ID d3 not found in the index."):
+        native.RunFile(run_path, _table("d0", "d1", "d2"))
+    dup = tmp_path / "dup.tsv"
+    dup.write_text("q1 Q0 d0 1 1.0 x\nq1 Q0 d0 2 0.5 x\n")
+    with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
+        native.RunFile(dup, _table("d0"))
+    short = tmp_path / "short.tsv"
+    short.write_text("q1 Q0 d0\n")
+    with pytest.raises(ValueError):
+        native.RunFile(short, _table("d0"))
+    with pytest.raises(ValueError):
+        native.RunFile(tmp_path / "missing.tsv", _table("d0"))
+
+
+def test_run_write_is_byte_identical_to_ranking_save(run_path, tmp_path):
+    """Same rows, ranks and float formatting as pandas' to_csv of a float32 column."""
+    table = _table("d0", "d1", "d2", "d3")
+    run = native.RunFile(run_path, table)
+    pair_off, pair_ids, _ = run.export()
+    scores = np.array([152.0, 3.5, 1e-5, 1234567.0, 100000.0, 0.1, 1e16], dtype=np.float32)
+    scores[3] = np.float32(-3.25e-7)
+    # order: per query, descending score, ties by position (what the device sort returns)
+    order = np.concatenate([
+        pair_off[q] + np.argsort(-scores[pair_off[q]:pair_off[q + 1]].astype(np.float64), kind="stable") for q in range(run.n_queries)
+    ]).astype(np.int32)
+    out_native = tmp_path / "native.tsv"
+    run.write(out_native, scores, order, tag="fused")
+    q_names = run.query_ids()
+    df = pd.DataFrame({
+        "q_id": np.repeat(q_names, np.diff(pair_off)), "id": [table.get(o) for o in pair_ids], "score": scores})
+    out_py = tmp_path / "python.tsv"
+    Ranking(df, name="fused").save(out_py)
+    assert out_native.read_text() == out_py.read_text()
+    # keep=2 writes the top two of every query
+    run.write(tmp_path / "top2.tsv", scores, order, keep=2, tag="fused")
+    assert (tmp_path / "top2.tsv").read_text() == "".join(
+        line + "\n" for line in out_py.read_text().splitlines() if int(line.split("\t")[3]) <= 2)
+
+
+@pytest.mark.parametrize("value", [0.0, -0.0, 1.0, 152.0, 0.1, 1e-5, 9.999e-5, 1e-4, 123456.7, 1e15, 1e16, 3.4e38, -2.5e-38, 16777216.0])
+def test_float_formatting_matches_numpy_str(value, tmp_path):
+    table = _table("d0")
+    src = tmp_path / "one.tsv"
+    src.write_text("q Q0 d0 1 0 t\n")
+    run = native.RunFile(src, table)
+    run.write(tmp_path / "o.tsv", np.array([value], dtype=np.float32), np.array([0], dtype=np.int32))
+    assert (tmp_path / "o.tsv").read_text().split("\t")[4] == str(np.float32(value))

@@ -328,3 +328,60 @@ def test_opq_and_generic_quantizers_score_decoded_rows():
     want = oracle_scores(wide.decode(wide.encode(x)))
     for q, i, s in zip(got["q_id"], got["id"], got["score"]):
         assert np.float32(s).view(np.uint32) == np.float32(want[(q, i)]).view(np.uint32)
+
+
+# ---- file-to-file path and PyTerrier adapters ----------------------------------
+def _write_run(path, case, pair_off, names, sparse, tag="bm25"):
+    pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+    with open(path, "w") as f:
+        for q, n, s in zip(pair_q, names, sparse):
+            f.write(f"{case.q_names[q]} Q0 {n} 0 {float(s)!r} {tag}\n")
+
+
+@pytest.mark.parametrize("mode", ["MAXP", "PASSAGE"])
+def test_rerank_file_equals_the_readme_pipeline(tmp_path, mode):
+    """run file -> run file natively == Ranking.from_file -> cut -> index -> interpolate -> save."""
+    case = load_scoring_case("config1")
+    qvecs = case.queries
+    idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mode]))
+    idx.add(case.vectors, doc_ids=case.doc_names, psg_ids=case.psg_names)
+    pair_off, _, sparse, names = case.pairs(mode)
+    queries = {q: str(i) for i, q in enumerate(case.q_names)}
+    run_in = tmp_path / "in.tsv"
+    _write_run(run_in, case, pair_off, names, sparse)
+    for cutoff in (None, 30):
+        first = Ranking.from_file(run_in).attach_queries(queries)
+        if cutoff:
+            first = first.cut(cutoff)
+        want = tmp_path / f"want_{cutoff}.tsv"
+        first.interpolate(idx(first), 0.1).save(want)
+        got = tmp_path / "sub" / f"got_{cutoff}.tsv"
+        stats = idx.rerank_file(run_in, got, 0.1, queries, cutoff=cutoff)
+        assert got.read_text() == want.read_text()
+        assert stats["n_queries"] == len(case.q_names) and stats["ms_gather_dot"] > 0
+    with pytest.raises(ValueError, match="Queries are incomplete"):
+        idx.rerank_file(run_in, tmp_path / "x.tsv", 0.1, {"q000": "0"})
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("q000 Q0 nope 1 1.0 t\n")
+    with pytest.raises(IndexError, match="ID nope not found in the index."):
+        idx.rerank_file(bad, tmp_path / "x.tsv", 0.1, queries)
+    idx.close()
+
+
+def test_pyterrier_transformers():
+    """reference util/pyterrier.py:26-48, :75-83 on plain frames (python-terrier itself is absent)."""
+    from fast_forward_amd.pyterrier import FFInterpolate, FFScore
+
+    idx = both_ids_index()
+    inp = pd.DataFrame([{"qid": q, "query": text, "docno": d, "score": np.float32(s)}
+                        for q, text in QUERIES.items() for d, s in DOC_RUN[q].items()])
+    scored = FFScore(idx).transform(inp)
+    assert set(scored.columns) >= {"qid", "docno", "score", "score_0", "query", "rank"}
+    row = scored[(scored.qid == "q1") & (scored.docno == "d0")].iloc[0]
+    assert row["score"] == 2.0 and row["score_0"] == 100.0
+    best = scored[scored["rank"] == 0].set_index("qid")["docno"].to_dict()
+    assert best == {"q1": "d3", "q2": "d3"}
+    mixed = FFInterpolate(0.5).transform(scored)
+    row = mixed[(mixed.qid == "q2") & (mixed.docno == "d3")].iloc[0]
+    assert row["score"] == 0.5 * 800 + 0.5 * 5 and row["rank"] == 0
+    assert "FFScore(" in repr(FFScore(idx))

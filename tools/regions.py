@@ -97,6 +97,22 @@ out["iii_interpolate_s"] = time.perf_counter() - t0
 t0 = time.perf_counter()
 fused = index.rerank(first, 0.1)
 out["iii_rerank_fused_s"] = time.perf_counter() - t0
+# the same pipeline file to file: native parser + id resolution + device sort + native writer
+import tempfile  # noqa: E402
+
+with tempfile.TemporaryDirectory() as tmp:
+    run_in, run_out, run_py = Path(tmp) / "in.tsv", Path(tmp) / "out.tsv", Path(tmp) / "py.tsv"
+    first.save(run_in)
+    queries_map = {f"q{i:05d}": str(i) for i in range(nq)}
+    index.rerank_file(run_in, run_out, 0.1, queries_map)  # warm (builds the native id table once)
+    t0 = time.perf_counter()
+    index.rerank_file(run_in, run_out, 0.1, queries_map)
+    out["iii_rerank_file_native_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    f2 = Ranking.from_file(run_in).attach_queries(queries_map)
+    f2.interpolate(index(f2), 0.1).save(run_py)
+    out["iii_readme_pipeline_python_s"] = time.perf_counter() - t0
+    out["iii_files_identical"] = run_out.read_text() == run_py.read_text()
 out["iii_pairs"] = nq * k
 out["iii_same_result"] = bool(fused == final)
 out["iii_kernel_ms"] = index.last_stats["ms_gather_dot"]
