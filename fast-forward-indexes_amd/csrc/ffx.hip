@@ -1015,6 +1015,63 @@ int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems) 
   return FFX_OK;
 }
 
+// ---- stand-alone epilogue ---------------------------------------------------------------------------
+int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, int64_t n_pairs, int mode,
+                  const float* sparse, double alpha, const int64_t* pair_off, int64_t n_queries, uint32_t flags,
+                  float* out_ff, float* out_interp, int32_t* out_order) {
+  if (n_pairs < 0 || !seg_off || (n_pairs > 0 && (!row_scores || !out_ff))) return fail(FFX_BAD_ARG, "bad argument");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores: nothing to interpolate");
+  const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
+  if (do_sort && (!pair_off || !out_order || n_queries < 0)) return fail(FFX_BAD_ARG, "sorting needs pair_off and out_order");
+  if (n_pairs == 0) return FFX_OK;
+  const int64_t R = seg_off[n_pairs];
+  if (seg_off[0] != 0 || R > INT32_MAX || n_pairs > INT32_MAX - 1) return fail(FFX_BAD_ARG, "bad segment offsets");
+  std::vector<int32_t> off32((size_t)n_pairs + 1);
+  for (int64_t p = 0; p <= n_pairs; ++p) {
+    if (p > 0 && seg_off[p] <= seg_off[p - 1]) return fail(FFX_BAD_ARG, "candidate %lld has no rows", (long long)(p - 1));
+    off32[(size_t)p] = (int32_t)seg_off[p];
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    return fail(FFX_NO_DEVICE, "no HIP device: libffx has no CPU fallback");
+  }
+  FFX_HIP(hipSetDevice(device));
+  DevBuf rs, so, sp, ff, in, po, order, iota, keys, tmp;
+  int rc = FFX_OK;
+  auto run = [&]() -> int {
+    FFX_TRY(rs.ensure((size_t)R * sizeof(float)));
+    FFX_TRY(so.ensure(off32.size() * sizeof(int32_t)));
+    FFX_TRY(ff.ensure((size_t)n_pairs * sizeof(float)));
+    FFX_HIP(hipMemcpy(rs.p, row_scores, (size_t)R * sizeof(float), hipMemcpyHostToDevice));
+    FFX_HIP(hipMemcpy(so.p, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (sparse) {
+      FFX_TRY(sp.ensure((size_t)n_pairs * sizeof(float)));
+      FFX_TRY(in.ensure((size_t)n_pairs * sizeof(float)));
+      FFX_HIP(hipMemcpy(sp.p, sparse, (size_t)n_pairs * sizeof(float), hipMemcpyHostToDevice));
+    }
+    ffx::reduce_kernel<<<blocks_for(n_pairs, 256), 256>>>(rs.as<float>(), so.as<int32_t>(), n_pairs, mode,
+                                                         sparse ? sp.as<float>() : nullptr, (float)alpha, (float)(1.0 - alpha),
+                                                         ff.as<float>(), in.as<float>());
+    FFX_HIP(hipGetLastError());
+    if (do_sort) {
+      FFX_TRY(po.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+      FFX_HIP(hipMemcpy(po.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+      const float* k = (sparse && !(flags & FFX_FLAG_SORT_FF)) ? in.as<float>() : ff.as<float>();
+      FFX_TRY(launch_segmented_sort(k, n_pairs, po.as<int64_t>(), n_queries, order, iota, keys, tmp, nullptr));
+    }
+    FFX_HIP(hipDeviceSynchronize());
+    FFX_HIP(hipMemcpy(out_ff, ff.p, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_interp) FFX_HIP(hipMemcpy(out_interp, in.p, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    if (do_sort) FFX_HIP(hipMemcpy(out_order, order.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FFX_OK;
+  };
+  rc = run();
+  for (DevBuf* b : {&rs, &so, &sp, &ff, &in, &po, &order, &iota, &keys, &tmp}) b->release();
+  return rc;
+}
+
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
               const int32_t* pair_ids, const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff,
               float* out_interp, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {

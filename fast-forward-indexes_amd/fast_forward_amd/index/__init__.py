@@ -1,9 +1,8 @@
-"""Indexes: ``Index`` (abstract), ``Mode``, ``InMemoryIndex`` (HBM-resident).
-
-``OnDiskIndex`` of the reference (HDF5 streaming) is not part of this
-build yet."""
+"""Indexes: ``Index`` (abstract), ``Mode``, ``InMemoryIndex`` (HBM-resident), ``OnDiskIndex``
+(file-backed, streamed through HBM while scoring)."""
 
 from fast_forward_amd.index.api import Index, Mode
 from fast_forward_amd.index.hbm import InMemoryIndex
+from fast_forward_amd.index.ondisk import OnDiskIndex
 
-__all__ = ["Index", "Mode", "InMemoryIndex"]
+__all__ = ["Index", "Mode", "InMemoryIndex", "OnDiskIndex"]

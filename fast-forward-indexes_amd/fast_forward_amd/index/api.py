@@ -26,6 +26,11 @@ LOGGER = logging.getLogger(__name__)
 IDSequence = Sequence["str | None"]
 
 
+# what pandas.read_csv turns into NaN by default (Ranking.from_file, ranking.py:400-409)
+_PANDAS_NA_STRINGS = frozenset(["", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>",
+                                "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"])
+
+
 class Mode(Enum):
     """Ranking mode of an index (values as in the reference, base.py:18-24)."""
 
@@ -289,6 +294,64 @@ class Index(abc.ABC):
         LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
         # the pairs are those of `ranking`, already known to be unique
         return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
+
+    @abc.abstractmethod
+    def _native_id_table(self, mode: Mode):
+        """The native (``ffx_ids``) table of document or passage ids, ordinals as ``_resolve_ids``."""
+
+    def rerank(self, ranking, alpha: float, cutoff: int | None = None):
+        """Fused device path for the usual pipeline ``first.interpolate(index(first), alpha)``:
+        dense scores, the alpha-interpolation (ranking.py:319) and the per-query ordering
+        (ranking.py:115-117) all happen on the device; returns the interpolated ``Ranking``
+        (optionally cut to the best ``cutoff`` per query).  Same scores, bit for bit."""
+        if not ranking.has_queries:
+            raise ValueError("Input ranking has no queries attached.")
+        df = ranking._df
+        q_no, _, texts = self._numbered_queries(df)
+        query_vectors = np.ascontiguousarray(self.encode_queries(texts))
+        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
+        perm, pair_off = _grouped_by_query(q_no, len(texts))
+        sparse = df["score"].to_numpy(dtype=np.float32)
+        if perm is not None:
+            ordinals, sparse = ordinals[perm], sparse[perm]
+        _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+        src = order if perm is None else perm[order]
+        if cutoff is not None:
+            rank = np.arange(len(src)) - np.repeat(pair_off[:-1], np.diff(pair_off))
+            keep = rank < cutoff
+            src, order = src[keep], order[keep]
+        out = df.iloc[src].reset_index(drop=True)
+        out["score"] = interp[order].astype(df.dtypes["score"])
+        # queries in the order the reference would list them: q_id descending
+        return Ranking(Ranking._trusted(out), name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
+
+    def rerank_file(self, run_in, run_out, alpha: float, queries, cutoff: int | None = None, name: str | None = None) -> dict:
+        """The README pipeline of the reference, file to file, with no pandas in between:
+
+            Ranking.from_file(run_in).attach_queries(queries).cut(cutoff)  ->  index(...)  ->
+            first.interpolate(out, alpha).save(run_out)
+
+        The run is parsed natively into the candidate CSR (ids resolved against this index while
+        parsing: an unknown id raises ``IndexError``), scored, interpolated and ordered on the
+        device, and written back as a TREC run.  ``queries`` maps query id -> query text.
+        Returns the device stage times.  Same scores and ordering as the step-by-step API."""
+        from fast_forward_amd import native
+
+        run = native.RunFile(run_in, self._native_id_table(self.mode))
+        try:
+            q_ids = run.query_ids()
+            missing = [q for q in q_ids if q not in queries]
+            if missing:
+                raise ValueError("Queries are incomplete.")
+            pair_off, ordinals, sparse = run.export(cutoff or 0)
+            query_vectors = np.ascontiguousarray(self.encode_queries([queries[q] for q in q_ids]))
+            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+            if name is None and run.tag in _PANDAS_NA_STRINGS:
+                name = "nan"  # Ranking.from_file reads such a method name as NaN and save() prints "nan"
+            run.write(run_out, interp, order, tag=name)
+            return dict(getattr(self, "last_stats", None) or {}, n_queries=len(q_ids), n_pairs=int(pair_off[-1]))
+        finally:
+            run.close()
 
     # ---- iteration ----------------------------------------------------------------------------------------
     def batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:

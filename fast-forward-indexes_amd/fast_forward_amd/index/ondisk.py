@@ -1,0 +1,388 @@
+"""``OnDiskIndex``: an index kept in a file and streamed through HBM while scoring.
+
+Interface of ``fast_forward.index.OnDiskIndex`` (reference ``src/fast_forward/index/disk.py:25-418``):
+same constructor / ``load`` / ``to_memory`` / ``add`` behaviour and errors.  Two things differ:
+
+* **File format.**  The reference writes HDF5 through h5py, which is not available here, so the
+  file is this build's own single-file container with the same logical content and the same
+  chunking idea (the reference memory-maps raw HDF5 chunks by byte offset, disk.py:100-121):
+
+      [0, 1 MiB)      header: magic ``FFXD0001``, uint64 length, JSON
+                      {num_vectors, dim, dtype, chunk_size, max_id_length, ff_version,
+                       chunks: [byte offset, ...], quantizer: {offset, length} | null}
+      quantizer blob  ``Quantizer.serialize()`` as an .npz (only replaceable while the index is empty)
+      chunk blocks    per chunk: vectors [chunk_size, dim] | doc_ids S<L>[chunk_size] | psg_ids S<L>[chunk_size]
+
+  Reading HDF5 files written by the reference is future work.
+
+* **Scoring.**  ``Index.__call__`` on this class streams only the rows a run needs: the candidate
+  rows are de-duplicated and cut into windows of ``window_bytes``; an uploader thread reads window
+  w+1 from the memory-mapped file and copies it to one of two HBM buffers while the HIP kernels
+  score window w from the other (ctypes releases the GIL, so the copy and the kernels overlap);
+  row scores are collected on the host and aggregated/interpolated/ordered once at the end by
+  ``ffx_aggregate``.  Same arithmetic as the resident index, bit for bit.
+"""
+
+from __future__ import annotations
+
+import io
+import json
+import logging
+import queue
+import struct
+import threading
+from collections.abc import Iterable, Iterator
+from pathlib import Path
+
+import numpy as np
+
+from fast_forward_amd import native
+from fast_forward_amd.encoder import Encoder
+from fast_forward_amd.index.api import IDSequence, Index, Mode
+from fast_forward_amd.index.hbm import InMemoryIndex
+from fast_forward_amd.index.ids import FIRSTP, PASSAGE, IdTable
+from fast_forward_amd.quantizer import Quantizer
+
+LOGGER = logging.getLogger(__name__)
+
+_MAGIC = b"FFXD0001"
+_HEADER_BYTES = 1 << 20
+_FORMAT_VERSION = 1
+
+
+class OnDiskIndex(Index):
+    """Fast-Forward index stored in a file; rows are streamed to the GPU on demand."""
+
+    def __init__(self, index_file: Path, query_encoder: Encoder | None = None, quantizer: Quantizer | None = None,
+                 mode: Mode = Mode.MAXP, encoder_batch_size: int = 32, init_size: int = 2**16, chunk_size: int = 2**16,
+                 max_id_length: int = 8, overwrite: bool = False, memory_mapped: bool = False,
+                 max_indexing_size: int = 2**10, device: int = 0, exact_sum: bool = True,
+                 window_bytes: int = 1 << 30) -> None:
+        """Create (or overwrite) an index file.
+
+        :param init_size: kept for API compatibility (chunks are allocated as rows arrive).
+        :param chunk_size: rows per chunk block of the file.
+        :param max_id_length: maximum length (bytes) of document and passage ids.
+        :param memory_mapped, max_indexing_size: kept for API compatibility; rows are always read
+            through memory maps of the chunk blocks.
+        :param window_bytes: HBM staging budget per window while scoring (two windows are resident).
+        :raises ValueError: when the file exists and ``overwrite`` is false.
+        """
+        index_file = Path(index_file)
+        if index_file.exists() and not overwrite:
+            raise ValueError(f"File {index_file} exists.")
+        native.lib()
+        self._index_file = index_file.absolute()
+        self._init_state(device, exact_sum, window_bytes)
+        self._meta = {"version": _FORMAT_VERSION, "ff_version": "0.8.0+amd", "num_vectors": 0, "dim": None, "dtype": None,
+                      "chunk_size": int(chunk_size), "max_id_length": int(max_id_length), "chunks": [], "quantizer": None}
+        self._index_file.parent.mkdir(parents=True, exist_ok=True)
+        with open(self._index_file, "wb") as f:
+            f.truncate(_HEADER_BYTES)
+        self._write_header()
+        super().__init__(query_encoder=query_encoder, quantizer=quantizer, mode=mode, encoder_batch_size=encoder_batch_size)
+
+    def _init_state(self, device: int, exact_sum: bool, window_bytes: int) -> None:
+        self._ids = IdTable()
+        self._maps: list[tuple[np.memmap, np.memmap, np.memmap]] = []
+        self._device, self.exact_sum, self._window_bytes = int(device), bool(exact_sum), int(window_bytes)
+        self.last_stats: dict | None = None
+
+    # ---- file plumbing ----------------------------------------------------------------------------
+    def _write_header(self) -> None:
+        blob = json.dumps(self._meta).encode()
+        if len(blob) + 16 > _HEADER_BYTES:
+            raise RuntimeError("index header overflow: use a larger chunk_size")
+        with open(self._index_file, "r+b") as f:
+            f.write(_MAGIC + struct.pack("<Q", len(blob)) + blob)
+
+    @staticmethod
+    def _read_header(path: Path) -> dict:
+        with open(path, "rb") as f:
+            head = f.read(16)
+            if head[:8] != _MAGIC:
+                raise ValueError(f"{path} is not an index file of this library (HDF5 files of the reference are not readable yet)")
+            return json.loads(f.read(struct.unpack("<Q", head[8:])[0]))
+
+    def _chunk_layout(self) -> tuple[int, int, int]:
+        m = self._meta
+        vec_bytes = m["chunk_size"] * m["dim"] * np.dtype(m["dtype"]).itemsize
+        id_bytes = m["chunk_size"] * m["max_id_length"]
+        return vec_bytes, id_bytes, vec_bytes + 2 * id_bytes
+
+    def _open_maps(self) -> None:
+        """(Re)create one memory map triple per chunk block (the reference's per-chunk np.memmap)."""
+        m = self._meta
+        self._maps = []
+        if not m["chunks"]:
+            return
+        vec_bytes, id_bytes, _ = self._chunk_layout()
+        ids_dt = np.dtype(f"S{m['max_id_length']}")
+        for off in m["chunks"]:
+            vec = np.memmap(self._index_file, mode="r+", dtype=np.dtype(m["dtype"]), offset=off, shape=(m["chunk_size"], m["dim"]))
+            docs = np.memmap(self._index_file, mode="r+", dtype=ids_dt, offset=off + vec_bytes, shape=(m["chunk_size"],))
+            psgs = np.memmap(self._index_file, mode="r+", dtype=ids_dt, offset=off + vec_bytes + id_bytes, shape=(m["chunk_size"],))
+            self._maps.append((vec, docs, psgs))
+
+    def _ensure_chunks(self, n_total: int) -> None:
+        m = self._meta
+        need = -(-n_total // m["chunk_size"])
+        if need <= len(m["chunks"]):
+            return
+        _, _, block = self._chunk_layout()
+        with open(self._index_file, "r+b") as f:
+            f.seek(0, 2)
+            end = max(f.tell(), _HEADER_BYTES)
+            while len(m["chunks"]) < need:
+                m["chunks"].append(end)
+                end += block
+            f.truncate(end)  # sparse until written
+        self._open_maps()
+
+    def _on_quantizer_set(self) -> None:
+        """Store the serialized quantizer in the file (disk.py:123-136); only possible while empty."""
+        meta, attributes, data = self._quantizer.serialize()
+        buf = io.BytesIO()
+        np.savez(buf, __meta__=np.frombuffer(json.dumps(dict(meta)).encode(), dtype=np.uint8),
+                 __attributes__=np.frombuffer(json.dumps(dict(attributes)).encode(), dtype=np.uint8), **data)
+        blob = buf.getvalue()
+        with open(self._index_file, "r+b") as f:
+            f.truncate(_HEADER_BYTES)
+            f.seek(_HEADER_BYTES)
+            f.write(blob)
+        self._meta["quantizer"] = {"offset": _HEADER_BYTES, "length": len(blob)}
+        self._write_header()
+
+    @staticmethod
+    def _load_quantizer(path: Path, where: dict) -> Quantizer:
+        with open(path, "rb") as f:
+            f.seek(where["offset"])
+            z = np.load(io.BytesIO(f.read(where["length"])))
+        meta = json.loads(bytes(z["__meta__"]).decode())
+        attributes = json.loads(bytes(z["__attributes__"]).decode())
+        data = {k: z[k] for k in z.files if not k.startswith("__")}
+        return Quantizer.deserialize(meta, attributes, data)
+
+    # ---- Index storage interface ------------------------------------------------------------------------
+    def _get_num_vectors(self) -> int:
+        return int(self._meta["num_vectors"])
+
+    def _get_internal_dim(self) -> int | None:
+        return self._meta["dim"]
+
+    def _get_doc_ids(self) -> set[str]:
+        return self._ids.doc_ids
+
+    def _get_psg_ids(self) -> set[str]:
+        return self._ids.psg_ids
+
+    def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
+        m = self._meta
+        limit = m["max_id_length"]
+        # every check first: the index must stay unchanged if anything is wrong (disk.py:207-241)
+        for d in doc_ids:
+            if d is not None and len(d.encode()) > limit:
+                raise RuntimeError(f"Document ID {d} is longer than the maximum ({limit} characters).")
+        for p in psg_ids:
+            if p is not None and len(p.encode()) > limit:
+                raise RuntimeError(f"Passage ID {p} is longer than the maximum ({limit} characters).")
+        if m["dim"] is None:
+            if self._quantizer is not None:
+                dtype = np.dtype(vectors.dtype)  # codes
+            else:
+                dtype = np.dtype(np.float16) if vectors.dtype == np.float16 else np.dtype(np.float32)
+            m["dim"], m["dtype"] = int(vectors.shape[1]), dtype.name
+        n0, n_new = m["num_vectors"], vectors.shape[0]
+        self._ids.add(doc_ids, psg_ids, n0)  # duplicate passage id -> RuntimeError, nothing modified
+        self._ensure_chunks(n0 + n_new)
+        data = np.ascontiguousarray(vectors, dtype=np.dtype(m["dtype"]))
+        docs = np.array([(d or "").encode() for d in doc_ids], dtype=f"S{limit}")
+        psgs = np.array([(p or "").encode() for p in psg_ids], dtype=f"S{limit}")
+        cs, done = m["chunk_size"], 0
+        while done < n_new:
+            c, lo = divmod(n0 + done, cs)
+            take = min(n_new - done, cs - lo)
+            vec, dmap, pmap = self._maps[c]
+            vec[lo:lo + take] = data[done:done + take]
+            dmap[lo:lo + take] = docs[done:done + take]
+            pmap[lo:lo + take] = psgs[done:done + take]
+            done += take
+        for maps in self._maps:
+            for mm in maps:
+                mm.flush()
+        m["num_vectors"] = n0 + n_new
+        self._write_header()
+
+    def _read_rows(self, rows: np.ndarray) -> np.ndarray:
+        """Stored rows (vectors or codes) for global row numbers, in the order given."""
+        rows = np.asarray(rows, dtype=np.int64)
+        out = np.empty((rows.shape[0], self._meta["dim"]), dtype=np.dtype(self._meta["dtype"]))
+        chunk, local = np.divmod(rows, self._meta["chunk_size"])
+        for c in np.unique(chunk):
+            sel = np.flatnonzero(chunk == c)
+            out[sel] = self._maps[int(c)][0][local[sel]]
+        return out
+
+    def _get_vectors(self, ids: Iterable[str]) -> tuple[np.ndarray, list[str]]:
+        rows, owners = self._ids.rows_for(ids, self.mode.value)
+        if not rows:
+            return np.array([]), []
+        return self._read_rows(np.asarray(rows)), owners
+
+    def _batch_iter(self, batch_size: int) -> Iterator[tuple[np.ndarray, IDSequence, IDSequence]]:
+        n = len(self)
+        docs, psgs = self._ids.row_ids(n)
+        for lo in range(0, n, batch_size):
+            hi = min(lo + batch_size, n)
+            yield self._read_rows(np.arange(lo, hi)), docs[lo:hi], psgs[lo:hi]
+
+    def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
+        return self._ids.resolve(ids, mode.value)
+
+    def _native_id_table(self, mode: Mode):
+        return self._ids.native_table(mode.value)
+
+    # ---- persistence ----------------------------------------------------------------------------------------
+    @classmethod
+    def load(cls, index_file: Path, query_encoder: Encoder | None = None, mode: Mode = Mode.MAXP, encoder_batch_size: int = 32,
+             memory_mapped: bool = False, max_indexing_size: int = 2**10, device: int = 0, exact_sum: bool = True,
+             window_bytes: int = 1 << 30) -> "OnDiskIndex":
+        """Open an existing index file (disk.py:355-418): ids are read back into the host tables,
+        the stored quantizer (if any) is reconstructed."""
+        index_file = Path(index_file)
+        native.lib()
+        index = cls.__new__(cls)
+        index._index_file = index_file.absolute()
+        index._init_state(device, exact_sum, window_bytes)
+        index._meta = cls._read_header(index_file)
+        Index.__init__(index, query_encoder=query_encoder, quantizer=None, mode=mode, encoder_batch_size=encoder_batch_size)
+        if index._meta.get("quantizer"):
+            index._quantizer = cls._load_quantizer(index_file, index._meta["quantizer"])
+            index._quantizer._attached = True
+        index._open_maps()
+        n, cs = index._meta["num_vectors"], index._meta["chunk_size"]
+        for c, (_, dmap, pmap) in enumerate(index._maps):
+            lo = c * cs
+            take = min(cs, n - lo)
+            if take <= 0:
+                break
+            docs = [d.decode() or None for d in np.asarray(dmap[:take])]
+            psgs = [p.decode() or None for p in np.asarray(pmap[:take])]
+            index._ids.add(docs, psgs, lo)
+        return index
+
+    def to_memory(self, batch_size: int | None = None) -> InMemoryIndex:
+        """The whole index resident in HBM (disk.py:177-205)."""
+        index = InMemoryIndex(query_encoder=self._query_encoder, quantizer=None, mode=self.mode,
+                              encoder_batch_size=self._encoder_batch_size, init_size=max(1, len(self)),
+                              device=self._device, exact_sum=self.exact_sum)
+        if self._quantizer is not None:
+            index._quantizer = self._quantizer  # already attached and trained; rows below are codes
+        n = len(self)
+        step = batch_size or max(n, 1)
+        docs, psgs = self._ids.row_ids(n)
+        for lo in range(0, n, step):
+            hi = min(lo + step, n)
+            index._add(self._read_rows(np.arange(lo, hi)), docs[lo:hi], psgs[lo:hi])
+        return index
+
+    # ---- scoring: stream the needed rows through two HBM windows --------------------------------------------
+    def _expand(self, pair_off: np.ndarray, pair_ids: np.ndarray, mode: int):
+        """Pairs -> gathered rows on the host (get_indices, index/util.py:29-41):
+        (row numbers [R], query of each row [R], segment offsets [P+1])."""
+        n_pairs = int(pair_off[-1])
+        pair_q = np.repeat(np.arange(pair_off.shape[0] - 1, dtype=np.int64), np.diff(pair_off))
+        ids = pair_ids.astype(np.int64)
+        if mode == PASSAGE:
+            return self._ids.psg_rows().astype(np.int64)[ids], pair_q, np.arange(n_pairs + 1, dtype=np.int64)
+        doc_off, doc_rows = self._ids.doc_csr()
+        start = doc_off[ids]
+        if mode == FIRSTP:
+            return doc_rows.astype(np.int64)[start], pair_q, np.arange(n_pairs + 1, dtype=np.int64)
+        cnt = doc_off[ids + 1] - start
+        seg_off = np.zeros(n_pairs + 1, dtype=np.int64)
+        np.cumsum(cnt, out=seg_off[1:])
+        within = np.arange(int(seg_off[-1]), dtype=np.int64) - np.repeat(seg_off[:-1], cnt)
+        return doc_rows.astype(np.int64)[np.repeat(start, cnt) + within], np.repeat(pair_q, cnt), seg_off
+
+    def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False):
+        if len(self) == 0:
+            raise IndexError("the index is empty")
+        q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+        book = self._quantizer.device_codebook() if self._quantizer is not None else None
+        host_decode = self._quantizer is not None and book is None
+        dim_q = self._quantizer.dims[0] if self._quantizer is not None else self._meta["dim"]
+        if q.ndim != 2 or q.shape[1] != dim_q:
+            raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({dim_q}).")
+        if book is not None and book[1] is not None:
+            q = np.ascontiguousarray(q @ book[1], dtype=np.float32)  # OPQ: rotate the queries (see hbm.py)
+        n_q = q.shape[0]
+        pair_off = np.asarray(pair_off, dtype=np.int64)
+        rows, row_q, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
+        uniq, slot_row = np.unique(rows, return_inverse=True)  # each needed row is read once
+        store_dtype = np.dtype(np.float32) if host_decode else np.dtype(self._meta["dtype"])
+        store_dim = dim_q if host_decode else self._meta["dim"]
+        per_window = max(1, self._window_bytes // max(1, store_dim * store_dtype.itemsize))
+        n_win = -(-uniq.shape[0] // per_window)
+        rs = np.empty(rows.shape[0], dtype=np.float32)
+        stats = {"windows": n_win, "unique_rows": int(uniq.shape[0]), "gathered_rows": int(rows.shape[0]), "ms_gather_dot": 0.0,
+                 "bytes_streamed": int(uniq.shape[0]) * store_dim * store_dtype.itemsize}
+
+        bufs, plans = [], []
+        for _ in range(min(2, n_win)):
+            buf = native.DeviceIndex(min(per_window, uniq.shape[0]), store_dim, self._device, dtype=store_dtype)
+            if book is not None:
+                buf.set_codebook(book[0])
+            buf.set_psg_rows(np.arange(buf.capacity, dtype=np.int32))
+            plan = native.Plan(buf)
+            plan.set_queries(q)
+            bufs.append(buf)
+            plans.append(plan)
+        free, ready = queue.Queue(), queue.Queue()
+        for i in range(len(bufs)):
+            free.put(i)
+        failure: list[BaseException] = []
+        stop = threading.Event()
+
+        def uploader() -> None:
+            try:
+                for w in range(n_win):
+                    i = free.get()
+                    if i is None or stop.is_set():
+                        return
+                    data = self._read_rows(uniq[w * per_window:(w + 1) * per_window])
+                    if host_decode:
+                        data = np.ascontiguousarray(self._quantizer.decode(data), dtype=np.float32)
+                    bufs[i].upload(data, 0)
+                    ready.put((w, i))
+            except BaseException as e:  # surfaced in the scoring thread
+                failure.append(e)
+                ready.put((-1, -1))
+
+        t = threading.Thread(target=uploader, name="ffx-ondisk-uploader", daemon=True)
+        t.start()
+        try:
+            window_of_slot = slot_row // per_window
+            for _ in range(n_win):
+                w, i = ready.get()
+                if w < 0:
+                    raise failure[0]
+                slots = np.flatnonzero(window_of_slot == w)  # ascending: grouped by query already
+                local_off = np.zeros(n_q + 1, dtype=np.int64)
+                np.cumsum(np.bincount(row_q[slots], minlength=n_q), out=local_off[1:])
+                plans[i].set_pairs(local_off, (slot_row[slots] - w * per_window).astype(np.int32), None, PASSAGE)
+                plans[i].run(0.0, exact_sum=self.exact_sum)
+                rs[slots] = plans[i].fetch()[0]
+                stats["ms_gather_dot"] += plans[i].stats()["ms_gather_dot"]
+                stats["kernel_variant"] = plans[i].stats()["kernel_variant"]
+                free.put(i)
+        finally:
+            stop.set()
+            free.put(None)  # unblock the uploader if the scoring thread failed first
+            t.join()
+            for p in plans:
+                p.close()
+            for b in bufs:
+                b.close()
+        self.last_stats = stats
+        return native.aggregate(rs, seg_off, mode.value, sparse, 0.0 if alpha is None else alpha, pair_off, sort=sort, device=self._device)

@@ -28,6 +28,7 @@ SYMBOLS = (
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
+    "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write",
 )
@@ -124,6 +125,7 @@ def lib() -> C.CDLL:
         "ffx_merge_sync": ([vp], C.c_int),
         "ffx_merge_fetch": ([vp, vp, vp, vp], C.c_int),
         "ffx_merge_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
+        "ffx_aggregate": ([C.c_int, vp, vp, i64, C.c_int, vp, C.c_double, vp, i64, C.c_uint32, vp, vp, vp], C.c_int),
         "ffx_ids_create": ([P(vp)], C.c_int),
         "ffx_ids_destroy": ([vp], C.c_int),
         "ffx_ids_count": ([vp, P(i64)], C.c_int),
@@ -503,3 +505,18 @@ class RunFile:
         Path(path).parent.mkdir(parents=True, exist_ok=True)
         _check(lib().ffx_run_write(self._h, str(path).encode(), _ptr(scores), _ptr(order), keep,
                                    None if tag is None else tag.encode()))
+
+
+def aggregate(row_scores, seg_off, mode: int, sparse=None, alpha: float = 0.0, pair_off=None, sort: bool = False, device: int = 0):
+    """``ffx_aggregate``: segment max/first/mean of host row scores, interpolation and per-query
+    order on the device.  Returns (dense, interpolated|None, order|None)."""
+    row_scores, seg_off = _arr(row_scores, np.float32), _arr(seg_off, np.int64)
+    n = seg_off.shape[0] - 1
+    sp = None if sparse is None else _arr(sparse, np.float32)
+    po = None if pair_off is None else _arr(pair_off, np.int64)
+    ff = np.empty(n, dtype=np.float32)
+    interp = None if sp is None else np.empty(n, dtype=np.float32)
+    order = np.empty(n, dtype=np.int32) if sort else None
+    _check(lib().ffx_aggregate(device, _ptr(row_scores), _ptr(seg_off), n, int(mode), _ptr(sp), float(alpha), _ptr(po),
+                               0 if po is None else po.shape[0] - 1, FLAG_SORT if sort else 0, _ptr(ff), _ptr(interp), _ptr(order)))
+    return ff, interp, order

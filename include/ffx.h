@@ -176,6 +176,14 @@ int ffx_merge_sync(ffx_merge* m);
 int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order);
 int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems);
 
+/* ---- stand-alone epilogue: the reduce / interpolate / sort stages of ffx_plan_run applied to row
+ * scores held by the caller (host arrays in, host arrays out).  A streamed (on-disk) index scores
+ * its rows window by window and aggregates once at the end: candidate p owns row scores
+ * seg_off[p] .. seg_off[p+1] (index/base.py:306-312, ranking.py:319, ranking.py:115-117). */
+int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, int64_t n_pairs, int mode,
+                  const float* sparse, double alpha, const int64_t* pair_off, int64_t n_queries, uint32_t flags,
+                  float* out_ff, float* out_interp, int32_t* out_order);
+
 /* ---- host natives: id tables and TREC run files ---------------------------------------------
  * ffx_ids: insertion-ordered string -> ordinal table; replaces the per-id dict look-ups of
  * get_indices (index/util.py:29-41).  Strings cross the ABI as arrays of fixed-width, NUL-padded

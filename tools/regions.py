@@ -112,7 +112,10 @@ with tempfile.TemporaryDirectory() as tmp:
     f2 = Ranking.from_file(run_in).attach_queries(queries_map)
     f2.interpolate(index(f2), 0.1).save(run_py)
     out["iii_readme_pipeline_python_s"] = time.perf_counter() - t0
-    out["iii_files_identical"] = run_out.read_text() == run_py.read_text()
+    a, b = run_out.read_text().splitlines(), run_py.read_text().splitlines()
+    out["iii_files_identical"] = a == b
+    diff = [(x, y) for x, y in zip(a, b) if x != y]
+    out["iii_lines"], out["iii_differing_lines"], out["iii_first_differences"] = (len(a), len(b)), len(diff), diff[:4]
 out["iii_pairs"] = nq * k
 out["iii_same_result"] = bool(fused == final)
 out["iii_kernel_ms"] = index.last_stats["ms_gather_dot"]
