@@ -309,3 +309,63 @@ def test_pq_synthetic_codes_fill():
     want = ((synth.mix64(np.arange(11 * m, (11 + n) * m, dtype=np.uint64), 7) >> np.uint64(32)) % np.uint64(ks)).astype(np.uint8).reshape(n, m)
     assert np.array_equal(got, want)
     idx.close()
+
+
+# ---- BASELINE.json's full size ----------------------------------------------------------------------------
+def test_baseline_config_full_size_properties():
+    """8 841 823 x 768 fp32 in HBM, 6980 queries x k=5000 (34.9 M pairs, the bench workload), checked
+    through properties that need no 27 GB host copy:
+      * the device order is a per-query permutation and scores are non-increasing along it
+      * reversing every candidate list reverses the scores bit for bit (no dependence on tiling)
+      * MAXP == FIRSTP == PASSAGE on one-passage documents
+      * 4096 sampled pairs equal the oracle on rows re-derived on the host
+    """
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, d, nq, k, seed = 8_841_823, 768, 6980, 5000, 2024
+    scale = float(1 / np.sqrt(d))
+    idx = native.DeviceIndex(n, d)
+    idx.fill_synthetic(seed, scale, 0, n)
+    idx.set_doc_rows(np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32))
+    idx.set_psg_rows(np.arange(n, dtype=np.int32))
+    ids, sparse = bench.candidates(n, nq, k, seed)
+    pair_off = np.arange(nq + 1, dtype=np.int64) * k
+    queries = synth.rows(seed + 3, scale, 0, nq, d)
+    plan = native.Plan(idx)
+    plan.set_queries(queries)
+    plan.set_pairs(pair_off, ids, sparse, 2)
+    plan.run(0.1, exact_sum=True, sort=True)
+    ff, interp, order = plan.fetch(interp=True, order=True)
+    st = plan.stats()
+    assert st["n_rows"] == nq * k and st["kernel_variant"] == 111
+    # order: permutation of each query's positions, scores non-increasing
+    o2 = order.reshape(nq, k).astype(np.int64)
+    assert np.array_equal(np.sort(o2, axis=1), pair_off[:-1, None] + np.arange(k)[None, :])
+    along = interp[o2]
+    assert (np.diff(along, axis=1) <= 0).all()
+    ties = np.diff(along, axis=1) == 0
+    assert (np.diff(o2, axis=1)[ties] > 0).all()  # exact ties keep first-stage order
+    # reversed candidate lists
+    rev = ids.reshape(nq, k)[:, ::-1].reshape(-1).copy()
+    plan.set_pairs(pair_off, rev, sparse.reshape(nq, k)[:, ::-1].reshape(-1).copy(), 2)
+    plan.run(0.1, exact_sum=True)
+    ff_r, interp_r, _ = plan.fetch(interp=True)
+    assert np.array_equal(bits(ff_r.reshape(nq, k)[:, ::-1]), bits(ff.reshape(nq, k)))
+    assert np.array_equal(bits(interp_r.reshape(nq, k)[:, ::-1]), bits(interp.reshape(nq, k)))
+    # modes agree on one-passage documents
+    for mode in (1, 3):
+        plan.set_pairs(pair_off, ids, None, mode)
+        plan.run(0.0, exact_sum=True)
+        assert np.array_equal(bits(plan.fetch()[0]), bits(ff)), mode
+    # sampled pairs against the oracle
+    sel = np.random.default_rng(1).choice(nq * k, size=4096, replace=False)
+    rows = fo.synth_row_list(seed, scale, ids[sel], d)
+    want = fo.row_scores(queries, rows, (sel // k).astype(np.int32), np.arange(sel.shape[0], dtype=np.int32))
+    assert np.array_equal(bits(ff[sel]), bits(want))
+    assert np.array_equal(bits(interp[sel]), bits(fo.interpolate(sparse[sel], want, 0.1)))
+    plan.close()
+    idx.close()
