@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Streaming throughput of OnDiskIndex (BASELINE config 5 scaled to one box):
+an index file larger than the staging windows is scored through two HBM windows while an uploader
+thread reads the next window from the memory-mapped file.  Reports GB/s of rows streamed, queries/s,
+and the same run on the HBM-resident copy (to_memory) for comparison and equality."""
+import argparse
+import json
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+from fast_forward_amd.index import Mode, OnDiskIndex  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=2_000_000)
+ap.add_argument("--dim", type=int, default=768)
+ap.add_argument("--queries", type=int, default=200)
+ap.add_argument("--k", type=int, default=5000)
+ap.add_argument("--window-mb", type=int, default=512)
+ap.add_argument("--dir", default=None)
+args = ap.parse_args()
+
+rng = np.random.default_rng(0)
+out = {"rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "window_mb": args.window_mb}
+with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
+    idx = OnDiskIndex(Path(tmp) / "index.ffx", mode=Mode.MAXP, chunk_size=2**16, max_id_length=12, window_bytes=args.window_mb << 20)
+    t0 = time.perf_counter()
+    step = 2**17
+    for lo in range(0, args.rows, step):
+        hi = min(args.rows, lo + step)
+        idx.add((rng.standard_normal((hi - lo, args.dim), dtype=np.float32) * np.float32(0.036)), doc_ids=[f"D{i}" for i in range(lo, hi)])
+    out["build_s"] = time.perf_counter() - t0
+    out["file_gb"] = (Path(tmp) / "index.ffx").stat().st_size / 1e9
+    qv = rng.standard_normal((args.queries, args.dim), dtype=np.float32) * np.float32(0.036)
+    pair_ids = np.concatenate([rng.choice(args.rows, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
+    pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
+    sparse = rng.random(pair_ids.shape[0], dtype=np.float32) * 25
+    for label in ("cold", "warm"):
+        t0 = time.perf_counter()
+        ff, interp, order = idx._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
+        dt = time.perf_counter() - t0
+        st = idx.last_stats
+        out[f"stream_{label}"] = {"seconds": dt, "queries_per_s": args.queries / dt, "windows": st["windows"],
+                                  "unique_rows": st["unique_rows"], "streamed_gb": st["bytes_streamed"] / 1e9,
+                                  "streamed_gb_per_s": st["bytes_streamed"] / 1e9 / dt, "kernel_ms_total": st["ms_gather_dot"]}
+    t0 = time.perf_counter()
+    mem = idx.to_memory(batch_size=2**18)
+    out["to_memory_s"] = time.perf_counter() - t0
+    mem._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
+    t0 = time.perf_counter()
+    ff2, interp2, order2 = mem._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
+    dt = time.perf_counter() - t0
+    out["resident"] = {"seconds": dt, "queries_per_s": args.queries / dt, "kernel_ms": mem.last_stats["ms_gather_dot"]}
+    out["streamed_equals_resident"] = bool(np.array_equal(ff.view(np.uint32), ff2.view(np.uint32)) and
+                                           np.array_equal(interp.view(np.uint32), interp2.view(np.uint32)) and np.array_equal(order, order2))
+print(json.dumps(out, indent=1))
