@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work to measure for the baseline")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per gather_dot launch from a rocprofv3 --pmc pass")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU leg even with one rank (rehearsal)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse N ranks on ONE GPU (exchange staged through the host; RCCL needs one GPU per rank)")
     return ap.parse_args()
 
 
@@ -158,8 +160,13 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
 
     from fast_forward_amd.sharded import ShardedScorer, doc_partition
 
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     scale = float(1.0 / np.sqrt(args.dim))
     doc_off = doc_layout(args.rows, args.layout, args.seed)
     n_docs = doc_off.shape[0] - 1
@@ -193,14 +200,15 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local_rank}")
+    coll_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     ms_per_step = float(elapsed.item()) * 1e3 / args.steps
 
     # kernel time of the last step on this rank (HIP events on the stream the kernel ran on)
     st = scorer.plan.stats()
     row_bytes = args.dim * np.dtype(store).itemsize + 4
-    mine = torch.tensor([st["ms_gather_dot"], float(st["n_rows"])], dtype=torch.float64, device=f"cuda:{local_rank}")
+    mine = torch.tensor([st["ms_gather_dot"], float(st["n_rows"])], dtype=torch.float64, device=coll_dev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     per_rank = [(float(t[0]), int(t[1])) for t in allr]

@@ -144,9 +144,18 @@ class ShardedScorer:
     def run(self, alpha: float, exact_sum: bool = True, sort: bool = False) -> None:
         import torch.distributed as dist
 
-        with self._torch.cuda.stream(self._tstream):
+        torch = self._torch
+        with torch.cuda.stream(self._tstream):
             self.plan.run(0.0, exact_sum=exact_sum)
-            dist.all_to_all_single(self._recv, self._send, self._out_split, self._in_split, group=self.group)
+            if dist.get_backend(self.group) == "gloo":
+                # rehearsal path (several ranks sharing one GPU, where RCCL refuses to run): the
+                # same exchange staged through host memory
+                self._tstream.synchronize()
+                recv_host = torch.empty(self._recv.shape[0], dtype=torch.float32)
+                dist.all_to_all_single(recv_host, self._send.cpu(), self._out_split, self._in_split, group=self.group)
+                self._recv.copy_(recv_host)
+            else:
+                dist.all_to_all_single(self._recv, self._send, self._out_split, self._in_split, group=self.group)
             self.merge.run(self._recv.data_ptr(), alpha, sort=sort, stream=self._stream)
 
     def sync(self) -> None:
