@@ -40,6 +40,7 @@ import numpy as np
 
 from fast_forward_amd import native
 from fast_forward_amd.encoder import Encoder
+from fast_forward_amd.index import h5read
 from fast_forward_amd.index.api import IDSequence, Index, Mode
 from fast_forward_amd.index.hbm import InMemoryIndex
 from fast_forward_amd.index.ids import FIRSTP, PASSAGE, IdTable
@@ -181,6 +182,8 @@ class OnDiskIndex(Index):
 
     def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
         m = self._meta
+        if m.get("read_only"):
+            raise RuntimeError("HDF5 index files of the reference are opened read-only; use to_memory() or copy into a new OnDiskIndex")
         limit = m["max_id_length"]
         # every check first: the index must stay unchanged if anything is wrong (disk.py:207-241)
         for d in doc_ids:
@@ -271,6 +274,9 @@ class OnDiskIndex(Index):
         index = cls.__new__(cls)
         index._index_file = index_file.absolute()
         index._init_state(device, exact_sum, window_bytes)
+        if h5read.is_hdf5(index_file):  # an index written by the reference (h5py): opened read-only
+            index._load_hdf5(query_encoder, mode, encoder_batch_size)
+            return index
         index._meta = cls._read_header(index_file)
         Index.__init__(index, query_encoder=query_encoder, quantizer=None, mode=mode, encoder_batch_size=encoder_batch_size)
         if index._meta.get("quantizer"):
@@ -287,6 +293,45 @@ class OnDiskIndex(Index):
             psgs = [p.decode() or None for p in np.asarray(pmap[:take])]
             index._ids.add(docs, psgs, lo)
         return index
+
+    def _load_hdf5(self, query_encoder, mode, encoder_batch_size) -> None:
+        """Open an HDF5 index file of the reference (layout: disk.py:83-85, :123-165).  The chunk
+        B-tree gives the byte offset of every ``vectors`` chunk, which is memory-mapped exactly as
+        the reference's own mmap mode does (disk.py:100-121); ids are read once into the host
+        tables.  The file is not modified: ``add`` raises."""
+        root = h5read.read(self._index_file)
+        n = int(root.attrs.get("num_vectors", 0))
+        self._meta = {"version": "hdf5", "ff_version": str(root.attrs.get("ff_version", "")), "num_vectors": n, "dim": None,
+                      "dtype": None, "chunk_size": 1, "max_id_length": 0, "chunks": [], "quantizer": None, "read_only": True}
+        Index.__init__(self, query_encoder=query_encoder, quantizer=None, mode=mode, encoder_batch_size=encoder_batch_size)
+        if "quantizer" in root.groups:
+            q = root.groups["quantizer"]
+            meta = dict(q.groups["meta"].attrs)
+            # the reference's quantizer classes live in fast_forward.quantizer.*; same names here
+            meta["__module__"] = "fast_forward_amd.quantizer"
+            meta["_trained"] = bool(meta.get("_trained", False))
+            attributes = {k: (bool(v) if k == "verbose" else v) for k, v in q.groups["attributes"].attrs.items()}
+            data = {k: d.read(self._index_file) for k, d in q.groups["data"].datasets.items()} if "data" in q.groups else {}
+            self._quantizer = Quantizer.deserialize(meta, attributes, data)
+            self._quantizer._attached = True
+        if "vectors" not in root.datasets:
+            return
+        vec = root.datasets["vectors"]
+        if vec.chunk_shape is None or vec.chunk_shape[1] != vec.shape[1]:
+            raise RuntimeError("This index does not support memory maps.")  # same condition as disk.py:103-107
+        cs, dim = vec.chunk_shape
+        self._meta.update(dim=int(dim), dtype=vec.dtype.name, chunk_size=int(cs),
+                          max_id_length=int(root.datasets["doc_ids"].dtype.itemsize))
+        n_chunks = -(-vec.shape[0] // cs)
+        empty = np.zeros((cs, dim), dtype=vec.dtype)
+        self._maps = []
+        for c in range(n_chunks):
+            where = vec.chunks.get((c * cs, 0))
+            rows = empty if where is None else np.memmap(self._index_file, mode="r", dtype=vec.dtype, offset=where[0], shape=(cs, dim))
+            self._maps.append((rows, None, None))
+        docs = root.datasets["doc_ids"].read(self._index_file)[:n]
+        psgs = root.datasets["psg_ids"].read(self._index_file)[:n]
+        self._ids.add([d.decode() or None for d in docs], [p.decode() or None for p in psgs], 0)
 
     def to_memory(self, batch_size: int | None = None) -> InMemoryIndex:
         """The whole index resident in HBM (disk.py:177-205)."""
@@ -337,7 +382,9 @@ class OnDiskIndex(Index):
         pair_off = np.asarray(pair_off, dtype=np.int64)
         rows, row_q, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
         uniq, slot_row = np.unique(rows, return_inverse=True)  # each needed row is read once
-        store_dtype = np.dtype(np.float32) if host_decode else np.dtype(self._meta["dtype"])
+        store_dtype = np.dtype(self._meta["dtype"])
+        if host_decode or store_dtype not in (np.dtype(np.float16), np.dtype(np.uint8)):
+            store_dtype = np.dtype(np.float32)  # float64 files of the reference are scored in fp32 (DESIGN.md divergence 1)
         store_dim = dim_q if host_decode else self._meta["dim"]
         per_window = max(1, self._window_bytes // max(1, store_dim * store_dtype.itemsize))
         n_win = -(-uniq.shape[0] // per_window)

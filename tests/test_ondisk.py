@@ -59,8 +59,8 @@ def test_create_add_load_roundtrip(tmp_path):
     assert next(again.batch_iter(10))[1:] == (["a", "b", None, None], [None, None, "x", "y"])
     assert len(OnDiskIndex.load(OnDiskIndex(tmp_path / "empty.ffx")._index_file).doc_ids) == 0
     with pytest.raises(ValueError, match="not an index file"):
-        (tmp_path / "junk.h5").write_bytes(b"\x89HDF\r\n\x1a\n" + b"0" * 64)
-        OnDiskIndex.load(tmp_path / "junk.h5")
+        (tmp_path / "junk.bin").write_bytes(b"neither format" + b"0" * 64)
+        OnDiskIndex.load(tmp_path / "junk.bin")
 
 
 def test_max_id_length_leaves_index_unchanged(tmp_path):
@@ -171,3 +171,100 @@ def test_to_memory_and_quantized_streaming(tmp_path):
     assert got == ref and qdisk.last_stats["windows"] > 3 and qdisk.last_stats["kernel_variant"] == 2108
     loaded = OnDiskIndex.load(tmp_path / "pq.ffx", LambdaEncoder(lambda t: qvecs[int(t)]))
     assert loaded(first) == ref and loaded.to_memory()(first) == ref
+
+
+# ---- HDF5 files of the reference ---------------------------------------------------------------------------
+import json  # noqa: E402
+from pathlib import Path  # noqa: E402
+
+from fast_forward_amd.index import h5read  # noqa: E402
+
+H5 = Path(__file__).resolve().parent / "golden" / "h5"
+
+
+def test_hdf5_reader_on_real_hdf5_files():
+    """tests/golden/h5/*.h5 were written by real HDF5 (h5py 3.3.0 / HDF5 1.10.6) replaying the
+    reference's calls (oracle/gen_h5_fixture.py); expected.json holds what went in."""
+    exp = json.loads((H5 / "expected.json").read_text())
+    root = h5read.read(H5 / "empty.h5")
+    assert root.attrs == {"num_vectors": 0, "ff_version": "0.8.0"} and not root.datasets
+    root = h5read.read(H5 / "plain.h5")
+    e = exp["plain.h5"]
+    assert root.attrs["num_vectors"] == e["num_vectors"] and root.attrs["ff_version"] == "0.8.0"
+    vec = root.datasets["vectors"]
+    assert vec.chunk_shape == (4, 16) and vec.dtype == np.float32 and len(vec.chunks) == 6
+    assert np.array_equal(vec.read(H5 / "plain.h5")[:23], np.array(e["vectors"], dtype=np.float32))
+    assert [d.decode() or None for d in root.datasets["doc_ids"].read(H5 / "plain.h5")[:23]] == e["doc_ids"]
+    root = h5read.read(H5 / "quantized.h5")
+    e = exp["quantized.h5"]
+    q = root.groups["quantizer"]
+    assert q.groups["meta"].attrs == {"__module__": "fast_forward.quantizer.nanopq", "__name__": "NanoPQ", "_trained": 1}
+    assert q.groups["attributes"].attrs == {"M": 4, "Ks": 8, "Ds": 6, "metric": "dot", "verbose": 0}
+    assert np.array_equal(q.groups["data"].datasets["codewords"].read(H5 / "quantized.h5"), np.array(e["codewords"], dtype=np.float32))
+    assert not h5read.is_hdf5(Path(__file__))
+
+
+def test_load_reference_hdf5_index_files(tmp_path):
+    exp = json.loads((H5 / "expected.json").read_text())
+    assert len(OnDiskIndex.load(H5 / "empty.h5")) == 0
+    e = exp["plain.h5"]
+    idx = OnDiskIndex.load(H5 / "plain.h5", mode=Mode.PASSAGE)
+    assert len(idx) == 23 and idx.dim == 16
+    assert idx.doc_ids == {d for d in e["doc_ids"] if d} and idx.psg_ids == {p for p in e["psg_ids"] if p}
+    want = np.array(e["vectors"], dtype=np.float32)
+    some = [p for p in e["psg_ids"] if p][::3]
+    vecs, ids = idx._get_vectors(some)
+    assert ids == some and np.array_equal(vecs, want[[e["psg_ids"].index(p) for p in some]])
+    idx.mode = Mode.MAXP
+    vecs, ids = idx._get_vectors(["d1"])
+    assert np.array_equal(vecs, want[[i for i, d in enumerate(e["doc_ids"]) if d == "d1"]])
+    v, d, p = zip(*idx.batch_iter(7))
+    assert np.array_equal(np.concatenate(v), want) and sum(d, []) == e["doc_ids"] and sum(p, []) == e["psg_ids"]
+    with pytest.raises(RuntimeError, match="read-only"):
+        idx.add(want[:1], doc_ids=["new"])
+    # float64 file, several chunks
+    e = exp["big_f64.h5"]
+    big = OnDiskIndex.load(H5 / "big_f64.h5")
+    assert len(big) == 1400 and big.dim == 32 and len(big.doc_ids) == 700
+    rows = big._read_rows(np.arange(1400))
+    assert rows.dtype == np.float64 and np.allclose(rows.sum(axis=1), e["row_sums"], rtol=0, atol=1e-12)
+    assert np.array_equal(rows[e["sample_rows"]], np.array(e["vectors_sample"]))
+    # quantized file: the reference's NanoPQ comes back as this build's NanoPQ with the same codewords
+    e = exp["quantized.h5"]
+    q = OnDiskIndex.load(H5 / "quantized.h5")
+    assert isinstance(q.quantizer, NanoPQ) and q.quantizer._trained and q.quantizer.dims == (24, 4) and q.dim == 24
+    assert np.array_equal(q.quantizer._pq.codewords, np.array(e["codewords"], dtype=np.float32))
+    codes, owners = q._get_vectors(["q3", "q0"])
+    assert owners == ["q3", "q0"] and np.array_equal(codes, np.array(e["vectors"], dtype=np.uint8)[[3, 0]])
+    assert next(iter(q))[0].shape == (24,)
+
+
+@pytest.mark.gpu
+def test_hdf5_index_scores_like_the_same_data_in_memory():
+    exp = json.loads((H5 / "expected.json").read_text())
+    rng = np.random.default_rng(0)
+    # float64 HDF5 file -> streamed fp32 scoring == an InMemoryIndex built from the same rows
+    qv = rng.standard_normal((3, 32)).astype(np.float32)
+    enc = LambdaEncoder(lambda t: qv[int(t)])
+    disk = OnDiskIndex.load(H5 / "big_f64.h5", enc, window_bytes=20_000)
+    rows = disk._read_rows(np.arange(1400))
+    mem = InMemoryIndex(enc)
+    mem.add(rows, doc_ids=[f"D{i // 2}" for i in range(1400)], psg_ids=[f"P{i}" for i in range(1400)])
+    run = {f"q{q}": {f"D{d}": float(rng.random()) for d in rng.choice(700, size=200, replace=False)} for q in range(3)}
+    first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(3)})
+    assert disk(first) == mem(first) and disk.last_stats["windows"] > 3
+    assert disk.to_memory()(first) == mem(first)
+    assert disk.rerank(first, 0.3) == mem.rerank(first, 0.3)
+    # quantized HDF5 file -> codes streamed, decode-then-dot with the stored codewords
+    e = exp["quantized.h5"]
+    qv2 = rng.standard_normal((2, 24)).astype(np.float32)
+    enc2 = LambdaEncoder(lambda t: qv2[int(t)])
+    qdisk = OnDiskIndex.load(H5 / "quantized.h5", enc2)
+    codewords, codes = np.array(e["codewords"], dtype=np.float32), np.array(e["vectors"], dtype=np.uint8)
+    decoded = np.concatenate([codewords[m][codes[:, m]] for m in range(4)], axis=1)
+    first = Ranking.from_run({"a": {f"q{i}": 1.0 for i in range(11)}, "b": {"q5": 2.0, "q1": 0.5}}, queries={"a": "0", "b": "1"})
+    got = qdisk(first)
+    import ffx_oracle as fo
+    for qid, qi in (("a", 0), ("b", 1)):
+        for doc, s in got[qid].items():
+            assert np.float32(s) == fo.dot_f32(qv2[qi], decoded[int(doc[1:])])
