@@ -168,3 +168,175 @@ class ShardedScorer:
     def close(self) -> None:
         self.plan.close()
         self.merge.close()
+
+
+# ---- the Index API over a sharded index ------------------------------------------------------------------
+def _owner_of(doc_id: str | None, psg_id: str | None, world: int) -> int:
+    """Rank holding a row: by document id (so a document's passages share a rank), else by
+    passage id.  crc32, not hash(): identical in every process."""
+    import zlib
+
+    key = doc_id if doc_id is not None else psg_id
+    return zlib.crc32(key.encode()) % world
+
+
+class ShardedInMemoryIndex:
+    """``InMemoryIndex`` spread over the ranks of a ``torch.distributed`` group (SPMD: every rank
+    makes the same calls with the same arguments).
+
+    * ``add(vectors, doc_ids, psg_ids)``: each rank keeps the rows whose document (or, for rows
+      without a document id, passage) hashes to it, in its own HBM.
+    * ``__call__(ranking)`` / ``rerank(ranking, alpha)``: every rank resolves the candidate ids it
+      holds (an id held by no rank is the reference's ``IndexError``, raised on all ranks), scores
+      them locally, and the dense scores of a query travel to the rank that owns the query
+      (``exchange``: one all-to-all).  Each rank returns the ``Ranking`` of the queries it owns;
+      ``gather=True`` assembles the complete ``Ranking`` on every rank.
+
+    Scores equal a single ``InMemoryIndex`` holding all rows, bit for bit (same kernels, same
+    per-document row order)."""
+
+    def __init__(self, query_encoder=None, mode=None, encoder_batch_size: int = 32, device: int | None = None,
+                 exact_sum: bool = True, group=None, **index_kwargs):
+        import torch  # before libffx is loaded (native.lib)
+        import torch.distributed as dist
+
+        from fast_forward_amd.index import InMemoryIndex, Mode
+
+        self._torch, self._dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if device is None:
+            device = self.rank % max(1, torch.cuda.device_count())
+        self.device = device
+        self.local = InMemoryIndex(query_encoder, mode=mode or Mode.MAXP, encoder_batch_size=encoder_batch_size, device=device,
+                                   exact_sum=exact_sum, **index_kwargs)
+        self._n_global = 0
+
+    # ---- configuration mirrors the local index -----------------------------------------------------------
+    @property
+    def mode(self):
+        return self.local.mode
+
+    @mode.setter
+    def mode(self, mode) -> None:
+        self.local.mode = mode
+
+    def __len__(self) -> int:
+        return self._n_global
+
+    @property
+    def dim(self):
+        return self.local.dim
+
+    def add(self, vectors: np.ndarray, doc_ids=None, psg_ids=None) -> None:
+        n = vectors.shape[0]
+        doc_ids = [None] * n if doc_ids is None else doc_ids
+        psg_ids = [None] * n if psg_ids is None else psg_ids
+        if not len(doc_ids) == len(psg_ids) == n:
+            raise ValueError("Number of IDs does not match number of vectors.")
+        if any(d is None and p is None for d, p in zip(doc_ids, psg_ids)):
+            raise ValueError("Vector has neither document nor passage ID.")
+        mine = [i for i in range(n) if _owner_of(doc_ids[i], psg_ids[i], self.world) == self.rank]
+        if mine:
+            self.local.add(vectors[mine], doc_ids=[doc_ids[i] for i in mine], psg_ids=[psg_ids[i] for i in mine])
+        self._n_global += n
+
+    # ---- scoring ---------------------------------------------------------------------------------------------
+    def _score(self, ranking, alpha: float | None, sort: bool):
+        import pandas as pd
+
+        from fast_forward_amd.index.api import _grouped_by_query
+
+        dist, torch = self._dist, self._torch
+        if not ranking.has_queries:
+            raise ValueError("Input ranking has no queries attached.")
+        df = ranking._df
+        q_no, q_ids, texts = self.local._numbered_queries(df)
+        n_q = len(texts)
+        query_vectors = np.ascontiguousarray(self.local.encode_queries(texts), dtype=np.float32)
+        perm, pair_off = _grouped_by_query(q_no, n_q)
+        ids = df["id"].to_numpy()
+        sparse = df["score"].to_numpy(dtype=np.float32)
+        if perm is not None:
+            ids, sparse, q_sorted = ids[perm], sparse[perm], q_no[perm]
+        else:
+            q_sorted = q_no
+        # which candidates do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
+        table = self.local._ids
+        lookup = table._psg_ordinal if self.local.mode.value == 1 else table._doc_ordinal
+        uniq, inv = np.unique(ids, return_inverse=True)
+        ord_u = np.fromiter((lookup.get(u, -1) for u in uniq), dtype=np.int64, count=len(uniq))
+        ordinals = ord_u[inv]
+        held = torch.from_numpy((ordinals >= 0).astype(np.int32))
+        total = held.clone()
+        dist.all_reduce(total, group=self.group)  # every pair must be held by exactly one rank
+        if int(total.min()) < 1:
+            bad = int(np.flatnonzero(total.numpy() < 1)[0])
+            raise IndexError(f"ID {ids[bad]} not found in the index.")
+        mine = np.flatnonzero(ordinals >= 0)
+        local_off = np.zeros(n_q + 1, dtype=np.int64)
+        np.cumsum(np.bincount(q_sorted[mine], minlength=n_q), out=local_off[1:])
+        if mine.size:
+            dense_local, _, _ = self.local._score_pairs(query_vectors, local_off, ordinals[mine].astype(np.int32), self.local.mode)
+        else:
+            dense_local = np.zeros(0, dtype=np.float32)
+        # all-to-all to the owners of the queries (contiguous blocks of q_no)
+        q_bounds = query_partition(n_q, self.world)
+        send_counts = np.diff(local_off[q_bounds])
+        holder = np.full(ids.shape[0], -1, dtype=np.int64)
+        gathered = [torch.zeros_like(held) for _ in range(self.world)]
+        dist.all_gather(gathered, held, group=self.group)
+        for r, h in enumerate(gathered):
+            holder[h.numpy() > 0] = r
+        q_lo, q_hi = int(q_bounds[self.rank]), int(q_bounds[self.rank + 1])
+        lo, hi = int(pair_off[q_lo]), int(pair_off[q_hi])
+        own_holder = holder[lo:hi]
+        recv_counts = np.bincount(own_holder, minlength=self.world).astype(np.int64)
+        use_gpu = dist.get_backend(self.group) != "gloo"
+        send = torch.from_numpy(dense_local)
+        if use_gpu:
+            send = send.cuda(self.device)
+        recv = exchange(send, send_counts, recv_counts, self.group)
+        recv = recv.cpu().numpy() if use_gpu else recv.numpy()
+        arrival = np.argsort(own_holder, kind="stable")
+        dense = np.empty(hi - lo, dtype=np.float32)
+        dense[arrival] = recv
+        # owner-side epilogue on the device: interpolation + order (ffx_aggregate with 1-row segments)
+        from fast_forward_amd import native
+
+        own_off = pair_off[q_lo:q_hi + 1] - lo
+        seg = np.arange(hi - lo + 1, dtype=np.int64)
+        if hi > lo:
+            ff, interp, order = native.aggregate(dense, seg, 1, sparse[lo:hi] if alpha is not None else None,
+                                                 0.0 if alpha is None else alpha, own_off, sort=sort, device=self.device)
+        else:
+            ff, interp, order = dense, (dense if alpha is not None else None), np.zeros(0, dtype=np.int32)
+        rows = np.arange(lo, hi) if perm is None else perm[lo:hi]
+        if sort:
+            rows, score = rows[order], (interp if alpha is not None else ff)[order]
+        else:
+            score = interp if alpha is not None else ff
+        out = df.iloc[rows].reset_index(drop=True)
+        out["score"] = score.astype(df.dtypes["score"])
+        return out
+
+    def _finish(self, frame, ranking, name, gather: bool):
+        import pandas as pd
+
+        from fast_forward_amd.ranking import Ranking
+
+        if gather:
+            frames = [None] * self.world
+            self._dist.all_gather_object(frames, frame, group=self.group)
+            frame = pd.concat(frames, ignore_index=True)
+        return Ranking(Ranking._trusted(frame), name=name, dtype=ranking._df.dtypes["score"], copy=False, is_sorted=False)
+
+    def __call__(self, ranking, gather: bool = False):
+        """Dense scores (``Index.__call__``) of the queries this rank owns, or of all with ``gather``."""
+        return self._finish(self._score(ranking, None, sort=False), ranking, "fast-forward", gather)
+
+    def rerank(self, ranking, alpha: float, gather: bool = False):
+        """``ranking.interpolate(index(ranking), alpha)`` with the epilogue on the owners' devices."""
+        return self._finish(self._score(ranking, alpha, sort=True), ranking, ranking.name, gather)
+
+    def close(self) -> None:
+        self.local.close()

@@ -1,0 +1,61 @@
+"""One rank of the ShardedInMemoryIndex test: N ranks share ONE GPU over gloo (RCCL needs a GPU
+per rank); launched by tests/test_index_api.py through torch.distributed.run."""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import torch  # before libffx
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
+    sys.path.insert(0, str(p))
+
+from _cases import MODE_NO, assert_same_order_modulo_ties, load_scoring_case  # noqa: E402
+from fast_forward_amd import Ranking  # noqa: E402
+from fast_forward_amd.encoder import LambdaEncoder  # noqa: E402
+from fast_forward_amd.index import Mode  # noqa: E402
+from fast_forward_amd.sharded import ShardedInMemoryIndex  # noqa: E402
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+case = load_scoring_case("config1")
+qvecs = case.queries
+checked = 0
+for mode in ("MAXP", "PASSAGE", "AVEP"):
+    idx = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mode]), device=0)
+    third = len(case.vectors) // 3
+    for lo, hi in ((0, third), (third, len(case.vectors))):
+        idx.add(case.vectors[lo:hi], doc_ids=case.doc_names[lo:hi], psg_ids=case.psg_names[lo:hi])
+    assert len(idx) == len(case.vectors) and 0 < len(idx.local) < len(case.vectors)
+    pair_off, _, sparse, names = case.pairs(mode)
+    pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+    first = Ranking(pd.DataFrame({"q_id": [case.q_names[q] for q in pair_q], "id": names, "score": sparse}),
+                    queries={q: str(i) for i, q in enumerate(case.q_names)})
+    dense = idx(first, gather=True)
+    exp = case.expected_order(f"{mode}_ff")
+    assert dense._df["q_id"].tolist() == case.z[f"{mode}_ff_q_id"].tolist()
+    for qn in case.q_names:
+        rows = dense._df[dense._df["q_id"] == qn]
+        assert_same_order_modulo_ties(rows["id"].tolist(), rows["score"].to_numpy(), exp[qn])
+    own = idx.rerank(first, 0.1)  # only the queries this rank owns
+    exp_i = case.expected_order(f"{mode}_int0.1")
+    assert 0 < len(own.q_ids) < len(case.q_names)
+    for qn in own.q_ids:
+        rows = own._df[own._df["q_id"] == qn]
+        assert_same_order_modulo_ties(rows["id"].tolist(), rows["score"].to_numpy(), exp_i[qn])
+        checked += len(rows)
+    try:
+        idx(Ranking.from_run({"q000": {names[0]: 1.0, "missing-id": 2.0}}, queries={"q000": "0"}))
+    except IndexError as e:
+        assert "missing-id" in str(e)
+    else:
+        raise AssertionError("unknown id accepted")
+    idx.close()
+total = torch.tensor([checked])
+dist.all_reduce(total)
+if rank == 0:
+    print(f"sharded api world={world}: {int(total)} owned rows checked against the reference frames")
+dist.destroy_process_group()

@@ -385,3 +385,21 @@ def test_pyterrier_transformers():
     row = mixed[(mixed.qid == "q2") & (mixed.docno == "d3")].iloc[0]
     assert row["score"] == 0.5 * 800 + 0.5 * 5 and row["rank"] == 0
     assert "FFScore(" in repr(FFScore(idx))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_index_api_matches_reference_frames(world):
+    """ShardedInMemoryIndex with 2 and 3 ranks (sharing this GPU, exchange over gloo): gathered
+    dense frames and per-owner interpolated frames equal the reference's."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29630 + world), str(root / "tests" / "_sharded_api_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "owned rows checked" in out.stdout
