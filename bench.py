@@ -324,7 +324,7 @@ def main():
         try:
             pm = json.loads((ROOT / "profiles" / "r01" / "pmc_summary.json").read_text())["bench_gather_dot"]
             same = (pm["algorithmic_bytes_per_launch"] == st["n_rows"] * row_bytes and args.layout == "single"
-                    and {111: "exact_lds_kernel<3, 4, 8, true>", 211: "fast_kernel<3, 4, 8, true>"}.get(st["kernel_variant"], "?") in pm["kernel"])
+                    and {111: "exact_lds_kernel<float, 3, 4, 8, true>", 211: "fast_kernel<float, 3, 4, 8, true>"}.get(st["kernel_variant"], "?") in pm["kernel"])
             if same:
                 traffic, traffic_src = pm["hbm_bytes_per_launch"], "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
         except (OSError, KeyError, ValueError):
