@@ -248,6 +248,8 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
             },
             "exchange_bytes_per_rank": int(scorer.route.recv_counts.sum() - scorer.route.recv_counts[rank]) * 4,
             "device": dev["name"],
+            "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize)),
+            "index_capacity_rows_total": world * int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize)),
         }
         if parity is not None:
             result["cpu_baseline"] = base
