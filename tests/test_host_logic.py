@@ -122,3 +122,18 @@ def test_argument_checks_fire_before_device_work():
     assert len(idx) == 0 and idx.dim is None and idx.mode == Mode.MAXP
     idx.mode = Mode.FIRSTP
     assert idx.mode == Mode.FIRSTP
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ffx.h must be consumable from C (the drop-in boundary is a C ABI, not C++)."""
+    import subprocess
+
+    src = tmp_path / "use_ffx.c"
+    src.write_text('#include "ffx.h"\nint main(void) { ffx_stats s; (void)s; return ffx_abi_version() == FFX_ABI_VERSION ? 0 : 1; }\n')
+    lib_dir = ROOT / "fast-forward-indexes_amd" / "fast_forward_amd"
+    exe = tmp_path / "use_ffx"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+           f"-L{lib_dir}", "-l:libffx.so", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert subprocess.run([str(exe)]).returncode == 0
