@@ -597,6 +597,18 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   // tuning hook (tools/kernel_ab.py): FFX_GATHER_VARIANT selects an experimental d=768 instantiation
   const char* exp_env = getenv("FFX_GATHER_VARIANT");
   const int exp_variant = exp_env ? atoi(exp_env) : 0;
+  if (exp_variant >= 800 && exp_variant < 900) {  // the strided-load form of the small-row dims, for A/B
+    switch (d) {
+      case 512: FFX_EXACT(4, 16, 2, 803); break;
+      case 384: FFX_EXACT(4, 12, 4, 804); break;
+      case 256: FFX_EXACT(2, 16, 2, 805); break;
+      case 128: FFX_EXACT(1, 16, 2, 806); break;
+      case 64: FFX_EXACT(1, 8, 4, 807); break;
+      default: return fail(FFX_BAD_ARG, "no strided variant for dim %d", d);
+    }
+    FFX_HIP(hipGetLastError());
+    return FFX_OK;
+  }
   if (d == 768 && exp_variant >= 900) {
     const unsigned waves = (unsigned)R;
     switch (exp_variant) {
@@ -639,11 +651,19 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R);
         pl->variant = 112 + HALF;
         break;
-      case 512: FFX_EXACT(4, 16, 2, 103); break;
-      case 384: FFX_EXACT(4, 12, 4, 104); break;
-      case 256: FFX_EXACT(2, 16, 2, 105); break;
-      case 128: FFX_EXACT(1, 16, 2, 106); break;
-      case 64: FFX_EXACT(1, 8, 4, 107); break;
+#define FFX_MULTI(LEAVES, NPER, U, TILE, ID)                                                                     \
+  do {                                                                                                           \
+    ffx::gather_dot_exact_lds_multi_kernel<T, LEAVES, NPER, U, TILE, true><<<blocks_for(R, 4 * TILE), 256, 0, st>>>( \
+        V, Q, desc, rs, R);                                                                                      \
+    pl->variant = ID + HALF;                                                                                     \
+  } while (0)
+      // smaller rows: several rows share a wave, same full-line nt loads + LDS transpose
+      case 512: FFX_MULTI(4, 16, 2, 16, 113); break;
+      case 384: FFX_MULTI(4, 12, 2, 16, 114); break;
+      case 256: FFX_MULTI(2, 16, 2, 32, 115); break;
+      case 128: FFX_MULTI(1, 16, 2, 64, 116); break;
+      case 64: FFX_MULTI(1, 8, 4, 64, 117); break;
+#undef FFX_MULTI
       default:
         if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
         ffx::gather_dot_exact_generic_kernel<T><<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(

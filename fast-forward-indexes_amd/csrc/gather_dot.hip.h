@@ -277,6 +277,97 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   }
 }
 
+// ---- the same for smaller rows: d = 8*LEAVES*NPER with LEAVES in {1,2,4}, NPER % 4 == 0 ----------
+// (d = 512, 384, 256, 128, 64, ...).  NumPy's tree for such a row has 8*LEAVES partial sums, so
+// RPP = 8/LEAVES rows fill a wave.  A pass takes RPP consecutive work rows and treats them as ONE
+// row of 64*NPER floats with 8 leaves of LL = 8*NPER elements: element e of the concatenation lives
+// in row e / D at offset e % D, leaf e / LL -- so the LDS transpose is the 8-leaf one above, the
+// only differences being per-lane row/query addresses and a shorter butterfly (a row's partial
+// sums occupy 8*LEAVES adjacent lanes; lane 8*LEAVES*s ends with the score of the pass's row s).
+template <typename T, int LEAVES, int NPER, int U, int TILE, bool NT>
+__global__ void __launch_bounds__(256)
+gather_dot_exact_lds_multi_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
+                                  const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  constexpr int LPR = 8 * LEAVES;     // lanes per row in the summation phase
+  constexpr int RPP = 64 / LPR;       // rows per pass
+  constexpr int D = LPR * NPER;
+  constexpr int LL = 8 * NPER;        // leaf length
+  constexpr int LPAD = LL + 8;
+  constexpr int NCH = NPER / 4;       // float4 groups per lane per pass
+  static_assert(LEAVES == 1 || LEAVES == 2 || LEAVES == 4, "use gather_dot_exact_lds_kernel for 8 leaves");
+  static_assert(NPER % 4 == 0 && LL % 32 == 0 && LL <= 128, "leaf length must be a multiple of 32");
+  static_assert(TILE % (U * RPP) == 0 && TILE <= 64, "bad tile");
+  __shared__ __attribute__((aligned(16))) float tile[4][8 * LPAD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+  const long base = (long)wave * TILE;
+  if (base >= n_rows) return;
+  const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+  const int my_t = lane < n_here ? lane : n_here - 1;
+  const int2 my = desc[base + my_t];
+
+  float* buf = tile[wave_in_block];
+  int woff[NCH], slot[NCH], roff[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = 4 * lane + 256 * c;
+    woff[c] = (e / LL) * LPAD + (e % LL);
+    slot[c] = e / D;  // which row of the pass these 4 elements belong to
+    roff[c] = e % D;  // and where in that row
+  }
+  const float* rbuf = buf + (lane >> 3) * LPAD + (lane & 7);
+  const int out_slot = lane / LPR;
+
+  float4 q[NCH];
+  int cur_q[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) cur_q[c] = -1;
+#pragma unroll 1
+  for (int b = 0; b < TILE; b += U * RPP) {
+    if (b >= n_here) break;
+    typename raw4<T>::type v[U][NCH];
+    int qn[U][NCH];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int t = b + u * RPP + slot[c];
+        t = t < n_here ? t : n_here - 1;
+        const int rid = __shfl(my.x, t, 64);
+        qn[u][c] = __shfl(my.y, t, 64);
+        v[u][c] = load4raw<T, NT>(vectors + (size_t)rid * D + roff[c]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (__ballot(qn[u][c] != cur_q[c]) != 0ull) {  // wave-uniform: reload only when some lane's query changed
+          cur_q[c] = qn[u][c];
+          q[c] = *reinterpret_cast<const float4*>(queries + (size_t)cur_q[c] * D + roff[c]);
+        }
+        const float4 w = widen4(v[u][c]);
+        float4 p;
+        p.x = __fmul_rn(q[c].x, w.x);
+        p.y = __fmul_rn(q[c].y, w.y);
+        p.z = __fmul_rn(q[c].z, w.z);
+        p.w = __fmul_rn(q[c].w, w.w);
+        *reinterpret_cast<float4*>(buf + woff[c]) = p;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float acc = rbuf[0];
+#pragma unroll
+      for (int i = 1; i < NPER; ++i) acc = __fadd_rn(acc, rbuf[8 * i]);
+      __builtin_amdgcn_wave_barrier();
+      acc = butterfly<LEAVES>(acc);
+      const int t = b + u * RPP + out_slot;
+      if ((lane & (LPR - 1)) == 0 && t < n_here) rs[base + t] = acc;
+    }
+  }
+}
+
 // ---- fast kernel, d = 256*NCH: lane holds NCH float4 per row (16-B coalesced loads) --------
 template <typename T, int NCH, int U, int TILE = 16, bool NT = false>
 __global__ void __launch_bounds__(256)

@@ -23,9 +23,10 @@ ap.add_argument("--k", type=int, default=5000)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--variants", default="0,900,907,911,913,916,919,920,fast,951,953,955,958,959")
 ap.add_argument("--store", default="f32", choices=["f32", "f16"])
+ap.add_argument("--dim", type=int, default=768)
 args = ap.parse_args()
 
-d, seed = 768, 2024
+d, seed = args.dim, 2024
 scale = float(1 / np.sqrt(d))
 store = np.float16 if args.store == "f16" else np.float32
 idx = native.DeviceIndex(args.rows, d, dtype=store)
@@ -50,6 +51,8 @@ for rnd in range(args.rounds + 1):
         else:
             os.environ["FFX_GATHER_VARIANT"] = v
             exact = not (v.startswith("95"))
+        if v == "strided":  # small-row dims: the strided-load form
+            os.environ["FFX_GATHER_VARIANT"] = "800"
         plan.run(0.1, exact_sum=exact)
         st = plan.stats()
         if rnd == 0:  # warm-up round doubles as a correctness check of every exact variant
