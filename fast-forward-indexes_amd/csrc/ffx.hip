@@ -677,6 +677,9 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       case 512: ffx::gather_dot_fast_kernel<T, 2, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213 + HALF; break;
       case 256: ffx::gather_dot_fast_kernel<T, 1, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214 + HALF; break;
       default:
+        // dims with a multi-row exact kernel but no FMA specialisation: the exact kernel is HBM-bound
+        // too (and 1.3-2.8x faster than the one-row-per-wave generic kernel), so "fast" uses it
+        if (d == 384 || d == 128 || d == 64) return launch_gather_dot_t<T>(pl, true, rs);
         if (d % 4 == 0) {
           ffx::gather_dot_fast_generic_kernel<T><<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);
           pl->variant = 298 + HALF;
