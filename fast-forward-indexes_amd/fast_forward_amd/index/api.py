@@ -235,16 +235,24 @@ class Index(abc.ABC):
             if b < cutoff:
                 continue
             if a > 0:
-                scored = ~np.isnan(ff)
-                for q in np.flatnonzero(active):
-                    rows = np.flatnonzero(scored & (q_no == q))
-                    if rows.size == 0:
-                        active[q] = False
-                        continue
-                    ints = np.sort(interp[rows])[::-1]
-                    kth = ints[min(cutoff, ints.size) - 1]
-                    bound = alpha * sparse[rows[-1]] + (1 - alpha) * np.max(ff[rows])
-                    active[q] = bool(kth < bound)
+                # continue-criterion for all queries at once.  Scored rows, grouped by query:
+                rows = np.flatnonzero(~np.isnan(ff))
+                rows = rows[np.argsort(q_no[rows], kind="stable")]          # frame order kept inside a query
+                qs = q_no[rows]
+                starts = np.flatnonzero(np.r_[True, qs[1:] != qs[:-1]])
+                ends = np.r_[starts[1:], rows.size]
+                present = qs[starts]
+                # cutoff-th best interpolated score so far (the worst one if fewer were scored)
+                by_score = rows[np.lexsort((-interp[rows].astype(np.float64), qs))]
+                kth = interp[by_score[np.minimum(starts + cutoff, ends) - 1]]
+                # best it could still reach: alpha * (sparse score of the last scored candidate) +
+                # (1 - alpha) * (best dense score so far) -- NumPy scalar promotion as in the reference
+                last_sparse = sparse[rows[ends - 1]]
+                best_dense = np.maximum.reduceat(ff[rows], starts)
+                bound = alpha * last_sparse + (1 - alpha) * best_dense
+                keep = np.zeros(n_q, dtype=bool)
+                keep[present] = kth < bound
+                active &= keep
             LOGGER.info("depth %s: %s queries left", b, int(active.sum()))
             take = np.flatnonzero(active[q_no] & (rank_in_q >= a) & (rank_in_q < b))
             if take.size == 0:
