@@ -283,9 +283,22 @@ class Index(abc.ABC):
         q_no, _, texts = self._numbered_queries(df)
         # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
         # work (the reference raises from its first batch; either way no partial result is returned)
-        work = df.assign(q_no=q_no, _ord=self._resolve_ids(df["id"].to_numpy(), self.mode))
+        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
+        if early_stopping is None and (batch_size is None or batch_size >= n_q) and len(df) > 0:
+            # the common case without the intermediate frames: CSR in, scores out
+            perm, pair_off = _grouped_by_query(q_no, n_q)
+            dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals if perm is None else ordinals[perm], self.mode)
+            if perm is not None:
+                unperm = np.empty_like(dense)
+                unperm[perm] = dense
+                dense = unperm
+            result = df.copy()
+            result["score"] = dense.astype(df.dtypes["score"], copy=False)
+            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+            return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
+        work = df.assign(q_no=q_no, _ord=ordinals)
 
         def score(part: pd.DataFrame) -> pd.DataFrame:
             if early_stopping is None:

@@ -396,9 +396,12 @@ def _as_fixed_bytes(strings) -> np.ndarray:
     a = np.asarray(strings)
     if a.dtype.kind == "S":
         return np.ascontiguousarray(a)
-    if a.dtype.kind == "U":
-        return np.char.encode(a, "utf-8")
-    return np.array([s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in a.tolist()] or [b""], dtype="S")[: len(a)]
+    if a.size == 0:
+        return np.empty(0, dtype="S1")
+    try:  # ASCII ids (the usual case): one vectorised conversion
+        return np.ascontiguousarray(a.astype("S"))
+    except (UnicodeEncodeError, ValueError, TypeError):
+        return np.array([s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in a.tolist()], dtype="S")
 
 
 class IdStrings:

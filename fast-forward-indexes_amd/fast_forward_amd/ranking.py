@@ -86,7 +86,15 @@ class Ranking:
             raise ValueError("Only one score per query-document/passage pair is allowed.")
 
         keep = _KEY + ["score"] + (["query"] if "query" in df.columns else [])
-        frame = df.loc[:, keep].dropna()
+        frame = df.loc[:, keep]
+        if getattr(df, "_ffx_pairs_unique", False):
+            # derived from an existing Ranking: ids and queries are known to be present, only a
+            # score can be missing (early stopping leaves unscored candidates as NaN)
+            scored = frame["score"].notna().to_numpy()
+            if not scored.all():
+                frame = frame[scored]
+        else:
+            frame = frame.dropna()
         if copy:
             frame = frame.copy()
         wanted = {"score": dtype, "q_id": str, "id": str}
