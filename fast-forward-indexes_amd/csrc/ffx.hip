@@ -706,7 +706,34 @@ static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
   const float* Q = pl->queries.as<float>();
   const int2* desc = pl->desc.as<int2>();
   hipStream_t st = pl->stream;
-  if (exact) {
+  // subspaces == leaves of NumPy's tree (every leaf has length Ds, M in {1,2,4,8,16}): exact ADC
+  // (FFX_PQ_NO_ADC forces decode-then-dot: tests and A/B)
+  bool aligned = exact && !getenv("FFX_PQ_NO_ADC") && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
+  if (aligned) {
+    std::vector<int> bounds;
+    numpy_leaf_plan(0, d, bounds);
+    for (int m = 0; m < M && aligned; ++m) aligned = bounds[(size_t)m] == m * Ds;
+  }
+  if (aligned) {
+    const size_t lut_bytes = (size_t)pl->n_queries * M * Ks * sizeof(float);
+    FFX_TRY(pl->lut.ensure(std::max<size_t>(lut_bytes, 16)));
+    if (pl->n_queries > 0) {
+      ffx::pq_lut_exact_kernel<<<dim3((unsigned)pl->n_queries, (unsigned)M), 256, 0, st>>>(Q, ix->codebook_t.as<float>(), M, Ks, Ds,
+                                                                                          pl->lut.as<float>());
+      FFX_HIP(hipGetLastError());
+    }
+    const size_t lds = (size_t)M * Ks * sizeof(float);
+#define FFX_ADCX(MM) ffx::pq_adc_exact_kernel<MM><<<blocks_for(R, 256), 256, lds, st>>>(codes, Ks, pl->lut.as<float>(), desc, rs, R)
+    switch (M) {
+      case 1: FFX_ADCX(1); break;
+      case 2: FFX_ADCX(2); break;
+      case 4: FFX_ADCX(4); break;
+      case 8: FFX_ADCX(8); break;
+      default: FFX_ADCX(16); break;
+    }
+#undef FFX_ADCX
+    pl->variant = 2200 + M;
+  } else if (exact) {
     const bool lds_ok = (d == 768 || d == 1024) && Ds % 4 == 0 && (M == 8 || M == 16 || M == 32);
     if (lds_ok) {
 #define FFX_PQ(NCH, MW) ffx::gather_dot_pq_lds_kernel<NCH, MW, 4, 16><<<blocks_for(R, 64), 256, 0, st>>>(codes, cb, Ks, Ds, Q, desc, rs, R)

@@ -662,6 +662,73 @@ pq_lut_kernel(const float* __restrict__ queries, const float* __restrict__ codeb
   }
 }
 
+// ---- exact ADC: when a subspace IS a leaf of NumPy's summation tree --------------------------------
+// For d = M*Ds with Ds <= 128 and M a power of two whose subspaces coincide with the leaves of the
+// pairwise recursion (d = 768, M = 8: leaves of 96 -- the reference's own NanoPQ(8, 256) on 768-d
+// vectors), the sum NumPy forms over one leaf involves one subspace only:
+//     leaf_m = tree8( sum_i q[m*Ds + 8i + j] * codeword[m][code_m][8i + j] )
+// so it can be tabulated per (query, subspace, codeword) WITH NumPy's rounding, and a row's score
+// is the balanced pairwise combination of its M table entries -- bit-identical to
+// np.sum(q * decode(codes)) at the cost of M look-ups and M-1 adds per row.
+__global__ void __launch_bounds__(256)
+pq_lut_exact_kernel(const float* __restrict__ queries, const float* __restrict__ codebook_t, int M, int Ks, int Ds,
+                    float* __restrict__ lut) {
+  const int q = blockIdx.x, m = blockIdx.y;
+  const float* qv = queries + ((size_t)q * M + m) * Ds;
+  const float* ct = codebook_t + (size_t)m * Ds * Ks;
+  for (int ks = threadIdx.x; ks < Ks; ks += blockDim.x) {
+    float res;
+    if (Ds < 8) {
+      res = -0.0f;
+      for (int i = 0; i < Ds; ++i) res = __fadd_rn(res, __fmul_rn(qv[i], ct[(size_t)i * Ks + ks]));
+    } else {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = __fmul_rn(qv[j], ct[(size_t)j * Ks + ks]);
+      const int lim = Ds - (Ds % 8);
+      for (int i = 8; i < lim; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], __fmul_rn(qv[i + j], ct[(size_t)(i + j) * Ks + ks]));
+      }
+      res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                      __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+      for (int i = lim; i < Ds; ++i) res = __fadd_rn(res, __fmul_rn(qv[i], ct[(size_t)i * Ks + ks]));
+    }
+    lut[((size_t)q * M + m) * Ks + ks] = res;
+  }
+}
+
+template <int M>
+__global__ void __launch_bounds__(256)
+pq_adc_exact_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __restrict__ lut,
+                    const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  extern __shared__ float table[];
+  const long r0 = (long)blockIdx.x * blockDim.x;
+  const long r = r0 + threadIdx.x;
+  const long last = (r0 + blockDim.x - 1) < (long)n_rows ? (r0 + blockDim.x - 1) : (long)n_rows - 1;
+  const int q_first = desc[r0].y, q_last = desc[last].y;
+  const bool one_query = q_first == q_last;
+  if (one_query) {
+    const float* src = lut + (size_t)q_first * M * Ks;
+    for (int i = threadIdx.x; i < M * Ks; i += blockDim.x) table[i] = src[i];
+  }
+  __syncthreads();
+  if (r >= n_rows) return;
+  const int2 de = desc[r];
+  const uint8_t* c = codes + (size_t)de.x * M;
+  const float* t = one_query ? table : lut + (size_t)de.y * M * Ks;
+  float leaf[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) leaf[m] = t[(size_t)m * Ks + c[m]];
+  // balanced pairwise combination = NumPy's recursion over equal leaves
+#pragma unroll
+  for (int s = 1; s < M; s *= 2) {
+#pragma unroll
+    for (int i = 0; i + s < M; i += 2 * s) leaf[i] = __fadd_rn(leaf[i], leaf[i + s]);
+  }
+  rs[r] = leaf[0];
+}
+
 // One thread per row.  Rows of a query are contiguous, so almost every block works for a single
 // query: its M*Ks-float table is staged in LDS once and the M look-ups per row hit LDS.
 __global__ void __launch_bounds__(256)

@@ -291,8 +291,18 @@ def test_pq_decode_then_dot_bit_identical_to_reference(name):
             exp = case.expected(key)
             want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
             assert np.array_equal(bits(got), bits(want)), (name, key, st["kernel_variant"])
-        assert st["kernel_variant"] == (2199 if name == "pq_d60_m5" else 2100 + m)
+        # subspaces == NumPy leaves (d=768, M=8): exact ADC; otherwise decode-then-dot (LDS / generic)
+        assert st["kernel_variant"] == {"pq_d768_m8": 2208, "pq_d768_m16": 2116, "pq_d1024_m32": 2132, "pq_d60_m5": 2199}[name]
         assert np.array_equal(order.astype(np.int64), fo.order(interp, pair_off))
+        if name == "pq_d768_m8":  # the decode-then-dot kernel must give the same bits
+            import os
+
+            os.environ["FFX_PQ_NO_ADC"] = "1"
+            try:
+                ff2, _, _, st2 = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=True)
+            finally:
+                del os.environ["FFX_PQ_NO_ADC"]
+            assert st2["kernel_variant"] == 2108 and np.array_equal(bits(ff2), bits(ff))
         # ADC (fast order): same value up to fp32 rounding of a different summation order
         fast, _, _, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=False)
         assert st["kernel_variant"] == 2300
@@ -368,4 +378,27 @@ def test_baseline_config_full_size_properties():
     assert np.array_equal(bits(ff[sel]), bits(want))
     assert np.array_equal(bits(interp[sel]), bits(fo.interpolate(sparse[sel], want, 0.1)))
     plan.close()
+    idx.close()
+
+
+@pytest.mark.parametrize("d,m,ks", [(768, 8, 256), (1024, 8, 64), (384, 4, 32), (2048, 16, 16), (96, 1, 8), (256, 2, 200)])
+def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
+    """Tabulated leaf sums + balanced pairwise combination == np.sum(q * decode(codes)), bit for bit."""
+    rng = np.random.default_rng(d + m)
+    n, nq, k = 3000, 5, 700
+    codewords = synth.rows(50 + d, 1.0, 0, m * ks, d // m).reshape(m, ks, d // m)
+    codes = rng.integers(0, ks, size=(n, m)).astype(np.uint8)
+    queries = synth.rows(51 + d, 1.0, 0, nq, d)
+    idx = native.DeviceIndex(n, m, dtype=np.uint8)
+    idx.set_codebook(codewords)
+    idx.upload(codes, 0)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    pair_off = np.arange(nq + 1) * k
+    pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for _ in range(nq)]).astype(np.int32)
+    ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 1, exact_sum=True)
+    assert st["kernel_variant"] == 2200 + m
+    decoded = np.concatenate([codewords[j][codes[:, j]] for j in range(m)], axis=1)
+    ref = np.sum(queries[np.repeat(np.arange(nq), k)] * decoded[pair_ids], axis=1)
+    assert np.array_equal(bits(ff), bits(ref))
     idx.close()
