@@ -708,7 +708,8 @@ static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
   hipStream_t st = pl->stream;
   // subspaces == leaves of NumPy's tree (every leaf has length Ds, M in {1,2,4,8,16}): exact ADC
   // (FFX_PQ_NO_ADC forces decode-then-dot: tests and A/B)
-  bool aligned = exact && !getenv("FFX_PQ_NO_ADC") && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
+  // (the exact table is also the fastest one, so exact_sum=false takes it too when it applies)
+  bool aligned = !getenv("FFX_PQ_NO_ADC") && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
   if (aligned) {
     std::vector<int> bounds;
     numpy_leaf_plan(0, d, bounds);

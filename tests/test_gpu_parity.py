@@ -305,7 +305,7 @@ def test_pq_decode_then_dot_bit_identical_to_reference(name):
             assert st2["kernel_variant"] == 2108 and np.array_equal(bits(ff2), bits(ff))
         # ADC (fast order): same value up to fp32 rounding of a different summation order
         fast, _, _, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=False)
-        assert st["kernel_variant"] == 2300
+        assert st["kernel_variant"] == (2208 if name == "pq_d768_m8" else 2300)  # the exact table is the faster one where it applies
         assert np.abs(fast - ff).max() <= FAST_TOL * max(1.0, float(np.abs(ff).max()))
     idx.close()
 
