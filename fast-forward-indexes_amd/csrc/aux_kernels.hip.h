@@ -196,9 +196,9 @@ fill_codes_kernel(uint8_t* __restrict__ dst, int64_t n_elems, uint64_t first_ele
 }
 
 __global__ void __launch_bounds__(256)
-iota_kernel(int32_t* __restrict__ dst, int64_t n) {
+iota_kernel(int32_t* __restrict__ dst, int64_t n, int32_t base) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (int32_t)i;
+  if (i < n) dst[i] = base + (int32_t)i;
 }
 
 }  // namespace ffx

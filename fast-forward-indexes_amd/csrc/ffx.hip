@@ -136,6 +136,8 @@ struct ffx_index {
   int64_t n_docs = 0, n_doc_rows = 0, n_psgs = 0;
   bool docs_identity = false;  // document ordinal o owns exactly row o
   bool psgs_identity = false;  // passage ordinal o is row o
+  // the two plans ffx_score alternates between (created on first use, freed with the index)
+  struct ffx_plan* score_plans[2] = {nullptr, nullptr};
 };
 
 struct ffx_plan {
@@ -156,6 +158,7 @@ struct ffx_plan {
   int n_leaves = 0;
   bool last_interp = false;
   int32_t variant = 0;
+  int32_t order_base = 0;  // added to the positions the per-query order is made of (slices of a larger batch)
   std::vector<int64_t> host_pair_off;
 };
 
@@ -241,6 +244,10 @@ int ffx_index_create_typed(int device, int64_t capacity_rows, int32_t dim, int32
 int ffx_index_destroy(ffx_index* idx) {
   if (!idx) return FFX_OK;
   (void)hipSetDevice(idx->device);
+  for (auto& pl : idx->score_plans) {
+    if (pl) ffx_plan_destroy(pl);
+    pl = nullptr;
+  }
   if (idx->vectors) (void)hipFree(idx->vectors);
   idx->doc_off.release();
   idx->doc_rows.release();
@@ -271,6 +278,10 @@ int ffx_index_set_codebook(ffx_index* idx, const float* codewords, int32_t m, in
   if (ks < 1 || ks > 256 || ds < 1) return fail(FFX_BAD_ARG, "bad codebook shape (Ks must be <= 256 for uint8 codes)");
   if ((int64_t)m * ds > (1 << 20)) return fail(FFX_BAD_ARG, "decoded dimensionality too large");
   FFX_HIP(hipSetDevice(idx->device));
+  for (auto& pl : idx->score_plans) {  // their leaf plan follows the decoded dimensionality
+    if (pl) ffx_plan_destroy(pl);
+    pl = nullptr;
+  }
   const size_t bytes = (size_t)m * ks * ds * sizeof(float);
   FFX_TRY(idx->codebook.ensure(bytes));
   FFX_HIP(hipMemcpy(idx->codebook.p, codewords, bytes, hipMemcpyHostToDevice));
@@ -778,12 +789,12 @@ extern "C" {
 
 // per-query order: key descending, ties by position (the radix sort is stable)
 static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* offs_dev, int64_t n_queries, DevBuf& order,
-                                 DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st) {
+                                 DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st, int32_t base = 0) {
   const size_t pb = (size_t)P;
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
   FFX_TRY(sorted_keys.ensure(pb * sizeof(float)));
-  ffx::iota_kernel<<<blocks_for(P, 256), 256, 0, st>>>(iota.as<int32_t>(), P);
+  ffx::iota_kernel<<<blocks_for(P, 256), 256, 0, st>>>(iota.as<int32_t>(), P, base);
   FFX_HIP(hipGetLastError());
   size_t tmp = 0;
   FFX_HIP(rocprim::segmented_radix_sort_pairs_desc(nullptr, tmp, keys, sorted_keys.as<float>(), iota.as<int32_t>(),
@@ -851,7 +862,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (do_sort && P > 0) {
     const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
     FFX_TRY(launch_segmented_sort(keys, P, pl->pair_off.as<int64_t>(), pl->n_queries, pl->order, pl->iota,
-                                  pl->sorted_keys, pl->sort_tmp, st));
+                                  pl->sorted_keys, pl->sort_tmp, st, pl->order_base));
   }
   FFX_HIP(hipEventRecord(pl->ev[4], st));
   pl->ran = true;
@@ -1123,21 +1134,116 @@ int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, i
   return rc;
 }
 
+// One-shot host-to-host form.  The batch is cut into slices of whole queries and the slices
+// alternate between two plans on their own streams: while slice c is being scored, the
+// candidates of slice c+1 go up and the scores of slice c-1 come down, so with page-locked host
+// buffers (ffx_host_alloc / ffx_host_pin) the call costs about one device pass plus one slice of
+// transfers.  Results do not depend on the slicing.
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
               const int32_t* pair_ids, const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff,
               float* out_interp, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
-  ffx_plan* pl = nullptr;
-  FFX_TRY(ffx_plan_create(idx, &pl));
-  int rc = ffx_plan_set_queries(pl, host_queries, n_queries);
-  if (rc == FFX_OK) rc = ffx_plan_set_pairs(pl, pair_off, n_queries, pair_ids, sparse, mode, bad_pair);
-  if (rc == FFX_OK) rc = ffx_plan_run(pl, alpha, flags);
-  if (rc == FFX_OK) rc = ffx_plan_sync(pl);
-  if (rc == FFX_OK) rc = ffx_plan_fetch(pl, out_ff, out_interp, out_order);
-  if (rc == FFX_OK && stats) rc = ffx_plan_stats(pl, stats);
-  const std::string keep = g_last_error;
-  ffx_plan_destroy(pl);
-  if (rc != FFX_OK) g_last_error = keep;
-  return rc;
+  if (bad_pair) *bad_pair = -1;
+  if (!idx || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
+  if (out_order && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "out_order needs FFX_FLAG_SORT");
+  // slices of about 4M pairs (a ~2 ms device pass at 768-d fp32), cut at query boundaries
+  int64_t per_slice = 4 << 20;
+  if (const char* e = getenv("FFX_SCORE_SLICE_PAIRS")) per_slice = std::max<int64_t>(1, atoll(e));
+  std::vector<int64_t> cut{0};
+  for (int64_t q = 1; q < n_queries; ++q)
+    if (pair_off[q + 1] - pair_off[cut.back()] > per_slice && q > cut.back()) cut.push_back(q);
+  cut.push_back(n_queries);
+  const int n_slices = (int)cut.size() - 1;
+  for (int i = 0; i < (n_slices > 1 ? 2 : 1); ++i)
+    if (!idx->score_plans[i]) FFX_TRY(ffx_plan_create(idx, &idx->score_plans[i]));
+  ffx_stats acc;
+  memset(&acc, 0, sizeof acc);
+  auto fetch = [&](int c) -> int {
+    ffx_plan* pl = idx->score_plans[c & 1];
+    const int64_t p0 = pair_off[cut[c]];
+    FFX_TRY(ffx_plan_fetch(pl, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr,
+                           out_order ? out_order + p0 : nullptr));
+    if (stats) {
+      ffx_stats s;
+      FFX_TRY(ffx_plan_stats(pl, &s));
+      acc.n_queries += s.n_queries;
+      acc.n_pairs += s.n_pairs;
+      acc.n_rows += s.n_rows;
+      acc.algorithmic_bytes += s.algorithmic_bytes;
+      acc.ms_expand += s.ms_expand;
+      acc.ms_gather_dot += s.ms_gather_dot;
+      acc.ms_reduce += s.ms_reduce;
+      acc.ms_sort += s.ms_sort;
+      acc.ms_total += s.ms_total;
+      acc.kernel_variant = s.kernel_variant;
+    }
+    return FFX_OK;
+  };
+  auto run_all = [&]() -> int {
+    std::vector<int64_t> off;
+    for (int c = 0; c < n_slices; ++c) {
+      ffx_plan* pl = idx->score_plans[c & 1];
+      const int64_t q0 = cut[c], q1 = cut[c + 1], p0 = pair_off[q0];
+      FFX_TRY(ffx_plan_set_queries(pl, host_queries ? host_queries + (size_t)q0 * idx->qdim : nullptr, q1 - q0));
+      off.resize((size_t)(q1 - q0 + 1));
+      for (int64_t q = q0; q <= q1; ++q) off[(size_t)(q - q0)] = pair_off[q] - p0;
+      pl->order_base = (int32_t)p0;
+      int64_t bad = -1;
+      const int rc = ffx_plan_set_pairs(pl, off.data(), q1 - q0, pair_ids ? pair_ids + p0 : nullptr,
+                                        sparse ? sparse + p0 : nullptr, mode, &bad);
+      if (rc != FFX_OK) {
+        if (bad_pair && bad >= 0) *bad_pair = p0 + bad;
+        return rc;
+      }
+      FFX_TRY(ffx_plan_run(pl, alpha, flags));
+      if (c > 0) FFX_TRY(fetch(c - 1));
+    }
+    return fetch(n_slices - 1);
+  };
+  const int rc = run_all();
+  if (rc != FFX_OK) {  // nothing may still be writing when the caller gets its buffers back
+    const std::string keep = g_last_error;
+    for (ffx_plan* pl : idx->score_plans)
+      if (pl) (void)hipStreamSynchronize(pl->stream);
+    g_last_error = keep;
+    return rc;
+  }
+  if (stats) *stats = acc;
+  return FFX_OK;
+}
+
+// ---- page-locked host memory ------------------------------------------------------------------
+int ffx_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(FFX_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(FFX_OOM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return FFX_OK;
+}
+
+int ffx_host_free(void* p) {
+  if (p) FFX_HIP(hipHostFree(p));
+  return FFX_OK;
+}
+
+int ffx_host_pin(void* p, size_t bytes) {
+  if (!p || bytes == 0) return fail(FFX_BAD_ARG, "bad argument");
+  FFX_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return FFX_OK;
+}
+
+int ffx_host_unpin(void* p) {
+  if (!p) return fail(FFX_BAD_ARG, "bad argument");
+  FFX_HIP(hipHostUnregister(p));
+  return FFX_OK;
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ SYMBOLS = (
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
 )
 
 
@@ -140,6 +141,10 @@ def lib() -> C.CDLL:
         "ffx_run_export": ([vp, i64, vp, vp, vp, P(i64)], C.c_int),
         "ffx_run_write": ([vp, C.c_char_p, vp, vp, i64, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
+        "ffx_host_alloc": ([C.c_size_t, P(vp)], C.c_int),
+        "ffx_host_free": ([vp], C.c_int),
+        "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
+        "ffx_host_unpin": ([vp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(L, name)
@@ -373,16 +378,71 @@ class Merge:
         return _DevArray(ptr.value or 0, n.value, "<i4" if which == BUF_ORDER else "<f4", self)
 
 
+def _free_pinned(self) -> None:
+    addr = C.addressof(self)
+    if addr and _lib is not None:
+        _lib.ffx_host_free(C.c_void_p(addr))
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """``np.empty`` in page-locked host memory (``ffx_host_alloc``): copies to and from the device
+    run at link rate and overlap the kernels.  The memory is released with its last view."""
+    dtype = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    nbytes = max(1, n * dtype.itemsize)
+    p = C.c_void_p()
+    _check(lib().ffx_host_alloc(nbytes, C.byref(p)))
+    # every view keeps this ctypes object alive through the buffer protocol; it frees on collection
+    owner = type("PinnedBytes", (C.c_char * nbytes,), {"__del__": _free_pinned}).from_address(p.value)
+    return np.frombuffer(owner, dtype=dtype, count=n).reshape(shape)
+
+
+class pinned:
+    """Context manager: page-lock existing arrays for the duration (``ffx_host_pin``)."""
+
+    min_bytes = 1 << 20  # smaller arrays gain nothing and may share pages with one another
+
+    def __init__(self, *arrays):
+        self._arrays = [a for a in arrays if a is not None and a.nbytes >= self.min_bytes]
+        self._done = []
+
+    def __enter__(self):
+        for a in self._arrays:
+            if not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("only contiguous arrays can be page-locked")
+            _check(lib().ffx_host_pin(_ptr(a), a.nbytes))
+            self._done.append(a)
+        return self
+
+    def __exit__(self, *exc):
+        for a in reversed(self._done):
+            lib().ffx_host_unpin(_ptr(a))
+        self._done = []
+        return False
+
+
 def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0,
-          exact_sum: bool = True, sort: bool = False):
-    """One-shot ``ffx_score``: host arrays in, host arrays out.  Returns (ff, interp, order, stats)."""
+          exact_sum: bool = True, sort: bool = False, out=None):
+    """One-shot ``ffx_score``: host arrays in, host arrays out.  Returns (ff, interp, order, stats).
+
+    ``out``: optional ``(ff, interp, order)`` arrays to write into (e.g. from :func:`pinned_empty`)."""
     queries = _arr(queries, np.float32)
     pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
     sp = None if sparse is None else _arr(sparse, np.float32)
     n = int(pair_off[-1])
-    ff = np.empty(n, dtype=np.float32)
-    interp = None if sp is None else np.empty(n, dtype=np.float32)
-    order = np.empty(n, dtype=np.int32) if sort else None
+    o_ff, o_interp, o_order = out if out is not None else (None, None, None)
+
+    def _out(a, dtype):
+        if a is None:
+            return np.empty(n, dtype=dtype)
+        if a.dtype != dtype or a.size < n or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("out arrays must be contiguous, of the result dtype and hold every pair")
+        return a[:n]
+
+    ff = _out(o_ff, np.float32)
+    interp = None if sp is None else _out(o_interp, np.float32)
+    order = _out(o_order, np.int32) if sort else None
     bad, st = C.c_int64(-1), Stats()
     flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0)
     rc = lib().ffx_score(index._h, _ptr(queries), queries.shape[0], _ptr(pair_off), _ptr(pair_ids), _ptr(sp), int(mode),

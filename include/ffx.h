@@ -213,11 +213,24 @@ int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pai
 int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
                   const char* tag);
 
-/* one-shot: set_queries + set_pairs + run + sync + fetch (host buffers in, host buffers out) */
+/* one-shot, host buffers in, host buffers out: the batch is cut into slices of whole queries
+ * that alternate between two plans kept with the index, so uploads, scoring and downloads of
+ * neighbouring slices overlap (results do not depend on the slicing; stats are summed over the
+ * slices).  FFX_SCORE_SLICE_PAIRS in the environment overrides the slice size (pairs). */
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               const int64_t* pair_off, const int32_t* pair_ids, const float* sparse, int mode,
               double alpha, uint32_t flags, float* out_ff, float* out_interp, int32_t* out_order,
               int64_t* bad_pair, ffx_stats* stats);
+
+/* ---- page-locked host memory ------------------------------------------------------------
+ * Host buffers handed to the calls above may live anywhere; when they are page-locked the
+ * copies to and from the device run at full link rate and overlap the kernels (ffx_score
+ * pipelines slices of the batch).  ffx_host_alloc returns such memory, ffx_host_pin locks a
+ * range the caller already owns (e.g. a NumPy array) until ffx_host_unpin. */
+int ffx_host_alloc(size_t bytes, void** out);
+int ffx_host_free(void* p);
+int ffx_host_pin(void* p, size_t bytes);
+int ffx_host_unpin(void* p);
 
 #ifdef __cplusplus
 }

@@ -402,3 +402,59 @@ def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
     ref = np.sum(queries[np.repeat(np.arange(nq), k)] * decoded[pair_ids], axis=1)
     assert np.array_equal(bits(ff), bits(ref))
     idx.close()
+
+
+@pytest.mark.parametrize("slice_pairs", [1, 50, 400])
+def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
+    """ffx_score pipelines slices of whole queries through two plans: scores, interpolation, the
+    per-query order (global positions) and the position of an unknown id must not depend on where
+    the batch is cut; page-locked buffers (allocated or locked in place) give the same bytes."""
+    d, n = 768, 900
+    vectors = synth.rows(21, 0.05, 0, n, d)
+    queries = synth.rows(22, 0.05, 0, 9, d)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    rng = np.random.default_rng(5)
+    per_doc = rng.integers(1, 4, size=300)
+    doc_off = np.concatenate([[0], np.cumsum(per_doc)])
+    doc_rows = rng.permutation(n)[: doc_off[-1]]
+    idx.set_doc_rows(doc_off, doc_rows)
+    idx.set_psg_rows(np.arange(n))
+    lens = [120, 0, 1, 77, 300, 0, 0, 250, 33]
+    pair_off = np.concatenate([[0], np.cumsum(lens)])
+    pair_ids = np.concatenate([rng.choice(300, size=k, replace=False) for k in lens]).astype(np.int32)
+    sparse = rng.random(len(pair_ids), dtype=np.float32) * 20
+    for mode in (2, 3, 4):
+        want_ff, want_in = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, pair_ids, mode, sparse, 0.3)
+        monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", str(slice_pairs))
+        ff, interp, order, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.3, sort=True)
+        assert np.array_equal(bits(ff), bits(want_ff)) and np.array_equal(bits(interp), bits(want_in))
+        assert np.array_equal(order.astype(np.int64), fo.order(want_in, pair_off))
+        assert st["n_pairs"] == len(pair_ids) and st["n_queries"] == 9
+        # page-locked in place, and allocated page-locked
+        out = tuple(native.pinned_empty(len(pair_ids), t) for t in (np.float32, np.float32, np.int32))
+        with native.pinned(queries, pair_ids, sparse):
+            ff2, in2, or2, _ = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.3, sort=True, out=out)
+        assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(in2), bits(interp)) and np.array_equal(or2, order)
+        assert ff2.base is not None  # views of the page-locked block
+    # arrays large enough to be locked in place (native.pinned skips those under 1 MiB)
+    monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", "60000")
+    big_off = np.arange(10, dtype=np.int64) * 40_000
+    big_ids = rng.integers(0, 300, size=int(big_off[-1])).astype(np.int32)
+    big_sp = rng.random(len(big_ids), dtype=np.float32)
+    want_ff, want_in = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, big_off, big_ids, 2, big_sp, 0.1)
+    with native.pinned(big_ids, big_sp) as pin:
+        assert len(pin._done) == 2
+        ff, interp, _, _ = native.score(idx, queries, big_off, big_ids, 2, big_sp, 0.1)
+    assert np.array_equal(bits(ff), bits(want_ff)) and np.array_equal(bits(interp), bits(want_in))
+    monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", str(slice_pairs))
+    bad = pair_ids.copy()
+    bad[600] = 10**6
+    with pytest.raises(native.NotFound) as e:
+        native.score(idx, queries, pair_off, bad, 2)
+    assert e.value.pair == 600
+    # the index is still usable after a failed call
+    ff, _, _, _ = native.score(idx, queries, pair_off, pair_ids, 2)
+    want_ff, _ = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, pair_ids, 2)
+    assert np.array_equal(bits(ff), bits(want_ff))
+    idx.close()

@@ -28,6 +28,7 @@ ap.add_argument("--k", type=int, default=5000)
 ap.add_argument("--api-rows", type=int, default=1_000_000)
 ap.add_argument("--api-queries", type=int, default=200)
 ap.add_argument("--api-k", type=int, default=1000)
+ap.add_argument("--only-ii", action="store_true", help="stop after the host-to-host region")
 args = ap.parse_args()
 d, seed = 768, 2024
 scale = float(1 / np.sqrt(d))
@@ -67,10 +68,40 @@ for _ in range(3):
     native.score(idx, queries, pair_off, ids, 2, sparse, 0.1)
     ts.append(time.perf_counter() - t0)
 out["ii_host_to_host_one_shot_ffx_score_ms"] = min(ts) * 1e3
+one_shot = native.score(idx, queries, pair_off, ids, 2, sparse, 0.1)
+out["ii_one_shot_equals_plan"] = bool(np.array_equal(one_shot[0], ff) and np.array_equal(one_shot[1], interp))
+out["ii_one_shot_device_ms_sum"] = one_shot[3]["ms_total"]
+# the same call with the caller's buffers page-locked in place (ffx_host_pin), lock time included / excluded
+ff_o, in_o = np.empty_like(ff), np.empty_like(interp)
+t0 = time.perf_counter()
+with native.pinned(queries, pair_off, ids, sparse, ff_o, in_o):
+    t1 = time.perf_counter()
+    ts = []
+    for _ in range(3):
+        t2 = time.perf_counter()
+        native.score(idx, queries, pair_off, ids, 2, sparse, 0.1, out=(ff_o, in_o, None))
+        ts.append(time.perf_counter() - t2)
+out["ii_pin_in_place_ms"] = (t1 - t0) * 1e3
+out["ii_host_to_host_pinned_in_place_ms"] = min(ts) * 1e3
+# ... and with buffers that were allocated page-locked (ffx_host_alloc)
+pq, po, pi_, ps = (native.pinned_empty(a.shape, a.dtype) for a in (queries, pair_off, ids, sparse))
+for dst, src in ((pq, queries), (po, pair_off), (pi_, ids), (ps, sparse)):
+    dst[...] = src
+pf, pn = native.pinned_empty(ff.shape, np.float32), native.pinned_empty(ff.shape, np.float32)
+ts = []
+for _ in range(4):
+    t0 = time.perf_counter()
+    native.score(idx, pq, po, pi_, 2, ps, 0.1, out=(pf, pn, None))
+    ts.append(time.perf_counter() - t0)
+out["ii_host_to_host_pinned_alloc_ms"] = min(ts) * 1e3
+out["ii_pinned_equals_plan"] = bool(np.array_equal(pf, ff) and np.array_equal(pn, interp))
 out["ii_bytes_moved"] = int(queries.nbytes + ids.nbytes + sparse.nbytes + pair_off.nbytes + 2 * ff.nbytes)
 out["queries"], out["k"] = args.queries, args.k
 plan.close()
 idx.close()
+if args.only_ii:
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 
 # (iii) the Python API with string ids, reduced size (host-bound)
 n, nq, k = args.api_rows, args.api_queries, args.api_k
