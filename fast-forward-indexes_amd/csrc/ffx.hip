@@ -14,8 +14,10 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
+#include <atomic>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ffx.h"
@@ -138,6 +140,12 @@ struct ffx_index {
   bool psgs_identity = false;  // passage ordinal o is row o
   // the two plans ffx_score alternates between (created on first use, freed with the index)
   struct ffx_plan* score_plans[2] = {nullptr, nullptr};
+  // page-locked staging of ffx_index_upload_rows: two blocks, filled by host threads while the
+  // other one is in flight to the device
+  void* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  hipStream_t copy_stream = nullptr;
 };
 
 struct ffx_plan {
@@ -248,6 +256,11 @@ int ffx_index_destroy(ffx_index* idx) {
     if (pl) ffx_plan_destroy(pl);
     pl = nullptr;
   }
+  for (int i = 0; i < 2; ++i) {
+    if (idx->stage[i]) (void)hipHostFree(idx->stage[i]);
+    if (idx->stage_ev[i]) (void)hipEventDestroy(idx->stage_ev[i]);
+  }
+  if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
   if (idx->vectors) (void)hipFree(idx->vectors);
   idx->doc_off.release();
   idx->doc_rows.release();
@@ -311,6 +324,76 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(idx->device));
   FFX_HIP(hipMemcpy(idx->row_ptr(row_offset), host_rows, (size_t)n_rows * idx->dim * idx->elem, hipMemcpyHostToDevice));
+  return FFX_OK;
+}
+
+// Rows scattered over the chunks of a memory-mapped file -> consecutive device rows.  Host threads
+// gather one block of rows into page-locked staging while the previous block travels to the
+// device (the streaming half of OnDiskIndex: disk.py:100-121 reads the same chunk maps).
+int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
+                          const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads) {
+  if (!idx || n_rows < 0 || dst_row < 0 || n_chunks < 0 || chunk_rows <= 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_rows == 0) return FFX_OK;
+  if (!chunks || !rows) return fail(FFX_BAD_ARG, "NULL argument");
+  if (dst_row + n_rows > idx->capacity) return fail(FFX_BAD_ARG, "rows [%lld, %lld) exceed the capacity %lld", (long long)dst_row, (long long)(dst_row + n_rows), (long long)idx->capacity);
+  const int64_t n_src = n_chunks * chunk_rows;
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (rows[i] < 0 || rows[i] >= n_src) return fail(FFX_BAD_ARG, "rows[%lld] = %lld is outside the %lld stored rows", (long long)i, (long long)rows[i], (long long)n_src);
+  for (int64_t c = 0; c < n_chunks; ++c)
+    if (!chunks[c]) return fail(FFX_BAD_ARG, "chunk %lld is NULL", (long long)c);
+  FFX_HIP(hipSetDevice(idx->device));
+  const size_t rb = (size_t)idx->dim * idx->elem;
+  size_t want = (size_t)64 << 20;
+  if (const char* e = getenv("FFX_STAGE_BYTES")) want = std::max<size_t>(rb, (size_t)atoll(e));
+  want = std::max(want, rb);
+  if (idx->stage_bytes < want) {
+    for (int i = 0; i < 2; ++i) {
+      if (idx->stage[i]) (void)hipHostFree(idx->stage[i]);
+      idx->stage[i] = nullptr;
+    }
+    idx->stage_bytes = 0;
+    for (int i = 0; i < 2; ++i) {
+      hipError_t e = hipHostMalloc(&idx->stage[i], want, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        idx->stage[i] = nullptr;
+        return fail(FFX_OOM, "hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+      }
+    }
+    idx->stage_bytes = want;
+  }
+  if (!idx->copy_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i)
+    if (!idx->stage_ev[i]) FFX_HIP(hipEventCreateWithFlags(&idx->stage_ev[i], hipEventDisableTiming));
+  const int64_t per = (int64_t)(idx->stage_bytes / rb);
+  const int T = std::max(1, std::min<int>(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency() / 2, 64));
+  bool used[2] = {false, false};
+  int k = 0;
+  for (int64_t b0 = 0; b0 < n_rows; b0 += per, ++k) {
+    const int s = k & 1;
+    if (used[s]) FFX_HIP(hipEventSynchronize(idx->stage_ev[s]));
+    const int64_t nb = std::min(per, n_rows - b0);
+    char* dst = static_cast<char*>(idx->stage[s]);
+    auto work = [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; ++i) {
+        const int64_t r = rows[b0 + i];
+        memcpy(dst + (size_t)i * rb, static_cast<const char*>(chunks[r / chunk_rows]) + (size_t)(r % chunk_rows) * rb, rb);
+      }
+    };
+    const int t_use = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)(nb * rb) >> 20));  // >= 1 MiB per thread
+    if (t_use <= 1) {
+      work(0, nb);
+    } else {
+      std::vector<std::thread> pool;
+      pool.reserve(t_use - 1);
+      for (int t = 1; t < t_use; ++t) pool.emplace_back(work, nb * t / t_use, nb * (t + 1) / t_use);
+      work(0, nb / t_use);
+      for (auto& th : pool) th.join();
+    }
+    FFX_HIP(hipMemcpyAsync(idx->row_ptr(dst_row + b0), dst, (size_t)nb * rb, hipMemcpyHostToDevice, idx->copy_stream));
+    FFX_HIP(hipEventRecord(idx->stage_ev[s], idx->copy_stream));
+    used[s] = true;
+  }
+  FFX_HIP(hipStreamSynchronize(idx->copy_stream));
   return FFX_OK;
 }
 

@@ -21,7 +21,7 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
     "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
-    "ffx_index_upload", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
+    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
     "ffx_plan_run", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         "ffx_index_dim": ([vp, P(i32)], C.c_int),
         "ffx_index_capacity": ([vp, P(i64)], C.c_int),
         "ffx_index_upload": ([vp, vp, i64, i64], C.c_int),
+        "ffx_index_upload_rows": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
         "ffx_index_gather": ([vp, vp, i64, vp], C.c_int),
         "ffx_index_fill_synthetic": ([vp, C.c_uint64, f32, i64, i64, i64], C.c_int),
@@ -231,6 +232,18 @@ class DeviceIndex:
         rows = _arr(rows, self.dtype)
         assert rows.ndim == 2 and rows.shape[1] == self.dim
         _check(lib().ffx_index_upload(self._h, _ptr(rows), row_offset, rows.shape[0]))
+
+    def upload_rows(self, chunks, rows, dst_row: int = 0, threads: int = 0) -> None:
+        """Stored rows ``rows`` (numbers over the concatenation of the equally sized 2-D arrays
+        ``chunks``, e.g. the memory maps of an on-disk index) -> device rows from ``dst_row`` on,
+        gathered by native threads through page-locked staging (``ffx_index_upload_rows``)."""
+        chunk_rows = int(chunks[0].shape[0]) if len(chunks) else 1
+        for c in chunks:
+            if c.dtype != self.dtype or c.ndim != 2 or c.shape != (chunk_rows, self.dim) or not c.flags["C_CONTIGUOUS"]:
+                raise ValueError("chunks must be contiguous (chunk_rows, dim) arrays of the index dtype")
+        ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
+        rows = _arr(rows, np.int64)
+        _check(lib().ffx_index_upload_rows(self._h, ptrs, len(chunks), chunk_rows, _ptr(rows), rows.shape[0], int(dst_row), int(threads)))
 
     def copy_rows_from(self, src: "DeviceIndex", n_rows: int) -> None:
         _check(lib().ffx_index_copy_rows(self._h, src._h, n_rows))

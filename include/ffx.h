@@ -110,6 +110,12 @@ int ffx_index_dim(const ffx_index* idx, int32_t* dim);
 int ffx_index_capacity(const ffx_index* idx, int64_t* rows);
 /* copy host rows into rows [row_offset, row_offset+n_rows): InMemoryIndex._add, memory.py:100-119 */
 int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, int64_t n_rows); /* rows in the index dtype */
+/* rows scattered over the equally sized chunks of a (memory-mapped) file -> device rows
+ * [dst_row, dst_row+n_rows): rows[i] names stored row rows[i] % chunk_rows of chunk
+ * rows[i] / chunk_rows (the chunk maps of OnDiskIndex, index/disk.py:100-121).  Host threads
+ * (n_threads; 0 = half the cores) fill page-locked staging while the previous block is copied. */
+int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
+                          const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads);
 /* device copy between two indexes on the same device (growing an index) */
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows);
 /* read rows back: InMemoryIndex._get_vectors, memory.py:139-140 / index/util.py:97-98 */

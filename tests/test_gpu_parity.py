@@ -458,3 +458,32 @@ def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
     want_ff, _ = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, pair_ids, 2)
     assert np.array_equal(bits(ff), bits(want_ff))
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.uint8])
+def test_upload_rows_gathers_from_chunk_maps(monkeypatch, dtype):
+    """ffx_index_upload_rows: stored rows scattered over equally sized chunks land in consecutive
+    device rows, through staging blocks smaller than the request (several round trips)."""
+    rng = np.random.default_rng(8)
+    d, cs = 96, 50
+    if dtype == np.uint8:
+        chunks = [rng.integers(0, 256, size=(cs, d), dtype=np.uint8) for _ in range(4)]
+    else:
+        chunks = [rng.standard_normal((cs, d)).astype(dtype) for _ in range(4)]
+    stored = np.concatenate(chunks)
+    want = np.concatenate([rng.permutation(4 * cs), rng.integers(0, 4 * cs, size=333)])
+    idx = native.DeviceIndex(len(want) + 7, d, dtype=dtype)
+    if dtype == np.uint8:
+        idx.set_codebook(rng.standard_normal((d, 4, 2)).astype(np.float32))
+    monkeypatch.setenv("FFX_STAGE_BYTES", str(40 * d * np.dtype(dtype).itemsize))  # 40 rows per staging block
+    idx.upload_rows(chunks, want, 7, threads=3)
+    got = idx.gather(np.arange(7, 7 + len(want)))
+    assert np.array_equal(got, stored[want])
+    idx.upload_rows(chunks, want[:0], 0)  # nothing to do
+    with pytest.raises(native.FFXError):
+        idx.upload_rows(chunks, np.array([4 * cs]), 0)  # past the stored rows
+    with pytest.raises(native.FFXError):
+        idx.upload_rows(chunks, want, 8)  # past the capacity
+    with pytest.raises(ValueError):
+        idx.upload_rows([c.astype(np.float64) for c in chunks], want, 0)
+    idx.close()

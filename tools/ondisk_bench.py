@@ -40,14 +40,16 @@ with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
     pair_ids = np.concatenate([rng.choice(args.rows, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
     pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
     sparse = rng.random(pair_ids.shape[0], dtype=np.float32) * 25
-    for label in ("cold", "warm"):
+    for label in ("cold", "warm", "warm2"):
         t0 = time.perf_counter()
         ff, interp, order = idx._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
         dt = time.perf_counter() - t0
         st = idx.last_stats
         out[f"stream_{label}"] = {"seconds": dt, "queries_per_s": args.queries / dt, "windows": st["windows"],
                                   "unique_rows": st["unique_rows"], "streamed_gb": st["bytes_streamed"] / 1e9,
-                                  "streamed_gb_per_s": st["bytes_streamed"] / 1e9 / dt, "kernel_ms_total": st["ms_gather_dot"]}
+                                  "streamed_gb_per_s": st["bytes_streamed"] / 1e9 / dt, "kernel_ms_total": st["ms_gather_dot"],
+                                  "upload_s": st["s_upload"], "upload_gb_per_s": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9),
+                                  "score_s": st["s_score"], "windows_s": st["s_windows"]}
     t0 = time.perf_counter()
     mem = idx.to_memory(batch_size=2**18)
     out["to_memory_s"] = time.perf_counter() - t0
