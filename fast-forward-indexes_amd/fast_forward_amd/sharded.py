@@ -101,7 +101,12 @@ def exchange(send, send_counts, recv_counts, group=None):
 
 
 class ShardedScorer:
-    """One rank of a row-sharded index: local ``gather_dot`` + RCCL all-to-all + owner merge."""
+    """One rank of a row-sharded index: local ``gather_dot`` + RCCL all-to-all + owner merge.
+
+    Two HIP streams and two plans: batch i is scored on the compute stream while the scores of
+    batch i-1 are still being exchanged and merged on the communication stream, so back-to-back
+    ``run`` calls cost max(scoring, exchange + merge) instead of their sum.  Each plan owns its
+    send buffer; a plan is reused only after the exchange that read it has finished."""
 
     def __init__(self, shard, doc_bounds, rank: int, world: int, device: int, group=None):
         import torch  # before the first libffx call: see native.lib() on the one-runtime-per-process rule
@@ -115,27 +120,35 @@ class ShardedScorer:
         self._torch = torch
         self._native = native
         self.shard, self.doc_bounds, self.rank, self.world, self.device, self.group = shard, doc_bounds, rank, world, device, group
-        self.plan = native.Plan(shard)
+        self.plans = [native.Plan(shard), native.Plan(shard)]
+        self.plan = self.plans[0]  # the plan of the most recent run (stats)
         self.merge = native.Merge(device)
         self.route: Route | None = None
-        # one explicit (non-null) stream orders the kernels, the collective and the merge; the
-        # C ABI reads a NULL stream as "use your own", so torch's default stream (handle 0) is
-        # never used here
-        self._tstream = torch.cuda.Stream(device)
-        self._stream = self._tstream.cuda_stream
-        assert self._stream != 0
-        self.plan.set_stream(self._stream)
+        # explicit (non-null) streams: the C ABI reads a NULL stream as "use your own", so torch's
+        # default stream (handle 0) is never used here
+        self._compute, self._comm = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        assert self._compute.cuda_stream != 0 and self._comm.cuda_stream != 0
+        for plan in self.plans:
+            plan.set_stream(self._compute.cuda_stream)
+        self._scored = [torch.cuda.Event(), torch.cuda.Event()]  # plan i has written its scores
+        self._sent = [torch.cuda.Event(), torch.cuda.Event()]    # the exchange has read plan i's scores
+        self._runs = 0
 
     def set_queries(self, queries: np.ndarray) -> None:
-        self.plan.set_queries(queries)  # replicated: Q*d*4 bytes (21 MB at Q=6980, d=768)
+        self.sync()
+        for plan in self.plans:
+            plan.set_queries(queries)  # replicated: Q*d*4 bytes (21 MB at Q=6980, d=768)
 
     def set_pairs(self, pair_off, pair_ids, sparse, mode: int) -> None:
         torch, native = self._torch, self._native
+        self.sync()
         r = route(pair_off, pair_ids, self.doc_bounds, self.rank, self.world, sparse)
-        self.plan.set_pairs(r.local_pair_off, r.local_pair_ids, None, mode)
+        self._send = []
+        for plan in self.plans:
+            plan.set_pairs(r.local_pair_off, r.local_pair_ids, None, mode)
+            self._send.append(torch.as_tensor(plan.device_array(native.BUF_FF), device=f"cuda:{self.device}"))
         self.merge.set(r.own_pair_off, r.recv_slot, r.own_sparse)
-        with torch.cuda.stream(self._tstream):
-            self._send = torch.as_tensor(self.plan.device_array(native.BUF_FF), device=f"cuda:{self.device}")
+        with torch.cuda.stream(self._comm):
             self._recv = torch.empty(int(r.recv_counts.sum()), dtype=torch.float32, device=f"cuda:{self.device}")
         self._in_split = [int(c) for c in r.send_counts]
         self._out_split = [int(c) for c in r.recv_counts]
@@ -145,18 +158,27 @@ class ShardedScorer:
         import torch.distributed as dist
 
         torch = self._torch
-        with torch.cuda.stream(self._tstream):
-            self.plan.run(0.0, exact_sum=exact_sum)
+        i = self._runs & 1
+        self._runs += 1
+        plan, send = self.plans[i], self._send[i]
+        self.plan = plan
+        with torch.cuda.stream(self._compute):
+            self._compute.wait_event(self._sent[i])  # the exchange of two runs ago read this plan's scores
+            plan.run(0.0, exact_sum=exact_sum)
+            self._scored[i].record(self._compute)
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(self._scored[i])
             if dist.get_backend(self.group) == "gloo":
                 # rehearsal path (several ranks sharing one GPU, where RCCL refuses to run): the
                 # same exchange staged through host memory
-                self._tstream.synchronize()
+                self._comm.synchronize()
                 recv_host = torch.empty(self._recv.shape[0], dtype=torch.float32)
-                dist.all_to_all_single(recv_host, self._send.cpu(), self._out_split, self._in_split, group=self.group)
+                dist.all_to_all_single(recv_host, send.cpu(), self._out_split, self._in_split, group=self.group)
                 self._recv.copy_(recv_host)
             else:
-                dist.all_to_all_single(self._recv, self._send, self._out_split, self._in_split, group=self.group)
-            self.merge.run(self._recv.data_ptr(), alpha, sort=sort, stream=self._stream)
+                dist.all_to_all_single(self._recv, send, self._out_split, self._in_split, group=self.group)
+            self._sent[i].record(self._comm)
+            self.merge.run(self._recv.data_ptr(), alpha, sort=sort, stream=self._comm.cuda_stream)
 
     def sync(self) -> None:
         self._torch.cuda.synchronize(self.device)
@@ -166,7 +188,9 @@ class ShardedScorer:
         return self.merge.fetch(ff=True, interp=self.merge.has_sparse, order=order)
 
     def close(self) -> None:
-        self.plan.close()
+        self.sync()
+        for plan in self.plans:
+            plan.close()
         self.merge.close()
 
 

@@ -40,6 +40,23 @@ for alpha in (0.1, 0.5):
                             MODE_NO["MAXP"], sparse, alpha)
     assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i))
     assert np.array_equal(order.astype(np.int64), fo.order(want_i, pair_off))
+# back-to-back runs alternate between the two plans and overlap scoring with the exchange of the
+# run before; the last one wins, and new pairs after that start from a clean state
+for alpha in (0.3, 0.7, 0.2, 0.9, 0.05):
+    scorer.run(alpha, exact_sum=True, sort=True)
+ff, interp, order = scorer.fetch(order=True)
+want, want_i = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids,
+                        MODE_NO["MAXP"], sparse, 0.05)
+assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i))
+assert np.array_equal(order.astype(np.int64), fo.order(want_i, pair_off))
+pair_off2, pair_ids2, sparse2, _ = case.pairs("FIRSTP")
+scorer.set_pairs(pair_off2, pair_ids2, sparse2, MODE_NO["FIRSTP"])
+for alpha in (0.6, 0.4, 0.25):
+    scorer.run(alpha, exact_sum=True)
+ff, interp, _ = scorer.fetch()
+want, want_i = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off2, pair_ids2,
+                        MODE_NO["FIRSTP"], sparse2, 0.25)
+assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i))
 scorer.close()
 idx.close()
 dist.destroy_process_group()
