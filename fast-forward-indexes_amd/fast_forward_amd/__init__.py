@@ -9,8 +9,8 @@ AMD MI355X (gfx950).  Same surface as the reference for this path --
 of ``libffx.so`` (``include/ffx.h``).  There is no CPU fallback.
 """
 
-from fast_forward_amd import encoder, index  # noqa: F401
+from fast_forward_amd import encoder, index, util  # noqa: F401
 from fast_forward_amd.ranking import Ranking
 
-__all__ = ["Ranking", "encoder", "index"]
+__all__ = ["Ranking", "encoder", "index", "util"]
 __version__ = "0.1.0"

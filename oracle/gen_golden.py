@@ -317,6 +317,41 @@ def pq_case(name, *, seed, dim, M, Ks, n_docs, n_q, k):
     return {"rows": n_rows, "M": M, "Ks": Ks}
 
 
+def coalesce_case():
+    """create_coalesced_index of the reference (util/__init__.py:51-101) on documents whose
+    passages drift slowly (so neighbouring passages merge) with a few jumps (so groups close)."""
+    from fast_forward.util import create_coalesced_index
+
+    rng = np.random.default_rng(77)
+    dim, n_docs = 32, 40
+    vectors, doc_ids = [], []
+    for i in range(n_docs):
+        base = rng.standard_normal(dim).astype(np.float32)
+        for j in range(int(rng.integers(1, 9))):
+            if rng.random() < 0.35:
+                base = rng.standard_normal(dim).astype(np.float32)  # topic change
+            vectors.append(base + 0.25 * rng.standard_normal(dim).astype(np.float32))
+            doc_ids.append(f"d{i}")
+    vectors = np.stack(vectors).astype(np.float32)
+    arrays = {"vectors": vectors, "doc_ids": np.array(doc_ids)}
+    info = {"file": "coalesce.npz", "deltas": [0.1, 0.3, 0.6], "rows": int(len(vectors))}
+    for delta in info["deltas"]:
+        src = InMemoryIndex(mode=Mode.MAXP, init_size=len(vectors))
+        src.add(vectors, doc_ids=doc_ids)
+        dst = InMemoryIndex(mode=Mode.MAXP, init_size=len(vectors))
+        create_coalesced_index(src, dst, delta, batch_size=50)
+        out_v, out_d = [], []
+        for i in range(n_docs):  # per document, in passage order
+            v, owners = dst._get_vectors([f"d{i}"])
+            out_v.append(np.asarray(v))
+            out_d.extend(owners)
+        arrays[f"coalesced_{delta}"] = np.concatenate(out_v).astype(np.float32)
+        arrays[f"coalesced_docs_{delta}"] = np.array(out_d)
+        info[f"rows_{delta}"] = int(len(out_d))
+    np.savez_compressed(OUT / "coalesce.npz", **arrays)
+    return info
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "--only":  # add one case without rewriting the others
@@ -331,6 +366,8 @@ def main():
             manifest["cases"]["dim128_f16"] = scoring_case(
                 "dim128_f16", seed=201, dim=128, n_docs=60, psg_lo=1, psg_hi=3, n_q=4, k=20, scale=1.0,
                 sparse_hi=10.0, modes=["MAXP"], store=np.float16)
+        if sys.argv[2] == "coalesce":
+            manifest["cases"]["coalesce"] = coalesce_case()
         if sys.argv[2] == "pq":
             manifest["cases"]["pq"] = {name: pq_case(name, **kw) for name, kw in PQ_CASES.items()}
         (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
@@ -355,6 +392,7 @@ def main():
     manifest["cases"]["partial_ids"] = partial_ids_case()
     manifest["cases"]["interpolate"] = interpolate_case()
     manifest["cases"]["early_stopping"] = early_stopping_case()
+    manifest["cases"]["coalesce"] = coalesce_case()
     (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     total = sum(f.stat().st_size for f in OUT.iterdir())
     print(f"wrote {len(list(OUT.iterdir()))} files, {total / 1e6:.2f} MB -> {OUT}")
