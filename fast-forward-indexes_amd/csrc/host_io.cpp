@@ -8,6 +8,7 @@
 //   ffx_run_*  a TREC run parsed straight into the CSR the kernels take, and written back
 // No device code here; plain C++17.
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
@@ -18,6 +19,7 @@
 #include <numeric>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <vector>
 
 #include "../../include/ffx.h"
@@ -191,6 +193,57 @@ int ffx_ids_lookup(const ffx_ids* t, const char* strs, int32_t width, int64_t n,
   }
   if (first_missing) *first_missing = miss;
   return miss < 0 ? FFX_OK : FFX_NOT_FOUND;
+}
+
+// The same look-up for strings handed over as ONE buffer with a separator byte between them
+// (what "\n".join(ids).encode() builds far faster than a fixed-width copy of every string).
+// Exactly n fields must be present.  Large requests are split over a few threads (the table is
+// only read).
+int ffx_ids_lookup_packed(const ffx_ids* t, const char* data, int64_t n_bytes, char sep, int64_t n,
+                          int32_t* out_ordinals, int64_t* first_missing) {
+  if (first_missing) *first_missing = -1;
+  if (!t || n < 0 || n_bytes < 0 || (n > 0 && (!data || !out_ordinals))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return n_bytes == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "bytes given for zero strings");
+  std::vector<int64_t> start;
+  try {
+    start.reserve((size_t)n + 1);
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
+  start.push_back(0);
+  for (const char* p = data; (int64_t)start.size() <= n;) {
+    const char* q = static_cast<const char*>(memchr(p, sep, (size_t)(data + n_bytes - p)));
+    if (!q) break;
+    start.push_back(q - data + 1);
+    p = q + 1;
+  }
+  if ((int64_t)start.size() != n) return ffx_fail(FFX_BAD_ARG, "the buffer does not hold exactly %lld separated strings", (long long)n);
+  start.push_back(n_bytes + 1);  // as if a separator followed the last string
+  std::atomic<int64_t> miss{INT64_MAX};
+  auto work = [&](int64_t lo, int64_t hi) {
+    int64_t mine = INT64_MAX;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int32_t o = t->find(std::string_view(data + start[(size_t)i], (size_t)(start[(size_t)i + 1] - 1 - start[(size_t)i])));
+      out_ordinals[i] = o;
+      if (o < 0 && mine == INT64_MAX) mine = i;
+    }
+    int64_t seen = miss.load();
+    while (mine < seen && !miss.compare_exchange_weak(seen, mine)) {
+    }
+  };
+  const int T = (int)std::min<int64_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), n >> 15);  // >= 32K strings each
+  if (T <= 1) {
+    work(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (int k = 1; k < T; ++k) pool.emplace_back(work, n * k / T, n * (k + 1) / T);
+    work(0, n / T);
+    for (auto& th : pool) th.join();
+  }
+  const int64_t m = miss.load();
+  if (m == INT64_MAX) return FFX_OK;
+  if (first_missing) *first_missing = m;
+  return FFX_NOT_FOUND;
 }
 
 int ffx_ids_get(const ffx_ids* t, int32_t ordinal, const char** str, int32_t* len) {

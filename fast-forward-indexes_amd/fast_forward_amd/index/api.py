@@ -182,10 +182,11 @@ class Index(abc.ABC):
         self._add(vectors if self._quantizer is None else self._quantizer.encode(vectors), doc_ids, psg_ids)
 
     # ---- scoring -------------------------------------------------------------------------------------
-    def _numbered_queries(self, df: pd.DataFrame) -> tuple[np.ndarray, list[str], list[str]]:
+    def _numbered_queries(self, ranking: Ranking) -> tuple[np.ndarray, list[str], list[str]]:
         """``q_no`` per row = order of first appearance of the query (base.py:418-421), plus the
         query ids and texts in that order."""
-        q_no, q_ids = pd.factorize(df["q_id"])
+        df = ranking._df
+        q_no, q_ids = ranking._numbering()
         first_rows = np.full(len(q_ids), -1, dtype=np.int64)
         first_rows[q_no[::-1]] = np.arange(len(df) - 1, -1, -1)
         texts = df["query"].to_numpy()[first_rows].tolist()
@@ -280,7 +281,7 @@ class Index(abc.ABC):
         t0 = perf_counter()
 
         df = ranking._df
-        q_no, _, texts = self._numbered_queries(df)
+        q_no, q_order, texts = self._numbered_queries(ranking)
         # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
         # work (the reference raises from its first batch; either way no partial result is returned)
         ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
@@ -289,11 +290,19 @@ class Index(abc.ABC):
         if early_stopping is None and (batch_size is None or batch_size >= n_q) and len(df) > 0:
             # the common case without the intermediate frames: CSR in, scores out
             perm, pair_off = _grouped_by_query(q_no, n_q)
-            dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals if perm is None else ordinals[perm], self.mode)
-            if perm is not None:
-                unperm = np.empty_like(dense)
-                unperm[perm] = dense
-                dense = unperm
+            if perm is None:
+                # rows of a query are adjacent and the queries already stand in their final order
+                # (a Ranking is sorted by q_id), so the device's per-query order is the whole sort
+                dense, _, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sort=True)
+                cols = {c: df[c].to_numpy()[order] for c in ("q_id", "id")}
+                cols["score"] = dense[order].astype(df.dtypes["score"], copy=False)
+                cols["query"] = df["query"].to_numpy()[order]
+                LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+                return Ranking._assemble(cols, "fast-forward", q_no, q_order)
+            dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals[perm], self.mode)
+            unperm = np.empty_like(dense)
+            unperm[perm] = dense
+            dense = unperm
             result = df.copy()
             result["score"] = dense.astype(df.dtypes["score"], copy=False)
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
@@ -328,7 +337,7 @@ class Index(abc.ABC):
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
         df = ranking._df
-        q_no, _, texts = self._numbered_queries(df)
+        q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         perm, pair_off = _grouped_by_query(q_no, len(texts))
@@ -341,9 +350,15 @@ class Index(abc.ABC):
             rank = np.arange(len(src)) - np.repeat(pair_off[:-1], np.diff(pair_off))
             keep = rank < cutoff
             src, order = src[keep], order[keep]
+        if perm is None:
+            # the queries already stand in their final order (a Ranking is sorted by q_id) and the
+            # device ordered each one: nothing is left to sort or to check
+            cols = {c: df[c].to_numpy()[src] for c in ("q_id", "id")}
+            cols["score"] = interp[order].astype(df.dtypes["score"], copy=False)
+            cols["query"] = df["query"].to_numpy()[src]
+            return Ranking._assemble(cols, ranking.name, q_no[src], q_order)
         out = df.iloc[src].reset_index(drop=True)
         out["score"] = interp[order].astype(df.dtypes["score"])
-        # queries in the order the reference would list them: q_id descending
         return Ranking(Ranking._trusted(out), name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
 
     def rerank_file(self, run_in, run_out, alpha: float, queries, cutoff: int | None = None, name: str | None = None) -> dict:

@@ -29,7 +29,7 @@ SYMBOLS = (
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
-    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get",
+    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
 )
@@ -133,6 +133,7 @@ def lib() -> C.CDLL:
         "ffx_ids_count": ([vp, P(i64)], C.c_int),
         "ffx_ids_intern": ([vp, vp, i32, i64, vp], C.c_int),
         "ffx_ids_lookup": ([vp, vp, i32, i64, vp, P(i64)], C.c_int),
+        "ffx_ids_lookup_packed": ([vp, C.c_char_p, i64, C.c_char, i64, vp, P(i64)], C.c_int),
         "ffx_ids_get": ([vp, i32, P(vp), P(i32)], C.c_int),
         "ffx_run_open": ([C.c_char_p, vp, P(vp), P(i64)], C.c_int),
         "ffx_run_close": ([vp], C.c_int),
@@ -506,6 +507,21 @@ class IdStrings:
 
     def lookup(self, strings) -> np.ndarray:
         """Ordinals of ``strings``; ``IndexError`` naming the first unknown one."""
+        if isinstance(strings, np.ndarray) and strings.dtype == object and strings.shape[0] >= 4096:
+            # Python strings: one joined buffer costs a fraction of a fixed-width copy of each
+            try:
+                blob = "\n".join(strings.tolist()).encode("utf-8")
+            except TypeError:  # not all str
+                blob = None
+            n = strings.shape[0]
+            if blob is not None and blob.count(b"\n") == n - 1 and b"\0" not in blob:
+                out = np.empty(n, dtype=np.int32)
+                miss = C.c_int64(-1)
+                rc = lib().ffx_ids_lookup_packed(self._h, blob, len(blob), b"\n", n, _ptr(out), C.byref(miss))
+                if rc == NOT_FOUND:
+                    raise IndexError(f"ID {strings[miss.value]} not found in the index.")
+                _check(rc)
+                return out
         b = _as_fixed_bytes(strings)
         out = np.empty(b.shape[0], dtype=np.int32)
         if b.shape[0] == 0:

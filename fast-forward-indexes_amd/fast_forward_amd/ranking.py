@@ -104,9 +104,29 @@ class Ranking:
         if not is_sorted:
             frame = _sorted_frame(frame)
         self._df = frame.reset_index(drop=True)
-        self._q_ids = set(self._df["q_id"].unique())
+        # one pass gives both the set of query ids and every row's query number (order of first
+        # appearance, base.py:418-421), which Index.__call__ needs again
+        self._q_no, q_ids = pd.factorize(self._df["q_id"])
+        self._q_order = list(q_ids)
+        self._q_ids = set(self._q_order)
         if queries is not None:
             self._df = _with_queries(self._df, queries)
+
+    @classmethod
+    def _assemble(cls, columns: Mapping[str, np.ndarray], name: str | None, q_no: np.ndarray, q_order: list[str]) -> "Ranking":
+        """Ranking from finished columns, with no scan at all.  For results derived on the device
+        from an existing Ranking: rows already in final order (q_id descending, score descending),
+        pairs unique, no missing values; ``q_no`` / ``q_order`` as the constructor computes them."""
+        out = cls.__new__(cls)
+        out.name = name
+        out._df = pd.DataFrame(dict(columns), copy=False)
+        out._q_no, out._q_order = q_no, list(q_order)
+        out._q_ids = set(out._q_order)
+        return out
+
+    def _numbering(self) -> tuple[np.ndarray, list[str]]:
+        """(query number of every row, query ids in that numbering): order of first appearance."""
+        return self._q_no, self._q_order
 
     # ---- container protocol ------------------------------------------------------------
     @property
@@ -163,8 +183,82 @@ class Ranking:
         object.__setattr__(df, "_ffx_pairs_unique", True)
         return df
 
+    def _combined(self, other: "Ranking", fn, left: pd.DataFrame | None = None, right: pd.DataFrame | None = None) -> "Ranking":
+        """``fn(score, score_other)`` over the outer join on (q_id, id) -- what ``_joined`` + the
+        constructor compute, without hashing a string pair per row: queries are numbered through
+        the cached per-row query numbers, ids through one factorize, and the join runs on the
+        resulting integer keys.  Same rows, scores and order (exact ties: by id, as the sorted
+        outer merge leaves them)."""
+        a, b = self._df, other._df
+        sa = (a if left is None else left)["score"].to_numpy()
+        sb = (b if right is None else right)["score"].to_numpy()
+        na, nb = len(a), len(b)
+        if na + nb == 0:
+            return None
+        qa, names_a = self._numbering()
+        qb, names_b = other._numbering()
+        code_of = {q: i for i, q in enumerate(names_a)}
+        for q in names_b:
+            code_of.setdefault(q, len(code_of))
+        names = list(code_of)
+        gb = np.fromiter((code_of[q] for q in names_b), dtype=np.int64, count=len(names_b))[qb] if nb else np.zeros(0, dtype=np.int64)
+        ids_a, ids_b = a["id"].to_numpy(), b["id"].to_numpy()
+        id_code, id_names = pd.factorize(np.concatenate([ids_a, ids_b]))
+        width = max(1, len(id_names))
+        keys, where = np.unique(np.concatenate([qa.astype(np.int64) * width + id_code[:na], gb * width + id_code[na:]]),
+                                return_inverse=True)
+        at_a, at_b = where[:na], where[na:]
+        n = keys.shape[0]
+        va, vb = np.zeros(n, dtype=sa.dtype), np.zeros(n, dtype=sb.dtype)
+        va[at_a], vb[at_b] = sa, sb
+        score = np.asarray(fn(va, vb)).astype(a.dtypes["score"], copy=False)
+        if np.isnan(score).any():
+            return None  # rows would be dropped: leave it to the general path
+        # final order: q_id descending, score descending, exact ties by id ascending
+        q_of = keys // width
+        rank_of = np.empty(len(names), dtype=np.int64)
+        rank_of[np.argsort(np.array(names, dtype=object))[::-1]] = np.arange(len(names))
+        q_rank = rank_of[q_of]
+        order = np.lexsort((-score.astype(np.float64), q_rank))
+        id_sorted = id_names.to_numpy() if hasattr(id_names, "to_numpy") else np.asarray(id_names)
+        id_col = id_sorted[(keys % width)[order]]
+        s_o, q_o = score[order], q_rank[order]
+        tied = np.flatnonzero((s_o[1:] == s_o[:-1]) & (q_o[1:] == q_o[:-1]))
+        if tied.size:
+            starts = tied[np.concatenate([[True], np.diff(tied) > 1])]
+            for lo in starts.tolist():
+                hi = lo + 1
+                while hi < n and s_o[hi] == s_o[lo] and q_o[hi] == q_o[lo]:
+                    hi += 1
+                fix = np.argsort(id_col[lo:hi], kind="stable")
+                order[lo:hi] = order[lo:hi][fix]
+                id_col[lo:hi] = id_col[lo:hi][fix]
+        q_names = np.array(names, dtype=object)
+        cols = {"q_id": q_names[q_of[order]], "id": id_col, "score": s_o}
+        # the query text comes from this ranking if it has any, else from `other`; a pair the
+        # chosen side lacks gets the merge's fill value 0
+        side = (a, at_a) if "query" in a.columns else (b, at_b) if "query" in b.columns else None
+        if side is not None:
+            src = np.full(n, -1, dtype=np.int64)
+            src[side[1]] = np.arange(len(side[0]))
+            src = src[order]
+            query = np.zeros(n, dtype=object)
+            have = src >= 0
+            query[have] = side[0]["query"].to_numpy()[src[have]]
+            cols["query"] = query
+        # numbering of the result: queries appear in rank order
+        present = np.flatnonzero(np.bincount(q_o, minlength=len(names)))
+        renumber = np.full(len(names), -1, dtype=np.int64)
+        renumber[present] = np.arange(present.shape[0])
+        by_rank = np.empty(len(names), dtype=object)
+        by_rank[rank_of] = q_names
+        return Ranking._assemble(cols, self.name, renumber[q_o], by_rank[present].tolist())
+
     def __add__(self, o: "Ranking | float") -> "Ranking":
         if isinstance(o, Ranking):
+            fast = self._combined(o, lambda x, y: x + y)
+            if fast is not None:
+                return fast
             both = self._joined(o)
             both["score"] = both["score"] + both["score_other"]
             return self._derived(both, is_sorted=False)
@@ -194,6 +288,10 @@ class Ranking:
         """
         left = _scaled_to_unit_range(self._df) if normalize else None
         right = _scaled_to_unit_range(other._df) if normalize else None
+        # a Python-float weight on a float32 array multiplies in float32 (ranking.py:319)
+        fast = self._combined(other, lambda x, y: alpha * x + (1 - alpha) * y, left, right)
+        if fast is not None:
+            return fast
         both = self._joined(other, left, right)
         # a Python-float weight on a float32 column multiplies in float32 (ranking.py:319)
         both["score"] = alpha * both["score"] + (1 - alpha) * both["score_other"]

@@ -274,7 +274,7 @@ class ShardedInMemoryIndex:
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
         df = ranking._df
-        q_no, q_ids, texts = self.local._numbered_queries(df)
+        q_no, q_ids, texts = self.local._numbered_queries(ranking)
         n_q = len(texts)
         query_vectors = np.ascontiguousarray(self.local.encode_queries(texts), dtype=np.float32)
         perm, pair_off = _grouped_by_query(q_no, n_q)

@@ -122,3 +122,27 @@ def test_float_formatting_matches_numpy_str(value, tmp_path):
     run = native.RunFile(src, table)
     run.write(tmp_path / "o.tsv", np.array([value], dtype=np.float32), np.array([0], dtype=np.int32))
     assert (tmp_path / "o.tsv").read_text().split("\t")[4] == str(np.float32(value))
+
+
+def test_lookup_of_python_strings_goes_through_one_packed_buffer():
+    """Large object arrays are joined into one buffer and split natively (ffx_ids_lookup_packed,
+    threaded): same ordinals as the fixed-width path, same first missing id, odd strings fall back."""
+    table = native.IdStrings()
+    known = [f"D{i}" for i in range(50_000)] + ["dóc-ü", "x" * 70, ""]
+    table.intern(np.array(known, dtype=object))
+    rng = np.random.default_rng(3)
+    pick = rng.integers(0, len(known), size=200_000)
+    want = np.asarray(known, dtype=object)[pick]
+    got = table.lookup(want)
+    assert np.array_equal(got, pick.astype(np.int32))
+    assert np.array_equal(got, table.lookup(native._as_fixed_bytes(want)))  # the fixed-width path
+    bad = want.copy()
+    bad[150_001] = "nope"
+    bad[199_000] = "neither"
+    with pytest.raises(IndexError, match="ID nope not found"):
+        table.lookup(bad)
+    odd = want.copy()
+    odd[17] = "two\nlines"  # cannot be packed with a newline separator: falls back, then fails as unknown
+    with pytest.raises(IndexError, match="two"):
+        table.lookup(odd)
+    table.close()

@@ -154,3 +154,57 @@ def test_interpolate_matches_reference_bits_and_order(alpha, norm):
     # same ordering: q_id sequence identical, scores non-increasing inside each query
     assert got["q_id"].tolist() == exp["q_id"].tolist()
     assert np.array_equal(bits(got["score"].to_numpy()), bits(exp["score"].to_numpy()))
+
+
+def _general_interpolate(a: Ranking, b: Ranking, alpha: float, normalize: bool) -> Ranking:
+    """The pandas route (outer merge on the string pairs) the integer-key join replaces."""
+    from fast_forward_amd.ranking import _scaled_to_unit_range
+
+    left = _scaled_to_unit_range(a._df) if normalize else None
+    right = _scaled_to_unit_range(b._df) if normalize else None
+    both = a._joined(b, left, right)
+    both["score"] = alpha * both["score"] + (1 - alpha) * both["score_other"]
+    return a._derived(both, is_sorted=False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_integer_key_join_equals_the_pandas_merge(seed):
+    """interpolate / + through `_combined`: same rows in the same order with the same bits as the
+    outer merge + constructor, for overlapping and disjoint pairs, exact ties, queries present on
+    either side, float64 on one side, and normalisation."""
+    rng = np.random.default_rng(seed)
+    docs = [f"d{i}" for i in range(40)]
+
+    def random_ranking(q_ids, dtype, coarse):
+        run = {}
+        for q in q_ids:
+            picked = rng.choice(docs, size=int(rng.integers(0, 25)), replace=False)
+            # coarse scores make exact ties (within and across the two sides) common
+            run[q] = {d: float(rng.integers(0, 4)) if coarse else float(rng.standard_normal()) for d in picked}
+        return Ranking.from_run(run, dtype=np.dtype(dtype))
+
+    qs_a, qs_b = [f"q{i}" for i in range(0, 9)], [f"q{i}" for i in range(3, 12)]
+    a = random_ranking(qs_a, np.float32, coarse=seed % 2 == 0)
+    b = random_ranking(qs_b, np.float64 if seed == 3 else np.float32, coarse=seed % 2 == 0)
+    if seed in (1, 4):
+        a = a.attach_queries({q: f"text {q}" for q in qs_a})
+    if seed in (2, 4):
+        b = b.attach_queries({q: f"text {q}" for q in qs_b})
+    for alpha, normalize in ((0.1, False), (0.5, False), (0.3, True)):
+        fast = a.interpolate(b, alpha, normalize=normalize)
+        want = _general_interpolate(a, b, alpha, normalize)
+        assert list(fast._df.columns) == list(want._df.columns)
+        for col in ("q_id", "id", "query"):
+            if col in want._df.columns:
+                assert fast._df[col].tolist() == want._df[col].tolist(), col
+        assert fast._df["score"].dtype == want._df["score"].dtype
+        assert np.array_equal(fast._df["score"].to_numpy().view(np.uint32), want._df["score"].to_numpy().view(np.uint32))
+        assert fast.q_ids == want.q_ids and fast == want
+        # the cached numbering of the assembled result is what the constructor would compute
+        q_no, q_order = pd.factorize(fast._df["q_id"])
+        assert np.array_equal(fast._numbering()[0], q_no) and fast._numbering()[1] == list(q_order)
+    total = a + b
+    both = a._joined(b)
+    both["score"] = both["score"] + both["score_other"]
+    want = a._derived(both, is_sorted=False)
+    assert total._df["id"].tolist() == want._df["id"].tolist() and total == want
