@@ -288,53 +288,106 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
   std::vector<int32_t> row_q, row_id;
   std::vector<float> row_s;
   int rc = FFX_OK;
-  int64_t line_no = 0;
-  const char* p = data.data();
-  const char* end = p + data.size();
-  auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r'; };
-  try {
-    while (p < end) {
-      const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
-      if (!eol) eol = end;
-      ++line_no;
-      std::string_view field[6];
-      int nf = 0;
-      const char* c = p;
-      while (c < eol && nf < 6) {
-        while (c < eol && is_space(*c)) ++c;
-        if (c >= eol) break;
-        const char* s = c;
-        while (c < eol && !is_space(*c)) ++c;
-        field[nf++] = {s, (size_t)(c - s)};
+  // The file is cut into pieces at line ends and the pieces are tokenised, resolved against the
+  // (read-only) id table and converted in parallel; query ids are run-length encoded per piece
+  // and interned afterwards in file order, so numbering and errors are those of a serial pass.
+  struct Piece {
+    const char *begin = nullptr, *end = nullptr;
+    std::vector<int32_t> id;
+    std::vector<float> score;
+    std::vector<std::pair<std::string_view, int64_t>> q_runs;  // (query id, consecutive rows)
+    std::string_view tag;
+    int64_t lines = 0;
+    int err = FFX_OK;  // first problem of the piece
+    int64_t err_line = 0;
+    std::string err_text;
+    bool oom = false;
+  };
+  const char* const base = data.data();
+  const char* const end = base + data.size();
+  const int T = (int)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<size_t>(1, data.size() >> 20));
+  std::vector<Piece> pieces((size_t)T);
+  {
+    const char* cut = base;
+    for (int t = 0; t < T; ++t) {
+      pieces[(size_t)t].begin = cut;
+      const char* want = t + 1 == T ? end : base + data.size() * (size_t)(t + 1) / (size_t)T;
+      if (want < cut) want = cut;
+      if (want < end) {
+        const char* nl = (const char*)memchr(want, '\n', (size_t)(end - want));
+        want = nl ? nl + 1 : end;
       }
-      p = eol + 1;
-      if (nf == 0) continue;  // blank line
-      if (nf < 5) {
-        if (bad_line) *bad_line = line_no;
-        rc = ffx_fail(FFX_BAD_ARG, "%s:%lld: expected 'q_id Q0 id rank score [name]'", path, (long long)line_no);
-        break;
-      }
-      const int32_t o = ids->find(field[2]);
-      if (o < 0) {
-        if (bad_line) *bad_line = line_no;
-        rc = ffx_fail(FFX_NOT_FOUND, "ID %.*s not found in the index.", (int)field[2].size(), field[2].data());
-        break;
-      }
-      double sc = 0;
-      {
-        const std::string tmp(field[4]);
-        char* endp = nullptr;
-        sc = strtod(tmp.c_str(), &endp);
-        if (endp == tmp.c_str()) {
-          if (bad_line) *bad_line = line_no;
-          rc = ffx_fail(FFX_BAD_ARG, "%s:%lld: bad score '%s'", path, (long long)line_no, tmp.c_str());
-          break;
+      pieces[(size_t)t].end = cut = want;
+    }
+  }
+  auto parse = [&](Piece& pc) {
+    auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r'; };
+    try {
+      const char* p = pc.begin;
+      while (p < pc.end) {
+        const char* eol = (const char*)memchr(p, '\n', (size_t)(pc.end - p));
+        if (!eol) eol = pc.end;
+        ++pc.lines;
+        std::string_view field[6];
+        int nf = 0;
+        const char* c = p;
+        while (c < eol && nf < 6) {
+          while (c < eol && is_space(*c)) ++c;
+          if (c >= eol) break;
+          const char* s0 = c;
+          while (c < eol && !is_space(*c)) ++c;
+          field[nf++] = {s0, (size_t)(c - s0)};
         }
+        p = eol + 1;
+        if (nf == 0) continue;  // blank line
+        if (nf < 5) {
+          pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "expected 'q_id Q0 id rank score [name]'";
+          return;
+        }
+        const int32_t o = ids->find(field[2]);
+        if (o < 0) {
+          pc.err = FFX_NOT_FOUND, pc.err_line = pc.lines, pc.err_text.assign(field[2]);
+          return;
+        }
+        // the buffer ends in NUL and a field ends at white space, so strtod cannot run past it
+        char* endp = nullptr;
+        const double sc = strtod(field[4].data(), &endp);
+        if (endp != field[4].data() + field[4].size()) {
+          pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
+          return;
+        }
+        if (pc.tag.data() == nullptr && nf >= 6) pc.tag = field[5];
+        if (pc.q_runs.empty() || pc.q_runs.back().first != field[0]) pc.q_runs.emplace_back(field[0], 0);
+        ++pc.q_runs.back().second;
+        pc.id.push_back(o);
+        pc.score.push_back((float)sc);  // scores become float32 (Ranking dtype, ranking.py:72)
       }
-      if (run->tag.empty() && nf >= 6) run->tag.assign(field[5]);
-      row_q.push_back(run->qids.intern(field[0]));
-      row_id.push_back(o);
-      row_s.push_back((float)sc);  // scores become float32 (Ranking dtype, ranking.py:72)
+    } catch (const std::bad_alloc&) {
+      pc.oom = true;
+    }
+  };
+  try {
+    {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < T; ++t) pool.emplace_back(parse, std::ref(pieces[(size_t)t]));
+      parse(pieces[0]);
+      for (auto& th : pool) th.join();
+    }
+    int64_t lines_before = 0;
+    for (Piece& pc : pieces) {
+      if (pc.oom) throw std::bad_alloc();
+      if (pc.err != FFX_OK) {
+        const int64_t line_no = lines_before + pc.err_line;
+        if (bad_line) *bad_line = line_no;
+        rc = pc.err == FFX_NOT_FOUND ? ffx_fail(FFX_NOT_FOUND, "ID %s not found in the index.", pc.err_text.c_str())
+                                     : ffx_fail(FFX_BAD_ARG, "%s:%lld: %s", path, (long long)line_no, pc.err_text.c_str());
+        break;
+      }
+      lines_before += pc.lines;
+      if (run->tag.empty() && pc.tag.data() != nullptr) run->tag.assign(pc.tag);
+      row_id.insert(row_id.end(), pc.id.begin(), pc.id.end());
+      row_s.insert(row_s.end(), pc.score.begin(), pc.score.end());
+      for (const auto& qr : pc.q_runs) row_q.insert(row_q.end(), (size_t)qr.second, run->qids.intern(qr.first));
     }
     if (rc == FFX_OK) {
       const int64_t nq = run->qids.size(), n = (int64_t)row_q.size();
@@ -349,14 +402,35 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
         run->pair_ids[(size_t)dst] = row_id[(size_t)i];
         run->score[(size_t)dst] = row_s[(size_t)i];
       }
-      // duplicate (query, id) pairs
-      std::vector<int32_t> tmp;
-      for (int64_t q = 0; q < nq && rc == FFX_OK; ++q) {
-        tmp.assign(run->pair_ids.begin() + run->pair_off[(size_t)q], run->pair_ids.begin() + run->pair_off[(size_t)q + 1]);
-        std::sort(tmp.begin(), tmp.end());
-        if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end())
-          rc = ffx_fail(FFX_BAD_ARG, "Only one score per query-document/passage pair is allowed.");
+      // duplicate (query, id) pairs: one mark per ordinal, set and cleared query by query
+      std::atomic<bool> dup{false}, scan_oom{false};
+      auto scan = [&](int64_t q_lo, int64_t q_hi) {
+        std::vector<uint8_t> seen;
+        try {
+          seen.assign((size_t)ids->size(), 0);
+        } catch (const std::bad_alloc&) {
+          scan_oom.store(true);
+          return;
+        }
+        for (int64_t q = q_lo; q < q_hi && !dup.load(std::memory_order_relaxed); ++q) {
+          const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
+          for (int64_t i = lo; i < hi; ++i) {
+            uint8_t& m = seen[(size_t)run->pair_ids[(size_t)i]];
+            if (m) dup.store(true);
+            m = 1;
+          }
+          for (int64_t i = lo; i < hi; ++i) seen[(size_t)run->pair_ids[(size_t)i]] = 0;
+        }
+      };
+      const int TD = (int)std::min<int64_t>(T, std::max<int64_t>(1, n >> 16));
+      {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < TD; ++t) pool.emplace_back(scan, nq * t / TD, nq * (t + 1) / TD);
+        scan(0, nq / TD);
+        for (auto& th : pool) th.join();
       }
+      if (scan_oom.load()) throw std::bad_alloc();
+      if (dup.load()) rc = ffx_fail(FFX_BAD_ARG, "Only one score per query-document/passage pair is allowed.");
     }
   } catch (const std::bad_alloc&) {
     rc = ffx_fail(FFX_OOM, "host allocation failed while parsing %s", path);
@@ -443,31 +517,59 @@ int ffx_run_write(const ffx_run* run, const char* path, const float* scores, con
   std::iota(qorder.begin(), qorder.end(), 0);
   std::sort(qorder.begin(), qorder.end(), [&](int64_t a, int64_t b) { return run->qids.get((int32_t)a) > run->qids.get((int32_t)b); });
   const std::string name = tag ? tag : run->tag;
-  std::string out;
-  out.reserve(1 << 20);
-  for (int64_t q : qorder) {
-    const std::string_view qid = run->qids.get((int32_t)q);
-    const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
-    const int64_t n = (keep > 0 && hi - lo > keep) ? keep : hi - lo;
-    for (int64_t r = 0; r < n; ++r) {
-      const int64_t p = order[lo + r];
-      const std::string_view id = run->ids->get(run->pair_ids[(size_t)p]);
-      out.append(qid).append("\tQ0\t").append(id).push_back('\t');
-      out += std::to_string(r + 1);
-      out.push_back('\t');
-      append_float_repr(out, scores[p]);
-      out.push_back('\t');
-      out += name;
-      out.push_back('\n');
-      if (out.size() > (1 << 20) - 256) {
-        fwrite(out.data(), 1, out.size(), f);
-        out.clear();
+  // formatting is the cost here (a shortest-round-trip float per line): queries are handed to a
+  // few threads in batches, each fills its own buffer, and the buffers are written in order
+  auto format = [&](int64_t q_lo, int64_t q_hi, std::string& out) {
+    out.clear();
+    for (int64_t qi = q_lo; qi < q_hi; ++qi) {
+      const int64_t q = qorder[(size_t)qi];
+      const std::string_view qid = run->qids.get((int32_t)q);
+      const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
+      const int64_t n = (keep > 0 && hi - lo > keep) ? keep : hi - lo;
+      for (int64_t r = 0; r < n; ++r) {
+        const int64_t p = order[lo + r];
+        const std::string_view id = run->ids->get(run->pair_ids[(size_t)p]);
+        out.append(qid).append("\tQ0\t").append(id).push_back('\t');
+        out += std::to_string(r + 1);
+        out.push_back('\t');
+        append_float_repr(out, scores[p]);
+        out.push_back('\t');
+        out += name;
+        out.push_back('\n');
       }
     }
+  };
+  const int64_t n_rows = run->pair_off.empty() ? 0 : run->pair_off.back();
+  const int T = (int)std::min<int64_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<int64_t>(1, n_rows >> 15));
+  std::vector<std::string> bufs((size_t)T);
+  bool ok = true;
+  try {
+    // a batch holds about 64K lines per thread
+    const int64_t avg = std::max<int64_t>(1, n_rows / std::max<int64_t>(1, nq));
+    const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
+    for (int64_t q0 = 0; q0 < nq && ok; q0 += q_per_thread * T) {
+      std::vector<std::thread> pool;
+      int used = 0;
+      for (int t = 0; t < T; ++t) {
+        const int64_t lo = q0 + t * q_per_thread, hi = std::min(nq, lo + q_per_thread);
+        if (lo >= hi) break;
+        ++used;
+        if (t > 0) pool.emplace_back(format, lo, hi, std::ref(bufs[(size_t)t]));
+      }
+      format(q0, std::min(nq, q0 + q_per_thread), bufs[0]);
+      for (auto& th : pool) th.join();
+      for (int t = 0; t < used && ok; ++t)
+        ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
+    }
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
   }
-  fwrite(out.data(), 1, out.size(), f);
-  const bool ok = fclose(f) == 0;
-  return ok ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+  if (!ok) {
+    fclose(f);
+    return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+  }
+  return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
 }
 
 }  // extern "C"

@@ -146,3 +146,54 @@ def test_lookup_of_python_strings_goes_through_one_packed_buffer():
     with pytest.raises(IndexError, match="two"):
         table.lookup(odd)
     table.close()
+
+
+def test_large_run_is_parsed_and_written_in_parallel_pieces(tmp_path):
+    """A file of several MiB is cut into pieces parsed by threads (and written back in batches):
+    numbering, CSR, errors with their line numbers and the written bytes are those of a serial pass."""
+    rng = np.random.default_rng(4)
+    n_docs, n_q, k = 20_000, 300, 1000
+    table = _table(*[f"D{i}" for i in range(n_docs)])
+    q_names = [f"q{i:04d}" for i in rng.permutation(n_q)]  # queries not in sorted order in the file
+    lines, want_ids, want_scores = [], [], []
+    for q in q_names:
+        docs = rng.choice(n_docs, size=k, replace=False)
+        scores = rng.random(k).astype(np.float32) * 30
+        want_ids.append(docs)
+        want_scores.append(scores)
+        lines += [f"{q} Q0 D{d} {r + 1} {s} first" for r, (d, s) in enumerate(zip(docs, scores))]
+    path = tmp_path / "big.tsv"
+    path.write_text("\n".join(lines) + "\n")
+    assert path.stat().st_size > 8 << 20
+    run = native.RunFile(path, table)
+    assert (run.n_queries, run.n_pairs, run.tag) == (n_q, n_q * k, "first")
+    assert run.query_ids() == q_names
+    pair_off, pair_ids, sparse = run.export()
+    assert np.array_equal(pair_off, np.arange(n_q + 1) * k)
+    assert np.array_equal(pair_ids, np.concatenate(want_ids)) and np.array_equal(sparse, np.concatenate(want_scores))
+    # written bytes == Ranking.save of the same scores
+    new = rng.random(n_q * k).astype(np.float32)
+    order = np.concatenate([q * k + np.argsort(-new[q * k:(q + 1) * k].astype(np.float64), kind="stable") for q in range(n_q)]).astype(np.int32)
+    run.write(tmp_path / "native.tsv", new, order, tag="second")
+    df = pd.DataFrame({"q_id": np.repeat(q_names, k), "id": [f"D{d}" for d in pair_ids], "score": new})
+    Ranking(df, name="second").save(tmp_path / "python.tsv")
+    assert (tmp_path / "native.tsv").read_bytes() == (tmp_path / "python.tsv").read_bytes()
+    run.close()
+    # problems deep inside the file: the first one in file order wins, with its line number
+    broken = list(lines)
+    broken[250_000] = broken[250_000].replace(" Q0 D", " Q0 X")
+    broken[120_000] = "q0001 Q0 D5 1 1.5abc first"
+    path.write_text("\n".join(broken) + "\n")
+    with pytest.raises(ValueError, match=r":120001: bad score '1.5abc'"):
+        native.RunFile(path, table)
+    broken[120_000] = lines[120_000]
+    path.write_text("\n".join(broken) + "\n")
+    with pytest.raises(IndexError, match=r"ID X\d+ not found in the index."):
+        native.RunFile(path, table)
+    # a repeated pair far apart in the file
+    broken[250_000] = lines[250_000]
+    q_of = broken[10].split()[0]
+    broken.append(f"{q_of} Q0 {broken[10].split()[2]} 9 0.5 first")
+    path.write_text("\n".join(broken) + "\n")
+    with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
+        native.RunFile(path, table)
