@@ -94,12 +94,31 @@ def candidates(n_docs: int, n_queries: int, k: int, seed: int, q_first: int = 0)
     return ids, sparse
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a container on a 256-core host is often allowed 16; 256 OpenMP threads on that quota crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            quota, period = parse(open(path).read())
+            if period is None:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(args, doc_off, n_docs, scale):
     """Reference-equivalent CPU path (oracle/ffx_oracle.py numpy_port_score: the reference's
     own three NumPy ops, index/base.py:301-303) on the first `cpu_sample_queries` queries of
     the same workload.  The rows those queries touch are re-derived on the host with the same
     counter-based generator the device index was filled with."""
     sys.path.insert(0, str(ROOT / "oracle"))
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))  # read by libgomp when the oracle library loads
     import ffx_oracle as fo
 
     nq = args.cpu_sample_queries
@@ -138,13 +157,13 @@ def cpu_baseline(args, doc_off, n_docs, scale):
         t_c += time.perf_counter() - t0
         passes_c += 1
     assert np.array_equal(ff.view(np.uint32), ff_c.view(np.uint32))
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count()))
+    threads = int(os.environ["OMP_NUM_THREADS"])
     out = {
         "value": nq * passes / t_np, "unit": "queries/s", "cores": 1, "kind": "port",
         "sample": f"first {nq} queries x k={args.k} ({nq * args.k} pairs, {rows_global.shape[0]} distinct rows = "
                   f"{vecs.nbytes / 1e6:.0f} MB re-derived on the host) of the same workload, {passes} whole passes "
                   f"({t_np:.1f} s) of the NumPy port of index/base.py:301-303 + ranking.py:319, 4 queries per batch; "
-                  f"host has {os.cpu_count()} cores, NumPy elementwise ops use 1",
+                  f"host has {os.cpu_count()} cores ({usable_cores()} usable by this process), NumPy elementwise ops use 1",
         "seconds": t_np, "passes": passes,
         "omp_c_port": {"value": nq * passes_c / t_c, "unit": "queries/s", "cores": threads, "seconds": t_c, "passes": passes_c,
                        "note": "oracle/ffx_oracle.c (scalar, NumPy summation order), OpenMP over candidates"},
