@@ -214,22 +214,35 @@ class Index(abc.ABC):
 
     def _early_stopping(self, df: pd.DataFrame, query_vectors: np.ndarray, cutoff: int, alpha: float,
                         depths: Iterable[int]) -> pd.DataFrame:
+        """Frame form of :meth:`_early_stopping_scores` (columns ``id``, ``q_no``, ``score`` in,
+        plus ``ff_score`` out; NaN where a candidate was not scored)."""
+        out = df.drop(columns=["_ord"], errors="ignore")
+        out["ff_score"] = self._early_stopping_scores(df["id"].to_numpy(), df["q_no"].to_numpy(dtype=np.int64), df["score"].to_numpy(),
+                                                      query_vectors, cutoff, alpha, depths)
+        return out
+
+    def _early_stopping_scores(self, ids: np.ndarray, q_no: np.ndarray, sparse: np.ndarray, query_vectors: np.ndarray,
+                               cutoff: int, alpha: float, depths: Iterable[int]) -> np.ndarray:
         """Score each query only as deep as needed for its top-``cutoff`` (base.py:316-387).
 
         Depth intervals ``[a, b)`` over the sorted depths ``>= cutoff``; after the first
         interval a query continues only while its ``cutoff``-th best interpolated score is below
         the best it could still reach, ``alpha * s_last + (1 - alpha) * max_dense`` (``s_last``:
-        sparse score of the last scored candidate).  Unscored candidates get no score."""
-        q_no = df["q_no"].to_numpy(dtype=np.int64)
-        sparse = df["score"].to_numpy()
-        n_q = query_vectors.shape[0]
-        rank_in_q = df.groupby("q_no", sort=False).cumcount().to_numpy()
+        sparse score of the last scored candidate).  Returns the dense scores in row order, NaN
+        for candidates that were never scored.  Ids are resolved interval by interval, so -- as in
+        the reference -- an id that is never reached is never looked up."""
+        n, n_q = q_no.shape[0], query_vectors.shape[0]
+        perm, pair_off = _grouped_by_query(q_no, n_q)
+        if perm is None:
+            rank_in_q = np.arange(n, dtype=np.int64) - pair_off[q_no]
+        else:
+            rank_in_q = pd.Series(q_no).groupby(q_no, sort=False).cumcount().to_numpy()
         # dense scores are float32 (as the reference's np.sum over float32 vectors); the criterion
         # below then follows NumPy's promotion for `python_float * np.float32` exactly as the
         # reference's expression does (NEP 50: stays float32 on numpy >= 2, the version the golden
         # fixtures were generated with)
-        ff = np.full(len(df), np.nan, dtype=np.float32)
-        interp = np.full(len(df), np.nan, dtype=np.result_type(sparse.dtype, np.float32))
+        ff = np.full(n, np.nan, dtype=np.float32)
+        interp = np.full(n, np.nan, dtype=np.result_type(sparse.dtype, np.float32))
         active = np.ones(n_q, dtype=bool)
         a = 0
         for b in sorted(depths):
@@ -258,14 +271,14 @@ class Index(abc.ABC):
             take = np.flatnonzero(active[q_no] & (rank_in_q >= a) & (rank_in_q < b))
             if take.size == 0:
                 break
-            cols = ["id", "q_no"] + (["_ord"] if "_ord" in df.columns else [])
-            chunk_ff = self._compute_scores(df.iloc[take][cols], query_vectors)["ff_score"].to_numpy(dtype=np.float32)
+            part_perm, part_off = _grouped_by_query(q_no[take], n_q)
+            if part_perm is not None:
+                take = take[part_perm]
+            chunk_ff, _, _ = self._score_pairs(query_vectors, part_off, self._resolve_ids(ids[take], self.mode), self.mode)
             ff[take] = chunk_ff
             interp[take] = alpha * sparse[take] + (1 - alpha) * chunk_ff
             a = b
-        out = df.drop(columns=["_ord"], errors="ignore")
-        out["ff_score"] = ff
-        return out
+        return ff
 
     def __call__(self, ranking: Ranking, early_stopping: int | None = None, early_stopping_alpha: float | None = None,
                  early_stopping_depths: Iterable[int] | None = None, batch_size: int | None = None) -> Ranking:
@@ -282,11 +295,25 @@ class Index(abc.ABC):
 
         df = ranking._df
         q_no, q_order, texts = self._numbered_queries(ranking)
-        # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
-        # work (the reference raises from its first batch; either way no partial result is returned)
-        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
+        if early_stopping is not None and (batch_size is None or batch_size >= n_q) and len(df) > 0:
+            # arrays in, arrays out: only the candidates that get scored are looked up and kept
+            ff = self._early_stopping_scores(df["id"].to_numpy(), q_no, df["score"].to_numpy(), query_vectors, early_stopping,
+                                             early_stopping_alpha, early_stopping_depths)
+            rows = np.flatnonzero(~np.isnan(ff))
+            rows = rows[np.lexsort((-ff[rows].astype(np.float64), q_no[rows]))]  # q_no ascending = q_id descending
+            cols = {c: df[c].to_numpy()[rows] for c in ("q_id", "id")}
+            cols["score"] = ff[rows].astype(df.dtypes["score"], copy=False)
+            cols["query"] = df["query"].to_numpy()[rows]
+            present = np.flatnonzero(np.bincount(q_no[rows], minlength=n_q))
+            renumber = np.full(n_q, -1, dtype=np.int64)
+            renumber[present] = np.arange(present.shape[0])
+            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+            return Ranking._assemble(cols, "fast-forward", renumber[q_no[rows]], [q_order[i] for i in present])
+        # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
+        # work (the reference raises from its first batch; either way no partial result is returned)
+        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode) if early_stopping is None else None
         if early_stopping is None and (batch_size is None or batch_size >= n_q) and len(df) > 0:
             # the common case without the intermediate frames: CSR in, scores out
             perm, pair_off = _grouped_by_query(q_no, n_q)
@@ -307,7 +334,7 @@ class Index(abc.ABC):
             result["score"] = dense.astype(df.dtypes["score"], copy=False)
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
             return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
-        work = df.assign(q_no=q_no, _ord=ordinals)
+        work = df.assign(q_no=q_no) if ordinals is None else df.assign(q_no=q_no, _ord=ordinals)
 
         def score(part: pd.DataFrame) -> pd.DataFrame:
             if early_stopping is None:

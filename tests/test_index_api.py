@@ -149,6 +149,31 @@ def test_early_stopping_known_answer():
         assert got == expected
 
 
+def test_early_stopping_looks_up_only_what_it_scores():
+    """As in the reference (get_indices runs per scored chunk, index/base.py:362-370), an id that is
+    never reached is never looked up: an unknown id below the stopping depth is harmless, one
+    inside a scored interval is an IndexError; batching gives the same result."""
+    idx = InMemoryIndex(LambdaEncoder(lambda q: np.array([10, 10])), mode=Mode.PASSAGE)
+    idx.add(np.stack([[1, 0], [1, 1]] * 10), psg_ids=[f"p{i}" for i in range(20)])
+    rows = [{"q_id": q, "query": q, "id": f"p{i}", "score": i} for i in range(20) for q in ("q1", "q2")]
+    # sparse scores 0..19: ranks 0..9 are p19..p10; the candidates with score < 10 are never reached
+    deep = [dict(r, id="unknown-" + r["id"]) if r["score"] < 10 else r for r in rows]
+    expected = Ranking(pd.DataFrame(
+        [{"q_id": q, "id": f"p{i}", "score": 20.0 if i % 2 else 10.0} for q in ("q1", "q2") for i in range(10, 20)]))
+    for batch_size in (None, 1):
+        got = idx(Ranking(pd.DataFrame(deep)), early_stopping=5, early_stopping_alpha=0.5, early_stopping_depths=(5, 10, 20),
+                  batch_size=batch_size)
+        assert got == expected
+        assert got._df["score"].is_monotonic_decreasing or len(got) == 2  # per-query order is checked below
+        for q in ("q1", "q2"):
+            assert got._df.loc[got._df["q_id"] == q, "score"].is_monotonic_decreasing
+    shallow = [dict(r, id="unknown") if (r["score"] == 15 and r["q_id"] == "q2") else r for r in rows]
+    with pytest.raises(IndexError, match="ID unknown not found in the index."):
+        idx(Ranking(pd.DataFrame(shallow)), early_stopping=5, early_stopping_alpha=0.5, early_stopping_depths=(5, 10, 20))
+    with pytest.raises(IndexError):  # without early stopping every id is needed
+        idx(Ranking(pd.DataFrame(deep)))
+
+
 def test_early_stopping_matches_reference_frames():
     z = np.load(GOLDEN / "early_stopping.npz")
     dim, seed, scale, n_psg = int(z["dim"]), int(z["seed"]), float(z["scale"]), int(z["n_psg"])

@@ -25,6 +25,7 @@ ap.add_argument("--k", type=int, default=1000)
 ap.add_argument("--cutoff", type=int, default=10)
 ap.add_argument("--alpha", type=float, default=0.2)
 ap.add_argument("--depths", default="50,200,1000")
+ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 d, seed = 768, 2024
 scale = float(1 / np.sqrt(d))
@@ -47,6 +48,15 @@ out["full_lookups"] = args.queries * args.k
 t0 = time.perf_counter()
 es = index(first, early_stopping=args.cutoff, early_stopping_alpha=args.alpha, early_stopping_depths=depths)
 out["early_stopping_s"] = time.perf_counter() - t0
+if "--profile" in sys.argv:
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    index(first, early_stopping=args.cutoff, early_stopping_alpha=args.alpha, early_stopping_depths=depths)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 out["early_stopping_lookups"] = int(len(es._df))
 # the top-`cutoff` of the interpolated ranking must not change (that is the point of the criterion)
 a = first.interpolate(full, args.alpha).cut(args.cutoff)
