@@ -487,3 +487,37 @@ def test_upload_rows_gathers_from_chunk_maps(monkeypatch, dtype):
     with pytest.raises(ValueError):
         idx.upload_rows([c.astype(np.float64) for c in chunks], want, 0)
     idx.close()
+
+
+LENGTHS = [0, 1, 2, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1000, 0, 4095, 4096, 4097, 5000, 8191, 8192]
+
+
+def test_per_query_order():
+    """The per-query order against the oracle: every power-of-two boundary up to 8192, empty
+    queries, heavy ties (ties keep first-stage order), +-0.0 equal, negative scores, infinities,
+    and a query longer than 8192."""
+    rng = np.random.default_rng(12)
+    pair_off = np.concatenate([[0], np.cumsum(LENGTHS)]).astype(np.int64)
+    n = int(pair_off[-1])
+    scores = rng.integers(-3, 4, size=n).astype(np.float32)          # seven distinct values: ties everywhere
+    smooth = rng.random(n) < 0.4
+    scores[smooth] = rng.standard_normal(int(smooth.sum())).astype(np.float32) * 5
+    zeros = np.flatnonzero(scores == 0)
+    scores[zeros[::2]] = -0.0
+    scores[rng.integers(0, n, 5)] = np.inf
+    scores[rng.integers(0, n, 5)] = -np.inf
+    seg_off = np.arange(n + 1, dtype=np.int64)
+    ff, _, order = native.aggregate(scores, seg_off, 2, pair_off=pair_off, sort=True)
+    assert np.array_equal(bits(ff), bits(scores))
+    assert np.array_equal(order.astype(np.int64), fo.order(scores, pair_off))
+    # with sparse scores the interpolated score is the key
+    sparse = rng.integers(0, 3, size=n).astype(np.float32)
+    _, interp, order = native.aggregate(scores, seg_off, 2, sparse, 0.5, pair_off=pair_off, sort=True)
+    finite = np.isfinite(interp)
+    assert finite.sum() >= n - 10
+    assert np.array_equal(order.astype(np.int64), fo.order(interp, pair_off))
+    # a long query between short ones
+    long_off = np.array([0, 3, 3 + 8193, 3 + 8193 + 100], dtype=np.int64)
+    long_scores = rng.integers(0, 50, size=int(long_off[-1])).astype(np.float32)
+    _, _, order = native.aggregate(long_scores, np.arange(long_off[-1] + 1, dtype=np.int64), 2, pair_off=long_off, sort=True)
+    assert np.array_equal(order.astype(np.int64), fo.order(long_scores, long_off))
