@@ -267,6 +267,30 @@ def test_sharded_scorer_single_rank_nccl():
     assert "sharded 1-rank ok" in out.stdout
 
 
+@pytest.mark.parametrize("world", [2])
+def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world):
+    """bench.py's multi-GPU leg (rows sharded by document, two plans alternating between a compute
+    and a communication stream, owner-side merge) with `world` ranks on this one GPU; the exchange
+    goes over gloo because RCCL refuses ranks that share a device.  Every rank's scores are checked
+    against the oracle inside bench.py (`parity_on_cpu_sample`)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + world), str(root / "bench.py"), "--gpus", str(world), "--dist-backend", "gloo",
+           "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "12",
+           "--cpu-seconds", "0.2", "--sort"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = next(ln for ln in out.stdout.splitlines() if ln.startswith("{"))
+    result = json.loads(line)
+    assert result["n_gpus"] == world and result["parity_on_cpu_sample"] == "bit-exact"
+    assert sum(result["roofline"]["gathered_rows_per_rank"]) == 90 * 700
+
+
 # ---- product-quantized rows (decode-then-dot and ADC) ------------------------------------------------
 from _cases import PQ_CASES, load_pq_case  # noqa: E402
 
