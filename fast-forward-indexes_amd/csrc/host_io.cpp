@@ -572,4 +572,86 @@ int ffx_run_write(const ffx_run* run, const char* path, const float* scores, con
   return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
 }
 
+// Ranking.save (ranking.py:348-366) for a frame that is already grouped by query: the q_id and id
+// columns arrive as two '\n'-joined buffers (n_queries names; n_pairs ids in frame order), pair_off
+// gives every query's rows.  Lines "q_id\tQ0\tid\trank\tscore\tname", rank = 1-based position inside
+// the query, score formatted like pandas' to_csv of a float32 column.  Formatted by threads.
+int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
+                 const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag) {
+  if (!path || !pair_off || n_queries < 0 || n_pairs < 0 || (n_pairs > 0 && (!id_blob || !scores || !q_blob)) || !tag)
+    return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (pair_off[0] != 0 || pair_off[n_queries] != n_pairs) return ffx_fail(FFX_BAD_ARG, "pair_off does not cover the rows");
+  auto split = [](const char* blob, int64_t bytes, int64_t n, std::vector<std::string_view>& out) -> bool {
+    out.clear();
+    if (n == 0) return bytes == 0;
+    out.reserve((size_t)n);
+    const char* p = blob;
+    const char* end = blob + bytes;
+    while ((int64_t)out.size() < n) {
+      const char* q = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+      if (!q) {
+        out.emplace_back(p, (size_t)(end - p));
+        p = end + 1;
+        break;
+      }
+      out.emplace_back(p, (size_t)(q - p));
+      p = q + 1;
+    }
+    return (int64_t)out.size() == n && p == end + 1;
+  };
+  std::vector<std::string_view> q_names, ids;
+  try {
+    if (!split(q_blob, q_bytes, n_queries, q_names) || !split(id_blob, id_bytes, n_pairs, ids))
+      return ffx_fail(FFX_BAD_ARG, "a buffer does not hold the announced number of strings");
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) return ffx_fail(FFX_BAD_ARG, "cannot create %s", path);
+  const std::string name = tag;
+  auto format = [&](int64_t q_lo, int64_t q_hi, std::string& out) {
+    out.clear();
+    for (int64_t q = q_lo; q < q_hi; ++q) {
+      for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
+        out.append(q_names[(size_t)q]).append("\tQ0\t").append(ids[(size_t)p]).push_back('\t');
+        out += std::to_string(p - pair_off[q] + 1);
+        out.push_back('\t');
+        append_float_repr(out, scores[p]);
+        out.push_back('\t');
+        out += name;
+        out.push_back('\n');
+      }
+    }
+  };
+  const int T = (int)std::min<int64_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<int64_t>(1, n_pairs >> 15));
+  std::vector<std::string> bufs((size_t)T);
+  bool ok = true;
+  try {
+    const int64_t avg = std::max<int64_t>(1, n_pairs / std::max<int64_t>(1, n_queries));
+    const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
+    for (int64_t q0 = 0; q0 < n_queries && ok; q0 += q_per_thread * T) {
+      std::vector<std::thread> pool;
+      int used = 0;
+      for (int t = 0; t < T; ++t) {
+        const int64_t lo = q0 + t * q_per_thread, hi = std::min(n_queries, lo + q_per_thread);
+        if (lo >= hi) break;
+        ++used;
+        if (t > 0) pool.emplace_back(format, lo, hi, std::ref(bufs[(size_t)t]));
+      }
+      format(q0, std::min(n_queries, q0 + q_per_thread), bufs[0]);
+      for (auto& th : pool) th.join();
+      for (int t = 0; t < used && ok; ++t)
+        ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
+    }
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
+  }
+  if (!ok) {
+    fclose(f);
+    return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+  }
+  return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+}
+
 }  // extern "C"

@@ -30,7 +30,7 @@ SYMBOLS = (
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_get",
-    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write",
+    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
 )
 
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
         "ffx_run_tag": ([vp, P(vp), P(i32)], C.c_int),
         "ffx_run_export": ([vp, i64, vp, vp, vp, P(i64)], C.c_int),
         "ffx_run_write": ([vp, C.c_char_p, vp, vp, i64, C.c_char_p], C.c_int),
+        "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
         "ffx_host_alloc": ([C.c_size_t, P(vp)], C.c_int),
         "ffx_host_free": ([vp], C.c_int),
@@ -537,6 +538,36 @@ class IdStrings:
         p, n = C.c_void_p(), C.c_int32(0)
         _check(lib().ffx_ids_get(self._h, int(ordinal), C.byref(p), C.byref(n)))
         return C.string_at(p.value, n.value).decode("utf-8")
+
+
+def _joined(strings) -> bytes | None:
+    """'\n'-joined UTF-8 of plain strings, or None when a CSV writer would have to quote one of them
+    (separator, quote or line-break characters inside, or an empty string)."""
+    items = strings.tolist() if isinstance(strings, np.ndarray) else list(strings)
+    try:
+        blob = "\n".join(items).encode("utf-8")
+    except TypeError:
+        return None
+    n = len(items)
+    if n == 0:
+        return b""
+    if blob.count(b"\n") != n - 1 or any(c in blob for c in (b"\t", b'"', b"\r", b"\0")):
+        return None
+    if blob.startswith(b"\n") or blob.endswith(b"\n") or b"\n\n" in blob:
+        return None
+    return blob
+
+
+def save_run(path, q_names, pair_off, ids, scores, tag: str) -> bool:
+    """``ffx_run_save``: write a run grouped by query; False when the strings need a real CSV writer."""
+    q_blob, id_blob = _joined(q_names), _joined(ids)
+    tag_b = str(tag).encode("utf-8")
+    if q_blob is None or id_blob is None or any(c in tag_b for c in (b"\t", b'"', b"\r", b"\n", b"\0")) or not tag_b:
+        return False
+    pair_off, scores = _arr(pair_off, np.int64), _arr(scores, np.float32)
+    _check(lib().ffx_run_save(str(path).encode(), q_blob, len(q_blob), len(pair_off) - 1, _ptr(pair_off), id_blob, len(id_blob),
+                              scores.shape[0], _ptr(scores), tag_b))
+    return True
 
 
 class RunFile:

@@ -320,12 +320,32 @@ class Ranking:
     # ---- I/O -----------------------------------------------------------------------------------
     def save(self, target: Path) -> None:
         """Write a TREC run file: ``q_id Q0 id rank score name`` (ranking.py:348-366)."""
+        target = Path(target)
+        if len(self._df) >= 4096 and self._df["score"].dtype == np.float32 and self._save_native(target):
+            return
         out = self._df[_KEY + ["score"]].copy()
         out["rank"] = _ranks_within_query(out)
         out["q0"] = "Q0"
         out["name"] = str(self.name)
         target.parent.mkdir(parents=True, exist_ok=True)
         out.to_csv(target, sep="\t", columns=["q_id", "q0", "id", "rank", "score", "name"], index=False, header=False)
+
+    def _save_native(self, target: Path) -> bool:
+        """The same bytes through libffx's threaded formatter (pandas' to_csv spends seconds on a
+        million rows); False when the library is not there or a field would need CSV quoting."""
+        try:
+            from fast_forward_amd import native
+
+            native.lib()
+        except (ImportError, OSError):
+            return False
+        q_no, q_order = self._numbering()
+        if (np.diff(q_no) < 0).any():  # rows of a query not adjacent: ranks would differ
+            return False
+        pair_off = np.zeros(len(q_order) + 1, dtype=np.int64)
+        np.cumsum(np.bincount(q_no, minlength=len(q_order)), out=pair_off[1:])
+        target.parent.mkdir(parents=True, exist_ok=True)
+        return native.save_run(target, q_order, pair_off, self._df["id"].to_numpy(), self._df["score"].to_numpy(), str(self.name))
 
     @classmethod
     def from_run(cls, run: Run, name: str | None = None, queries: Mapping[str, str] | None = None,

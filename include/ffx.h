@@ -222,6 +222,13 @@ int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pai
 int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
                   const char* tag);
 
+/* Ranking.save (ranking.py:348-366) of a frame grouped by query, without a parsed run: q_blob holds
+ * the n_queries query ids and id_blob the n_pairs candidate ids (frame order), each joined by '\n';
+ * pair_off[q] .. pair_off[q+1] are the rows of query q.  Scores are printed like pandas prints
+ * float32. */
+int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
+                 const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag);
+
 /* one-shot, host buffers in, host buffers out: the batch is cut into slices of whole queries
  * that alternate between two plans kept with the index, so uploads, scoring and downloads of
  * neighbouring slices overlap (results do not depend on the slicing; stats are summed over the

@@ -208,3 +208,34 @@ def test_integer_key_join_equals_the_pandas_merge(seed):
     both["score"] = both["score"] + both["score_other"]
     want = a._derived(both, is_sorted=False)
     assert total._df["id"].tolist() == want._df["id"].tolist() and total == want
+
+
+def test_save_of_a_large_ranking_is_byte_identical_to_pandas(tmp_path, monkeypatch):
+    """Rankings of >= 4096 float32 rows are written by libffx's threaded formatter: the same bytes
+    as DataFrame.to_csv (ranks, float formatting, query order), and anything a CSV writer would
+    have to quote falls back to pandas."""
+    rng = np.random.default_rng(7)
+    n_q, k = 37, 400
+    scores = rng.standard_normal(n_q * k).astype(np.float32) * rng.choice([1e-6, 1.0, 1e5, 1e17], size=n_q * k).astype(np.float32)
+    scores[:5] = [0.0, -0.0, 1.0, 16777216.0, 1e-5]
+    df = pd.DataFrame({"q_id": np.repeat([f"q{i:03d}" for i in rng.permutation(n_q)], k),
+                       "id": [f"doc-{i}" for i in rng.permutation(n_q * k)], "score": scores})
+    r = Ranking(df, name="run-ß")
+    fast, slow = tmp_path / "a" / "fast.tsv", tmp_path / "slow.tsv"
+    r.save(fast)
+    monkeypatch.setattr(Ranking, "_save_native", lambda self, target: False)
+    r.save(slow)
+    assert fast.read_bytes() == slow.read_bytes()
+    assert Ranking.from_file(fast) == Ranking.from_file(slow)
+    monkeypatch.undo()
+    # ids that need quoting, an unnamed ranking ("None"), float64 scores: pandas writes them, same result either way
+    odd = df.copy()
+    odd.loc[17, "id"] = "has\ttab"
+    odd.loc[99, "id"] = 'has"quote'
+    for ranking in (Ranking(odd, name="x"), Ranking(df), Ranking(df, name="f64", dtype=np.dtype(np.float64))):
+        a, b = tmp_path / "n.tsv", tmp_path / "p.tsv"
+        ranking.save(a)
+        monkeypatch.setattr(Ranking, "_save_native", lambda self, target: False)
+        ranking.save(b)
+        monkeypatch.undo()
+        assert a.read_bytes() == b.read_bytes()
