@@ -57,6 +57,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work to measure for the baseline")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per gather_dot launch from a rocprofv3 --pmc pass")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU leg even with one rank (rehearsal)")
+    ap.add_argument("--sharding", default="rows", choices=["rows", "queries"],
+                    help="multi-GPU layout: rows = index row-sharded by document + all-to-all of scores (north star); "
+                         "queries = every rank holds the whole index and scores its block of the queries, no exchange "
+                         "(the zero-communication comparison point when the index fits one GPU)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse N ranks on ONE GPU (exchange staged through the host; RCCL needs one GPU per rank)")
     return ap.parse_args()
@@ -186,6 +190,8 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
     else:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.sharding == "queries":
+        return bench_replicas(args, rank, world, local_rank, dist, torch)
     scale = float(1.0 / np.sqrt(args.dim))
     doc_off = doc_layout(args.rows, args.layout, args.seed)
     n_docs = doc_off.shape[0] - 1
@@ -277,6 +283,87 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
         if parity == "MISMATCH":
             dist.destroy_process_group()
             sys.exit("sharded GPU scores disagree with the CPU oracle on the sampled queries")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def bench_replicas(args, rank: int, world: int, local_rank: int, dist, torch):
+    """--sharding queries: the whole index on every GPU, queries split into `world` contiguous blocks,
+    no data-path collective.  Same workload and same `value` definition as the row-sharded leg."""
+    from fast_forward_amd.sharded import query_partition
+
+    scale = float(1.0 / np.sqrt(args.dim))
+    doc_off = doc_layout(args.rows, args.layout, args.seed)
+    n_docs = doc_off.shape[0] - 1
+    store = np.float16 if args.store == "f16" else np.float32
+    index = native.DeviceIndex(args.rows, args.dim, device=local_rank, dtype=store)
+    index.fill_synthetic(args.seed, scale, 0, args.rows)
+    index.set_doc_rows(doc_off, np.arange(args.rows, dtype=np.int32))
+    index.set_psg_rows(np.arange(args.rows, dtype=np.int32))
+    bounds = query_partition(args.queries, world)
+    q_lo, q_hi = int(bounds[rank]), int(bounds[rank + 1])
+    ids, sparse = candidates(n_docs, q_hi - q_lo, args.k, args.seed, q_first=q_lo)
+    pair_off = np.arange(q_hi - q_lo + 1, dtype=np.int64) * args.k
+    queries = synth.rows(args.seed + 3, scale, q_lo, q_hi - q_lo, args.dim)
+    plan = native.Plan(index)
+    plan.set_queries(queries)
+    plan.set_pairs(pair_off, ids, sparse, MODE_NO[args.mode])
+    exact = args.sum == "exact"
+    for _ in range(args.warmup):
+        plan.run(args.alpha, exact_sum=exact, sort=args.sort)
+    plan.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(args.alpha, exact_sum=exact, sort=args.sort)
+    plan.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    coll_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    ms_per_step = float(elapsed.item()) * 1e3 / args.steps
+    st = plan.stats()
+    mine = torch.tensor([st["ms_gather_dot"], float(st["n_rows"])], dtype=torch.float64, device=coll_dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    per_rank = [(float(t[0]), int(t[1])) for t in allr]
+    if rank == 0:
+        row_bytes = args.dim * np.dtype(store).itemsize + 4
+        slowest = max(per_rank, key=lambda t: t[0])
+        achieved = slowest[1] * row_bytes / (slowest[0] * 1e-3) / 1e9
+        result = {
+            "metric": "re-ranked queries/sec at k=5000, 768-d fp32; achieved HBM GB/s vs peak",
+            "value": args.queries / (ms_per_step * 1e-3), "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} index replicated on {world} GPUs, "
+                            f"{args.queries} queries split into {world} blocks, k={args.k}, Mode.{args.mode}, alpha={args.alpha}, "
+                            f"sum={args.sum}; no exchange (comparison point of the row-sharded layout)",
+                "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
+                "layout": args.layout, "sum": args.sum, "pairs": args.queries * args.k,
+                "sharding": f"queries: {world} replicas, contiguous query blocks",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']}), slowest rank of the last step",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms_per_rank": [t[0] for t in per_rank], "gathered_rows_per_rank": [t[1] for t in per_rank],
+            },
+        }
+        if args.cpu_sample_queries > 0:
+            args.cpu_sample_queries = min(args.cpu_sample_queries, q_hi - q_lo)
+            base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale)
+            _, interp, _ = plan.fetch(interp=True)
+            n_s = s_ids.shape[0]
+            ok = np.array_equal(interp[:n_s].view(np.uint32), s_interp.view(np.uint32)) if exact else bool(np.abs(interp[:n_s] - s_interp).max() <= 1e-4)
+            result["cpu_baseline"] = base
+            result["parity_on_cpu_sample"] = ("bit-exact" if exact else "within 1e-4") if ok else "MISMATCH"
+        print(json.dumps(result))
+        if result.get("parity_on_cpu_sample") == "MISMATCH":
+            dist.destroy_process_group()
+            sys.exit("GPU scores disagree with the CPU oracle on the sampled queries")
     dist.barrier()
     dist.destroy_process_group()
 

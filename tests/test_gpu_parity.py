@@ -267,8 +267,8 @@ def test_sharded_scorer_single_rank_nccl():
     assert "sharded 1-rank ok" in out.stdout
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world):
+@pytest.mark.parametrize("world,sharding", [(2, "rows"), (2, "queries")])
+def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding):
     """bench.py's multi-GPU leg (rows sharded by document, two plans alternating between a compute
     and a communication stream, owner-side merge) with `world` ranks on this one GPU; the exchange
     goes over gloo because RCCL refuses ranks that share a device.  Every rank's scores are checked
@@ -280,9 +280,9 @@ def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world):
 
     root = Path(__file__).resolve().parent.parent
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + world), str(root / "bench.py"), "--gpus", str(world), "--dist-backend", "gloo",
+           "--master-port", str(29700 + world + (10 if sharding == "queries" else 0)), str(root / "bench.py"), "--gpus", str(world), "--dist-backend", "gloo",
            "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "12",
-           "--cpu-seconds", "0.2", "--sort"]
+           "--cpu-seconds", "0.2", "--sort", "--sharding", sharding]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = next(ln for ln in out.stdout.splitlines() if ln.startswith("{"))
