@@ -168,7 +168,43 @@ struct ffx_plan {
   int32_t variant = 0;
   int32_t order_base = 0;  // added to the positions the per-query order is made of (slices of a larger batch)
   std::vector<int64_t> host_pair_off;
+  // Small batches (a service scoring one query at a time) are latency-bound on the copies: a
+  // copy between pageable memory and the device blocks the caller each time, so inputs and
+  // outputs of up to kStageBytes travel through this page-locked block and only one wait remains.
+  static constexpr size_t kStageBytes = 1 << 20;
+  char* hstage = nullptr;
+  size_t hstage_used = 0;
+  // room for `bytes` more in the staging block (nullptr: too large, or no page-locked memory)
+  char* stage(size_t bytes) {
+    if (!hstage) {
+      if (hstage_failed || hipHostMalloc(reinterpret_cast<void**>(&hstage), kStageBytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        hstage = nullptr;
+        hstage_failed = true;
+        return nullptr;
+      }
+    }
+    const size_t at = (hstage_used + 63) & ~size_t(63);
+    if (at + bytes > kStageBytes) return nullptr;
+    hstage_used = at + bytes;
+    return hstage + at;
+  }
+  bool hstage_failed = false;
 };
+
+namespace {
+// host -> device on the plan's stream; small sources go through the page-locked block (the
+// caller's buffer is free again on return either way)
+int plan_h2d(ffx_plan* pl, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return FFX_OK;
+  if (char* st = bytes <= ffx_plan::kStageBytes / 4 ? pl->stage(bytes) : nullptr) {
+    memcpy(st, src, bytes);
+    src = st;
+  }
+  FFX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pl->stream));
+  return FFX_OK;
+}
+}  // namespace
 
 // --------------------------------------------------------------------------------------------
 extern "C" {
@@ -558,6 +594,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
   for (auto& e : pl->ev)
     if (e) (void)hipEventDestroy(e);
   if (pl->own_stream) (void)hipStreamDestroy(pl->own_stream);
+  if (pl->hstage) (void)hipHostFree(pl->hstage);
   delete pl;
   return FFX_OK;
 }
@@ -576,7 +613,8 @@ int ffx_plan_set_queries(ffx_plan* pl, const float* host_queries, int64_t n_quer
   FFX_HIP(hipSetDevice(pl->idx->device));
   const size_t bytes = (size_t)n_queries * pl->idx->qdim * sizeof(float);
   FFX_TRY(pl->queries.ensure(std::max<size_t>(bytes, 16)));
-  if (bytes) FFX_HIP(hipMemcpyAsync(pl->queries.p, host_queries, bytes, hipMemcpyHostToDevice, pl->stream));
+  pl->hstage_used = 0;
+  FFX_TRY(plan_h2d(pl, pl->queries.p, host_queries, bytes));
   FFX_HIP(hipStreamSynchronize(pl->stream));
   pl->n_queries_set = (int)n_queries;
   pl->ran = false;
@@ -636,19 +674,28 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
     FFX_TRY(pl->sparse.ensure(pb * sizeof(float)));
     FFX_TRY(pl->interp.ensure(pb * sizeof(float)));
   }
-  FFX_HIP(hipMemcpyAsync(pl->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice, pl->stream));
+  pl->hstage_used = 0;
+  FFX_TRY(plan_h2d(pl, pl->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t)));
   if (P > 0) {
-    FFX_HIP(hipMemcpyAsync(pl->pair_ids.p, pair_ids, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, pl->stream));
-    if (sparse) FFX_HIP(hipMemcpyAsync(pl->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice, pl->stream));
+    FFX_TRY(plan_h2d(pl, pl->pair_ids.p, pair_ids, (size_t)P * sizeof(int32_t)));
+    if (sparse) FFX_TRY(plan_h2d(pl, pl->sparse.p, sparse, (size_t)P * sizeof(float)));
   }
   // validate ordinals and size the row list on the device (get_indices, index/util.py:29-41)
   FFX_HIP(hipMemsetAsync(pl->flags.p, 0xFF, sizeof(unsigned long long), pl->stream));
   FFX_TRY(launch_count_scan(pl));
   unsigned long long bad = ~0ull;
   int32_t total = 0;
-  FFX_HIP(hipMemcpyAsync(&bad, pl->flags.p, sizeof bad, hipMemcpyDeviceToHost, pl->stream));
-  FFX_HIP(hipMemcpyAsync(&total, pl->seg_off.as<int32_t>() + P, sizeof total, hipMemcpyDeviceToHost, pl->stream));
-  FFX_HIP(hipStreamSynchronize(pl->stream));
+  if (char* back = pl->stage(16)) {  // both read-backs land in page-locked memory: one wait, no blocking copies
+    FFX_HIP(hipMemcpyAsync(back, pl->flags.p, sizeof bad, hipMemcpyDeviceToHost, pl->stream));
+    FFX_HIP(hipMemcpyAsync(back + 8, pl->seg_off.as<int32_t>() + P, sizeof total, hipMemcpyDeviceToHost, pl->stream));
+    FFX_HIP(hipStreamSynchronize(pl->stream));
+    memcpy(&bad, back, sizeof bad);
+    memcpy(&total, back + 8, sizeof total);
+  } else {
+    FFX_HIP(hipMemcpyAsync(&bad, pl->flags.p, sizeof bad, hipMemcpyDeviceToHost, pl->stream));
+    FFX_HIP(hipMemcpyAsync(&total, pl->seg_off.as<int32_t>() + P, sizeof total, hipMemcpyDeviceToHost, pl->stream));
+    FFX_HIP(hipStreamSynchronize(pl->stream));
+  }
   if (bad != ~0ull) {
     if (bad_pair) *bad_pair = (int64_t)bad;
     return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad);
@@ -968,6 +1015,22 @@ int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_
   if (out_interp && !pl->last_interp) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
   if (out_order && !pl->ran_sort) return fail(FFX_BAD_ARG, "the last run did not request FFX_FLAG_SORT");
   if (P > 0) {
+    pl->hstage_used = 0;
+    const size_t each = P * sizeof(float);
+    char* back = 3 * (each + 64) <= ffx_plan::kStageBytes ? pl->stage(3 * (each + 64)) : nullptr;
+    if (back) {  // small result: three copies into page-locked memory, one wait, then hand the bytes over
+      char* b_ff = back;
+      char* b_in = back + ((each + 63) & ~size_t(63));
+      char* b_or = b_in + ((each + 63) & ~size_t(63));
+      if (out_ff) FFX_HIP(hipMemcpyAsync(b_ff, pl->ff.p, each, hipMemcpyDeviceToHost, pl->stream));
+      if (out_interp) FFX_HIP(hipMemcpyAsync(b_in, pl->interp.p, each, hipMemcpyDeviceToHost, pl->stream));
+      if (out_order) FFX_HIP(hipMemcpyAsync(b_or, pl->order.p, each, hipMemcpyDeviceToHost, pl->stream));
+      FFX_HIP(hipStreamSynchronize(pl->stream));
+      if (out_ff) memcpy(out_ff, b_ff, each);
+      if (out_interp) memcpy(out_interp, b_in, each);
+      if (out_order) memcpy(out_order, b_or, each);
+      return FFX_OK;
+    }
     if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff, pl->ff.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));
     if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp, pl->interp.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));
     if (out_order) FFX_HIP(hipMemcpyAsync(out_order, pl->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, pl->stream));
