@@ -314,13 +314,24 @@ class Index(abc.ABC):
         # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
         # work (the reference raises from its first batch; either way no partial result is returned)
         ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode) if early_stopping is None else None
-        if early_stopping is None and (batch_size is None or batch_size >= n_q) and len(df) > 0:
+        if early_stopping is None and len(df) > 0 and (batch_size is None or batch_size >= n_q or _grouped_by_query(q_no, n_q)[0] is None):
             # the common case without the intermediate frames: CSR in, scores out
             perm, pair_off = _grouped_by_query(q_no, n_q)
             if perm is None:
                 # rows of a query are adjacent and the queries already stand in their final order
                 # (a Ranking is sorted by q_id), so the device's per-query order is the whole sort
-                dense, _, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sort=True)
+                if batch_size is None or batch_size >= n_q:
+                    dense, _, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sort=True)
+                else:
+                    # `batch_size` queries per device call (bounds the workspace, base.py:445-459)
+                    dense, order = np.empty(len(df), dtype=np.float32), np.empty(len(df), dtype=np.int64)
+                    for qa in range(0, n_q, batch_size):
+                        qb = min(n_q, qa + batch_size)
+                        pa, pb = int(pair_off[qa]), int(pair_off[qb])
+                        if pb > pa:
+                            part, _, part_order = self._score_pairs(query_vectors[qa:qb], pair_off[qa:qb + 1] - pa, ordinals[pa:pb],
+                                                                    self.mode, sort=True)
+                            dense[pa:pb], order[pa:pb] = part, part_order.astype(np.int64) + pa
                 cols = {c: df[c].to_numpy()[order] for c in ("q_id", "id")}
                 cols["score"] = dense[order].astype(df.dtypes["score"], copy=False)
                 cols["query"] = df["query"].to_numpy()[order]

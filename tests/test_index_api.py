@@ -103,8 +103,12 @@ def test_batch_size_invariance():
          "q5": {"d0": 14, "d1": 7, "d2": 0, "d3": 3}},
         queries={f"q{n}": f"query {n}" for n in range(1, 6)})
     expected = idx(r)
-    for bs in (1, 2, 5, 10):  # 1 and 5 divide Q: the reference raises there (base.py:455); here they work
-        assert idx(r, batch_size=bs) == expected
+    for bs in (1, 2, 3, 5, 10):  # 1 and 5 divide Q: the reference raises there (base.py:455); here they work
+        got = idx(r, batch_size=bs)
+        assert got == expected
+        # not only the same triples: the same frame, row for row (order, dtypes, query column, numbering)
+        pd.testing.assert_frame_equal(got._df, expected._df)
+        assert got._numbering()[1] == expected._numbering()[1] and np.array_equal(got._numbering()[0], expected._numbering()[0])
 
 
 def test_add_retrieve_while_growing():
