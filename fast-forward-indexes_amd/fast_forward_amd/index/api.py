@@ -297,10 +297,20 @@ class Index(abc.ABC):
         q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
-        if early_stopping is not None and (batch_size is None or batch_size >= n_q) and len(df) > 0:
+        grouped, block_off = _grouped_by_query(q_no, n_q) if len(df) > 0 else (0, None)
+        if early_stopping is not None and len(df) > 0 and (batch_size is None or batch_size >= n_q or grouped is None):
             # arrays in, arrays out: only the candidates that get scored are looked up and kept
-            ff = self._early_stopping_scores(df["id"].to_numpy(), q_no, df["score"].to_numpy(), query_vectors, early_stopping,
-                                             early_stopping_alpha, early_stopping_depths)
+            ids_col, sparse_col = df["id"].to_numpy(), df["score"].to_numpy()
+            if batch_size is None or batch_size >= n_q:
+                ff = self._early_stopping_scores(ids_col, q_no, sparse_col, query_vectors, early_stopping, early_stopping_alpha,
+                                                 early_stopping_depths)
+            else:  # `batch_size` queries at a time
+                ff = np.full(len(df), np.nan, dtype=np.float32)
+                for qa in range(0, n_q, batch_size):
+                    pa, pb = int(block_off[qa]), int(block_off[min(n_q, qa + batch_size)])
+                    if pb > pa:
+                        ff[pa:pb] = self._early_stopping_scores(ids_col[pa:pb], q_no[pa:pb], sparse_col[pa:pb], query_vectors,
+                                                                early_stopping, early_stopping_alpha, early_stopping_depths)
             rows = np.flatnonzero(~np.isnan(ff))
             rows = rows[np.lexsort((-ff[rows].astype(np.float64), q_no[rows]))]  # q_no ascending = q_id descending
             cols = {c: df[c].to_numpy()[rows] for c in ("q_id", "id")}
