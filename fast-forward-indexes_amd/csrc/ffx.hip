@@ -1297,8 +1297,17 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
   if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
   if (out_order && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "out_order needs FFX_FLAG_SORT");
-  // slices of about 4M pairs (a ~2 ms device pass at 768-d fp32), cut at query boundaries
-  int64_t per_slice = 4 << 20;
+  // slices cut at query boundaries: ~2M pairs (a ~1 ms device pass at 768-d fp32) when the caller's
+  // buffers are page-locked and the copies truly overlap, ~6M when they are pageable and every copy
+  // blocks the caller for its duration (measured: tools/regions.py --only-ii)
+  int64_t per_slice = 6 << 20;
+  {
+    hipPointerAttribute_t attr;
+    if (pair_ids && hipPointerGetAttributes(&attr, pair_ids) == hipSuccess && attr.type == hipMemoryTypeHost)
+      per_slice = 2 << 20;
+    else
+      (void)hipGetLastError();  // an ordinary pointer is "invalid value" to the runtime: not an error here
+  }
   if (const char* e = getenv("FFX_SCORE_SLICE_PAIRS")) per_slice = std::max<int64_t>(1, atoll(e));
   std::vector<int64_t> cut{0};
   for (int64_t q = 1; q < n_queries; ++q)
