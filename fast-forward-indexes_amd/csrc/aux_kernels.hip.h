@@ -201,4 +201,43 @@ iota_kernel(int32_t* __restrict__ dst, int64_t n, int32_t base) {
   if (i < n) dst[i] = base + (int32_t)i;
 }
 
+// ---- long rows as several short ones --------------------------------------------------------
+// NumPy's pairwise sum of a row of d = S*b elements (S a power of two, b one of the row lengths the
+// gather_dot kernels are specialised for) is the balanced pairwise sum of the S sums of its
+// b-element segments.  So a row list over d-element rows becomes a list over the S*N "virtual"
+// rows of b elements that the same memory holds (row r, segment s = virtual row r*S+s; likewise
+// for the queries), the specialised kernel scores those, and the S partial sums are combined.
+// Virtual rows are laid out in blocks of B rows per segment, so that a wave's tile has one segment
+// (its query slice stays in registers); the tail of the last block repeats the last row.
+__global__ void __launch_bounds__(256)
+segment_desc_kernel(const int2* __restrict__ desc, int n_rows, int S, int B, int2* __restrict__ vdesc, long n_virtual) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_virtual) return;
+  const long t = p / ((long)S * B);
+  const int s = (int)((p / B) % S), i = (int)(p % B);
+  long r = t * B + i;
+  if (r > n_rows - 1) r = n_rows - 1;
+  const int2 d = desc[r];
+  vdesc[p] = make_int2(d.x * S + s, d.y * S + s);
+}
+
+__global__ void __launch_bounds__(256)
+combine_segments_kernel(const float* __restrict__ rs_v, int n_rows, int S, int B, float* __restrict__ rs) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  const long t = r / B;
+  const int i = (int)(r % B);
+  float v[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) v[s] = s < S ? rs_v[(t * S + s) * B + i] : 0.f;
+#pragma unroll
+  for (int st = 1; st < 8; st *= 2) {
+    if (st < S) {
+#pragma unroll
+      for (int j = 0; j + st < 8; j += 2 * st) v[j] = __fadd_rn(v[j], v[j + st]);
+    }
+  }
+  rs[r] = v[0];
+}
+
 }  // namespace ffx

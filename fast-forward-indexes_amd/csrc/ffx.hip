@@ -156,7 +156,10 @@ struct ffx_plan {
   // inputs
   DevBuf queries, pair_off, pair_ids, sparse;
   // workspace
-  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags, lut;
+  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags, lut, vdesc, rs_v;
+  // set while a long row is scored as S short ones (launch_gather_dot_t): the row length, row
+  // count and row list the kernels are to see
+  int ov_dim = 0, ov_rows = 0;
   // outputs
   DevBuf ff, interp, order;
   int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
@@ -588,7 +591,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
   if (pl->idx) (void)hipSetDevice(pl->idx->device);
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
-                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut,
+                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v,
                     &pl->flags, &pl->ff, &pl->interp, &pl->order})
     b->release();
   for (auto& e : pl->ev)
@@ -716,12 +719,42 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
 template <typename T>
 static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   const ffx_index* ix = pl->idx;
-  const int d = ix->dim;
-  const int R = (int)pl->n_rows;
+  hipStream_t st = pl->stream;
+  if (!pl->ov_dim) {
+    // d = S * b with S in {2, 4, 8} and b a specialised row length (1536 = 2*768, 2048 = 2*1024,
+    // 3072 = 4*768, 4096 = 4*1024, ...): score the S*N b-element rows the same memory holds and
+    // combine the S partial sums pairwise -- NumPy's own recursion (aux_kernels.hip.h)
+    static const int bases[] = {1024, 768, 512, 384, 256, 128, 64};
+    int base = 0, S = 0;
+    bool own_kernel = false;
+    for (int b : bases) own_kernel = own_kernel || ix->dim == b;
+    for (int b : bases)
+      for (int m = 2; m <= 8 && !base && !own_kernel; m *= 2)
+        if (ix->dim == b * m) base = b, S = m;
+    constexpr int B = 16;
+    const long n_virtual = ((pl->n_rows + B - 1) / B) * B * (long)S;
+    if (base && n_virtual <= INT32_MAX && ix->capacity * S <= INT32_MAX && (long)pl->n_queries * S <= INT32_MAX) {
+      FFX_TRY(pl->vdesc.ensure((size_t)n_virtual * sizeof(int2)));
+      FFX_TRY(pl->rs_v.ensure((size_t)n_virtual * sizeof(float)));
+      ffx::segment_desc_kernel<<<blocks_for(n_virtual, 256), 256, 0, st>>>(pl->desc.as<int2>(), (int)pl->n_rows, S, B,
+                                                                          pl->vdesc.as<int2>(), n_virtual);
+      FFX_HIP(hipGetLastError());
+      pl->ov_dim = base;
+      pl->ov_rows = (int)n_virtual;
+      const int rc = launch_gather_dot_t<T>(pl, exact, pl->rs_v.as<float>());
+      pl->ov_dim = pl->ov_rows = 0;
+      FFX_TRY(rc);
+      ffx::combine_segments_kernel<<<blocks_for(pl->n_rows, 256), 256, 0, st>>>(pl->rs_v.as<float>(), (int)pl->n_rows, S, B, rs);
+      FFX_HIP(hipGetLastError());
+      pl->variant += 10000 * S;  // e.g. 20111: two 768-element segments through variant 111
+      return FFX_OK;
+    }
+  }
+  const int d = pl->ov_dim ? pl->ov_dim : ix->dim;
+  const int R = pl->ov_dim ? pl->ov_rows : (int)pl->n_rows;
   const T* V = static_cast<const T*>(ix->vectors);
   const float* Q = pl->queries.as<float>();
-  const int2* desc = pl->desc.as<int2>();
-  hipStream_t st = pl->stream;
+  const int2* desc = pl->ov_dim ? pl->vdesc.as<int2>() : pl->desc.as<int2>();
   constexpr int HALF = sizeof(T) == 2 ? 1000 : 0;
   // 4 rows in flight per wave for both row types (8 is slower: tools/kernel_ab.py,
   // profiles/r01/kernel_ab_f16.log); half rows run best with 16-row tiles, float rows with 8

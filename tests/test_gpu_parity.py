@@ -180,7 +180,8 @@ def test_many_passages_per_document():
 
 
 @pytest.mark.parametrize("store", [np.float32, np.float16])
-@pytest.mark.parametrize("d", [64, 128, 256, 384, 512, 768, 1024, 8, 24, 1000, 2048, 4100])
+@pytest.mark.parametrize("d", [64, 128, 256, 384, 512, 768, 1024, 8, 24, 1000, 4100,
+                               1536, 2048, 3072, 4096, 6144, 8192])  # second line: S x (768 | 1024), scored as S short rows
 def test_every_kernel_variant_exact(d, store):
     """Each gather_dot instantiation (and the generic kernel), float32 and float16 rows, against
     the oracle and against NumPy itself, bit for bit."""
@@ -197,7 +198,10 @@ def test_every_kernel_variant_exact(d, store):
     ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=True)
     want, _ = fo.score(vectors, np.arange(n + 1), np.arange(n), np.arange(n), queries, pair_off, pair_ids, 2)
     assert np.array_equal(bits(ff), bits(want)), f"d={d} variant {st['kernel_variant']}"
-    assert (st["kernel_variant"] >= 1000) == (store == np.float16)
+    assert (st["kernel_variant"] % 10000 >= 1000) == (store == np.float16)
+    if d in (1536, 2048, 3072, 4096, 6144, 8192):  # S * 10000 + the variant of the short-row kernel
+        base = 768 if d % 768 == 0 else 1024
+        assert st["kernel_variant"] // 10000 == d // base and st["kernel_variant"] % 1000 == (111 if base == 768 else 112)
     ref = np.sum(queries[np.repeat(np.arange(nq), k)] * vectors[pair_ids], axis=1)  # NumPy itself
     assert ref.dtype == np.float32
     assert np.array_equal(bits(ff), bits(ref))
