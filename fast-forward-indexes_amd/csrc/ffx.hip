@@ -115,6 +115,19 @@ void numpy_leaf_plan(int start, int n, std::vector<int>& bounds) {
   numpy_leaf_plan(start + n2, n - n2, bounds);
 }
 
+// The order in which NumPy's recursion adds the leaf sums, as a list of (a, b) steps
+// "sum[a] += sum[b]" over the in-order leaf indices; the total ends up in sum[0].
+int numpy_combine_plan(int n, int& next_leaf, std::vector<int>& steps) {
+  if (n <= 128) return next_leaf++;
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const int a = numpy_combine_plan(n2, next_leaf, steps);
+  const int b = numpy_combine_plan(n - n2, next_leaf, steps);
+  steps.push_back(a);
+  steps.push_back(b);
+  return a;
+}
+
 }  // namespace
 
 struct ffx_index {
@@ -156,7 +169,7 @@ struct ffx_plan {
   // inputs
   DevBuf queries, pair_off, pair_ids, sparse;
   // workspace
-  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags, lut, vdesc, rs_v;
+  DevBuf cnt, seg_off, desc, rs, scan_tmp, sort_tmp, iota, sorted_keys, leaf_start, flags, lut, vdesc, rs_v, combine_steps;
   // set while a long row is scored as S short ones (launch_gather_dot_t): the row length, row
   // count and row list the kernels are to see
   int ov_dim = 0, ov_rows = 0;
@@ -577,6 +590,15 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
   int rc = pl->leaf_start.ensure(bounds.size() * sizeof(int));
   if (rc == FFX_OK && hipMemcpy(pl->leaf_start.p, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(FFX_HIP_ERROR, "leaf plan upload failed");
+  if (rc == FFX_OK) {
+    std::vector<int> steps;
+    int next_leaf = 0;
+    numpy_combine_plan(idx->qdim, next_leaf, steps);
+    steps.push_back(0);  // never empty
+    rc = pl->combine_steps.ensure(steps.size() * sizeof(int));
+    if (rc == FFX_OK && hipMemcpy(pl->combine_steps.p, steps.data(), steps.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(FFX_HIP_ERROR, "combine plan upload failed");
+  }
   if (rc == FFX_OK) rc = pl->flags.ensure(64);
   if (rc != FFX_OK) {
     ffx_plan_destroy(pl);
@@ -591,7 +613,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
   if (pl->idx) (void)hipSetDevice(pl->idx->device);
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
-                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v,
+                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps,
                     &pl->flags, &pl->ff, &pl->interp, &pl->order})
     b->release();
   for (auto& e : pl->ev)
@@ -838,11 +860,24 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       case 128: FFX_MULTI(1, 16, 2, 64, 116); break;
       case 64: FFX_MULTI(1, 8, 4, 64, 117); break;
 #undef FFX_MULTI
-      default:
+      default: {
         if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
+        // any other row length: the row is staged in LDS (coalesced, independent loads) and the
+        // leaves are walked from there; rows too long for a wave's share of LDS use the plain form
+        const int dp = (d + 3) & ~3, lp = (pl->n_leaves + 3) & ~3;
+        const size_t per_wave = (size_t)(2 * dp + lp) * sizeof(float);
+        const int waves = (int)std::min<size_t>(4, (48 << 10) / per_wave);
+        if (waves >= 1 && !getenv("FFX_GENERIC_PLAIN")) {
+          const int rows_per_wave = 8;
+          ffx::gather_dot_exact_generic_staged_kernel<T><<<blocks_for(R, waves * rows_per_wave), 64 * waves, per_wave * waves, st>>>(
+              V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>(), dp, lp, rows_per_wave);
+          pl->variant = 198 + HALF;
+          break;
+        }
         ffx::gather_dot_exact_generic_kernel<T><<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
-            V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
+            V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>());
         pl->variant = 199 + HALF;
+      }
     }
   } else {
     switch (d) {
@@ -857,11 +892,8 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         if (d % 4 == 0) {
           ffx::gather_dot_fast_generic_kernel<T><<<blocks_for(R, 4), 256, 0, st>>>(V, Q, desc, rs, R, d);
           pl->variant = 298 + HALF;
-        } else {  // rows are not 8/16-byte aligned: the exact generic kernel is the only scalar path
-          if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large", d);
-          ffx::gather_dot_exact_generic_kernel<T><<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
-              V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
-          pl->variant = 199 + HALF;
+        } else {  // rows are not 8/16-byte aligned: the exact generic kernels are the only scalar path
+          return launch_gather_dot_t<T>(pl, true, rs);
         }
     }
   }
@@ -922,7 +954,7 @@ static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
     } else {
       if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
       ffx::gather_dot_pq_exact_generic_kernel<<<(unsigned)R, 64, (size_t)pl->n_leaves * sizeof(float), st>>>(
-          codes, M, cb, Ks, Ds, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves);
+          codes, M, cb, Ks, Ds, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>());
       pl->variant = 2199;
     }
   } else {

@@ -449,15 +449,8 @@ gather_dot_fast_generic_kernel(const T* __restrict__ vectors, const float* __res
 
 // ---- exact kernel, any d: leaves of NumPy's recursion handed to 8-lane groups -------------
 // leaf_start[0..n_leaves] are the leaf boundaries in in-order (host: numpy_leaf_plan).
-// One wave (= one block) per row; leaf sums go through LDS, lane 0 replays the recursion.
-__device__ inline float combine_leaves(int n, const float* leaf_sum, int& next) {
-  if (n <= 128) return leaf_sum[next++];
-  int n2 = n / 2;
-  n2 -= n2 % 8;
-  const float a = combine_leaves(n2, leaf_sum, next);
-  const float b = combine_leaves(n - n2, leaf_sum, next);
-  return __fadd_rn(a, b);
-}
+// One wave (= one block) per row; leaf sums go through LDS, lane 0 replays the recursion from
+// the host-made list of steps (ffx.hip: numpy_combine_plan).
 
 // row accessors for the generic kernels: element i of the (decoded) row as fp32
 template <typename T>
@@ -480,7 +473,7 @@ struct PqRow {
 template <typename Row>
 __device__ __forceinline__ void exact_generic_row(const Row row, const float* __restrict__ q, int d,
                                                   const int* __restrict__ leaf_start, int n_leaves,
-                                                  float* leaf_sum, float* out) {
+                                                  const int* __restrict__ combine_steps, float* leaf_sum, float* out) {
   const int lane = threadIdx.x;
   const int g = lane >> 3, j = lane & 7;
   for (int leaf = g; leaf < n_leaves; leaf += 8) {
@@ -504,8 +497,13 @@ __device__ __forceinline__ void exact_generic_row(const Row row, const float* __
   }
   __syncthreads();
   if (lane == 0) {
-    int next = 0;
-    *out = combine_leaves(d, leaf_sum, next);
+    // NumPy's recursion over the leaf sums, unrolled on the host into "sum[a] += sum[b]" steps
+    // (a recursive device function kept its frames in scratch memory and dominated the kernel)
+    for (int t = 0; t < n_leaves - 1; ++t) {
+      const int a = combine_steps[2 * t], b = combine_steps[2 * t + 1];
+      leaf_sum[a] = __fadd_rn(leaf_sum[a], leaf_sum[b]);
+    }
+    *out = leaf_sum[0];
   }
 }
 
@@ -513,13 +511,79 @@ template <typename T>
 __global__ void __launch_bounds__(64)
 gather_dot_exact_generic_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                                 const int2* __restrict__ desc, float* __restrict__ rs, int n_rows,
-                                int d, const int* __restrict__ leaf_start, int n_leaves) {
+                                int d, const int* __restrict__ leaf_start, int n_leaves,
+                                const int* __restrict__ combine_steps) {
   extern __shared__ float leaf_sum[];
   const long r = blockIdx.x;
   if (r >= n_rows) return;  // whole block leaves together
   const int2 de = desc[r];
   exact_generic_row(PlainRow<T>{vectors + (size_t)de.x * d}, queries + (size_t)de.y * d, d, leaf_start, n_leaves,
-                    leaf_sum, rs + r);
+                    combine_steps, leaf_sum, rs + r);
+}
+
+// The same arithmetic with the row staged in LDS first: a wave fetches its row (and, when the query
+// changes, the query) with independent, coalesced loads -- the loop above waits for memory once per
+// element of a leaf -- and then walks the leaves out of LDS.  Each wave owns its slice of LDS
+// (row | query | leaf sums) and a run of `rows_per_wave` consecutive rows of the work list; LDS
+// operations of one wave execute in order, so the wave barrier is only a scheduling fence.
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_dot_exact_generic_staged_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
+                                       const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int d,
+                                       const int* __restrict__ leaf_start, int n_leaves,
+                                       const int* __restrict__ combine_steps, int dp, int lp, int rows_per_wave) {
+  extern __shared__ float staged[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* row_s = staged + (size_t)w * (2 * dp + lp);
+  float* q_s = row_s + dp;
+  float* leaf_s = q_s + dp;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + w;
+  long r = wave * rows_per_wave;
+  const long r_end = r + rows_per_wave < (long)n_rows ? r + rows_per_wave : (long)n_rows;
+  const int g = lane >> 3, j = lane & 7;
+  int cur_q = -1;
+  for (; r < r_end; ++r) {
+    const int2 de = desc[r];
+    const int row = __builtin_amdgcn_readfirstlane(de.x), q = __builtin_amdgcn_readfirstlane(de.y);
+    const T* src = vectors + (size_t)row * d;
+    for (int i = lane; i < d; i += 64) row_s[i] = (float)src[i];
+    if (q != cur_q) {
+      const float* qs = queries + (size_t)q * d;
+      for (int i = lane; i < d; i += 64) q_s[i] = qs[i];
+      cur_q = q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int leaf = g; leaf < n_leaves; leaf += 8) {
+      const int s = leaf_start[leaf];
+      const int len = leaf_start[leaf + 1] - s;
+      float res;
+      if (len < 8) {
+        res = -0.0f;
+        for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q_s[s + i], row_s[s + i]));
+      } else {
+        const int lim = len - (len % 8);
+        float acc = __fmul_rn(q_s[s + j], row_s[s + j]);
+        for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q_s[s + i + j], row_s[s + i + j]));
+        acc = __fadd_rn(acc, xor1(acc));
+        acc = __fadd_rn(acc, xor2(acc));
+        acc = __fadd_rn(acc, xor4(acc));
+        res = acc;
+        for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q_s[s + i], row_s[s + i]));
+      }
+      if (j == 0) leaf_s[leaf] = res;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      // NumPy's recursion over the leaf sums, unrolled on the host into "sum[a] += sum[b]" steps
+      for (int t = 0; t < n_leaves - 1; ++t) {
+        const int a = combine_steps[2 * t], b = combine_steps[2 * t + 1];
+        leaf_s[a] = __fadd_rn(leaf_s[a], leaf_s[b]);
+      }
+      rs[r] = leaf_s[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ---- product-quantized rows --------------------------------------------------------------------
@@ -533,13 +597,14 @@ __global__ void __launch_bounds__(64)
 gather_dot_pq_exact_generic_kernel(const uint8_t* __restrict__ codes, int M, const float* __restrict__ codebook,
                                    int Ks, int Ds, const float* __restrict__ queries,
                                    const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int d,
-                                   const int* __restrict__ leaf_start, int n_leaves) {
+                                   const int* __restrict__ leaf_start, int n_leaves,
+                                   const int* __restrict__ combine_steps) {
   extern __shared__ float leaf_sum[];
   const long r = blockIdx.x;
   if (r >= n_rows) return;
   const int2 de = desc[r];
   exact_generic_row(PqRow{codes + (size_t)de.x * M, codebook, Ks, Ds}, queries + (size_t)de.y * d, d, leaf_start,
-                    n_leaves, leaf_sum, rs + r);
+                    n_leaves, combine_steps, leaf_sum, rs + r);
 }
 
 // d = 256*NCH with 8 leaves (768, 1024), M = 8*MW code bytes per row, Ds % 4 == 0: the float
