@@ -865,12 +865,15 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         // any other row length: the row is staged in LDS (coalesced, independent loads) and the
         // leaves are walked from there; rows too long for a wave's share of LDS use the plain form
         const int dp = (d + 3) & ~3, lp = (pl->n_leaves + 3) & ~3;
-        const size_t per_wave = (size_t)(2 * dp + lp) * sizeof(float);
+        int RP = 1;  // rows a wave takes per pass: 8 / (leaves per row rounded up to a power of two)
+        while (RP < 8 && pl->n_leaves * (RP * 2) <= 8) RP *= 2;
+        while (RP > 1 && (size_t)RP * (2 * dp + lp) * sizeof(float) > (12 << 10)) RP /= 2;  // keep 4 waves per block
+        const size_t per_wave = (size_t)RP * (2 * dp + lp) * sizeof(float);
         const int waves = (int)std::min<size_t>(4, (48 << 10) / per_wave);
         if (waves >= 1 && !getenv("FFX_GENERIC_PLAIN")) {
-          const int rows_per_wave = 8;
+          const int rows_per_wave = 8 * RP;
           ffx::gather_dot_exact_generic_staged_kernel<T><<<blocks_for(R, waves * rows_per_wave), 64 * waves, per_wave * waves, st>>>(
-              V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>(), dp, lp, rows_per_wave);
+              V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>(), dp, lp, rows_per_wave, RP);
           pl->variant = 198 + HALF;
           break;
         }

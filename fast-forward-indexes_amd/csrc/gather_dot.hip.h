@@ -521,66 +521,91 @@ gather_dot_exact_generic_kernel(const T* __restrict__ vectors, const float* __re
                     combine_steps, leaf_sum, rs + r);
 }
 
-// The same arithmetic with the row staged in LDS first: a wave fetches its row (and, when the query
+// The same arithmetic with the rows staged in LDS first: a wave fetches its rows (and, when it
 // changes, the query) with independent, coalesced loads -- the loop above waits for memory once per
-// element of a leaf -- and then walks the leaves out of LDS.  Each wave owns its slice of LDS
-// (row | query | leaf sums) and a run of `rows_per_wave` consecutive rows of the work list; LDS
-// operations of one wave execute in order, so the wave barrier is only a scheduling fence.
+// element of a leaf -- and then walks the leaves out of LDS.  Short rows have few leaves, so a
+// wave takes RP = 8 / LG rows per pass (LG = leaves per row rounded up to a power of two, at most
+// 8): 8-lane group g works on row g / LG, leaves g % LG, g % LG + LG, ...  Each wave owns its slice
+// of LDS (RP rows | RP queries | RP x leaf sums) and a run of `rows_per_wave` consecutive rows of
+// the work list; LDS operations of one wave execute in order, so the wave barrier is only a
+// scheduling fence.
 template <typename T>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_generic_staged_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                                        const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int d,
                                        const int* __restrict__ leaf_start, int n_leaves,
-                                       const int* __restrict__ combine_steps, int dp, int lp, int rows_per_wave) {
+                                       const int* __restrict__ combine_steps, int dp, int lp, int rows_per_wave, int RP) {
   extern __shared__ float staged[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* row_s = staged + (size_t)w * (2 * dp + lp);
-  float* q_s = row_s + dp;
-  float* leaf_s = q_s + dp;
+  float* row_s = staged + (size_t)w * RP * (2 * dp + lp);
+  float* q_s = row_s + RP * dp;
+  float* leaf_s = q_s + RP * dp;
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + w;
   long r = wave * rows_per_wave;
   const long r_end = r + rows_per_wave < (long)n_rows ? r + rows_per_wave : (long)n_rows;
+  const int LG = 8 / RP;
   const int g = lane >> 3, j = lane & 7;
-  int cur_q = -1;
-  for (; r < r_end; ++r) {
-    const int2 de = desc[r];
-    const int row = __builtin_amdgcn_readfirstlane(de.x), q = __builtin_amdgcn_readfirstlane(de.y);
-    const T* src = vectors + (size_t)row * d;
-    for (int i = lane; i < d; i += 64) row_s[i] = (float)src[i];
-    if (q != cur_q) {
-      const float* qs = queries + (size_t)q * d;
-      for (int i = lane; i < d; i += 64) q_s[i] = qs[i];
-      cur_q = q;
+  const int slot = g / LG, leaf0 = g % LG;
+  int cur_q = -1;  // the query held in slot 0 of q_s, if all rows of the last pass shared one
+  for (; r < r_end; r += RP) {
+    const int n_now = (int)(r_end - r < RP ? r_end - r : RP);
+    int q_first = 0;
+    bool same = true;
+    for (int t = 0; t < n_now; ++t) {  // wave-uniform
+      const int2 de = desc[r + t];
+      const int row = __builtin_amdgcn_readfirstlane(de.x), q = __builtin_amdgcn_readfirstlane(de.y);
+      if (t == 0) q_first = q;
+      same = same && q == q_first;
+      const T* src = vectors + (size_t)row * d;
+      for (int i = lane; i < d; i += 64) row_s[t * dp + i] = (float)src[i];
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int leaf = g; leaf < n_leaves; leaf += 8) {
-      const int s = leaf_start[leaf];
-      const int len = leaf_start[leaf + 1] - s;
-      float res;
-      if (len < 8) {
-        res = -0.0f;
-        for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q_s[s + i], row_s[s + i]));
-      } else {
-        const int lim = len - (len % 8);
-        float acc = __fmul_rn(q_s[s + j], row_s[s + j]);
-        for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(q_s[s + i + j], row_s[s + i + j]));
-        acc = __fadd_rn(acc, xor1(acc));
-        acc = __fadd_rn(acc, xor2(acc));
-        acc = __fadd_rn(acc, xor4(acc));
-        res = acc;
-        for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(q_s[s + i], row_s[s + i]));
+    if (same) {
+      if (q_first != cur_q) {
+        const float* qs = queries + (size_t)q_first * d;
+        for (int i = lane; i < d; i += 64) q_s[i] = qs[i];
+        cur_q = q_first;
       }
-      if (j == 0) leaf_s[leaf] = res;
+    } else {  // a query boundary inside the pass: every row brings its own query
+      for (int t = 0; t < n_now; ++t) {
+        const float* qs = queries + (size_t)__builtin_amdgcn_readfirstlane(desc[r + t].y) * d;
+        for (int i = lane; i < d; i += 64) q_s[t * dp + i] = qs[i];
+      }
+      cur_q = -1;
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
+    if (slot < n_now) {
+      const float* rowp = row_s + slot * dp;
+      const float* qp = q_s + (same ? 0 : slot * dp);
+      for (int leaf = leaf0; leaf < n_leaves; leaf += LG) {
+        const int s0 = leaf_start[leaf];
+        const int len = leaf_start[leaf + 1] - s0;
+        float res;
+        if (len < 8) {
+          res = -0.0f;
+          for (int i = 0; i < len; ++i) res = __fadd_rn(res, __fmul_rn(qp[s0 + i], rowp[s0 + i]));
+        } else {
+          const int lim = len - (len % 8);
+          float acc = __fmul_rn(qp[s0 + j], rowp[s0 + j]);
+          for (int i = 8; i < lim; i += 8) acc = __fadd_rn(acc, __fmul_rn(qp[s0 + i + j], rowp[s0 + i + j]));
+          acc = __fadd_rn(acc, xor1(acc));
+          acc = __fadd_rn(acc, xor2(acc));
+          acc = __fadd_rn(acc, xor4(acc));
+          res = acc;
+          for (int i = lim; i < len; ++i) res = __fadd_rn(res, __fmul_rn(qp[s0 + i], rowp[s0 + i]));
+        }
+        if (j == 0) leaf_s[slot * lp + leaf] = res;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (j == 0 && leaf0 == 0 && slot < n_now) {
       // NumPy's recursion over the leaf sums, unrolled on the host into "sum[a] += sum[b]" steps
+      float* sums = leaf_s + slot * lp;
       for (int t = 0; t < n_leaves - 1; ++t) {
         const int a = combine_steps[2 * t], b = combine_steps[2 * t + 1];
-        leaf_s[a] = __fadd_rn(leaf_s[a], leaf_s[b]);
+        sums[a] = __fadd_rn(sums[a], sums[b]);
       }
-      rs[r] = leaf_s[0];
+      rs[r + slot] = sums[0];
     }
     __builtin_amdgcn_wave_barrier();
   }
