@@ -159,6 +159,16 @@ def lib() -> C.CDLL:
     return L
 
 
+def _close_quietly(self) -> None:
+    """``__del__`` of the handle classes: at interpreter shutdown the module's globals may already be
+    gone (the process is ending and the driver frees everything anyway), which is not worth a
+    traceback on stderr."""
+    try:
+        self.close()
+    except Exception:
+        pass
+
+
 def _check(rc: int, bad_pair: int | None = None) -> None:
     if rc == OK:
         return
@@ -228,7 +238,7 @@ class DeviceIndex:
             lib().ffx_index_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    __del__ = _close_quietly
 
     def upload(self, rows: np.ndarray, row_offset: int) -> None:
         rows = _arr(rows, self.dtype)
@@ -294,7 +304,7 @@ class Plan:
             lib().ffx_plan_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    __del__ = _close_quietly
 
     def set_queries(self, queries: np.ndarray) -> None:
         queries = _arr(queries, np.float32)
@@ -363,7 +373,7 @@ class Merge:
             lib().ffx_merge_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    __del__ = _close_quietly
 
     def set(self, pair_off, recv_slot, sparse=None) -> None:
         pair_off, recv_slot = _arr(pair_off, np.int64), _arr(recv_slot, np.int32)
@@ -492,7 +502,7 @@ class IdStrings:
             lib().ffx_ids_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    __del__ = _close_quietly
 
     def __len__(self) -> int:
         n = C.c_int64(0)
@@ -592,7 +602,7 @@ class RunFile:
             lib().ffx_run_close(self._h)
             self._h = None
 
-    __del__ = close
+    __del__ = _close_quietly
 
     def query_ids(self) -> list[str]:
         out = []

@@ -290,11 +290,16 @@ class ShardedInMemoryIndex:
         uniq, inv = np.unique(ids, return_inverse=True)
         ord_u = np.fromiter((lookup.get(u, -1) for u in uniq), dtype=np.int64, count=len(uniq))
         ordinals = ord_u[inv]
+        # control traffic travels on the backend's kind of memory: device tensors under RCCL
+        use_gpu = dist.get_backend(self.group) != "gloo"
         held = torch.from_numpy((ordinals >= 0).astype(np.int32))
+        if use_gpu:
+            held = held.cuda(self.device)
         total = held.clone()
         dist.all_reduce(total, group=self.group)  # every pair must be held by exactly one rank
-        if int(total.min()) < 1:
-            bad = int(np.flatnonzero(total.numpy() < 1)[0])
+        total_h = total.cpu().numpy()
+        if total_h.size and int(total_h.min()) < 1:
+            bad = int(np.flatnonzero(total_h < 1)[0])
             raise IndexError(f"ID {ids[bad]} not found in the index.")
         mine = np.flatnonzero(ordinals >= 0)
         local_off = np.zeros(n_q + 1, dtype=np.int64)
@@ -310,12 +315,11 @@ class ShardedInMemoryIndex:
         gathered = [torch.zeros_like(held) for _ in range(self.world)]
         dist.all_gather(gathered, held, group=self.group)
         for r, h in enumerate(gathered):
-            holder[h.numpy() > 0] = r
+            holder[h.cpu().numpy() > 0] = r
         q_lo, q_hi = int(q_bounds[self.rank]), int(q_bounds[self.rank + 1])
         lo, hi = int(pair_off[q_lo]), int(pair_off[q_hi])
         own_holder = holder[lo:hi]
         recv_counts = np.bincount(own_holder, minlength=self.world).astype(np.int64)
-        use_gpu = dist.get_backend(self.group) != "gloo"
         send = torch.from_numpy(dense_local)
         if use_gpu:
             send = send.cuda(self.device)

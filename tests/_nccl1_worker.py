@@ -59,5 +59,34 @@ want, want_i = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row,
 assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i))
 scorer.close()
 idx.close()
+
+# the Index-API class over the same 1-rank RCCL group: its control collectives (who holds which
+# id, the unknown-id check, gather=True) must run on device tensors under this backend
+import pandas as pd  # noqa: E402
+
+from fast_forward_amd import Ranking  # noqa: E402
+from fast_forward_amd.encoder import LambdaEncoder  # noqa: E402
+from fast_forward_amd.index import InMemoryIndex, Mode  # noqa: E402
+from fast_forward_amd.sharded import ShardedInMemoryIndex  # noqa: E402
+
+rng = np.random.default_rng(3)
+n, d = 400, 64
+rows = rng.standard_normal((n, d)).astype(np.float32)
+qv = rng.standard_normal((4, d)).astype(np.float32)
+enc = LambdaEncoder(lambda t: qv[int(t)])
+docs = [f"D{i // 2}" for i in range(n)]
+sharded, plain = ShardedInMemoryIndex(enc, mode=Mode.MAXP), InMemoryIndex(enc, mode=Mode.MAXP)
+sharded.add(rows, doc_ids=docs)
+plain.add(rows, doc_ids=docs)
+run = {f"q{q}": {f"D{x}": float(rng.random()) for x in rng.choice(n // 2, size=50, replace=False)} for q in range(4)}
+first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(4)})
+assert sharded(first, gather=True) == plain(first)
+assert sharded.rerank(first, 0.2, gather=True) == plain.rerank(first, 0.2)
+bad = Ranking(pd.concat([first._df, pd.DataFrame([{"q_id": "q0", "id": "nowhere", "score": 1.0, "query": "0"}])]))
+try:
+    sharded(bad)
+    raise SystemExit("an unknown id must raise IndexError")
+except IndexError as e:
+    assert "nowhere" in str(e)
 dist.destroy_process_group()
 print("sharded 1-rank ok")
