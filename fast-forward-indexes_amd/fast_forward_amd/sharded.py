@@ -231,6 +231,8 @@ class ShardedInMemoryIndex:
         if device is None:
             device = self.rank % max(1, torch.cuda.device_count())
         self.device = device
+        if dist.get_backend(group) != "gloo":
+            torch.cuda.set_device(device)  # object collectives of the RCCL backend use the current device
         self.local = InMemoryIndex(query_encoder, mode=mode or Mode.MAXP, encoder_batch_size=encoder_batch_size, device=device,
                                    exact_sum=exact_sum, **index_kwargs)
         self._n_global = 0
