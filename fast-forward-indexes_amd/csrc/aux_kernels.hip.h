@@ -201,6 +201,26 @@ iota_kernel(int32_t* __restrict__ dst, int64_t n, int32_t base) {
   if (i < n) dst[i] = base + (int32_t)i;
 }
 
+// ---- per-query order of batches with very long queries ---------------------------------------
+// The segmented sort gives every query to one workgroup, which is right for thousands of
+// candidates and hopeless for millions.  Such batches are ordered by ONE device-wide stable radix
+// sort instead, on 64-bit words  (query number) << 32 | ~(order-preserving image of the score):
+// ascending words = queries in order, scores descending inside, exact ties by position
+// (stability), -0.0 counted as +0.0.
+__global__ void __launch_bounds__(256)
+sort_words_kernel(const float* __restrict__ keys, const int64_t* __restrict__ pair_off, int n_queries,
+                  double queries_per_pair, int64_t n_pairs, int32_t base, unsigned long long* __restrict__ words,
+                  int32_t* __restrict__ positions) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  uint32_t b = __float_as_uint(keys[p]);
+  if (b == 0x80000000u) b = 0u;
+  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // larger score -> larger image
+  const unsigned long long q = (unsigned long long)query_of_pair(pair_off, n_queries, p, queries_per_pair);
+  words[p] = (q << 32) | (unsigned long long)(~b);
+  positions[p] = base + (int32_t)p;
+}
+
 // ---- long rows as several short ones --------------------------------------------------------
 // NumPy's pairwise sum of a row of d = S*b elements (S a power of two, b one of the row lengths the
 // gather_dot kernels are specialised for) is the balanced pairwise sum of the S sums of its

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls memset unqualified
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
@@ -985,12 +986,38 @@ static int launch_gather_dot(ffx_plan* pl, bool exact, float* rs) {
 
 extern "C" {
 
-// per-query order: key descending, ties by position (the radix sort is stable)
+static int64_t longest_segment(const int64_t* off, int64_t n) {
+  int64_t m = 0;
+  for (int64_t q = 0; q < n; ++q) m = std::max(m, off[q + 1] - off[q]);
+  return m;
+}
+
+// per-query order: key descending, ties by position (the radix sorts are stable).  Queries of up
+// to 64K candidates: one workgroup each (segmented sort, 1.3 ms at 6980 x 5000).  A batch with a
+// longer query: one device-wide sort on (query, score) words -- the segmented sort needs 112 ms for
+// a single query of 5 M candidates, the device-wide one 2 ms (tools/shapes.py).
 static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* offs_dev, int64_t n_queries, DevBuf& order,
-                                 DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st, int32_t base = 0) {
+                                 DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st, int64_t max_len,
+                                 int32_t base = 0) {
   const size_t pb = (size_t)P;
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
+  if (max_len > (64 << 10)) {
+    // words in / words out share `sorted_keys` (2 x 8 bytes per pair)
+    FFX_TRY(sorted_keys.ensure(2 * pb * sizeof(unsigned long long)));
+    unsigned long long* w_in = sorted_keys.as<unsigned long long>();
+    unsigned long long* w_out = w_in + pb;
+    ffx::sort_words_kernel<<<blocks_for(P, 256), 256, 0, st>>>(keys, offs_dev, (int)n_queries, (double)n_queries / (double)P, P, base,
+                                                              w_in, iota.as<int32_t>());
+    FFX_HIP(hipGetLastError());
+    int q_bits = 1;
+    while (q_bits < 31 && (int64_t(1) << q_bits) < n_queries) ++q_bits;
+    size_t tmp = 0;
+    FFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp, w_in, w_out, iota.as<int32_t>(), order.as<int32_t>(), pb, 0, 32 + q_bits, st));
+    FFX_TRY(sort_tmp.ensure(std::max<size_t>(tmp, 16)));
+    FFX_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp, w_in, w_out, iota.as<int32_t>(), order.as<int32_t>(), pb, 0, 32 + q_bits, st));
+    return FFX_OK;
+  }
   FFX_TRY(sorted_keys.ensure(pb * sizeof(float)));
   ffx::iota_kernel<<<blocks_for(P, 256), 256, 0, st>>>(iota.as<int32_t>(), P, base);
   FFX_HIP(hipGetLastError());
@@ -1060,7 +1087,8 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (do_sort && P > 0) {
     const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
     FFX_TRY(launch_segmented_sort(keys, P, pl->pair_off.as<int64_t>(), pl->n_queries, pl->order, pl->iota,
-                                  pl->sorted_keys, pl->sort_tmp, st, pl->order_base));
+                                  pl->sorted_keys, pl->sort_tmp, st, longest_segment(pl->host_pair_off.data(), pl->n_queries),
+                                  pl->order_base));
   }
   FFX_HIP(hipEventRecord(pl->ev[4], st));
   pl->ran = true;
@@ -1159,7 +1187,7 @@ struct ffx_merge {
   int device = 0;
   hipStream_t own_stream = nullptr, last_stream = nullptr;
   DevBuf pair_off, slot, sparse, ff, interp, order, iota, sorted_keys, sort_tmp;
-  int64_t n_queries = 0, n_pairs = 0;
+  int64_t n_queries = 0, n_pairs = 0, max_len = 0;
   bool have_sparse = false, ready = false, ran = false, ran_sort = false;
 };
 
@@ -1224,6 +1252,7 @@ int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, cons
   }
   m->n_queries = n_queries;
   m->n_pairs = P;
+  m->max_len = longest_segment(pair_off, n_queries);
   m->ready = true;
   return FFX_OK;
 }
@@ -1245,7 +1274,7 @@ int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t fl
     if (do_sort) {
       const float* keys = (m->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? m->interp.as<float>() : m->ff.as<float>();
       FFX_TRY(launch_segmented_sort(keys, P, m->pair_off.as<int64_t>(), m->n_queries, m->order, m->iota, m->sorted_keys,
-                                    m->sort_tmp, st));
+                                    m->sort_tmp, st, m->max_len));
     }
   }
   m->ran = true;
@@ -1335,7 +1364,8 @@ int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, i
       FFX_TRY(po.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
       FFX_HIP(hipMemcpy(po.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
       const float* k = (sparse && !(flags & FFX_FLAG_SORT_FF)) ? in.as<float>() : ff.as<float>();
-      FFX_TRY(launch_segmented_sort(k, n_pairs, po.as<int64_t>(), n_queries, order, iota, keys, tmp, nullptr));
+      FFX_TRY(launch_segmented_sort(k, n_pairs, po.as<int64_t>(), n_queries, order, iota, keys, tmp, nullptr,
+                                    longest_segment(pair_off, n_queries)));
     }
     FFX_HIP(hipDeviceSynchronize());
     FFX_HIP(hipMemcpy(out_ff, ff.p, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));

@@ -544,6 +544,14 @@ def test_per_query_order():
     finite = np.isfinite(interp)
     assert finite.sum() >= n - 10
     assert np.array_equal(order.astype(np.int64), fo.order(interp, pair_off))
+    # a very long query (device-wide sort on (query, score) words instead of one workgroup per query)
+    huge_off = np.array([0, 5, 5, 5 + 70_001, 5 + 70_001 + 4096, 5 + 70_001 + 4096 + 1], dtype=np.int64)
+    huge = rng.integers(-20, 20, size=int(huge_off[-1])).astype(np.float32)
+    huge[rng.random(huge.shape[0]) < 0.5] *= np.float32(0.37)
+    huge[huge == 0][::2] = -0.0
+    huge_sparse = rng.integers(0, 2, size=huge.shape[0]).astype(np.float32)
+    _, h_interp, order = native.aggregate(huge, np.arange(huge_off[-1] + 1, dtype=np.int64), 2, huge_sparse, 0.25, pair_off=huge_off, sort=True)
+    assert np.array_equal(order.astype(np.int64), fo.order(h_interp, huge_off))
     # a long query between short ones
     long_off = np.array([0, 3, 3 + 8193, 3 + 8193 + 100], dtype=np.int64)
     long_scores = rng.integers(0, 50, size=int(long_off[-1])).astype(np.float32)
