@@ -1002,7 +1002,9 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
   const size_t pb = (size_t)P;
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
-  if (max_len > (64 << 10)) {
+  int64_t device_wide_from = 64 << 10;
+  if (const char* e = getenv("FFX_SORT_DEVICE_WIDE_FROM")) device_wide_from = atoll(e);  // A/B hook
+  if (max_len > device_wide_from) {
     // words in / words out share `sorted_keys` (2 x 8 bytes per pair)
     FFX_TRY(sorted_keys.ensure(2 * pb * sizeof(unsigned long long)));
     unsigned long long* w_in = sorted_keys.as<unsigned long long>();
