@@ -993,16 +993,18 @@ static int64_t longest_segment(const int64_t* off, int64_t n) {
 }
 
 // per-query order: key descending, ties by position (the radix sorts are stable).  Queries of up
-// to 64K candidates: one workgroup each (segmented sort, 1.3 ms at 6980 x 5000).  A batch with a
-// longer query: one device-wide sort on (query, score) words -- the segmented sort needs 112 ms for
-// a single query of 5 M candidates, the device-wide one 2 ms (tools/shapes.py).
+// to 16K candidates: one workgroup each (segmented sort, 1.3 ms at 6980 x 5000 against 1.9 ms
+// device-wide).  A batch with a longer query: one device-wide sort on (query, score) words, whose
+// cost does not depend on the query lengths (0.085 ms per million pairs; the segmented sort needs
+// 0.10 / 0.15 / 0.28 ms per million at 15K / 30K / 60K candidates and 112 ms for one query of 5 M:
+// tools/shapes.py).
 static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* offs_dev, int64_t n_queries, DevBuf& order,
                                  DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st, int64_t max_len,
                                  int32_t base = 0) {
   const size_t pb = (size_t)P;
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
-  int64_t device_wide_from = 64 << 10;
+  int64_t device_wide_from = 16 << 10;
   if (const char* e = getenv("FFX_SORT_DEVICE_WIDE_FROM")) device_wide_from = atoll(e);  // A/B hook
   if (max_len > device_wide_from) {
     // words in / words out share `sorted_keys` (2 x 8 bytes per pair)

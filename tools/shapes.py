@@ -1,6 +1,8 @@
+#!/usr/bin/env python3
+"""Extreme batch shapes through one plan (many tiny queries, a few huge ones): stage times and a sortedness check."""
 import sys, time, json
 from pathlib import Path
-ROOT = Path("/root/repo")
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd")); sys.path.insert(0, str(ROOT))
 import numpy as np
 from fast_forward_amd import native, synth
@@ -9,7 +11,7 @@ rows, d = 8_841_823, 768
 scale = float(1 / np.sqrt(d))
 idx = native.DeviceIndex(rows, d); idx.fill_synthetic(2024, scale, 0, rows)
 idx.set_doc_rows(np.arange(rows + 1, dtype=np.int64), np.arange(rows, dtype=np.int32)); idx.set_psg_rows(np.arange(rows, dtype=np.int32))
-for nq, k in ((100_000, 100), (1, 5_000_000), (20, 500_000), (1_000_000, 10)):
+for nq, k in ((100_000, 100), (1, 5_000_000), (20, 500_000), (1_000_000, 10), (100, 60_000), (200, 30_000), (400, 15_000)):
     ids, sparse = B.candidates(rows, nq, k, 7); pair_off = np.arange(nq + 1, dtype=np.int64) * k; q = synth.rows(5, scale, 0, nq, d)
     plan = native.Plan(idx); plan.set_queries(q); plan.set_pairs(pair_off, ids, sparse, 2)
     plan.run(0.1, sort=True); plan.sync()
