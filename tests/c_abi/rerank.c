@@ -1,9 +1,9 @@
-/* rerank.c -- the C ABI of libffx (include/ffx.h) used from plain C99, no Python anywhere:
+/* rerank.c (test infrastructure: it links the oracle) -- the C ABI of libffx (include/ffx.h) used from plain C99, no Python anywhere:
  * build an HBM-resident index, score a batch of (query, candidate) pairs with MaxP aggregation,
  * interpolate with first-stage scores, get the per-query order back -- and check every number
  * against the CPU oracle (oracle/ffx_oracle.c, test infrastructure) bit for bit.
  *
- *   gcc -std=c99 -Iinclude examples/rerank.c -o rerank \
+ *   gcc -std=c99 -Iinclude tests/c_abi/rerank.c -o rerank \
  *       -Lfast-forward-indexes_amd/fast_forward_amd -lffx -Loracle -lffx_oracle -lm
  *
  * tests/test_gpu_parity.py::test_c_example_runs_against_the_oracle builds and runs it on the GPU box.

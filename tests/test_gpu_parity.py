@@ -560,7 +560,7 @@ def test_per_query_order():
 
 
 def test_c_example_runs_against_the_oracle(tmp_path):
-    """examples/rerank.c: the ABI used from plain C99 (no Python in the process) -- index build,
+    """tests/c_abi/rerank.c: the ABI used from plain C99 (no Python in the process) -- index build,
     ffx_score with MaxP + interpolation + order, error reporting -- self-checked against the
     oracle library bit for bit."""
     import shutil
@@ -574,7 +574,7 @@ def test_c_example_runs_against_the_oracle(tmp_path):
         pytest.skip("no C compiler on this box")
     exe = tmp_path / "rerank"
     build = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{root / 'include'}",
-                            str(root / "examples" / "rerank.c"), "-o", str(exe), f"-L{lib_dir}", "-lffx", f"-L{oracle_dir}",
+                            str(root / "tests" / "c_abi" / "rerank.c"), "-o", str(exe), f"-L{lib_dir}", "-lffx", f"-L{oracle_dir}",
                             "-lffx_oracle", "-lm", f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{oracle_dir}", "-Wl,-rpath,/opt/rocm/lib"],
                            capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
