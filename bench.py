@@ -39,8 +39,8 @@ MODE_NO = {"PASSAGE": 1, "MAXP": 2, "FIRSTP": 3, "AVEP": 4}
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=8_841_823, help="index rows (MS MARCO passage count)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=6980)
