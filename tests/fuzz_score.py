@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end check of the C ABI against the oracle: ragged batches, every mode, several
+row lengths and stores, random slice sizes of ffx_score, sort on and off.  Not collected by pytest
+(it is a soak: `python tests/fuzz_score.py --rounds 300` on the GPU box, under a minute); prints the
+seed of any failure.  Last run of round 1: 300 configurations, all bit-exact."""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle"):
+    sys.path.insert(0, str(p))
+import ffx_oracle as fo  # noqa: E402  (a checking tool, like the tests)
+from fast_forward_amd import native, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=150)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)  # noqa: E731
+DIMS = [8, 24, 64, 100, 128, 256, 300, 384, 512, 768, 1024, 1536, 2048]
+for rnd in range(args.rounds):
+    seed = args.seed * 100_000 + rnd
+    rng = np.random.default_rng(seed)
+    d = int(rng.choice(DIMS))
+    store = np.float16 if rng.random() < 0.3 else np.float32
+    n_docs = int(rng.integers(1, 400))
+    per_doc = rng.integers(1, 6, size=n_docs)
+    doc_off = np.concatenate([[0], np.cumsum(per_doc)]).astype(np.int64)
+    n = int(doc_off[-1])
+    doc_rows = rng.permutation(n).astype(np.int32)
+    psg_row = rng.permutation(n).astype(np.int32)
+    vectors = synth.rows(seed, 0.2, 0, n, d).astype(store)
+    n_q = int(rng.integers(1, 12))
+    queries = synth.rows(seed + 1, 0.2, 0, n_q, d)
+    mode = int(rng.integers(1, 5))
+    pool = n if mode == 1 else n_docs
+    lens = [int(rng.integers(0, min(pool, 300) + 1)) for _ in range(n_q)]
+    pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pair_ids = np.concatenate([rng.choice(pool, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    sparse = (rng.integers(0, 5, size=len(pair_ids)) if rng.random() < 0.5 else rng.random(len(pair_ids)) * 10).astype(np.float32)
+    alpha = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
+    os.environ["FFX_SCORE_SLICE_PAIRS"] = str(int(rng.choice([1, 7, 100, 10**9])))
+    idx = native.DeviceIndex(n, d, dtype=store)
+    idx.upload(vectors, 0)
+    idx.set_doc_rows(doc_off, doc_rows)
+    idx.set_psg_rows(psg_row)
+    try:
+        ff, interp, order, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, alpha, exact_sum=True, sort=True)
+        want_ff, want_in = fo.score(vectors.astype(np.float32), doc_off, doc_rows, psg_row, queries, pair_off, pair_ids, mode, sparse, alpha)
+        assert np.array_equal(bits(ff), bits(want_ff)), "dense"
+        assert np.array_equal(bits(interp), bits(want_in)), "interp"
+        assert np.array_equal(order.astype(np.int64), fo.order(want_in, pair_off)), "order"
+        fast, _, _, _ = native.score(idx, queries, pair_off, pair_ids, mode, exact_sum=False)
+        if len(fast):
+            assert np.abs(fast - want_ff).max() <= 1e-4 * max(1.0, float(np.abs(want_ff).max())), "fast"
+    except AssertionError as e:
+        print(f"FAIL seed={seed} d={d} store={np.dtype(store).name} mode={mode} n_q={n_q} pairs={len(pair_ids)} what={e}")
+        sys.exit(1)
+    finally:
+        idx.close()
+    if rnd % 25 == 0:
+        print(f"round {rnd}: d={d} {np.dtype(store).name} mode={mode} pairs={len(pair_ids)} variant={st['kernel_variant']} ok", flush=True)
+print(f"fuzz ok: {args.rounds} configurations")
