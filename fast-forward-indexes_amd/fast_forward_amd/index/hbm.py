@@ -109,7 +109,7 @@ class InMemoryIndex(Index):
         self._store = grown
         self._ids_on_device = -1
 
-    def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
+    def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence, _uploader=None) -> None:
         """``vectors`` are codes when a quantizer is attached (``Index.add`` encodes first).
 
         Quantized rows are kept in HBM as uint8 product-quantizer codes when the quantizer exposes
@@ -133,7 +133,13 @@ class InMemoryIndex(Index):
             codewords, self._rotation = self._quantizer.device_codebook()
             self._store.set_codebook(codewords)
         self._ids.add(doc_ids, psg_ids, self._n)  # a duplicate passage id raises before anything is modified
-        self._store.upload(np.ascontiguousarray(vectors, dtype=self._dtype), self._n)
+        if _uploader is not None:
+            # rows that already sit in files (OnDiskIndex.to_memory): `vectors` only carries shape
+            # and dtype, the rows go from the chunk maps to HBM natively (ffx_index_upload_rows)
+            assert np.dtype(vectors.dtype) == self._dtype, "stored rows must already be in the index dtype"
+            _uploader(self._store, self._n)
+        else:
+            self._store.upload(np.ascontiguousarray(vectors, dtype=self._dtype), self._n)
         if codes is not None:
             self._host_codes.append(np.array(codes, copy=True))
         self._n += n_new

@@ -360,9 +360,23 @@ class OnDiskIndex(Index):
         n = len(self)
         step = batch_size or max(n, 1)
         docs, psgs = self._ids.row_ids(n)
+        chunk_maps = [m[0] for m in self._maps]
+        stored = np.dtype(self._meta["dtype"]) if self._meta["dtype"] else None
+        book = self._quantizer.device_codebook() if self._quantizer is not None else None
+        # stored rows can go to HBM as they are (fp32 / fp16 vectors, or codes the kernels read)
+        direct = (n > 0 and stored in (np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.uint8))
+                  and (self._quantizer is None) == (stored != np.dtype(np.uint8)) and (self._quantizer is None or book is not None)
+                  and all(isinstance(c, np.ndarray) and c.flags["C_CONTIGUOUS"] for c in chunk_maps))
         for lo in range(0, n, step):
             hi = min(lo + step, n)
-            index._add(self._read_rows(np.arange(lo, hi)), docs[lo:hi], psgs[lo:hi])
+            if direct:
+                from types import SimpleNamespace
+
+                shape = SimpleNamespace(shape=(hi - lo, self._meta["dim"]), dtype=stored)
+                index._add(shape, docs[lo:hi], psgs[lo:hi],
+                           _uploader=lambda store, at, lo=lo, hi=hi: store.upload_rows(chunk_maps, np.arange(lo, hi), at, _READ_THREADS))
+            else:
+                index._add(self._read_rows(np.arange(lo, hi)), docs[lo:hi], psgs[lo:hi])
         return index
 
     # ---- scoring: stream the needed rows through two HBM windows --------------------------------------------
