@@ -198,7 +198,8 @@ def device_info(device: int = 0) -> dict:
     name = C.create_string_buffer(256)
     total, free, cus = C.c_int64(0), C.c_int64(0), C.c_int32(0)
     _check(lib().ffx_device_info(device, name, 256, C.byref(total), C.byref(free), C.byref(cus)))
-    return {"name": name.value.decode(), "total_bytes": total.value, "free_bytes": free.value, "compute_units": cus.value}
+    # some boxes report no marketing name, only "(gfx950:...)"
+    return {"name": name.value.decode().strip(), "total_bytes": total.value, "free_bytes": free.value, "compute_units": cus.value}
 
 
 def require_device() -> None:
