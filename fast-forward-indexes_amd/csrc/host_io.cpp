@@ -9,6 +9,7 @@
 // No device code here; plain C++17.
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
@@ -93,9 +94,37 @@ struct ffx_run {
   std::vector<float> score;
   std::string tag;                  // last column of the first line (Ranking.name, ranking.py:409)
   const ffx_ids* ids = nullptr;     // borrowed: candidate id strings for writing
+  // opened without an id table (Ranking.from_file): the candidate ids stay views into the file text
+  std::string text;
+  std::vector<std::string_view> pair_view;
+  int32_t q_flags = 0, id_flags = 0, misc_flags = 0;
 };
 
 namespace {
+
+// What pandas.read_csv would make of a column holding this token (it decides per column, so the
+// caller ORs the classes of all tokens): an integer it prints back unchanged, another number or
+// boolean (printed back differently, or only when the whole column is like that), one of its NA
+// words, or plain text.
+inline int token_class(std::string_view t) {
+  static const char* const na_words[] = {"#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN",
+                                         "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+  for (const char* w : na_words)
+    if (t == w) return FFX_TOKEN_NA;
+  size_t i = 0;
+  if (i < t.size() && t[i] == '-') ++i;
+  const size_t digits_from = i;
+  while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i;
+  if (i == t.size() && i > digits_from && i - digits_from <= 18 && (t[digits_from] != '0' || (i - digits_from == 1 && digits_from == 0)))
+    return FFX_TOKEN_INT;
+  std::string tmp(t);
+  for (char& c : tmp) c = (char)tolower((unsigned char)c);
+  if (tmp == "true" || tmp == "false") return FFX_TOKEN_NUMBER;
+  char* endp = nullptr;
+  (void)strtod(tmp.c_str(), &endp);
+  if (endp == tmp.c_str() + tmp.size() && !tmp.empty()) return FFX_TOKEN_NUMBER;
+  return FFX_TOKEN_TEXT;
+}
 
 inline std::string_view fixed_width(const char* base, int32_t width, int64_t i) {
   const char* p = base + (size_t)i * width;
@@ -262,8 +291,9 @@ int ffx_ids_get(const ffx_ids* t, int32_t ordinal, const char** str, int32_t* le
 // A (query, id) pair that appears twice is FFX_BAD_ARG (ValueError, ranking.py:95-98).
 int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* bad_line) {
   if (bad_line) *bad_line = -1;
-  if (!path || !ids || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (!path || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
   *out = nullptr;
+  const bool standalone = ids == nullptr;  // keep the id strings instead of resolving them
   FILE* f = fopen(path, "rb");
   if (!f) return ffx_fail(FFX_BAD_ARG, "cannot open %s", path);
   std::string data;
@@ -286,6 +316,7 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
   if (!run) return ffx_fail(FFX_OOM, "host allocation failed");
   run->ids = ids;
   std::vector<int32_t> row_q, row_id;
+  std::vector<std::string_view> row_view;
   std::vector<float> row_s;
   int rc = FFX_OK;
   // The file is cut into pieces at line ends and the pieces are tokenised, resolved against the
@@ -294,6 +325,8 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
   struct Piece {
     const char *begin = nullptr, *end = nullptr;
     std::vector<int32_t> id;
+    std::vector<std::string_view> id_view;  // standalone mode
+    int32_t q_flags = 0, id_flags = 0, misc_flags = 0;
     std::vector<float> score;
     std::vector<std::pair<std::string_view, int64_t>> q_runs;  // (query id, consecutive rows)
     std::string_view tag;
@@ -303,15 +336,20 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
     std::string err_text;
     bool oom = false;
   };
-  const char* const base = data.data();
-  const char* const end = base + data.size();
-  const int T = (int)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<size_t>(1, data.size() >> 20));
+  if (standalone) {
+    run->text = std::move(data);  // the id views point into it
+    if (memchr(run->text.data(), '"', run->text.size())) run->misc_flags |= FFX_RUN_QUOTES;
+  }
+  const std::string& text = standalone ? run->text : data;
+  const char* const base = text.data();
+  const char* const end = base + text.size();
+  const int T = (int)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<size_t>(1, text.size() >> 20));
   std::vector<Piece> pieces((size_t)T);
   {
     const char* cut = base;
     for (int t = 0; t < T; ++t) {
       pieces[(size_t)t].begin = cut;
-      const char* want = t + 1 == T ? end : base + data.size() * (size_t)(t + 1) / (size_t)T;
+      const char* want = t + 1 == T ? end : base + text.size() * (size_t)(t + 1) / (size_t)T;
       if (want < cut) want = cut;
       if (want < end) {
         const char* nl = (const char*)memchr(want, '\n', (size_t)(end - want));
@@ -344,10 +382,19 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
           pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "expected 'q_id Q0 id rank score [name]'";
           return;
         }
-        const int32_t o = ids->find(field[2]);
-        if (o < 0) {
-          pc.err = FFX_NOT_FOUND, pc.err_line = pc.lines, pc.err_text.assign(field[2]);
-          return;
+        int32_t o = 0;
+        if (standalone) {
+          pc.id_flags |= token_class(field[2]);
+          if (pc.q_runs.empty() || pc.q_runs.back().first != field[0]) pc.q_flags |= token_class(field[0]);
+          if (nf < 6) pc.misc_flags |= FFX_RUN_SHORT_LINE;
+          for (const char* x = c; x < eol; ++x)
+            if (!is_space(*x)) pc.misc_flags |= FFX_RUN_LONG_LINE;
+        } else {
+          o = ids->find(field[2]);
+          if (o < 0) {
+            pc.err = FFX_NOT_FOUND, pc.err_line = pc.lines, pc.err_text.assign(field[2]);
+            return;
+          }
         }
         // the buffer ends in NUL and a field ends at white space, so strtod cannot run past it
         char* endp = nullptr;
@@ -359,7 +406,10 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
         if (pc.tag.data() == nullptr && nf >= 6) pc.tag = field[5];
         if (pc.q_runs.empty() || pc.q_runs.back().first != field[0]) pc.q_runs.emplace_back(field[0], 0);
         ++pc.q_runs.back().second;
-        pc.id.push_back(o);
+        if (standalone)
+          pc.id_view.push_back(field[2]);
+        else
+          pc.id.push_back(o);
         pc.score.push_back((float)sc);  // scores become float32 (Ranking dtype, ranking.py:72)
       }
     } catch (const std::bad_alloc&) {
@@ -386,6 +436,10 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
       lines_before += pc.lines;
       if (run->tag.empty() && pc.tag.data() != nullptr) run->tag.assign(pc.tag);
       row_id.insert(row_id.end(), pc.id.begin(), pc.id.end());
+      row_view.insert(row_view.end(), pc.id_view.begin(), pc.id_view.end());
+      run->q_flags |= pc.q_flags;
+      run->id_flags |= pc.id_flags;
+      run->misc_flags |= pc.misc_flags;
       row_s.insert(row_s.end(), pc.score.begin(), pc.score.end());
       for (const auto& qr : pc.q_runs) row_q.insert(row_q.end(), (size_t)qr.second, run->qids.intern(qr.first));
     }
@@ -394,17 +448,34 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
       run->pair_off.assign((size_t)nq + 1, 0);
       for (int32_t q : row_q) ++run->pair_off[(size_t)q + 1];
       for (int64_t q = 0; q < nq; ++q) run->pair_off[(size_t)q + 1] += run->pair_off[(size_t)q];
-      run->pair_ids.resize((size_t)n);
+      run->pair_ids.resize(standalone ? 0 : (size_t)n);
+      run->pair_view.resize(standalone ? (size_t)n : 0);
       run->score.resize((size_t)n);
       std::vector<int64_t> cursor(run->pair_off.begin(), run->pair_off.end() - 1);
       for (int64_t i = 0; i < n; ++i) {  // stable: rows of a query keep file order
         const int64_t dst = cursor[(size_t)row_q[(size_t)i]]++;
-        run->pair_ids[(size_t)dst] = row_id[(size_t)i];
+        if (standalone)
+          run->pair_view[(size_t)dst] = row_view[(size_t)i];
+        else
+          run->pair_ids[(size_t)dst] = row_id[(size_t)i];
         run->score[(size_t)dst] = row_s[(size_t)i];
       }
       // duplicate (query, id) pairs: one mark per ordinal, set and cleared query by query
       std::atomic<bool> dup{false}, scan_oom{false};
       auto scan = [&](int64_t q_lo, int64_t q_hi) {
+        if (standalone) {  // no ordinals: order each query's id strings and look at neighbours
+          std::vector<std::string_view> tmp;
+          try {
+            for (int64_t q = q_lo; q < q_hi && !dup.load(std::memory_order_relaxed); ++q) {
+              tmp.assign(run->pair_view.begin() + run->pair_off[(size_t)q], run->pair_view.begin() + run->pair_off[(size_t)q + 1]);
+              std::sort(tmp.begin(), tmp.end());
+              if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) dup.store(true);
+            }
+          } catch (const std::bad_alloc&) {
+            scan_oom.store(true);
+          }
+          return;
+        }
         std::vector<uint8_t> seen;
         try {
           seen.assign((size_t)ids->size(), 0);
@@ -451,7 +522,7 @@ int ffx_run_close(ffx_run* run) {
 int ffx_run_counts(const ffx_run* run, int64_t* n_queries, int64_t* n_pairs) {
   if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
   if (n_queries) *n_queries = run->qids.size();
-  if (n_pairs) *n_pairs = (int64_t)run->pair_ids.size();
+  if (n_pairs) *n_pairs = (int64_t)run->score.size();
   return FFX_OK;
 }
 
@@ -472,6 +543,7 @@ int ffx_run_tag(const ffx_run* run, const char** str, int32_t* len) {
 int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pair_ids, float* sparse, int64_t* n_pairs_out) {
   if (!run || !pair_off) return ffx_fail(FFX_BAD_ARG, "NULL argument");
   const int64_t nq = run->qids.size();
+  if (!run->ids && (cutoff > 0 || pair_ids)) return ffx_fail(FFX_BAD_ARG, "a run opened without an id table has no ordinals to export or cut");
   if (cutoff > 0) {  // trim in place, once
     std::vector<int64_t> new_off((size_t)nq + 1, 0);
     std::vector<int32_t> ids2;
@@ -496,7 +568,7 @@ int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pai
     run->pair_ids.swap(ids2);
     run->score.swap(sc2);
   }
-  const int64_t n = (int64_t)run->pair_ids.size();
+  const int64_t n = (int64_t)run->score.size();
   if (n_pairs_out) *n_pairs_out = n;
   memcpy(pair_off, run->pair_off.data(), (size_t)(nq + 1) * sizeof(int64_t));
   if (pair_ids) memcpy(pair_ids, run->pair_ids.data(), (size_t)n * sizeof(int32_t));
@@ -507,9 +579,40 @@ int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pai
 // write `q_id Q0 id rank score tag` (tab separated; Ranking.save, ranking.py:348-366): queries in
 // descending q_id order, candidates of a query in the order given by `order` (positions into the
 // CSR, e.g. the device sort of ffx_plan_run); keep > 0 writes only the first `keep` of each query.
+// standalone runs (opened without an id table): what pandas would make of the q_id / id columns
+// (FFX_TOKEN_* classes OR-ed over the column) and of the file's shape (FFX_RUN_* bits)
+int ffx_run_flags(const ffx_run* run, int32_t* q_flags, int32_t* id_flags, int32_t* misc_flags) {
+  if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
+  if (q_flags) *q_flags = run->q_flags;
+  if (id_flags) *id_flags = run->id_flags;
+  if (misc_flags) *misc_flags = run->misc_flags;
+  return FFX_OK;
+}
+
+// standalone runs: the candidate ids in CSR order (grouped by query, file order inside), joined by
+// '\n'.  Call with buf == NULL to learn the size.
+int ffx_run_ids_blob(const ffx_run* run, char* buf, int64_t cap, int64_t* needed) {
+  if (!run || !needed) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (run->ids) return ffx_fail(FFX_BAD_ARG, "this run was resolved against an id table: it holds ordinals, not strings");
+  int64_t total = 0;
+  for (const std::string_view& v : run->pair_view) total += (int64_t)v.size() + 1;
+  if (total > 0) --total;  // no separator after the last one
+  *needed = total;
+  if (!buf) return FFX_OK;
+  if (cap < total) return ffx_fail(FFX_BAD_ARG, "buffer too small");
+  char* w = buf;
+  for (size_t i = 0; i < run->pair_view.size(); ++i) {
+    if (i) *w++ = '\n';
+    memcpy(w, run->pair_view[i].data(), run->pair_view[i].size());
+    w += run->pair_view[i].size();
+  }
+  return FFX_OK;
+}
+
 int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
                   const char* tag) {
   if (!run || !path || !scores || !order) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (!run->ids) return ffx_fail(FFX_BAD_ARG, "this run was opened without an id table");
   FILE* f = fopen(path, "wb");
   if (!f) return ffx_fail(FFX_BAD_ARG, "cannot create %s", path);
   const int64_t nq = run->qids.size();

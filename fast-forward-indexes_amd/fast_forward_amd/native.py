@@ -15,6 +15,8 @@ LIB_PATH = Path(__file__).resolve().parent / "libffx.so"
 
 OK, BAD_ARG, OOM, HIP_ERROR, RCCL_ERROR, NOT_FOUND, NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF = 1, 2, 4
+TOKEN_INT, TOKEN_NUMBER, TOKEN_NA, TOKEN_TEXT = 1, 2, 4, 8
+RUN_SHORT_LINE, RUN_LONG_LINE, RUN_QUOTES = 1, 2, 4
 BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 3, 4, 5
 
 # every symbol include/ffx.h declares (tests check the library exports all of them)
@@ -30,7 +32,7 @@ SYMBOLS = (
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_get",
-    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save",
+    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_flags", "ffx_run_ids_blob",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
 )
 
@@ -142,6 +144,8 @@ def lib() -> C.CDLL:
         "ffx_run_tag": ([vp, P(vp), P(i32)], C.c_int),
         "ffx_run_export": ([vp, i64, vp, vp, vp, P(i64)], C.c_int),
         "ffx_run_write": ([vp, C.c_char_p, vp, vp, i64, C.c_char_p], C.c_int),
+        "ffx_run_flags": ([vp, P(i32), P(i32), P(i32)], C.c_int),
+        "ffx_run_ids_blob": ([vp, vp, i64, P(i64)], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
         "ffx_host_alloc": ([C.c_size_t, P(vp)], C.c_int),
@@ -584,9 +588,11 @@ def save_run(path, q_names, pair_off, ids, scores, tag: str) -> bool:
 class RunFile:
     """Owns one ``ffx_run``: a TREC run parsed natively into the kernels' CSR (and written back)."""
 
-    def __init__(self, path, ids: IdStrings):
+    def __init__(self, path, ids: "IdStrings | None"):
+        """``ids`` None: nothing to resolve the candidate ids against; they stay strings
+        (:meth:`id_strings`) and :meth:`flags` tells how pandas would have typed the columns."""
         h, bad = C.c_void_p(), C.c_int64(-1)
-        rc = lib().ffx_run_open(str(path).encode(), ids._h, C.byref(h), C.byref(bad))
+        rc = lib().ffx_run_open(str(path).encode(), None if ids is None else ids._h, C.byref(h), C.byref(bad))
         if rc == NOT_FOUND:
             msg = (lib().ffx_last_error() or b"").decode("utf-8", "replace")
             raise IndexError(msg)
@@ -618,6 +624,30 @@ class RunFile:
         p, n = C.c_void_p(), C.c_int32(0)
         _check(lib().ffx_run_tag(self._h, C.byref(p), C.byref(n)))
         return C.string_at(p.value, n.value).decode("utf-8") if n.value else ""
+
+    def flags(self) -> tuple[int, int, int]:
+        """(q_id column, id column, file shape): FFX_TOKEN_* / FFX_RUN_* bits of a run opened without ids."""
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(lib().ffx_run_flags(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def id_strings(self) -> list[str]:
+        """Candidate ids of a run opened without an id table, grouped by query, file order inside."""
+        need = C.c_int64(0)
+        _check(lib().ffx_run_ids_blob(self._h, None, 0, C.byref(need)))
+        if self.n_pairs == 0:
+            return []
+        buf = C.create_string_buffer(max(1, need.value))
+        _check(lib().ffx_run_ids_blob(self._h, buf, need.value, C.byref(need)))
+        return buf.raw[:need.value].decode("utf-8").split("\n")
+
+    def scores(self) -> tuple[np.ndarray, np.ndarray]:
+        """(pair_off, first-stage scores) without touching ordinals (any run)."""
+        pair_off = np.empty(self.n_queries + 1, dtype=np.int64)
+        sparse = np.empty(self.n_pairs, dtype=np.float32)
+        n = C.c_int64(0)
+        _check(lib().ffx_run_export(self._h, 0, _ptr(pair_off), None, _ptr(sparse), C.byref(n)))
+        return pair_off, sparse
 
     def export(self, cutoff: int = 0):
         """(pair_off, pair_ids, sparse); ``cutoff`` > 0 keeps each query's best ``cutoff`` first."""

@@ -57,6 +57,21 @@ def _ranks_within_query(df: pd.DataFrame) -> pd.Series:
     return df.groupby("q_id").cumcount() + 1
 
 
+def _is_plain_text(token: str) -> bool:
+    """A run name pandas reads as the string it is (not a number, boolean or NA word)."""
+    if token in _PANDAS_NA_WORDS or token.lower() in ("true", "false"):
+        return False
+    try:
+        float(token)
+        return False
+    except ValueError:
+        return True
+
+
+_PANDAS_NA_WORDS = frozenset(("", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>",
+                              "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"))
+
+
 def _sorted_frame(df: pd.DataFrame) -> pd.DataFrame:
     """q_id descending, score descending, ties in input order (stable)."""
     q_codes = pd.factorize(df["q_id"], sort=True)[0]
@@ -330,6 +345,64 @@ class Ranking:
         target.parent.mkdir(parents=True, exist_ok=True)
         out.to_csv(target, sep="\t", columns=["q_id", "q0", "id", "rank", "score", "name"], index=False, header=False)
 
+    @classmethod
+    def _from_file_native(cls, f: Path, queries, dtype: np.dtype) -> "Ranking | None":
+        """``from_file`` through libffx's threaded parser, for files where that provably gives what
+        ``pandas.read_csv`` + the constructor give: float32 scores, six fields per line, no quotes,
+        id columns that pandas would leave as the strings they are (text, or integers that print
+        back unchanged) with none of its NA words, a textual run name.  Anything else -- and any
+        parse problem -- returns None and the pandas route decides."""
+        if dtype != np.float32:
+            return None
+        try:
+            if f.stat().st_size < (1 << 18):
+                return None
+            from fast_forward_amd import native
+
+            native.lib()
+            run = native.RunFile(f, None)
+        except (ImportError, OSError, ValueError, IndexError):
+            return None
+        try:
+            q_flags, id_flags, misc = run.flags()
+
+            def strings_survive(flags: int) -> bool:
+                if flags & native.TOKEN_NA:
+                    return False
+                return bool(flags & native.TOKEN_TEXT) or flags == native.TOKEN_INT
+
+            name = run.tag
+            if misc or not name or not strings_survive(q_flags) or not strings_survive(id_flags):
+                return None
+            if not _is_plain_text(name):
+                return None
+            pair_off, scores = run.scores()
+            q_names = np.array(run.query_ids(), dtype=object)
+            ids = np.array(run.id_strings(), dtype=object)
+        finally:
+            run.close()
+        counts = np.diff(pair_off)
+        q_of = np.repeat(np.arange(len(q_names)), counts)
+        keep = ~np.isnan(scores)
+        if not keep.all():  # dropna (ranking.py:103)
+            q_of, ids, scores = q_of[keep], ids[keep], scores[keep]
+        # q_id descending, score descending, exact ties in file order
+        rank_of = np.empty(len(q_names), dtype=np.int64)
+        rank_of[np.argsort(q_names)[::-1]] = np.arange(len(q_names))
+        q_rank = rank_of[q_of]
+        order = np.lexsort((-scores.astype(np.float64), q_rank))
+        q_sorted = q_rank[order]
+        present = np.flatnonzero(np.bincount(q_sorted, minlength=len(q_names)))
+        renumber = np.full(len(q_names), -1, dtype=np.int64)
+        renumber[present] = np.arange(present.shape[0])
+        by_rank = np.empty(len(q_names), dtype=object)
+        by_rank[rank_of] = q_names
+        out = cls._assemble({"q_id": q_names[q_of[order]], "id": ids[order], "score": scores[order]}, name,
+                            renumber[q_sorted], by_rank[present].tolist())
+        if queries is not None:
+            out._df = _with_queries(out._df, queries)
+        return out
+
     def _save_native(self, target: Path) -> bool:
         """The same bytes through libffx's threaded formatter (pandas' to_csv spends seconds on a
         million rows); False when the library is not there or a field would need CSV quoting."""
@@ -364,6 +437,9 @@ class Ranking:
     def from_file(cls, f: Path, queries: Mapping[str, str] | None = None,
                   dtype: np.dtype = np.dtype(np.float32)) -> "Ranking":
         """From a TREC run file; the method name is taken from its last column."""
+        fast = cls._from_file_native(Path(f), queries, np.dtype(dtype))
+        if fast is not None:
+            return fast
         df = pd.read_csv(f, sep=r"\s+", skipinitialspace=True, header=None,
                          names=["q_id", "q0", "id", "rank", "score", "name"])
         return cls(df, name=df["name"][0], queries=queries, dtype=dtype, copy=False)

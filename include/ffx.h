@@ -212,7 +212,20 @@ int ffx_ids_get(const ffx_ids* table, int32_t ordinal, const char** str, int32_t
  * (ranking.py:388-409, :279-291, :348-366) on the file-to-file path.  Candidate ids are resolved
  * against `ids` (which must outlive the run); an unknown id is FFX_NOT_FOUND (+ its line). */
 typedef struct ffx_run ffx_run;
+/* `ids` NULL: no id table to resolve against (Ranking.from_file): the candidate ids are kept as
+ * strings (ffx_run_ids_blob) and the q_id / id columns are classified the way pandas.read_csv
+ * would type them (ffx_run_flags), so a caller can tell whether the plain strings are what the
+ * reference's reader would have produced. */
+#define FFX_TOKEN_INT 1    /* an integer literal that prints back unchanged                      */
+#define FFX_TOKEN_NUMBER 2 /* another number or boolean: re-printed differently, or only column-wide */
+#define FFX_TOKEN_NA 4     /* one of pandas' NA words: the row would be dropped                  */
+#define FFX_TOKEN_TEXT 8   /* anything else: the column stays text                               */
+#define FFX_RUN_SHORT_LINE 1 /* a line with 5 fields (no run name)                               */
+#define FFX_RUN_LONG_LINE 2  /* a line with more than 6 fields                                   */
+#define FFX_RUN_QUOTES 4     /* a double quote somewhere in the file                             */
 int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* bad_line);
+int ffx_run_flags(const ffx_run* run, int32_t* q_flags, int32_t* id_flags, int32_t* misc_flags);
+int ffx_run_ids_blob(const ffx_run* run, char* buf, int64_t cap, int64_t* needed);
 int ffx_run_close(ffx_run* run);
 int ffx_run_counts(const ffx_run* run, int64_t* n_queries, int64_t* n_pairs);
 int ffx_run_query_id(const ffx_run* run, int64_t q, const char** str, int32_t* len);

@@ -239,3 +239,77 @@ def test_save_of_a_large_ranking_is_byte_identical_to_pandas(tmp_path, monkeypat
         ranking.save(b)
         monkeypatch.undo()
         assert a.read_bytes() == b.read_bytes()
+
+
+def _run_lines(rng, n_q, k, id_fmt="D{}", q_fmt="q{:03d}", name="bm25"):
+    lines = []
+    for q in rng.permutation(n_q):
+        docs = rng.choice(10**6, size=k, replace=False)
+        scores = np.sort(rng.random(k).astype(np.float32) * 30)[::-1]
+        scores[rng.integers(0, k, 3)] = scores[0]  # exact ties
+        lines += [f"{q_fmt.format(q)} Q0 {id_fmt.format(d)} {r + 1} {s} {name}" for r, (d, s) in enumerate(zip(docs, scores))]
+    return lines
+
+
+@pytest.mark.parametrize("case", ["text ids", "integer ids", "leading zeros", "na word", "nan score", "quotes", "short line",
+                                  "numeric name", "float ids", "mixed ids", "tabs and blank lines"])
+def test_from_file_native_parser_equals_the_pandas_route(tmp_path, monkeypatch, case):
+    """Large run files go through libffx's threaded parser when that provably gives what
+    read_csv + the constructor give, and through pandas otherwise: either way the Ranking is the
+    same frame, row for row, with the same name."""
+    rng = np.random.default_rng(len(case))
+    kwargs = {"integer ids": dict(id_fmt="{}", q_fmt="{}"), "leading zeros": dict(id_fmt="0{}"), "numeric name": dict(name="7"),
+              "float ids": dict(id_fmt="{}.50"), "mixed ids": dict(id_fmt="{}")}.get(case, {})
+    lines = _run_lines(rng, 40, 400, **kwargs)
+    if case == "na word":
+        lines[1234] = lines[1234].replace(lines[1234].split()[2], "NA")
+    if case == "nan score":
+        parts = lines[777].split()
+        parts[4] = "nan"
+        lines[777] = " ".join(parts)
+    if case == "quotes":
+        lines[50] = lines[50].replace(" Q0 ", ' Q0 "') .replace(" 51 ", '" 51 ')
+    if case == "short line":
+        lines[9000] = " ".join(lines[9000].split()[:5])
+    if case == "mixed ids":
+        lines[5] = lines[5].replace(lines[5].split()[2], "doc-five")
+    text = "\n".join(lines) + "\n"
+    if case == "tabs and blank lines":
+        text = text.replace(" ", "\t", 3000).replace("\n", "\n\n", 7)
+    path = tmp_path / "run.tsv"
+    path.write_text(text)
+    assert path.stat().st_size > 1 << 18
+    calls = []
+    real = Ranking._from_file_native.__func__
+
+    def spy(cls, f, queries, dtype):
+        out = real(cls, f, queries, dtype)
+        calls.append(out is not None)
+        return out
+
+    monkeypatch.setattr(Ranking, "_from_file_native", classmethod(spy))
+    got = Ranking.from_file(path)
+    monkeypatch.setattr(Ranking, "_from_file_native", classmethod(lambda cls, f, queries, dtype: None))
+    want = Ranking.from_file(path)
+    native_expected = case in ("text ids", "integer ids", "nan score", "mixed ids", "tabs and blank lines")
+    assert calls == [native_expected], case
+    pd.testing.assert_frame_equal(got._df, want._df)
+    assert str(got.name) == str(want.name) and got.q_ids == want.q_ids and got == want
+    assert np.array_equal(got._numbering()[0], want._numbering()[0]) and got._numbering()[1] == want._numbering()[1]
+    if native_expected:
+        queries = {q: f"text of {q}" for q in got.q_ids}
+        monkeypatch.setattr(Ranking, "_from_file_native", classmethod(real))
+        with_q = Ranking.from_file(path, queries=queries)
+        pd.testing.assert_frame_equal(with_q._df, want.attach_queries(queries)._df)
+        with pytest.raises(ValueError):
+            Ranking.from_file(path, queries={"only": "one"})
+
+
+def test_from_file_native_parser_reports_repeated_pairs(tmp_path):
+    rng = np.random.default_rng(1)
+    lines = _run_lines(rng, 40, 400)
+    lines.append(lines[10])
+    path = tmp_path / "dup.tsv"
+    path.write_text("\n".join(lines) + "\n")
+    with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
+        Ranking.from_file(path)
