@@ -325,7 +325,15 @@ class Ranking:
     # ---- reshaping -------------------------------------------------------------------------
     def attach_queries(self, queries: Mapping[str, str]) -> "Ranking":
         """Copy of this ranking with query strings attached (``ValueError`` if incomplete)."""
-        return Ranking(self._df, self.name, queries=queries, dtype=self._df.dtypes["score"], copy=True, is_sorted=True)
+        if any(q not in queries for q in self._q_order):
+            raise ValueError("Queries are incomplete.")
+        # rows, order and pairs are this ranking's own: nothing to re-check, the texts follow the
+        # per-row query numbers
+        cols = {c: self._df[c].to_numpy().copy() for c in (*_KEY, "score")}
+        texts = np.empty(len(self._q_order), dtype=object)
+        texts[:] = [queries[q] for q in self._q_order]
+        cols["query"] = texts[self._q_no] if len(self._q_order) else np.empty(0, dtype=object)
+        return Ranking._assemble(cols, self.name, self._q_no, self._q_order)
 
     def cut(self, cutoff: int) -> "Ranking":
         """Keep the ``cutoff`` best candidates of every query (frame is sorted by score)."""
