@@ -337,6 +337,17 @@ class Ranking:
 
     def cut(self, cutoff: int) -> "Ranking":
         """Keep the ``cutoff`` best candidates of every query (frame is sorted by score)."""
+        q_no = self._q_no
+        if len(q_no) and (np.diff(q_no) >= 0).all():
+            # rows of a query are adjacent (always, for a sorted frame): rank = position inside the run
+            starts = np.zeros(len(self._q_order) + 1, dtype=np.int64)
+            np.cumsum(np.bincount(q_no, minlength=len(self._q_order)), out=starts[1:])
+            keep = np.flatnonzero(np.arange(len(q_no)) - starts[q_no] < cutoff)
+            cols = {c: self._df[c].to_numpy()[keep] for c in self._df.columns}
+            present = np.flatnonzero(np.bincount(q_no[keep], minlength=len(self._q_order)))
+            renumber = np.full(len(self._q_order), -1, dtype=np.int64)
+            renumber[present] = np.arange(present.shape[0])
+            return Ranking._assemble(cols, self.name, renumber[q_no[keep]], [self._q_order[i] for i in present])
         top = self._df[_ranks_within_query(self._df) <= cutoff]
         return self._derived(top.reset_index(drop=True), is_sorted=True, copy=True)
 

@@ -313,3 +313,19 @@ def test_from_file_native_parser_reports_repeated_pairs(tmp_path):
     path.write_text("\n".join(lines) + "\n")
     with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
         Ranking.from_file(path)
+
+
+def test_cut_on_arrays_equals_the_frame_route():
+    from fast_forward_amd.ranking import _ranks_within_query
+
+    rng = np.random.default_rng(0)
+    run = {f"q{q}": {f"d{d}": float(rng.integers(0, 5)) for d in rng.choice(50, size=int(rng.integers(0, 30)), replace=False)}
+           for q in range(12)}
+    r = Ranking.from_run(run, queries={f"q{q}": f"t{q}" for q in range(12)})
+    for cutoff in (0, 1, 3, 100):
+        got = r.cut(cutoff)
+        top = r._df[_ranks_within_query(r._df) <= cutoff].reset_index(drop=True)
+        want = Ranking(top, name=r.name, dtype=np.dtype(np.float32), copy=True, is_sorted=True)
+        pd.testing.assert_frame_equal(got._df, want._df)
+        assert got.q_ids == want.q_ids and got._numbering()[1] == want._numbering()[1]
+        assert np.array_equal(got._numbering()[0], want._numbering()[0])
