@@ -97,6 +97,8 @@ class Ranking:
         (query, id) pair and for incomplete ``queries`` (ranking.py:67-121).
         """
         self.name = name
+        if self._init_from_columns(df, queries, np.dtype(dtype), copy, is_sorted):
+            return
         if not getattr(df, "_ffx_pairs_unique", False) and df.duplicated(subset=_KEY).any():
             raise ValueError("Only one score per query-document/passage pair is allowed.")
 
@@ -126,6 +128,58 @@ class Ranking:
         self._q_ids = set(self._q_order)
         if queries is not None:
             self._df = _with_queries(self._df, queries)
+
+    def _init_from_columns(self, df: pd.DataFrame, queries, dtype: np.dtype, copy: bool, is_sorted: bool) -> bool:
+        """The constructor for the ordinary large frame -- string ids, numeric scores, nothing missing
+        but possibly some scores -- on column arrays: each id column is numbered once and the
+        duplicate check, the NaN drop, the sort and the per-row query numbers all work on integers.
+        Returns False (nothing done) for anything else; the general code below then decides."""
+        from pandas.api.types import infer_dtype, is_bool_dtype, is_numeric_dtype
+
+        if len(df) < 2048 or any(c not in df.columns for c in (*_KEY, "score")):
+            return False
+        s_col = df["score"]
+        if not is_numeric_dtype(s_col.dtype) or is_bool_dtype(s_col.dtype) or not isinstance(s_col.dtype, np.dtype):
+            return False
+        text_cols = [*_KEY] + (["query"] if "query" in df.columns else [])
+        if any(df[c].dtype != object or infer_dtype(df[c], skipna=False) != "string" for c in text_cols):
+            return False
+        q, ids, score = df["q_id"].to_numpy(), df["id"].to_numpy(), s_col.to_numpy()
+        query = df["query"].to_numpy() if "query" in df.columns else None
+        q_code, q_names = pd.factorize(q)
+        if not getattr(df, "_ffx_pairs_unique", False):
+            id_code, id_names = pd.factorize(ids)
+            key = q_code.astype(np.int64) * max(1, len(id_names)) + id_code
+            key.sort()
+            if (key[1:] == key[:-1]).any():
+                raise ValueError("Only one score per query-document/passage pair is allowed.")
+        rows = None  # None: every row, in frame order
+        if score.dtype.kind == "f":
+            missing = np.isnan(score)
+            if missing.any():
+                rows = np.flatnonzero(~missing)
+        score = score.astype(dtype, copy=True) if rows is None else score[rows].astype(dtype)
+        codes = q_code if rows is None else q_code[rows]
+        if not is_sorted:
+            rank_of = np.empty(len(q_names), dtype=np.int64)
+            rank_of[np.argsort(np.asarray(q_names, dtype=object))[::-1]] = np.arange(len(q_names))
+            order = np.lexsort((-score.astype(np.float64), rank_of[codes]))
+            rows = order if rows is None else rows[order]
+            score, codes = score[order], codes[order]
+
+        def column(a: np.ndarray) -> np.ndarray:
+            return a[rows] if rows is not None else (a.copy() if copy else a)
+
+        cols = {"q_id": column(q), "id": column(ids), "score": score}
+        if query is not None:
+            cols["query"] = column(query)
+        self._df = pd.DataFrame(cols, copy=False)
+        self._q_no, firsts = pd.factorize(codes)
+        self._q_order = [q_names[i] for i in firsts]
+        self._q_ids = set(self._q_order)
+        if queries is not None:
+            self._df = _with_queries(self._df, queries)
+        return True
 
     @classmethod
     def _assemble(cls, columns: Mapping[str, np.ndarray], name: str | None, q_no: np.ndarray, q_order: list[str]) -> "Ranking":

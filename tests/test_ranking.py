@@ -329,3 +329,44 @@ def test_cut_on_arrays_equals_the_frame_route():
         pd.testing.assert_frame_equal(got._df, want._df)
         assert got.q_ids == want.q_ids and got._numbering()[1] == want._numbering()[1]
         assert np.array_equal(got._numbering()[0], want._numbering()[0])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_column_array_constructor_equals_the_general_one(monkeypatch, seed):
+    """Frames of >= 2048 rows with string ids take the constructor's integer-key route: same frame
+    (rows, order, dtypes), same numbering, same errors as the general pandas route, for sorted and
+    unsorted input, missing scores, attached or separate queries, float64 and int scores."""
+    rng = np.random.default_rng(seed)
+    n_q, k = 30, 100
+    rows = []
+    for q in rng.permutation(n_q):
+        for d in rng.choice(5000, size=k, replace=False):
+            rows.append((f"q{q:02d}", f"doc{d}", float(rng.integers(0, 6)) if seed % 2 else float(rng.standard_normal())))
+    df = pd.DataFrame(rows, columns=["q_id", "id", "score"])
+    if seed in (2, 3):
+        df.loc[rng.choice(len(df), size=50, replace=False), "score"] = np.nan
+    if seed == 4:
+        df["score"] = rng.integers(0, 100, size=len(df))  # integer scores
+    if seed in (5, 6):
+        df["query"] = "text of " + df["q_id"]
+    if seed == 7:
+        df["extra"] = 1.0  # dropped by both routes
+    kwargs = dict(name="n", dtype=np.dtype(np.float64) if seed == 6 else np.dtype(np.float32))
+    queries = {f"q{q:02d}": f"Q{q}" for q in range(n_q)} if seed in (1, 3) else None
+    for is_sorted in (False, True):
+        frame = df if not is_sorted else Ranking(df, **kwargs)._df
+        fast = Ranking(frame, queries=queries, is_sorted=is_sorted, **kwargs)
+        with monkeypatch.context() as m:
+            m.setattr(Ranking, "_init_from_columns", lambda self, *a: False)
+            slow = Ranking(frame, queries=queries, is_sorted=is_sorted, **kwargs)
+        pd.testing.assert_frame_equal(fast._df, slow._df)
+        assert fast.q_ids == slow.q_ids and fast._numbering()[1] == slow._numbering()[1]
+        assert np.array_equal(fast._numbering()[0], slow._numbering()[0])
+    # the input frame is never modified, and copy=True really copies
+    before = df.copy()
+    r = Ranking(df, copy=True, is_sorted=False, **kwargs)
+    pd.testing.assert_frame_equal(df, before)
+    dup = pd.concat([df, df.iloc[[17]]])
+    with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
+        Ranking(dup, **kwargs)
+    assert r._df["score"].dtype == kwargs["dtype"]
