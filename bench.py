@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: re-ranked queries/sec at k=5000, 768-d fp32, MS MARCO passage scale.
 
-    python bench.py [--gpus N --steps K --warmup W]       (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: one rank per GPU.  Either launched by `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or plainly as
+`python bench.py --gpus N`: then this process starts the N ranks itself (before it touches the GPU),
+relays rank 0's JSON line and exits with their status.  The ranks talk through libffx's own
+communicator (RCCL over xGMI; `--transport host` = shared memory, for ranks that share a GPU).
 
 One *step* = one pass of the re-ranking hot path over one batch of synthetic first-stage
-candidates: expand candidates -> gather_dot (HIP) -> MaxP segment reduce + alpha interpolation
-(-> score exchange between ranks when N>1).  All inputs (index, query vectors, candidate CSR,
-sparse scores) are resident in HBM before the timed region; outputs stay in HBM.
+candidates: expand candidates -> gather_dot (HIP) -> MaxP segment reduce + alpha interpolation ->
+per-query ordering (N > 1: local gather_dot -> all-to-all of scores -> owner-side interpolation +
+ordering).  All inputs (index, query vectors, candidate CSR, sparse scores) are resident in HBM
+before the timed region; outputs stay in HBM.
 
 Prints ONE JSON line (rank 0) with the fields the driver expects plus
   "roofline":     achieved algorithmic GB/s of the gather_dot kernel vs the 8 TB/s HBM peak,
                   kernel time measured with HIP events on the kernel's own stream
   "cpu_baseline": the reference-equivalent NumPy path (oracle port) timed on this host on a
-                  bounded sample of the same workload.
+                  bounded sample of the same workload
+  "regions":      SURVEY.md 8(d)'s timed regions side by side: (i) device-resident without / with the
+                  ordering, (ii) host buffers in -> host buffers out through ffx_score (page-locked and
+                  pageable), (iii) Index.rerank from a Ranking of strings; and what the box streams.
 """
 
 from __future__ import annotations
@@ -20,8 +30,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+import uuid
 from pathlib import Path
 
 import numpy as np
@@ -51,7 +63,12 @@ def parse_args():
     ap.add_argument("--sum", default="exact", choices=["exact", "fast"], help="summation order of gather_dot")
     ap.add_argument("--store", default="f32", choices=["f32", "f16", "pq"], help="row storage: float32, float16, or PQ codes (M=8, Ks=256)")
     ap.add_argument("--alpha", type=float, default=0.1)
-    ap.add_argument("--sort", action="store_true", help="also order every query's candidates on the device")
+    ap.add_argument("--sort", dest="sort", action="store_true", default=True,
+                    help="order every query's candidates on the device as part of the step (default)")
+    ap.add_argument("--no-sort", dest="sort", action="store_false", help="leave the ordering out of the step")
+    ap.add_argument("--no-regions", dest="regions", action="store_false", default=True,
+                    help="skip the side measurements (host-to-host, Index API, stream ceiling) of the 1-GPU line")
+    ap.add_argument("--api-queries", type=int, default=6980, help="queries of the Index-API region (iii); 0: skip")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-sample-queries", type=int, default=64, help="queries in the CPU-baseline sample (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work to measure for the baseline")
@@ -61,9 +78,24 @@ def parse_args():
                     help="multi-GPU layout: rows = index row-sharded by document + all-to-all of scores (north star); "
                          "queries = every rank holds the whole index and scores its block of the queries, no exchange "
                          "(the zero-communication comparison point when the index fits one GPU)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: rehearse N ranks on ONE GPU (exchange staged through the host; RCCL needs one GPU per rank)")
-    return ap.parse_args()
+    ap.add_argument("--transport", default=None, choices=["rccl", "host"],
+                    help="rccl (default): RCCL over xGMI, one GPU per rank; host: the exchange staged through shared "
+                         "memory, so N ranks can rehearse on ONE GPU (RCCL refuses ranks that share a device)")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"], help="older spelling of --transport (gloo = host)")
+    args = ap.parse_args()
+    if args.transport is None:
+        args.transport = "host" if args.dist_backend == "gloo" else "rccl"
+    return args
+
+
+def metric_name(args) -> str:
+    store = {"f32": "fp32", "f16": "fp16", "pq": "PQ(M=8,Ks=256)"}[args.store]
+    return f"re-ranked queries/sec at k={args.k}, {args.dim}-d {store}; achieved HBM GB/s vs peak"
+
+
+def compute_dtype(args) -> str:
+    """The arithmetic type of the path: fp32 products and sums whatever the rows are stored as."""
+    return {"f32": "f32", "f16": "f32 (rows stored as f16, widened exactly)", "pq": "f32 (rows stored as u8 PQ codes)"}[args.store]
 
 
 def doc_layout(n_rows: int, layout: str, seed: int):
@@ -175,23 +207,52 @@ def cpu_baseline(args, doc_off, n_docs, scale):
     return out, (ids, sparse, interp)
 
 
-def bench_sharded(args, rank: int, world: int, local_rank: int):
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes BEFORE this
+    process makes any GPU call (it never does), let them print (rank 0 prints the JSON line), and
+    return their status.  Never exec from a process that has touched the GPU."""
+    key = f"bench_{os.getpid()}_{uuid.uuid4().hex[:12]}"
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   FFX_RDZV_KEY=key, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    status, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and status == 0:
+                status = p.returncode  # one rank failed: give the others a moment (they fail at their next collective), then stop them
+                deadline = time.monotonic() + 30
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()  # the exact children started above
+        time.sleep(0.05)
+    for p in procs:
+        if p.returncode != 0 and status == 0:
+            status = p.returncode
+    return status
+
+
+def gather_stats(comm, st: dict) -> list[dict]:
+    """Every rank's per-step figures, in rank order (control plane of the communicator)."""
+    keys = ("ms_gather_dot", "ms_expand", "ms_total", "n_rows", "n_pairs", "own_pairs", "own_queries", "send_bytes", "recv_bytes", "kernel_variant")
+    mine = np.array([float(st[k]) for k in keys], dtype=np.float64)
+    return [dict(zip(keys, row.tolist())) for row in comm.allgather_array(mine)]
+
+
+def bench_sharded(args, rank: int, world: int):
     """bench.py --gpus N>1: the SAME workload as N=1 (fixed index, queries and k: strong
-    scaling), index row-sharded by document, one rank per GPU."""
-    import torch
-    import torch.distributed as dist
+    scaling), index row-sharded by document, one rank per GPU, scores exchanged through libffx's
+    communicator (RCCL, or shared memory with --transport host)."""
+    from fast_forward_amd.sharded import ShardedScorer, connect, doc_partition, query_partition
 
-    from fast_forward_amd.sharded import ShardedScorer, doc_partition
-
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo")
-    else:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.transport == "rccl" and native.device_count() < world:
+        sys.exit(f"--gpus {world} over RCCL needs {world} GPUs, {native.device_count()} visible (use --transport host to rehearse on fewer)")
+    comm = connect(args.transport, rank=rank, world=world)
+    local_rank = comm.device
     if args.sharding == "queries":
-        return bench_replicas(args, rank, world, local_rank, dist, torch)
+        return bench_replicas(args, comm)
     scale = float(1.0 / np.sqrt(args.dim))
     doc_off = doc_layout(args.rows, args.layout, args.seed)
     n_docs = doc_off.shape[0] - 1
@@ -201,6 +262,8 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
     n_local = r_hi - r_lo
 
     store = np.float16 if args.store == "f16" else np.float32
+    if args.store == "pq":
+        sys.exit("--store pq is a single-GPU leg")
     shard = native.DeviceIndex(max(n_local, 1), args.dim, device=local_rank, dtype=store)
     shard.fill_synthetic(args.seed, scale, 0, n_local, first_global_row=r_lo)
     shard.set_doc_rows(doc_off[d_lo:d_hi + 1] - r_lo, np.arange(n_local, dtype=np.int32))
@@ -209,89 +272,95 @@ def bench_sharded(args, rank: int, world: int, local_rank: int):
     pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
     queries = synth.rows(args.seed + 3, scale, 0, args.queries, args.dim)
 
-    scorer = ShardedScorer(shard, doc_bounds, rank, world, local_rank)
+    scorer = ShardedScorer(shard, doc_bounds, comm)
     scorer.set_queries(queries)
+    t_route = time.perf_counter()
     scorer.set_pairs(pair_off, ids, sparse, MODE_NO[args.mode])
+    t_route = time.perf_counter() - t_route
     exact = args.sum == "exact"
 
     for _ in range(args.warmup):
         scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
     scorer.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    coll_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    ms_per_step = float(elapsed.item()) * 1e3 / args.steps
+    scorer.sync()       # this rank's streams have drained ...
+    comm.barrier()      # ... and so have everybody else's
+    elapsed = float(comm.allreduce([time.perf_counter() - t0], native.OP_MAX)[0])
+    ms_per_step = elapsed * 1e3 / args.steps
 
-    # kernel time of the last step on this rank (HIP events on the stream the kernel ran on)
-    st = scorer.plan.stats()
+    # one more step, alone (no neighbour batch to overlap with): per-rank kernel time from HIP events on the
+    # stream the kernel ran on
+    scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
+    per_rank = gather_stats(comm, scorer.stats())
     row_bytes = args.dim * np.dtype(store).itemsize + 4
-    mine = torch.tensor([st["ms_gather_dot"], float(st["n_rows"])], dtype=torch.float64, device=coll_dev)
-    allr = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allr, mine)
-    per_rank = [(float(t[0]), int(t[1])) for t in allr]
 
     # parity: owned queries' interpolated scores vs the oracle on a small sample (rank 0 only)
-    parity = None
+    parity = base = None
     if rank == 0 and args.cpu_sample_queries > 0:
-        args.cpu_sample_queries = min(args.cpu_sample_queries, scorer.route.q_hi)
+        args.cpu_sample_queries = min(args.cpu_sample_queries, scorer.q_hi)
         base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale)
         _, interp, _ = scorer.fetch()
         n_s = s_ids.shape[0]
         ok = np.array_equal(interp[:n_s].view(np.uint32), s_interp.view(np.uint32)) if exact else bool(np.abs(interp[:n_s] - s_interp).max() <= 1e-4)
         parity = ("bit-exact" if exact else "within 1e-4") if ok else "MISMATCH"
+    failed = parity == "MISMATCH"
     if rank == 0:
-        slowest = max(per_rank, key=lambda t: t[0])
-        achieved = slowest[1] * row_bytes / (slowest[0] * 1e-3) / 1e9
+        slowest = max(per_rank, key=lambda t: t["ms_gather_dot"])
+        achieved = slowest["n_rows"] * row_bytes / (slowest["ms_gather_dot"] * 1e-3) / 1e9
         dev = native.device_info(local_rank)
+        rows_per_rank = [int(t["n_rows"]) for t in per_rank]
+        cap = int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize))
         result = {
-            "metric": "re-ranked queries/sec at k=5000, 768-d fp32; achieved HBM GB/s vs peak",
+            "metric": metric_name(args),
             "value": args.queries / (ms_per_step * 1e-3), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": compute_dtype(args), "data": "synthetic",
             "config": {
                 "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} {'fp16' if args.store == 'f16' else 'fp32'} index row-sharded by document over "
                             f"{world} GPUs ({n_local} rows on rank 0), {args.queries} queries, k={args.k}, Mode.{args.mode}, "
-                            f"alpha={args.alpha}, sum={args.sum}; per step: local gather_dot, RCCL all-to-all of dense scores to "
-                            f"the owning rank, owner-side interpolation{' + sort' if args.sort else ''}",
+                            f"alpha={args.alpha}, sum={args.sum}; per step: local gather_dot, all-to-all of dense scores to "
+                            f"the owning rank ({'ncclSend/ncclRecv full mesh' if args.transport == 'rccl' else 'shared-memory rehearsal transport'}), "
+                            f"owner-side interpolation{' + per-query ordering' if args.sort else ''}",
                 "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
-                "layout": args.layout, "sum": args.sum, "pairs": int(pair_off[-1]),
+                "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": int(pair_off[-1]), "store": args.store,
                 "sharding": f"rows by document, {world} ranks; queries owned in {world} contiguous blocks",
                 "rows_per_rank": [int(doc_off[doc_bounds[r + 1]] - doc_off[doc_bounds[r]]) for r in range(world)],
             },
             "roofline": {
-                "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']}), slowest rank of the last step",
+                "bound": "hbm", "kernel": f"gather_dot (variant {int(slowest['kernel_variant'])}), slowest rank of one step",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms_per_rank": [t[0] for t in per_rank], "gathered_rows_per_rank": [t[1] for t in per_rank],
+                "kernel_ms_per_rank": [t["ms_gather_dot"] for t in per_rank], "gathered_rows_per_rank": rows_per_rank,
             },
-            "exchange_bytes_per_rank": int(scorer.route.recv_counts.sum() - scorer.route.recv_counts[rank]) * 4,
+            "transport": args.transport, "rccl_ranks": world if args.transport == "rccl" else 0,
+            "load_balance": {"gathered_rows_max": max(rows_per_rank), "gathered_rows_mean": float(np.mean(rows_per_rank)),
+                             "max_over_mean": max(rows_per_rank) / max(1.0, float(np.mean(rows_per_rank)))},
+            "exchange_bytes_per_rank": {"sent": [int(t["send_bytes"]) for t in per_rank], "received": [int(t["recv_bytes"]) for t in per_rank]},
+            "local_step_ms_per_rank": [t["ms_total"] for t in per_rank],
+            "owned_pairs_per_rank": [int(t["own_pairs"]) for t in per_rank],
+            "route_and_upload_s": t_route,
             "device": dev["name"],
-            "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize)),
-            "index_capacity_rows_total": world * int(dev["total_bytes"] * 0.97 // (args.dim * np.dtype(store).itemsize)),
+            "index_capacity_rows_per_gpu": cap, "index_capacity_rows_total": world * cap,
         }
         if parity is not None:
             result["cpu_baseline"] = base
             result["parity_on_cpu_sample"] = parity
-        print(json.dumps(result))
-        if parity == "MISMATCH":
-            dist.destroy_process_group()
-            sys.exit("sharded GPU scores disagree with the CPU oracle on the sampled queries")
-    dist.barrier()
-    dist.destroy_process_group()
+        print(json.dumps(result), flush=True)
+    failed = bool(comm.allreduce([1.0 if failed else 0.0], native.OP_MAX)[0])
+    scorer.close()
+    comm.close()
+    if failed:
+        sys.exit("sharded GPU scores disagree with the CPU oracle on the sampled queries")
 
 
-def bench_replicas(args, rank: int, world: int, local_rank: int, dist, torch):
+def bench_replicas(args, comm):
     """--sharding queries: the whole index on every GPU, queries split into `world` contiguous blocks,
     no data-path collective.  Same workload and same `value` definition as the row-sharded leg."""
     from fast_forward_amd.sharded import query_partition
 
+    rank, world, local_rank = comm.rank, comm.world, comm.device
     scale = float(1.0 / np.sqrt(args.dim))
     doc_off = doc_layout(args.rows, args.layout, args.seed)
     n_docs = doc_off.shape[0] - 1
@@ -312,45 +381,41 @@ def bench_replicas(args, rank: int, world: int, local_rank: int, dist, torch):
     for _ in range(args.warmup):
         plan.run(args.alpha, exact_sum=exact, sort=args.sort)
     plan.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         plan.run(args.alpha, exact_sum=exact, sort=args.sort)
     plan.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    coll_dev = "cpu" if args.dist_backend == "gloo" else f"cuda:{local_rank}"
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    ms_per_step = float(elapsed.item()) * 1e3 / args.steps
+    comm.barrier()
+    elapsed = float(comm.allreduce([time.perf_counter() - t0], native.OP_MAX)[0])
+    ms_per_step = elapsed * 1e3 / args.steps
     st = plan.stats()
-    mine = torch.tensor([st["ms_gather_dot"], float(st["n_rows"])], dtype=torch.float64, device=coll_dev)
-    allr = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allr, mine)
-    per_rank = [(float(t[0]), int(t[1])) for t in allr]
+    st.update(own_pairs=st["n_pairs"], own_queries=q_hi - q_lo, send_bytes=0, recv_bytes=0)
+    per_rank = gather_stats(comm, st)
+    failed = False
     if rank == 0:
         row_bytes = args.dim * np.dtype(store).itemsize + 4
-        slowest = max(per_rank, key=lambda t: t[0])
-        achieved = slowest[1] * row_bytes / (slowest[0] * 1e-3) / 1e9
+        slowest = max(per_rank, key=lambda t: t["ms_gather_dot"])
+        achieved = slowest["n_rows"] * row_bytes / (slowest["ms_gather_dot"] * 1e-3) / 1e9
         result = {
-            "metric": "re-ranked queries/sec at k=5000, 768-d fp32; achieved HBM GB/s vs peak",
+            "metric": metric_name(args),
             "value": args.queries / (ms_per_step * 1e-3), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": compute_dtype(args), "data": "synthetic",
             "config": {
                 "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} index replicated on {world} GPUs, "
                             f"{args.queries} queries split into {world} blocks, k={args.k}, Mode.{args.mode}, alpha={args.alpha}, "
                             f"sum={args.sum}; no exchange (comparison point of the row-sharded layout)",
                 "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
-                "layout": args.layout, "sum": args.sum, "pairs": args.queries * args.k,
+                "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": args.queries * args.k, "store": args.store,
                 "sharding": f"queries: {world} replicas, contiguous query blocks",
             },
             "roofline": {
-                "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']}), slowest rank of the last step",
+                "bound": "hbm", "kernel": f"gather_dot (variant {int(slowest['kernel_variant'])}), slowest rank of the last step",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms_per_rank": [t[0] for t in per_rank], "gathered_rows_per_rank": [t[1] for t in per_rank],
+                "kernel_ms_per_rank": [t["ms_gather_dot"] for t in per_rank], "gathered_rows_per_rank": [int(t["n_rows"]) for t in per_rank],
             },
+            "transport": args.transport,
         }
         if args.cpu_sample_queries > 0:
             args.cpu_sample_queries = min(args.cpu_sample_queries, q_hi - q_lo)
@@ -360,28 +425,120 @@ def bench_replicas(args, rank: int, world: int, local_rank: int, dist, torch):
             ok = np.array_equal(interp[:n_s].view(np.uint32), s_interp.view(np.uint32)) if exact else bool(np.abs(interp[:n_s] - s_interp).max() <= 1e-4)
             result["cpu_baseline"] = base
             result["parity_on_cpu_sample"] = ("bit-exact" if exact else "within 1e-4") if ok else "MISMATCH"
-        print(json.dumps(result))
-        if result.get("parity_on_cpu_sample") == "MISMATCH":
-            dist.destroy_process_group()
-            sys.exit("GPU scores disagree with the CPU oracle on the sampled queries")
-    dist.barrier()
-    dist.destroy_process_group()
+            failed = not ok
+        print(json.dumps(result), flush=True)
+    failed = bool(comm.allreduce([1.0 if failed else 0.0], native.OP_MAX)[0])
+    plan.close()
+    comm.close()
+    if failed:
+        sys.exit("GPU scores disagree with the CPU oracle on the sampled queries")
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if world > 1 or args.force_sharded:
-        for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-            os.environ.setdefault(key, val)
-        return bench_sharded(args, rank, world, local_rank)
+def timed(fn, reps: int) -> float:
+    """Best of `reps` wall-clock times of fn(), in ms."""
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
 
+
+def side_regions(args, index, plan, queries, pair_off, ids, sparse, exact: bool) -> dict:
+    """the regions around the headline, measured in this same run.  (i) was timed by
+    the caller; here (ii) host buffers in -> host buffers out through ffx_score, and what the box
+    streams (the same kernel reading every row of the index exactly once)."""
+    mode = MODE_NO[args.mode]
+    out = {}
+    # (i) without the ordering
+    plan.run(args.alpha, exact_sum=exact, sort=False)
+    plan.sync()
+    out["i_device_ms"] = timed(lambda: (plan.run(args.alpha, exact_sum=exact, sort=False), plan.sync()), 5)
+    # (ii) ffx_score, scores + order: caller's arrays pageable, then page-locked
+    n = int(pair_off[-1])
+    out["ii_pageable_ms"] = timed(lambda: native.score(index, queries, pair_off, ids, mode, sparse, args.alpha, exact_sum=exact, sort=args.sort), 2)
+    p_q = native.pinned_empty(queries.shape, np.float32)
+    p_ids, p_sp = native.pinned_empty(n, np.int32), native.pinned_empty(n, np.float32)
+    p_q[...], p_ids[...], p_sp[...] = queries, ids, sparse
+    outs = (native.pinned_empty(n, np.float32), native.pinned_empty(n, np.float32), native.pinned_empty(n, np.int32))
+    run_ii = lambda: native.score(index, p_q, pair_off, p_ids, mode, p_sp, args.alpha, exact_sum=exact, sort=args.sort, out=outs)  # noqa: E731
+    run_ii()
+    out["ii_pinned_ms"] = timed(run_ii, 4)
+    out["ii_pinned_queries_per_s"] = args.queries / (out["ii_pinned_ms"] * 1e-3)
+    out["ii_note"] = ("ffx_score: candidate CSR + sparse scores + query vectors in host memory -> dense + interpolated scores"
+                      f"{' + per-query order' if args.sort else ''} in host memory ({(n * (8 + 4 * (3 if args.sort else 2)) + queries.nbytes) / 1e6:.0f} MB over PCIe "
+                      "per step); slices of whole queries alternate between two plans so copies overlap the kernels")
+    # what the box streams: every row once, in order and in a random permutation
+    if args.store != "pq" and args.layout == "single":
+        row_bytes = args.dim * index.dtype.itemsize + 4
+        n_rows = args.rows
+        q4 = np.ascontiguousarray(queries[:4])
+        off4 = np.array([0, n_rows // 4, n_rows // 2, 3 * (n_rows // 4), n_rows], dtype=np.int64)
+        sweep = native.Plan(index)
+        sweep.set_queries(q4)
+        ceil = {}
+        for label, rows in (("in_order", np.arange(n_rows, dtype=np.int32)),
+                            ("permuted", np.random.default_rng(0).permutation(n_rows).astype(np.int32))):
+            sweep.set_pairs(off4, rows, None, 1)
+            ms = []
+            for _ in range(4):
+                sweep.run(0.0, exact_sum=exact)
+                ms.append(sweep.stats()["ms_gather_dot"])
+            ceil[label] = n_rows * row_bytes / float(np.mean(ms[1:])) / 1e6
+        sweep.close()
+        out["stream_ceiling_GBs"] = ceil
+        out["stream_ceiling_note"] = "the gather_dot kernel itself over every index row exactly once (no reuse possible): the practical ceiling of this box for this access pattern"
+    return out
+
+
+def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
+    """Region (iii): the public API on the same index -- a first-stage ``Ranking`` of STRING ids in,
+    ``InMemoryIndex.rerank`` (= ``ranking.interpolate(index(ranking), alpha)`` with the epilogue on
+    the device) out, id resolution and frame construction included."""
+    import pandas as pd
+
+    from fast_forward_amd import Ranking
+    from fast_forward_amd.encoder import ArrayEncoder
+    from fast_forward_amd.index import InMemoryIndex, Mode
+
+    nq = min(args.api_queries, args.queries)
+    n_docs = doc_off.shape[0] - 1
+    out = {}
+    if not hasattr(InMemoryIndex, "adopt"):
+        return out
+    t0 = time.perf_counter()
+    doc_names = np.char.add("D", np.arange(n_docs).astype("U"))
+    api = InMemoryIndex.adopt(index, doc_ids=doc_names, doc_off=doc_off, mode=Mode[args.mode], exact_sum=exact)
+    out["iii_adopt_ids_s"] = time.perf_counter() - t0
+    out["iii_ids"] = n_docs
+    ids, sparse = candidates(n_docs, nq, args.k, args.seed)
+    qvecs = synth.rows(args.seed + 3, scale, 0, nq, args.dim)
+    q_names = np.char.add("q", np.char.zfill(np.arange(nq).astype("U"), 6))
+    api.query_encoder = ArrayEncoder(dict(zip(q_names.tolist(), qvecs)))
+    t0 = time.perf_counter()
+    frame = pd.DataFrame({"q_id": np.repeat(q_names, args.k), "id": doc_names[ids], "score": sparse,
+                          "query": np.repeat(q_names, args.k)})
+    first = Ranking(frame, name="first-stage", copy=False)
+    out["iii_build_first_stage_ranking_s"] = time.perf_counter() - t0
+    api.rerank(first, args.alpha)  # warm-up (plans, id caches)
+    t0 = time.perf_counter()
+    final = api.rerank(first, args.alpha)
+    out["iii_rerank_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dense = api(first)
+    t1 = time.perf_counter()
+    final2 = first.interpolate(dense, args.alpha)
+    out["iii_call_s"], out["iii_interpolate_s"] = t1 - t0, time.perf_counter() - t1
+    out["iii_pairs"] = int(nq * args.k)
+    out["iii_queries_per_s_rerank"] = nq / out["iii_rerank_s"]
+    out["iii_rerank_equals_call_then_interpolate"] = bool(final == final2)
+    out["iii_note"] = (f"{nq} queries x k={args.k} from a pandas-backed Ranking of string ids: Index.rerank (dense + interpolation + order "
+                       "on the device) vs Index.__call__ followed by Ranking.interpolate")
+    api.release()
+    return out
+
+
+def bench_single(args):
     native.require_device()
     dev = native.device_info(0)
     scale = float(1.0 / np.sqrt(args.dim))  # scores O(1): 1e-4 absolute ~ 1e-4 relative
@@ -425,33 +582,21 @@ def main():
     # per gathered row, payload + int32 row id
     row_bytes = (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize) + 4
     kern_avg_ms = float(np.mean(kern_ms))
-    traffic, traffic_src = args.traffic_bytes, "--traffic-bytes" if args.traffic_bytes else None
-    if traffic is None:
-        # PMC counters cannot be read from inside the process; use the committed rocprofv3 --pmc passes
-        # of this same command when (and only when) workload and kernel match
-        try:
-            pm = json.loads((ROOT / "profiles" / "r01" / "pmc_summary.json").read_text())["bench_gather_dot"]
-            same = (pm["algorithmic_bytes_per_launch"] == st["n_rows"] * row_bytes and args.layout == "single"
-                    and {111: "exact_lds_kernel<float, 3, 4, 8, true>", 211: "fast_kernel<float, 3, 4, 8, true>"}.get(st["kernel_variant"], "?") in pm["kernel"])
-            if same:
-                traffic, traffic_src = pm["hbm_bytes_per_launch"], "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
-        except (OSError, KeyError, ValueError):
-            pass
     achieved = st["n_rows"] * row_bytes / (kern_avg_ms * 1e-3) / 1e9
     result = {
-        "metric": "re-ranked queries/sec at k=5000, 768-d fp32; achieved HBM GB/s vs peak",
+        "metric": metric_name(args),
         "value": args.queries / (ms_per_step * 1e-3),
         "unit": "queries/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": compute_dtype(args), "data": "synthetic",
         "config": {
             "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} { {'f16': 'fp16', 'pq': 'PQ(M=8,Ks=256)'}.get(args.store, 'fp32') } InMemoryIndex in HBM, "
                         f"{args.queries} queries, k={args.k}, Mode.{args.mode}, alpha={args.alpha}, "
                         f"{'1 passage/doc' if args.layout == 'single' else '1..8 passages/doc'}, sum={args.sum}"
-                        f"{', device sort' if args.sort else ''}",
+                        f"{', per-query ordering on the device' if args.sort else ''}; inputs and outputs resident in HBM",
             "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
-            "layout": args.layout, "sum": args.sum, "pairs": st["n_pairs"], "gathered_rows": st["n_rows"],
+            "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": st["n_pairs"], "gathered_rows": st["n_rows"],
             "sharding": "none (1 GPU)", "index_bytes": args.rows * (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize), "store": args.store,
         },
         "roofline": {
@@ -460,7 +605,9 @@ def main():
                         "(exact ADC: 34.9 M lines = 4.5 GB in 0.68 ms = 6.6 TB/s, plus 0.19 ms of table build); decode-then-dot is "
                         "bound by L2->CU codeword traffic.  The fraction of algorithmic bytes is not the figure of merit here"} if args.store == "pq" else {}),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src,
+            # PMC counters cannot be read from inside the process: null unless a rocprofv3 --pmc pass of this very command
+            # is handed in (--traffic-bytes); the committed passes live under profiles/ 
+            "traffic": args.traffic_bytes, "traffic_source": "--traffic-bytes (rocprofv3 --pmc pass of this command)" if args.traffic_bytes else None,
             "algorithmic_bytes_per_launch": st["n_rows"] * row_bytes, "kernel_ms_avg": kern_avg_ms,
             "kernel_ms_min": float(np.min(kern_ms)), "kernel_ms_max": float(np.max(kern_ms)),
         },
@@ -470,6 +617,7 @@ def main():
         "index_capacity_rows_per_gpu": int(dev["total_bytes"] * 0.97 // (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize)),
     }
 
+    ok = True
     if args.cpu_sample_queries > 0:
         base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale)
         result["cpu_baseline"] = base
@@ -482,10 +630,28 @@ def main():
         else:
             ok = bool(np.abs(interp[:n_s] - s_interp).max() <= 1e-4)
         result["parity_on_cpu_sample"] = "bit-exact" if (ok and exact) else ("within 1e-4" if ok else "MISMATCH")
-        if not ok:
-            print(json.dumps(result))
-            sys.exit("GPU scores disagree with the CPU oracle on the sampled queries")
-    print(json.dumps(result))
+    if ok and args.regions:
+        regions = {"i_device_sorted_ms" if args.sort else "i_device_ms": ms_per_step}
+        regions.update(side_regions(args, index, plan, queries, pair_off, ids, sparse, exact))
+        if args.api_queries > 0 and args.store == "f32" and args.layout == "single":
+            regions.update(api_region(args, index, doc_off, scale, exact))
+        result["regions"] = regions
+    print(json.dumps(result), flush=True)
+    if not ok:
+        sys.exit("GPU scores disagree with the CPU oracle on the sampled queries")
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # no GPU call has been made in this process
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        args.gpus = world
+    if world > 1 or args.force_sharded:
+        return bench_sharded(args, rank, world)
+    return bench_single(args)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,918 @@
+// comm.hip -- multi-GPU half of the C ABI (include/ffx.h: ffx_comm_*, ffx_route, ffx_sharded_*).
+//
+// One process per GPU.  The index is row-sharded by document; every rank scores the candidates
+// whose documents it holds and the dense scores of a query travel to the rank that owns the
+// query: ONE all-to-all-v of fp32 scores per batch.  Two transports sit behind the
+// same entry points:
+//   FFX_COMM_RCCL  ncclSend/ncclRecv full mesh inside one ncclGroup on the communicator's HIP
+//                  stream -- every peer slice rides its own xGMI link.  librccl is dlopen'ed on
+//                  first use, so a single-GPU process never loads it.
+//   FFX_COMM_HOST  the same exchange staged through POSIX shared memory: ranks may share a GPU
+//                  (RCCL refuses that) or have none at all (host buffers; the CPU test-suite).
+// Nothing here depends on PyTorch; this file uses the public ABI of ffx.hip only.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is resolved with dlopen/dlsym
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ffx.h"
+
+int ffx_fail(int code, const char* fmt, ...);  // ffx.hip
+
+namespace {
+
+#define C_HIP(expr)                                                                                \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return ffx_fail(e_ == hipErrorOutOfMemory ? FFX_OOM : FFX_HIP_ERROR, "%s: %s (%s:%d)", #expr, \
+                      hipGetErrorString(e_), __FILE__, __LINE__);                                  \
+  } while (0)
+
+#define C_TRY(expr)                \
+  do {                             \
+    int rc_ = (expr);              \
+    if (rc_ != FFX_OK) return rc_; \
+  } while (0)
+
+// ---- librccl, resolved lazily ---------------------------------------------------------------------
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  std::string error;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return &r;
+  tried = true;
+  // the soname first: if another library of this process already brought an RCCL (and with it a
+  // HIP runtime), that one must be used
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) {
+    r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    return &r;
+  }
+  bool ok = true;
+#define SYM(field, name)                                                \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name)); \
+  if (!r.field) {                                                       \
+    ok = false;                                                         \
+    r.error = std::string("librccl lacks ") + name;                     \
+  }
+  SYM(GetUniqueId, "ncclGetUniqueId")
+  SYM(CommInitRank, "ncclCommInitRank")
+  SYM(CommDestroy, "ncclCommDestroy")
+  SYM(GetErrorString, "ncclGetErrorString")
+  SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd")
+  SYM(Send, "ncclSend")
+  SYM(Recv, "ncclRecv")
+  SYM(AllReduce, "ncclAllReduce")
+  SYM(AllGather, "ncclAllGather")
+#undef SYM
+  if (!ok) {
+    dlclose(r.handle);
+    r.handle = nullptr;
+  }
+  return &r;
+}
+
+#define C_NCCL(expr)                                                                                        \
+  do {                                                                                                      \
+    ncclResult_t r_ = (expr);                                                                               \
+    if (r_ != ncclSuccess)                                                                                  \
+      return ffx_fail(FFX_RCCL_ERROR, "%s: %s (%s:%d)", #expr, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- shared-memory transport ----------------------------------------------------------------------
+constexpr int kMaxWorld = 64;
+constexpr size_t kSmall = 65536;      // bytes of control payload per rank and round
+constexpr uint32_t kMagic = 0x46465831;  // "FFX1"
+
+struct ShmSlot {
+  std::atomic<uint32_t> data_gen;  // generation of this rank's data segment (0: none yet)
+  uint32_t pad;
+  uint64_t data_cap;               // its size in bytes
+  int64_t counts[kMaxWorld];       // elements this rank sends to each peer in the current exchange
+  char small[kSmall];
+};
+
+struct ShmHeader {
+  std::atomic<uint32_t> magic;
+  uint32_t world;
+  std::atomic<uint32_t> arrived, generation;  // sense-counting barrier
+  std::atomic<uint32_t> failed;               // a rank gave up: everybody waiting fails too
+  uint32_t pad;
+  ShmSlot slot[1];  // [world]
+};
+
+double barrier_timeout_s() {
+  const char* e = getenv("FFX_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0 ? v : 120.0;
+}
+
+struct Mapping {
+  void* p = nullptr;
+  size_t bytes = 0;
+  uint32_t gen = 0;
+  void unmap() {
+    if (p) munmap(p, bytes);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct ffx_comm {
+  int transport = FFX_COMM_RCCL, device = -1, rank = 0, world = 1;
+  hipStream_t stream = nullptr;
+  // RCCL
+  ncclComm_t nccl = nullptr;
+  void* ctl_dev = nullptr;   // kSmall * (world + 1) bytes of device scratch for the control collectives
+  void* ctl_host = nullptr;  // page-locked mirror
+  // shared memory
+  std::string name;
+  ShmHeader* hdr = nullptr;
+  size_t hdr_bytes = 0;
+  Mapping seg[kMaxWorld];  // seg[rank] is this rank's own send segment
+};
+
+namespace {
+
+size_t header_bytes(int world) { return sizeof(ShmHeader) + sizeof(ShmSlot) * (size_t)(world - 1); }
+
+std::string seg_name(const ffx_comm* c, int rank, uint32_t gen) {
+  char buf[160];
+  snprintf(buf, sizeof buf, "%s.r%d.g%u", c->name.c_str(), rank, gen);
+  return buf;
+}
+
+int shm_barrier(ffx_comm* c) {
+  ShmHeader* h = c->hdr;
+  if (h->failed.load()) return ffx_fail(FFX_RCCL_ERROR, "host transport: a peer rank failed");
+  const uint32_t gen = h->generation.load();
+  if (h->arrived.fetch_add(1) + 1 == (uint32_t)c->world) {
+    h->arrived.store(0);
+    h->generation.fetch_add(1);
+    return FFX_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const double limit = barrier_timeout_s();
+  for (unsigned spin = 0; h->generation.load() == gen; ++spin) {
+    if (h->failed.load()) return ffx_fail(FFX_RCCL_ERROR, "host transport: a peer rank failed");
+    if (spin < 2000) {
+      sched_yield();
+    } else {
+      usleep(50);
+      if ((spin & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+        h->failed.store(1);
+        return ffx_fail(FFX_RCCL_ERROR, "host transport: rank %d waited %.0f s at a barrier (peer gone?)", c->rank, limit);
+      }
+    }
+  }
+  return FFX_OK;
+}
+
+// this rank's send segment must hold `bytes`
+int shm_own_segment(ffx_comm* c, size_t bytes) {
+  Mapping& m = c->seg[c->rank];
+  if (m.p && m.bytes >= bytes) return FFX_OK;
+  const uint32_t gen = m.gen + 1;
+  const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+  const std::string nm = seg_name(c, c->rank, gen);
+  int fd = shm_open(nm.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return ffx_fail(FFX_OOM, "shm_open(%s) failed: %s", nm.c_str(), strerror(errno));
+  if (ftruncate(fd, (off_t)want) != 0) {
+    close(fd);
+    shm_unlink(nm.c_str());
+    return ffx_fail(FFX_OOM, "ftruncate(%s, %zu) failed: %s", nm.c_str(), want, strerror(errno));
+  }
+  void* p = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) {
+    shm_unlink(nm.c_str());
+    return ffx_fail(FFX_OOM, "mmap(%s) failed: %s", nm.c_str(), strerror(errno));
+  }
+  if (m.p) {  // peers re-map when they see the new generation; the old pages go with the last unmap
+    shm_unlink(seg_name(c, c->rank, m.gen).c_str());
+    m.unmap();
+  }
+  m.p = p;
+  m.bytes = want;
+  m.gen = gen;
+  c->hdr->slot[c->rank].data_cap = want;
+  c->hdr->slot[c->rank].data_gen.store(gen);
+  return FFX_OK;
+}
+
+int shm_peer_segment(ffx_comm* c, int peer) {
+  if (peer == c->rank) return FFX_OK;
+  const uint32_t gen = c->hdr->slot[peer].data_gen.load();
+  Mapping& m = c->seg[peer];
+  if (m.p && m.gen == gen) return FFX_OK;
+  m.unmap();
+  if (gen == 0) return FFX_OK;
+  const std::string nm = seg_name(c, peer, gen);
+  int fd = shm_open(nm.c_str(), O_RDONLY, 0);
+  if (fd < 0) return ffx_fail(FFX_RCCL_ERROR, "shm_open(%s) failed: %s", nm.c_str(), strerror(errno));
+  const size_t bytes = c->hdr->slot[peer].data_cap;
+  void* p = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return ffx_fail(FFX_RCCL_ERROR, "mmap(%s) failed: %s", nm.c_str(), strerror(errno));
+  m.p = p;
+  m.bytes = bytes;
+  m.gen = gen;
+  return FFX_OK;
+}
+
+// all-gather of <= kSmall bytes per rank through the control slots
+int shm_allgather_small(ffx_comm* c, const void* mine, size_t bytes, void* all) {
+  memcpy(c->hdr->slot[c->rank].small, mine, bytes);
+  C_TRY(shm_barrier(c));
+  for (int r = 0; r < c->world; ++r) memcpy(static_cast<char*>(all) + (size_t)r * bytes, c->hdr->slot[r].small, bytes);
+  return shm_barrier(c);
+}
+
+int rccl_allgather_small(ffx_comm* c, const void* mine, size_t bytes, void* all) {
+  char* host = static_cast<char*>(c->ctl_host);
+  char* dev = static_cast<char*>(c->ctl_dev);
+  memcpy(host, mine, bytes);
+  C_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+  C_NCCL(rccl()->AllGather(dev, dev + kSmall, bytes, ncclChar, c->nccl, c->stream));
+  C_HIP(hipMemcpyAsync(host + kSmall, dev + kSmall, bytes * c->world, hipMemcpyDeviceToHost, c->stream));
+  C_HIP(hipStreamSynchronize(c->stream));
+  memcpy(all, host + kSmall, bytes * c->world);
+  return FFX_OK;
+}
+
+int allgather_small(ffx_comm* c, const void* mine, size_t bytes, void* all) {
+  if (c->world == 1) {
+    memcpy(all, mine, bytes);
+    return FFX_OK;
+  }
+  return c->transport == FFX_COMM_RCCL ? rccl_allgather_small(c, mine, bytes, all) : shm_allgather_small(c, mine, bytes, all);
+}
+
+void destroy_comm(ffx_comm* c) {
+  if (!c) return;
+  if (c->device >= 0) (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
+  if (c->ctl_dev) (void)hipFree(c->ctl_dev);
+  if (c->ctl_host) (void)hipHostFree(c->ctl_host);
+  if (c->hdr) {
+    if (c->seg[c->rank].p) shm_unlink(seg_name(c, c->rank, c->seg[c->rank].gen).c_str());
+    for (int r = 0; r < c->world; ++r) c->seg[r].unmap();
+    // (rank 0 unlinked the header's name right after start-up, when everybody had attached)
+    munmap(c->hdr, c->hdr_bytes);
+  }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffx_comm_unique_id(int transport, void* id) {
+  if (!id) return ffx_fail(FFX_BAD_ARG, "id is NULL");
+  memset(id, 0, FFX_COMM_ID_BYTES);
+  if (transport == FFX_COMM_RCCL) {
+    static_assert(sizeof(ncclUniqueId) == FFX_COMM_ID_BYTES, "FFX_COMM_ID_BYTES must hold an ncclUniqueId");
+    Rccl* r = rccl();
+    if (!r->handle) return ffx_fail(FFX_RCCL_ERROR, "%s", r->error.c_str());
+    ncclUniqueId uid;
+    C_NCCL(r->GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof uid);
+    return FFX_OK;
+  }
+  if (transport == FFX_COMM_HOST) {  // a shared-memory name nobody else will pick
+    unsigned char rnd[16];
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f || fread(rnd, 1, sizeof rnd, f) != sizeof rnd) {
+      if (f) fclose(f);
+      return ffx_fail(FFX_RCCL_ERROR, "cannot read /dev/urandom");
+    }
+    fclose(f);
+    char* out = static_cast<char*>(id);
+    int n = snprintf(out, FFX_COMM_ID_BYTES, "/ffx.%d.", (int)getpid());
+    for (unsigned char b : rnd) n += snprintf(out + n, FFX_COMM_ID_BYTES - n, "%02x", b);
+    return FFX_OK;
+  }
+  return ffx_fail(FFX_BAD_ARG, "unknown transport %d", transport);
+}
+
+int ffx_comm_init(int transport, int device, int rank, int world, const void* id, ffx_comm** out) {
+  if (!out || !id) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return ffx_fail(FFX_BAD_ARG, "bad rank %d / world %d (at most %d ranks)", rank, world, kMaxWorld);
+  if (transport != FFX_COMM_RCCL && transport != FFX_COMM_HOST) return ffx_fail(FFX_BAD_ARG, "unknown transport %d", transport);
+  if (transport == FFX_COMM_RCCL && device < 0) return ffx_fail(FFX_BAD_ARG, "the RCCL transport needs a device");
+  ffx_comm* c = new (std::nothrow) ffx_comm();
+  if (!c) return ffx_fail(FFX_OOM, "host allocation failed");
+  c->transport = transport;
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  int rc = FFX_OK;
+  auto bail = [&](int code) {
+    destroy_comm(c);
+    return code;
+  };
+  if (device >= 0) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+      (void)hipGetLastError();
+      return bail(ffx_fail(FFX_NO_DEVICE, "no HIP device: libffx has no CPU fallback"));
+    }
+    if (device >= n) return bail(ffx_fail(FFX_BAD_ARG, "device %d out of range (%d devices)", device, n));
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+      return bail(ffx_fail(FFX_HIP_ERROR, "stream creation failed on device %d", device));
+  }
+  if (transport == FFX_COMM_RCCL) {
+    Rccl* r = rccl();
+    if (!r->handle) return bail(ffx_fail(FFX_RCCL_ERROR, "%s", r->error.c_str()));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t nr = r->CommInitRank(&c->nccl, world, uid, rank);
+    if (nr != ncclSuccess) {
+      c->nccl = nullptr;
+      return bail(ffx_fail(FFX_RCCL_ERROR, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, r->GetErrorString(nr)));
+    }
+    const size_t ctl = kSmall * (size_t)(world + 1);
+    if (hipMalloc(&c->ctl_dev, ctl) != hipSuccess || hipHostMalloc(&c->ctl_host, ctl, hipHostMallocDefault) != hipSuccess)
+      return bail(ffx_fail(FFX_OOM, "control buffers"));
+  } else {
+    const char* nm = static_cast<const char*>(id);
+    if (nm[0] != '/' || memchr(nm, 0, FFX_COMM_ID_BYTES) == nullptr) return bail(ffx_fail(FFX_BAD_ARG, "not an id of ffx_comm_unique_id(FFX_COMM_HOST)"));
+    c->name = nm;
+    c->hdr_bytes = header_bytes(world);
+    int fd = -1;
+    if (rank == 0) {
+      fd = shm_open(nm, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0) return bail(ffx_fail(FFX_RCCL_ERROR, "shm_open(%s) failed: %s", nm, strerror(errno)));
+      if (ftruncate(fd, (off_t)c->hdr_bytes) != 0) {
+        close(fd);
+        shm_unlink(nm);
+        return bail(ffx_fail(FFX_OOM, "ftruncate(%s) failed: %s", nm, strerror(errno)));
+      }
+    } else {  // wait for rank 0 to create and size the segment
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        fd = shm_open(nm, O_RDWR, 0);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= c->hdr_bytes) break;
+        if (fd >= 0) close(fd);
+        fd = -1;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > barrier_timeout_s())
+          return bail(ffx_fail(FFX_RCCL_ERROR, "rank %d: rank 0 never created %s", rank, nm));
+        usleep(1000);
+      }
+    }
+    void* p = mmap(nullptr, c->hdr_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return bail(ffx_fail(FFX_OOM, "mmap(%s) failed: %s", nm, strerror(errno)));
+    c->hdr = static_cast<ShmHeader*>(p);
+    if (rank == 0) {  // fresh pages are zero: counters start at 0
+      c->hdr->world = (uint32_t)world;
+      c->hdr->magic.store(kMagic);
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (c->hdr->magic.load() != kMagic) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > barrier_timeout_s())
+          return bail(ffx_fail(FFX_RCCL_ERROR, "rank %d: %s was never initialised", rank, nm));
+        usleep(200);
+      }
+      if (c->hdr->world != (uint32_t)world) return bail(ffx_fail(FFX_BAD_ARG, "rank %d expects %d ranks, rank 0 set up %u", rank, world, c->hdr->world));
+    }
+    rc = shm_barrier(c);  // everybody is attached: the name is no longer needed
+    if (rank == 0) shm_unlink(nm);
+    if (rc != FFX_OK) return bail(rc);
+  }
+  *out = c;
+  return FFX_OK;
+}
+
+int ffx_comm_destroy(ffx_comm* c) {
+  destroy_comm(c);
+  return FFX_OK;
+}
+
+int ffx_comm_rank(const ffx_comm* c, int* rank, int* world) {
+  if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  return FFX_OK;
+}
+
+int ffx_comm_stream(ffx_comm* c, void** stream) {
+  if (!c || !stream) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *stream = (void*)c->stream;
+  return FFX_OK;
+}
+
+int ffx_comm_allgather(ffx_comm* c, const void* mine, int64_t bytes, void* all) {
+  if (!c || bytes < 0 || (bytes > 0 && (!mine || !all))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (c->device >= 0) C_HIP(hipSetDevice(c->device));
+  for (int64_t at = 0; at < bytes; at += (int64_t)kSmall) {  // control-sized messages: a few rounds at most
+    const size_t n = (size_t)std::min<int64_t>((int64_t)kSmall, bytes - at);
+    std::vector<char> round(n * (size_t)c->world);
+    C_TRY(allgather_small(c, static_cast<const char*>(mine) + at, n, round.data()));
+    for (int r = 0; r < c->world; ++r) memcpy(static_cast<char*>(all) + (size_t)r * (size_t)bytes + (size_t)at, round.data() + (size_t)r * n, n);
+  }
+  return FFX_OK;
+}
+
+int ffx_comm_barrier(ffx_comm* c) {
+  if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
+  if (c->world == 1) return FFX_OK;
+  if (c->transport == FFX_COMM_HOST) return shm_barrier(c);
+  char one = 1;
+  std::vector<char> all((size_t)c->world);
+  C_HIP(hipSetDevice(c->device));
+  return rccl_allgather_small(c, &one, 1, all.data());
+}
+
+int ffx_comm_allreduce_f64(ffx_comm* c, double* inout, int32_t n, int op) {
+  if (!c || n < 0 || (n > 0 && !inout)) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (op < FFX_OP_SUM || op > FFX_OP_MIN) return ffx_fail(FFX_BAD_ARG, "unknown reduction %d", op);
+  if (n == 0 || c->world == 1) return FFX_OK;
+  std::vector<double> all((size_t)n * (size_t)c->world);
+  C_TRY(ffx_comm_allgather(c, inout, (int64_t)n * 8, all.data()));
+  for (int i = 0; i < n; ++i) {
+    double v = all[i];
+    for (int r = 1; r < c->world; ++r) {
+      const double x = all[(size_t)r * n + i];
+      v = op == FFX_OP_SUM ? v + x : op == FFX_OP_MAX ? std::max(v, x) : std::min(v, x);
+    }
+    inout[i] = v;
+  }
+  return FFX_OK;
+}
+
+static int check_counts(const ffx_comm* c, const int64_t* send_counts, const int64_t* recv_counts, int64_t* n_send, int64_t* n_recv) {
+  if (!send_counts || !recv_counts) return ffx_fail(FFX_BAD_ARG, "counts are NULL");
+  *n_send = *n_recv = 0;
+  for (int r = 0; r < c->world; ++r) {
+    if (send_counts[r] < 0 || recv_counts[r] < 0) return ffx_fail(FFX_BAD_ARG, "negative count for peer %d", r);
+    *n_send += send_counts[r];
+    *n_recv += recv_counts[r];
+  }
+  if (send_counts[c->rank] != recv_counts[c->rank]) return ffx_fail(FFX_BAD_ARG, "a rank sends itself %lld and expects %lld", (long long)send_counts[c->rank], (long long)recv_counts[c->rank]);
+  return FFX_OK;
+}
+
+// host transport: publish the send buffer, then pull this rank's slice out of every peer's segment.
+// `device`: buffers are device pointers (copies ordered on `st`); else plain host memory.
+static int shm_exchange(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts,
+                        bool device, hipStream_t st) {
+  int64_t n_send = 0, n_recv = 0;
+  // an error on one rank must not leave the others waiting at the barrier: mark the communicator failed
+  int pre = check_counts(c, send_counts, recv_counts, &n_send, &n_recv);
+  if (pre == FFX_OK) pre = shm_own_segment(c, (size_t)n_send * sizeof(float));
+  if (pre != FFX_OK) {
+    c->hdr->failed.store(1);
+    return pre;
+  }
+  ShmSlot& mine = c->hdr->slot[c->rank];
+  for (int r = 0; r < c->world; ++r) mine.counts[r] = send_counts[r];
+  if (n_send > 0) {
+    if (device) {
+      C_HIP(hipMemcpyAsync(c->seg[c->rank].p, send, (size_t)n_send * sizeof(float), hipMemcpyDeviceToHost, st));
+      C_HIP(hipStreamSynchronize(st));
+    } else {
+      memcpy(c->seg[c->rank].p, send, (size_t)n_send * sizeof(float));
+    }
+  }
+  C_TRY(shm_barrier(c));  // every send segment is complete
+  int64_t at = 0;
+  int rc = FFX_OK;
+  for (int r = 0; r < c->world && rc == FFX_OK; ++r) {
+    const ShmSlot& peer = c->hdr->slot[r];
+    if (peer.counts[c->rank] != recv_counts[r]) {
+      rc = ffx_fail(FFX_BAD_ARG, "rank %d sends %lld scores to rank %d, which expects %lld", r, (long long)peer.counts[c->rank], c->rank, (long long)recv_counts[r]);
+      break;
+    }
+    if (recv_counts[r] > 0) {
+      rc = shm_peer_segment(c, r);
+      if (rc != FFX_OK) break;
+      int64_t off = 0;
+      for (int i = 0; i < c->rank; ++i) off += peer.counts[i];
+      const float* src = static_cast<const float*>(c->seg[r].p) + off;
+      const size_t bytes = (size_t)recv_counts[r] * sizeof(float);
+      if (device) {
+        if (hipMemcpyAsync(recv + at, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "copy of peer %d's scores to the device failed", r);
+      } else {
+        memcpy(recv + at, src, bytes);
+      }
+    }
+    at += recv_counts[r];
+  }
+  if (rc == FFX_OK && device && hipStreamSynchronize(st) != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream synchronisation failed");
+  if (rc != FFX_OK) {
+    c->hdr->failed.store(1);
+    return rc;
+  }
+  return shm_barrier(c);  // every rank has read: the segments may be overwritten
+}
+
+int ffx_comm_exchange_host(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts) {
+  if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
+  if (c->transport != FFX_COMM_HOST) return ffx_fail(FFX_BAD_ARG, "host buffers travel on the host transport only");
+  return shm_exchange(c, send, send_counts, recv, recv_counts, false, nullptr);
+}
+
+int ffx_comm_exchange(ffx_comm* c, const float* send_dev, const int64_t* send_counts, float* recv_dev, const int64_t* recv_counts,
+                      void* stream) {
+  if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
+  if (c->device < 0) return ffx_fail(FFX_BAD_ARG, "this communicator has no device: use ffx_comm_exchange_host");
+  C_HIP(hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (c->transport == FFX_COMM_HOST) return shm_exchange(c, send_dev, send_counts, recv_dev, recv_counts, true, st);
+  int64_t n_send = 0, n_recv = 0;
+  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
+  if ((n_send > 0 && !send_dev) || (n_recv > 0 && !recv_dev)) return ffx_fail(FFX_BAD_ARG, "NULL buffer");
+  // full mesh: one send and one receive per peer inside one group; the slice a rank keeps is a
+  // device copy.  Zero-length slices are skipped on both sides (the counts are symmetric by
+  // construction: send_counts[j] here == recv_counts[me] on j).
+  Rccl* r = rccl();
+  int64_t s_at = 0, r_at = 0;
+  bool grouped = false;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) {
+      if (send_counts[p] > 0)
+        C_HIP(hipMemcpyAsync(recv_dev + r_at, send_dev + s_at, (size_t)send_counts[p] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (send_counts[p] > 0 || recv_counts[p] > 0) {
+      if (!grouped) {
+        C_NCCL(r->GroupStart());
+        grouped = true;
+      }
+      if (send_counts[p] > 0) C_NCCL(r->Send(send_dev + s_at, (size_t)send_counts[p], ncclFloat, p, c->nccl, st));
+      if (recv_counts[p] > 0) C_NCCL(r->Recv(recv_dev + r_at, (size_t)recv_counts[p], ncclFloat, p, c->nccl, st));
+    }
+    s_at += send_counts[p];
+    r_at += recv_counts[p];
+  }
+  if (grouped) C_NCCL(r->GroupEnd());
+  return FFX_OK;
+}
+
+// ---- routing: which rank scores which candidate, and where each score lands at the owner ----------
+int ffx_query_partition(int64_t n_queries, int world, int64_t* bounds) {
+  if (!bounds || world < 1 || n_queries < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  for (int r = 0; r <= world; ++r) bounds[r] = (int64_t)(((__int128)r * n_queries) / world);
+  return FFX_OK;
+}
+
+int ffx_route(const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids, const int32_t* holder,
+              const int64_t* doc_bounds, int rank, int world, int64_t* local_pair_off, int32_t* local_pair_ids,
+              int64_t* send_counts, int64_t* recv_counts, int32_t* recv_slot, int64_t* own, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!pair_off || n_queries < 0 || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || !local_pair_off || !send_counts || !recv_counts || !own)
+    return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (!holder && !doc_bounds) return ffx_fail(FFX_BAD_ARG, "either holder[] or doc_bounds[] must be given");
+  if (pair_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > 0 && !pair_ids) return ffx_fail(FFX_BAD_ARG, "pair_ids is NULL");
+  if (P > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  auto holder_of = [&](int64_t p) -> int {
+    if (holder) return holder[p];
+    const int64_t id = pair_ids[p];
+    if (id < doc_bounds[0] || id >= doc_bounds[world]) return -1;
+    return (int)(std::upper_bound(doc_bounds, doc_bounds + world + 1, id) - doc_bounds) - 1;
+  };
+  const int64_t base = doc_bounds ? doc_bounds[rank] : 0;
+  // pass 1 (threads over blocks of queries): pairs of each query this rank holds
+  const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (int64_t)std::thread::hardware_concurrency(), P / (1 << 18) + 1}));
+  std::atomic<int64_t> first_bad(INT64_MAX);
+  auto for_query_blocks = [&](auto&& body) {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; ++t) {
+      const int64_t q0 = n_queries * t / n_thr, q1 = n_queries * (t + 1) / n_thr;
+      if (t + 1 < n_thr) pool.emplace_back(body, q0, q1);
+      else body(q0, q1);
+    }
+    for (auto& th : pool) th.join();
+  };
+  local_pair_off[0] = 0;
+  for_query_blocks([&](int64_t q0, int64_t q1) {
+    for (int64_t q = q0; q < q1; ++q) {
+      int64_t mine = 0;
+      for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
+        const int h = holder_of(p);
+        if (h < 0 || h >= world) {
+          int64_t cur = first_bad.load();
+          while (p < cur && !first_bad.compare_exchange_weak(cur, p)) {
+          }
+        }
+        mine += h == rank;
+      }
+      local_pair_off[q + 1] = mine;  // counts now, offsets after the scan below
+    }
+  });
+  if (first_bad.load() != INT64_MAX) {
+    if (bad_pair) *bad_pair = first_bad.load();
+    return ffx_fail(FFX_NOT_FOUND, "pair %lld names a document no rank of the sharded index holds", (long long)first_bad.load());
+  }
+  for (int64_t q = 0; q < n_queries; ++q) local_pair_off[q + 1] += local_pair_off[q];
+  // pass 2: the local CSR (ordinals relative to the shard)
+  if (local_pair_ids)
+    for_query_blocks([&](int64_t q0, int64_t q1) {
+      for (int64_t q = q0; q < q1; ++q) {
+        int64_t at = local_pair_off[q];
+        for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p)
+          if (holder_of(p) == rank) local_pair_ids[at++] = (int32_t)(pair_ids[p] - (holder ? 0 : base));
+      }
+    });
+  std::vector<int64_t> qb((size_t)world + 1);
+  ffx_query_partition(n_queries, world, qb.data());
+  for (int r = 0; r < world; ++r) send_counts[r] = local_pair_off[qb[r + 1]] - local_pair_off[qb[r]];
+  // owner side: candidates of the owned queries arrive grouped by source rank, first-stage order inside
+  const int64_t q_lo = qb[rank], q_hi = qb[rank + 1], lo = pair_off[q_lo], hi = pair_off[q_hi];
+  own[0] = q_lo;
+  own[1] = q_hi;
+  own[2] = lo;
+  own[3] = hi - lo;
+  for (int r = 0; r < world; ++r) recv_counts[r] = 0;
+  for (int64_t p = lo; p < hi; ++p) ++recv_counts[holder_of(p)];
+  if (recv_slot) {
+    int64_t next[kMaxWorld];
+    int64_t acc = 0;
+    for (int r = 0; r < world; ++r) {
+      next[r] = acc;
+      acc += recv_counts[r];
+    }
+    for (int64_t p = lo; p < hi; ++p) recv_slot[p - lo] = (int32_t)next[holder_of(p)]++;
+  }
+  return FFX_OK;
+}
+
+}  // extern "C"
+
+// ---- one rank of a row-sharded index: local gather_dot + exchange + owner merge ------------------------
+struct ffx_sharded {
+  ffx_index* shard = nullptr;
+  ffx_comm* comm = nullptr;
+  int device = 0;
+  std::vector<int64_t> doc_bounds;
+  ffx_plan* plans[2] = {nullptr, nullptr};
+  ffx_merge* merge = nullptr;
+  hipStream_t compute = nullptr;
+  hipEvent_t scored[2] = {nullptr, nullptr}, sent[2] = {nullptr, nullptr}, merged = nullptr;
+  bool sent_valid[2] = {false, false};
+  float* send_dev[2] = {nullptr, nullptr};
+  void* recv = nullptr;
+  size_t recv_cap = 0;
+  std::vector<int64_t> send_counts, recv_counts;
+  int64_t own[4] = {0, 0, 0, 0};
+  int64_t local_pairs = 0;
+  bool have_pairs = false, have_sparse = false;
+  uint64_t runs = 0;
+  int last = 0;
+};
+
+namespace {
+
+int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids, const int32_t* holder,
+                const float* sparse, int mode, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!s || !pair_off || n_queries < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  int rank = 0, world = 1;
+  ffx_comm_rank(s->comm, &rank, &world);
+  C_TRY(ffx_sharded_sync(s));
+  s->have_pairs = false;
+  const int64_t P = pair_off[n_queries];
+  std::vector<int64_t> local_off((size_t)n_queries + 1);
+  s->send_counts.assign((size_t)world, 0);
+  s->recv_counts.assign((size_t)world, 0);
+  // sizes first (no id outputs), then the arrays
+  C_TRY(ffx_route(pair_off, n_queries, pair_ids, holder, holder ? nullptr : s->doc_bounds.data(), rank, world, local_off.data(), nullptr,
+                  s->send_counts.data(), s->recv_counts.data(), nullptr, s->own, bad_pair));
+  std::vector<int32_t> local_ids((size_t)std::max<int64_t>(local_off[n_queries], 1));
+  std::vector<int32_t> slot((size_t)std::max<int64_t>(s->own[3], 1));
+  C_TRY(ffx_route(pair_off, n_queries, pair_ids, holder, holder ? nullptr : s->doc_bounds.data(), rank, world, local_off.data(), local_ids.data(),
+                  s->send_counts.data(), s->recv_counts.data(), slot.data(), s->own, bad_pair));
+  (void)P;
+  s->local_pairs = local_off[n_queries];
+  for (int i = 0; i < 2; ++i) {
+    int64_t bad_local = -1;
+    int rc = ffx_plan_set_pairs(s->plans[i], local_off.data(), n_queries, local_ids.data(), nullptr, mode, &bad_local);
+    if (rc == FFX_NOT_FOUND && bad_pair && bad_local >= 0) {  // local position -> position in the caller's list
+      const int64_t q = std::upper_bound(local_off.begin(), local_off.end(), bad_local) - local_off.begin() - 1;
+      int64_t seen = local_off[q];
+      for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
+        const bool mine = holder ? holder[p] == rank : (pair_ids[p] >= s->doc_bounds[rank] && pair_ids[p] < s->doc_bounds[rank + 1]);
+        if (mine && seen++ == bad_local) {
+          *bad_pair = p;
+          break;
+        }
+      }
+    }
+    C_TRY(rc);
+    void* p = nullptr;
+    C_TRY(ffx_plan_device_ptr(s->plans[i], FFX_BUF_FF, &p, nullptr));
+    s->send_dev[i] = static_cast<float*>(p);
+  }
+  const int64_t q_lo = s->own[0], q_hi = s->own[1], lo = s->own[2];
+  std::vector<int64_t> own_off((size_t)(q_hi - q_lo) + 1);
+  for (int64_t q = q_lo; q <= q_hi; ++q) own_off[(size_t)(q - q_lo)] = pair_off[q] - lo;
+  C_TRY(ffx_merge_set(s->merge, own_off.data(), q_hi - q_lo, slot.data(), sparse ? sparse + lo : nullptr));
+  s->have_sparse = sparse != nullptr;
+  const size_t need = (size_t)std::max<int64_t>(s->own[3], 1) * sizeof(float);
+  if (need > s->recv_cap) {
+    C_HIP(hipSetDevice(s->device));
+    if (s->recv) C_HIP(hipFree(s->recv));
+    s->recv = nullptr;
+    s->recv_cap = 0;
+    C_HIP(hipMalloc(&s->recv, need + need / 8));
+    s->recv_cap = need + need / 8;
+  }
+  s->have_pairs = true;
+  return FFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_bounds, ffx_sharded** out) {
+  if (!shard || !comm || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (comm->device < 0) return ffx_fail(FFX_BAD_ARG, "the communicator has no device");
+  ffx_sharded* s = new (std::nothrow) ffx_sharded();
+  if (!s) return ffx_fail(FFX_OOM, "host allocation failed");
+  s->shard = shard;
+  s->comm = comm;
+  s->device = comm->device;
+  if (doc_bounds) {
+    s->doc_bounds.assign(doc_bounds, doc_bounds + comm->world + 1);
+    for (int r = 0; r < comm->world; ++r)
+      if (doc_bounds[r + 1] < doc_bounds[r]) {
+        delete s;
+        return ffx_fail(FFX_BAD_ARG, "doc_bounds not monotone at rank %d", r);
+      }
+  }
+  int rc = FFX_OK;
+  hipError_t e = hipSetDevice(s->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipEventCreateWithFlags(&s->scored[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->sent[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->merged, hipEventDisableTiming);
+  if (e != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
+  for (int i = 0; i < 2 && rc == FFX_OK; ++i) {
+    rc = ffx_plan_create(shard, &s->plans[i]);
+    if (rc == FFX_OK) rc = ffx_plan_set_stream(s->plans[i], s->compute);
+  }
+  if (rc == FFX_OK) rc = ffx_merge_create(s->device, &s->merge);
+  if (rc != FFX_OK) {
+    ffx_sharded_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return FFX_OK;
+}
+
+int ffx_sharded_destroy(ffx_sharded* s) {
+  if (!s) return FFX_OK;
+  (void)hipSetDevice(s->device);
+  if (s->compute) (void)hipStreamSynchronize(s->compute);
+  if (s->comm && s->comm->stream) (void)hipStreamSynchronize(s->comm->stream);
+  for (auto* p : s->plans)
+    if (p) ffx_plan_destroy(p);
+  if (s->merge) ffx_merge_destroy(s->merge);
+  for (int i = 0; i < 2; ++i) {
+    if (s->scored[i]) (void)hipEventDestroy(s->scored[i]);
+    if (s->sent[i]) (void)hipEventDestroy(s->sent[i]);
+  }
+  if (s->merged) (void)hipEventDestroy(s->merged);
+  if (s->recv) (void)hipFree(s->recv);
+  if (s->compute) (void)hipStreamDestroy(s->compute);
+  delete s;
+  return FFX_OK;
+}
+
+int ffx_sharded_set_queries(ffx_sharded* s, const float* host_queries, int64_t n_queries) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  C_TRY(ffx_sharded_sync(s));
+  for (auto* p : s->plans) C_TRY(ffx_plan_set_queries(p, host_queries, n_queries));  // replicated: Q*d*4 bytes
+  return FFX_OK;
+}
+
+int ffx_sharded_set_pairs(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids, const float* sparse,
+                          int mode, int64_t* bad_pair) {
+  if (s && s->doc_bounds.empty()) return ffx_fail(FFX_BAD_ARG, "created without doc_bounds: use ffx_sharded_set_pairs_held");
+  return sharded_set(s, pair_off, n_queries, pair_ids, nullptr, sparse, mode, bad_pair);
+}
+
+int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* holder,
+                               const int32_t* local_ids, const float* sparse, int mode, int64_t* bad_pair) {
+  if (!holder) return ffx_fail(FFX_BAD_ARG, "holder is NULL");
+  return sharded_set(s, pair_off, n_queries, local_ids, holder, sparse, mode, bad_pair);
+}
+
+int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_set_pairs has not succeeded on this handle");
+  C_HIP(hipSetDevice(s->device));
+  const int i = (int)(s->runs & 1);
+  ++s->runs;
+  s->last = i;
+  hipStream_t cs = s->comm->stream;
+  // Two plans alternate as send buffers: batch i is scored on the compute stream while the scores of
+  // batch i-1 are exchanged and merged on the communicator's stream.
+  if (s->sent_valid[i]) C_HIP(hipStreamWaitEvent(s->compute, s->sent[i], 0));  // the exchange of two runs ago has read this plan's scores
+  C_TRY(ffx_plan_run(s->plans[i], 0.0, flags & FFX_FLAG_EXACT_SUM));
+  C_HIP(hipEventRecord(s->scored[i], s->compute));
+  C_HIP(hipStreamWaitEvent(cs, s->scored[i], 0));
+  C_TRY(ffx_comm_exchange(s->comm, s->send_dev[i], s->send_counts.data(), static_cast<float*>(s->recv), s->recv_counts.data(), cs));
+  C_HIP(hipEventRecord(s->sent[i], cs));
+  s->sent_valid[i] = true;
+  C_TRY(ffx_merge_run(s->merge, static_cast<const float*>(s->recv), alpha, flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), cs));
+  C_HIP(hipEventRecord(s->merged, cs));
+  return FFX_OK;
+}
+
+int ffx_sharded_sync(ffx_sharded* s) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  C_HIP(hipSetDevice(s->device));
+  C_HIP(hipStreamSynchronize(s->compute));
+  C_HIP(hipStreamSynchronize(s->comm->stream));
+  return FFX_OK;
+}
+
+int ffx_sharded_fetch(ffx_sharded* s, float* out_ff, float* out_interp, int32_t* out_order) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  C_TRY(ffx_sharded_sync(s));
+  return ffx_merge_fetch(s->merge, out_ff, out_interp, out_order);
+}
+
+int ffx_sharded_owned(const ffx_sharded* s, int64_t* q_lo, int64_t* q_hi, int64_t* first_pair, int64_t* n_pairs) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_set_pairs has not succeeded on this handle");
+  if (q_lo) *q_lo = s->own[0];
+  if (q_hi) *q_hi = s->own[1];
+  if (first_pair) *first_pair = s->own[2];
+  if (n_pairs) *n_pairs = s->own[3];
+  return FFX_OK;
+}
+
+int ffx_sharded_stats(ffx_sharded* s, ffx_shard_stats* out) {
+  if (!s || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (s->runs == 0) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_run has not been called");
+  C_TRY(ffx_sharded_sync(s));
+  memset(out, 0, sizeof *out);
+  C_TRY(ffx_plan_stats(s->plans[s->last], &out->local));
+  ffx_comm_rank(s->comm, &out->rank, &out->world);
+  out->own_queries = s->own[1] - s->own[0];
+  out->own_pairs = s->own[3];
+  for (int r = 0; r < out->world; ++r) {
+    if (r == out->rank) continue;
+    out->send_bytes += s->send_counts[r] * 4;
+    out->recv_bytes += s->recv_counts[r] * 4;
+  }
+  out->transport = s->comm->transport;
+  return FFX_OK;
+}
+
+int ffx_sharded_device_ptr(ffx_sharded* s, int which, void** ptr, int64_t* n_elems) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  return ffx_merge_device_ptr(s->merge, which, ptr, n_elems);
+}
+
+}  // extern "C"

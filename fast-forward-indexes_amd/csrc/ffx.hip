@@ -164,6 +164,7 @@ struct ffx_index {
 
 struct ffx_plan {
   ffx_index* idx = nullptr;
+  int device = 0;                    // idx->device, kept so that destroying the plan never touches the index
   hipStream_t stream = nullptr;      // the stream work is issued on
   hipStream_t own_stream = nullptr;  // created with the plan; `stream` may point elsewhere
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -458,6 +459,9 @@ int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows) {
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(dst->device));
   FFX_HIP(hipMemcpy(dst->vectors, src->vectors, (size_t)n_rows * src->dim * src->elem, hipMemcpyDeviceToDevice));
+  // a device-to-device hipMemcpy may return before the copy is done, and the plans' streams are
+  // non-blocking (not ordered after the null stream): wait here, so callers may use either index freely
+  FFX_HIP(hipDeviceSynchronize());
   return FFX_OK;
 }
 
@@ -572,6 +576,7 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
   ffx_plan* pl = new (std::nothrow) ffx_plan();
   if (!pl) return fail(FFX_OOM, "host allocation failed");
   pl->idx = idx;
+  pl->device = idx->device;
   hipError_t e = hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking);
   pl->stream = pl->own_stream;
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
@@ -611,7 +616,7 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
 
 int ffx_plan_destroy(ffx_plan* pl) {
   if (!pl) return FFX_OK;
-  if (pl->idx) (void)hipSetDevice(pl->idx->device);
+  (void)hipSetDevice(pl->device);
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
                     &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps,

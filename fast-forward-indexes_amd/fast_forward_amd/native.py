@@ -34,7 +34,14 @@ SYMBOLS = (
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_flags", "ffx_run_ids_blob",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
+    "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
+    "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
+    "ffx_query_partition", "ffx_route",
+    "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs", "ffx_sharded_set_pairs_held",
+    "ffx_sharded_run", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
 )
+COMM_RCCL, COMM_HOST, COMM_ID_BYTES = 0, 1, 128
+OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 
 
 class Stats(C.Structure):
@@ -48,6 +55,18 @@ class Stats(C.Structure):
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+class ShardStats(C.Structure):
+    _fields_ = [
+        ("local", Stats), ("own_queries", C.c_int64), ("own_pairs", C.c_int64), ("send_bytes", C.c_int64), ("recv_bytes", C.c_int64),
+        ("rank", C.c_int32), ("world", C.c_int32), ("transport", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def as_dict(self) -> dict:
+        d = {name: getattr(self, name) for name, _ in self._fields_ if name not in ("reserved", "local")}
+        d.update(self.local.as_dict())
+        return d
 
 
 class FFXError(RuntimeError):
@@ -152,6 +171,29 @@ def lib() -> C.CDLL:
         "ffx_host_free": ([vp], C.c_int),
         "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
         "ffx_host_unpin": ([vp], C.c_int),
+        "ffx_comm_unique_id": ([C.c_int, vp], C.c_int),
+        "ffx_comm_init": ([C.c_int, C.c_int, C.c_int, C.c_int, vp, P(vp)], C.c_int),
+        "ffx_comm_destroy": ([vp], C.c_int),
+        "ffx_comm_rank": ([vp, P(C.c_int), P(C.c_int)], C.c_int),
+        "ffx_comm_stream": ([vp, P(vp)], C.c_int),
+        "ffx_comm_barrier": ([vp], C.c_int),
+        "ffx_comm_allreduce_f64": ([vp, vp, i32, C.c_int], C.c_int),
+        "ffx_comm_allgather": ([vp, vp, i64, vp], C.c_int),
+        "ffx_comm_exchange": ([vp, vp, vp, vp, vp, vp], C.c_int),
+        "ffx_comm_exchange_host": ([vp, vp, vp, vp, vp], C.c_int),
+        "ffx_query_partition": ([i64, C.c_int, vp], C.c_int),
+        "ffx_route": ([vp, i64, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, P(i64)], C.c_int),
+        "ffx_sharded_create": ([vp, vp, vp, P(vp)], C.c_int),
+        "ffx_sharded_destroy": ([vp], C.c_int),
+        "ffx_sharded_set_queries": ([vp, vp, i64], C.c_int),
+        "ffx_sharded_set_pairs": ([vp, vp, i64, vp, vp, C.c_int, P(i64)], C.c_int),
+        "ffx_sharded_set_pairs_held": ([vp, vp, i64, vp, vp, vp, C.c_int, P(i64)], C.c_int),
+        "ffx_sharded_run": ([vp, C.c_double, C.c_uint32], C.c_int),
+        "ffx_sharded_sync": ([vp], C.c_int),
+        "ffx_sharded_fetch": ([vp, vp, vp, vp], C.c_int),
+        "ffx_sharded_owned": ([vp, P(i64), P(i64), P(i64), P(i64)], C.c_int),
+        "ffx_sharded_stats": ([vp, P(ShardStats)], C.c_int),
+        "ffx_sharded_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(L, name)
@@ -684,3 +726,161 @@ def aggregate(row_scores, seg_off, mode: int, sparse=None, alpha: float = 0.0, p
     _check(lib().ffx_aggregate(device, _ptr(row_scores), _ptr(seg_off), n, int(mode), _ptr(sp), float(alpha), _ptr(po),
                                0 if po is None else po.shape[0] - 1, FLAG_SORT if sort else 0, _ptr(ff), _ptr(interp), _ptr(order)))
     return ff, interp, order
+
+
+# ---- multi-GPU: communicator, routing, one rank of a row-sharded index ------------------------------------
+class Comm:
+    """Owns one ``ffx_comm``.  ``Comm.unique_id`` on one rank, the bytes handed to the others by any
+    means, then ``Comm(transport, device, rank, world, id)`` on every rank (collective)."""
+
+    @staticmethod
+    def unique_id(transport: int) -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib().ffx_comm_unique_id(int(transport), buf))
+        return buf.raw
+
+    def __init__(self, transport: int, device: int, rank: int, world: int, uid: bytes):
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError(f"a communicator id has {COMM_ID_BYTES} bytes")
+        h = C.c_void_p()
+        _check(lib().ffx_comm_init(int(transport), int(device), int(rank), int(world), uid, C.byref(h)))
+        self._h = h
+        self.transport, self.device, self.rank, self.world = int(transport), int(device), int(rank), int(world)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = _close_quietly
+
+    def barrier(self) -> None:
+        _check(lib().ffx_comm_barrier(self._h))
+
+    def allreduce(self, values, op: int = OP_SUM) -> np.ndarray:
+        a = np.array(values, dtype=np.float64, ndmin=1)
+        _check(lib().ffx_comm_allreduce_f64(self._h, _ptr(a), a.shape[0], int(op)))
+        return a
+
+    def allgather_bytes(self, mine: bytes) -> list[bytes]:
+        """Same-length byte strings of every rank, in rank order (control plane)."""
+        n = len(mine)
+        out = C.create_string_buffer(max(1, n * self.world))
+        _check(lib().ffx_comm_allgather(self._h, mine, n, out))
+        return [out.raw[r * n:(r + 1) * n] for r in range(self.world)]
+
+    def allgather_array(self, a: np.ndarray) -> np.ndarray:
+        """``(world, *a.shape)``: every rank's array of the same shape and dtype."""
+        a = np.ascontiguousarray(a)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        _check(lib().ffx_comm_allgather(self._h, _ptr(a), a.nbytes, _ptr(out)))
+        return out
+
+    def exchange_host(self, send: np.ndarray, send_counts, recv_counts) -> np.ndarray:
+        """All-to-all-v of float32 HOST arrays (host transport)."""
+        send = _arr(send, np.float32)
+        sc, rc = _arr(send_counts, np.int64), _arr(recv_counts, np.int64)
+        assert sc.shape[0] == rc.shape[0] == self.world and int(sc.sum()) == send.shape[0]
+        recv = np.empty(int(rc.sum()), dtype=np.float32)
+        _check(lib().ffx_comm_exchange_host(self._h, _ptr(send), _ptr(sc), _ptr(recv), _ptr(rc)))
+        return recv
+
+
+def query_partition(n_queries: int, world: int) -> np.ndarray:
+    b = np.empty(world + 1, dtype=np.int64)
+    _check(lib().ffx_query_partition(int(n_queries), int(world), _ptr(b)))
+    return b
+
+
+def route(pair_off, pair_ids, rank: int, world: int, doc_bounds=None, holder=None) -> dict:
+    """``ffx_route`` (host only): what rank ``rank`` scores and what it finalises."""
+    pair_off = _arr(pair_off, np.int64)
+    pair_ids = _arr(pair_ids, np.int32)
+    n_q = pair_off.shape[0] - 1
+    db = None if doc_bounds is None else _arr(doc_bounds, np.int64)
+    ho = None if holder is None else _arr(holder, np.int32)
+    local_off = np.empty(n_q + 1, dtype=np.int64)
+    send, recv, own = np.empty(world, dtype=np.int64), np.empty(world, dtype=np.int64), np.empty(4, dtype=np.int64)
+    bad = C.c_int64(-1)
+
+    def call(local_ids, slot):
+        rc = lib().ffx_route(_ptr(pair_off), n_q, _ptr(pair_ids), _ptr(ho), _ptr(db), int(rank), int(world), _ptr(local_off), _ptr(local_ids),
+                             _ptr(send), _ptr(recv), _ptr(slot), _ptr(own), C.byref(bad))
+        if rc == NOT_FOUND:
+            raise IndexError(f"pair {bad.value} names document ordinal {int(pair_ids[bad.value])}, outside the sharded index")
+        _check(rc)
+
+    call(None, None)  # sizes
+    local_ids = np.empty(int(local_off[-1]), dtype=np.int32)
+    slot = np.empty(int(own[3]), dtype=np.int32)
+    call(local_ids, slot)
+    return {"local_pair_off": local_off, "local_pair_ids": local_ids, "send_counts": send, "recv_counts": recv, "recv_slot": slot,
+            "q_lo": int(own[0]), "q_hi": int(own[1]), "own_first_pair": int(own[2]), "own_pairs": int(own[3])}
+
+
+class Sharded:
+    """Owns one ``ffx_sharded``: this rank's share of a row-sharded index (local plans + exchange +
+    owner-side merge)."""
+
+    def __init__(self, shard: DeviceIndex, comm: Comm, doc_bounds=None):
+        db = None if doc_bounds is None else _arr(doc_bounds, np.int64)
+        if db is not None and db.shape[0] != comm.world + 1:
+            raise ValueError("doc_bounds must have world + 1 entries")
+        h = C.c_void_p()
+        _check(lib().ffx_sharded_create(shard._h, comm._h, _ptr(db), C.byref(h)))
+        self._h, self._shard, self._comm = h, shard, comm
+        self.has_sparse = False
+        self.q_lo = self.q_hi = self.own_first_pair = self.own_pairs = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ffx_sharded_destroy(self._h)
+            self._h = None
+
+    __del__ = _close_quietly
+
+    def set_queries(self, queries: np.ndarray) -> None:
+        queries = _arr(queries, np.float32)
+        assert queries.ndim == 2 and queries.shape[1] == self._shard.query_dim, "query dimensionality does not match the index"
+        _check(lib().ffx_sharded_set_queries(self._h, _ptr(queries), queries.shape[0]))
+
+    def _owned(self) -> None:
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().ffx_sharded_owned(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self.q_lo, self.q_hi, self.own_first_pair, self.own_pairs = a.value, b.value, c.value, d.value
+
+    def set_pairs(self, pair_off, pair_ids, sparse, mode: int, holder=None) -> None:
+        """CSR of ALL queries.  ``pair_ids``: global document ordinals (shards = the ``doc_bounds``
+        ranges), or with ``holder`` the holder-local ordinal of every pair."""
+        pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
+        sp = None if sparse is None else _arr(sparse, np.float32)
+        assert pair_ids.shape[0] == int(pair_off[-1])
+        bad = C.c_int64(-1)
+        if holder is None:
+            rc = lib().ffx_sharded_set_pairs(self._h, _ptr(pair_off), pair_off.shape[0] - 1, _ptr(pair_ids), _ptr(sp), int(mode), C.byref(bad))
+        else:
+            ho = _arr(holder, np.int32)
+            rc = lib().ffx_sharded_set_pairs_held(self._h, _ptr(pair_off), pair_off.shape[0] - 1, _ptr(ho), _ptr(pair_ids), _ptr(sp), int(mode), C.byref(bad))
+        _check(rc, bad.value)
+        self.has_sparse = sp is not None
+        self._owned()
+
+    def run(self, alpha: float = 0.0, exact_sum: bool = True, sort: bool = False, sort_ff: bool = False) -> None:
+        flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0) | (FLAG_SORT_FF if sort_ff else 0)
+        _check(lib().ffx_sharded_run(self._h, float(alpha), flags))
+
+    def sync(self) -> None:
+        _check(lib().ffx_sharded_sync(self._h))
+
+    def fetch(self, ff: bool = True, interp: bool = False, order: bool = False):
+        n = self.own_pairs
+        a = np.empty(n, dtype=np.float32) if ff else None
+        b = np.empty(n, dtype=np.float32) if interp else None
+        c = np.empty(n, dtype=np.int32) if order else None
+        _check(lib().ffx_sharded_fetch(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        return a, b, c
+
+    def stats(self) -> dict:
+        s = ShardStats()
+        _check(lib().ffx_sharded_stats(self._h, C.byref(s)))
+        return s.as_dict()

@@ -5,18 +5,25 @@ path.  The embedding matrix is sharded by *document* (a d
 passages never straddle ranks, so MaxP/FirstP/AveP stay rank-local), query vectors are
 replicated, and every rank scores the candidates whose documents it holds.  The one exchange
 step is an all-to-all of dense scores: query ``q`` is *owned* by one rank, which receives q's
-scores from every rank, puts them back in first-stage order, interpolates and orders them
-(``ffx_merge_*``).  Per step each rank sends/receives ~P/world * 4 bytes, spread over all
-peers at once -- with 7 point-to-point xGMI links per GPU a full-mesh all-to-all uses every
-link, where a ring all-gather of all scores would be bound by one.
+scores from every rank, puts them back in first-stage order, interpolates and orders them.
+Per step each rank sends/receives ~P/world * 4 bytes, spread over all peers at once -- with 7
+point-to-point xGMI links per GPU a full-mesh all-to-all uses every link, where a ring
+all-gather of all scores would be bound by one.
 
-Routing (which rank scores which candidate, where each score lands at the owner) is computed on
-the host once per run by every rank from the same CSR; it is pure NumPy and is covered by the
-world_size-2 gloo tests, which drive exactly these functions with CPU tensors.
+Everything on the data path is native and behind the C ABI (``include/ffx.h``: ``ffx_comm_*`` =
+communicator over RCCL or shared memory, ``ffx_route`` = routing, ``ffx_sharded_*`` = local plans +
+exchange + owner merge); this module is the ctypes-thin Python face of it plus the process
+bootstrap (handing the communicator id from rank 0 to the others through a file).  No PyTorch.
+
+``route`` below is the NumPy statement of ``ffx_route``: the CPU tests check the native routing
+against it, and the world_size-2 gloo tests drive it with CPU tensors.
 """
 
 from __future__ import annotations
 
+import os
+import tempfile
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -89,109 +96,129 @@ def route(pair_off, pair_ids, doc_bounds, rank: int, world: int, sparse=None) ->
     )
 
 
-def exchange(send, send_counts, recv_counts, group=None):
-    """All-to-all of dense scores (torch tensors, CPU/gloo or GPU/RCCL): slice j of ``send`` goes
-    to rank j; returns the concatenation of what every rank sent here, in rank order."""
-    import torch
-    import torch.distributed as dist
+# ---- process bootstrap -------------------------------------------------------------------------------
+def _rendezvous_key() -> str:
+    """Names this job: the same string in every rank of one launch, different between launches.
+    ``FFX_RDZV_KEY`` if set (bench.py's own launcher); else derived from what torch.distributed.run
+    gives its workers (they share a parent process, a master port and a run id)."""
+    key = os.environ.get("FFX_RDZV_KEY")
+    if key:
+        return key
+    return "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                     os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
 
-    recv = torch.empty(int(np.sum(recv_counts)), dtype=send.dtype, device=send.device)
-    dist.all_to_all_single(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
-    return recv
+
+def connect(transport: str | int = "rccl", rank: int | None = None, world: int | None = None, device: int | None = None,
+            key: str | None = None, timeout: float = 120.0):
+    """Collective: build this job's communicator.  Rank 0 draws the id (``ffx_comm_unique_id``) and
+    publishes it in a file under ``FFX_RDZV_DIR`` (default /tmp) named after the job's key; the other
+    ranks wait for that file.  ``rank`` / ``world`` / ``device`` default to RANK / WORLD_SIZE /
+    LOCAL_RANK (what ``python -m torch.distributed.run`` and ``bench.py --gpus N`` export).
+
+    ``transport``: "rccl" (one GPU per rank) or "host" (shared memory: ranks may share a GPU;
+    ``device=-1`` for none at all)."""
+    from fast_forward_amd import native
+
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    code = {"rccl": native.COMM_RCCL, "nccl": native.COMM_RCCL, "host": native.COMM_HOST}.get(transport, transport)
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if code == native.COMM_HOST:
+            device %= max(1, native.device_count())
+    if world == 1:
+        return native.Comm(code, device, 0, 1, native.Comm.unique_id(code))
+    path = os.path.join(os.environ.get("FFX_RDZV_DIR", tempfile.gettempdir()), f"ffx_rdzv_{key or _rendezvous_key()}_{code}")
+    if rank == 0:
+        uid = native.Comm.unique_id(code)
+        tmp = f"{path}.{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)  # atomic: a reader sees all 128 bytes or no file
+    else:
+        t0, uid = time.monotonic(), b""
+        while len(uid) != native.COMM_ID_BYTES:
+            try:
+                fresh = time.time() - os.stat(path).st_mtime < 600  # not a leftover of some crashed job
+                uid = open(path, "rb").read() if fresh else b""
+            except OSError:
+                uid = b""
+            if len(uid) != native.COMM_ID_BYTES:
+                if time.monotonic() - t0 > timeout:
+                    raise TimeoutError(f"rank {rank}: rank 0 never published the communicator id at {path}")
+                time.sleep(0.01)
+    try:
+        comm = native.Comm(code, device, rank, world, uid)
+    finally:
+        if rank == 0:
+            try:
+                os.unlink(path)  # ffx_comm_init is collective: everybody has read the id by now
+            except OSError:
+                pass
+    return comm
 
 
+# ---- one rank of the row-sharded index --------------------------------------------------------------------
 class ShardedScorer:
-    """One rank of a row-sharded index: local ``gather_dot`` + RCCL all-to-all + owner merge.
+    """One rank of a row-sharded index (``ffx_sharded``): local ``gather_dot`` + all-to-all of scores
+    + owner-side merge, all native.
 
     Two HIP streams and two plans: batch i is scored on the compute stream while the scores of
-    batch i-1 are still being exchanged and merged on the communication stream, so back-to-back
-    ``run`` calls cost max(scoring, exchange + merge) instead of their sum.  Each plan owns its
-    send buffer; a plan is reused only after the exchange that read it has finished."""
+    batch i-1 are still being exchanged and merged on the communicator's stream, so back-to-back
+    ``run`` calls cost max(scoring, exchange + merge) instead of their sum."""
 
-    def __init__(self, shard, doc_bounds, rank: int, world: int, device: int, group=None):
-        import torch  # before the first libffx call: see native.lib() on the one-runtime-per-process rule
-
+    def __init__(self, shard, doc_bounds, comm):
         from fast_forward_amd import native
 
-        native.lib()
-        if not native.TORCH_LOADED_FIRST:
-            raise RuntimeError("libffx was loaded before torch in this process; import torch first "
-                               "(two HIP runtimes cannot share a process)")
-        self._torch = torch
-        self._native = native
-        self.shard, self.doc_bounds, self.rank, self.world, self.device, self.group = shard, doc_bounds, rank, world, device, group
-        self.plans = [native.Plan(shard), native.Plan(shard)]
-        self.plan = self.plans[0]  # the plan of the most recent run (stats)
-        self.merge = native.Merge(device)
-        self.route: Route | None = None
-        # explicit (non-null) streams: the C ABI reads a NULL stream as "use your own", so torch's
-        # default stream (handle 0) is never used here
-        self._compute, self._comm = torch.cuda.Stream(device), torch.cuda.Stream(device)
-        assert self._compute.cuda_stream != 0 and self._comm.cuda_stream != 0
-        for plan in self.plans:
-            plan.set_stream(self._compute.cuda_stream)
-        self._scored = [torch.cuda.Event(), torch.cuda.Event()]  # plan i has written its scores
-        self._sent = [torch.cuda.Event(), torch.cuda.Event()]    # the exchange has read plan i's scores
-        self._runs = 0
+        self.shard, self.comm = shard, comm
+        self.rank, self.world = comm.rank, comm.world
+        self.doc_bounds = None if doc_bounds is None else np.asarray(doc_bounds, dtype=np.int64)
+        self._s = native.Sharded(shard, comm, self.doc_bounds)
 
     def set_queries(self, queries: np.ndarray) -> None:
-        self.sync()
-        for plan in self.plans:
-            plan.set_queries(queries)  # replicated: Q*d*4 bytes (21 MB at Q=6980, d=768)
+        self._s.set_queries(queries)  # replicated: Q*d*4 bytes (21 MB at Q=6980, d=768)
 
-    def set_pairs(self, pair_off, pair_ids, sparse, mode: int) -> None:
-        torch, native = self._torch, self._native
-        self.sync()
-        r = route(pair_off, pair_ids, self.doc_bounds, self.rank, self.world, sparse)
-        self._send = []
-        for plan in self.plans:
-            plan.set_pairs(r.local_pair_off, r.local_pair_ids, None, mode)
-            self._send.append(torch.as_tensor(plan.device_array(native.BUF_FF), device=f"cuda:{self.device}"))
-        self.merge.set(r.own_pair_off, r.recv_slot, r.own_sparse)
-        with torch.cuda.stream(self._comm):
-            self._recv = torch.empty(int(r.recv_counts.sum()), dtype=torch.float32, device=f"cuda:{self.device}")
-        self._in_split = [int(c) for c in r.send_counts]
-        self._out_split = [int(c) for c in r.recv_counts]
-        self.route = r
+    def set_pairs(self, pair_off, pair_ids, sparse, mode: int, holder=None) -> None:
+        try:
+            self._s.set_pairs(pair_off, pair_ids, sparse, mode, holder=holder)
+        except Exception as e:
+            from fast_forward_amd import native
+
+            if isinstance(e, native.NotFound):
+                raise IndexError(f"pair {e.pair} names an ordinal outside the sharded index") from None
+            raise
 
     def run(self, alpha: float, exact_sum: bool = True, sort: bool = False) -> None:
-        import torch.distributed as dist
-
-        torch = self._torch
-        i = self._runs & 1
-        self._runs += 1
-        plan, send = self.plans[i], self._send[i]
-        self.plan = plan
-        with torch.cuda.stream(self._compute):
-            self._compute.wait_event(self._sent[i])  # the exchange of two runs ago read this plan's scores
-            plan.run(0.0, exact_sum=exact_sum)
-            self._scored[i].record(self._compute)
-        with torch.cuda.stream(self._comm):
-            self._comm.wait_event(self._scored[i])
-            if dist.get_backend(self.group) == "gloo":
-                # rehearsal path (several ranks sharing one GPU, where RCCL refuses to run): the
-                # same exchange staged through host memory
-                self._comm.synchronize()
-                recv_host = torch.empty(self._recv.shape[0], dtype=torch.float32)
-                dist.all_to_all_single(recv_host, send.cpu(), self._out_split, self._in_split, group=self.group)
-                self._recv.copy_(recv_host)
-            else:
-                dist.all_to_all_single(self._recv, send, self._out_split, self._in_split, group=self.group)
-            self._sent[i].record(self._comm)
-            self.merge.run(self._recv.data_ptr(), alpha, sort=sort, stream=self._comm.cuda_stream)
+        self._s.run(alpha, exact_sum=exact_sum, sort=sort)
 
     def sync(self) -> None:
-        self._torch.cuda.synchronize(self.device)
+        self._s.sync()
+
+    @property
+    def q_lo(self) -> int:
+        return self._s.q_lo
+
+    @property
+    def q_hi(self) -> int:
+        return self._s.q_hi
+
+    @property
+    def own_first_pair(self) -> int:
+        return self._s.own_first_pair
+
+    @property
+    def own_pairs(self) -> int:
+        return self._s.own_pairs
 
     def fetch(self, order: bool = False):
         """(dense, interpolated|None, order|None) of the owned queries, first-stage order."""
-        return self.merge.fetch(ff=True, interp=self.merge.has_sparse, order=order)
+        return self._s.fetch(ff=True, interp=self._s.has_sparse, order=order)
+
+    def stats(self) -> dict:
+        return self._s.stats()
 
     def close(self) -> None:
-        self.sync()
-        for plan in self.plans:
-            plan.close()
-        self.merge.close()
+        self._s.close()
 
 
 # ---- the Index API over a sharded index ------------------------------------------------------------------
@@ -205,37 +232,31 @@ def _owner_of(doc_id: str | None, psg_id: str | None, world: int) -> int:
 
 
 class ShardedInMemoryIndex:
-    """``InMemoryIndex`` spread over the ranks of a ``torch.distributed`` group (SPMD: every rank
-    makes the same calls with the same arguments).
+    """``InMemoryIndex`` spread over the ranks of a communicator (SPMD: every rank makes the same
+    calls with the same arguments).
 
     * ``add(vectors, doc_ids, psg_ids)``: each rank keeps the rows whose document (or, for rows
       without a document id, passage) hashes to it, in its own HBM.
     * ``__call__(ranking)`` / ``rerank(ranking, alpha)``: every rank resolves the candidate ids it
       holds (an id held by no rank is the reference's ``IndexError``, raised on all ranks), scores
-      them locally, and the dense scores of a query travel to the rank that owns the query
-      (``exchange``: one all-to-all).  Each rank returns the ``Ranking`` of the queries it owns;
+      them locally, and the dense scores of a query travel to the rank that owns the query (one
+      all-to-all, ``ffx_comm_exchange``).  Each rank returns the ``Ranking`` of the queries it owns;
       ``gather=True`` assembles the complete ``Ranking`` on every rank.
 
     Scores equal a single ``InMemoryIndex`` holding all rows, bit for bit (same kernels, same
     per-document row order)."""
 
-    def __init__(self, query_encoder=None, mode=None, encoder_batch_size: int = 32, device: int | None = None,
-                 exact_sum: bool = True, group=None, **index_kwargs):
-        import torch  # before libffx is loaded (native.lib)
-        import torch.distributed as dist
-
+    def __init__(self, query_encoder=None, mode=None, encoder_batch_size: int = 32, comm=None, exact_sum: bool = True, **index_kwargs):
         from fast_forward_amd.index import InMemoryIndex, Mode
 
-        self._torch, self._dist, self.group = torch, dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        if device is None:
-            device = self.rank % max(1, torch.cuda.device_count())
-        self.device = device
-        if dist.get_backend(group) != "gloo":
-            torch.cuda.set_device(device)  # object collectives of the RCCL backend use the current device
-        self.local = InMemoryIndex(query_encoder, mode=mode or Mode.MAXP, encoder_batch_size=encoder_batch_size, device=device,
+        self.comm = comm if comm is not None else connect()
+        self.rank, self.world, self.device = self.comm.rank, self.comm.world, self.comm.device
+        self.exact_sum = exact_sum
+        self.local = InMemoryIndex(query_encoder, mode=mode or Mode.MAXP, encoder_batch_size=encoder_batch_size, device=self.device,
                                    exact_sum=exact_sum, **index_kwargs)
         self._n_global = 0
+        self._scorer: ShardedScorer | None = None
+        self._scorer_store = None
 
     # ---- configuration mirrors the local index -----------------------------------------------------------
     @property
@@ -262,17 +283,27 @@ class ShardedInMemoryIndex:
         if any(d is None and p is None for d, p in zip(doc_ids, psg_ids)):
             raise ValueError("Vector has neither document nor passage ID.")
         mine = [i for i in range(n) if _owner_of(doc_ids[i], psg_ids[i], self.world) == self.rank]
+        if self._scorer is not None:  # its plans belong to the store, which add() may re-allocate
+            self._scorer.close()
+            self._scorer = self._scorer_store = None
         if mine:
             self.local.add(vectors[mine], doc_ids=[doc_ids[i] for i in mine], psg_ids=[psg_ids[i] for i in mine])
         self._n_global += n
 
     # ---- scoring ---------------------------------------------------------------------------------------------
-    def _score(self, ranking, alpha: float | None, sort: bool):
-        import pandas as pd
+    def _sharded(self) -> ShardedScorer:
+        """The native scorer over the local store (rebuilt when the store was re-allocated by add)."""
+        self.local._sync_ids()
+        store = self.local._store
+        if self._scorer is None or self._scorer_store is not store:
+            if self._scorer is not None:
+                self._scorer.close()
+            self._scorer, self._scorer_store = ShardedScorer(store, None, self.comm), store
+        return self._scorer
 
+    def _score(self, ranking, alpha: float | None, sort: bool):
         from fast_forward_amd.index.api import _grouped_by_query
 
-        dist, torch = self._dist, self._torch
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
         df = ranking._df
@@ -283,81 +314,51 @@ class ShardedInMemoryIndex:
         ids = df["id"].to_numpy()
         sparse = df["score"].to_numpy(dtype=np.float32)
         if perm is not None:
-            ids, sparse, q_sorted = ids[perm], sparse[perm], q_no[perm]
-        else:
-            q_sorted = q_no
+            ids, sparse = ids[perm], sparse[perm]
         # which candidates do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
         table = self.local._ids
         lookup = table._psg_ordinal if self.local.mode.value == 1 else table._doc_ordinal
         uniq, inv = np.unique(ids, return_inverse=True)
         ord_u = np.fromiter((lookup.get(u, -1) for u in uniq), dtype=np.int64, count=len(uniq))
-        ordinals = ord_u[inv]
-        # control traffic travels on the backend's kind of memory: device tensors under RCCL
-        use_gpu = dist.get_backend(self.group) != "gloo"
-        held = torch.from_numpy((ordinals >= 0).astype(np.int32))
-        if use_gpu:
-            held = held.cuda(self.device)
-        total = held.clone()
-        dist.all_reduce(total, group=self.group)  # every pair must be held by exactly one rank
-        total_h = total.cpu().numpy()
-        if total_h.size and int(total_h.min()) < 1:
-            bad = int(np.flatnonzero(total_h < 1)[0])
-            raise IndexError(f"ID {ids[bad]} not found in the index.")
-        mine = np.flatnonzero(ordinals >= 0)
-        local_off = np.zeros(n_q + 1, dtype=np.int64)
-        np.cumsum(np.bincount(q_sorted[mine], minlength=n_q), out=local_off[1:])
-        if mine.size:
-            dense_local, _, _ = self.local._score_pairs(query_vectors, local_off, ordinals[mine].astype(np.int32), self.local.mode)
-        else:
-            dense_local = np.zeros(0, dtype=np.float32)
-        # all-to-all to the owners of the queries (contiguous blocks of q_no)
-        q_bounds = query_partition(n_q, self.world)
-        send_counts = np.diff(local_off[q_bounds])
-        holder = np.full(ids.shape[0], -1, dtype=np.int64)
-        gathered = [torch.zeros_like(held) for _ in range(self.world)]
-        dist.all_gather(gathered, held, group=self.group)
-        for r, h in enumerate(gathered):
-            holder[h.cpu().numpy() > 0] = r
-        q_lo, q_hi = int(q_bounds[self.rank]), int(q_bounds[self.rank + 1])
-        lo, hi = int(pair_off[q_lo]), int(pair_off[q_hi])
-        own_holder = holder[lo:hi]
-        recv_counts = np.bincount(own_holder, minlength=self.world).astype(np.int64)
-        send = torch.from_numpy(dense_local)
-        if use_gpu:
-            send = send.cuda(self.device)
-        recv = exchange(send, send_counts, recv_counts, self.group)
-        recv = recv.cpu().numpy() if use_gpu else recv.numpy()
-        arrival = np.argsort(own_holder, kind="stable")
-        dense = np.empty(hi - lo, dtype=np.float32)
-        dense[arrival] = recv
-        # owner-side epilogue on the device: interpolation + order (ffx_aggregate with 1-row segments)
-        from fast_forward_amd import native
-
-        own_off = pair_off[q_lo:q_hi + 1] - lo
-        seg = np.arange(hi - lo + 1, dtype=np.int64)
-        if hi > lo:
-            ff, interp, order = native.aggregate(dense, seg, 1, sparse[lo:hi] if alpha is not None else None,
-                                                 0.0 if alpha is None else alpha, own_off, sort=sort, device=self.device)
-        else:
-            ff, interp, order = dense, (dense if alpha is not None else None), np.zeros(0, dtype=np.int32)
+        # one small control message: the bit mask of the unique ids every rank holds
+        held = self.comm.allgather_array(np.packbits(ord_u >= 0))
+        held = np.unpackbits(held, axis=1, count=len(uniq)).astype(bool) if len(uniq) else np.zeros((self.world, 0), dtype=bool)
+        if len(uniq) and not held.any(axis=0).all():
+            missing = np.flatnonzero(~held.any(axis=0))
+            first = int(np.flatnonzero(np.isin(inv, missing))[0])  # the first one in candidate order, on every rank
+            raise IndexError(f"ID {ids[first]} not found in the index.")
+        holder_u = held.argmax(axis=0).astype(np.int32) if len(uniq) else np.zeros(0, dtype=np.int32)
+        scorer = self._sharded() if len(self.local) else None
+        if scorer is None:
+            raise RuntimeError(f"rank {self.rank} holds no rows: a sharded index needs at least one row per rank")
+        scorer.set_queries(query_vectors)
+        scorer.set_pairs(pair_off, np.maximum(ord_u, 0)[inv].astype(np.int32), sparse if alpha is not None else None,
+                         self.local.mode.value, holder=holder_u[inv])
+        scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
+        ff, interp, order = scorer.fetch(order=sort)
+        lo, hi = scorer.own_first_pair, scorer.own_first_pair + scorer.own_pairs
+        score = interp if alpha is not None else ff
         rows = np.arange(lo, hi) if perm is None else perm[lo:hi]
         if sort:
-            rows, score = rows[order], (interp if alpha is not None else ff)[order]
-        else:
-            score = interp if alpha is not None else ff
+            rows, score = rows[order], score[order]
         out = df.iloc[rows].reset_index(drop=True)
         out["score"] = score.astype(df.dtypes["score"])
         return out
 
     def _finish(self, frame, ranking, name, gather: bool):
+        import pickle
+
         import pandas as pd
 
         from fast_forward_amd.ranking import Ranking
 
-        if gather:
-            frames = [None] * self.world
-            self._dist.all_gather_object(frames, frame, group=self.group)
-            frame = pd.concat(frames, ignore_index=True)
+        if gather:  # every rank's frame, through the control plane (sizes first, then padded payloads)
+            blob = pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL)
+            sizes = self.comm.allgather_array(np.array([len(blob)], dtype=np.int64))[:, 0]
+            padded = np.zeros(int(sizes.max()), dtype=np.uint8)
+            padded[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+            blobs = self.comm.allgather_array(padded)
+            frame = pd.concat([pickle.loads(blobs[r, :int(sizes[r])].tobytes()) for r in range(self.world)], ignore_index=True)
         return Ranking(Ranking._trusted(frame), name=name, dtype=ranking._df.dtypes["score"], copy=False, is_sorted=False)
 
     def __call__(self, ranking, gather: bool = False):
@@ -369,4 +370,7 @@ class ShardedInMemoryIndex:
         return self._finish(self._score(ranking, alpha, sort=True), ranking, ranking.name, gather)
 
     def close(self) -> None:
+        if self._scorer is not None:
+            self._scorer.close()
+            self._scorer = None
         self.local.close()

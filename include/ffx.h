@@ -37,7 +37,7 @@ extern "C" {
 #define FFX_BAD_ARG (-1)
 #define FFX_OOM (-2)
 #define FFX_HIP_ERROR (-3)
-#define FFX_RCCL_ERROR (-4) /* reserved: the score exchange runs above the ABI */
+#define FFX_RCCL_ERROR (-4) /* a collective of the multi-GPU path failed (RCCL, or a peer rank that went away) */
 #define FFX_NOT_FOUND (-5)  /* an ordinal names no row: the reference's IndexError, index/util.py:38-39 */
 #define FFX_NO_DEVICE (-6)
 
@@ -165,10 +165,9 @@ int ffx_plan_set_stream(ffx_plan* plan, void* stream);
 /* ---- merge: the owner-side half of a row-sharded index --------------------------------------
  * With the index row-sharded by document over several GPUs (one process each), every rank scores
  * the candidates whose documents it holds, and the dense scores of one query arrive at the
- * query's owner rank from all ranks (an all-to-all done above this ABI, RCCL via
- * torch.distributed).  The owner then scatters them back into first-stage order, interpolates
- * (ranking.py:319) and orders (ranking.py:115-117) -- the same arithmetic as ffx_plan_run's
- * epilogue, on a caller-provided device buffer. */
+ * query's owner rank from all ranks (ffx_comm_exchange below).  The owner then scatters them back
+ * into first-stage order, interpolates (ranking.py:319) and orders (ranking.py:115-117) -- the same
+ * arithmetic as ffx_plan_run's epilogue, on a device buffer. */
 typedef struct ffx_merge ffx_merge;
 int ffx_merge_create(int device, ffx_merge** out);
 int ffx_merge_destroy(ffx_merge* m);
@@ -181,6 +180,90 @@ int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t fl
 int ffx_merge_sync(ffx_merge* m);
 int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order);
 int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems);
+
+/* ---- multi-GPU: one process per GPU, row-sharded index ------------------------------------------
+ * The reference is single-process; this is the sharded form of the same path
+ * (Index._compute_scores, index/base.py:279-314, per shard; Ranking.interpolate + sort,
+ * ranking.py:293-326, at the query's owner).  Shard = a contiguous range of documents, so
+ * MaxP/FirstP/AveP stay rank-local; queries are replicated; the ONE exchange per batch is an
+ * all-to-all-v of fp32 dense scores (every rank sends each owner its slice directly).
+ *
+ * ffx_comm: the communicator.  Bootstrap: one rank calls ffx_comm_unique_id and hands the
+ * FFX_COMM_ID_BYTES to the others by any means (a file, a socket, MPI, a torch store); then every
+ * rank calls ffx_comm_init (collective). */
+#define FFX_COMM_RCCL 0 /* ncclSend/ncclRecv full mesh over xGMI on a HIP stream; one GPU per rank        */
+#define FFX_COMM_HOST 1 /* staged through POSIX shared memory: ranks may share a GPU, or have none (-1) */
+#define FFX_COMM_ID_BYTES 128
+#define FFX_OP_SUM 0
+#define FFX_OP_MAX 1
+#define FFX_OP_MIN 2
+typedef struct ffx_comm ffx_comm;
+int ffx_comm_unique_id(int transport, void* id /* FFX_COMM_ID_BYTES out */);
+int ffx_comm_init(int transport, int device, int rank, int world, const void* id, ffx_comm** out);
+int ffx_comm_destroy(ffx_comm* comm);
+int ffx_comm_rank(const ffx_comm* comm, int* rank, int* world);
+int ffx_comm_stream(ffx_comm* comm, void** stream); /* hipStream_t the exchange is ordered on */
+/* control plane (host values, small): blocking collectives */
+int ffx_comm_barrier(ffx_comm* comm);
+int ffx_comm_allreduce_f64(ffx_comm* comm, double* inout, int32_t n, int op);
+int ffx_comm_allgather(ffx_comm* comm, const void* mine, int64_t bytes, void* all /* world*bytes, rank order */);
+/* all-to-all-v of fp32 scores between DEVICE buffers: slice j of send_dev (send_counts[j] floats,
+ * slices in rank order) goes to rank j; recv_dev receives recv_counts[i] floats from rank i, in
+ * rank order.  RCCL: asynchronous on `stream` (NULL: the communicator's).  Host transport: blocks
+ * until the scores have arrived. */
+int ffx_comm_exchange(ffx_comm* comm, const float* send_dev, const int64_t* send_counts, float* recv_dev,
+                      const int64_t* recv_counts, void* stream);
+/* the same between HOST buffers (host transport only; needs no GPU) */
+int ffx_comm_exchange_host(ffx_comm* comm, const float* send, const int64_t* send_counts, float* recv,
+                           const int64_t* recv_counts);
+
+/* routing, host only: from the CSR of ALL queries (pair_ids = GLOBAL document ordinals) what rank
+ * `rank` scores and what it finalises.  Shards are the document ranges doc_bounds[r]..doc_bounds[r+1];
+ * or, with holder != NULL, pair p is held by rank holder[p] and pair_ids[p] is already the
+ * holder-local ordinal (doc_bounds may be NULL).  Queries are owned in `world` contiguous blocks
+ * (ffx_query_partition).  Outputs (caller-allocated):
+ *   local_pair_off[Q+1], local_pair_ids[<= P] (may be NULL: sizes only)  this rank's CSR over all queries
+ *   send_counts[world]   local scores going to each owner (contiguous slices of the local list)
+ *   recv_counts[world]   scores of the owned queries arriving from each rank
+ *   recv_slot[own pairs] (may be NULL) position of owned candidate p in the received buffer
+ *   own[4]               first owned query, one past the last, first owned pair, number of owned pairs
+ * FFX_NOT_FOUND (+ *bad_pair) if a pair names a document outside every shard. */
+int ffx_query_partition(int64_t n_queries, int world, int64_t* bounds /* world+1 */);
+int ffx_route(const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids, const int32_t* holder,
+              const int64_t* doc_bounds, int rank, int world, int64_t* local_pair_off, int32_t* local_pair_ids,
+              int64_t* send_counts, int64_t* recv_counts, int32_t* recv_slot, int64_t* own, int64_t* bad_pair);
+
+/* ffx_sharded: one rank of the row-sharded index = local plans + exchange + owner merge.  All ranks
+ * make the same calls with the same arguments (SPMD).  Two plans alternate as send buffers, scoring
+ * runs on a compute stream and exchange + merge on the communicator's stream, so back-to-back
+ * ffx_sharded_run calls overlap: a step costs max(scoring, exchange + merge). */
+typedef struct ffx_sharded ffx_sharded;
+typedef struct ffx_shard_stats {
+  ffx_stats local;      /* the local ffx_plan_run of the last step (kernel times, gathered rows) */
+  int64_t own_queries;  /* queries this rank finalises   */
+  int64_t own_pairs;    /* and their candidates          */
+  int64_t send_bytes;   /* scores sent to / received from OTHER ranks per step */
+  int64_t recv_bytes;
+  int32_t rank, world, transport, reserved;
+} ffx_shard_stats;
+/* shard: this rank's rows (document ordinals relative to the shard); doc_bounds[world+1]: first
+ * global document ordinal of every shard (NULL: pairs come with explicit holders, below) */
+int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_bounds, ffx_sharded** out);
+int ffx_sharded_destroy(ffx_sharded* s);
+int ffx_sharded_set_queries(ffx_sharded* s, const float* host_queries, int64_t n_queries);
+/* the CSR of ALL queries with GLOBAL document ordinals, as for ffx_plan_set_pairs */
+int ffx_sharded_set_pairs(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids,
+                          const float* sparse, int mode, int64_t* bad_pair);
+/* pair p is held by rank holder[p]; local_ids[p] = its ordinal on that rank (read where holder[p] == rank) */
+int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* holder,
+                               const int32_t* local_ids, const float* sparse, int mode, int64_t* bad_pair);
+int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags); /* asynchronous */
+int ffx_sharded_sync(ffx_sharded* s);
+/* results of the OWNED queries, first-stage order (ffx_sharded_owned tells which) */
+int ffx_sharded_fetch(ffx_sharded* s, float* out_ff, float* out_interp, int32_t* out_order);
+int ffx_sharded_owned(const ffx_sharded* s, int64_t* q_lo, int64_t* q_hi, int64_t* first_pair, int64_t* n_pairs);
+int ffx_sharded_stats(ffx_sharded* s, ffx_shard_stats* out);
+int ffx_sharded_device_ptr(ffx_sharded* s, int which, void** ptr, int64_t* n_elems);
 
 /* ---- stand-alone epilogue: the reduce / interpolate / sort stages of ffx_plan_run applied to row
  * scores held by the caller (host arrays in, host arrays out).  A streamed (on-disk) index scores

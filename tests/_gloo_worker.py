@@ -1,8 +1,8 @@
 """One rank of the world_size-2 CPU rehearsal of the row-sharded path (launched by
 tests/test_sharded_gloo.py through torch.distributed.run, backend gloo).
 
-The product's routing and exchange functions (fast_forward_amd.sharded.route / exchange /
-doc_partition) run unchanged on CPU tensors; the two device steps are stood in for by the oracle
+The product's routing (fast_forward_amd.sharded.route / doc_partition, the NumPy statement of
+ffx_route) runs unchanged, the exchange is torch.distributed's all_to_all_single over gloo; the two device steps are stood in for by the oracle
 (local scoring) and by the one-line NumPy statement of ffx_merge (recv[recv_slot], interpolate).
 Every rank checks the queries it owns against the single-process oracle, bit for bit."""
 
@@ -19,7 +19,16 @@ for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
 
 import ffx_oracle as fo  # noqa: E402
 from _cases import MODE_NO, load_scoring_case  # noqa: E402
-from fast_forward_amd.sharded import doc_partition, exchange, query_partition, route  # noqa: E402
+from fast_forward_amd.sharded import doc_partition, query_partition, route  # noqa: E402
+
+
+def exchange(send, send_counts, recv_counts):
+    """The all-to-all-v of dense scores as torch.distributed states it (gloo, CPU tensors): slice j of
+    ``send`` goes to rank j.  The product's own transports are ffx_comm_exchange[_host]
+    (tests/test_sharded_native.py); this checks the routing against an independent collective."""
+    recv = torch.empty(int(np.sum(recv_counts)), dtype=send.dtype)
+    dist.all_to_all_single(recv, send, [int(c) for c in recv_counts], [int(c) for c in send_counts])
+    return recv
 
 
 def main():

@@ -1,13 +1,11 @@
-"""Single-rank RCCL rehearsal of fast_forward_amd.sharded.ShardedScorer on one GPU
-(launched by tests/test_gpu_parity.py in a fresh interpreter)."""
+"""Single-rank RCCL run of the native sharded scorer (ffx_comm + ffx_sharded) on one GPU
+(launched by tests/test_gpu_parity.py in a fresh interpreter; no torch in the process)."""
 
 import os
 import sys
 from pathlib import Path
 
 import numpy as np
-import torch  # first: the process then uses torch's HIP runtime for libffx too
-import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
@@ -17,18 +15,18 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import ffx_oracle as fo  # noqa: E402
 from _cases import MODE_NO, bits, load_scoring_case  # noqa: E402
 from fast_forward_amd import native  # noqa: E402
-from fast_forward_amd.sharded import ShardedScorer, doc_partition  # noqa: E402
+from fast_forward_amd.sharded import ShardedScorer, connect, doc_partition  # noqa: E402
 
 case = load_scoring_case("s2_sub")
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29541")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+comm = connect("rccl", rank=0, world=1, device=0)
+assert "torch" not in sys.modules
+assert comm.allreduce([2.0], native.OP_SUM)[0] == 2.0
+comm.barrier()
 idx = native.DeviceIndex(case.vectors.shape[0], case.vectors.shape[1])
 idx.upload(case.vectors, 0)
 idx.set_doc_rows(case.doc_off, case.doc_rows)
 idx.set_psg_rows(case.psg_row)
-scorer = ShardedScorer(idx, doc_partition(case.doc_off, 1), 0, 1, 0)
+scorer = ShardedScorer(idx, doc_partition(case.doc_off, 1), comm)
 scorer.set_queries(case.queries)
 pair_off, pair_ids, sparse, _ = case.pairs("MAXP")
 scorer.set_pairs(pair_off, pair_ids, sparse, MODE_NO["MAXP"])
@@ -60,8 +58,8 @@ assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bit
 scorer.close()
 idx.close()
 
-# the Index-API class over the same 1-rank RCCL group: its control collectives (who holds which
-# id, the unknown-id check, gather=True) must run on device tensors under this backend
+# the Index-API class over the same 1-rank RCCL communicator (control collectives: who holds which
+# id, the unknown-id check, gather=True)
 import pandas as pd  # noqa: E402
 
 from fast_forward_amd import Ranking  # noqa: E402
@@ -75,7 +73,7 @@ rows = rng.standard_normal((n, d)).astype(np.float32)
 qv = rng.standard_normal((4, d)).astype(np.float32)
 enc = LambdaEncoder(lambda t: qv[int(t)])
 docs = [f"D{i // 2}" for i in range(n)]
-sharded, plain = ShardedInMemoryIndex(enc, mode=Mode.MAXP), InMemoryIndex(enc, mode=Mode.MAXP)
+sharded, plain = ShardedInMemoryIndex(enc, mode=Mode.MAXP, comm=comm), InMemoryIndex(enc, mode=Mode.MAXP)
 sharded.add(rows, doc_ids=docs)
 plain.add(rows, doc_ids=docs)
 run = {f"q{q}": {f"D{x}": float(rng.random()) for x in rng.choice(n // 2, size=50, replace=False)} for q in range(4)}
@@ -88,5 +86,7 @@ try:
     raise SystemExit("an unknown id must raise IndexError")
 except IndexError as e:
     assert "nowhere" in str(e)
-dist.destroy_process_group()
+sharded.close()
+comm.close()
+assert "torch" not in sys.modules
 print("sharded 1-rank ok")

@@ -1,13 +1,12 @@
-"""One rank of the ShardedInMemoryIndex test: N ranks share ONE GPU over gloo (RCCL needs a GPU
-per rank); launched by tests/test_index_api.py through torch.distributed.run."""
+"""One rank of the ShardedInMemoryIndex test: N ranks share ONE GPU, scores exchanged through
+libffx's shared-memory transport (RCCL needs a GPU per rank); launched by tests/test_index_api.py
+as N plain processes (RANK / WORLD_SIZE / FFX_RDZV_KEY in the environment)."""
 
 import sys
 from pathlib import Path
 
 import numpy as np
 import pandas as pd
-import torch  # before libffx
-import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
@@ -17,15 +16,15 @@ from _cases import MODE_NO, assert_same_order_modulo_ties, load_scoring_case  # 
 from fast_forward_amd import Ranking  # noqa: E402
 from fast_forward_amd.encoder import LambdaEncoder  # noqa: E402
 from fast_forward_amd.index import Mode  # noqa: E402
-from fast_forward_amd.sharded import ShardedInMemoryIndex  # noqa: E402
+from fast_forward_amd.sharded import ShardedInMemoryIndex, connect  # noqa: E402
 
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
+comm = connect("host")
+rank, world = comm.rank, comm.world
 case = load_scoring_case("config1")
 qvecs = case.queries
 checked = 0
 for mode in ("MAXP", "PASSAGE", "AVEP"):
-    idx = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mode]), device=0)
+    idx = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mode]), comm=comm)
     third = len(case.vectors) // 3
     for lo, hi in ((0, third), (third, len(case.vectors))):
         idx.add(case.vectors[lo:hi], doc_ids=case.doc_names[lo:hi], psg_ids=case.psg_names[lo:hi])
@@ -54,8 +53,8 @@ for mode in ("MAXP", "PASSAGE", "AVEP"):
     else:
         raise AssertionError("unknown id accepted")
     idx.close()
-total = torch.tensor([checked])
-dist.all_reduce(total)
+total = int(comm.allreduce([checked])[0])
+assert "torch" not in sys.modules
 if rank == 0:
-    print(f"sharded api world={world}: {int(total)} owned rows checked against the reference frames")
-dist.destroy_process_group()
+    print(f"sharded api world={world}: {total} owned rows checked against the reference frames")
+comm.close()

@@ -7,6 +7,8 @@ Bars (BASELINE.json north_star):
   * aggregation, interpolation, ordering: bit-exact / identical modulo exact ties
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -257,10 +259,10 @@ def test_full_size_properties():
 
 
 def test_sharded_scorer_single_rank_nccl():
-    """The multi-GPU code path end to end on one GPU: a 1-rank RCCL group, the plan on torch's
-    stream, the all-to-all on plan-owned memory (zero-copy), the owner-side merge kernel.
-    Runs in its own interpreter because torch must be imported before libffx is loaded
-    (fast_forward_amd.native.lib)."""
+    """The multi-GPU code path end to end on one GPU: a 1-rank RCCL communicator created through the
+    C ABI (ffx_comm_init), plans on the compute stream, the exchange on plan-owned memory
+    (zero-copy), the owner-side merge kernel.  Own interpreter: the worker asserts that the whole
+    path runs without PyTorch in the process."""
     import subprocess
     import sys
     from pathlib import Path
@@ -271,28 +273,73 @@ def test_sharded_scorer_single_rank_nccl():
     assert "sharded 1-rank ok" in out.stdout
 
 
-@pytest.mark.parametrize("world,sharding", [(2, "rows"), (2, "queries")])
+@pytest.mark.parametrize("world,sharding", [(2, "rows"), (3, "rows"), (2, "queries")])
 def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding):
-    """bench.py's multi-GPU leg (rows sharded by document, two plans alternating between a compute
-    and a communication stream, owner-side merge) with `world` ranks on this one GPU; the exchange
-    goes over gloo because RCCL refuses ranks that share a device.  Every rank's scores are checked
-    against the oracle inside bench.py (`parity_on_cpu_sample`)."""
+    """`python bench.py --gpus N` exactly as the driver starts it (no outer launcher: bench.py starts
+    its own ranks): rows sharded by document, two plans alternating between a compute and a
+    communication stream, owner-side merge, with `world` ranks on this one GPU; the exchange goes
+    through the shared-memory transport because RCCL refuses ranks that share a device.  Rank 0's
+    scores are checked against the oracle inside bench.py (`parity_on_cpu_sample`)."""
     import json
     import subprocess
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + world + (10 if sharding == "queries" else 0)), str(root / "bench.py"), "--gpus", str(world), "--dist-backend", "gloo",
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(world), "--transport", "host",
            "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "12",
-           "--cpu-seconds", "0.2", "--sort", "--sharding", sharding]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+           "--cpu-seconds", "0.2", "--sharding", sharding]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = next(ln for ln in out.stdout.splitlines() if ln.startswith("{"))
     result = json.loads(line)
     assert result["n_gpus"] == world and result["parity_on_cpu_sample"] == "bit-exact"
     assert sum(result["roofline"]["gathered_rows_per_rank"]) == 90 * 700
+    if sharding == "rows":
+        assert result["transport"] == "host" and len(result["exchange_bytes_per_rank"]["sent"]) == world
+        assert sum(result["owned_pairs_per_rank"]) == 90 * 700
+        assert sum(result["exchange_bytes_per_rank"]["sent"]) == sum(result["exchange_bytes_per_rank"]["received"])
+
+
+def test_sharded_bench_leg_also_runs_under_torchrun():
+    """The other way the driver may start N ranks: `python -m torch.distributed.run ... bench.py --gpus N`
+    (RANK / WORLD_SIZE from the launcher; the ranks find each other through the launcher's run id)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29712", str(root / "bench.py"), "--gpus", "2", "--transport", "host",
+           "--rows", "200000", "--queries", "60", "--k", "500", "--steps", "3", "--warmup", "1", "--cpu-sample-queries", "8", "--cpu-seconds", "0.2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    result = json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{")))
+    assert result["n_gpus"] == 2 and result["parity_on_cpu_sample"] == "bit-exact"
+
+
+def test_single_rank_rccl_bench_leg_matches_the_plain_leg():
+    """`--force-sharded` with one rank runs the whole sharded machinery (RCCL communicator, exchange =
+    a device copy, owner merge) on the N=1 workload: same scores, and a step time close to the plain
+    leg's (the sharded path adds one copy and one merge kernel)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    common = ["--rows", "2000000", "--queries", "400", "--k", "5000", "--steps", "10", "--warmup", "3", "--cpu-sample-queries", "4",
+              "--cpu-seconds", "0.2", "--no-regions"]
+    vals = {}
+    for name, extra in (("plain", []), ("sharded", ["--force-sharded"])):
+        out = subprocess.run([sys.executable, str(root / "bench.py"), *common, *extra], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        vals[name] = json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{")))
+        assert vals[name]["parity_on_cpu_sample"] == "bit-exact"
+    assert vals["sharded"]["rccl_ranks"] == 1
+    assert vals["sharded"]["value"] > 0.9 * vals["plain"]["value"], (vals["sharded"]["value"], vals["plain"]["value"])
 
 
 # ---- product-quantized rows (decode-then-dot and ADC) ------------------------------------------------

@@ -418,17 +418,14 @@ def test_pyterrier_transformers():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_index_api_matches_reference_frames(world):
-    """ShardedInMemoryIndex with 2 and 3 ranks (sharing this GPU, exchange over gloo): gathered
-    dense frames and per-owner interpolated frames equal the reference's."""
-    import os
-    import subprocess
-    import sys
+    """ShardedInMemoryIndex with 2 and 3 ranks (sharing this GPU, exchange through libffx's
+    shared-memory transport): gathered dense frames and per-owner interpolated frames equal the
+    reference's."""
     from pathlib import Path
 
+    from test_sharded_native import run_ranks
+
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29630 + world), str(root / "tests" / "_sharded_api_worker.py")]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "owned rows checked" in out.stdout
+    codes, outs = run_ranks(world, root / "tests" / "_sharded_api_worker.py")
+    assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    assert "owned rows checked" in outs[0][0]
