@@ -62,10 +62,20 @@ def frame_arrays(r: Ranking) -> dict[str, np.ndarray]:
     }
 
 
-def make_index(vectors, doc_ids, psg_ids, qvecs, mode):
+def make_index(vectors, doc_ids, psg_ids, qvecs, mode, chunk=None):
+    """``chunk`` None: one chunk holding everything (fp32 throughout).  ``chunk`` = n: the
+    reference's chunked growth with init_size = alloc_size = n; every chunk after the first is
+    allocated without a dtype (index/memory.py:106), i.e. float64 -- the behaviour of a DEFAULT
+    reference index beyond 65 536 vectors, reproduced here at fixture size."""
     enc = LambdaEncoder(lambda t: qvecs[int(t)])
-    idx = InMemoryIndex(query_encoder=enc, mode=mode, init_size=max(1, len(vectors)))
+    if chunk is None:
+        idx = InMemoryIndex(query_encoder=enc, mode=mode, init_size=max(1, len(vectors)))
+    else:
+        idx = InMemoryIndex(query_encoder=enc, mode=mode, init_size=chunk, alloc_size=chunk)
     idx.add(vectors, doc_ids=doc_ids, psg_ids=psg_ids)
+    if chunk is not None and len(vectors) > chunk:
+        kinds = [c.dtype.name for c in idx._chunks]
+        assert kinds[0] == np.dtype(vectors.dtype).name and set(kinds[1:]) == {"float64"}, kinds
     return idx
 
 
@@ -79,9 +89,11 @@ def run_frame(q_names, cand_ids, sparse):
     return Ranking(df, queries={qn: str(i) for i, qn in enumerate(q_names)})
 
 
-def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, sparse_hi, modes, k_psg=None, store=np.float32):
+def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, sparse_hi, modes, k_psg=None, store=np.float32,
+                 chunk=None, alphas=ALPHAS):
     """Synthetic corpus: docs with psg_lo..psg_hi passages, stored contiguously.  ``store`` is
-    the dtype handed to ``Index.add`` (the reference keeps it: index/memory.py:80-83)."""
+    the dtype handed to ``Index.add`` (the reference keeps it: index/memory.py:80-83); ``chunk``:
+    see make_index."""
     rng = np.random.default_rng(seed)
     per_doc = rng.integers(psg_lo, psg_hi + 1, size=n_docs)
     n_rows = int(per_doc.sum())
@@ -101,7 +113,7 @@ def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, spar
         "doc_of_row": doc_of_row, "cand_docs": cand_docs, "cand_psgs": cand_psgs,
         "sparse_doc": sparse_doc, "sparse_psg": sparse_psg,
         "vectors_sha": sha(vectors), "queries_sha": sha(qvecs), "q_names": np.array(q_names),
-        "store": np.dtype(store).name,
+        "store": np.dtype(store).name, "chunk": 0 if chunk is None else chunk,
     }
     for mname in modes:
         mode = MODES[mname]
@@ -109,17 +121,17 @@ def scoring_case(name, *, seed, dim, n_docs, psg_lo, psg_hi, n_q, k, scale, spar
             first = run_frame(q_names, [[f"P{c}" for c in row] for row in cand_psgs], sparse_psg)
         else:
             first = run_frame(q_names, [[f"D{c}" for c in row] for row in cand_docs], sparse_doc)
-        idx = make_index(vectors, doc_ids, psg_ids, qvecs, mode)
+        idx = make_index(vectors, doc_ids, psg_ids, qvecs, mode, chunk)
         dense = idx(first)
         for key, val in frame_arrays(dense).items():
             out[f"{mname}_ff_{key}"] = val
-        for a in ALPHAS:
+        for a in alphas:
             inter = first.interpolate(dense, a)
             for key, val in frame_arrays(inter).items():
                 out[f"{mname}_int{a}_{key}"] = val
     # batch_size invariance, straight from the reference (index/base.py:445-459)
     mode = MODES[modes[-1]]
-    idx = make_index(vectors, doc_ids, psg_ids, qvecs, mode)
+    idx = make_index(vectors, doc_ids, psg_ids, qvecs, mode, chunk)
     first = run_frame(q_names, [[f"D{c}" for c in row] for row in cand_docs], sparse_doc) \
         if mode != Mode.PASSAGE else run_frame(q_names, [[f"P{c}" for c in row] for row in cand_psgs], sparse_psg)
     assert idx(first) == idx(first, batch_size=7)  # (a divisor of Q trips index/base.py:455)
@@ -228,6 +240,49 @@ def known_answers():
     assert got["PASSAGE"]["q1"] == {f"p{i}": i + 1 for i in range(5)}
     return {"vectors": vecs.tolist(), "doc_ids": doc_ids, "psg_ids": psg_ids, "queries": queries,
             "doc_run": doc_run, "psg_run": psg_run, "expected": got}
+
+
+def sub200k_case():
+    """The sub-sampled config 2 of BASELINE.md section 4: 200 k rows x 768 (documents of 1..8 passages),
+    Q = 200, k = 1000, Mode.MAXP -- through the reference twice: as ONE fp32 chunk (what the build
+    reproduces bit for bit) and with the reference's DEFAULT chunking (init_size = alloc_size =
+    65 536: chunks 1.. are float64, so scores are accumulated in float64 and cast at the end).
+    Inputs are re-derivable from seeds (fast_forward_amd.synth), so only the two score arrays are
+    stored, aligned with the candidate lists."""
+    import time
+
+    seed, dim, scale, n_rows_target, n_q, k = 21, 768, 1.0 / np.sqrt(768), 200_000, 200, 1000
+    per = (synth.uniform_u32(np.arange(n_rows_target, dtype=np.uint64), seed + 7) % np.uint32(8)).astype(np.int64) + 1
+    n_docs = int(np.searchsorted(np.cumsum(per), n_rows_target, side="right"))
+    per = per[:n_docs]
+    n_rows = int(per.sum())
+    doc_of_row = np.repeat(np.arange(n_docs), per).astype(np.int32)
+    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    qvecs = synth.rows(seed + 1000, scale, 0, n_q, dim)
+    # k distinct documents per query: candidate j drawn from stratum j of k equal strata
+    stratum = n_docs // k
+    idx_u = np.arange(n_q * k, dtype=np.uint64)
+    cand = ((np.arange(n_q * k) % k) * stratum + (synth.uniform_u32(idx_u, seed + 1) % np.uint32(stratum)).astype(np.int64)).astype(np.int32).reshape(n_q, k)
+    sparse = (synth.uniform_u32(idx_u, seed + 2).astype(np.float32) * np.float32(25.0 / 2**32)).astype(np.float32).reshape(n_q, k)
+    doc_ids = [f"D{d}" for d in doc_of_row]
+    q_names = [f"q{i:03d}" for i in range(n_q)]
+    first = run_frame(q_names, [[f"D{c}" for c in row] for row in cand], sparse)
+    out = {"seed": seed, "dim": dim, "scale": np.float32(scale), "n_rows": n_rows, "n_docs": n_docs, "n_q": n_q, "k": k,
+           "vectors_sha": sha(vectors), "queries_sha": sha(qvecs), "cand_sha": sha(cand), "sparse_sha": sha(sparse)}
+    info = {"rows": n_rows, "docs": n_docs, "pairs": n_q * k}
+    for label, chunk in (("f32chunk", None), ("default_chunks", 2**16)):
+        t0 = time.perf_counter()
+        idx = make_index(vectors, doc_ids, None, qvecs, Mode.MAXP, chunk)
+        dense = idx(first, batch_size=64)
+        info[f"reference_seconds_{label}"] = round(time.perf_counter() - t0, 1)
+        table = {(q, i): sc for q, i, sc in zip(dense._df["q_id"], dense._df["id"], dense._df["score"].to_numpy())}
+        out[f"ff_{label}"] = np.array([[table[(q_names[q], f"D{c}")] for c in cand[q]] for q in range(n_q)], dtype=np.float32)
+        assert dense._df["score"].dtype == np.float32
+        del idx, dense, table
+    np.savez_compressed(OUT / "sub200k.npz", **out)
+    d = np.abs(out["ff_f32chunk"].astype(np.float64) - out["ff_default_chunks"].astype(np.float64))
+    info["max_abs_diff_between_the_two_reference_runs"] = float(d.max())
+    return info
 
 
 PQ_CASES = {
@@ -352,6 +407,26 @@ def coalesce_case():
     return info
 
 
+def f64_cases():
+    """The reference's DEFAULT arithmetic on any index larger than one chunk: float64 chunks after the
+    first (index/memory.py:106), hence float64 products and sums, cast to float32 at the very end
+    (index/base.py:466).  Same corpora as d768 / config1-like, forced into >= 3 chunks."""
+    return {
+        "multichunk_f64": scoring_case(
+            "multichunk_f64", seed=3, dim=768, n_docs=64, psg_lo=1, psg_hi=8, n_q=8, k=32, scale=1.0,
+            sparse_hi=25.0, modes=["PASSAGE", "FIRSTP", "AVEP", "MAXP"], chunk=64, alphas=(0.1, 0.5)),
+        "multichunk_f64_unit": scoring_case(
+            "multichunk_f64_unit", seed=31, dim=768, n_docs=300, psg_lo=1, psg_hi=8, n_q=16, k=100, scale=float(1 / np.sqrt(768)),
+            sparse_hi=25.0, modes=["PASSAGE", "FIRSTP", "AVEP", "MAXP"], chunk=64, alphas=(0.1, 0.5)),
+        "multichunk_f64_d128": scoring_case(
+            "multichunk_f64_d128", seed=32, dim=128, n_docs=200, psg_lo=1, psg_hi=4, n_q=10, k=60, scale=0.15,
+            sparse_hi=20.0, modes=["MAXP", "AVEP"], chunk=64, alphas=(0.1, 0.5)),
+        "multichunk_f64_d300": scoring_case(
+            "multichunk_f64_d300", seed=33, dim=300, n_docs=100, psg_lo=1, psg_hi=3, n_q=6, k=40, scale=1.0,
+            sparse_hi=10.0, modes=["MAXP"], chunk=64, alphas=(0.1, 0.5)),
+    }
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "--only":  # add one case without rewriting the others
@@ -368,6 +443,10 @@ def main():
                 sparse_hi=10.0, modes=["MAXP"], store=np.float16)
         if sys.argv[2] == "coalesce":
             manifest["cases"]["coalesce"] = coalesce_case()
+        if sys.argv[2] == "f64":
+            manifest["cases"].update(f64_cases())
+        if sys.argv[2] == "sub200k":
+            manifest["cases"]["sub200k"] = sub200k_case()
         if sys.argv[2] == "pq":
             manifest["cases"]["pq"] = {name: pq_case(name, **kw) for name, kw in PQ_CASES.items()}
         (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
@@ -393,6 +472,8 @@ def main():
     manifest["cases"]["interpolate"] = interpolate_case()
     manifest["cases"]["early_stopping"] = early_stopping_case()
     manifest["cases"]["coalesce"] = coalesce_case()
+    manifest["cases"].update(f64_cases())
+    manifest["cases"]["sub200k"] = sub200k_case()
     (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     total = sum(f.stat().st_size for f in OUT.iterdir())
     print(f"wrote {len(list(OUT.iterdir()))} files, {total / 1e6:.2f} MB -> {OUT}")

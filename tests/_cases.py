@@ -114,6 +114,67 @@ def assert_same_order_modulo_ties(got_ids, got_scores, exp):
         start = end
 
 
+# ---- the reference's DEFAULT arithmetic (float64 chunks, index/memory.py:106) ------------------------
+F64_CASES = ["multichunk_f64", "multichunk_f64_unit", "multichunk_f64_d128", "multichunk_f64_d300"]
+F64_TOL = 1e-4      # north_star: scores match the reference's to 1e-4 (fp32)
+F64_ALPHAS = (0.1, 0.5)
+
+
+def tolerance_report(got: np.ndarray, want: np.ndarray, pair_off: np.ndarray) -> dict:
+    """How fp32 scores `got` sit against the float64-accumulated reference scores `want`
+    (both float32 arrays over the same pairs): the largest absolute difference, the bar it is held
+    to, and how the two orderings differ -- the number of adjacent inversions (pairs that the two
+    sides order differently although their reference scores differ) and the widest reference gap
+    any of them spans."""
+    got, want = np.asarray(got, dtype=np.float32), np.asarray(want, dtype=np.float32)
+    scale = max(1.0, float(np.abs(want).max())) if want.size else 1.0
+    inversions, widest = 0, 0.0
+    for q in range(len(pair_off) - 1):
+        lo, hi = int(pair_off[q]), int(pair_off[q + 1])
+        g, w = got[lo:hi], want[lo:hi]
+        mine = np.argsort(-g.astype(np.float64), kind="stable")
+        w_in_my_order = w[mine].astype(np.float64)
+        bad = np.flatnonzero(w_in_my_order[:-1] < w_in_my_order[1:])  # the reference puts these two the other way round
+        inversions += int(bad.size)
+        if bad.size:
+            widest = max(widest, float((w_in_my_order[bad + 1] - w_in_my_order[bad]).max()))
+    return {"max_abs_diff": float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0,
+            "bar": F64_TOL * scale, "order_inversions": inversions, "widest_inverted_gap": widest, "pairs": int(want.size)}
+
+
+def assert_within_reference_tolerance(got, want, pair_off, what: str) -> dict:
+    """The parity bar against the reference's float64 path: |diff| <= 1e-4 * max(1, |score|_inf), and
+    the orderings agree except inside reference score gaps below 2e-4 * that scale."""
+    rep = tolerance_report(got, want, pair_off)
+    assert rep["max_abs_diff"] <= rep["bar"], f"{what}: {rep}"
+    assert rep["widest_inverted_gap"] < 2 * rep["bar"], f"{what}: {rep}"
+    return rep
+
+
+def load_sub200k() -> dict:
+    """The sub-sampled config 2 (BASELINE.md section 4; oracle/gen_golden.py::sub200k_case): 200 k rows x
+    768, Q = 200, k = 1000, MaxP, scored by the reference as one fp32 chunk and with its default
+    (float64) chunking.  Inputs come back from the seeds; vectors are NOT materialised here (614 MB:
+    ``synth.rows(seed, scale, 0, n_rows, dim)`` on the host, ``fill_synthetic`` on the device)."""
+    z = np.load(GOLDEN / "sub200k.npz")
+    seed, dim, scale, n_rows, n_docs, n_q, k = (int(z["seed"]), int(z["dim"]), float(z["scale"]), int(z["n_rows"]), int(z["n_docs"]),
+                                                int(z["n_q"]), int(z["k"]))
+    per = (synth.uniform_u32(np.arange(200_000, dtype=np.uint64), seed + 7) % np.uint32(8)).astype(np.int64) + 1
+    per = per[:n_docs]
+    assert int(per.sum()) == n_rows
+    doc_off = np.concatenate([[0], np.cumsum(per)]).astype(np.int64)
+    stratum = n_docs // k
+    idx_u = np.arange(n_q * k, dtype=np.uint64)
+    cand = ((np.arange(n_q * k) % k) * stratum + (synth.uniform_u32(idx_u, seed + 1) % np.uint32(stratum)).astype(np.int64)).astype(np.int32)
+    sparse = (synth.uniform_u32(idx_u, seed + 2).astype(np.float32) * np.float32(25.0 / 2**32)).astype(np.float32)
+    assert sha(cand.reshape(n_q, k)) == str(z["cand_sha"]) and sha(sparse.reshape(n_q, k)) == str(z["sparse_sha"])
+    queries = synth.rows(seed + 1000, scale, 0, n_q, dim)
+    assert sha(queries) == str(z["queries_sha"])
+    return {"seed": seed, "dim": dim, "scale": scale, "n_rows": n_rows, "n_docs": n_docs, "doc_off": doc_off,
+            "pair_off": np.arange(n_q + 1, dtype=np.int64) * k, "pair_ids": cand, "sparse": sparse, "queries": queries,
+            "vectors_sha": str(z["vectors_sha"]), "ff_f32chunk": z["ff_f32chunk"].reshape(-1), "ff_default_chunks": z["ff_default_chunks"].reshape(-1)}
+
+
 # ---- product-quantized fixtures (oracle/gen_golden.py::pq_case) ------------------------------------
 PQ_CASES = ["pq_d768_m8", "pq_d768_m16", "pq_d1024_m32", "pq_d60_m5"]
 

@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 import ffx_oracle as fo
-from _cases import ALPHAS, MODE_NO, SCORING_CASES, assert_same_order_modulo_ties, bits, load_scoring_case
+from _cases import (ALPHAS, F64_ALPHAS, F64_CASES, MODE_NO, SCORING_CASES, assert_same_order_modulo_ties, assert_within_reference_tolerance,
+                    bits, load_scoring_case, load_sub200k)
 from fast_forward_amd import native, synth
 
 pytestmark = pytest.mark.gpu
@@ -69,6 +70,55 @@ def test_fast_scores_within_tolerance(cases, name):
         want, _ = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids, MODE_NO[mode])
         scale = max(1.0, float(np.abs(want).max()))
         assert np.abs(ff - want).max() <= FAST_TOL * scale, f"{name}/{mode}"
+    idx.close()
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact_sum", "fast_sum"])
+@pytest.mark.parametrize("name", F64_CASES)
+def test_scores_within_tolerance_of_the_references_default_float64_path(name, exact, record_property):
+    """The reference's DEFAULT index scores in float64 once it holds more than one chunk
+    (index/memory.py:106; fixtures: the reference run with init_size = alloc_size = 64).  Both
+    summation modes of the HIP path must sit within 1e-4 * max(1, |s|_inf) of those frames, and order
+    the candidates identically except inside reference score gaps below 2e-4 * that scale."""
+    case = load_scoring_case(name)
+    idx = device_index(case)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        for alpha in F64_ALPHAS:
+            ff, interp, order, _ = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], sparse, alpha, exact_sum=exact, sort=True)
+            exp, exp_i = case.expected(f"{mode}_ff"), case.expected(f"{mode}_int{alpha}")
+            want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+            want_i = np.array([exp_i[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+            rep = assert_within_reference_tolerance(ff, want, pair_off, f"{name}/{mode}/dense")
+            rep_i = assert_within_reference_tolerance(interp, want_i, pair_off, f"{name}/{mode}/alpha={alpha}")
+            record_property(f"{mode}_a{alpha}", {"dense": rep, "interpolated": rep_i})
+            # the device's own order is the descending order of its own scores
+            for q in range(len(case.q_names)):
+                sel = order[pair_off[q]:pair_off[q + 1]]
+                assert (np.diff(interp[sel]) <= 0).all()
+    idx.close()
+
+
+def test_sub_sampled_config2_200k_rows_against_both_reference_runs(record_property):
+    """BASELINE.md section 4's sub-sample (200 k rows x 768, Q = 200, k = 1000, MaxP; rows generated on the
+    device from the fixture's seed): the HIP path equals the reference's single-fp32-chunk run bit
+    for bit, and both summation modes sit within 1e-4 of its DEFAULT float64-chunk run with the same
+    ordering outside tiny gaps."""
+    c = load_sub200k()
+    idx = native.DeviceIndex(c["n_rows"], c["dim"])
+    idx.fill_synthetic(c["seed"], c["scale"], 0, c["n_rows"])
+    idx.set_doc_rows(c["doc_off"], np.arange(c["n_rows"], dtype=np.int32))
+    idx.set_psg_rows(np.arange(c["n_rows"], dtype=np.int32))
+    ff, interp, order, st = native.score(idx, c["queries"], c["pair_off"], c["pair_ids"], MODE_NO["MAXP"], c["sparse"], 0.1, exact_sum=True, sort=True)
+    assert st["n_rows"] > 4 * st["n_pairs"]  # 1..8 passages per document
+    assert np.array_equal(bits(ff), bits(c["ff_f32chunk"]))
+    assert np.array_equal(bits(interp), bits(fo.interpolate(c["sparse"], c["ff_f32chunk"], 0.1)))
+    assert np.array_equal(order.astype(np.int64), fo.order(interp, c["pair_off"]))
+    record_property("exact_vs_float64_chunks", assert_within_reference_tolerance(ff, c["ff_default_chunks"], c["pair_off"], "exact"))
+    fast, _, _, _ = native.score(idx, c["queries"], c["pair_off"], c["pair_ids"], MODE_NO["MAXP"], exact_sum=False)
+    record_property("fast_vs_float64_chunks", assert_within_reference_tolerance(fast, c["ff_default_chunks"], c["pair_off"], "fast"))
+    record_property("fast_vs_fp32_chunk", assert_within_reference_tolerance(fast, c["ff_f32chunk"], c["pair_off"], "fast vs fp32"))
     idx.close()
 
 

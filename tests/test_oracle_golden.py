@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import ffx_oracle as fo
-from _cases import ALPHAS, GOLDEN, MODE_NO, SCORING_CASES, assert_same_order_modulo_ties, bits, load_scoring_case, manifest
+from _cases import (ALPHAS, F64_ALPHAS, F64_CASES, GOLDEN, MODE_NO, SCORING_CASES, assert_same_order_modulo_ties,
+                    assert_within_reference_tolerance, bits, load_scoring_case, load_sub200k, manifest)
 
 
 @pytest.mark.parametrize("name", SCORING_CASES)
@@ -114,3 +115,62 @@ def test_synth_c_matches_numpy():
 
     for seed, scale, first, n, dim in [(1, 1.0, 0, 7, 5), (9, 0.0625, 12345, 4, 768), (2**40 + 3, 0.3, 2**33, 3, 128)]:
         assert np.array_equal(bits(fo.synth_rows(seed, scale, first, n, dim)), bits(synth.rows(seed, scale, first, n, dim)))
+
+
+@pytest.mark.parametrize("name", F64_CASES)
+def test_fp32_oracle_within_tolerance_of_the_references_float64_path(name):
+    """A default reference index larger than one chunk scores in float64 (index/memory.py:106) and
+    casts at the end.  The build always follows the single-chunk fp32 semantics; against the float64
+    frames the bar is the north star's 1e-4 and an ordering that differs only inside tiny gaps."""
+    case = load_scoring_case(name)
+    assert int(case.z["chunk"]) == 64 and case.vectors.shape[0] > 3 * 64  # >= 3 reference chunks
+    worst = 0.0
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, names = case.pairs(mode)
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        ff, _ = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids, MODE_NO[mode])
+        exp = case.expected(f"{mode}_ff")
+        want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+        rep = assert_within_reference_tolerance(ff, want, pair_off, f"{name}/{mode}/dense")
+        worst = max(worst, rep["max_abs_diff"] / rep["bar"])
+        for alpha in F64_ALPHAS:
+            _, interp = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids,
+                                 MODE_NO[mode], sparse, alpha)
+            exp_i = case.expected(f"{mode}_int{alpha}")
+            want_i = np.array([exp_i[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
+            assert_within_reference_tolerance(interp, want_i, pair_off, f"{name}/{mode}/alpha={alpha}")
+    assert worst < 0.5, f"fp32 summation uses {worst:.2f} of the tolerance: closer to the bar than expected"
+
+
+def test_float64_frames_really_differ_from_fp32_frames():
+    """multichunk_f64 is the d768 corpus pushed through >= 3 reference chunks: same inputs, different
+    arithmetic -- if the two frames were equal the fixture would not exercise the float64 path."""
+    a, b = load_scoring_case("d768"), load_scoring_case("multichunk_f64")
+    assert np.array_equal(a.vectors, b.vectors) and np.array_equal(a.z["cand_docs"], b.z["cand_docs"])
+    ea, eb = a.expected("MAXP_ff"), b.expected("MAXP_ff")
+    assert ea.keys() == eb.keys()
+    diff = np.array([abs(float(ea[k]) - float(eb[k])) for k in ea])
+    assert 0 < diff.max() < 1e-4 * max(1.0, max(abs(float(v)) for v in ea.values()))
+
+
+def test_sub_sampled_config2_200k_rows_against_both_reference_runs():
+    """BASELINE.md section 4's equivalence check: 200 k rows x 768, Q = 200, k = 1000, MaxP.  The oracle
+    (and its NumPy port) equal the reference's single-fp32-chunk run bit for bit and sit within the
+    1e-4 bar of its default float64-chunk run, with the same ordering outside tiny gaps."""
+    from fast_forward_amd import synth
+    from _cases import sha, tolerance_report
+
+    c = load_sub200k()
+    vectors = synth.rows(c["seed"], c["scale"], 0, c["n_rows"], c["dim"])
+    assert sha(vectors) == c["vectors_sha"]
+    rows = np.arange(c["n_rows"], dtype=np.int32)
+    ff, interp = fo.score(vectors, c["doc_off"], rows, rows, c["queries"], c["pair_off"], c["pair_ids"], MODE_NO["MAXP"], c["sparse"], 0.1)
+    assert np.array_equal(bits(ff), bits(c["ff_f32chunk"]))
+    rep = assert_within_reference_tolerance(ff, c["ff_default_chunks"], c["pair_off"], "sub200k dense vs float64 chunks")
+    assert rep["pairs"] == 200_000 and rep["max_abs_diff"] < 1e-6
+    # the NumPy port (what bench.py times as the CPU baseline) on the first queries
+    n_q = 8
+    hi = int(c["pair_off"][n_q])
+    ff_np, _ = fo.numpy_port_score(vectors, c["doc_off"], rows, rows, c["queries"][:n_q], c["pair_off"][:n_q + 1], c["pair_ids"][:hi],
+                                   MODE_NO["MAXP"], c["sparse"][:hi], 0.1, batch_queries=4)
+    assert np.array_equal(bits(ff_np), bits(c["ff_f32chunk"][:hi]))
