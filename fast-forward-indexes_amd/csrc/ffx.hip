@@ -224,6 +224,31 @@ int plan_h2d(ffx_plan* pl, void* dst, const void* src, size_t bytes) {
 }
 }  // namespace
 
+namespace {
+// A product-quantized index whose quantizer has fewer than 256 codewords per subspace: code bytes
+// >= Ks (a corrupt or foreign index file) would index past the codebook and the ADC tables.  The
+// kernels clamp; uploads refuse.  Checks device rows [row, row + n_rows) after they have landed.
+int check_pq_codes(ffx_index* idx, int64_t row, int64_t n_rows) {
+  if (idx->dtype != FFX_DTYPE_PQ8 || idx->pq_ks <= 0 || idx->pq_ks >= 256 || n_rows <= 0) return FFX_OK;
+  unsigned long long* flag = nullptr;
+  FFX_HIP(hipMalloc(reinterpret_cast<void**>(&flag), sizeof *flag));
+  unsigned long long bad = ~0ull;
+  const long n_bytes = (long)n_rows * idx->dim;
+  hipError_t e = hipMemset(flag, 0xFF, sizeof *flag);
+  if (e == hipSuccess) {
+    ffx::pq_check_codes_kernel<<<blocks_for(n_bytes, 256), 256>>>(reinterpret_cast<const uint8_t*>(idx->row_ptr(row)), n_bytes, idx->pq_ks, flag);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&bad, flag, sizeof bad, hipMemcpyDeviceToHost);
+  (void)hipFree(flag);
+  if (e != hipSuccess) return fail(FFX_HIP_ERROR, "code check failed: %s", hipGetErrorString(e));
+  if (bad != ~0ull)
+    return fail(FFX_BAD_ARG, "row %lld holds a code >= Ks = %d in subspace %lld: not codes of this index's quantizer",
+                (long long)(row + (int64_t)(bad / (unsigned long long)idx->dim)), idx->pq_ks, (long long)(bad % (unsigned long long)idx->dim));
+  return FFX_OK;
+}
+}  // namespace
+
 // --------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -378,7 +403,7 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(idx->device));
   FFX_HIP(hipMemcpy(idx->row_ptr(row_offset), host_rows, (size_t)n_rows * idx->dim * idx->elem, hipMemcpyHostToDevice));
-  return FFX_OK;
+  return check_pq_codes(idx, row_offset, n_rows);
 }
 
 // Rows scattered over the chunks of a memory-mapped file -> consecutive device rows.  Host threads
@@ -448,7 +473,7 @@ int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_c
     used[s] = true;
   }
   FFX_HIP(hipStreamSynchronize(idx->copy_stream));
-  return FFX_OK;
+  return check_pq_codes(idx, dst_row, n_rows);
 }
 
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows) {
@@ -974,8 +999,21 @@ static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
                                                                                     pl->lut.as<float>());
       FFX_HIP(hipGetLastError());
     }
-    ffx::pq_adc_kernel<<<blocks_for(R, 256), 256, (size_t)M * Ks * sizeof(float), st>>>(codes, M, Ks, pl->lut.as<float>(), desc, rs, R);
-    pl->variant = 2300;
+    // the block's table lives in LDS when it fits: 64 KB by default, up to the CU's 160 KB on request;
+    // a larger table (NanoPQ(M=96, Ks=256) on d=768 is 96 KB; M=192 would be 192 KB) is read through L2
+    size_t lds = (size_t)M * Ks * sizeof(float);
+    int stage = 1;
+    if (lds > 64 * 1024) {
+      const bool raise_ok = lds <= 160 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(ffx::pq_adc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      if (!raise_ok) {
+        (void)hipGetLastError();
+        stage = 0;
+        lds = 0;
+      }
+    }
+    ffx::pq_adc_kernel<<<blocks_for(R, 256), 256, lds, st>>>(codes, M, Ks, pl->lut.as<float>(), desc, rs, R, stage);
+    pl->variant = stage ? 2300 : 2301;
   }
   FFX_HIP(hipGetLastError());
   return FFX_OK;

@@ -466,7 +466,8 @@ struct PqRow {
   int Ks, Ds;
   __device__ __forceinline__ float at(int i) const {
     const int m = i / Ds;
-    return codebook[((size_t)m * Ks + codes[m]) * Ds + (i - m * Ds)];
+    const int code = codes[m] < Ks ? codes[m] : Ks - 1;  // never past the codebook (uploads reject such codes)
+    return codebook[((size_t)m * Ks + code) * Ds + (i - m * Ds)];
   }
 };
 
@@ -701,7 +702,8 @@ gather_dot_pq_lds_kernel(const uint8_t* __restrict__ codes, const float* __restr
         uint32_t sel = word[0];
 #pragma unroll
         for (int w = 1; w < 2 * MW; ++w) sel = (wsel[c] == w) ? word[w] : sel;
-        const int code = (sel >> shift[c]) & 0xFF;
+        int code = (sel >> shift[c]) & 0xFF;
+        code = code < Ks ? code : Ks - 1;  // a corrupt code must not read past the codebook (uploads reject them; belt and braces)
         v[u][c] = *reinterpret_cast<const float4*>(cbase[c] + (size_t)code * Ds);
       }
     }
@@ -809,7 +811,10 @@ pq_adc_exact_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __re
   const float* t = one_query ? table : lut + (size_t)de.y * M * Ks;
   float leaf[M];
 #pragma unroll
-  for (int m = 0; m < M; ++m) leaf[m] = t[(size_t)m * Ks + c[m]];
+  for (int m = 0; m < M; ++m) {
+    const int code = c[m] < Ks ? c[m] : Ks - 1;  // never past the table (uploads reject such codes)
+    leaf[m] = t[(size_t)m * Ks + code];
+  }
   // balanced pairwise combination = NumPy's recursion over equal leaves
 #pragma unroll
   for (int s = 1; s < M; s *= 2) {
@@ -823,13 +828,14 @@ pq_adc_exact_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __re
 // query: its M*Ks-float table is staged in LDS once and the M look-ups per row hit LDS.
 __global__ void __launch_bounds__(256)
 pq_adc_kernel(const uint8_t* __restrict__ codes, int M, int Ks, const float* __restrict__ lut,
-              const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+              const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int stage) {
   extern __shared__ float table[];
   const long r0 = (long)blockIdx.x * blockDim.x;
   const long r = r0 + threadIdx.x;
   const long last = (r0 + blockDim.x - 1) < (long)n_rows ? (r0 + blockDim.x - 1) : (long)n_rows - 1;
   const int q_first = desc[r0].y, q_last = desc[last].y;   // block-uniform
-  const bool one_query = q_first == q_last;
+  // stage == 0: the M*Ks table does not fit the LDS the launch was given; read it through L2
+  const bool one_query = stage && q_first == q_last;
   if (one_query) {
     const float* src = lut + (size_t)q_first * M * Ks;
     for (int i = threadIdx.x; i < M * Ks; i += blockDim.x) table[i] = src[i];
@@ -839,13 +845,22 @@ pq_adc_kernel(const uint8_t* __restrict__ codes, int M, int Ks, const float* __r
   const int2 de = desc[r];
   const uint8_t* c = codes + (size_t)de.x * M;
   float acc = 0.f;
+  const int top = Ks - 1;  // never past the table (uploads reject codes >= Ks)
   if (one_query) {
-    for (int m = 0; m < M; ++m) acc += table[m * Ks + c[m]];
+    for (int m = 0; m < M; ++m) acc += table[m * Ks + (c[m] < Ks ? c[m] : top)];
   } else {
     const float* t = lut + (size_t)de.y * M * Ks;
-    for (int m = 0; m < M; ++m) acc += t[(size_t)m * Ks + c[m]];
+    for (int m = 0; m < M; ++m) acc += t[(size_t)m * Ks + (c[m] < Ks ? c[m] : top)];
   }
   rs[r] = acc;
+}
+
+// first position whose code byte is >= Ks (atomicMin into *first_bad, preset to ~0): run after
+// every upload into a product-quantized index with Ks < 256
+__global__ void __launch_bounds__(256)
+pq_check_codes_kernel(const uint8_t* __restrict__ codes, long n_bytes, int Ks, unsigned long long* __restrict__ first_bad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_bytes && codes[i] >= Ks) atomicMin(first_bad, (unsigned long long)i);
 }
 
 }  // namespace ffx

@@ -126,6 +126,34 @@ inline int token_class(std::string_view t) {
   return FFX_TOKEN_TEXT;
 }
 
+// A score field as pandas.read_csv would take it: 0 = a plain decimal number or an infinity (strtod
+// and pandas agree on those), 1 = one of pandas' NA words (the row is dropped, ranking.py:103),
+// 2 = anything else -- hexadecimal floats, "nan(123)", "NAN", ... -- which strtod would accept but
+// pandas would not read as a number: the caller rejects the file so that the pandas route decides.
+inline int score_token_kind(std::string_view t) {
+  if (token_class(t) == FFX_TOKEN_NA) return 1;
+  size_t i = 0;
+  if (i < t.size() && (t[i] == '-' || t[i] == '+')) ++i;
+  std::string low(t.substr(i));
+  for (char& c : low) c = (char)tolower((unsigned char)c);
+  if (low == "inf" || low == "infinity") return 0;
+  size_t digits = 0;
+  while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++digits;
+  if (i < t.size() && t[i] == '.') {
+    ++i;
+    while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++digits;
+  }
+  if (digits == 0) return 2;
+  if (i < t.size() && (t[i] == 'e' || t[i] == 'E')) {
+    ++i;
+    if (i < t.size() && (t[i] == '-' || t[i] == '+')) ++i;
+    size_t exp_digits = 0;
+    while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++exp_digits;
+    if (exp_digits == 0) return 2;
+  }
+  return i == t.size() ? 0 : 2;
+}
+
 inline std::string_view fixed_width(const char* base, int32_t width, int64_t i) {
   const char* p = base + (size_t)i * width;
   size_t n = 0;
@@ -156,7 +184,7 @@ void append_float_repr(std::string& out, float v) {
     out.push_back(digits[0]);
     if (digits.size() > 1) { out.push_back('.'); out.append(digits, 1, std::string::npos); }
     char eb[8];
-    snprintf(eb, sizeof eb, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10));
+    snprintf(eb, sizeof eb, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10) % 1000);  // a float's decimal exponent has two digits
     out += eb;
   } else if (exp10 < 0) {
     out += "0.";
@@ -382,6 +410,12 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
           pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "expected 'q_id Q0 id rank score [name]'";
           return;
         }
+        const int score_kind = score_token_kind(field[4]);
+        if (score_kind == 2) {
+          pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
+          return;
+        }
+        if (score_kind == 1) continue;  // a missing score: the reference drops the row (ranking.py:103)
         int32_t o = 0;
         if (standalone) {
           pc.id_flags |= token_class(field[2]);
@@ -571,8 +605,8 @@ int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pai
   const int64_t n = (int64_t)run->score.size();
   if (n_pairs_out) *n_pairs_out = n;
   memcpy(pair_off, run->pair_off.data(), (size_t)(nq + 1) * sizeof(int64_t));
-  if (pair_ids) memcpy(pair_ids, run->pair_ids.data(), (size_t)n * sizeof(int32_t));
-  if (sparse) memcpy(sparse, run->score.data(), (size_t)n * sizeof(float));
+  if (pair_ids && n > 0) memcpy(pair_ids, run->pair_ids.data(), (size_t)n * sizeof(int32_t));  // (an empty vector's data() may be NULL)
+  if (sparse && n > 0) memcpy(sparse, run->score.data(), (size_t)n * sizeof(float));
   return FFX_OK;
 }
 
@@ -684,6 +718,8 @@ int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t 
   if (!path || !pair_off || n_queries < 0 || n_pairs < 0 || (n_pairs > 0 && (!id_blob || !scores || !q_blob)) || !tag)
     return ffx_fail(FFX_BAD_ARG, "bad argument");
   if (pair_off[0] != 0 || pair_off[n_queries] != n_pairs) return ffx_fail(FFX_BAD_ARG, "pair_off does not cover the rows");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
   auto split = [](const char* blob, int64_t bytes, int64_t n, std::vector<std::string_view>& out) -> bool {
     out.clear();
     if (n == 0) return bytes == 0;

@@ -40,6 +40,12 @@ class Mode(Enum):
     AVEP = 4
 
 
+def _in_final_order(q_order: Sequence[str]) -> bool:
+    """Query ids strictly descending: the order a ``Ranking`` the constructor sorted has
+    (ranking.py:115-117).  A user-built ``Ranking(..., is_sorted=True)`` need not be."""
+    return all(q_order[i] > q_order[i + 1] for i in range(len(q_order) - 1))
+
+
 def _grouped_by_query(q_no: np.ndarray, n_queries: int):
     """CSR over pairs: a permutation that makes every query's pairs contiguous (identity when
     they already are) and the offsets of each query."""
@@ -298,7 +304,8 @@ class Index(abc.ABC):
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
         grouped, block_off = _grouped_by_query(q_no, n_q) if len(df) > 0 else (0, None)
-        if early_stopping is not None and len(df) > 0 and (batch_size is None or batch_size >= n_q or grouped is None):
+        final_order = _in_final_order(q_order)
+        if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
             # arrays in, arrays out: only the candidates that get scored are looked up and kept
             ids_col, sparse_col = df["id"].to_numpy(), df["score"].to_numpy()
             if batch_size is None or batch_size >= n_q:
@@ -327,9 +334,10 @@ class Index(abc.ABC):
         if early_stopping is None and len(df) > 0 and (batch_size is None or batch_size >= n_q or _grouped_by_query(q_no, n_q)[0] is None):
             # the common case without the intermediate frames: CSR in, scores out
             perm, pair_off = _grouped_by_query(q_no, n_q)
-            if perm is None:
+            if perm is None and final_order:
                 # rows of a query are adjacent and the queries already stand in their final order
-                # (a Ranking is sorted by q_id), so the device's per-query order is the whole sort
+                # (a Ranking the constructor sorted: checked above), so the device's per-query order
+                # is the whole sort
                 if batch_size is None or batch_size >= n_q:
                     dense, _, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sort=True)
                 else:
@@ -347,10 +355,13 @@ class Index(abc.ABC):
                 cols["query"] = df["query"].to_numpy()[order]
                 LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
                 return Ranking._assemble(cols, "fast-forward", q_no, q_order)
-            dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals[perm], self.mode)
-            unperm = np.empty_like(dense)
-            unperm[perm] = dense
-            dense = unperm
+            if perm is None:
+                dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals, self.mode)
+            else:
+                dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals[perm], self.mode)
+                unperm = np.empty_like(dense)
+                unperm[perm] = dense
+                dense = unperm
             result = df.copy()
             result["score"] = dense.astype(df.dtypes["score"], copy=False)
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
@@ -398,9 +409,9 @@ class Index(abc.ABC):
             rank = np.arange(len(src)) - np.repeat(pair_off[:-1], np.diff(pair_off))
             keep = rank < cutoff
             src, order = src[keep], order[keep]
-        if perm is None:
-            # the queries already stand in their final order (a Ranking is sorted by q_id) and the
-            # device ordered each one: nothing is left to sort or to check
+        if perm is None and _in_final_order(q_order):
+            # the queries already stand in their final order (a Ranking the constructor sorted) and
+            # the device ordered each one: nothing is left to sort or to check
             cols = {c: df[c].to_numpy()[src] for c in ("q_id", "id")}
             cols["score"] = interp[order].astype(df.dtypes["score"], copy=False)
             cols["query"] = df["query"].to_numpy()[src]

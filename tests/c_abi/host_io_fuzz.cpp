@@ -1,0 +1,199 @@
+// Sanitizer driver for csrc/host_io.cpp (string-id tables + TREC run parser/writer), the only part
+// of libffx that parses untrusted input.  Built by `make -C fast-forward-indexes_amd/csrc host_asan`
+// with g++ -fsanitize=address,undefined and run by tests/test_host_io.py: a well-formed run, a set
+// of hand-written adversarial files, and a few thousand seeded mutations of both (truncations, NUL
+// bytes, huge fields, missing columns, non-numeric scores) go through every entry point.  Any
+// out-of-bounds access, use-after-free, overflow or misaligned access aborts the process.
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ffx.h"
+
+// host_io.cpp reports errors through ffx.hip's ffx_fail; the sanitizer build has no HIP side
+static std::string g_err;
+int ffx_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return rng_state;
+}
+
+static void write_file(const std::string& path, const std::string& data) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { perror(path.c_str()); exit(2); }
+  fwrite(data.data(), 1, data.size(), f);
+  fclose(f);
+}
+
+static long g_opened = 0, g_rejected = 0;
+
+// every entry point on one file, with and without an id table
+static void exercise(const std::string& path, const std::string& out_path, ffx_ids* ids) {
+  for (int pass = 0; pass < 2; ++pass) {
+    ffx_run* run = nullptr;
+    int64_t bad = -1;
+    int rc = ffx_run_open(path.c_str(), pass ? ids : nullptr, &run, &bad);
+    if (rc != FFX_OK) {
+      ++g_rejected;
+      if (run) { fprintf(stderr, "a failed open returned a handle\n"); exit(1); }
+      continue;
+    }
+    ++g_opened;
+    int64_t nq = 0, np = 0;
+    ffx_run_counts(run, &nq, &np);
+    int32_t a = 0, b = 0, c = 0;
+    ffx_run_flags(run, &a, &b, &c);
+    const char* s = nullptr;
+    int32_t len = 0;
+    for (int64_t q = -1; q <= nq; ++q)
+      if (ffx_run_query_id(run, q, &s, &len) == FFX_OK && len > 0) (void)s[len - 1];
+    if (ffx_run_tag(run, &s, &len) == FFX_OK && len > 0) (void)s[len - 1];
+    if (!pass) {
+      int64_t need = 0;
+      ffx_run_ids_blob(run, nullptr, 0, &need);
+      std::vector<char> blob((size_t)need + 1);
+      ffx_run_ids_blob(run, blob.data(), need, &need);
+      ffx_run_ids_blob(run, blob.data(), need > 0 ? need - 1 : 0, &need);  // too small a buffer
+    }
+    std::vector<int64_t> off((size_t)nq + 1);
+    std::vector<int32_t> pid((size_t)np + 1);
+    std::vector<float> sp((size_t)np + 1);
+    int64_t n = 0;
+    const int64_t cutoff = (int64_t)(rnd() % 4);  // 0 = keep all
+    ffx_run_export(run, cutoff, off.data(), pass ? pid.data() : nullptr, sp.data(), &n);
+    ffx_run_counts(run, &nq, &np);
+    if (pass) {
+      std::vector<int32_t> order((size_t)np);
+      for (int64_t q = 0; q < nq; ++q)
+        for (int64_t p = off[(size_t)q]; p < off[(size_t)q + 1]; ++p) order[(size_t)p] = (int32_t)(off[(size_t)q + 1] - 1 - (p - off[(size_t)q]));
+      ffx_run_write(run, out_path.c_str(), sp.data(), order.data(), (int64_t)(rnd() % 3), rnd() % 2 ? "tag" : nullptr);
+    }
+    ffx_run_close(run);
+  }
+}
+
+int main(int argc, char** argv) {
+  const std::string dir = argc > 1 ? argv[1] : "/tmp";
+  const int rounds = argc > 2 ? atoi(argv[2]) : 3000;
+  const std::string in = dir + "/ffx_fuzz_in.tsv", out = dir + "/ffx_fuzz_out.tsv";
+
+  // ---- id table: fixed-width and packed look-ups, growth across rehashes, odd bytes
+  ffx_ids* ids = nullptr;
+  if (ffx_ids_create(&ids) != FFX_OK) return 2;
+  {
+    const int width = 12, n = 5000;
+    std::vector<char> buf((size_t)width * n, 0);
+    for (int i = 0; i < n; ++i) snprintf(&buf[(size_t)i * width], width, "D%d", i % 4000);  // repeats intern to the same ordinal
+    std::vector<int32_t> ord((size_t)n);
+    if (ffx_ids_intern(ids, buf.data(), width, n, ord.data()) != FFX_OK) return 2;
+    int64_t cnt = 0;
+    ffx_ids_count(ids, &cnt);
+    if (cnt != 4000 || ord[4500] != 500) { fprintf(stderr, "intern: %" PRId64 " ids, ord %d\n", cnt, ord[4500]); return 1; }
+    int64_t miss = -1;
+    std::vector<char> q((size_t)width * 3, 0);
+    snprintf(&q[0], width, "D17");
+    snprintf(&q[(size_t)width], width, "nope");
+    memset(&q[(size_t)2 * width], 'x', (size_t)width);  // a field with no NUL terminator at all
+    int rc = ffx_ids_lookup(ids, q.data(), width, 3, ord.data(), &miss);
+    if (rc != FFX_NOT_FOUND || miss != 1 || ord[0] != 17 || ord[2] != -1) { fprintf(stderr, "lookup rc %d miss %" PRId64 "\n", rc, miss); return 1; }
+    const char packed[] = "D1\nD3999\nD4000\n\nD2";
+    rc = ffx_ids_lookup_packed(ids, packed, (int64_t)sizeof packed - 1, '\n', 5, ord.data(), &miss);
+    if (rc != FFX_NOT_FOUND || miss != 2 || ord[1] != 3999 || ord[4] != 2) { fprintf(stderr, "packed rc %d miss %" PRId64 "\n", rc, miss); return 1; }
+    if (ffx_ids_lookup_packed(ids, packed, (int64_t)sizeof packed - 1, '\n', 4, ord.data(), &miss) != FFX_BAD_ARG) return 1;  // wrong count
+    if (ffx_ids_lookup_packed(ids, packed, (int64_t)sizeof packed - 1, '\n', 9, ord.data(), &miss) != FFX_BAD_ARG) return 1;
+    const char* s = nullptr;
+    int32_t len = 0;
+    if (ffx_ids_get(ids, 3999, &s, &len) != FFX_OK || len != 5 || memcmp(s, "D3999", 5) != 0) return 1;
+    if (ffx_ids_get(ids, 4000, &s, &len) == FFX_OK || ffx_ids_get(ids, -1, &s, &len) == FFX_OK) return 1;
+  }
+
+  // ---- well-formed and hand-written adversarial runs
+  std::string good;
+  for (int q = 0; q < 7; ++q)
+    for (int r = 0; r < 9; ++r) {
+      char line[128];
+      snprintf(line, sizeof line, "q%d\tQ0\tD%d\t%d\t%g\trun-x\n", q, (q * 37 + r * 11) % 4000, r + 1, 20.0 - r * 1.25 + q * 0.01);
+      good += line;
+    }
+  std::vector<std::string> seeds = {
+      good,
+      "",                                       // empty file
+      "\n\n\n",                                 // blank lines only
+      "q1 Q0 D1 1 0.5 t",                       // no trailing newline
+      "q1 Q0 D1 1 0.5\n",                       // five fields
+      "q1 Q0 D1 1 0.5 t extra more\n",          // more than six
+      "q1 Q0 D1 1\n",                           // too few
+      "q1 Q0 D1 1 abc t\n",                     // score is text
+      "q1 Q0 D1 1 0x1A t\nq1 Q0 D2 2 0x1p3 t\n",  // hex floats: strtod would take them, pandas does not
+      "q1 Q0 D1 1 nan(123) t\nq1 Q0 D2 2 NAN t\n",
+      "q1 Q0 D1 1 nan t\nq1 Q0 D2 2 NA t\nq2 Q0 D3 1 1.5 t\n",  // pandas NA words: rows dropped
+      "q1 Q0 D1 1 inf t\nq1 Q0 D2 2 -Infinity t\nq1 Q0 D3 3 1e400 t\nq1 Q0 D4 4 1e-400 t\n",
+      "q1 Q0 D99999 1 0.5 t\n",                 // id not in the table
+      std::string("q1 Q0 D1 1 0.5 t\n") + std::string(1 << 16, 'A') + " Q0 D2 1 0.25 t\n",  // a 64 KiB query id
+      "q1 Q0 " + std::string(1 << 16, 'B') + " 1 0.25 t\n",
+      std::string("q1 Q0 D1 1 0.5 t\0q2 Q0 D2 1 0.5 t\n", 34),  // NUL inside the file
+      "q1\tQ0\tD1\t1\t\"0.5\"\tt\n",           // quotes
+      "  q1   Q0   D1   1   0.5   t  \r\n",     // CRLF and runs of blanks
+      "\xff\xfe\xfd Q0 D1 1 0.5 t\n",           // not UTF-8
+      "q1 Q0 D1 1 0.5 t\nq2 Q0 D1 1 0.7 t\nq1 Q0 D2 2 0.1 t\n",  // a query that comes back later
+  };
+  for (const std::string& s : seeds) {
+    write_file(in, s);
+    exercise(in, out, ids);
+  }
+  if (ffx_run_open((dir + "/does-not-exist.tsv").c_str(), nullptr, nullptr, nullptr) == FFX_OK) return 1;
+
+  // ---- seeded mutations
+  for (int it = 0; it < rounds; ++it) {
+    std::string s = seeds[rnd() % seeds.size()];
+    const int edits = 1 + (int)(rnd() % 4);
+    for (int e = 0; e < edits && !s.empty(); ++e) {
+      const size_t at = (size_t)(rnd() % s.size());
+      switch (rnd() % 7) {
+        case 0: s.resize(at); break;                                        // truncate
+        case 1: s[at] = (char)(rnd() & 0xFF); break;                        // flip a byte
+        case 2: s[at] = '\0'; break;
+        case 3: s.insert(at, std::string((size_t)(rnd() % 300), (char)('0' + rnd() % 75))); break;
+        case 4: s.erase(at, (size_t)(rnd() % 40)); break;
+        case 5: s[at] = "\t\n \r"[rnd() % 4]; break;
+        default: s.insert(at, s.substr((size_t)(rnd() % s.size()), (size_t)(rnd() % 200))); break;  // duplicate a piece
+      }
+    }
+    write_file(in, s);
+    exercise(in, out, ids);
+  }
+
+  // ---- Ranking.save without a parsed run
+  {
+    const char qb[] = "qa\nqb", ib[] = "D1\nD2\nD3";
+    const int64_t off[] = {0, 2, 3};
+    const float sc[] = {1.5f, 0.25f, 1e-7f};
+    if (ffx_run_save(out.c_str(), qb, 5, 2, off, ib, 8, 3, sc, "name") != FFX_OK) { fprintf(stderr, "save: %s\n", g_err.c_str()); return 1; }
+    const int64_t bad_off[] = {0, 5, 3};
+    (void)ffx_run_save(out.c_str(), qb, 5, 2, bad_off, ib, 8, 3, sc, "name");   // must be refused, not read past the scores
+    const int64_t off3[] = {0, 2, 3, 3};
+    if (ffx_run_save(out.c_str(), qb, 5, 3, off3, ib, 8, 3, sc, "name") == FFX_OK) return 1;  // fewer query ids than queries
+    if (ffx_run_save(out.c_str(), qb, 5, 2, bad_off, ib, 8, 3, sc, "name") == FFX_OK) return 1;
+  }
+  ffx_ids_destroy(ids);
+  remove(in.c_str());
+  remove(out.c_str());
+  printf("host_io sanitizer run ok: %ld files parsed, %ld rejected\n", g_opened, g_rejected);
+  return g_opened > 0 && g_rejected > 0 ? 0 : 1;
+}

@@ -446,6 +446,50 @@ def test_pq_synthetic_codes_fill():
     idx.close()
 
 
+def test_pq_codes_outside_the_codebook_are_refused_on_upload():
+    """With fewer than 256 codewords per subspace, a code byte >= Ks (a corrupt or foreign index
+    file) would index past the codebook and the ADC tables: uploads reject it, naming row and
+    subspace (and the kernels clamp, so even a code that slipped through reads defined memory)."""
+    m, ks, ds = 8, 16, 96
+    idx = native.DeviceIndex(100, m, dtype=np.uint8)
+    idx.set_codebook(synth.rows(3, 1.0, 0, m * ks, ds).reshape(m, ks, ds))
+    codes = (np.arange(100 * m, dtype=np.int64).reshape(100, m) % ks).astype(np.uint8)
+    idx.upload(codes, 0)
+    bad = codes.copy()
+    bad[37, 5] = ks  # first illegal value
+    with pytest.raises(native.FFXError, match=r"row 37 holds a code >= Ks = 16 in subspace 5"):
+        idx.upload(bad, 0)
+    with pytest.raises(native.FFXError, match=r"row 47 "):
+        idx.upload(bad[30:50], 10)
+    idx.close()
+
+
+@pytest.mark.parametrize("m,ks", [(96, 256), (192, 256)])
+def test_pq_adc_tables_larger_than_the_default_lds_window(m, ks):
+    """exact_sum=False on a quantizer whose per-query table M*Ks*4 exceeds 64 KB (NanoPQ(96, 256) on
+    d = 768 needs 96 KB: opt-in LDS up to the CU's 160 KB) or even the whole LDS (192 KB: tables are
+    read through L2 instead): same scores as decode + dot, within the tolerance."""
+    d, n, nq, k = 768, 500, 3, 100
+    ds = d // m
+    rng = np.random.default_rng(m)
+    codewords = rng.standard_normal((m, ks, ds)).astype(np.float32) * 0.1
+    codes = rng.integers(0, ks, size=(n, m)).astype(np.uint8)
+    idx = native.DeviceIndex(n, m, dtype=np.uint8)
+    idx.set_codebook(codewords)
+    idx.upload(codes, 0)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    pair_off = np.arange(nq + 1, dtype=np.int64) * k
+    pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for _ in range(nq)]).astype(np.int32)
+    ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, MODE_NO["PASSAGE"], exact_sum=False)
+    assert st["kernel_variant"] == (2300 if m * ks * 4 <= 160 * 1024 else 2301)
+    decoded = np.concatenate([codewords[j][codes[:, j]] for j in range(m)], axis=1)
+    want = (queries[np.repeat(np.arange(nq), k)].astype(np.float64) * decoded[pair_ids].astype(np.float64)).sum(1)
+    assert np.abs(ff - want).max() <= FAST_TOL * max(1.0, np.abs(want).max())
+    idx.close()
+
+
 # ---- BASELINE.json's full size ----------------------------------------------------------------------------
 def test_baseline_config_full_size_properties():
     """8 841 823 x 768 fp32 in HBM, 6980 queries x k=5000 (34.9 M pairs, the bench workload), checked

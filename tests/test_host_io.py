@@ -197,3 +197,40 @@ def test_large_run_is_parsed_and_written_in_parallel_pieces(tmp_path):
     path.write_text("\n".join(broken) + "\n")
     with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
         native.RunFile(path, table)
+
+
+def test_run_parser_drops_rows_with_missing_scores_and_refuses_non_decimal_ones(tmp_path):
+    """File-to-file path: a score that is one of pandas' NA words drops the row (Ranking's dropna,
+    ranking.py:103); a spelling pandas would not read as a number is an error, not a silent number."""
+    table = _table("d0", "d1", "d2")
+    p = tmp_path / "na.tsv"
+    p.write_text("q1 Q0 d0 1 1.5 t\nq1 Q0 d1 2 nan t\nq1 Q0 d2 3 NA t\nq2 Q0 d1 1 N/A t\nq3 Q0 d2 1 inf t\n")
+    run = native.RunFile(p, table)
+    pair_off, pair_ids, sparse = run.export()
+    assert run.query_ids() == ["q1", "q3"] and pair_off.tolist() == [0, 1, 2] and pair_ids.tolist() == [0, 2]
+    assert sparse.tolist() == [1.5, float("inf")]
+    for bad in ("0x1A", "0x1p3", "nan(123)", "NAN", "1e", "abc"):
+        p.write_text(f"q1 Q0 d0 1 1.5 t\nq1 Q0 d1 2 {bad} t\n")
+        with pytest.raises(ValueError, match="bad score"):
+            native.RunFile(p, table)
+
+
+def test_host_natives_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """csrc/host_io.cpp -- the code that parses untrusted run files -- built alone with
+    g++ -fsanitize=address,undefined and driven by tests/c_abi/host_io_fuzz.cpp: a well-formed run,
+    20 hand-written adversarial files (truncated, NUL bytes, 64 KiB fields, hex floats, missing
+    columns, not UTF-8 ...) and 3000 seeded mutations of them through every ffx_ids_* / ffx_run_*
+    entry point.  Any out-of-bounds access or undefined behaviour aborts the driver."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ here")
+    csrc = Path(__file__).resolve().parent.parent / "fast-forward-indexes_amd" / "csrc"
+    build = subprocess.run(["make", "-C", str(csrc), "host_asan"], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stdout[-2000:] + build.stderr[-4000:]
+    run = subprocess.run([str(csrc / "build" / "host_io_asan"), str(tmp_path), "3000"], capture_output=True, text=True, timeout=600,
+                         env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1", "PATH": "/usr/bin:/bin"})
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-6000:]
+    assert "host_io sanitizer run ok" in run.stdout

@@ -429,3 +429,26 @@ def test_sharded_index_api_matches_reference_frames(world):
     codes, outs = run_ranks(world, root / "tests" / "_sharded_api_worker.py")
     assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
     assert "owned rows checked" in outs[0][0]
+
+
+def test_call_on_a_ranking_the_user_declared_sorted_still_comes_back_sorted():
+    """A Ranking built with is_sorted=True whose queries are contiguous but NOT in q_id-descending
+    order: the reference re-sorts the result (base.py:463-469), so must the fast paths."""
+    rng = np.random.default_rng(5)
+    n, d = 60, 32
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qv = rng.standard_normal((3, d)).astype(np.float32)
+    index = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=Mode.PASSAGE)
+    index.add(rows, psg_ids=[f"p{i}" for i in range(n)])
+    frame = pd.DataFrame({"q_id": ["qa"] * 5 + ["qc"] * 5 + ["qb"] * 5,               # ascending-ish: not the constructor's order
+                          "id": [f"p{i}" for i in rng.choice(n, 15, replace=False)], "score": np.linspace(5, 1, 15).astype(np.float32),
+                          "query": ["0"] * 5 + ["2"] * 5 + ["1"] * 5})
+    declared = Ranking(frame, is_sorted=True)
+    honest = Ranking(frame, is_sorted=False)
+    for got, want in ((index(declared), index(honest)), (index.rerank(declared, 0.3), index.rerank(honest, 0.3)),
+                      (index(declared, early_stopping=2, early_stopping_alpha=0.3, early_stopping_depths=(2, 5)),
+                       index(honest, early_stopping=2, early_stopping_alpha=0.3, early_stopping_depths=(2, 5)))):
+        assert got == want
+        assert got._df["q_id"].tolist() == want._df["q_id"].tolist() == sorted(want._df["q_id"].tolist(), reverse=True)
+        assert got._df["id"].tolist() == want._df["id"].tolist()
+    index.close()

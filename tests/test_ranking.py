@@ -305,6 +305,28 @@ def test_from_file_native_parser_equals_the_pandas_route(tmp_path, monkeypatch, 
             Ranking.from_file(path, queries={"only": "one"})
 
 
+@pytest.mark.parametrize("token,raises", [("0x1A", True), ("0x1p3", True), ("nan(123)", True), ("NAN", False), ("1e", True), ("--1", True)])
+def test_from_file_native_parser_leaves_odd_score_spellings_to_pandas(tmp_path, monkeypatch, token, raises):
+    """strtod would read hexadecimal floats and "nan(...)" as numbers; pandas.read_csv does not.  The
+    native parser refuses such files, so from_file behaves exactly as the pandas route does (the
+    reference raises ValueError on them, or keeps an upper-case NAN as a NaN-scored row)."""
+    rng = np.random.default_rng(11)
+    lines = _run_lines(rng, 40, 400)
+    parts = lines[4321].split()
+    parts[4] = token
+    lines[4321] = " ".join(parts)
+    path = tmp_path / "run.tsv"
+    path.write_text("\n".join(lines) + "\n")
+    assert Ranking._from_file_native(path, None, np.dtype(np.float32)) is None
+    if raises:
+        with pytest.raises(ValueError):
+            Ranking.from_file(path)
+    else:
+        got = Ranking.from_file(path)
+        monkeypatch.setattr(Ranking, "_from_file_native", classmethod(lambda cls, f, queries, dtype: None))
+        pd.testing.assert_frame_equal(got._df, Ranking.from_file(path)._df)
+
+
 def test_from_file_native_parser_reports_repeated_pairs(tmp_path):
     rng = np.random.default_rng(1)
     lines = _run_lines(rng, 40, 400)
