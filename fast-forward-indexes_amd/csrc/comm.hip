@@ -550,8 +550,23 @@ static int shm_exchange(ffx_comm* c, const float* send, const int64_t* send_coun
 
 int ffx_comm_exchange_host(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts) {
   if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
-  if (c->transport != FFX_COMM_HOST) return ffx_fail(FFX_BAD_ARG, "host buffers travel on the host transport only");
-  return shm_exchange(c, send, send_counts, recv, recv_counts, false, nullptr);
+  if (c->transport == FFX_COMM_HOST) return shm_exchange(c, send, send_counts, recv, recv_counts, false, nullptr);
+  // RCCL: the same all-to-all-v, staged through device scratch (a streamed index produces its local
+  // scores on the host: they are PCIe-bound already)
+  int64_t n_send = 0, n_recv = 0;
+  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
+  C_HIP(hipSetDevice(c->device));
+  float* dev = nullptr;
+  C_HIP(hipMalloc(reinterpret_cast<void**>(&dev), (size_t)std::max<int64_t>(n_send + n_recv, 1) * sizeof(float)));
+  int rc = FFX_OK;
+  if (n_send > 0 && hipMemcpyAsync(dev, send, (size_t)n_send * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    rc = ffx_fail(FFX_HIP_ERROR, "upload of the local scores failed");
+  if (rc == FFX_OK) rc = ffx_comm_exchange(c, dev, send_counts, dev + n_send, recv_counts, c->stream);
+  if (rc == FFX_OK && n_recv > 0 && hipMemcpyAsync(recv, dev + n_send, (size_t)n_recv * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    rc = ffx_fail(FFX_HIP_ERROR, "download of the received scores failed");
+  if (hipStreamSynchronize(c->stream) != hipSuccess && rc == FFX_OK) rc = ffx_fail(FFX_HIP_ERROR, "stream synchronisation failed");
+  (void)hipFree(dev);
+  return rc;
 }
 
 int ffx_comm_exchange(ffx_comm* c, const float* send_dev, const int64_t* send_counts, float* recv_dev, const int64_t* recv_counts,

@@ -114,6 +114,11 @@ class IdTable:
             raise IndexError(f"ID {first_bad} not found in the index.")
         return ordinals[codes].astype(np.int32)
 
+    def lookup_optional(self, ids, mode: int) -> np.ndarray:
+        """Ordinals (int64) of ``ids`` for ``mode``, -1 where the id is not in the table."""
+        table = self._psg_ordinal if mode == PASSAGE else self._doc_ordinal
+        return np.fromiter((table.get(u, -1) for u in ids), dtype=np.int64, count=len(ids))
+
     def native_table(self, mode: int):
         """The native (libffx) mirror of the doc- or passage-id table, rebuilt when ids changed;
         ordinals agree with ``resolve``.  Used by the file-to-file path (``RunFile``)."""

@@ -231,7 +231,111 @@ def _owner_of(doc_id: str | None, psg_id: str | None, world: int) -> int:
     return zlib.crc32(key.encode()) % world
 
 
-class ShardedInMemoryIndex:
+class _ShardedIndex:
+    """What the sharded index classes share: the ``Index`` surface over SPMD ranks.  Subclasses say
+    who holds each candidate (``_holders``) and own the shard."""
+
+    comm = None
+    local = None  # the object carrying mode / query encoder (an Index)
+    exact_sum = True
+
+    # ---- configuration mirrors the local index -----------------------------------------------------------
+    @property
+    def mode(self):
+        return self.local.mode
+
+    @mode.setter
+    def mode(self, mode) -> None:
+        self.local.mode = mode
+
+    @property
+    def dim(self):
+        return self.local.dim
+
+    def _holders(self, ids: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """(holder rank, ordinal on that rank) of every candidate id; ``IndexError`` on EVERY rank for
+        an id no rank holds (the reference's util.py:38-39)."""
+        raise NotImplementedError
+
+    def _sharded(self) -> ShardedScorer:
+        raise NotImplementedError
+
+    def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode) -> np.ndarray | None:
+        """Dense scores of this rank's candidates computed outside ``ffx_sharded`` (a shard that is
+        streamed from its file instead of resident), or None when the resident scorer does it."""
+        return None
+
+    def _score(self, ranking, alpha: float | None, sort: bool):
+        from fast_forward_amd import native
+        from fast_forward_amd.index.api import _grouped_by_query
+
+        if not ranking.has_queries:
+            raise ValueError("Input ranking has no queries attached.")
+        df = ranking._df
+        q_no, q_ids, texts = self.local._numbered_queries(ranking)
+        n_q = len(texts)
+        query_vectors = np.ascontiguousarray(self.local.encode_queries(texts), dtype=np.float32)
+        perm, pair_off = _grouped_by_query(q_no, n_q)
+        ids = df["id"].to_numpy()
+        sparse = df["score"].to_numpy(dtype=np.float32)
+        if perm is not None:
+            ids, sparse = ids[perm], sparse[perm]
+        holder, local_ids = self._holders(ids)
+        mode = self.local.mode.value
+        streamed = self._local_scores(query_vectors, pair_off, holder, local_ids, mode)
+        if streamed is None:
+            scorer = self._sharded()
+            scorer.set_queries(query_vectors)
+            scorer.set_pairs(pair_off, local_ids, sparse if alpha is not None else None, mode, holder=holder)
+            scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
+            ff, interp, order = scorer.fetch(order=sort)
+            lo, hi = scorer.own_first_pair, scorer.own_first_pair + scorer.own_pairs
+        else:
+            # the same exchange on host buffers, then the owner-side epilogue (ffx_aggregate, 1-row segments)
+            r = native.route(pair_off, local_ids, self.comm.rank, self.comm.world, holder=holder)
+            recv = self.comm.exchange_host(streamed, r["send_counts"], r["recv_counts"])
+            dense = recv[r["recv_slot"]]
+            lo, hi = r["own_first_pair"], r["own_first_pair"] + r["own_pairs"]
+            own_off = pair_off[r["q_lo"]:r["q_hi"] + 1] - lo
+            if hi > lo:
+                ff, interp, order = native.aggregate(dense, np.arange(hi - lo + 1, dtype=np.int64), 1, sparse[lo:hi] if alpha is not None else None,
+                                                     0.0 if alpha is None else alpha, own_off, sort=sort, device=self.comm.device)
+            else:
+                ff, interp, order = dense, (dense if alpha is not None else None), np.zeros(0, dtype=np.int32)
+        score = interp if alpha is not None else ff
+        rows = np.arange(lo, hi) if perm is None else perm[lo:hi]
+        if sort:
+            rows, score = rows[order], score[order]
+        out = df.iloc[rows].reset_index(drop=True)
+        out["score"] = score.astype(df.dtypes["score"])
+        return out
+
+    def _finish(self, frame, ranking, name, gather: bool):
+        import pickle
+
+        import pandas as pd
+
+        from fast_forward_amd.ranking import Ranking
+
+        if gather:  # every rank's frame, through the control plane (sizes first, then padded payloads)
+            blob = pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL)
+            sizes = self.comm.allgather_array(np.array([len(blob)], dtype=np.int64))[:, 0]
+            padded = np.zeros(int(sizes.max()), dtype=np.uint8)
+            padded[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+            blobs = self.comm.allgather_array(padded)
+            frame = pd.concat([pickle.loads(blobs[r, :int(sizes[r])].tobytes()) for r in range(self.comm.world)], ignore_index=True)
+        return Ranking(Ranking._trusted(frame), name=name, dtype=ranking._df.dtypes["score"], copy=False, is_sorted=False)
+
+    def __call__(self, ranking, gather: bool = False):
+        """Dense scores (``Index.__call__``) of the queries this rank owns, or of all with ``gather``."""
+        return self._finish(self._score(ranking, None, sort=False), ranking, "fast-forward", gather)
+
+    def rerank(self, ranking, alpha: float, gather: bool = False):
+        """``ranking.interpolate(index(ranking), alpha)`` with the epilogue on the owners' devices."""
+        return self._finish(self._score(ranking, alpha, sort=True), ranking, ranking.name, gather)
+
+
+class ShardedInMemoryIndex(_ShardedIndex):
     """``InMemoryIndex`` spread over the ranks of a communicator (SPMD: every rank makes the same
     calls with the same arguments).
 
@@ -258,21 +362,8 @@ class ShardedInMemoryIndex:
         self._scorer: ShardedScorer | None = None
         self._scorer_store = None
 
-    # ---- configuration mirrors the local index -----------------------------------------------------------
-    @property
-    def mode(self):
-        return self.local.mode
-
-    @mode.setter
-    def mode(self, mode) -> None:
-        self.local.mode = mode
-
     def __len__(self) -> int:
         return self._n_global
-
-    @property
-    def dim(self):
-        return self.local.dim
 
     def add(self, vectors: np.ndarray, doc_ids=None, psg_ids=None) -> None:
         n = vectors.shape[0]
@@ -293,6 +384,8 @@ class ShardedInMemoryIndex:
     # ---- scoring ---------------------------------------------------------------------------------------------
     def _sharded(self) -> ShardedScorer:
         """The native scorer over the local store (rebuilt when the store was re-allocated by add)."""
+        if not len(self.local):
+            raise RuntimeError(f"rank {self.rank} holds no rows: a sharded index needs at least one row per rank")
         self.local._sync_ids()
         store = self.local._store
         if self._scorer is None or self._scorer_store is not store:
@@ -301,25 +394,11 @@ class ShardedInMemoryIndex:
             self._scorer, self._scorer_store = ShardedScorer(store, None, self.comm), store
         return self._scorer
 
-    def _score(self, ranking, alpha: float | None, sort: bool):
-        from fast_forward_amd.index.api import _grouped_by_query
-
-        if not ranking.has_queries:
-            raise ValueError("Input ranking has no queries attached.")
-        df = ranking._df
-        q_no, q_ids, texts = self.local._numbered_queries(ranking)
-        n_q = len(texts)
-        query_vectors = np.ascontiguousarray(self.local.encode_queries(texts), dtype=np.float32)
-        perm, pair_off = _grouped_by_query(q_no, n_q)
-        ids = df["id"].to_numpy()
-        sparse = df["score"].to_numpy(dtype=np.float32)
-        if perm is not None:
-            ids, sparse = ids[perm], sparse[perm]
+    def _holders(self, ids: np.ndarray):
         # which candidates do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
         table = self.local._ids
-        lookup = table._psg_ordinal if self.local.mode.value == 1 else table._doc_ordinal
         uniq, inv = np.unique(ids, return_inverse=True)
-        ord_u = np.fromiter((lookup.get(u, -1) for u in uniq), dtype=np.int64, count=len(uniq))
+        ord_u = table.lookup_optional(uniq, self.local.mode.value)
         # one small control message: the bit mask of the unique ids every rank holds
         held = self.comm.allgather_array(np.packbits(ord_u >= 0))
         held = np.unpackbits(held, axis=1, count=len(uniq)).astype(bool) if len(uniq) else np.zeros((self.world, 0), dtype=bool)
@@ -328,49 +407,146 @@ class ShardedInMemoryIndex:
             first = int(np.flatnonzero(np.isin(inv, missing))[0])  # the first one in candidate order, on every rank
             raise IndexError(f"ID {ids[first]} not found in the index.")
         holder_u = held.argmax(axis=0).astype(np.int32) if len(uniq) else np.zeros(0, dtype=np.int32)
-        scorer = self._sharded() if len(self.local) else None
-        if scorer is None:
-            raise RuntimeError(f"rank {self.rank} holds no rows: a sharded index needs at least one row per rank")
-        scorer.set_queries(query_vectors)
-        scorer.set_pairs(pair_off, np.maximum(ord_u, 0)[inv].astype(np.int32), sparse if alpha is not None else None,
-                         self.local.mode.value, holder=holder_u[inv])
-        scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
-        ff, interp, order = scorer.fetch(order=sort)
-        lo, hi = scorer.own_first_pair, scorer.own_first_pair + scorer.own_pairs
-        score = interp if alpha is not None else ff
-        rows = np.arange(lo, hi) if perm is None else perm[lo:hi]
-        if sort:
-            rows, score = rows[order], score[order]
-        out = df.iloc[rows].reset_index(drop=True)
-        out["score"] = score.astype(df.dtypes["score"])
-        return out
-
-    def _finish(self, frame, ranking, name, gather: bool):
-        import pickle
-
-        import pandas as pd
-
-        from fast_forward_amd.ranking import Ranking
-
-        if gather:  # every rank's frame, through the control plane (sizes first, then padded payloads)
-            blob = pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL)
-            sizes = self.comm.allgather_array(np.array([len(blob)], dtype=np.int64))[:, 0]
-            padded = np.zeros(int(sizes.max()), dtype=np.uint8)
-            padded[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
-            blobs = self.comm.allgather_array(padded)
-            frame = pd.concat([pickle.loads(blobs[r, :int(sizes[r])].tobytes()) for r in range(self.world)], ignore_index=True)
-        return Ranking(Ranking._trusted(frame), name=name, dtype=ranking._df.dtypes["score"], copy=False, is_sorted=False)
-
-    def __call__(self, ranking, gather: bool = False):
-        """Dense scores (``Index.__call__``) of the queries this rank owns, or of all with ``gather``."""
-        return self._finish(self._score(ranking, None, sort=False), ranking, "fast-forward", gather)
-
-    def rerank(self, ranking, alpha: float, gather: bool = False):
-        """``ranking.interpolate(index(ranking), alpha)`` with the epilogue on the owners' devices."""
-        return self._finish(self._score(ranking, alpha, sort=True), ranking, ranking.name, gather)
+        return holder_u[inv], np.maximum(ord_u, 0)[inv].astype(np.int32)
 
     def close(self) -> None:
         if self._scorer is not None:
             self._scorer.close()
             self._scorer = None
         self.local.close()
+
+
+class ShardedOnDiskIndex(_ShardedIndex):
+    """An index FILE (this build's container, or an HDF5 file written by the reference) spread over
+    the ranks of a communicator: BASELINE config 5 (100 M x 768 fp32 = 307 GB does not fit one GPU;
+    over 8 GPUs a shard is 38.4 GB and is simply resident).
+
+    Every rank opens the same file and reads the id tables; documents are cut into ``world``
+    contiguous ordinal ranges of ~equal row count (``doc_partition``; rows without a document id are
+    dealt out in contiguous blocks), and rank r moves ITS rows from the chunk maps to its HBM through
+    ``ffx_index_upload_rows`` (native threads, page-locked staging) -- the sharded form of
+    ``OnDiskIndex.to_memory`` (reference disk.py:177-205).  Scoring is then exactly the resident
+    sharded path (local gather_dot, one all-to-all of scores, owner-side merge).
+
+    ``resident=False`` (or a shard larger than the free HBM): the shard stays in the file and each
+    call streams the rows its local candidates need through two HBM windows, as the 1-GPU
+    ``OnDiskIndex`` does (reference disk.py:309-336); local scores are then exchanged from host
+    buffers.  Either way the scores equal the single-process result bit for bit."""
+
+    def __init__(self, index_file, comm=None, query_encoder=None, mode=None, encoder_batch_size: int = 32, exact_sum: bool = True,
+                 resident: bool | None = None, window_bytes: int = 1 << 30):
+        from fast_forward_amd import native
+        from fast_forward_amd.index import Mode
+        from fast_forward_amd.index.ondisk import _READ_THREADS, OnDiskIndex
+
+        self.comm = comm if comm is not None else connect()
+        self.rank, self.world, self.device = self.comm.rank, self.comm.world, self.comm.device
+        self.exact_sum = exact_sum
+        self.local = OnDiskIndex.load(index_file, query_encoder=query_encoder, mode=mode or Mode.MAXP, encoder_batch_size=encoder_batch_size,
+                                      device=self.device, exact_sum=exact_sum, window_bytes=window_bytes)
+        disk, ids = self.local, self.local._ids
+        n = len(disk)
+        doc_off, doc_rows = ids.doc_csr()
+        psg_rows = ids.psg_rows().astype(np.int64)
+        self.doc_bounds = doc_partition(doc_off, self.world)
+        # who holds which stored row: the rows of a rank's documents, then its share of the rows that
+        # belong to no document (passage-only rows), both in a fixed order every rank derives alike
+        row_holder = np.full(n, -1, dtype=np.int32)
+        for r in range(self.world):
+            row_holder[doc_rows[doc_off[self.doc_bounds[r]]:doc_off[self.doc_bounds[r + 1]]]] = r
+        orphans = np.flatnonzero(row_holder < 0)
+        cuts = (np.arange(self.world + 1, dtype=np.int64) * orphans.shape[0]) // self.world
+        for r in range(self.world):
+            row_holder[orphans[cuts[r]:cuts[r + 1]]] = r
+        d_lo, d_hi = int(self.doc_bounds[self.rank]), int(self.doc_bounds[self.rank + 1])
+        my_doc_rows = doc_rows[doc_off[d_lo]:doc_off[d_hi]].astype(np.int64)  # grouped by document, insertion order inside
+        self._my_rows = np.concatenate([my_doc_rows, orphans[cuts[self.rank]:cuts[self.rank + 1]]])
+        self._local_doc_off = (doc_off[d_lo:d_hi + 1] - doc_off[d_lo]).astype(np.int64)
+        local_row = np.full(n, -1, dtype=np.int64)
+        local_row[self._my_rows] = np.arange(self._my_rows.shape[0])
+        # passage ordinal -> (holder, ordinal on the holder): a rank numbers its passages in global ordinal order
+        self._psg_holder = row_holder[psg_rows] if psg_rows.size else np.zeros(0, dtype=np.int32)
+        order = np.argsort(self._psg_holder, kind="stable")
+        starts = np.searchsorted(self._psg_holder[order], np.arange(self.world))
+        self._psg_local = np.empty(psg_rows.shape[0], dtype=np.int32)
+        self._psg_local[order] = (np.arange(psg_rows.shape[0]) - starts[self._psg_holder[order]]).astype(np.int32)
+        mine_psg = np.flatnonzero(self._psg_holder == self.rank)
+        self._my_psg_global = mine_psg                                   # local passage ordinal -> global passage ordinal
+        self._local_psg_row = local_row[psg_rows[mine_psg]].astype(np.int32)
+        self.rows_per_rank = np.bincount(row_holder, minlength=self.world)
+        stored = np.dtype(disk._meta["dtype"]) if disk._meta["dtype"] else np.dtype(np.float32)
+        book = disk._quantizer.device_codebook() if disk._quantizer is not None else None
+        direct = (stored in (np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.uint8)) and (disk._quantizer is None) == (stored != np.dtype(np.uint8))
+                  and (disk._quantizer is None or book is not None))
+        shard_bytes = int(self._my_rows.shape[0]) * int(disk._meta["dim"] or 0) * (stored.itemsize if direct else 4)
+        if resident is None:
+            resident = shard_bytes <= 0.8 * native.device_info(self.device)["free_bytes"]
+        # every rank must take the same branch (the exchange differs): resident only if it is for all
+        self.resident = bool(self.comm.allreduce([1.0 if resident else 0.0], native.OP_MIN)[0])
+        self._store = self._scorer = None
+        if self.resident and self._my_rows.shape[0]:
+            chunk_maps = [m[0] for m in disk._maps]
+            if direct and all(isinstance(c, np.ndarray) and c.flags["C_CONTIGUOUS"] for c in chunk_maps):
+                self._store = native.DeviceIndex(self._my_rows.shape[0], int(disk._meta["dim"]), self.device, dtype=stored)
+                if book is not None:
+                    self._store.set_codebook(book[0])
+                self._store.upload_rows(chunk_maps, self._my_rows, 0, _READ_THREADS)
+            else:  # float64 files of the reference, or a quantizer the kernels cannot read: decoded fp32 rows
+                data = disk._read_rows(self._my_rows)
+                if disk._quantizer is not None:
+                    data = disk._quantizer.decode(data)
+                self._store = native.DeviceIndex(self._my_rows.shape[0], data.shape[1], self.device, dtype=np.float32)
+                self._store.upload(np.ascontiguousarray(data, dtype=np.float32), 0)
+            self._rotation = book[1] if (book is not None and self._store.dtype == np.uint8) else None
+            n_doc_rows = int(self._local_doc_off[-1])
+            self._store.set_doc_rows(self._local_doc_off, np.arange(n_doc_rows, dtype=np.int32))
+            self._store.set_psg_rows(self._local_psg_row if self._local_psg_row.size else np.zeros(0, dtype=np.int32))
+            self._scorer = ShardedScorer(self._store, None, self.comm)
+        elif self.resident:
+            raise RuntimeError(f"rank {self.rank} holds no rows: a sharded index needs at least one row per rank")
+
+    def __len__(self) -> int:
+        return len(self.local)
+
+    def _sharded(self) -> ShardedScorer:
+        return self._scorer
+
+    def _holders(self, ids: np.ndarray):
+        # every rank has the whole id table: an unknown id raises the same IndexError everywhere
+        ordinals = self.local._resolve_ids(ids, self.local.mode).astype(np.int64)
+        if self.local.mode.value == 1:
+            return self._psg_holder[ordinals].astype(np.int32), self._psg_local[ordinals]
+        holder = (np.searchsorted(self.doc_bounds, ordinals, side="right") - 1).astype(np.int32)
+        return holder, (ordinals - self.doc_bounds[holder]).astype(np.int32)
+
+    def _score(self, ranking, alpha, sort):
+        if self.resident and getattr(self, "_rotation", None) is not None:
+            raise NotImplementedError("OPQ-rotated queries on a sharded on-disk index: use to_memory() on one GPU")
+        return super()._score(ranking, alpha, sort)
+
+    def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode):
+        if self.resident:
+            return None
+        mine = np.flatnonzero(holder == self.rank)
+        n_q = pair_off.shape[0] - 1
+        pair_q = np.repeat(np.arange(n_q, dtype=np.int64), np.diff(pair_off))
+        local_off = np.zeros(n_q + 1, dtype=np.int64)
+        np.cumsum(np.bincount(pair_q[mine], minlength=n_q), out=local_off[1:])
+        if mine.size == 0:
+            return np.zeros(0, dtype=np.float32)
+        # back to the file's own ordinals: the 1-GPU streaming path takes it from there
+        if mode == 1:
+            global_ids = self._my_psg_global[local_ids[mine]]
+        else:
+            global_ids = local_ids[mine].astype(np.int64) + self.doc_bounds[self.rank]
+        ff, _, _ = self.local._score_pairs(query_vectors, local_off, global_ids.astype(np.int32), self.local.mode)
+        return ff
+
+    def close(self) -> None:
+        if self._scorer is not None:
+            self._scorer.close()
+            self._scorer = None
+        if self._store is not None:
+            self._store.close()
+            self._store = None
+        self.local._release_windows()

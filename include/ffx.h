@@ -213,7 +213,8 @@ int ffx_comm_allgather(ffx_comm* comm, const void* mine, int64_t bytes, void* al
  * until the scores have arrived. */
 int ffx_comm_exchange(ffx_comm* comm, const float* send_dev, const int64_t* send_counts, float* recv_dev,
                       const int64_t* recv_counts, void* stream);
-/* the same between HOST buffers (host transport only; needs no GPU) */
+/* the same between HOST buffers (shared-memory transport: needs no GPU; RCCL: staged through device
+ * scratch -- for scores a streamed index produced on the host) */
 int ffx_comm_exchange_host(ffx_comm* comm, const float* send, const int64_t* send_counts, float* recv,
                            const int64_t* recv_counts);
 

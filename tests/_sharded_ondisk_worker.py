@@ -1,0 +1,104 @@
+"""One rank of the ShardedOnDiskIndex test (BASELINE config 5 at fixture size): N ranks share ONE GPU
+and open the same index files -- an HDF5 file written by real HDF5 replaying the reference's calls,
+and this build's own container with documents whose rows are NOT contiguous -- resident shards
+and streamed shards; launched by tests/test_ondisk.py as N plain processes."""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
+    sys.path.insert(0, str(p))
+
+from _cases import MODE_NO, load_scoring_case  # noqa: E402
+from fast_forward_amd import Ranking  # noqa: E402
+from fast_forward_amd.encoder import LambdaEncoder  # noqa: E402
+from fast_forward_amd.index import InMemoryIndex, Mode, OnDiskIndex  # noqa: E402
+from fast_forward_amd.sharded import ShardedOnDiskIndex, connect  # noqa: E402
+
+H5 = ROOT / "tests" / "golden" / "h5"
+work = Path(sys.argv[1])
+comm = connect("host")
+rank, world = comm.rank, comm.world
+checked = 0
+
+# ---- 1. the reference's HDF5 layout (float64 rows, several chunks): every rank maps the file -------------
+rng = np.random.default_rng(0)
+qv = rng.standard_normal((5, 32)).astype(np.float32)
+enc = LambdaEncoder(lambda t: qv[int(t)])
+disk = OnDiskIndex.load(H5 / "big_f64.h5", enc)
+rows = disk._read_rows(np.arange(1400))
+mem = InMemoryIndex(enc)
+mem.add(rows, doc_ids=[f"D{i // 2}" for i in range(1400)], psg_ids=[f"P{i}" for i in range(1400)])
+run = {f"q{q}": {f"D{d}": float(rng.random()) for d in rng.choice(700, size=150 + 10 * q, replace=False)} for q in range(5)}
+first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(5)})
+psg_run = {f"q{q}": {f"P{p}": float(rng.random()) for p in rng.choice(1400, size=90, replace=False)} for q in range(5)}
+first_psg = Ranking.from_run(psg_run, queries={f"q{q}": str(q) for q in range(5)})
+for resident in (True, False):
+    sharded = ShardedOnDiskIndex(H5 / "big_f64.h5", comm, enc, resident=resident, window_bytes=20_000)
+    assert sharded.resident == resident and len(sharded) == 1400
+    assert sharded.rows_per_rank.sum() == 1400 and sharded.rows_per_rank.min() > 0
+    for mode in (Mode.MAXP, Mode.FIRSTP, Mode.AVEP):
+        sharded.mode = mem.mode = mode
+        assert sharded(first, gather=True) == mem(first), (resident, mode)
+        own = sharded.rerank(first, 0.3)
+        want = mem.rerank(first, 0.3)
+        assert 0 < len(own.q_ids) < 5
+        for q in own.q_ids:
+            assert own[q] == want[q]
+            checked += len(own[q])
+    sharded.mode = mem.mode = Mode.PASSAGE
+    assert sharded(first_psg, gather=True) == mem(first_psg), (resident, "PASSAGE")
+    assert sharded.rerank(first_psg, 0.7, gather=True) == mem.rerank(first_psg, 0.7)
+    try:
+        sharded(Ranking.from_run({"q0": {"P1": 1.0, "nowhere": 2.0}}, queries={"q0": "0"}))
+    except IndexError as e:
+        assert "nowhere" in str(e)
+    else:
+        raise AssertionError("unknown id accepted")
+    sharded.close()
+mem.close()
+
+# ---- 2. this build's container; documents re-opened by later add() calls (rows not contiguous), rows
+#         with only a passage id, fp16 storage -------------------------------------------------------------
+case = load_scoring_case("d768_f16")
+qvecs = case.queries
+enc = LambdaEncoder(lambda t: qvecs[int(t)])
+path = work / "shared.ffx"
+n = len(case.vectors)
+perm = np.random.default_rng(3).permutation(n)  # insertion order scrambled: a document's rows are scattered over the file
+doc_names = [case.doc_names[i] if i % 7 else None for i in perm]   # every 7th row has no document id
+psg_names = [case.psg_names[i] for i in perm]
+if rank == 0:
+    w = OnDiskIndex(path, enc, mode=Mode.MAXP, chunk_size=64, overwrite=True)
+    third = n // 3
+    for lo, hi in ((0, third), (third, 2 * third), (2 * third, n)):
+        w.add(case.vectors[perm[lo:hi]], doc_ids=doc_names[lo:hi], psg_ids=psg_names[lo:hi])
+    del w
+comm.barrier()
+mem = InMemoryIndex(enc)
+mem.add(case.vectors[perm], doc_ids=doc_names, psg_ids=psg_names)
+docs = sorted({d for d in doc_names if d})
+rng = np.random.default_rng(9)
+run = {f"q{q}": {d: float(rng.random() * 20) for d in rng.choice(docs, size=30, replace=False)} for q in range(len(case.q_names))}
+first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(len(case.q_names))})
+psg_run = {f"q{q}": {p: float(rng.random()) for p in rng.choice(psg_names, size=40, replace=False)} for q in range(len(case.q_names))}
+first_psg = Ranking.from_run(psg_run, queries={f"q{q}": str(q) for q in range(len(case.q_names))})
+for resident in (True, False):
+    sharded = ShardedOnDiskIndex(path, comm, enc, resident=resident, window_bytes=60_000)
+    assert sharded._store is None or sharded._store.dtype == np.float16
+    for mode in ("MAXP", "AVEP", "FIRSTP"):
+        sharded.mode = mem.mode = Mode(MODE_NO[mode])
+        assert sharded(first, gather=True) == mem(first), (resident, mode)
+        assert sharded.rerank(first, 0.1, gather=True) == mem.rerank(first, 0.1), (resident, mode)
+    sharded.mode = mem.mode = Mode.PASSAGE
+    assert sharded(first_psg, gather=True) == mem(first_psg)
+    checked += len(first_psg._df)
+    sharded.close()
+total = int(comm.allreduce([checked])[0])
+assert "torch" not in sys.modules
+if rank == 0:
+    print(f"sharded on-disk world={world}: {total} rows checked bit for bit against the in-memory index")
+comm.close()

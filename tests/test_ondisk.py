@@ -270,6 +270,22 @@ def test_hdf5_index_scores_like_the_same_data_in_memory():
             assert np.float32(s) == fo.dot_f32(qv2[qi], decoded[int(doc[1:])])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_on_disk_index_equals_the_in_memory_index(tmp_path, world):
+    """BASELINE config 5 at fixture size: `world` ranks (sharing this GPU; scores exchanged through the
+    shared-memory transport) open the same index file -- an HDF5 file in the reference's layout, and
+    this build's container with scattered document rows and fp16 storage -- take a document range each,
+    and score with resident shards and with shards streamed through HBM windows: every frame equals
+    the single-process in-memory index's, bit for bit (tests/_sharded_ondisk_worker.py)."""
+    from test_sharded_native import run_ranks
+
+    root = Path(__file__).resolve().parent.parent
+    codes, outs = run_ranks(world, root / "tests" / "_sharded_ondisk_worker.py", str(tmp_path))
+    assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    assert "rows checked bit for bit" in outs[0][0]
+
+
 # ---- writing HDF5 index files the reference can open (index/h5write.py) ------------------------------
 import subprocess  # noqa: E402
 import sys  # noqa: E402
