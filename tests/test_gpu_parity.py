@@ -459,7 +459,7 @@ def test_pq_codes_outside_the_codebook_are_refused_on_upload():
     bad[37, 5] = ks  # first illegal value
     with pytest.raises(native.FFXError, match=r"row 37 holds a code >= Ks = 16 in subspace 5"):
         idx.upload(bad, 0)
-    with pytest.raises(native.FFXError, match=r"row 47 "):
+    with pytest.raises(native.FFXError, match=r"row 17 "):  # device row: 10 + (37 - 30)
         idx.upload(bad[30:50], 10)
     idx.close()
 
@@ -636,7 +636,7 @@ def test_upload_rows_gathers_from_chunk_maps(monkeypatch, dtype):
     rng = np.random.default_rng(8)
     d, cs = 96, 50
     if dtype == np.uint8:
-        chunks = [rng.integers(0, 256, size=(cs, d), dtype=np.uint8) for _ in range(4)]
+        chunks = [rng.integers(0, 4, size=(cs, d), dtype=np.uint8) for _ in range(4)]  # codes of a Ks = 4 quantizer (others are refused)
     else:
         chunks = [rng.standard_normal((cs, d)).astype(dtype) for _ in range(4)]
     stored = np.concatenate(chunks)
