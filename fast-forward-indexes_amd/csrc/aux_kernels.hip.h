@@ -131,6 +131,137 @@ reduce_kernel(const float* __restrict__ rs, const int32_t* __restrict__ seg_off,
   if (sparse != nullptr) interp[p] = interp_one(a, b, sparse[p], out);
 }
 
+// ---- early stopping (index/base.py:316-387) on the device ---------------------------------------------
+// State: active[q] (the query is still being scored), full-length ff / interp (NaN = not scored).
+// Candidates of a query stand in first-stage rank order, so "ranks a..b-1" is a slice of its list.
+
+// order-preserving image of a float: larger float <=> larger unsigned
+__device__ __forceinline__ unsigned float_image(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float image_float(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// The continue-criterion of base.py:350-358 for every query at once, one block per query: the
+// cutoff-th best interpolated score so far (the worst one if fewer were scored) must be below
+//   alpha * (sparse score of the last scored candidate) + (1 - alpha) * (best dense score so far)
+// in float32 as NumPy >= 2 evaluates it (python_float * np.float32 stays float32).  The k-th
+// largest comes from a 4-pass radix select on the float images: exact, independent of cutoff.
+__global__ void __launch_bounds__(256)
+es_criterion_kernel(const float* __restrict__ interp, const float* __restrict__ ff, const float* __restrict__ sparse,
+                    const int64_t* __restrict__ pair_off, int scored_depth, int cutoff, float a, float b,
+                    int32_t* __restrict__ active) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_k;
+  __shared__ float s_max[4];
+  const int q = blockIdx.x;
+  if (!active[q]) return;  // block-uniform
+  const int64_t lo = pair_off[q];
+  const int64_t len = pair_off[q + 1] - lo;
+  const int n = (int)(len < scored_depth ? len : scored_depth);
+  if (n == 0) {  // nothing scored: the reference's filter never sees the query, so it is not continued
+    if (threadIdx.x == 0) active[q] = 0;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    s_prefix = 0;
+    s_k = (unsigned)(cutoff < n ? cutoff : n);
+  }
+  unsigned mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const unsigned key = float_image(interp[lo + i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned k = s_k;
+      int bin = 255;
+      for (; bin > 0; --bin) {
+        if (hist[bin] >= k) break;
+        k -= hist[bin];
+      }
+      s_prefix = prefix | ((unsigned)bin << shift);
+      s_k = k;
+    }
+    mask |= 0xFFu << shift;
+    __syncthreads();
+  }
+  float best = -__builtin_inff();
+  bool any_nan = false;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float x = ff[lo + i];
+    any_nan |= x != x;
+    best = x > best ? x : best;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(best, off);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = s_max[0];
+    for (int w = 1; w < 4; ++w) best = s_max[w] > best ? s_max[w] : best;
+    const float kth = image_float(s_prefix);
+    const float bound = __fadd_rn(__fmul_rn(a, sparse[lo + n - 1]), __fmul_rn(b, best));
+    active[q] = kth < bound ? 1 : 0;
+  }
+  (void)any_nan;
+}
+
+// candidates of the next interval: cnt[q] = active ? |ranks [a, b) of q| : 0 (+ a zero sentinel)
+__global__ void __launch_bounds__(256)
+es_count_kernel(const int64_t* __restrict__ pair_off, int n_queries, const int32_t* __restrict__ active, int a, int b,
+                int64_t* __restrict__ cnt) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > n_queries) return;
+  int64_t c = 0;
+  if (q < n_queries && active[q]) {
+    const int64_t len = pair_off[q + 1] - pair_off[q];
+    const int64_t hi = len < b ? len : b, lo = len < a ? len : a;
+    c = hi - lo;
+  }
+  cnt[q] = c;
+}
+
+// the interval's own CSR: ordinals, first-stage scores and the position of every pair in the full list
+__global__ void __launch_bounds__(256)
+es_fill_kernel(const int64_t* __restrict__ pair_off, const int32_t* __restrict__ pair_ids, const float* __restrict__ sparse,
+               const int64_t* __restrict__ sub_off, int a, int32_t* __restrict__ sub_ids, float* __restrict__ sub_sparse,
+               int32_t* __restrict__ sub_pos) {
+  const int q = blockIdx.x;
+  const int64_t dst = sub_off[q];
+  const int64_t n = sub_off[q + 1] - dst;
+  const int64_t src = pair_off[q] + a;
+  for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
+    sub_ids[dst + j] = pair_ids[src + j];
+    sub_sparse[dst + j] = sparse[src + j];
+    sub_pos[dst + j] = (int32_t)(src + j);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+es_scatter_kernel(const float* __restrict__ sub_ff, const float* __restrict__ sub_interp, const int32_t* __restrict__ sub_pos,
+                  int64_t n, float* __restrict__ ff, float* __restrict__ interp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t p = sub_pos[i];
+  ff[p] = sub_ff[i];
+  interp[p] = sub_interp[i];
+}
+
+__global__ void __launch_bounds__(256)
+fill_u32_kernel(uint32_t* __restrict__ dst, int64_t n, uint32_t value) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = value;
+}
+
 __global__ void __launch_bounds__(256)
 interp_kernel(const float* __restrict__ ff, const float* __restrict__ sparse, int64_t n_pairs,
               float a, float b, float* __restrict__ interp) {

@@ -186,6 +186,11 @@ struct ffx_plan {
   int32_t variant = 0;
   int32_t order_base = 0;  // added to the positions the per-query order is made of (slices of a larger batch)
   std::vector<int64_t> host_pair_off;
+  // early stopping (ffx_plan_early_stopping): the interval's own CSR lives in a child plan that
+  // shares this plan's stream; pairs set "lazily" have not been validated yet
+  struct ffx_plan* es_child = nullptr;
+  DevBuf es_active, es_cnt, es_pos, es_scan_tmp;
+  bool lazy_pairs = false;
   // Small batches (a service scoring one query at a time) are latency-bound on the copies: a
   // copy between pageable memory and the device blocks the caller each time, so inputs and
   // outputs of up to kStageBytes travel through this page-locked block and only one wait remains.
@@ -643,6 +648,12 @@ int ffx_plan_destroy(ffx_plan* pl) {
   if (!pl) return FFX_OK;
   (void)hipSetDevice(pl->device);
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
+  if (pl->es_child) {
+    pl->es_child->stream = pl->es_child->own_stream;  // it borrowed this plan's stream
+    ffx_plan_destroy(pl->es_child);
+    pl->es_child = nullptr;
+  }
+  for (DevBuf* b : {&pl->es_active, &pl->es_cnt, &pl->es_pos, &pl->es_scan_tmp}) b->release();
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
                     &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps,
                     &pl->flags, &pl->ff, &pl->interp, &pl->order})
@@ -762,6 +773,48 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   FFX_TRY(pl->desc.ensure(rb * sizeof(int2)));
   if (pl->n_rows != pl->n_pairs) FFX_TRY(pl->rs.ensure(rb * sizeof(float)));
   pl->have_pairs = true;
+  pl->lazy_pairs = false;
+  return FFX_OK;
+}
+
+// Candidate lists for ffx_plan_early_stopping: uploaded, NOT validated.  An ordinal that names no
+// row (e.g. -1 for an id the host could not resolve) is an error only if early stopping actually
+// reaches it -- the reference looks ids up interval by interval (index/base.py:362-371).
+int ffx_plan_set_pairs_lazy(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids,
+                            const float* sparse, int mode) {
+  if (!pl || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  if (n_queries > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many queries");
+  if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  if (P > 0 && (!pair_ids || !sparse)) return fail(FFX_BAD_ARG, "early stopping needs candidate ordinals and first-stage scores");
+  FFX_HIP(hipSetDevice(pl->device));
+  pl->have_pairs = false;
+  pl->lazy_pairs = false;
+  pl->ran = false;
+  pl->n_queries = n_queries;
+  pl->n_pairs = P;
+  pl->n_rows = 0;
+  pl->mode = mode;
+  pl->have_sparse = true;
+  pl->host_pair_off.assign(pair_off, pair_off + n_queries + 1);
+  const size_t pb = std::max<size_t>((size_t)P, 1);
+  FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(pl->sparse.ensure(pb * sizeof(float)));
+  FFX_TRY(pl->ff.ensure(pb * sizeof(float)));
+  FFX_TRY(pl->interp.ensure(pb * sizeof(float)));
+  pl->hstage_used = 0;
+  FFX_TRY(plan_h2d(pl, pl->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t)));
+  if (P > 0) {
+    FFX_TRY(plan_h2d(pl, pl->pair_ids.p, pair_ids, (size_t)P * sizeof(int32_t)));
+    FFX_TRY(plan_h2d(pl, pl->sparse.p, sparse, (size_t)P * sizeof(float)));
+  }
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  pl->lazy_pairs = true;
   return FFX_OK;
 }
 
@@ -1140,6 +1193,129 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   FFX_HIP(hipEventRecord(pl->ev[4], st));
   pl->ran = true;
   pl->ran_sort = do_sort;
+  return FFX_OK;
+}
+
+// Index._early_stopping (index/base.py:316-387), device-resident: the per-query state (still active?
+// dense and interpolated score of every candidate scored so far) never leaves HBM between depth
+// intervals; per interval the host reads back two counters (how many candidates / rows the interval
+// has: they size the launches) and nothing else.
+int ffx_plan_early_stopping(ffx_plan* pl, int32_t cutoff, double alpha, const int32_t* depths, int32_t n_depths, uint32_t flags,
+                            int64_t* bad_pair, int64_t* n_scored_pairs, int32_t* n_intervals) {
+  if (bad_pair) *bad_pair = -1;
+  if (n_scored_pairs) *n_scored_pairs = 0;
+  if (n_intervals) *n_intervals = 0;
+  if (!pl || (n_depths > 0 && !depths) || n_depths < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (!pl->lazy_pairs && !pl->have_pairs) return fail(FFX_BAD_ARG, "set the candidate lists first (ffx_plan_set_pairs_lazy)");
+  if (!pl->have_sparse) return fail(FFX_BAD_ARG, "early stopping needs first-stage scores");
+  if (cutoff < 1) return fail(FFX_BAD_ARG, "cutoff must be positive");
+  if (pl->n_queries_set < pl->n_queries) return fail(FFX_BAD_ARG, "%d query vectors set, %lld queries in the pairs", pl->n_queries_set, (long long)pl->n_queries);
+  ffx_index* ix = pl->idx;
+  FFX_HIP(hipSetDevice(pl->device));
+  hipStream_t st = pl->stream;
+  const int64_t Q = pl->n_queries, P = pl->n_pairs;
+  std::vector<int32_t> ds(depths, depths + n_depths);
+  std::sort(ds.begin(), ds.end());
+  pl->ran = false;
+  if (!pl->es_child) {
+    FFX_TRY(ffx_plan_create(ix, &pl->es_child));
+    pl->es_child->stream = st;  // everything of one early-stopping call is ordered on this plan's stream
+  }
+  ffx_plan* ch = pl->es_child;
+  ch->stream = st;
+  const size_t pb = std::max<size_t>((size_t)P, 1), qb = (size_t)Q + 1;
+  FFX_TRY(pl->es_active.ensure(qb * sizeof(int32_t)));
+  FFX_TRY(pl->es_cnt.ensure(qb * sizeof(int64_t)));
+  FFX_TRY(pl->es_pos.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(ch->pair_off.ensure(qb * sizeof(int64_t)));
+  FFX_TRY(ch->pair_ids.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(ch->sparse.ensure(pb * sizeof(float)));
+  FFX_TRY(ch->cnt.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(ch->seg_off.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(ch->ff.ensure(pb * sizeof(float)));
+  FFX_TRY(ch->interp.ensure(pb * sizeof(float)));
+  const size_t q_bytes = (size_t)pl->n_queries_set * ix->qdim * sizeof(float);
+  FFX_TRY(ch->queries.ensure(std::max<size_t>(q_bytes, 16)));
+  if (q_bytes) FFX_HIP(hipMemcpyAsync(ch->queries.p, pl->queries.p, q_bytes, hipMemcpyDeviceToDevice, st));
+  ch->n_queries_set = pl->n_queries_set;
+  FFX_HIP(hipEventRecord(pl->ev[0], st));
+  FFX_HIP(hipEventRecord(pl->ev[1], st));
+  if (P > 0) {
+    ffx::fill_u32_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->ff.as<uint32_t>(), P, 0x7FC00000u);  // NaN: not scored
+    ffx::fill_u32_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->interp.as<uint32_t>(), P, 0x7FC00000u);
+  }
+  if (Q > 0) ffx::fill_u32_kernel<<<blocks_for(Q, 256), 256, 0, st>>>(pl->es_active.as<uint32_t>(), Q, 1u);
+  FFX_HIP(hipGetLastError());
+  const float fa = (float)alpha, fb = (float)(1.0 - alpha);
+  int32_t a = 0, intervals = 0;
+  int64_t scored = 0, rows_total = 0;
+  for (int32_t b : ds) {
+    if (b < cutoff || Q == 0 || P == 0) continue;
+    if (b <= a) continue;
+    if (a > 0) {
+      ffx::es_criterion_kernel<<<(unsigned)Q, 256, 0, st>>>(pl->interp.as<float>(), pl->ff.as<float>(), pl->sparse.as<float>(),
+                                                           pl->pair_off.as<int64_t>(), a, cutoff, fa, fb, pl->es_active.as<int32_t>());
+      FFX_HIP(hipGetLastError());
+    }
+    ffx::es_count_kernel<<<blocks_for(Q + 1, 256), 256, 0, st>>>(pl->pair_off.as<int64_t>(), (int)Q, pl->es_active.as<int32_t>(), a, b,
+                                                                pl->es_cnt.as<int64_t>());
+    FFX_HIP(hipGetLastError());
+    size_t tmp = 0;
+    FFX_HIP(rocprim::exclusive_scan(nullptr, tmp, pl->es_cnt.as<int64_t>(), ch->pair_off.as<int64_t>(), (int64_t)0, (size_t)(Q + 1),
+                                    rocprim::plus<int64_t>(), st));
+    FFX_TRY(pl->es_scan_tmp.ensure(std::max<size_t>(tmp, 16)));
+    FFX_HIP(rocprim::exclusive_scan(pl->es_scan_tmp.p, tmp, pl->es_cnt.as<int64_t>(), ch->pair_off.as<int64_t>(), (int64_t)0, (size_t)(Q + 1),
+                                    rocprim::plus<int64_t>(), st));
+    int64_t n_sub = 0;  // counter 1 of 2: candidates of this interval
+    FFX_HIP(hipMemcpyAsync(&n_sub, ch->pair_off.as<int64_t>() + Q, sizeof n_sub, hipMemcpyDeviceToHost, st));
+    FFX_HIP(hipStreamSynchronize(st));
+    if (n_sub == 0) break;  // no pairs are left (base.py:368-369)
+    ffx::es_fill_kernel<<<(unsigned)Q, 256, 0, st>>>(pl->pair_off.as<int64_t>(), pl->pair_ids.as<int32_t>(), pl->sparse.as<float>(),
+                                                    ch->pair_off.as<int64_t>(), a, ch->pair_ids.as<int32_t>(), ch->sparse.as<float>(),
+                                                    pl->es_pos.as<int32_t>());
+    FFX_HIP(hipGetLastError());
+    ch->n_queries = Q;
+    ch->n_pairs = n_sub;
+    ch->mode = pl->mode;
+    ch->have_sparse = true;
+    ch->have_pairs = false;
+    // get_indices for the interval only: an unknown id is an IndexError when (and only when) it is reached
+    FFX_HIP(hipMemsetAsync(ch->flags.p, 0xFF, sizeof(unsigned long long), st));
+    FFX_TRY(launch_count_scan(ch));
+    unsigned long long bad = ~0ull;
+    int32_t rows = 0;  // counter 2 of 2: index rows the interval gathers
+    FFX_HIP(hipMemcpyAsync(&bad, ch->flags.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    FFX_HIP(hipMemcpyAsync(&rows, ch->seg_off.as<int32_t>() + n_sub, sizeof rows, hipMemcpyDeviceToHost, st));
+    FFX_HIP(hipStreamSynchronize(st));
+    if (bad != ~0ull) {
+      int32_t at = -1;
+      FFX_HIP(hipMemcpy(&at, pl->es_pos.as<int32_t>() + bad, sizeof at, hipMemcpyDeviceToHost));
+      if (bad_pair) *bad_pair = at;
+      return fail(FFX_NOT_FOUND, "pair %d names an ordinal with no rows in the index", at);
+    }
+    if (rows < 0) return fail(FFX_BAD_ARG, "more than 2^31-1 gathered rows in one interval: split the queries");
+    ch->n_rows = rows;
+    const size_t rb = std::max<size_t>((size_t)rows, 1);
+    FFX_TRY(ch->desc.ensure(rb * sizeof(int2)));
+    if (ch->n_rows != ch->n_pairs) FFX_TRY(ch->rs.ensure(rb * sizeof(float)));
+    ch->have_pairs = true;
+    FFX_TRY(ffx_plan_run(ch, alpha, flags & FFX_FLAG_EXACT_SUM));
+    ffx::es_scatter_kernel<<<blocks_for(n_sub, 256), 256, 0, st>>>(ch->ff.as<float>(), ch->interp.as<float>(), pl->es_pos.as<int32_t>(), n_sub,
+                                                                  pl->ff.as<float>(), pl->interp.as<float>());
+    FFX_HIP(hipGetLastError());
+    pl->variant = ch->variant;
+    scored += n_sub;
+    rows_total += rows;
+    a = b;
+    ++intervals;
+  }
+  for (int i = 2; i < 5; ++i) FFX_HIP(hipEventRecord(pl->ev[i], st));
+  pl->n_rows = rows_total;
+  pl->ran = true;
+  pl->ran_sort = false;
+  pl->last_interp = true;
+  if (n_scored_pairs) *n_scored_pairs = scored;
+  if (n_intervals) *n_intervals = intervals;
   return FFX_OK;
 }
 

@@ -191,6 +191,47 @@ class InMemoryIndex(Index):
         self.last_stats = plan.stats()
         return ff, interp, order
 
+    def _early_stopping_scores(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths) -> np.ndarray:
+        """Early stopping (base.py:316-387) resident on the device (``ffx_plan_early_stopping``): the
+        active mask, the running best dense score and the running top-``cutoff`` threshold of every
+        query stay in HBM between depth intervals; one upload of the candidate lists, one download
+        of the final scores.  Ids are resolved once, leniently: an unknown id raises ``IndexError``
+        only if some interval reaches it, as in the reference."""
+        if self._store is None:
+            raise IndexError("the index is empty")
+        sparse = np.asarray(sparse)
+        if sparse.dtype != np.float32:
+            return super()._early_stopping_scores(ids, q_no, sparse, query_vectors, cutoff, alpha, depths)  # float64 rankings: host criterion
+        from fast_forward_amd.index.api import _grouped_by_query
+
+        n_q = query_vectors.shape[0]
+        q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self._store.query_dim:
+            raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.query_dim}).")
+        if self._rotation is not None:
+            q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
+        perm, pair_off = _grouped_by_query(q_no, n_q)  # stable: the frame's order inside a query is its rank order
+        ids_g, sparse_g = (ids, sparse) if perm is None else (ids[perm], sparse[perm])
+        ordinals = self._ids.lookup_optional(ids_g, self.mode.value).astype(np.int32)
+        self._sync_ids()
+        if self._plan is None:
+            self._plan = native.Plan(self._store)
+        plan = self._plan
+        plan.set_queries(q)
+        plan.set_pairs_lazy(pair_off, ordinals, sparse_g, self.mode.value)
+        try:
+            scored, intervals = plan.early_stopping(cutoff, alpha, depths, exact_sum=self.exact_sum)
+        except native.NotFound as e:
+            raise IndexError(f"ID {ids_g[e.pair]} not found in the index.") from None
+        ff = plan.fetch(ff=True)[0]
+        self.last_stats = dict(plan.stats(), early_stopping_scored_pairs=scored, early_stopping_intervals=intervals)
+        LOGGER.info("early stopping: %s of %s candidates scored in %s depth intervals", scored, len(ids_g), intervals)
+        if perm is None:
+            return ff
+        out = np.empty_like(ff)
+        out[perm] = ff
+        return out
+
     def _native_id_table(self, mode: Mode):
         return self._ids.native_table(mode.value)
 

@@ -26,7 +26,7 @@ SYMBOLS = (
     "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
-    "ffx_plan_run", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
+    "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
@@ -135,6 +135,8 @@ def lib() -> C.CDLL:
         "ffx_plan_set_queries": ([vp, vp, i64], C.c_int),
         "ffx_plan_set_pairs": ([vp, vp, i64, vp, vp, C.c_int, P(i64)], C.c_int),
         "ffx_plan_run": ([vp, C.c_double, C.c_uint32], C.c_int),
+        "ffx_plan_set_pairs_lazy": ([vp, vp, i64, vp, vp, C.c_int], C.c_int),
+        "ffx_plan_early_stopping": ([vp, i32, C.c_double, vp, i32, C.c_uint32, P(i64), P(i64), P(i32)], C.c_int),
         "ffx_plan_sync": ([vp], C.c_int),
         "ffx_plan_fetch": ([vp, vp, vp, vp], C.c_int),
         "ffx_plan_stats": ([vp, P(Stats)], C.c_int),
@@ -371,6 +373,25 @@ class Plan:
     def run(self, alpha: float = 0.0, exact_sum: bool = True, sort: bool = False, sort_ff: bool = False) -> None:
         flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0) | (FLAG_SORT_FF if sort_ff else 0)
         _check(lib().ffx_plan_run(self._h, float(alpha), flags))
+
+    def set_pairs_lazy(self, pair_off, pair_ids, sparse, mode: int) -> None:
+        """Candidate lists for :meth:`early_stopping` (rank order inside a query); ordinals are not
+        validated here: -1 marks an id the host could not resolve."""
+        pair_off, pair_ids, sp = _arr(pair_off, np.int64), _arr(pair_ids, np.int32), _arr(sparse, np.float32)
+        assert pair_ids.shape[0] == sp.shape[0] == int(pair_off[-1])
+        _check(lib().ffx_plan_set_pairs_lazy(self._h, _ptr(pair_off), pair_off.shape[0] - 1, _ptr(pair_ids), _ptr(sp), int(mode)))
+        self.n_pairs, self.has_sparse = int(pair_off[-1]), True
+
+    def early_stopping(self, cutoff: int, alpha: float, depths, exact_sum: bool = True) -> tuple[int, int]:
+        """``ffx_plan_early_stopping``: returns (scored pairs, depth intervals run); afterwards
+        ``fetch(ff=True, interp=True)`` holds NaN where a candidate was not scored.  ``NotFound``
+        (with ``.pair``) when an unresolved ordinal is reached."""
+        d = _arr(sorted(int(x) for x in depths), np.int32)
+        bad, scored, intervals = C.c_int64(-1), C.c_int64(0), C.c_int32(0)
+        rc = lib().ffx_plan_early_stopping(self._h, int(cutoff), float(alpha), _ptr(d), d.shape[0], FLAG_EXACT_SUM if exact_sum else 0,
+                                           C.byref(bad), C.byref(scored), C.byref(intervals))
+        _check(rc, bad.value)
+        return scored.value, intervals.value
 
     def sync(self) -> None:
         _check(lib().ffx_plan_sync(self._h))

@@ -148,6 +148,19 @@ int ffx_plan_set_queries(ffx_plan* plan, const float* host_queries, int64_t n_qu
 int ffx_plan_set_pairs(ffx_plan* plan, const int64_t* pair_off, int64_t n_queries,
                        const int32_t* pair_ids, const float* sparse, int mode, int64_t* bad_pair);
 int ffx_plan_run(ffx_plan* plan, double alpha, uint32_t flags);
+/* ---- early stopping: replaces Index._early_stopping, index/base.py:316-387 ------------------
+ * Candidates of a query stand in first-stage rank order.  set_pairs_lazy uploads the lists without
+ * validating ordinals (use -1 for an id the host could not resolve): as in the reference, an unknown
+ * id is an error only if it is reached (FFX_NOT_FOUND + *bad_pair).  early_stopping scores depth
+ * intervals [a, b) over the sorted depths >= cutoff; after the first interval a query continues only
+ * while its cutoff-th best interpolated score is below alpha * (first-stage score of its last scored
+ * candidate) + (1 - alpha) * (its best dense score so far).  All per-query state stays on the device;
+ * per interval two counters come back to size the launches.  Afterwards ffx_plan_fetch gives the
+ * dense and interpolated scores of ALL pairs, NaN where a candidate was never scored. */
+int ffx_plan_set_pairs_lazy(ffx_plan* plan, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids,
+                            const float* sparse, int mode);
+int ffx_plan_early_stopping(ffx_plan* plan, int32_t cutoff, double alpha, const int32_t* depths, int32_t n_depths,
+                            uint32_t flags, int64_t* bad_pair, int64_t* n_scored_pairs, int32_t* n_intervals);
 int ffx_plan_sync(ffx_plan* plan);
 /* any of the outputs may be NULL */
 int ffx_plan_fetch(ffx_plan* plan, float* out_ff, float* out_interp, int32_t* out_order);

@@ -48,6 +48,19 @@ out["full_lookups"] = args.queries * args.k
 t0 = time.perf_counter()
 es = index(first, early_stopping=args.cutoff, early_stopping_alpha=args.alpha, early_stopping_depths=depths)
 out["early_stopping_s"] = time.perf_counter() - t0
+out["early_stopping_device_stats"] = {k: index.last_stats[k] for k in ("early_stopping_scored_pairs", "early_stopping_intervals", "ms_total")}
+# the same call with the criterion evaluated on the host each interval (round 1's path: D2H of the interval's
+# scores, lexsort + reduceat in NumPy, ids re-resolved and re-uploaded per interval)
+from fast_forward_amd.index.api import Index  # noqa: E402
+from fast_forward_amd.index.hbm import InMemoryIndex as _IMI  # noqa: E402
+
+device_impl = _IMI._early_stopping_scores
+_IMI._early_stopping_scores = Index._early_stopping_scores
+t0 = time.perf_counter()
+es_host = index(first, early_stopping=args.cutoff, early_stopping_alpha=args.alpha, early_stopping_depths=depths)
+out["early_stopping_host_criterion_s"] = time.perf_counter() - t0
+_IMI._early_stopping_scores = device_impl
+out["host_and_device_criterion_agree"] = bool(es_host == es)
 if "--profile" in sys.argv:
     import cProfile
     import pstats
