@@ -520,20 +520,28 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
                           "query": np.repeat(q_names, args.k)})
     first = Ranking(frame, name="first-stage", copy=False)
     out["iii_build_first_stage_ranking_s"] = time.perf_counter() - t0
-    api.rerank(first, args.alpha)  # warm-up (plans, id caches)
+    api.rerank(first, args.alpha)  # warm-up: plans; the distinct ids are looked up once per (ranking, index)
     t0 = time.perf_counter()
     final = api.rerank(first, args.alpha)
     out["iii_rerank_s"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    dense = api(first)
-    t1 = time.perf_counter()
-    final2 = first.interpolate(dense, args.alpha)
-    out["iii_call_s"], out["iii_interpolate_s"] = t1 - t0, time.perf_counter() - t1
     out["iii_pairs"] = int(nq * args.k)
     out["iii_queries_per_s_rerank"] = nq / out["iii_rerank_s"]
-    out["iii_rerank_equals_call_then_interpolate"] = bool(final == final2)
-    out["iii_note"] = (f"{nq} queries x k={args.k} from a pandas-backed Ranking of string ids: Index.rerank (dense + interpolation + order "
-                       "on the device) vs Index.__call__ followed by Ranking.interpolate")
+    t0 = time.perf_counter()
+    n_final = len(final._df)  # results come back as integer codes; the pandas frame of strings is built on first use
+    out["iii_result_frame_on_first_use_s"] = time.perf_counter() - t0
+    # Index.__call__ followed by Ranking.interpolate (the general host join) on the first queries only: the join
+    # sorts string-keyed pairs on one core (~1.5 us per pair)
+    nq2 = min(nq, 400)
+    sub = Ranking(frame.iloc[:nq2 * args.k], name="first-stage", copy=False)
+    api(sub)
+    t0 = time.perf_counter()
+    dense = api(sub)
+    t1 = time.perf_counter()
+    final2 = sub.interpolate(dense, args.alpha)
+    out["iii_call_s"], out["iii_interpolate_s"], out["iii_call_interpolate_pairs"] = t1 - t0, time.perf_counter() - t1, int(nq2 * args.k)
+    out["iii_rerank_equals_call_then_interpolate"] = bool(api.rerank(sub, args.alpha) == final2) and n_final == nq * args.k
+    out["iii_note"] = (f"{nq} queries x k={args.k} from a pandas-backed Ranking of string ids through Index.rerank (dense + interpolation + "
+                       f"order on the device; ids travel as integer codes); Index.__call__ + Ranking.interpolate on the first {nq2} queries")
     api.release()
     return out
 

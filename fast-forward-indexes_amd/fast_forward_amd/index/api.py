@@ -40,6 +40,9 @@ class Mode(Enum):
     AVEP = 4
 
 
+_CODED_MIN_ROWS = 4096  # from here on results are returned in coded form (the frame is built on first use)
+
+
 def _in_final_order(q_order: Sequence[str]) -> bool:
     """Query ids strictly descending: the order a ``Ranking`` the constructor sorted has
     (ranking.py:115-117).  A user-built ``Ranking(..., is_sorted=True)`` need not be."""
@@ -191,12 +194,8 @@ class Index(abc.ABC):
     def _numbered_queries(self, ranking: Ranking) -> tuple[np.ndarray, list[str], list[str]]:
         """``q_no`` per row = order of first appearance of the query (base.py:418-421), plus the
         query ids and texts in that order."""
-        df = ranking._df
         q_no, q_ids = ranking._numbering()
-        first_rows = np.full(len(q_ids), -1, dtype=np.int64)
-        first_rows[q_no[::-1]] = np.arange(len(df) - 1, -1, -1)
-        texts = df["query"].to_numpy()[first_rows].tolist()
-        return q_no.astype(np.int64), list(q_ids), texts
+        return q_no.astype(np.int64, copy=False), list(q_ids), ranking._query_texts()
 
     def _compute_scores(self, data: pd.DataFrame, query_vectors: np.ndarray) -> pd.DataFrame:
         """``data`` (columns ``id``, ``q_no``, ...) plus an ``ff_score`` column: the dense score of
@@ -299,12 +298,21 @@ class Index(abc.ABC):
             raise ValueError("Early stopping requires alpha and depths.")
         t0 = perf_counter()
 
-        df = ranking._df
         q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
-        grouped, block_off = _grouped_by_query(q_no, n_q) if len(df) > 0 else (0, None)
+        grouped, block_off = _grouped_by_query(q_no, n_q) if len(q_no) > 0 else (0, None)
         final_order = _in_final_order(q_order)
+        if (early_stopping is None and grouped is None and final_order and len(q_no) >= _CODED_MIN_ROWS
+                and (batch_size is None or batch_size >= n_q)):
+            # a large run in the constructor's order: integer codes in, integer codes out -- no Python string
+            # per row on the way to the device, none on the way back (the frame is built on first use)
+            codes, names = ranking._id_coding()
+            dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True)
+            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+            return Ranking._assemble_coded("fast-forward", q_no[order], q_order, codes[order], names,
+                                           dense[order].astype(ranking._score_dtype(), copy=False), texts)
+        df = ranking._df
         if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
             # arrays in, arrays out: only the candidates that get scored are looked up and kept
             ids_col, sparse_col = df["id"].to_numpy(), df["score"].to_numpy()
@@ -384,6 +392,29 @@ class Index(abc.ABC):
         # the pairs are those of `ranking`, already known to be unique
         return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
 
+    def _ordinals_of_codes(self, ranking: Ranking, codes: np.ndarray, names: np.ndarray) -> np.ndarray:
+        """Index ordinals of a ranking's rows through its id codes: the DISTINCT id strings are looked
+        up once (and remembered on the ranking for this index and mode), the rows follow by an integer
+        gather.  ``IndexError`` names the first unknown id in row order, like ``_resolve_ids``."""
+        key = (id(self), getattr(getattr(self, "_ids", None), "version", None), self.mode)
+        cached = getattr(ranking, "_ordinal_cache", None)
+        if cached is None or cached[0] != key or cached[1] is not names:
+            try:
+                by_code = self._resolve_ids(names, self.mode)
+            except IndexError:
+                by_code = None
+            if by_code is None:  # name the first unknown id in ROW order, as _resolve_ids on the rows would
+                missing = self._lookup_optional(names, self.mode) < 0
+                first = int(np.flatnonzero(missing[codes])[0])
+                raise IndexError(f"ID {names[codes[first]]} not found in the index.")
+            cached = (key, names, by_code.astype(np.int32, copy=False))
+            ranking._ordinal_cache = cached
+        return cached[2][codes]
+
+    def _lookup_optional(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
+        """Ordinals of ``ids``, -1 where unknown."""
+        return self._ids.lookup_optional(ids, mode.value)
+
     @abc.abstractmethod
     def _native_id_table(self, mode: Mode):
         """The native (``ffx_ids``) table of document or passage ids, ordinals as ``_resolve_ids``."""
@@ -395,11 +426,22 @@ class Index(abc.ABC):
         (optionally cut to the best ``cutoff`` per query).  Same scores, bit for bit."""
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
-        df = ranking._df
         q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
-        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         perm, pair_off = _grouped_by_query(q_no, len(texts))
+        if perm is None and len(q_no) >= _CODED_MIN_ROWS and _in_final_order(q_order):
+            # a large run in the constructor's order: integer codes in, integer codes out, no Python string per row
+            codes, names = ranking._id_coding()
+            ordinals = self._ordinals_of_codes(ranking, codes, names)
+            sparse = np.ascontiguousarray(ranking._scores(), dtype=np.float32)
+            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+            if cutoff is not None:
+                rank = np.arange(len(order)) - np.repeat(pair_off[:-1], np.diff(pair_off))
+                order = order[rank < cutoff]
+            return Ranking._assemble_coded(ranking.name, q_no[order], q_order, codes[order], names,
+                                           interp[order].astype(ranking._score_dtype(), copy=False), texts)
+        df = ranking._df
+        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         sparse = df["score"].to_numpy(dtype=np.float32)
         if perm is not None:
             ordinals, sparse = ordinals[perm], sparse[perm]

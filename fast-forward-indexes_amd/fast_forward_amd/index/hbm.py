@@ -61,11 +61,43 @@ class InMemoryIndex(Index):
         self._device = int(device)
         self._dtype = None if dtype is None else np.dtype(dtype)
         self._ids_on_device = -1
+        self._owns_store = True
         self._rotation: np.ndarray | None = None    # OPQ: queries are rotated instead of rows
         self._host_codes: list[np.ndarray] = []     # codes of a quantizer the device cannot read
         self.exact_sum = bool(exact_sum)
         self.last_stats: dict | None = None
         super().__init__(query_encoder=query_encoder, quantizer=quantizer, mode=mode, encoder_batch_size=encoder_batch_size)
+
+    @classmethod
+    def adopt(cls, store: "native.DeviceIndex", doc_ids=None, psg_ids=None, doc_off=None, n_rows: int | None = None,
+              query_encoder: Encoder | None = None, mode: Mode = Mode.MAXP, exact_sum: bool = True) -> "InMemoryIndex":
+        """An ``InMemoryIndex`` over rows that are ALREADY resident in a ``DeviceIndex`` (filled on the
+        device, uploaded through the C ABI, or moved there from a file): only the ids are registered.
+        ``doc_ids`` / ``psg_ids`` name the rows one by one; or, with ``doc_off``, ``doc_ids[o]`` names
+        the document owning rows ``doc_off[o] .. doc_off[o+1]``.  The store stays the caller's
+        (``release`` detaches it; ``close`` does not free it)."""
+        n = int(store.capacity if n_rows is None else n_rows)
+        index = cls(query_encoder, mode=mode, device=store.device, exact_sum=exact_sum, dtype=store.dtype)
+        if doc_ids is not None and doc_off is not None:
+            doc_off = np.asarray(doc_off, dtype=np.int64)
+            names = np.asarray(doc_ids)
+            if (np.diff(doc_off) != 1).any():
+                names = names[np.repeat(np.arange(doc_off.shape[0] - 1), np.diff(doc_off))]
+            doc_ids = names
+        if doc_ids is None and psg_ids is None:
+            raise ValueError("Vector has neither document nor passage ID.")
+        index._ids.add([None] * n if doc_ids is None else doc_ids, [None] * n if psg_ids is None else psg_ids, 0)
+        index._store, index._n, index._dtype, index._owns_store = store, n, store.dtype, False
+        return index
+
+    def release(self) -> "native.DeviceIndex | None":
+        """Detach the device store (its plans are closed) and hand it back; the index is empty afterwards."""
+        store = self._store
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+        self._store, self._n = None, 0
+        return store
 
     # ---- storage --------------------------------------------------------------------------------
     def _get_num_vectors(self) -> int:
@@ -105,8 +137,9 @@ class InMemoryIndex(Index):
             if self._plan is not None:
                 self._plan.close()
                 self._plan = None
-            self._store.close()
-        self._store = grown
+            if self._owns_store:
+                self._store.close()
+        self._store, self._owns_store = grown, True
         self._ids_on_device = -1
 
     def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence, _uploader=None) -> None:
@@ -241,7 +274,8 @@ class InMemoryIndex(Index):
             self._plan.close()
             self._plan = None
         if self._store is not None:
-            self._store.close()
+            if self._owns_store:
+                self._store.close()
             self._store = None
         self._n = 0
 

@@ -31,7 +31,7 @@ SYMBOLS = (
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
-    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_get",
+    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_flags", "ffx_run_ids_blob",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
@@ -157,6 +157,8 @@ def lib() -> C.CDLL:
         "ffx_ids_intern": ([vp, vp, i32, i64, vp], C.c_int),
         "ffx_ids_lookup": ([vp, vp, i32, i64, vp, P(i64)], C.c_int),
         "ffx_ids_lookup_packed": ([vp, C.c_char_p, i64, C.c_char, i64, vp, P(i64)], C.c_int),
+        "ffx_ids_intern_packed": ([vp, C.c_char_p, i64, C.c_char, i64, vp], C.c_int),
+        "ffx_ids_blob": ([vp, C.c_char, vp, i64, P(i64)], C.c_int),
         "ffx_ids_get": ([vp, i32, P(vp), P(i32)], C.c_int),
         "ffx_run_open": ([C.c_char_p, vp, P(vp), P(i64)], C.c_int),
         "ffx_run_close": ([vp], C.c_int),
@@ -557,6 +559,28 @@ def _as_fixed_bytes(strings) -> np.ndarray:
         return np.array([s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in a.tolist()], dtype="S")
 
 
+def _packed(strings) -> "tuple[bytes, int] | None":
+    """Many Python strings as ONE '\n'-joined UTF-8 buffer (a fraction of the cost of a fixed-width copy
+    of each), or None when that form does not apply: few strings, not all ``str``, or a string that
+    holds the separator or a NUL byte."""
+    if isinstance(strings, np.ndarray):
+        if strings.dtype != object or strings.shape[0] < 4096:
+            return None
+        items = strings.tolist()
+    elif isinstance(strings, (list, tuple)) and len(strings) >= 4096:
+        items = strings
+    else:
+        return None
+    try:
+        blob = "\n".join(items).encode("utf-8")
+    except TypeError:  # not all str
+        return None
+    n = len(items)
+    if blob.count(b"\n") != n - 1 or b"\0" in blob:
+        return None
+    return blob, n
+
+
 class IdStrings:
     """Owns one ``ffx_ids``: an insertion-ordered string -> ordinal table on the native side."""
 
@@ -578,29 +602,33 @@ class IdStrings:
         return n.value
 
     def intern(self, strings) -> np.ndarray:
+        packed = _packed(strings)
+        if packed is not None:
+            blob, n = packed
+            out = np.empty(n, dtype=np.int32)
+            _check(lib().ffx_ids_intern_packed(self._h, blob, len(blob), b"\n", n, _ptr(out)))
+            return out
         b = _as_fixed_bytes(strings)
         out = np.empty(b.shape[0], dtype=np.int32)
         if b.shape[0]:
             _check(lib().ffx_ids_intern(self._h, _ptr(b), b.dtype.itemsize, b.shape[0], _ptr(out)))
         return out
 
-    def lookup(self, strings) -> np.ndarray:
-        """Ordinals of ``strings``; ``IndexError`` naming the first unknown one."""
-        if isinstance(strings, np.ndarray) and strings.dtype == object and strings.shape[0] >= 4096:
-            # Python strings: one joined buffer costs a fraction of a fixed-width copy of each
-            try:
-                blob = "\n".join(strings.tolist()).encode("utf-8")
-            except TypeError:  # not all str
-                blob = None
-            n = strings.shape[0]
-            if blob is not None and blob.count(b"\n") == n - 1 and b"\0" not in blob:
-                out = np.empty(n, dtype=np.int32)
-                miss = C.c_int64(-1)
-                rc = lib().ffx_ids_lookup_packed(self._h, blob, len(blob), b"\n", n, _ptr(out), C.byref(miss))
-                if rc == NOT_FOUND:
-                    raise IndexError(f"ID {strings[miss.value]} not found in the index.")
-                _check(rc)
-                return out
+    def lookup(self, strings, missing_ok: bool = False) -> np.ndarray:
+        """Ordinals of ``strings``; ``IndexError`` naming the first unknown one, or -1 in its place
+        with ``missing_ok``."""
+        packed = _packed(strings)
+        if packed is not None:
+            blob, n = packed
+            out = np.empty(n, dtype=np.int32)
+            miss = C.c_int64(-1)
+            rc = lib().ffx_ids_lookup_packed(self._h, blob, len(blob), b"\n", n, _ptr(out), C.byref(miss))
+            if rc == NOT_FOUND:
+                if missing_ok:
+                    return out
+                raise IndexError(f"ID {strings[miss.value]} not found in the index.")
+            _check(rc)
+            return out
         b = _as_fixed_bytes(strings)
         out = np.empty(b.shape[0], dtype=np.int32)
         if b.shape[0] == 0:
@@ -608,6 +636,8 @@ class IdStrings:
         miss = C.c_int64(-1)
         rc = lib().ffx_ids_lookup(self._h, _ptr(b), b.dtype.itemsize, b.shape[0], _ptr(out), C.byref(miss))
         if rc == NOT_FOUND:
+            if missing_ok:
+                return out
             raise IndexError(f"ID {b[miss.value].decode('utf-8', 'replace')} not found in the index.")
         _check(rc)
         return out
@@ -616,6 +646,16 @@ class IdStrings:
         p, n = C.c_void_p(), C.c_int32(0)
         _check(lib().ffx_ids_get(self._h, int(ordinal), C.byref(p), C.byref(n)))
         return C.string_at(p.value, n.value).decode("utf-8")
+
+    def strings(self) -> list[str]:
+        """Every string of the table, in ordinal order."""
+        need = C.c_int64(0)
+        _check(lib().ffx_ids_blob(self._h, b"\0", None, 0, C.byref(need)))
+        if len(self) == 0:
+            return []
+        buf = C.create_string_buffer(max(1, need.value))
+        _check(lib().ffx_ids_blob(self._h, b"\0", buf, need.value, C.byref(need)))
+        return buf.raw[:need.value].decode("utf-8").split("\0")
 
 
 def _joined(strings) -> bytes | None:

@@ -80,7 +80,78 @@ def _sorted_frame(df: pd.DataFrame) -> pd.DataFrame:
 
 
 class Ranking:
-    """Rankings of documents/passages w.r.t. queries (drop-in for ``fast_forward.Ranking``)."""
+    """Rankings of documents/passages w.r.t. queries (drop-in for ``fast_forward.Ranking``).
+
+    Two representations of the same rows.  The *frame* (``_df``: pandas, string columns) is what the
+    reference has and what every method here works on.  The *coded* form keeps what the device
+    produced or needs -- per row a query number, an int32 id code and a score, plus the tables that
+    turn numbers back into strings -- so that ``Index.rerank`` / ``Index.__call__`` on a large run
+    never touch a Python string per row; a coded ranking grows its frame the first time somebody
+    asks for it."""
+
+    _frame: "pd.DataFrame | None" = None
+    _coded: "dict | None" = None      # q_no, q_order, id_codes, id_names, score, q_texts (None: no queries)
+    _id_cache: "tuple | None" = None  # (id code of every frame row, id strings by code): valid for the current frame
+
+    @property
+    def _df(self) -> pd.DataFrame:
+        if self._frame is None:
+            c = self._coded
+            q_names = np.empty(len(c["q_order"]), dtype=object)
+            q_names[:] = c["q_order"]
+            cols = {"q_id": q_names[c["q_no"]] if len(q_names) else np.empty(0, dtype=object),
+                    "id": c["id_names"][c["id_codes"]] if len(c["id_names"]) else np.empty(0, dtype=object), "score": c["score"]}
+            if c["q_texts"] is not None:
+                texts = np.empty(len(c["q_texts"]), dtype=object)
+                texts[:] = c["q_texts"]
+                cols["query"] = texts[c["q_no"]] if len(texts) else np.empty(0, dtype=object)
+            self._frame = pd.DataFrame(cols, copy=False)
+        return self._frame
+
+    @_df.setter
+    def _df(self, frame: pd.DataFrame) -> None:
+        self._frame = frame
+        self._coded = None
+        self._id_cache = None
+
+    @classmethod
+    def _assemble_coded(cls, name, q_no: np.ndarray, q_order: list, id_codes: np.ndarray, id_names: np.ndarray, score: np.ndarray,
+                        q_texts: "list | None") -> "Ranking":
+        """Ranking from device results in coded form (rows in final order, pairs unique, nothing missing);
+        the frame is built on first use."""
+        out = cls.__new__(cls)
+        out.name = name
+        out._coded = {"q_no": q_no, "q_order": list(q_order), "id_codes": id_codes, "id_names": id_names, "score": score,
+                      "q_texts": None if q_texts is None else list(q_texts)}
+        out._q_no, out._q_order = q_no, list(q_order)
+        out._q_ids = set(out._q_order)
+        return out
+
+    def _id_coding(self) -> tuple[np.ndarray, np.ndarray]:
+        """(int32 code of every row's id, id strings by code)."""
+        if self._coded is not None:
+            return self._coded["id_codes"], self._coded["id_names"]
+        if self._id_cache is None:
+            codes, names = pd.factorize(self._frame["id"].to_numpy())
+            self._id_cache = (codes.astype(np.int32), np.asarray(names, dtype=object))
+        return self._id_cache
+
+    def _scores(self) -> np.ndarray:
+        return self._coded["score"] if self._coded is not None else self._frame["score"].to_numpy()
+
+    def _score_dtype(self) -> np.dtype:
+        return self._scores().dtype
+
+    def _query_texts(self) -> "list | None":
+        """Query text per query number, or None when no queries are attached."""
+        if self._coded is not None:
+            return self._coded["q_texts"]
+        if "query" not in self._frame.columns:
+            return None
+        q_no = self._q_no
+        first_rows = np.full(len(self._q_order), -1, dtype=np.int64)
+        first_rows[q_no[::-1]] = np.arange(len(q_no) - 1, -1, -1)
+        return self._frame["query"].to_numpy()[first_rows].tolist()
 
     def __init__(
         self,
@@ -174,11 +245,15 @@ class Ranking:
         if query is not None:
             cols["query"] = column(query)
         self._df = pd.DataFrame(cols, copy=False)
+        if not getattr(df, "_ffx_pairs_unique", False):  # the ids were numbered for the duplicate check: keep that
+            self._id_cache = ((id_code if rows is None else id_code[rows]).astype(np.int32), np.asarray(id_names, dtype=object))
         self._q_no, firsts = pd.factorize(codes)
         self._q_order = [q_names[i] for i in firsts]
         self._q_ids = set(self._q_order)
         if queries is not None:
+            keep = self._id_cache
             self._df = _with_queries(self._df, queries)
+            self._id_cache = keep  # same rows, one more column
         return True
 
     @classmethod
@@ -201,6 +276,8 @@ class Ranking:
     @property
     def has_queries(self) -> bool:
         """Whether query strings are attached."""
+        if self._coded is not None:
+            return self._coded["q_texts"] is not None
         return "query" in self._df.columns
 
     @property

@@ -302,6 +302,10 @@ int ffx_ids_lookup(const ffx_ids* table, const char* strs, int32_t width, int64_
 /* ffx_ids_lookup for n strings handed over as one buffer with the byte `sep` between them */
 int ffx_ids_lookup_packed(const ffx_ids* ids, const char* data, int64_t n_bytes, char sep, int64_t n,
                           int32_t* out_ordinals, int64_t* first_missing);
+/* ffx_ids_intern for n strings handed over as one buffer with `sep` between them */
+int ffx_ids_intern_packed(ffx_ids* table, const char* data, int64_t n_bytes, char sep, int64_t n, int32_t* out_ordinals);
+/* all strings in ordinal order joined by `sep`; *needed = bytes required, copied when cap suffices */
+int ffx_ids_blob(const ffx_ids* table, char sep, char* buf, int64_t cap, int64_t* needed);
 int ffx_ids_get(const ffx_ids* table, int32_t ordinal, const char** str, int32_t* len);
 
 /* ffx_run: a TREC run file (q_id Q0 id rank score name) parsed straight into the CSR of
