@@ -316,16 +316,21 @@ class Index(abc.ABC):
         if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
             # arrays in, arrays out: only the candidates that get scored are looked up and kept
             ids_col, sparse_col = df["id"].to_numpy(), df["score"].to_numpy()
+            lenient = None
+            if len(df) >= _CODED_MIN_ROWS and getattr(self, "_early_stopping_takes_ordinals", False):
+                # a large run: its distinct ids are looked up once (unknown -> -1: an error only if reached)
+                lenient = self._ordinals_of_codes(ranking, *ranking._id_coding(), missing_ok=True)
+            extra = (lambda lo, hi: {}) if lenient is None else (lambda lo, hi: {"ordinals": lenient[lo:hi]})
             if batch_size is None or batch_size >= n_q:
                 ff = self._early_stopping_scores(ids_col, q_no, sparse_col, query_vectors, early_stopping, early_stopping_alpha,
-                                                 early_stopping_depths)
+                                                 early_stopping_depths, **extra(0, len(df)))
             else:  # `batch_size` queries at a time
                 ff = np.full(len(df), np.nan, dtype=np.float32)
                 for qa in range(0, n_q, batch_size):
                     pa, pb = int(block_off[qa]), int(block_off[min(n_q, qa + batch_size)])
                     if pb > pa:
                         ff[pa:pb] = self._early_stopping_scores(ids_col[pa:pb], q_no[pa:pb], sparse_col[pa:pb], query_vectors,
-                                                                early_stopping, early_stopping_alpha, early_stopping_depths)
+                                                                early_stopping, early_stopping_alpha, early_stopping_depths, **extra(pa, pb))
             rows = np.flatnonzero(~np.isnan(ff))
             rows = rows[np.lexsort((-ff[rows].astype(np.float64), q_no[rows]))]  # q_no ascending = q_id descending
             cols = {c: df[c].to_numpy()[rows] for c in ("q_id", "id")}
@@ -392,24 +397,22 @@ class Index(abc.ABC):
         # the pairs are those of `ranking`, already known to be unique
         return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
 
-    def _ordinals_of_codes(self, ranking: Ranking, codes: np.ndarray, names: np.ndarray) -> np.ndarray:
+    def _ordinals_of_codes(self, ranking: Ranking, codes: np.ndarray, names: np.ndarray, missing_ok: bool = False) -> np.ndarray:
         """Index ordinals of a ranking's rows through its id codes: the DISTINCT id strings are looked
         up once (and remembered on the ranking for this index and mode), the rows follow by an integer
-        gather.  ``IndexError`` names the first unknown id in row order, like ``_resolve_ids``."""
+        gather.  ``IndexError`` names the first unknown id in row order, like ``_resolve_ids``; with
+        ``missing_ok`` unknown ids come back as -1 instead (early stopping looks ids up leniently)."""
         key = (id(self), getattr(getattr(self, "_ids", None), "version", None), self.mode)
         cached = getattr(ranking, "_ordinal_cache", None)
         if cached is None or cached[0] != key or cached[1] is not names:
-            try:
-                by_code = self._resolve_ids(names, self.mode)
-            except IndexError:
-                by_code = None
-            if by_code is None:  # name the first unknown id in ROW order, as _resolve_ids on the rows would
-                missing = self._lookup_optional(names, self.mode) < 0
-                first = int(np.flatnonzero(missing[codes])[0])
-                raise IndexError(f"ID {names[codes[first]]} not found in the index.")
-            cached = (key, names, by_code.astype(np.int32, copy=False))
+            cached = (key, names, self._lookup_optional(names, self.mode).astype(np.int32, copy=False))
             ranking._ordinal_cache = cached
-        return cached[2][codes]
+        ordinals = cached[2][codes]
+        if not missing_ok and cached[2].size and cached[2].min() < 0:
+            unknown = np.flatnonzero(ordinals < 0)
+            if unknown.size:  # the first one in ROW order, as _resolve_ids on the rows would name it
+                raise IndexError(f"ID {names[codes[int(unknown[0])]]} not found in the index.")
+        return ordinals
 
     def _lookup_optional(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
         """Ordinals of ``ids``, -1 where unknown."""

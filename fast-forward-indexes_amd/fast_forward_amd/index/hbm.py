@@ -224,7 +224,9 @@ class InMemoryIndex(Index):
         self.last_stats = plan.stats()
         return ff, interp, order
 
-    def _early_stopping_scores(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths) -> np.ndarray:
+    _early_stopping_takes_ordinals = True
+
+    def _early_stopping_scores(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths, ordinals=None) -> np.ndarray:
         """Early stopping (base.py:316-387) resident on the device (``ffx_plan_early_stopping``): the
         active mask, the running best dense score and the running top-``cutoff`` threshold of every
         query stay in HBM between depth intervals; one upload of the candidate lists, one download
@@ -245,7 +247,10 @@ class InMemoryIndex(Index):
             q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
         perm, pair_off = _grouped_by_query(q_no, n_q)  # stable: the frame's order inside a query is its rank order
         ids_g, sparse_g = (ids, sparse) if perm is None else (ids[perm], sparse[perm])
-        ordinals = self._ids.lookup_optional(ids_g, self.mode.value).astype(np.int32)
+        if ordinals is None:
+            ordinals = self._ids.lookup_optional(ids_g, self.mode.value).astype(np.int32)
+        elif perm is not None:
+            ordinals = ordinals[perm]
         self._sync_ids()
         if self._plan is None:
             self._plan = native.Plan(self._store)
