@@ -153,7 +153,7 @@ class Index(abc.ABC):
     @abc.abstractmethod
     def _score_pairs(self, query_vectors: np.ndarray, pair_off: np.ndarray, pair_ids: np.ndarray, mode: Mode,
                      sparse: np.ndarray | None = None, alpha: float | None = None,
-                     sort: bool = False) -> tuple[np.ndarray, np.ndarray | None, np.ndarray | None]:
+                     sort: bool = False, want_dense: bool = True) -> tuple[np.ndarray, np.ndarray | None, np.ndarray | None]:
         """Device scoring of CSR candidate lists: ``(dense, interpolated|None, order|None)``."""
 
     @property
@@ -301,7 +301,7 @@ class Index(abc.ABC):
         q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         n_q = len(texts)
-        grouped, block_off = _grouped_by_query(q_no, n_q) if len(q_no) > 0 else (0, None)
+        grouped, block_off = ranking._csr() if len(q_no) > 0 else (0, None)
         final_order = _in_final_order(q_order)
         if (early_stopping is None and grouped is None and final_order and len(q_no) >= _CODED_MIN_ROWS
                 and (batch_size is None or batch_size >= n_q)):
@@ -309,8 +309,9 @@ class Index(abc.ABC):
             # per row on the way to the device, none on the way back (the frame is built on first use)
             codes, names = ranking._id_coding()
             dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True)
+            order = order.astype(np.intp, copy=False)  # a permutation inside every query: the query numbers stay as they are
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            return Ranking._assemble_coded("fast-forward", q_no[order], q_order, codes[order], names,
+            return Ranking._assemble_coded("fast-forward", q_no, q_order, codes[order], names,
                                            dense[order].astype(ranking._score_dtype(), copy=False), texts)
         df = ranking._df
         if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
@@ -404,11 +405,14 @@ class Index(abc.ABC):
         ``missing_ok`` unknown ids come back as -1 instead (early stopping looks ids up leniently)."""
         key = (id(self), getattr(getattr(self, "_ids", None), "version", None), self.mode)
         cached = getattr(ranking, "_ordinal_cache", None)
-        if cached is None or cached[0] != key or cached[1] is not names:
-            cached = (key, names, self._lookup_optional(names, self.mode).astype(np.int32, copy=False))
+        if cached is None or cached[0] != key or cached[1] is not names or cached[2] is not codes:
+            by_code = self._lookup_optional(names, self.mode).astype(np.int32, copy=False)
+            # a ranking's rows never change: the resolved candidate list is kept with it (SURVEY.md 8e: "amortise /
+            # cache the resolved CSR per run")
+            cached = (key, names, codes, by_code[codes], bool(by_code.size and by_code.min() < 0))
             ranking._ordinal_cache = cached
-        ordinals = cached[2][codes]
-        if not missing_ok and cached[2].size and cached[2].min() < 0:
+        ordinals = cached[3]
+        if not missing_ok and cached[4]:
             unknown = np.flatnonzero(ordinals < 0)
             if unknown.size:  # the first one in ROW order, as _resolve_ids on the rows would name it
                 raise IndexError(f"ID {names[codes[int(unknown[0])]]} not found in the index.")
@@ -431,17 +435,19 @@ class Index(abc.ABC):
             raise ValueError("Input ranking has no queries attached.")
         q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
-        perm, pair_off = _grouped_by_query(q_no, len(texts))
+        perm, pair_off = ranking._csr()
         if perm is None and len(q_no) >= _CODED_MIN_ROWS and _in_final_order(q_order):
             # a large run in the constructor's order: integer codes in, integer codes out, no Python string per row
             codes, names = ranking._id_coding()
             ordinals = self._ordinals_of_codes(ranking, codes, names)
             sparse = np.ascontiguousarray(ranking._scores(), dtype=np.float32)
-            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False)
+            order = order.astype(np.intp, copy=False)
             if cutoff is not None:
                 rank = np.arange(len(order)) - np.repeat(pair_off[:-1], np.diff(pair_off))
-                order = order[rank < cutoff]
-            return Ranking._assemble_coded(ranking.name, q_no[order], q_order, codes[order], names,
+                keep = rank < cutoff
+                order, q_no = order[keep], q_no[keep]  # (the device order is a permutation inside every query)
+            return Ranking._assemble_coded(ranking.name, q_no, q_order, codes[order], names,
                                            interp[order].astype(ranking._score_dtype(), copy=False), texts)
         df = ranking._df
         ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)

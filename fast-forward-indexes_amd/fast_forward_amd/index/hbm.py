@@ -203,7 +203,7 @@ class InMemoryIndex(Index):
     def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
         return self._ids.resolve(ids, mode.value)
 
-    def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False):
+    def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False, want_dense=True):
         if self._store is None:
             raise IndexError("the index is empty")
         q = np.ascontiguousarray(query_vectors, dtype=np.float32)
@@ -220,7 +220,7 @@ class InMemoryIndex(Index):
         plan.set_queries(q)
         plan.set_pairs(pair_off, pair_ids, sparse, mode.value)
         plan.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
-        ff, interp, order = plan.fetch(ff=True, interp=sparse is not None, order=sort)
+        ff, interp, order = plan.fetch(ff=want_dense or sparse is None, interp=sparse is not None, order=sort)
         self.last_stats = plan.stats()
         return ff, interp, order
 

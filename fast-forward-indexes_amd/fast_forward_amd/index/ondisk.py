@@ -398,7 +398,7 @@ class OnDiskIndex(Index):
         within = np.arange(int(seg_off[-1]), dtype=np.int64) - np.repeat(seg_off[:-1], cnt)
         return doc_rows.astype(np.int64)[np.repeat(start, cnt) + within], np.repeat(pair_q, cnt), seg_off
 
-    def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False):
+    def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False, want_dense=True):
         if len(self) == 0:
             raise IndexError("the index is empty")
         q = np.ascontiguousarray(query_vectors, dtype=np.float32)

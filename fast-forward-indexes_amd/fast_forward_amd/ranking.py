@@ -142,16 +142,32 @@ class Ranking:
     def _score_dtype(self) -> np.dtype:
         return self._scores().dtype
 
+    def _csr(self) -> tuple["np.ndarray | None", np.ndarray]:
+        """(permutation that makes every query's rows adjacent, or None when they already are; offsets of
+        every query number).  Rows never change after construction, so this is computed once."""
+        cached = getattr(self, "_csr_cache", None)
+        if cached is None or cached[0] is not self._q_no:
+            q_no = np.asarray(self._q_no)
+            pair_off = np.zeros(len(self._q_order) + 1, dtype=np.int64)
+            np.cumsum(np.bincount(q_no, minlength=len(self._q_order)), out=pair_off[1:])
+            perm = None if (q_no.shape[0] < 2 or (q_no[1:] >= q_no[:-1]).all()) else np.argsort(q_no, kind="stable")
+            cached = (self._q_no, perm, pair_off)
+            self._csr_cache = cached
+        return cached[1], cached[2]
+
     def _query_texts(self) -> "list | None":
         """Query text per query number, or None when no queries are attached."""
         if self._coded is not None:
             return self._coded["q_texts"]
         if "query" not in self._frame.columns:
             return None
-        q_no = self._q_no
-        first_rows = np.full(len(self._q_order), -1, dtype=np.int64)
-        first_rows[q_no[::-1]] = np.arange(len(q_no) - 1, -1, -1)
-        return self._frame["query"].to_numpy()[first_rows].tolist()
+        cached = getattr(self, "_texts_cache", None)
+        if cached is None or cached[0] is not self._frame:
+            perm, pair_off = self._csr()
+            first_rows = pair_off[:-1] if perm is None else perm[pair_off[:-1]]  # every query number has >= 1 row
+            cached = (self._frame, self._frame["query"].to_numpy()[first_rows].tolist())
+            self._texts_cache = cached
+        return cached[1]
 
     def __init__(
         self,

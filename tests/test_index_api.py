@@ -495,3 +495,72 @@ def test_call_on_a_ranking_the_user_declared_sorted_still_comes_back_sorted():
         assert got._df["q_id"].tolist() == want._df["q_id"].tolist() == sorted(want._df["q_id"].tolist(), reverse=True)
         assert got._df["id"].tolist() == want._df["id"].tolist()
     index.close()
+
+
+def test_coded_results_equal_frame_results(monkeypatch):
+    """Large runs travel as integer codes (Ranking._assemble_coded; the frame of strings is built on
+    first use): same rows, scores and order as the small-run path that works on the frame itself --
+    for __call__, rerank (with and without cutoff), early stopping, a repeated call (cached candidate
+    list), and an unknown id named exactly as before."""
+    from fast_forward_amd.index import api
+
+    rng = np.random.default_rng(12)
+    n, d, n_q, k = 3000, 64, 9, 700
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qv = rng.standard_normal((n_q, d)).astype(np.float32)
+    index = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=Mode.MAXP)
+    index.add(rows, doc_ids=[f"D{i // 2}" for i in range(n)], psg_ids=[f"P{i}" for i in range(n)])
+    frame = pd.DataFrame({"q_id": np.repeat([f"q{i}" for i in range(n_q)], k),
+                          "id": np.concatenate([[f"D{x}" for x in rng.choice(n // 2, size=k, replace=False)] for _ in range(n_q)]),
+                          "score": (rng.random(n_q * k) * 20).astype(np.float32)})
+    first = Ranking(frame, queries={f"q{i}": str(i) for i in range(n_q)})
+    assert len(first._df) >= api._CODED_MIN_ROWS
+    coded = {"call": index(first), "rerank": index.rerank(first, 0.3), "cut": index.rerank(first, 0.3, cutoff=10),
+             "again": index.rerank(first, 0.3), "es": index(first, early_stopping=5, early_stopping_alpha=0.3, early_stopping_depths=(5, 50, 200))}
+    assert coded["rerank"]._frame is None and coded["rerank"]._coded is not None  # nothing materialised yet
+    monkeypatch.setattr(api, "_CODED_MIN_ROWS", 10**9)
+    fresh = Ranking(frame, queries={f"q{i}": str(i) for i in range(n_q)})
+    plain = {"call": index(fresh), "rerank": index.rerank(fresh, 0.3), "cut": index.rerank(fresh, 0.3, cutoff=10),
+             "again": index.rerank(fresh, 0.3), "es": index(fresh, early_stopping=5, early_stopping_alpha=0.3, early_stopping_depths=(5, 50, 200))}
+    for key in coded:
+        a, b = coded[key], plain[key]
+        pd.testing.assert_frame_equal(a._df, b._df)
+        assert a.q_ids == b.q_ids and a.name == b.name and a.has_queries == b.has_queries
+        assert np.array_equal(a._numbering()[0], b._numbering()[0]) and a._numbering()[1] == b._numbering()[1]
+    assert len(coded["cut"]._df) == n_q * 10
+    # a coded ranking is a Ranking: it goes back into the index and through the host algebra
+    monkeypatch.undo()
+    again = index(coded["rerank"])
+    assert again == index(plain["rerank"]) and first.interpolate(coded["call"], 0.3) == plain["rerank"]
+    bad = frame.copy()
+    bad.loc[4321, "id"] = "nowhere"
+    bad.loc[5000, "id"] = "nowhere-either"
+    with pytest.raises(IndexError, match="ID nowhere not found in the index."):
+        index.rerank(Ranking(bad, queries={f"q{i}": str(i) for i in range(n_q)}), 0.3)
+    index.close()
+
+
+def test_adopting_rows_that_are_already_on_the_device():
+    """InMemoryIndex.adopt: ids registered over a DeviceIndex that was filled elsewhere (bench.py's
+    synthetic index, a sharded load); the store stays the caller's."""
+    from fast_forward_amd import native
+
+    n, d = 5000, 128
+    store = native.DeviceIndex(n, d)
+    store.fill_synthetic(5, 0.1, 0, n)
+    host = synth.rows(5, 0.1, 0, n, d)
+    qv = synth.rows(6, 0.1, 0, 3, d)
+    doc_off = np.arange(0, n + 1, 2)
+    names = np.char.add("D", np.arange(n // 2).astype("U"))
+    adopted = InMemoryIndex.adopt(store, doc_ids=names, doc_off=doc_off, query_encoder=LambdaEncoder(lambda t: qv[int(t)]))
+    plain = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]))
+    plain.add(host, doc_ids=[f"D{i // 2}" for i in range(n)])
+    rng = np.random.default_rng(2)
+    run = {f"q{q}": {f"D{x}": float(rng.random()) for x in rng.choice(n // 2, size=200, replace=False)} for q in range(3)}
+    first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(3)})
+    assert adopted(first) == plain(first) and len(adopted) == n and adopted.doc_ids == plain.doc_ids
+    assert adopted.release() is store and len(adopted) == 0
+    adopted.close()
+    assert store.gather(np.array([7], dtype=np.int32)).shape == (1, d)  # still alive
+    store.close()
+    plain.close()
