@@ -535,7 +535,13 @@ def test_coded_results_equal_frame_results(monkeypatch):
     bad = frame.copy()
     bad.loc[4321, "id"] = "nowhere"
     bad.loc[5000, "id"] = "nowhere-either"
-    with pytest.raises(IndexError, match="ID nowhere not found in the index."):
+    broken = Ranking(bad, queries={f"q{i}": str(i) for i in range(n_q)})
+    first_unknown = next(i for i in broken._df["id"] if i.startswith("nowhere"))  # in the ranking's row order
+    for call in (lambda: index.rerank(broken, 0.3), lambda: index(broken)):
+        with pytest.raises(IndexError, match=f"ID {first_unknown} not found in the index."):
+            call()
+    monkeypatch.setattr(api, "_CODED_MIN_ROWS", 10**9)
+    with pytest.raises(IndexError, match=f"ID {first_unknown} not found in the index."):
         index.rerank(Ranking(bad, queries={f"q{i}": str(i) for i in range(n_q)}), 0.3)
     index.close()
 

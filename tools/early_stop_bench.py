@@ -56,10 +56,12 @@ from fast_forward_amd.index.hbm import InMemoryIndex as _IMI  # noqa: E402
 
 device_impl = _IMI._early_stopping_scores
 _IMI._early_stopping_scores = Index._early_stopping_scores
+_IMI._early_stopping_takes_ordinals = False
 t0 = time.perf_counter()
 es_host = index(first, early_stopping=args.cutoff, early_stopping_alpha=args.alpha, early_stopping_depths=depths)
 out["early_stopping_host_criterion_s"] = time.perf_counter() - t0
 _IMI._early_stopping_scores = device_impl
+_IMI._early_stopping_takes_ordinals = True
 out["host_and_device_criterion_agree"] = bool(es_host == es)
 if "--profile" in sys.argv:
     import cProfile
