@@ -182,6 +182,7 @@ struct ffx_plan {
   int mode = 0;
   bool have_sparse = false, have_pairs = false, ran = false, ran_sort = false;
   int n_leaves = 0;
+  bool anyd_ok = false, anyd_tails = false;  // every leaf has 8..128 elements; some leaf has len % 8 != 0
   bool last_interp = false;
   int32_t variant = 0;
   int32_t order_base = 0;  // added to the positions the per-query order is made of (slices of a larger batch)
@@ -623,6 +624,12 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
   numpy_leaf_plan(0, idx->qdim, bounds);
   bounds.push_back(idx->qdim);
   pl->n_leaves = (int)bounds.size() - 1;
+  pl->anyd_ok = true;
+  for (size_t l = 0; l + 1 < bounds.size(); ++l) {
+    const int len = bounds[l + 1] - bounds[l];
+    pl->anyd_ok = pl->anyd_ok && len >= 8 && len <= 128;
+    pl->anyd_tails = pl->anyd_tails || (len % 8) != 0;
+  }
   int rc = pl->leaf_start.ensure(bounds.size() * sizeof(int));
   if (rc == FFX_OK && hipMemcpy(pl->leaf_start.p, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(FFX_HIP_ERROR, "leaf plan upload failed");
@@ -946,6 +953,28 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
 #undef FFX_MULTI
       default: {
         if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
+        // any other row length with at most 8 leaves (8 <= d <= 1024): the strided form with a run-time leaf
+        // table -- every lane loads what it sums, nothing is staged or combined serially
+        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !getenv("FFX_GENERIC_STAGED")) {
+          const int* LS = pl->leaf_start.as<int>();
+          const int* CS = pl->combine_steps.as<int>();
+          const int nl = pl->n_leaves;
+#define FFX_ANYD(LG, U)                                                                                                       \
+  do {                                                                                                                        \
+    constexpr int TILE_ = ffx::exact_default_passes(LG) * (64 / (8 * LG));                                                    \
+    if (pl->anyd_tails)                                                                                                       \
+      ffx::gather_dot_exact_anyd_kernel<T, LG, U, true><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R, d, LS, nl, CS);  \
+    else                                                                                                                      \
+      ffx::gather_dot_exact_anyd_kernel<T, LG, U, false><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R, d, LS, nl, CS); \
+  } while (0)
+          if (nl == 1) FFX_ANYD(1, 4);
+          else if (nl == 2) FFX_ANYD(2, 4);
+          else if (nl <= 4) FFX_ANYD(4, 4);
+          else FFX_ANYD(8, 4);
+#undef FFX_ANYD
+          pl->variant = 130 + nl + HALF;
+          break;
+        }
         // any other row length: the row is staged in LDS (coalesced, independent loads) and the
         // leaves are walked from there; rows too long for a wave's share of LDS use the plain form
         const int dp = (d + 3) & ~3, lp = (pl->n_leaves + 3) & ~3;

@@ -452,6 +452,98 @@ gather_dot_fast_generic_kernel(const T* __restrict__ vectors, const float* __res
 // One wave (= one block) per row; leaf sums go through LDS, lane 0 replays the recursion from
 // the host-made list of steps (ffx.hip: numpy_combine_plan).
 
+// ---- exact kernel for ANY row length with at most 8 leaves (8 <= d <= 1024) -----------------------
+// The strided form of gather_dot_exact_kernel with the leaf table at run time.  NumPy cuts a row of
+// d elements into leaves of <= 128 (numpy_leaf_plan on the host); inside a leaf, accumulator j sums
+// elements s + j + 8*i in order of i, the 8 accumulators are tree-combined, the len % 8 trailing
+// elements are then added one by one, and the leaf sums are added in the order of the recursion
+// (combine_steps: "sum[a] += sum[b]").  LG = leaves per row rounded up to a power of two, so
+// 8*LG lanes own a row and a wave takes 64 / (8*LG) rows per pass: lane (leaf l, accumulator j)
+// loads exactly the <= 16 elements it sums, each 128-B line is shared by the four load
+// instructions that follow one another and merges in L1 (the round-1 "strided dword" form: 90 % of
+// the full-line + LDS-transpose kernel at d = 768), and nothing is staged or walked serially --
+// the staged generic kernel below ran at 1.2 - 3.5 TB/s because one wave walked its leaves out of
+// LDS element by element and lane 0 combined the leaf sums alone.
+template <typename T, int LG, int U, bool TAILS>
+__global__ void __launch_bounds__(256)
+gather_dot_exact_anyd_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
+                             const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int d,
+                             const int* __restrict__ leaf_start, int n_leaves, const int* __restrict__ combine_steps) {
+  constexpr int LPR = 8 * LG;
+  constexpr int RPW = 64 / LPR;
+  constexpr int PASSES = exact_default_passes(LG);
+  constexpr int TILE = PASSES * RPW;
+  constexpr int NMAX = 16;  // a leaf has at most 128 elements
+  static_assert(PASSES % U == 0 && TILE <= 64, "bad tiling");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long base = (long)wave * TILE;
+  if (base >= n_rows) return;
+  const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+  const int my_t = lane < n_here ? lane : n_here - 1;
+  const int2 my = desc[base + my_t];
+
+  const int sub = lane & (LPR - 1);
+  const int slot = lane / LPR;
+  const int leaf = sub >> 3, j = sub & 7;
+  const bool live = leaf < n_leaves;
+  const int s = live ? leaf_start[leaf] : 0;
+  const int len = live ? leaf_start[leaf + 1] - s : 0;
+  const int cnt = len >> 3;            // strided elements of this lane
+  const int tail = len & 7;            // trailing elements of this leaf
+  const int lane_off = s + j;
+  const int tail_off = s + 8 * cnt + j;  // lane j holds trailing element j (j < tail)
+  const int group0 = lane & ~7;          // first lane of this leaf's 8-lane group
+  const int row0 = lane & ~(LPR - 1);    // first lane of this row's lanes
+
+#pragma unroll 1
+  for (int b = 0; b < PASSES; b += U) {
+    if (b * RPW >= n_here) break;
+    float v[U][NMAX], tv[U];
+    int qn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = (b + u) * RPW + slot;
+      t = t < n_here ? t : n_here - 1;
+      const int rid = __shfl(my.x, t, 64);
+      qn[u] = __shfl(my.y, t, 64);
+      const T* rowp = vectors + (size_t)rid * d;
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) v[u][i] = i < cnt ? load1<T, false>(rowp + lane_off + 8 * i) : 0.f;
+      if constexpr (TAILS) tv[u] = j < tail ? load1<T, false>(rowp + tail_off) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* qp = queries + (size_t)qn[u] * d;  // L2-resident; consecutive rows share it
+      float acc = 0.f;
+      if (cnt > 0) acc = __fmul_rn(qp[lane_off], v[u][0]);
+#pragma unroll
+      for (int i = 1; i < NMAX; ++i)
+        if (i < cnt) acc = __fadd_rn(acc, __fmul_rn(qp[lane_off + 8 * i], v[u][i]));
+      acc = __fadd_rn(acc, xor1(acc));
+      acc = __fadd_rn(acc, xor2(acc));
+      acc = __fadd_rn(acc, xor4(acc));
+      if constexpr (TAILS) {
+        const float tp = j < tail ? __fmul_rn(qp[tail_off], tv[u]) : 0.f;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {  // res += a[lim + t], one by one, on every lane of the group alike
+          const float x = __shfl(tp, group0 + t, 64);
+          if (t < tail) acc = __fadd_rn(acc, x);
+        }
+      }
+      // leaf sums -> row sum in the order of NumPy's recursion
+      for (int t = 0; t < n_leaves - 1; ++t) {
+        const int a = combine_steps[2 * t], bb = combine_steps[2 * t + 1];  // wave-uniform
+        const float x = __shfl(acc, row0 + 8 * bb, 64);
+        if (leaf == a) acc = __fadd_rn(acc, x);
+      }
+      const int t = (b + u) * RPW + slot;
+      if (sub == 0 && t < n_here) rs[base + t] = acc;
+    }
+  }
+}
+
 // row accessors for the generic kernels: element i of the (decoded) row as fp32
 template <typename T>
 struct PlainRow {

@@ -263,6 +263,35 @@ def test_every_kernel_variant_exact(d, store):
 
 
 @pytest.mark.parametrize("store", [np.float32, np.float16])
+def test_any_row_length_up_to_eight_leaves_is_bit_exact(store):
+    """gather_dot_exact_anyd_kernel (run-time leaf table, every lane loads what it sums): row lengths with
+    1, 2, 3, 4 .. 8 leaves of NumPy's tree, with and without trailing elements (len % 8), balanced and
+    unbalanced recursions (d = 260 gives leaves 128 | 64 + 68) -- against NumPy itself, bit for bit;
+    beyond 8 leaves (d > 1024) and below 8 elements the staged generic kernel still answers."""
+    rng = np.random.default_rng(77)
+    dims = [8, 9, 15, 16, 17, 31, 100, 127, 129, 130, 136, 200, 255, 257, 260, 300, 383, 385, 500, 513, 640, 700, 767, 769, 900,
+            1000, 1016, 1023, 5, 1032, 1100]
+    for d in dims:
+        n, nq, k = 140, 3, 90
+        vectors = (rng.standard_normal((n, d)) * 1.5).astype(store)
+        queries = rng.standard_normal((nq, d)).astype(np.float32)
+        idx = native.DeviceIndex(n, d, dtype=store)
+        idx.upload(vectors, 0)
+        idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+        idx.set_psg_rows(np.arange(n))
+        pair_off = np.array([0, 1, k + 1, 2 * k + 1 - 7], dtype=np.int64)  # ragged, so tiles end inside a query
+        pair_ids = rng.integers(0, n, size=int(pair_off[-1])).astype(np.int32)
+        ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 1, exact_sum=True)
+        ref = np.sum(queries[np.repeat(np.arange(nq), np.diff(pair_off))] * vectors[pair_ids], axis=1)
+        assert ref.dtype == np.float32
+        assert np.array_equal(bits(ff), bits(ref)), f"d={d} variant {st['kernel_variant']}"
+        variant = st["kernel_variant"] % 1000
+        if 8 <= d <= 1024:
+            assert 131 <= variant <= 138, (d, variant)  # 130 + number of leaves
+        idx.close()
+
+
+@pytest.mark.parametrize("store", [np.float32, np.float16])
 def test_synthetic_fill_matches_host_generator(store):
     d, n = 768, 1000
     idx = native.DeviceIndex(n, d, dtype=store)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""gather_dot at row lengths that have no kernel of their own (the "any d" strided kernel, and the staged
+generic kernel it replaces: FFX_GENERIC_STAGED=1), index ~13 GB each, 2000 queries x k=5000."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+sys.path.insert(0, str(ROOT))
+from fast_forward_amd import native, synth  # noqa: E402
+import bench as B  # noqa: E402
+
+out = {}
+for d in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "32,100,200,300,1000,768").split(",")]:
+    n = min(40_000_000, int(13e9 / (d * 4)))
+    nq, k = 2000, 5000
+    idx = native.DeviceIndex(n, d)
+    idx.fill_synthetic(1, 0.05, 0, n)
+    idx.set_doc_rows(np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32))
+    idx.set_psg_rows(np.arange(n, dtype=np.int32))
+    ids, sparse = B.candidates(n, nq, k, 3)
+    plan = native.Plan(idx)
+    plan.set_queries(synth.rows(2, 0.05, 0, nq, d))
+    plan.set_pairs(np.arange(nq + 1, dtype=np.int64) * k, ids, sparse, 1)
+    res = {}
+    for label, env in (("anyd", None), ("staged", "1")):
+        if env:
+            os.environ["FFX_GENERIC_STAGED"] = env
+        else:
+            os.environ.pop("FFX_GENERIC_STAGED", None)
+        ms = []
+        for _ in range(6):
+            plan.run(0.1, exact_sum=True)
+            ms.append(plan.stats()["ms_gather_dot"])
+        st = plan.stats()
+        ff = plan.fetch()[0]
+        res[label] = {"ms": float(np.mean(ms[1:])), "GBs": nq * k * (d * 4 + 4) / float(np.mean(ms[1:])) / 1e6, "variant": st["kernel_variant"],
+                      "checksum": float(ff.astype(np.float64).sum())}
+    os.environ.pop("FFX_GENERIC_STAGED", None)
+    res["same_bits"] = res["anyd"]["checksum"] == res["staged"]["checksum"]
+    out[str(d)] = res
+    plan.close()
+    idx.close()
+print(json.dumps(out, indent=1))
