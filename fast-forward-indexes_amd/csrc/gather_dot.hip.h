@@ -497,6 +497,10 @@ gather_dot_exact_anyd_kernel(const T* __restrict__ vectors, const float* __restr
   const int group0 = lane & ~7;          // first lane of this leaf's 8-lane group
   const int row0 = lane & ~(LPR - 1);    // first lane of this row's lanes
 
+  // the query's elements this lane multiplies with live in registers and are reloaded only when the
+  // query changes (rows of a query are contiguous, so nearly every pass serves one query)
+  float q[NMAX], tq = 0.f;
+  int cur_q = -1;
 #pragma unroll 1
   for (int b = 0; b < PASSES; b += U) {
     if (b * RPW >= n_here) break;
@@ -515,17 +519,25 @@ gather_dot_exact_anyd_kernel(const T* __restrict__ vectors, const float* __restr
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* qp = queries + (size_t)qn[u] * d;  // L2-resident; consecutive rows share it
+      const int q0 = __builtin_amdgcn_readfirstlane(qn[u]);
+      const bool one_query = __all(qn[u] == q0);  // wave-uniform
+      if (!one_query || q0 != cur_q) {
+        const float* qp = queries + (size_t)qn[u] * d;  // L2-resident
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) q[i] = i < cnt ? qp[lane_off + 8 * i] : 0.f;
+        if constexpr (TAILS) tq = j < tail ? qp[tail_off] : 0.f;
+        cur_q = one_query ? q0 : -1;
+      }
       float acc = 0.f;
-      if (cnt > 0) acc = __fmul_rn(qp[lane_off], v[u][0]);
+      if (cnt > 0) acc = __fmul_rn(q[0], v[u][0]);
 #pragma unroll
       for (int i = 1; i < NMAX; ++i)
-        if (i < cnt) acc = __fadd_rn(acc, __fmul_rn(qp[lane_off + 8 * i], v[u][i]));
+        if (i < cnt) acc = __fadd_rn(acc, __fmul_rn(q[i], v[u][i]));
       acc = __fadd_rn(acc, xor1(acc));
       acc = __fadd_rn(acc, xor2(acc));
       acc = __fadd_rn(acc, xor4(acc));
       if constexpr (TAILS) {
-        const float tp = j < tail ? __fmul_rn(qp[tail_off], tv[u]) : 0.f;
+        const float tp = j < tail ? __fmul_rn(tq, tv[u]) : 0.f;
 #pragma unroll
         for (int t = 0; t < 7; ++t) {  // res += a[lim + t], one by one, on every lane of the group alike
           const float x = __shfl(tp, group0 + t, 64);

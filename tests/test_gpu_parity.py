@@ -286,8 +286,18 @@ def test_any_row_length_up_to_eight_leaves_is_bit_exact(store):
         assert ref.dtype == np.float32
         assert np.array_equal(bits(ff), bits(ref)), f"d={d} variant {st['kernel_variant']}"
         variant = st["kernel_variant"] % 1000
-        if 8 <= d <= 1024:
-            assert 131 <= variant <= 138, (d, variant)  # 130 + number of leaves
+
+        def leaves(n):  # NumPy's pairwise recursion
+            if n <= 128:
+                return [n]
+            n2 = n // 2 - (n // 2) % 8
+            return leaves(n2) + leaves(n - n2)
+
+        shape = leaves(d)
+        if len(shape) <= 8 and min(shape) >= 8:
+            assert variant == 130 + len(shape), (d, variant, shape)
+        else:
+            assert variant == 198, (d, variant, shape)  # the staged generic kernel
         idx.close()
 
 
