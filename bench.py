@@ -249,7 +249,17 @@ def bench_sharded(args, rank: int, world: int):
 
     if args.transport == "rccl" and native.device_count() < world:
         sys.exit(f"--gpus {world} over RCCL needs {world} GPUs, {native.device_count()} visible (use --transport host to rehearse on fewer)")
-    comm = connect(args.transport, rank=rank, world=world)
+    try:
+        comm = connect(args.transport, rank=rank, world=world)
+    except (native.FFXError, TimeoutError) as e:
+        if args.transport != "rccl" or (isinstance(e, native.FFXError) and e.code != native.RCCL_ERROR):
+            raise
+        os.environ["FFX_COMM_TIMEOUT_S"] = "600"  # ranks may arrive here minutes apart
+        # RCCL could not be brought up on this node (the same way on every rank): the exchange falls back to
+        # the shared-memory transport so that the scaling run still measures something; the line says so
+        print(f"rank {rank}: RCCL unavailable ({e}); falling back to the shared-memory transport", file=sys.stderr, flush=True)
+        args.transport = f"host (rccl unavailable: {str(e)[:120]})"
+        comm = connect("host", rank=rank, world=world)
     local_rank = comm.device
     if args.sharding == "queries":
         return bench_replicas(args, comm)
@@ -322,7 +332,7 @@ def bench_sharded(args, rank: int, world: int):
                 "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} {'fp16' if args.store == 'f16' else 'fp32'} index row-sharded by document over "
                             f"{world} GPUs ({n_local} rows on rank 0), {args.queries} queries, k={args.k}, Mode.{args.mode}, "
                             f"alpha={args.alpha}, sum={args.sum}; per step: local gather_dot, all-to-all of dense scores to "
-                            f"the owning rank ({'ncclSend/ncclRecv full mesh' if args.transport == 'rccl' else 'shared-memory rehearsal transport'}), "
+                            f"the owning rank ({'ncclSend/ncclRecv full mesh' if args.transport == 'rccl' else 'shared-memory transport'}), "
                             f"owner-side interpolation{' + per-query ordering' if args.sort else ''}",
                 "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
                 "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": int(pair_off[-1]), "store": args.store,

@@ -119,6 +119,10 @@ def connect(transport: str | int = "rccl", rank: int | None = None, world: int |
     ``device=-1`` for none at all)."""
     from fast_forward_amd import native
 
+    # one node by construction (one process per GPU of the same host): RCCL's bootstrap sockets can use
+    # the loopback interface, which exists and resolves everywhere (container hostnames often do not)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the driver supports dmabuf IPC only
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
     code = {"rccl": native.COMM_RCCL, "nccl": native.COMM_RCCL, "host": native.COMM_HOST}.get(transport, transport)

@@ -761,3 +761,29 @@ def test_c_example_runs_against_the_oracle(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-3000:]
     assert "rerank.c ok: 1200 pairs, 3600 rows gathered" in run.stdout
+
+
+@pytest.mark.parametrize("args,ranks", [(["rccl"], 1), (["host", "2"], 2), (["host", "3"], 3)])
+def test_sharded_c_example_runs_against_the_oracle(tmp_path, args, ranks):
+    """tests/c_abi/rerank_sharded.c: the multi-GPU entry points (ffx_comm_*, ffx_sharded_*) driven from plain
+    C99 -- no Python, no PyTorch in the processes: one rank over RCCL, and 2 / 3 forked ranks sharing this
+    GPU over the shared-memory transport (communicator id through a pipe); every owner checks its
+    queries against the oracle bit for bit."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    lib_dir, oracle_dir = root / "fast-forward-indexes_amd" / "fast_forward_amd", root / "oracle"
+    fo.lib()
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler on this box")
+    exe = tmp_path / "rerank_sharded"
+    build = subprocess.run(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{root / 'include'}",
+                            str(root / "tests" / "c_abi" / "rerank_sharded.c"), "-o", str(exe), f"-L{lib_dir}", "-lffx", f"-L{oracle_dir}",
+                            "-lffx_oracle", "-lm", f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{oracle_dir}", "-Wl,-rpath,/opt/rocm/lib"],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300, env=dict(os.environ, FFX_COMM_TIMEOUT_S="60"))
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-3000:]
+    assert f"rerank_sharded.c ok: {ranks} rank(s)" in run.stdout and "702 owned pairs checked" in run.stdout
