@@ -12,7 +12,9 @@
 #include <cstring>  // before rocprim: its texture iterator calls memset unqualified
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <atomic>
@@ -150,6 +152,7 @@ struct ffx_index {
   DevBuf psg_row;   // int32[n_psgs]
   DevBuf doc_first; // int32[n_docs]: first row of every document (FIRSTP / single-passage docs)
   int64_t n_docs = 0, n_doc_rows = 0, n_psgs = 0;
+  int64_t max_doc_rows = 1;  // rows of the longest document: bounds what a candidate can contribute
   bool docs_identity = false;  // document ordinal o owns exactly row o
   bool psgs_identity = false;  // passage ordinal o is row o
   // the two plans ffx_score alternates between (created on first use, freed with the index)
@@ -582,6 +585,8 @@ int ffx_index_set_doc_rows(ffx_index* idx, const int64_t* doc_off, int64_t n_doc
     FFX_HIP(hipMemcpy(idx->doc_rows.p, doc_rows, (size_t)n_doc_rows * sizeof(int32_t), hipMemcpyHostToDevice));
   idx->n_docs = n_docs;
   idx->n_doc_rows = n_doc_rows;
+  idx->max_doc_rows = 1;
+  for (int64_t i = 0; i < n_docs; ++i) idx->max_doc_rows = std::max(idx->max_doc_rows, doc_off[i + 1] - doc_off[i]);
   idx->docs_identity = identity && n_docs > 0;
   return FFX_OK;
 }
@@ -773,6 +778,22 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   if (bad != ~0ull) {
     if (bad_pair) *bad_pair = (int64_t)bad;
     return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad);
+  }
+  // the row list is addressed with int32 and the counts were scanned in int32: where that scan could have
+  // wrapped (a candidate contributes at most the rows of the longest document) the total is re-derived in int64
+  if (mode != FFX_MODE_PASSAGE && mode != FFX_MODE_FIRSTP && P * ix->max_doc_rows > (int64_t)INT32_MAX) {
+    size_t tmp = 0;
+    auto wide = rocprim::make_transform_iterator(pl->cnt.as<int32_t>(), [] __device__(int32_t c) { return (long long)c; });
+    FFX_TRY(pl->sort_tmp.ensure(64));
+    long long* out64 = pl->sort_tmp.as<long long>();
+    FFX_HIP(rocprim::reduce(nullptr, tmp, wide, out64, (long long)0, (size_t)P, rocprim::plus<long long>(), pl->stream));
+    FFX_TRY(pl->scan_tmp.ensure(std::max<size_t>(tmp, 16)));
+    FFX_HIP(rocprim::reduce(pl->scan_tmp.p, tmp, wide, out64, (long long)0, (size_t)P, rocprim::plus<long long>(), pl->stream));
+    long long exact = 0;
+    FFX_HIP(hipMemcpyAsync(&exact, out64, sizeof exact, hipMemcpyDeviceToHost, pl->stream));
+    FFX_HIP(hipStreamSynchronize(pl->stream));
+    if (exact > (long long)INT32_MAX)
+      return fail(FFX_BAD_ARG, "%lld gathered rows in one batch (more than 2^31-1): split the queries", exact);
   }
   if (total < 0) return fail(FFX_BAD_ARG, "more than 2^31-1 gathered rows in one batch: split the queries");
   pl->n_rows = total;

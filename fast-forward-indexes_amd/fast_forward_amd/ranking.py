@@ -347,14 +347,15 @@ class Ranking:
 
     def _combined(self, other: "Ranking", fn, left: pd.DataFrame | None = None, right: pd.DataFrame | None = None) -> "Ranking":
         """``fn(score, score_other)`` over the outer join on (q_id, id) -- what ``_joined`` + the
-        constructor compute, without hashing a string pair per row: queries are numbered through
-        the cached per-row query numbers, ids through one factorize, and the join runs on the
-        resulting integer keys.  Same rows, scores and order (exact ties: by id, as the sorted
-        outer merge leaves them)."""
-        a, b = self._df, other._df
-        sa = (a if left is None else left)["score"].to_numpy()
-        sb = (b if right is None else right)["score"].to_numpy()
-        na, nb = len(a), len(b)
+        constructor compute, without hashing a string pair per row: queries are numbered through the
+        cached per-row query numbers, ids through the two rankings' id codes (shared as they are when
+        ``other`` came out of ``index(self)``; otherwise the two tables of DISTINCT ids are merged), and
+        the join runs on the resulting integer keys.  Same rows, scores and order (exact ties: by id,
+        as the sorted outer merge leaves them).  The result is coded whenever every row has its query
+        text on the side that provides it (always, when both sides hold the same pairs)."""
+        sa = self._scores() if left is None else left["score"].to_numpy()
+        sb = other._scores() if right is None else right["score"].to_numpy()
+        na, nb = len(sa), len(sb)
         if na + nb == 0:
             return None
         qa, names_a = self._numbering()
@@ -364,16 +365,21 @@ class Ranking:
             code_of.setdefault(q, len(code_of))
         names = list(code_of)
         gb = np.fromiter((code_of[q] for q in names_b), dtype=np.int64, count=len(names_b))[qb] if nb else np.zeros(0, dtype=np.int64)
-        ids_a, ids_b = a["id"].to_numpy(), b["id"].to_numpy()
-        id_code, id_names = pd.factorize(np.concatenate([ids_a, ids_b]))
+        ca, ids_a = self._id_coding()
+        cb, ids_b = other._id_coding()
+        if ids_a is ids_b:
+            id_names, code_a, code_b = ids_a, ca.astype(np.int64), cb.astype(np.int64)
+        else:  # merge the two tables of distinct ids (not the rows)
+            merged, uniques = pd.factorize(np.concatenate([ids_a, ids_b]))
+            id_names = np.asarray(uniques, dtype=object)
+            code_a, code_b = merged[:len(ids_a)][ca], merged[len(ids_a):][cb]
         width = max(1, len(id_names))
-        keys, where = np.unique(np.concatenate([qa.astype(np.int64) * width + id_code[:na], gb * width + id_code[na:]]),
-                                return_inverse=True)
+        keys, where = np.unique(np.concatenate([np.asarray(qa, dtype=np.int64) * width + code_a, gb * width + code_b]), return_inverse=True)
         at_a, at_b = where[:na], where[na:]
         n = keys.shape[0]
         va, vb = np.zeros(n, dtype=sa.dtype), np.zeros(n, dtype=sb.dtype)
         va[at_a], vb[at_b] = sa, sb
-        score = np.asarray(fn(va, vb)).astype(a.dtypes["score"], copy=False)
+        score = np.asarray(fn(va, vb)).astype(self._score_dtype(), copy=False)
         if np.isnan(score).any():
             return None  # rows would be dropped: leave it to the general path
         # final order: q_id descending, score descending, exact ties by id ascending
@@ -382,8 +388,7 @@ class Ranking:
         rank_of[np.argsort(np.array(names, dtype=object))[::-1]] = np.arange(len(names))
         q_rank = rank_of[q_of]
         order = np.lexsort((-score.astype(np.float64), q_rank))
-        id_sorted = id_names.to_numpy() if hasattr(id_names, "to_numpy") else np.asarray(id_names)
-        id_col = id_sorted[(keys % width)[order]]
+        id_code = (keys % width)[order].astype(np.int32)
         s_o, q_o = score[order], q_rank[order]
         tied = np.flatnonzero((s_o[1:] == s_o[:-1]) & (q_o[1:] == q_o[:-1]))
         if tied.size:
@@ -392,29 +397,35 @@ class Ranking:
                 hi = lo + 1
                 while hi < n and s_o[hi] == s_o[lo] and q_o[hi] == q_o[lo]:
                     hi += 1
-                fix = np.argsort(id_col[lo:hi], kind="stable")
+                fix = np.argsort(id_names[id_code[lo:hi]], kind="stable")
                 order[lo:hi] = order[lo:hi][fix]
-                id_col[lo:hi] = id_col[lo:hi][fix]
+                id_code[lo:hi] = id_code[lo:hi][fix]
         q_names = np.array(names, dtype=object)
-        cols = {"q_id": q_names[q_of[order]], "id": id_col, "score": s_o}
-        # the query text comes from this ranking if it has any, else from `other`; a pair the
-        # chosen side lacks gets the merge's fill value 0
-        side = (a, at_a) if "query" in a.columns else (b, at_b) if "query" in b.columns else None
-        if side is not None:
-            src = np.full(n, -1, dtype=np.int64)
-            src[side[1]] = np.arange(len(side[0]))
-            src = src[order]
-            query = np.zeros(n, dtype=object)
-            have = src >= 0
-            query[have] = side[0]["query"].to_numpy()[src[have]]
-            cols["query"] = query
         # numbering of the result: queries appear in rank order
         present = np.flatnonzero(np.bincount(q_o, minlength=len(names)))
         renumber = np.full(len(names), -1, dtype=np.int64)
         renumber[present] = np.arange(present.shape[0])
         by_rank = np.empty(len(names), dtype=object)
         by_rank[rank_of] = q_names
-        return Ranking._assemble(cols, self.name, renumber[q_o], by_rank[present].tolist())
+        q_order = by_rank[present].tolist()
+        # the query text comes from this ranking if it has any, else from `other`; a pair the
+        # chosen side lacks gets the merge's fill value 0
+        side = (self, at_a) if self.has_queries else (other, at_b) if other.has_queries else None
+        if side is None or np.unique(side[1]).shape[0] == n:
+            q_texts = None
+            if side is not None:  # every row has its text on that side: one text per query
+                text_of = dict(zip(side[0]._numbering()[1], side[0]._query_texts()))
+                q_texts = [text_of[q] for q in q_order]
+            return Ranking._assemble_coded(self.name, renumber[q_o], q_order, id_code, id_names, s_o, q_texts)
+        cols = {"q_id": q_names[q_of[order]], "id": id_names[id_code], "score": s_o}
+        src = np.full(n, -1, dtype=np.int64)
+        src[side[1]] = np.arange(len(side[1]))
+        src = src[order]
+        query = np.zeros(n, dtype=object)
+        have = src >= 0
+        query[have] = side[0]._df["query"].to_numpy()[src[have]]
+        cols["query"] = query
+        return Ranking._assemble(cols, self.name, renumber[q_o], q_order)
 
     def __add__(self, o: "Ranking | float") -> "Ranking":
         if isinstance(o, Ranking):

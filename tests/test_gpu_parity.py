@@ -178,6 +178,28 @@ def test_unknown_ordinal_is_not_found(cases):
     idx.close()
 
 
+def test_row_count_beyond_int32_is_refused_not_wrapped():
+    """The row list is addressed with int32.  A batch that would gather more than 2^31-1 rows is refused --
+    also when the int32 scan of the per-candidate counts would wrap past 2^32 back into positive
+    numbers (62 000 candidates x a 70 000-passage document = 4.34e9 rows)."""
+    n, d = 70_000, 8
+    idx = native.DeviceIndex(n, d)
+    idx.fill_synthetic(1, 1.0, 0, n)
+    idx.set_doc_rows(np.array([0, n]), np.arange(n))  # ONE document owning every row
+    idx.set_psg_rows(np.arange(n))
+    plan = native.Plan(idx)
+    plan.set_queries(np.ones((2, d), dtype=np.float32))
+    for p in (31_000, 62_000):  # 2.17e9 (wraps negative) and 4.34e9 (wraps to a positive number)
+        with pytest.raises(native.FFXError, match="gathered rows in one batch"):
+            plan.set_pairs(np.array([0, p // 2, p]), np.zeros(p, dtype=np.int32), None, MODE_NO["MAXP"])
+    plan.set_pairs(np.array([0, 2, 3]), np.zeros(3, dtype=np.int32), None, MODE_NO["MAXP"])  # 210 000 rows: fine
+    plan.run(0.0)
+    assert plan.stats()["n_rows"] == 3 * n
+    plan.set_pairs(np.array([0, 31_000, 62_000]), np.zeros(62_000, dtype=np.int32), None, MODE_NO["FIRSTP"])  # one row each: fine
+    plan.close()
+    idx.close()
+
+
 def test_ragged_and_empty_queries():
     """Queries with 0, 1 and many candidates; a tile boundary inside a query; R not a multiple
     of the wave tile."""
