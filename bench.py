@@ -247,10 +247,15 @@ def bench_sharded(args, rank: int, world: int):
     communicator (RCCL, or shared memory with --transport host)."""
     from fast_forward_amd.sharded import ShardedScorer, connect, doc_partition, query_partition
 
-    if args.transport == "rccl" and native.device_count() < world:
-        sys.exit(f"--gpus {world} over RCCL needs {world} GPUs, {native.device_count()} visible (use --transport host to rehearse on fewer)")
+    visible = native.device_count()
+    masked = any(os.environ.get(v) for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    device = None
+    if args.transport == "rccl" and visible < world:
+        if not (masked and visible >= 1):
+            sys.exit(f"--gpus {world} over RCCL needs {world} GPUs, {visible} visible (use --transport host to rehearse on fewer)")
+        device = int(os.environ.get("LOCAL_RANK", str(rank))) % visible  # a launcher gave every rank its own device mask
     try:
-        comm = connect(args.transport, rank=rank, world=world)
+        comm = connect(args.transport, rank=rank, world=world, device=device)
     except (native.FFXError, TimeoutError) as e:
         if args.transport != "rccl" or (isinstance(e, native.FFXError) and e.code != native.RCCL_ERROR):
             raise
@@ -259,7 +264,7 @@ def bench_sharded(args, rank: int, world: int):
         # the shared-memory transport so that the scaling run still measures something; the line says so
         print(f"rank {rank}: RCCL unavailable ({e}); falling back to the shared-memory transport", file=sys.stderr, flush=True)
         args.transport = f"host (rccl unavailable: {str(e)[:120]})"
-        comm = connect("host", rank=rank, world=world)
+        comm = connect("host", rank=rank, world=world, device=device)
     local_rank = comm.device
     if args.sharding == "queries":
         return bench_replicas(args, comm)
