@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <rocprim/block/block_radix_sort.hpp>
+
 #include "../../include/ffx.h"
 
 namespace ffx {
@@ -330,6 +332,53 @@ __global__ void __launch_bounds__(256)
 iota_kernel(int32_t* __restrict__ dst, int64_t n, int32_t base) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = base + (int32_t)i;
+}
+
+// ---- per-query order, one workgroup per query, entirely in LDS -----------------------------------
+// rocPRIM's segmented sort keeps queries of up to ~4 K candidates inside a workgroup, but sends longer
+// ones (k = 5000 is just past that) through radix passes over global memory: 1.3 ms for 6980 x 5000.
+// Here a query of up to BS * IPT candidates is loaded once (coalesced, through an LDS stage into the
+// blocked arrangement a stable sort needs), ordered by rocprim::block_radix_sort in LDS -- keys are the
+// order-preserving unsigned images of the scores (-0.0 counted as +0.0), values the positions, so
+// "descending, exact ties by position" is the plain stable descending sort -- and stored once.
+// Padding items carry image 0 behind every real item (stability), so they never reach the output.
+template <unsigned BS, unsigned IPT>
+__global__ void __launch_bounds__(BS)
+block_sort_desc_kernel(const float* __restrict__ keys, const int64_t* __restrict__ pair_off, int32_t base,
+                       int32_t* __restrict__ order) {
+  using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, int32_t>;
+  __shared__ typename Sort::storage_type storage;
+  __shared__ uint32_t stage[BS * IPT];
+  const int q = blockIdx.x;
+  const int64_t lo = pair_off[q];
+  const int n = (int)(pair_off[q + 1] - lo);
+  if (n == 0) return;  // block-uniform
+  for (int i = threadIdx.x; i < (int)(BS * IPT); i += BS) {
+    uint32_t image = 0u;
+    if (i < n) {
+      uint32_t b = __float_as_uint(keys[lo + i]);
+      if (b == 0x80000000u) b = 0u;
+      image = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    }
+    stage[i] = image;
+  }
+  __syncthreads();
+  uint32_t k[IPT];
+  int32_t v[IPT];
+#pragma unroll
+  for (unsigned i = 0; i < IPT; ++i) {
+    const int at = (int)(threadIdx.x * IPT + i);
+    k[i] = stage[at];
+    v[i] = at;
+  }
+  __syncthreads();
+  Sort().sort_desc(k, v, storage);
+  __syncthreads();
+#pragma unroll
+  for (unsigned i = 0; i < IPT; ++i) stage[threadIdx.x * IPT + i] = (uint32_t)v[i];
+  __syncthreads();
+  const int32_t first = base + (int32_t)lo;
+  for (int i = threadIdx.x; i < n; i += BS) order[lo + i] = first + (int32_t)stage[i];
 }
 
 // ---- per-query order of batches with very long queries ---------------------------------------
