@@ -1168,15 +1168,19 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
     FFX_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp, w_in, w_out, iota.as<int32_t>(), order.as<int32_t>(), pb, 0, 32 + q_bits, st));
     return FFX_OK;
   }
-  // queries of 2049 .. 8192 candidates: one workgroup per query, sorted in LDS (rocPRIM's segmented sort
-  // takes ~4 K-candidate queries and longer ones through global-memory passes: 1.30 ms vs the time below
-  // at 6980 x 5000); FFX_SORT_BLOCK_FROM / _TO move the window (A/B hook)
-  int64_t block_from = 2049, block_to = 8192;
+  // longest query of 129 .. 8192 candidates: one workgroup per query, sorted in LDS.  Measured against
+  // rocPRIM's segmented sort at 7 M pairs (tools/sort_ab.py): k = 256: 0.078 vs 0.214 ms, 1000: 0.090 vs
+  // 0.150, 5000: 0.102 vs 0.365 (6980 x 5000: 0.45 vs 1.37 ms); rocPRIM wins below ~128 candidates per
+  // query (k = 100: 0.115 vs 0.179, k = 10: 0.77 vs 1.63) where it packs many queries into a workgroup.
+  // FFX_SORT_BLOCK_FROM / _TO move the window (A/B hook)
+  int64_t block_from = 129, block_to = 8192;
   if (const char* e = getenv("FFX_SORT_BLOCK_FROM")) block_from = atoll(e);
   if (const char* e = getenv("FFX_SORT_BLOCK_TO")) block_to = atoll(e);
   if (max_len >= block_from && max_len <= std::min<int64_t>(block_to, 8192) && n_queries > 0) {
     const unsigned nq = (unsigned)n_queries;
-    if (max_len <= 1024) ffx::block_sort_desc_kernel<256, 4><<<nq, 256, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
+    if (max_len <= 256) ffx::block_sort_desc_kernel<64, 4><<<nq, 64, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 512) ffx::block_sort_desc_kernel<128, 4><<<nq, 128, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 1024) ffx::block_sort_desc_kernel<256, 4><<<nq, 256, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
     else if (max_len <= 2048) ffx::block_sort_desc_kernel<256, 8><<<nq, 256, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
     else if (max_len <= 4096) ffx::block_sort_desc_kernel<512, 8><<<nq, 512, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
     else if (max_len <= 5120) ffx::block_sort_desc_kernel<512, 10><<<nq, 512, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());

@@ -12,15 +12,17 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
 from fast_forward_amd import native  # noqa: E402
 
-n, d, nq = 200_000, 64, 6980
+n, d = 200_000, 64
+PAIRS = 7_000_000  # per case: queries = PAIRS / k
 idx = native.DeviceIndex(n, d)
 idx.fill_synthetic(1, 0.1, 0, n)
 idx.set_doc_rows(np.arange(n + 1), np.arange(n))
 idx.set_psg_rows(np.arange(n))
 rng = np.random.default_rng(0)
-queries = rng.standard_normal((nq, d)).astype(np.float32)
 out = {}
-for k in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1000,2000,3000,4096,5000,8192").split(",")]:
+for k in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "10,50,100,256,500,1000,2000,5000,8192").split(",")]:
+    nq = max(1, PAIRS // k)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
     pair_off = np.arange(nq + 1, dtype=np.int64) * k
     ids = rng.integers(0, n, size=nq * k).astype(np.int32)
     sparse = (rng.random(nq * k) * 25).astype(np.float32)
