@@ -7,6 +7,7 @@ HIP device is visible when device work is requested, the error is raised to the 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -275,6 +276,7 @@ class DeviceIndex:
         self.capacity, self.dim, self.device = int(capacity_rows), int(dim), int(device)
         self.query_dim = 0 if self.dtype == np.uint8 else int(dim)
         self.codebook_shape: tuple[int, int, int] | None = None
+        self._dependents = weakref.WeakSet()  # plans / sharded scorers built on this index: closed before it
 
     def set_codebook(self, codewords: np.ndarray) -> None:
         """Codewords ``[M, Ks, Ds]`` float32 of the product quantizer whose codes the rows hold."""
@@ -286,6 +288,8 @@ class DeviceIndex:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for dep in list(getattr(self, "_dependents", ())):  # their device state refers to this index
+                dep.close()
             lib().ffx_index_destroy(self._h)
             self._h = None
 
@@ -347,6 +351,7 @@ class Plan:
         _check(lib().ffx_plan_create(index._h, C.byref(h)))
         self._h = h
         self._index = index  # keep the index alive as long as the plan
+        index._dependents.add(self)
         self.n_pairs = 0
         self.has_sparse = False
 
@@ -807,9 +812,12 @@ class Comm:
         _check(lib().ffx_comm_init(int(transport), int(device), int(rank), int(world), uid, C.byref(h)))
         self._h = h
         self.transport, self.device, self.rank, self.world = int(transport), int(device), int(rank), int(world)
+        self._dependents = weakref.WeakSet()  # sharded scorers using this communicator's stream: closed before it
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for dep in list(getattr(self, "_dependents", ())):
+                dep.close()
             lib().ffx_comm_destroy(self._h)
             self._h = None
 
@@ -890,6 +898,8 @@ class Sharded:
         h = C.c_void_p()
         _check(lib().ffx_sharded_create(shard._h, comm._h, _ptr(db), C.byref(h)))
         self._h, self._shard, self._comm = h, shard, comm
+        shard._dependents.add(self)
+        comm._dependents.add(self)
         self.has_sparse = False
         self.q_lo = self.q_hi = self.own_first_pair = self.own_pairs = 0
 

@@ -178,6 +178,22 @@ def test_unknown_ordinal_is_not_found(cases):
     idx.close()
 
 
+def test_closing_an_index_closes_what_was_built_on_it(cases):
+    """A Plan (or sharded scorer) holds device state that refers to its index: closing the index first
+    closes them, so their own close / collection later is a no-op instead of a use-after-free."""
+    case = cases["dim20"]
+    idx = device_index(case)
+    plan, other = native.Plan(idx), native.Plan(idx)
+    pair_off, pair_ids, sparse, _ = case.pairs("MAXP")
+    plan.set_queries(case.queries)
+    plan.set_pairs(pair_off, pair_ids, sparse, MODE_NO["MAXP"])
+    plan.run(0.1)
+    idx.close()
+    assert plan._h is None and other._h is None
+    plan.close()
+    del plan, other
+
+
 def test_row_count_beyond_int32_is_refused_not_wrapped():
     """The row list is addressed with int32.  A batch that would gather more than 2^31-1 rows is refused --
     also when the int32 scan of the per-candidate counts would wrap past 2^32 back into positive
