@@ -108,6 +108,11 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C fast-forward-indexes_amd/csrc`).  This package has no CPU fallback."
         )
+    import os
+
+    # read by the HSA runtime when it starts (the first HIP call): this host's driver supports dmabuf IPC only,
+    # and RCCL's intra-node transport needs IPC (harmless for a single-GPU process)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     L = C.CDLL(str(LIB_PATH))
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     P = C.POINTER

@@ -34,7 +34,7 @@ def run_ranks(world: int, script: Path, *args, timeout: int = 600, extra_env=Non
     return [p.returncode for p in procs], outs
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_path_over_native_host_transport(world):
     codes, outs = run_ranks(world, ROOT / "tests" / "_host_comm_worker.py")
     assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
