@@ -41,6 +41,18 @@ def test_sharded_path_over_native_host_transport(world):
     assert "checked bit-exact" in outs[0][0]
 
 
+def test_ranks_started_by_torchrun_find_each_other():
+    """The other way N ranks get started (`python -m torch.distributed.run ...`): no FFX_RDZV_KEY; the ranks
+    derive the job's name from the launcher's port, run id and their common parent process."""
+    env = {k: v for k, v in os.environ.items() if k not in ("FFX_RDZV_KEY", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="2", FFX_COMM_TIMEOUT_S="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29644", str(ROOT / "tests" / "_host_comm_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "host transport world=2" in out.stdout and "checked bit-exact" in out.stdout
+
+
 def test_native_query_partition_matches_numpy():
     for n_q in (0, 1, 7, 6980, 10**6 + 3):
         for world in (1, 2, 3, 8):
