@@ -398,6 +398,12 @@ int ffx_index_set_codebook(ffx_index* idx, const float* codewords, int32_t m, in
   return FFX_OK;
 }
 
+int ffx_index_device_ptr(const ffx_index* idx, void** ptr) {
+  if (!idx || !ptr) return fail(FFX_BAD_ARG, "NULL argument");
+  *ptr = idx->vectors;
+  return FFX_OK;
+}
+
 int ffx_index_capacity(const ffx_index* idx, int64_t* rows) {
   if (!idx || !rows) return fail(FFX_BAD_ARG, "NULL argument");
   *rows = idx->capacity;
@@ -694,6 +700,19 @@ int ffx_plan_set_queries(ffx_plan* pl, const float* host_queries, int64_t n_quer
   FFX_TRY(pl->queries.ensure(std::max<size_t>(bytes, 16)));
   pl->hstage_used = 0;
   FFX_TRY(plan_h2d(pl, pl->queries.p, host_queries, bytes));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  pl->n_queries_set = (int)n_queries;
+  pl->ran = false;
+  return FFX_OK;
+}
+
+int ffx_plan_set_queries_device(ffx_plan* pl, const float* dev_queries, int64_t n_queries) {
+  if (!pl || n_queries < 0 || (n_queries > 0 && !dev_queries)) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_queries > INT32_MAX) return fail(FFX_BAD_ARG, "too many queries");
+  FFX_HIP(hipSetDevice(pl->device));
+  const size_t bytes = (size_t)n_queries * pl->idx->qdim * sizeof(float);
+  FFX_TRY(pl->queries.ensure(std::max<size_t>(bytes, 16)));
+  if (bytes) FFX_HIP(hipMemcpyAsync(pl->queries.p, dev_queries, bytes, hipMemcpyDeviceToDevice, pl->stream));
   FFX_HIP(hipStreamSynchronize(pl->stream));
   pl->n_queries_set = (int)n_queries;
   pl->ran = false;

@@ -23,10 +23,10 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 # every symbol include/ffx.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
-    "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity",
+    "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
     "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
-    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_pairs",
+    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs",
     "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
         "ffx_index_destroy": ([vp], C.c_int),
         "ffx_index_dim": ([vp, P(i32)], C.c_int),
         "ffx_index_capacity": ([vp, P(i64)], C.c_int),
+        "ffx_index_device_ptr": ([vp, P(vp)], C.c_int),
         "ffx_index_upload": ([vp, vp, i64, i64], C.c_int),
         "ffx_index_upload_rows": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
@@ -139,6 +140,7 @@ def lib() -> C.CDLL:
         "ffx_plan_create": ([vp, P(vp)], C.c_int),
         "ffx_plan_destroy": ([vp], C.c_int),
         "ffx_plan_set_queries": ([vp, vp, i64], C.c_int),
+        "ffx_plan_set_queries_device": ([vp, vp, i64], C.c_int),
         "ffx_plan_set_pairs": ([vp, vp, i64, vp, vp, C.c_int, P(i64)], C.c_int),
         "ffx_plan_run": ([vp, C.c_double, C.c_uint32], C.c_int),
         "ffx_plan_set_pairs_lazy": ([vp, vp, i64, vp, vp, C.c_int], C.c_int),
@@ -317,6 +319,12 @@ class DeviceIndex:
         rows = _arr(rows, np.int64)
         _check(lib().ffx_index_upload_rows(self._h, ptrs, len(chunks), chunk_rows, _ptr(rows), rows.shape[0], int(dst_row), int(threads)))
 
+    def device_ptr(self) -> int:
+        """Device address of row 0 (rows contiguous, in the index dtype)."""
+        p = C.c_void_p()
+        _check(lib().ffx_index_device_ptr(self._h, C.byref(p)))
+        return p.value or 0
+
     def copy_rows_from(self, src: "DeviceIndex", n_rows: int) -> None:
         _check(lib().ffx_index_copy_rows(self._h, src._h, n_rows))
 
@@ -371,6 +379,10 @@ class Plan:
         queries = _arr(queries, np.float32)
         assert queries.ndim == 2 and queries.shape[1] == self._index.query_dim, "query dimensionality does not match the index"
         _check(lib().ffx_plan_set_queries(self._h, _ptr(queries), queries.shape[0]))
+
+    def set_queries_device(self, dev_ptr: int, n_queries: int) -> None:
+        """Query vectors that already sit in device memory of this GPU (fp32, ``[n_queries, query_dim]``)."""
+        _check(lib().ffx_plan_set_queries_device(self._h, C.c_void_p(dev_ptr), int(n_queries)))
 
     def set_pairs(self, pair_off, pair_ids, sparse, mode: int) -> None:
         pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)

@@ -108,6 +108,8 @@ int ffx_index_query_dim(const ffx_index* idx, int32_t* dim);
 int ffx_index_destroy(ffx_index* idx);
 int ffx_index_dim(const ffx_index* idx, int32_t* dim);
 int ffx_index_capacity(const ffx_index* idx, int64_t* rows);
+/* device address of row 0 (rows are contiguous, in the index dtype): zero-copy consumers / producers on the same GPU */
+int ffx_index_device_ptr(const ffx_index* idx, void** ptr);
 /* copy host rows into rows [row_offset, row_offset+n_rows): InMemoryIndex._add, memory.py:100-119 */
 int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, int64_t n_rows); /* rows in the index dtype */
 /* rows scattered over the equally sized chunks of a (memory-mapped) file -> device rows
@@ -142,6 +144,9 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out);
 int ffx_plan_destroy(ffx_plan* plan);
 /* query vectors [n_queries, dim] fp32, row q = query number q (q_no of index/base.py:418-421) */
 int ffx_plan_set_queries(ffx_plan* plan, const float* host_queries, int64_t n_queries);
+/* the same for query vectors that are already in DEVICE memory of the plan's GPU (a query encoder running
+ * on the GPU hands over its output without a trip through the host): device-to-device copy on the plan's stream */
+int ffx_plan_set_queries_device(ffx_plan* plan, const float* dev_queries, int64_t n_queries);
 /* candidate lists in CSR form: pairs pair_off[q] .. pair_off[q+1] belong to query q and name
  * ordinal pair_ids[p] (document ordinal, or passage ordinal for FFX_MODE_PASSAGE); sparse[p] is
  * the first-stage score (may be NULL).  get_indices, index/util.py:12-42, runs here. */
