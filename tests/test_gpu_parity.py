@@ -178,6 +178,31 @@ def test_unknown_ordinal_is_not_found(cases):
     idx.close()
 
 
+def test_query_vectors_handed_over_in_device_memory(cases):
+    """ffx_plan_set_queries_device: query vectors that already sit in HBM (a GPU-side encoder's output; here:
+    the rows of a second index on the same device, via ffx_index_device_ptr) give the same bits as the
+    same vectors uploaded from the host."""
+    case = cases["d768"]
+    idx = device_index(case)
+    holder = native.DeviceIndex(case.queries.shape[0], case.queries.shape[1])
+    holder.upload(case.queries, 0)
+    pair_off, pair_ids, sparse, _ = case.pairs("MAXP")
+    a, b = native.Plan(idx), native.Plan(idx)
+    a.set_queries(case.queries)
+    b.set_queries_device(holder.device_ptr(), case.queries.shape[0])
+    outs = []
+    for plan in (a, b):
+        plan.set_pairs(pair_off, pair_ids, sparse, MODE_NO["MAXP"])
+        plan.run(0.1, exact_sum=True, sort=True)
+        outs.append(plan.fetch(interp=True, order=True))
+    for x, y in zip(*outs):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    with pytest.raises(native.FFXError):
+        b.set_queries_device(0, 3)
+    idx.close()
+    holder.close()
+
+
 def test_closing_an_index_closes_what_was_built_on_it(cases):
     """A Plan (or sharded scorer) holds device state that refers to its index: closing the index first
     closes them, so their own close / collection later is a no-op instead of a use-after-free."""
