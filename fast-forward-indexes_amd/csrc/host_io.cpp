@@ -7,6 +7,8 @@
 //   ffx_ids_*  an insertion-ordered string -> ordinal table (open addressing, FNV-1a)
 //   ffx_run_*  a TREC run parsed straight into the CSR the kernels take, and written back
 // No device code here; plain C++17.
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cctype>
@@ -20,6 +22,7 @@
 #include <numeric>
 #include <string>
 #include <string_view>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -28,6 +31,22 @@
 int ffx_fail(int code, const char* fmt, ...);  // ffx.hip: records the thread's last error
 
 namespace {
+
+// cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container on a
+// 256-core host is often allowed 16; 128 threads on that quota crawl)
+inline int usable_cores() {
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32];
+    long period = 0;
+    if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+      n = std::min(n, std::max(1, (int)((atol(quota) + period / 2) / period)));
+    fclose(f);
+  }
+  return n;
+}
 
 inline uint64_t fnv1a(const char* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
@@ -346,6 +365,57 @@ int ffx_ids_blob(const ffx_ids* t, char sep, char* buf, int64_t cap, int64_t* ne
     if (i + 1 < n) *w++ = sep;
   }
   return FFX_OK;
+}
+
+// Per-query order on the host: scores descending, exact ties by position (stable), -0.0 counted as
+// +0.0 -- the order FFX_FLAG_SORT produces on the device (ranking.py:115-117), for score arrays that were
+// combined on the host (Ranking.interpolate).  Threads take blocks of queries; out_order[p] is a
+// position inside the whole array, as ffx_plan_fetch hands it out.
+int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queries, int32_t n_threads, int32_t* out_order) {
+  if (!pair_off || n_queries < 0 || pair_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many pairs");
+  if (P > 0 && (!scores || !out_order)) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  auto image = [](float x) -> uint32_t {  // larger score <=> larger image
+    uint32_t b;
+    memcpy(&b, &x, sizeof b);
+    if (b == 0x80000000u) b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  };
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, P / (1 << 16) + 1, std::max<int64_t>(n_queries, 1)}));
+  std::atomic<int64_t> next(0);
+  std::atomic<bool> oom(false);
+  auto work = [&]() {
+    try {
+      std::vector<uint64_t> keys;
+      for (;;) {
+        const int64_t q0 = next.fetch_add(16);
+        if (q0 >= n_queries) return;
+        for (int64_t q = q0; q < std::min(n_queries, q0 + 16); ++q) {
+          const int64_t lo = pair_off[q], n = pair_off[q + 1] - lo;
+          keys.resize((size_t)n);
+          // one 64-bit word per candidate: (inverted image, position) ascending = score descending, ties by position
+          for (int64_t i = 0; i < n; ++i) keys[(size_t)i] = ((uint64_t)(~image(scores[lo + i])) << 32) | (uint32_t)i;
+          std::sort(keys.begin(), keys.end());
+          for (int64_t i = 0; i < n; ++i) out_order[lo + i] = (int32_t)(lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu));
+        }
+      }
+    } catch (const std::bad_alloc&) {
+      oom.store(true);
+    }
+  };
+  try {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  return oom.load() ? ffx_fail(FFX_OOM, "host allocation failed") : FFX_OK;
 }
 
 int ffx_ids_get(const ffx_ids* t, int32_t ordinal, const char** str, int32_t* len) {

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import abc
 import logging
+import weakref
 from collections.abc import Iterable, Iterator, Sequence
 from enum import Enum
 from time import perf_counter
@@ -311,8 +312,11 @@ class Index(abc.ABC):
             dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True)
             order = order.astype(np.intp, copy=False)  # a permutation inside every query: the query numbers stay as they are
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            return Ranking._assemble_coded("fast-forward", q_no, q_order, codes[order], names,
-                                           dense[order].astype(ranking._score_dtype(), copy=False), texts)
+            out = Ranking._assemble_coded("fast-forward", q_no, q_order, codes[order], names,
+                                          dense[order].astype(ranking._score_dtype(), copy=False), texts)
+            # row i of the result is row order[i] of `ranking`: ranking.interpolate(result, alpha) needs no join
+            out._source_rows = (weakref.ref(ranking), order)
+            return out
         df = ranking._df
         if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
             # arrays in, arrays out: only the candidates that get scored are looked up and kept

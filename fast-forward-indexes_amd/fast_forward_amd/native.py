@@ -34,7 +34,7 @@ SYMBOLS = (
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route",
@@ -183,6 +183,7 @@ def lib() -> C.CDLL:
         "ffx_host_free": ([vp], C.c_int),
         "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
         "ffx_host_unpin": ([vp], C.c_int),
+        "ffx_host_order": ([vp, vp, i64, i32, vp], C.c_int),
         "ffx_comm_unique_id": ([C.c_int, vp], C.c_int),
         "ffx_comm_init": ([C.c_int, C.c_int, C.c_int, C.c_int, vp, P(vp)], C.c_int),
         "ffx_comm_destroy": ([vp], C.c_int),
@@ -566,6 +567,15 @@ def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=Non
                          float(alpha), flags, _ptr(ff), _ptr(interp), _ptr(order), C.byref(bad), C.byref(st))
     _check(rc, bad.value)
     return ff, interp, order, st.as_dict()
+
+
+def host_order(scores, pair_off, threads: int = 0) -> np.ndarray:
+    """``ffx_host_order``: per-query order (scores descending, exact ties by position) computed by host
+    threads; positions are indices into ``scores``."""
+    scores, pair_off = _arr(scores, np.float32), _arr(pair_off, np.int64)
+    out = np.empty(scores.shape[0], dtype=np.int32)
+    _check(lib().ffx_host_order(_ptr(scores), _ptr(pair_off), pair_off.shape[0] - 1, int(threads), _ptr(out)))
+    return out
 
 
 def _as_fixed_bytes(strings) -> np.ndarray:

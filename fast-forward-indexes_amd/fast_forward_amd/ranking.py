@@ -452,6 +452,40 @@ class Ranking:
 
     __rmul__ = __mul__
 
+    def _interpolated_with_own_dense_scores(self, other: "Ranking", alpha: float) -> "Ranking | None":
+        """``self.interpolate(index(self), alpha)`` -- the reference's documented pipeline -- without a join:
+        a ranking that came out of ``Index.__call__(self)`` remembers which row of ``self`` each of its rows
+        is (``_source_rows``), so the dense scores are put back in place by one scatter, combined with the same
+        float32 expression as the general path, and every query is re-ordered by host threads
+        (``ffx_host_order``: score descending, exact ties by first-stage position -- the order
+        ``Index.rerank`` returns; the general path breaks exact ties by id, the reference leaves them
+        unspecified).  None when this is not that case."""
+        link = getattr(other, "_source_rows", None)
+        if link is None or link[0]() is not self or len(link[1]) != len(self._q_no):
+            return None
+        perm, pair_off = self._csr()
+        q_order = self._q_order
+        if perm is not None or any(q_order[i] <= q_order[i + 1] for i in range(len(q_order) - 1)):
+            return None  # rows not in the constructor's order: the general path sorts them
+        mine = self._scores()
+        if mine.dtype != np.float32 or other._scores().dtype != np.float32:
+            return None
+        try:
+            from fast_forward_amd import native
+
+            native.lib()
+        except (ImportError, OSError):
+            return None
+        dense = np.empty_like(mine)
+        dense[link[1]] = other._scores()
+        score = alpha * mine + (1 - alpha) * dense  # a Python-float weight on a float32 array multiplies in float32 (ranking.py:319)
+        if score.dtype != np.float32 or np.isnan(score).any():
+            return None
+        order = native.host_order(score, pair_off).astype(np.intp)
+        codes, names = self._id_coding()
+        texts = self._query_texts() if self.has_queries else other._query_texts()
+        return Ranking._assemble_coded(self.name, self._q_no, q_order, codes[order], names, score[order], texts)
+
     def interpolate(self, other: "Ranking", alpha: float, normalize: bool = False) -> "Ranking":
         """``alpha * self + (1 - alpha) * other`` per (query, id) pair (ranking.py:293-326).
 
@@ -459,6 +493,10 @@ class Ranking:
         ``Index.__call__(..., alpha=...)`` / ``Index.rerank`` which fuse this step into the
         scoring kernel's epilogue; this method is the general host path and gives the same bits.
         """
+        if not normalize:
+            direct = self._interpolated_with_own_dense_scores(other, alpha)
+            if direct is not None:
+                return direct
         left = _scaled_to_unit_range(self._df) if normalize else None
         right = _scaled_to_unit_range(other._df) if normalize else None
         # a Python-float weight on a float32 array multiplies in float32 (ranking.py:319)

@@ -357,6 +357,11 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               double alpha, uint32_t flags, float* out_ff, float* out_interp, int32_t* out_order,
               int64_t* bad_pair, ffx_stats* stats);
 
+/* per-query order computed on the HOST (threads over queries): scores descending, exact ties by position,
+ * -0.0 == +0.0 -- the same order FFX_FLAG_SORT gives on the device (ranking.py:115-117), for scores that were
+ * combined on the host (Ranking.interpolate, ranking.py:293-326).  out_order[p]: position in the whole array. */
+int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queries, int32_t n_threads, int32_t* out_order);
+
 /* ---- page-locked host memory ------------------------------------------------------------
  * Host buffers handed to the calls above may live anywhere; when they are page-locked the
  * copies to and from the device run at full link rate and overlap the kernels (ffx_score

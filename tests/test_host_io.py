@@ -234,3 +234,25 @@ def test_host_natives_under_address_and_undefined_behaviour_sanitizers(tmp_path)
                          env={"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1", "PATH": "/usr/bin:/bin"})
     assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-6000:]
     assert "host_io sanitizer run ok" in run.stdout
+
+
+def test_host_order_equals_the_oracle_order():
+    """ffx_host_order (threads over queries, 64-bit words of inverted score image and position): scores
+    descending, exact ties by position, -0.0 == +0.0, infinities -- the order the device's FFX_FLAG_SORT gives."""
+    import ffx_oracle as fo
+
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 3000, size=300)
+    lens[5] = 0
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    s = rng.integers(-5, 6, size=int(off[-1])).astype(np.float32)
+    s[::7] *= np.float32(0.37)
+    zeros = np.flatnonzero(s == 0)
+    s[zeros[::2]] = -0.0
+    s[rng.integers(0, len(s), 5)] = np.inf
+    s[rng.integers(0, len(s), 5)] = -np.inf
+    for threads in (0, 1, 3):
+        assert np.array_equal(native.host_order(s, off, threads).astype(np.int64), fo.order(s, off))
+    assert native.host_order(np.zeros(0, dtype=np.float32), np.array([0, 0, 0])).shape == (0,)
+    with pytest.raises(native.FFXError):
+        native.host_order(s, np.array([0, 5, 3]))

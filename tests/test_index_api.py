@@ -532,6 +532,13 @@ def test_coded_results_equal_frame_results(monkeypatch):
     monkeypatch.undo()
     again = index(coded["rerank"])
     assert again == index(plain["rerank"]) and first.interpolate(coded["call"], 0.3) == plain["rerank"]
+    # first.interpolate(index(first), alpha) -- the reference's own idiom -- needs no join: same rows in the same order as rerank
+    two_calls = first.interpolate(index(first), 0.3)
+    assert two_calls._coded is not None
+    pd.testing.assert_frame_equal(two_calls._df, coded["rerank"]._df)
+    # ... and a dense ranking that is NOT linked to `first` (rebuilt from a frame) goes through the general join: same triples
+    unlinked = Ranking(index(first)._df.copy())
+    assert first.interpolate(unlinked, 0.3) == coded["rerank"]
     bad = frame.copy()
     bad.loc[4321, "id"] = "nowhere"
     bad.loc[5000, "id"] = "nowhere-either"
