@@ -18,9 +18,7 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <atomic>
-#include <mutex>
 #include <new>
-#include <system_error>
 #include <string>
 #include <thread>
 #include <vector>
@@ -221,143 +219,11 @@ struct ffx_plan {
   bool hstage_failed = false;
 };
 
-int ffx_usable_cores(void);  // host_io.cpp
-
 namespace {
-
-// ---- large copies between ORDINARY (pageable) host memory and the device -------------------------
-// The runtime moves such a buffer through its own staging at ~10-14 GB/s on one core.  Here a few host
-// threads each take a contiguous part of the buffer and run their own two-deep pipeline of 2-MiB pieces:
-// memcpy into (out of) a page-locked piece while the neighbouring piece is on the PCIe link, so the link,
-// not one core's memcpy, sets the pace.  Page-locked caller buffers never come here (the plain async copy
-// is already at link rate).  Blocking: on return the bytes are where they belong.
-struct BigCopy {
-  static constexpr size_t kPiece = 2u << 20;
-  static constexpr int kLanes = 8;
-  struct Lane {
-    int device = -1;
-    hipStream_t st = nullptr;
-    void* buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-  };
-  std::mutex mu;  // one large copy at a time per process
-  Lane lanes[kLanes];
-
-  bool prepare(Lane& ln, int device) {
-    if (ln.device == device && ln.st) return true;
-    if (ln.st) {
-      (void)hipSetDevice(ln.device);
-      (void)hipStreamDestroy(ln.st);
-      for (int i = 0; i < 2; ++i) {
-        if (ln.buf[i]) (void)hipHostFree(ln.buf[i]);
-        if (ln.ev[i]) (void)hipEventDestroy(ln.ev[i]);
-        ln.buf[i] = nullptr;
-        ln.ev[i] = nullptr;
-      }
-      ln.st = nullptr;
-    }
-    ln.device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking) != hipSuccess) return false;
-    for (int i = 0; i < 2; ++i)
-      if (hipHostMalloc(&ln.buf[i], kPiece, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ln.ev[i], hipEventDisableTiming) != hipSuccess)
-        return false;
-    return true;
-  }
-};
-
-BigCopy& big_copy_state() {
-  static BigCopy b;
-  return b;
-}
-
-bool is_page_locked(const void* p) {
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) == hipSuccess) return attr.type == hipMemoryTypeHost;
-  (void)hipGetLastError();  // an ordinary pointer is "invalid value" to the runtime: not an error here
-  return false;
-}
-
-// false: not handled (too small, page-locked, or the lanes could not be set up) -- the caller copies as before
-bool big_copy(int device, void* dev, void* host, size_t bytes, bool to_device) {
-  constexpr size_t kMin = 16u << 20;
-  if (bytes < kMin || getenv("FFX_NO_BIG_COPY") || is_page_locked(host)) return false;
-  BigCopy& bc = big_copy_state();
-  std::lock_guard<std::mutex> hold(bc.mu);
-  const int T = (int)std::max<size_t>(1, std::min<size_t>({(size_t)BigCopy::kLanes, (size_t)std::max(1, ffx_usable_cores() / 2), bytes / (8u << 20)}));
-  for (int t = 0; t < T; ++t)
-    if (!bc.prepare(bc.lanes[t], device)) {
-      (void)hipGetLastError();
-      return false;
-    }
-  std::atomic<bool> ok(true);
-  auto work = [&](int t) {
-    BigCopy::Lane& ln = bc.lanes[t];
-    if (hipSetDevice(device) != hipSuccess) {
-      ok.store(false);
-      return;
-    }
-    const size_t lo = (bytes * (size_t)t / (size_t)T) & ~size_t(255), hi = t + 1 == T ? bytes : ((bytes * (size_t)(t + 1) / (size_t)T) & ~size_t(255));
-    char* h = static_cast<char*>(host);
-    char* d = static_cast<char*>(dev);
-    const size_t n_pieces = (hi - lo + BigCopy::kPiece - 1) / BigCopy::kPiece;
-    auto piece = [&](size_t i, size_t& off, size_t& n) {
-      off = lo + i * BigCopy::kPiece;
-      n = std::min(BigCopy::kPiece, hi - off);
-    };
-    bool fine = true;
-    if (to_device) {
-      for (size_t i = 0; i < n_pieces && fine; ++i) {
-        const int s = (int)(i & 1);
-        size_t off, n;
-        piece(i, off, n);
-        if (i >= 2) fine = hipEventSynchronize(ln.ev[s]) == hipSuccess;  // the piece two back has left this buffer
-        memcpy(ln.buf[s], h + off, n);
-        fine = fine && hipMemcpyAsync(d + off, ln.buf[s], n, hipMemcpyHostToDevice, ln.st) == hipSuccess && hipEventRecord(ln.ev[s], ln.st) == hipSuccess;
-      }
-    } else {
-      for (size_t i = 0; i <= n_pieces && fine; ++i) {
-        if (i < n_pieces) {
-          const int s = (int)(i & 1);
-          size_t off, n;
-          piece(i, off, n);
-          fine = hipMemcpyAsync(ln.buf[s], d + off, n, hipMemcpyDeviceToHost, ln.st) == hipSuccess && hipEventRecord(ln.ev[s], ln.st) == hipSuccess;
-        }
-        if (i >= 1 && fine) {  // hand the previous piece to the caller while this one is on the link
-          const int s = (int)((i - 1) & 1);
-          size_t off, n;
-          piece(i - 1, off, n);
-          fine = hipEventSynchronize(ln.ev[s]) == hipSuccess;
-          if (fine) memcpy(h + off, ln.buf[s], n);
-        }
-      }
-    }
-    fine = fine && hipStreamSynchronize(ln.st) == hipSuccess;
-    if (!fine) {
-      (void)hipGetLastError();
-      ok.store(false);
-    }
-  };
-  try {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
-  } catch (const std::system_error&) {
-    return false;
-  }
-  (void)hipSetDevice(device);
-  return ok.load();  // on a failed piece the caller repeats the whole copy the plain way
-}
-
 // host -> device on the plan's stream; small sources go through the page-locked block (the
 // caller's buffer is free again on return either way)
 int plan_h2d(ffx_plan* pl, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return FFX_OK;
-  if (bytes >= (16u << 20) && !getenv("FFX_NO_BIG_COPY") && !is_page_locked(src)) {
-    // the staged copy runs on streams of its own: whatever the plan's stream still does with `dst` comes first
-    FFX_HIP(hipStreamSynchronize(pl->stream));
-    if (big_copy(pl->device, dst, const_cast<void*>(src), bytes, true)) return FFX_OK;
-  }
   if (char* st = bytes <= ffx_plan::kStageBytes / 4 ? pl->stage(bytes) : nullptr) {
     memcpy(st, src, bytes);
     src = st;
@@ -551,9 +417,7 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
                 (long long)(row_offset + n_rows), (long long)idx->capacity);
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(idx->device));
-  const size_t bytes = (size_t)n_rows * idx->dim * idx->elem;
-  if (!big_copy(idx->device, idx->row_ptr(row_offset), const_cast<void*>(host_rows), bytes, true))
-    FFX_HIP(hipMemcpy(idx->row_ptr(row_offset), host_rows, bytes, hipMemcpyHostToDevice));
+  FFX_HIP(hipMemcpy(idx->row_ptr(row_offset), host_rows, (size_t)n_rows * idx->dim * idx->elem, hipMemcpyHostToDevice));
   return check_pq_codes(idx, row_offset, n_rows);
 }
 
@@ -1573,15 +1437,6 @@ int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_
       if (out_ff) memcpy(out_ff, b_ff, each);
       if (out_interp) memcpy(out_interp, b_in, each);
       if (out_order) memcpy(out_order, b_or, each);
-      return FFX_OK;
-    }
-    if (P * sizeof(float) >= (16u << 20) && !is_page_locked(out_ff ? (void*)out_ff : out_interp ? (void*)out_interp : (void*)out_order)) {
-      // large results into ordinary memory: the kernels first, then threaded staged copies (big_copy)
-      FFX_HIP(hipStreamSynchronize(pl->stream));
-      struct { void* host; void* dev; } outs[3] = {{out_ff, pl->ff.p}, {out_interp, pl->interp.p}, {out_order, pl->order.p}};
-      for (auto& o : outs)
-        if (o.host && !big_copy(pl->device, o.dev, o.host, P * sizeof(float), false))
-          FFX_HIP(hipMemcpy(o.host, o.dev, P * sizeof(float), hipMemcpyDeviceToHost));
       return FFX_OK;
     }
     if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff, pl->ff.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));

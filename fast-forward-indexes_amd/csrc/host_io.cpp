@@ -225,8 +225,6 @@ void append_float_repr(std::string& out, float v) {
 
 }  // namespace
 
-int ffx_usable_cores(void) { return usable_cores(); }  // shared with ffx.hip
-
 extern "C" {
 
 int ffx_ids_create(ffx_ids** out) {

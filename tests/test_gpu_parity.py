@@ -178,46 +178,6 @@ def test_unknown_ordinal_is_not_found(cases):
     idx.close()
 
 
-def test_large_pageable_buffers_take_the_threaded_staged_copy(monkeypatch):
-    """Inputs and results of 16 MB and more in ordinary (pageable) memory travel through big_copy (host
-    threads, each with a two-deep pipeline of page-locked 2-MiB pieces): same bytes as the plain copies,
-    for set_pairs / fetch, the one-shot ffx_score and an index upload; page-locked buffers skip it."""
-    n, d, nq, k = 300_000, 64, 1200, 5000  # 6 M pairs: 24 MB per array
-    rng = np.random.default_rng(3)
-    rows = rng.standard_normal((n, d)).astype(np.float32)  # 77 MB upload
-    idx = native.DeviceIndex(n, d)
-    idx.upload(rows, 0)
-    assert np.array_equal(idx.gather(np.array([0, 1, n // 2, n - 1], dtype=np.int32)), rows[[0, 1, n // 2, n - 1]])
-    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
-    idx.set_psg_rows(np.arange(n))
-    queries = rng.standard_normal((nq, d)).astype(np.float32)
-    pair_off = np.arange(nq + 1, dtype=np.int64) * k
-    pair_ids = rng.integers(0, n, size=nq * k).astype(np.int32)
-    sparse = rng.random(nq * k).astype(np.float32)
-    results = {}
-    for label, env in (("staged", None), ("plain", "1")):
-        if env:
-            monkeypatch.setenv("FFX_NO_BIG_COPY", env)
-        else:
-            monkeypatch.delenv("FFX_NO_BIG_COPY", raising=False)
-        plan = native.Plan(idx)
-        plan.set_queries(queries)
-        plan.set_pairs(pair_off, pair_ids, sparse, 1)
-        plan.run(0.3, sort=True)
-        results[label] = plan.fetch(interp=True, order=True) + native.score(idx, queries, pair_off, pair_ids, 1, sparse, 0.3, sort=True)[:3]
-        plan.close()
-    for a, b in zip(results["staged"], results["plain"]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    monkeypatch.delenv("FFX_NO_BIG_COPY", raising=False)
-    pinned = native.pinned_empty(nq * k, np.int32)
-    pinned[...] = pair_ids
-    ff, _, _, _ = native.score(idx, queries, pair_off, pinned, 1)
-    assert np.array_equal(ff.view(np.uint32), results["plain"][0].view(np.uint32))
-    want = fo.row_scores(queries, rows[pair_ids[:2000]], np.zeros(2000, dtype=np.int32), np.arange(2000, dtype=np.int32))
-    assert np.array_equal(bits(results["staged"][0][:2000]), bits(want))
-    idx.close()
-
-
 def test_query_vectors_handed_over_in_device_memory(cases):
     """ffx_plan_set_queries_device: query vectors that already sit in HBM (a GPU-side encoder's output; here:
     the rows of a second index on the same device, via ffx_index_device_ptr) give the same bits as the
