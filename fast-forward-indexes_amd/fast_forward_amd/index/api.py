@@ -309,8 +309,9 @@ class Index(abc.ABC):
             # a large run in the constructor's order: integer codes in, integer codes out -- no Python string
             # per row on the way to the device, none on the way back (the frame is built on first use)
             codes, names = ranking._id_coding()
-            dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True)
-            order = order.astype(np.intp, copy=False)  # a permutation inside every query: the query numbers stay as they are
+            dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True,
+                                                **self._reuse_kw())
+            order = order.astype(np.intp)  # a permutation inside every query: the query numbers stay as they are
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
             out = Ranking._assemble_coded("fast-forward", q_no, q_order, codes[order], names,
                                           dense[order].astype(ranking._score_dtype(), copy=False), texts)
@@ -422,6 +423,11 @@ class Index(abc.ABC):
                 raise IndexError(f"ID {names[codes[int(unknown[0])]]} not found in the index.")
         return ordinals
 
+    def _reuse_kw(self) -> dict:
+        """``reuse_outputs=True`` for backends whose ``_score_pairs`` can hand out its own result buffers (the
+        caller gathers out of them before the next call)."""
+        return {"reuse_outputs": True} if getattr(self, "_result_buffers", None) is not None else {}
+
     def _lookup_optional(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
         """Ordinals of ``ids``, -1 where unknown."""
         return self._ids.lookup_optional(ids, mode.value)
@@ -445,8 +451,9 @@ class Index(abc.ABC):
             codes, names = ranking._id_coding()
             ordinals = self._ordinals_of_codes(ranking, codes, names)
             sparse = np.ascontiguousarray(ranking._scores(), dtype=np.float32)
-            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False)
-            order = order.astype(np.intp, copy=False)
+            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False,
+                                                 **self._reuse_kw())
+            order = order.astype(np.intp)
             if cutoff is not None:
                 rank = np.arange(len(order)) - np.repeat(pair_off[:-1], np.diff(pair_off))
                 keep = rank < cutoff
