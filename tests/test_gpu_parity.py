@@ -178,6 +178,48 @@ def test_unknown_ordinal_is_not_found(cases):
     idx.close()
 
 
+def test_early_stopping_native_edge_cases(cases):
+    """ffx_plan_early_stopping on degenerate inputs: no queries, no candidates, depths all below the cutoff
+    (nothing is scored), a cutoff beyond every list, an unresolved ordinal (-1) that is never reached (fine)
+    and one that is reached in the second interval (NotFound naming its position)."""
+    case = cases["dim20"]
+    idx = device_index(case)
+    plan = native.Plan(idx)
+    d = case.queries.shape[1]
+    # no queries / no candidates
+    plan.set_queries(np.zeros((0, d), dtype=np.float32))
+    plan.set_pairs_lazy(np.array([0]), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), 2)
+    assert plan.early_stopping(3, 0.5, (5, 10)) == (0, 0)
+    plan.set_queries(case.queries[:2])
+    plan.set_pairs_lazy(np.array([0, 0, 0]), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), 2)
+    assert plan.early_stopping(3, 0.5, (5, 10)) == (0, 0)
+    # two queries, 9 and 4 candidates
+    n_docs = len(case.doc_off) - 1
+    ids = (np.arange(13) % n_docs).astype(np.int32)
+    sparse = np.linspace(9, 1, 13).astype(np.float32)
+    off = np.array([0, 9, 13])
+    plan.set_pairs_lazy(off, ids, sparse, 2)
+    assert plan.early_stopping(5, 0.5, (2, 3, 4)) == (0, 0)              # every depth below the cutoff: nothing scored
+    assert np.isnan(plan.fetch()[0]).all()
+    scored, intervals = plan.early_stopping(100, 0.5, (100, 200))          # cutoff beyond every list: one interval takes all
+    assert (scored, intervals) == (13, 1) and not np.isnan(plan.fetch()[0]).any()
+    want, _ = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries[:2], off, ids, 2)
+    assert np.array_equal(bits(plan.fetch()[0]), bits(want))
+    # an unresolved id below the stopping depth is never looked at
+    lazy = ids.copy()
+    lazy[8] = -1
+    plan.set_pairs_lazy(off, lazy, np.concatenate([np.linspace(90, 10, 9), np.linspace(9, 1, 4)]).astype(np.float32), 2)
+    scored, intervals = plan.early_stopping(2, 1.0, (2, 20))  # alpha = 1: the bound is the last sparse score, far below the top-2
+    assert intervals == 1 and scored == 4                      # ranks 0..1 of both queries; nobody continues
+    # ... but reached in the second interval it is the reference's IndexError
+    plan.set_pairs_lazy(off, lazy, np.full(13, 1.0, dtype=np.float32), 2)
+    with pytest.raises(native.NotFound) as e:
+        plan.early_stopping(2, 0.0, (2, 20))                   # alpha = 0: everybody continues (best dense > k-th best unless equal)
+    assert e.value.pair == 8
+    plan.close()
+    idx.close()
+
+
 def test_query_vectors_handed_over_in_device_memory(cases):
     """ffx_plan_set_queries_device: query vectors that already sit in HBM (a GPU-side encoder's output; here:
     the rows of a second index on the same device, via ffx_index_device_ptr) give the same bits as the
