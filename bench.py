@@ -630,6 +630,9 @@ def bench_single(args):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": compute_dtype(args), "data": "synthetic",
+        "value_region": "(i) inputs and outputs resident in HBM, per-query ordering included (the measurement contract: the PCIe-inclusive rate "
+                        "is never `value`); SURVEY 8(d)'s region (ii) host buffers -> host buffers and (iii) through Index.rerank / "
+                        "Index.__call__ + Ranking.interpolate are in `regions`",
         "config": {
             "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} { {'f16': 'fp16', 'pq': 'PQ(M=8,Ks=256)'}.get(args.store, 'fp32') } InMemoryIndex in HBM, "
                         f"{args.queries} queries, k={args.k}, Mode.{args.mode}, alpha={args.alpha}, "
