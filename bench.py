@@ -236,7 +236,8 @@ def launch_ranks(args) -> int:
 
 def gather_stats(comm, st: dict) -> list[dict]:
     """Every rank's per-step figures, in rank order (control plane of the communicator)."""
-    keys = ("ms_gather_dot", "ms_expand", "ms_total", "n_rows", "n_pairs", "own_pairs", "own_queries", "send_bytes", "recv_bytes", "kernel_variant")
+    keys = ("ms_gather_dot", "ms_expand", "ms_total", "n_rows", "n_pairs", "own_pairs", "own_queries", "send_bytes", "recv_bytes", "kernel_variant",
+            "ms_exchange", "ms_merge")
     mine = np.array([float(st[k]) for k in keys], dtype=np.float64)
     return [dict(zip(keys, row.tolist())) for row in comm.allgather_array(mine)]
 
@@ -357,6 +358,10 @@ def bench_sharded(args, rank: int, world: int):
                              "max_over_mean": max(rows_per_rank) / max(1.0, float(np.mean(rows_per_rank)))},
             "exchange_bytes_per_rank": {"sent": [int(t["send_bytes"]) for t in per_rank], "received": [int(t["recv_bytes"]) for t in per_rank]},
             "local_step_ms_per_rank": [t["ms_total"] for t in per_rank],
+            "exchange_ms_per_rank": [t["ms_exchange"] for t in per_rank], "merge_ms_per_rank": [t["ms_merge"] for t in per_rank],
+            "per_rank_note": "HIP events of one step run alone after the timed loop (nothing to overlap with): local = expand + gather_dot on the compute "
+                             "stream; exchange and merge (+ per-query order) on the communicator's stream.  In the timed loop batch i's exchange + merge "
+                             "overlap batch i+1's scoring, so a step costs about max(local, exchange + merge)",
             "owned_pairs_per_rank": [int(t["own_pairs"]) for t in per_rank],
             "route_and_upload_s": t_route,
             "device": dev["name"],
@@ -409,7 +414,7 @@ def bench_replicas(args, comm):
     elapsed = float(comm.allreduce([time.perf_counter() - t0], native.OP_MAX)[0])
     ms_per_step = elapsed * 1e3 / args.steps
     st = plan.stats()
-    st.update(own_pairs=st["n_pairs"], own_queries=q_hi - q_lo, send_bytes=0, recv_bytes=0)
+    st.update(own_pairs=st["n_pairs"], own_queries=q_hi - q_lo, send_bytes=0, recv_bytes=0, ms_exchange=0.0, ms_merge=st["ms_reduce"] + st["ms_sort"])
     per_rank = gather_stats(comm, st)
     failed = False
     if rank == 0:

@@ -708,6 +708,7 @@ struct ffx_sharded {
   ffx_merge* merge = nullptr;
   hipStream_t compute = nullptr;
   hipEvent_t scored[2] = {nullptr, nullptr}, sent[2] = {nullptr, nullptr}, merged = nullptr;
+  hipEvent_t x_begin = nullptr, x_end = nullptr;  // timing of the last step's exchange (merge: x_end .. merged)
   bool sent_valid[2] = {false, false};
   float* send_dev[2] = {nullptr, nullptr};
   void* recv = nullptr;
@@ -808,7 +809,9 @@ int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_boun
     e = hipEventCreateWithFlags(&s->scored[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->sent[i], hipEventDisableTiming);
   }
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->merged, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&s->merged);
+  if (e == hipSuccess) e = hipEventCreate(&s->x_begin);
+  if (e == hipSuccess) e = hipEventCreate(&s->x_end);
   if (e != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
   for (int i = 0; i < 2 && rc == FFX_OK; ++i) {
     rc = ffx_plan_create(shard, &s->plans[i]);
@@ -836,6 +839,8 @@ int ffx_sharded_destroy(ffx_sharded* s) {
     if (s->sent[i]) (void)hipEventDestroy(s->sent[i]);
   }
   if (s->merged) (void)hipEventDestroy(s->merged);
+  if (s->x_begin) (void)hipEventDestroy(s->x_begin);
+  if (s->x_end) (void)hipEventDestroy(s->x_end);
   if (s->recv) (void)hipFree(s->recv);
   if (s->compute) (void)hipStreamDestroy(s->compute);
   delete s;
@@ -875,7 +880,9 @@ int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags) {
   C_TRY(ffx_plan_run(s->plans[i], 0.0, flags & FFX_FLAG_EXACT_SUM));
   C_HIP(hipEventRecord(s->scored[i], s->compute));
   C_HIP(hipStreamWaitEvent(cs, s->scored[i], 0));
+  C_HIP(hipEventRecord(s->x_begin, cs));
   C_TRY(ffx_comm_exchange(s->comm, s->send_dev[i], s->send_counts.data(), static_cast<float*>(s->recv), s->recv_counts.data(), cs));
+  C_HIP(hipEventRecord(s->x_end, cs));
   C_HIP(hipEventRecord(s->sent[i], cs));
   s->sent_valid[i] = true;
   C_TRY(ffx_merge_run(s->merge, static_cast<const float*>(s->recv), alpha, flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), cs));
@@ -922,6 +929,8 @@ int ffx_sharded_stats(ffx_sharded* s, ffx_shard_stats* out) {
     out->recv_bytes += s->recv_counts[r] * 4;
   }
   out->transport = s->comm->transport;
+  C_HIP(hipEventElapsedTime(&out->ms_exchange, s->x_begin, s->x_end));
+  C_HIP(hipEventElapsedTime(&out->ms_merge, s->x_end, s->merged));
   return FFX_OK;
 }
 

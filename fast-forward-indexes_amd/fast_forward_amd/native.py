@@ -62,6 +62,7 @@ class ShardStats(C.Structure):
     _fields_ = [
         ("local", Stats), ("own_queries", C.c_int64), ("own_pairs", C.c_int64), ("send_bytes", C.c_int64), ("recv_bytes", C.c_int64),
         ("rank", C.c_int32), ("world", C.c_int32), ("transport", C.c_int32), ("reserved", C.c_int32),
+        ("ms_exchange", C.c_float), ("ms_merge", C.c_float),
     ]
 
     def as_dict(self) -> dict:

@@ -264,6 +264,8 @@ typedef struct ffx_shard_stats {
   int64_t send_bytes;   /* scores sent to / received from OTHER ranks per step */
   int64_t recv_bytes;
   int32_t rank, world, transport, reserved;
+  float ms_exchange;    /* last step, HIP events on the communicator's stream: the all-to-all of scores */
+  float ms_merge;       /* ... and the owner-side scatter + interpolation + per-query order            */
 } ffx_shard_stats;
 /* shard: this rank's rows (document ordinals relative to the shard); doc_bounds[world+1]: first
  * global document ordinal of every shard (NULL: pairs come with explicit holders, below) */
