@@ -220,6 +220,34 @@ def early_stopping_case():
     return {"configs": len(configs)}
 
 
+def early_stopping_docs_case():
+    """index/base.py:316-387 on DOCUMENT runs (MaxP and AveP over 1..6 passages per document): the
+    interval's candidates gather several rows each, the criterion works on the aggregated scores."""
+    dim, seed, scale, n_docs, n_q = 48, 78, 0.3, 220, 5
+    rng = np.random.default_rng(seed)
+    per_doc = rng.integers(1, 7, size=n_docs)
+    n_rows = int(per_doc.sum())
+    doc_of_row = np.repeat(np.arange(n_docs), per_doc).astype(np.int32)
+    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    qvecs = synth.rows(seed + 1000, scale, 0, n_q, dim)
+    q_names = [f"q{i}" for i in range(n_q)]
+    lens = [220, 180, 75, 12, 220]
+    cands = [rng.choice(n_docs, size=n, replace=False).astype(np.int32) for n in lens]
+    sparse = [np.sort(rng.random(n).astype(np.float32) * 6)[::-1].copy() for n in lens]
+    first = run_frame(q_names, [[f"D{c}" for c in row] for row in cands], sparse)
+    out = {"seed": seed, "dim": dim, "scale": np.float32(scale), "n_rows": n_rows, "doc_of_row": doc_of_row, "q_names": np.array(q_names),
+           "lens": np.array(lens), "cands": np.concatenate(cands), "sparse": np.concatenate(sparse)}
+    configs = [("MAXP", 10, 0.2, (20, 50, 100, 220)), ("MAXP", 5, 0.6, (5, 30, 300)), ("AVEP", 8, 0.1, (10, 40, 220)), ("FIRSTP", 3, 0.5, (3, 6, 12, 220))]
+    out["configs"] = json.dumps(configs)
+    for ci, (mname, cutoff, alpha, depths) in enumerate(configs):
+        idx = make_index(vectors, [f"D{d}" for d in doc_of_row], None, qvecs, MODES[mname])
+        res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+        for key, val in frame_arrays(res).items():
+            out[f"es{ci}_{key}"] = val
+    np.savez_compressed(OUT / "early_stopping_docs.npz", **out)
+    return {"configs": len(configs), "rows": n_rows}
+
+
 def known_answers():
     """The reference tests' own known answers, re-derived by running the reference
     (tests/test_index.py:19-43,135-200; tests/test_ranking.py:157-188)."""
@@ -445,6 +473,8 @@ def main():
             manifest["cases"]["coalesce"] = coalesce_case()
         if sys.argv[2] == "f64":
             manifest["cases"].update(f64_cases())
+        if sys.argv[2] == "es_docs":
+            manifest["cases"]["early_stopping_docs"] = early_stopping_docs_case()
         if sys.argv[2] == "sub200k":
             manifest["cases"]["sub200k"] = sub200k_case()
         if sys.argv[2] == "pq":
@@ -471,6 +501,7 @@ def main():
     manifest["cases"]["partial_ids"] = partial_ids_case()
     manifest["cases"]["interpolate"] = interpolate_case()
     manifest["cases"]["early_stopping"] = early_stopping_case()
+    manifest["cases"]["early_stopping_docs"] = early_stopping_docs_case()
     manifest["cases"]["coalesce"] = coalesce_case()
     manifest["cases"].update(f64_cases())
     manifest["cases"]["sub200k"] = sub200k_case()

@@ -200,6 +200,39 @@ def test_early_stopping_matches_reference_frames():
         assert np.array_equal(bits(np.array([have[k] for k in ks])), bits(np.array([want[k] for k in ks]))), ci
 
 
+@pytest.mark.parametrize("criterion", ["device", "host"])
+def test_early_stopping_on_document_runs_matches_reference_frames(criterion, monkeypatch):
+    """Frames the reference produced with early stopping on DOCUMENT runs (MaxP / AveP / FirstP over 1..6
+    passages per document; oracle/gen_golden.py::early_stopping_docs_case): same scored set, same bits --
+    through the device-resident criterion (ffx_plan_early_stopping) and through its NumPy statement."""
+    from fast_forward_amd.index.api import Index
+
+    z = np.load(GOLDEN / "early_stopping_docs.npz")
+    dim, seed, scale, n_rows = int(z["dim"]), int(z["seed"]), float(z["scale"]), int(z["n_rows"])
+    q_names = z["q_names"].tolist()
+    qvecs = synth.rows(seed + 1000, scale, 0, len(q_names), dim)
+    vectors = synth.rows(seed, scale, 0, n_rows, dim)
+    rows, pos = [], 0
+    for qi, n in enumerate(z["lens"].tolist()):
+        for c, s in zip(z["cands"][pos:pos + n], z["sparse"][pos:pos + n]):
+            rows.append((q_names[qi], f"D{c}", s))
+        pos += n
+    first = Ranking(pd.DataFrame(rows, columns=["q_id", "id", "score"]), queries={q: str(i) for i, q in enumerate(q_names)})
+    if criterion == "host":
+        monkeypatch.setattr(InMemoryIndex, "_early_stopping_scores", Index._early_stopping_scores)
+        monkeypatch.setattr(InMemoryIndex, "_early_stopping_takes_ordinals", False)
+    for ci, (mname, cutoff, alpha, depths) in enumerate(json.loads(str(z["configs"]))):
+        idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mname]))
+        idx.add(vectors, doc_ids=[f"D{d}" for d in z["doc_of_row"]])
+        got = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)._df
+        want = {(q, i): s for q, i, s in zip(z[f"es{ci}_q_id"].tolist(), z[f"es{ci}_id"].tolist(), z[f"es{ci}_score"])}
+        have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
+        assert have.keys() == want.keys(), f"config {ci} ({mname}): scored sets differ"
+        ks = sorted(want)
+        assert np.array_equal(bits(np.array([have[k] for k in ks])), bits(np.array([want[k] for k in ks]))), (ci, mname)
+        idx.close()
+
+
 @pytest.mark.parametrize("mode", ["MAXP", "PASSAGE", "AVEP"])
 def test_device_resident_early_stopping_equals_the_host_criterion(mode):
     """ffx_plan_early_stopping (per-query state in HBM between depth intervals, radix-select of the
