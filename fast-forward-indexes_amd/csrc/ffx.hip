@@ -1007,10 +1007,21 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     else                                                                                                                      \
       ffx::gather_dot_exact_anyd_kernel<T, LG, U, false><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R, d, LS, nl, CS); \
   } while (0)
-          if (nl == 1) FFX_ANYD(1, 4);
-          else if (nl == 2) FFX_ANYD(2, 4);
-          else if (nl <= 4) FFX_ANYD(4, 4);
-          else FFX_ANYD(8, 4);
+          const char* u_env = getenv("FFX_ANYD_U");  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
+          // measured (profiles/r02/anyd_kernel_dims.json): 2 passes in flight win for 3 .. 7 leaves (d = 300: 5.09 vs
+          // 4.59 TB/s, d = 520: 5.61 vs 5.20), 4 for one or two leaves and for long rows (d = 1000: 5.85 vs 5.65)
+          const int u_sel = u_env ? atoi(u_env) : ((nl >= 3 && d < 768) ? 2 : 4);
+#define FFX_ANYD_LG(LG)                    \
+  do {                                     \
+    if (u_sel == 2) FFX_ANYD(LG, 2);       \
+    else if (u_sel == 8) FFX_ANYD(LG, 8);  \
+    else FFX_ANYD(LG, 4);                  \
+  } while (0)
+          if (nl == 1) FFX_ANYD_LG(1);
+          else if (nl == 2) FFX_ANYD_LG(2);
+          else if (nl <= 4) FFX_ANYD_LG(4);
+          else FFX_ANYD_LG(8);
+#undef FFX_ANYD_LG
 #undef FFX_ANYD
           pl->variant = 130 + nl + HALF;
           break;

@@ -27,11 +27,13 @@ for d in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "32,100,200,300
     plan.set_queries(synth.rows(2, 0.05, 0, nq, d))
     plan.set_pairs(np.arange(nq + 1, dtype=np.int64) * k, ids, sparse, 1)
     res = {}
-    for label, env in (("anyd", None), ("staged", "1")):
-        if env:
+    for label, env in (("anyd", None), ("anyd_u2", "u2"), ("anyd_u8", "u8"), ("staged", "1")):
+        os.environ.pop("FFX_ANYD_U", None)
+        os.environ.pop("FFX_GENERIC_STAGED", None)
+        if env == "1":
             os.environ["FFX_GENERIC_STAGED"] = env
-        else:
-            os.environ.pop("FFX_GENERIC_STAGED", None)
+        elif env:
+            os.environ["FFX_ANYD_U"] = env[1:]
         ms = []
         for _ in range(6):
             plan.run(0.1, exact_sum=True)
