@@ -61,6 +61,22 @@ for resident in (True, False):
     sharded.close()
 mem.close()
 
+# ---- 1b. a quantized HDF5 file (NanoPQ codes + codewords stored by the reference's layout): shards hold codes ------
+rng2 = np.random.default_rng(5)
+qv2 = rng2.standard_normal((2, 24)).astype(np.float32)
+enc2 = LambdaEncoder(lambda t: qv2[int(t)])
+single = OnDiskIndex.load(H5 / "quantized.h5", enc2)
+n_q = len(single)
+pq_run = Ranking.from_run({"a": {f"q{i}": float(i) for i in range(n_q)}, "b": {"q5": 2.0, "q1": 0.5, "q7": 0.1}}, queries={"a": "0", "b": "1"})
+want_pq, want_pq_i = single(pq_run), single.rerank(pq_run, 0.4)
+for resident in (True, False):
+    sharded = ShardedOnDiskIndex(H5 / "quantized.h5", comm, enc2, resident=resident)
+    if resident:
+        assert sharded._store.dtype == np.uint8 and sharded._store.codebook_shape is not None  # codes + codebook in HBM
+    assert sharded(pq_run, gather=True) == want_pq and sharded.rerank(pq_run, 0.4, gather=True) == want_pq_i, resident
+    checked += len(pq_run._df)
+    sharded.close()
+
 # ---- 2. this build's container; documents re-opened by later add() calls (rows not contiguous), rows
 #         with only a passage id, fp16 storage -------------------------------------------------------------
 case = load_scoring_case("d768_f16")
