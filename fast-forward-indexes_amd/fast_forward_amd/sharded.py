@@ -256,10 +256,28 @@ class _ShardedIndex:
     def dim(self):
         return self.local.dim
 
-    def _holders(self, ids: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        """(holder rank, ordinal on that rank) of every candidate id; ``IndexError`` on EVERY rank for
-        an id no rank holds (the reference's util.py:38-39)."""
+    def _holders_by_code(self, names: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """For the DISTINCT candidate ids of a ranking: (holder rank, ordinal on this rank where this rank is
+        the holder, "no rank holds it" mask).  Collective (every rank calls it with the same ids)."""
         raise NotImplementedError
+
+    def _holders(self, ranking, perm) -> tuple[np.ndarray, np.ndarray]:
+        """(holder rank, ordinal on that rank) of every candidate, rows grouped by query.  The distinct ids are
+        looked up once per (ranking, index, mode) and remembered with the ranking; ``IndexError`` on EVERY rank
+        for an id no rank holds (the reference's util.py:38-39), naming the first one in row order."""
+        codes, names = ranking._id_coding()
+        key = (id(self), self.local.mode, getattr(self, "_n_global", None), getattr(self.local._ids, "version", None))
+        cached = getattr(ranking, "_holder_cache", None)
+        if cached is None or cached[0] != key or cached[1] is not names or cached[2] is not codes:
+            holder_c, local_c, missing_c = self._holders_by_code(names)
+            if missing_c.any():
+                bad = np.flatnonzero(missing_c[codes])
+                if bad.size:
+                    raise IndexError(f"ID {names[codes[int(bad[0])]]} not found in the index.")
+            cached = (key, names, codes, holder_c.astype(np.int32)[codes], local_c.astype(np.int32)[codes])
+            ranking._holder_cache = cached
+        holder, local_ids = cached[3], cached[4]
+        return (holder, local_ids) if perm is None else (holder[perm], local_ids[perm])
 
     def _sharded(self) -> ShardedScorer:
         raise NotImplementedError
@@ -269,23 +287,27 @@ class _ShardedIndex:
         streamed from its file instead of resident), or None when the resident scorer does it."""
         return None
 
-    def _score(self, ranking, alpha: float | None, sort: bool):
+    def _rank(self, ranking, alpha: float | None, name, gather: bool):
+        """Score, exchange, finish the owned queries; the ``Ranking`` of this rank's queries (or of all)."""
         from fast_forward_amd import native
-        from fast_forward_amd.index.api import _grouped_by_query
+        from fast_forward_amd.index.api import _in_final_order
+        from fast_forward_amd.ranking import Ranking
 
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
-        df = ranking._df
-        q_no, q_ids, texts = self.local._numbered_queries(ranking)
+        q_no, q_order, texts = self.local._numbered_queries(ranking)
         n_q = len(texts)
         query_vectors = np.ascontiguousarray(self.local.encode_queries(texts), dtype=np.float32)
-        perm, pair_off = _grouped_by_query(q_no, n_q)
-        ids = df["id"].to_numpy()
-        sparse = df["score"].to_numpy(dtype=np.float32)
+        perm, pair_off = ranking._csr()
+        sparse = np.asarray(ranking._scores(), dtype=np.float32)
         if perm is not None:
-            ids, sparse = ids[perm], sparse[perm]
-        holder, local_ids = self._holders(ids)
+            sparse = sparse[perm]
+        holder, local_ids = self._holders(ranking, perm)
         mode = self.local.mode.value
+        # rows of a query adjacent and the queries in the constructor's order: the device's per-query order is the
+        # whole sort and the result can stay in integer codes; otherwise the frame route below re-sorts on the host
+        coded = perm is None and _in_final_order(q_order)
+        sort = coded or alpha is not None
         streamed = self._local_scores(query_vectors, pair_off, holder, local_ids, mode)
         if streamed is None:
             scorer = self._sharded()
@@ -293,50 +315,64 @@ class _ShardedIndex:
             scorer.set_pairs(pair_off, local_ids, sparse if alpha is not None else None, mode, holder=holder)
             scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
             ff, interp, order = scorer.fetch(order=sort)
+            q_lo, q_hi = scorer.q_lo, scorer.q_hi
             lo, hi = scorer.own_first_pair, scorer.own_first_pair + scorer.own_pairs
         else:
             # the same exchange on host buffers, then the owner-side epilogue (ffx_aggregate, 1-row segments)
             r = native.route(pair_off, local_ids, self.comm.rank, self.comm.world, holder=holder)
             recv = self.comm.exchange_host(streamed, r["send_counts"], r["recv_counts"])
             dense = recv[r["recv_slot"]]
+            q_lo, q_hi = r["q_lo"], r["q_hi"]
             lo, hi = r["own_first_pair"], r["own_first_pair"] + r["own_pairs"]
-            own_off = pair_off[r["q_lo"]:r["q_hi"] + 1] - lo
+            own_off = pair_off[q_lo:q_hi + 1] - lo
             if hi > lo:
                 ff, interp, order = native.aggregate(dense, np.arange(hi - lo + 1, dtype=np.int64), 1, sparse[lo:hi] if alpha is not None else None,
                                                      0.0 if alpha is None else alpha, own_off, sort=sort, device=self.comm.device)
             else:
                 ff, interp, order = dense, (dense if alpha is not None else None), np.zeros(0, dtype=np.int32)
         score = interp if alpha is not None else ff
+        dtype = ranking._score_dtype()
+        if coded:
+            codes, names = ranking._id_coding()
+            order = order.astype(np.intp)  # positions inside the owned block, every query ordered
+            own_codes, own_score = codes[lo:hi][order], score[order].astype(dtype, copy=False)
+            if not gather:
+                return Ranking._assemble_coded(name, np.asarray(q_no[lo:hi]) - q_lo, q_order[q_lo:q_hi], own_codes, names, own_score, texts[q_lo:q_hi])
+            # every rank's block, in rank order = query order (queries are owned in contiguous blocks)
+            sizes = self.comm.allgather_array(np.array([hi - lo], dtype=np.int64))[:, 0]
+            room = int(sizes.max())
+            pad_c, pad_s = np.zeros(room, dtype=np.int32), np.zeros(room, dtype=np.float32)
+            pad_c[:hi - lo], pad_s[:hi - lo] = own_codes, own_score.astype(np.float32, copy=False)
+            all_c, all_s = self.comm.allgather_array(pad_c), self.comm.allgather_array(pad_s)
+            full_c = np.concatenate([all_c[r, :int(sizes[r])] for r in range(self.comm.world)])
+            full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(self.comm.world)]).astype(dtype, copy=False)
+            return Ranking._assemble_coded(name, q_no, q_order, full_c, names, full_s, texts)
+        df = ranking._df
         rows = np.arange(lo, hi) if perm is None else perm[lo:hi]
         if sort:
             rows, score = rows[order], score[order]
-        out = df.iloc[rows].reset_index(drop=True)
-        out["score"] = score.astype(df.dtypes["score"])
-        return out
-
-    def _finish(self, frame, ranking, name, gather: bool):
-        import pickle
-
-        import pandas as pd
-
-        from fast_forward_amd.ranking import Ranking
-
+        frame = df.iloc[rows].reset_index(drop=True)
+        frame["score"] = score.astype(df.dtypes["score"])
         if gather:  # every rank's frame, through the control plane (sizes first, then padded payloads)
+            import pickle
+
+            import pandas as pd
+
             blob = pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL)
             sizes = self.comm.allgather_array(np.array([len(blob)], dtype=np.int64))[:, 0]
             padded = np.zeros(int(sizes.max()), dtype=np.uint8)
             padded[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
             blobs = self.comm.allgather_array(padded)
             frame = pd.concat([pickle.loads(blobs[r, :int(sizes[r])].tobytes()) for r in range(self.comm.world)], ignore_index=True)
-        return Ranking(Ranking._trusted(frame), name=name, dtype=ranking._df.dtypes["score"], copy=False, is_sorted=False)
+        return Ranking(Ranking._trusted(frame), name=name, dtype=dtype, copy=False, is_sorted=False)
 
     def __call__(self, ranking, gather: bool = False):
         """Dense scores (``Index.__call__``) of the queries this rank owns, or of all with ``gather``."""
-        return self._finish(self._score(ranking, None, sort=False), ranking, "fast-forward", gather)
+        return self._rank(ranking, None, "fast-forward", gather)
 
     def rerank(self, ranking, alpha: float, gather: bool = False):
         """``ranking.interpolate(index(ranking), alpha)`` with the epilogue on the owners' devices."""
-        return self._finish(self._score(ranking, alpha, sort=True), ranking, ranking.name, gather)
+        return self._rank(ranking, alpha, ranking.name, gather)
 
 
 class ShardedInMemoryIndex(_ShardedIndex):
@@ -398,20 +434,14 @@ class ShardedInMemoryIndex(_ShardedIndex):
             self._scorer, self._scorer_store = ShardedScorer(store, None, self.comm), store
         return self._scorer
 
-    def _holders(self, ids: np.ndarray):
-        # which candidates do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
-        table = self.local._ids
-        uniq, inv = np.unique(ids, return_inverse=True)
-        ord_u = table.lookup_optional(uniq, self.local.mode.value)
-        # one small control message: the bit mask of the unique ids every rank holds
+    def _holders_by_code(self, names: np.ndarray):
+        # which ids do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
+        ord_u = self.local._ids.lookup_optional(names, self.local.mode.value)
+        # one small control message: the bit mask of the distinct ids every rank holds
         held = self.comm.allgather_array(np.packbits(ord_u >= 0))
-        held = np.unpackbits(held, axis=1, count=len(uniq)).astype(bool) if len(uniq) else np.zeros((self.world, 0), dtype=bool)
-        if len(uniq) and not held.any(axis=0).all():
-            missing = np.flatnonzero(~held.any(axis=0))
-            first = int(np.flatnonzero(np.isin(inv, missing))[0])  # the first one in candidate order, on every rank
-            raise IndexError(f"ID {ids[first]} not found in the index.")
-        holder_u = held.argmax(axis=0).astype(np.int32) if len(uniq) else np.zeros(0, dtype=np.int32)
-        return holder_u[inv], np.maximum(ord_u, 0)[inv].astype(np.int32)
+        held = np.unpackbits(held, axis=1, count=len(names)).astype(bool) if len(names) else np.zeros((self.world, 0), dtype=bool)
+        holder = held.argmax(axis=0).astype(np.int32) if len(names) else np.zeros(0, dtype=np.int32)
+        return holder, np.maximum(ord_u, 0), ~held.any(axis=0)
 
     def close(self) -> None:
         if self._scorer is not None:
@@ -515,18 +545,23 @@ class ShardedOnDiskIndex(_ShardedIndex):
     def _sharded(self) -> ShardedScorer:
         return self._scorer
 
-    def _holders(self, ids: np.ndarray):
-        # every rank has the whole id table: an unknown id raises the same IndexError everywhere
-        ordinals = self.local._resolve_ids(ids, self.local.mode).astype(np.int64)
+    def _holders_by_code(self, names: np.ndarray):
+        # every rank has the whole id table: an unknown id is unknown everywhere
+        ordinals = self.local._ids.lookup_optional(names, self.local.mode.value)
+        known = np.maximum(ordinals, 0)
         if self.local.mode.value == 1:
-            return self._psg_holder[ordinals].astype(np.int32), self._psg_local[ordinals]
-        holder = (np.searchsorted(self.doc_bounds, ordinals, side="right") - 1).astype(np.int32)
-        return holder, (ordinals - self.doc_bounds[holder]).astype(np.int32)
+            n_psg = self._psg_holder.shape[0]
+            safe = np.minimum(known, max(n_psg - 1, 0))
+            holder = self._psg_holder[safe] if n_psg else np.zeros(len(names), dtype=np.int32)
+            local = self._psg_local[safe] if n_psg else np.zeros(len(names), dtype=np.int32)
+            return holder, local, ordinals < 0
+        holder = np.clip(np.searchsorted(self.doc_bounds, known, side="right") - 1, 0, self.world - 1).astype(np.int32)
+        return holder, (known - self.doc_bounds[holder]).astype(np.int32), ordinals < 0
 
-    def _score(self, ranking, alpha, sort):
+    def _rank(self, ranking, alpha, name, gather):
         if self.resident and getattr(self, "_rotation", None) is not None:
             raise NotImplementedError("OPQ-rotated queries on a sharded on-disk index: use to_memory() on one GPU")
-        return super()._score(ranking, alpha, sort)
+        return super()._rank(ranking, alpha, name, gather)
 
     def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode):
         if self.resident:

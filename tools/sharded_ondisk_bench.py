@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 scaled to one box: ONE index file opened by N ranks (`python tools/sharded_ondisk_bench.py
+--ranks 2`; the ranks share the GPU, scores travel over the shared-memory transport).  Every rank takes its
+document range, moves it from the chunk maps to HBM (ffx_index_upload_rows) and the sharded path scores a
+run; also with the shards left in the file and streamed per call.  Reports per-rank load rate and the
+re-ranking time, and checks the result against a 1-process OnDiskIndex.to_memory() run."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+import uuid
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ranks", type=int, default=2)
+ap.add_argument("--rows", type=int, default=2_000_000)
+ap.add_argument("--dim", type=int, default=768)
+ap.add_argument("--queries", type=int, default=400)
+ap.add_argument("--k", type=int, default=5000)
+ap.add_argument("--file", default=None)
+args = ap.parse_args()
+
+
+def make_run(rng, n_rows, nq, k):
+    import pandas as pd
+
+    from fast_forward_amd import Ranking
+
+    ids = np.concatenate([rng.choice(n_rows, size=k, replace=False) for _ in range(nq)])
+    q = np.repeat([f"q{i:04d}" for i in range(nq)], k)
+    frame = pd.DataFrame({"q_id": q, "id": np.char.add("D", ids.astype("U")), "score": (rng.random(nq * k) * 25).astype(np.float32), "query": q})
+    return Ranking(frame, copy=False)
+
+
+if "RANK" not in os.environ:  # parent: build the file, start the ranks (no GPU call in this process)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(args.file or Path(tmp) / "index.ffx")
+        env = dict(os.environ, FFX_RDZV_KEY=f"sod_{uuid.uuid4().hex[:10]}", WORLD_SIZE=str(args.ranks))
+        procs = [subprocess.Popen([sys.executable, __file__, *sys.argv[1:], "--file", str(path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+                 for r in range(args.ranks)]
+        sys.exit(max(p.wait() for p in procs))
+
+from fast_forward_amd.encoder import ArrayEncoder  # noqa: E402
+from fast_forward_amd.index import Mode, OnDiskIndex  # noqa: E402
+from fast_forward_amd.sharded import ShardedOnDiskIndex, connect  # noqa: E402
+
+comm = connect("host")
+rank, world = comm.rank, comm.world
+rng = np.random.default_rng(0)
+out = {"ranks": world, "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k}
+if rank == 0:
+    t0 = time.perf_counter()
+    w = OnDiskIndex(Path(args.file), mode=Mode.MAXP, chunk_size=2**16, max_id_length=12, overwrite=True)
+    step = 2**17
+    for lo in range(0, args.rows, step):
+        hi = min(args.rows, lo + step)
+        w.add(rng.standard_normal((hi - lo, args.dim), dtype=np.float32) * np.float32(0.036), doc_ids=[f"D{i}" for i in range(lo, hi)])
+    out["build_file_s"], out["file_gb"] = time.perf_counter() - t0, Path(args.file).stat().st_size / 1e9
+    del w
+comm.barrier()
+qv = np.random.default_rng(1).standard_normal((args.queries, args.dim), dtype=np.float32) * np.float32(0.036)
+enc = ArrayEncoder({f"q{i:04d}": qv[i] for i in range(args.queries)})
+first = make_run(np.random.default_rng(2), args.rows, args.queries, args.k)
+t0 = time.perf_counter()
+sharded = ShardedOnDiskIndex(args.file, comm, enc, resident=True)
+t_load = time.perf_counter() - t0
+shard_gb = int(sharded.rows_per_rank[rank]) * args.dim * 4 / 1e9
+loads = comm.allgather_array(np.array([t_load, shard_gb]))
+sharded.rerank(first, 0.1)  # warm-up: plans, resolved candidates
+comm.barrier()
+t0 = time.perf_counter()
+own = sharded.rerank(first, 0.1)
+comm.barrier()
+t_resident = time.perf_counter() - t0
+sharded.close()
+streamed = ShardedOnDiskIndex(args.file, comm, enc, resident=False, window_bytes=512 << 20)
+streamed.rerank(first, 0.1)
+comm.barrier()
+t0 = time.perf_counter()
+own_s = streamed.rerank(first, 0.1)
+comm.barrier()
+t_streamed = time.perf_counter() - t0
+same = bool(own == own_s)
+stats = streamed.local.last_stats or {}
+streamed.close()
+agree = comm.allreduce([1.0 if same else 0.0], 2)[0] == 1.0  # OP_MIN
+if rank == 0:
+    out["open_and_load_shard_s_per_rank (ids of the whole file + this rank's rows to HBM)"] = loads[:, 0].tolist()
+    out["shard_gb_per_rank"] = loads[:, 1].tolist()
+    out["resident_rerank_s"] = t_resident
+    out["resident_queries_per_s"] = args.queries / t_resident
+    out["streamed_rerank_s"] = t_streamed
+    out["streamed_queries_per_s"] = args.queries / t_streamed
+    out["rank0_streamed_gb"] = stats.get("bytes_streamed", 0) / 1e9
+    out["streamed_equals_resident_on_every_rank"] = bool(agree)
+    single = OnDiskIndex.load(args.file, enc).to_memory()
+    want = single.rerank(first, 0.1)
+    out["rank0_owned_queries_equal_the_single_process_result"] = all(own[q] == want[q] for q in own.q_ids)
+    print(json.dumps(out, indent=1))
+comm.close()
