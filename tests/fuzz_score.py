@@ -2,7 +2,8 @@
 """Randomised end-to-end check of the C ABI against the oracle: ragged batches, every mode, several
 row lengths and stores, random slice sizes of ffx_score, sort on and off.  Not collected by pytest
 (it is a soak: `python tests/fuzz_score.py --rounds 300` on the GPU box, under a minute); prints the
-seed of any failure.  Last runs of round 1: 300 + 1000 configurations (seeds 0 and 1), all bit-exact."""
+seed of any failure.  Last runs of round 1: 300 + 1000 configurations (seeds 0 and 1), all bit-exact;
+round 2 (any-d kernel, in-LDS sort): 600 + 600 configurations (seeds 2 and 3), all bit-exact."""
 import argparse
 import os
 import sys
@@ -21,7 +22,8 @@ ap.add_argument("--rounds", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
 args = ap.parse_args()
 bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)  # noqa: E731
-DIMS = [8, 24, 64, 100, 128, 256, 300, 384, 512, 768, 1024, 1536, 2048]
+DIMS = [8, 24, 64, 100, 128, 256, 300, 384, 512, 768, 1024, 1536, 2048,
+        9, 17, 130, 200, 260, 500, 520, 700, 900, 1000, 1016, 1023, 1100, 5]  # second line (round 2): the any-d kernel's lengths, and its fall-backs
 for rnd in range(args.rounds):
     seed = args.seed * 100_000 + rnd
     rng = np.random.default_rng(seed)
@@ -38,7 +40,7 @@ for rnd in range(args.rounds):
     queries = synth.rows(seed + 1, 0.2, 0, n_q, d)
     mode = int(rng.integers(1, 5))
     pool = n if mode == 1 else n_docs
-    lens = [int(rng.integers(0, min(pool, 300) + 1)) for _ in range(n_q)]
+    lens = [int(rng.integers(0, min(pool, 300 if rng.random() < 0.8 else 3000) + 1)) for _ in range(n_q)]
     pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     pair_ids = np.concatenate([rng.choice(pool, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
     sparse = (rng.integers(0, 5, size=len(pair_ids)) if rng.random() < 0.5 else rng.random(len(pair_ids)) * 10).astype(np.float32)
