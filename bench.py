@@ -255,8 +255,24 @@ def bench_sharded(args, rank: int, world: int):
         if not (masked and visible >= 1):
             sys.exit(f"--gpus {world} over RCCL needs {world} GPUs, {visible} visible (use --transport host to rehearse on fewer)")
         device = int(os.environ.get("LOCAL_RANK", str(rank))) % visible  # a launcher gave every rank its own device mask
+    # RCCL prints a version banner to STDOUT when the first communicator comes up; stdout of this program is the
+    # one JSON line, so anything the libraries print while connecting goes to stderr
+    sys.stdout.flush()
+    keep_stdout = os.dup(1)
+    os.dup2(2, 1)
     try:
-        comm = connect(args.transport, rank=rank, world=world, device=device)
+        comm = _connect_with_fallback(args, rank, world, device, connect)
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep_stdout, 1)
+        os.close(keep_stdout)
+    local_rank = comm.device
+    return _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, query_partition, ShardedScorer)
+
+
+def _connect_with_fallback(args, rank: int, world: int, device, connect):
+    try:
+        return connect(args.transport, rank=rank, world=world, device=device)
     except (native.FFXError, TimeoutError) as e:
         if args.transport != "rccl" or (isinstance(e, native.FFXError) and e.code != native.RCCL_ERROR):
             raise
@@ -265,8 +281,10 @@ def bench_sharded(args, rank: int, world: int):
         # the shared-memory transport so that the scaling run still measures something; the line says so
         print(f"rank {rank}: RCCL unavailable ({e}); falling back to the shared-memory transport", file=sys.stderr, flush=True)
         args.transport = f"host (rccl unavailable: {str(e)[:120]})"
-        comm = connect("host", rank=rank, world=world, device=device)
-    local_rank = comm.device
+        return connect("host", rank=rank, world=world, device=device)
+
+
+def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, query_partition, ShardedScorer):
     if args.sharding == "queries":
         return bench_replicas(args, comm)
     scale = float(1.0 / np.sqrt(args.dim))
