@@ -1070,6 +1070,55 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
 }
 
 // product-quantized rows: decode-then-dot (exact, variants 21xx) or ADC (fast, 2300)
+// subspaces == leaves of NumPy's tree (every leaf has length Ds, M in {1,2,4,8,16}): exact ADC applies
+// (FFX_PQ_NO_ADC forces decode-then-dot: tests and A/B)
+static bool pq_exact_adc_applies(const ffx_plan* pl) {
+  const ffx_index* ix = pl->idx;
+  if (ix->dtype != FFX_DTYPE_PQ8) return false;
+  const int d = ix->qdim, M = ix->dim, Ds = ix->pq_ds;
+  bool aligned = !getenv("FFX_PQ_NO_ADC") && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
+  if (aligned) {
+    std::vector<int> bounds;
+    numpy_leaf_plan(0, d, bounds);
+    for (int m = 0; m < M && aligned; ++m) aligned = bounds[(size_t)m] == m * Ds;
+  }
+  return aligned;
+}
+
+// single-row candidates on exact-ADC rows: expand + look-ups + interpolation fused (pq_adc_exact_pairs_kernel)
+static int launch_pq_fused(ffx_plan* pl, float a, float b) {
+  const ffx_index* ix = pl->idx;
+  const int M = ix->dim, Ks = ix->pq_ks, Ds = ix->pq_ds;
+  const int64_t P = pl->n_pairs;
+  hipStream_t st = pl->stream;
+  const size_t lut_bytes = (size_t)pl->n_queries * M * Ks * sizeof(float);
+  FFX_TRY(pl->lut.ensure(std::max<size_t>(lut_bytes, 16)));
+  if (pl->n_queries > 0) {
+    ffx::pq_lut_exact_kernel<<<dim3((unsigned)pl->n_queries, (unsigned)M), 256, 0, st>>>(pl->queries.as<float>(), ix->codebook_t.as<float>(), M, Ks, Ds,
+                                                                                        pl->lut.as<float>());
+    FFX_HIP(hipGetLastError());
+  }
+  const int32_t* row_of = pl->mode == FFX_MODE_PASSAGE ? (ix->psgs_identity ? nullptr : ix->psg_row.as<int32_t>())
+                                                       : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
+  const size_t lds = (size_t)M * Ks * sizeof(float);
+  const double qpp = (double)pl->n_queries / (double)P;
+#define FFX_ADCP(MM)                                                                                                               \
+  ffx::pq_adc_exact_pairs_kernel<MM><<<blocks_for(P, 256), 256, lds, st>>>(static_cast<const uint8_t*>(ix->vectors), Ks, pl->lut.as<float>(), \
+      pl->pair_ids.as<int32_t>(), pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of,                                    \
+      pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b, pl->ff.as<float>(), pl->interp.as<float>(), (long)P)
+  switch (M) {
+    case 1: FFX_ADCP(1); break;
+    case 2: FFX_ADCP(2); break;
+    case 4: FFX_ADCP(4); break;
+    case 8: FFX_ADCP(8); break;
+    default: FFX_ADCP(16); break;
+  }
+#undef FFX_ADCP
+  FFX_HIP(hipGetLastError());
+  pl->variant = 2400 + M;
+  return FFX_OK;
+}
+
 static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
   const ffx_index* ix = pl->idx;
   const int d = ix->qdim, M = ix->dim, Ks = ix->pq_ks, Ds = ix->pq_ds;
@@ -1079,15 +1128,8 @@ static int launch_gather_dot_pq(ffx_plan* pl, bool exact, float* rs) {
   const float* Q = pl->queries.as<float>();
   const int2* desc = pl->desc.as<int2>();
   hipStream_t st = pl->stream;
-  // subspaces == leaves of NumPy's tree (every leaf has length Ds, M in {1,2,4,8,16}): exact ADC
-  // (FFX_PQ_NO_ADC forces decode-then-dot: tests and A/B)
   // (the exact table is also the fastest one, so exact_sum=false takes it too when it applies)
-  bool aligned = !getenv("FFX_PQ_NO_ADC") && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
-  if (aligned) {
-    std::vector<int> bounds;
-    numpy_leaf_plan(0, d, bounds);
-    for (int m = 0; m < M && aligned; ++m) aligned = bounds[(size_t)m] == m * Ds;
-  }
+  const bool aligned = pq_exact_adc_applies(pl);
   if (aligned) {
     const size_t lut_bytes = (size_t)pl->n_queries * M * Ks * sizeof(float);
     FFX_TRY(pl->lut.ensure(std::max<size_t>(lut_bytes, 16)));
@@ -1245,7 +1287,14 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   const bool exact = (flags & FFX_FLAG_EXACT_SUM) != 0;
   pl->ran = false;
   FFX_HIP(hipEventRecord(pl->ev[0], st));
-  if (P > 0) {
+  // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
+  const bool pq_fused = single && P > 0 && !getenv("FFX_PQ_NO_FUSE") && pq_exact_adc_applies(pl);
+  if (pq_fused) {
+    FFX_HIP(hipEventRecord(pl->ev[1], st));
+    FFX_TRY(launch_pq_fused(pl, (float)alpha, (float)(1.0 - alpha)));
+    FFX_HIP(hipEventRecord(pl->ev[2], st));
+  }
+  if (P > 0 && !pq_fused) {
     // 1. candidates -> row list
     const double qpp = (double)pl->n_queries / (double)P;
     if (single) {
@@ -1262,15 +1311,15 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
     }
     FFX_HIP(hipGetLastError());
   }
-  FFX_HIP(hipEventRecord(pl->ev[1], st));
+  if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[1], st));
   // 2. gather + inner product (the hot kernel)
   float* rs = single ? pl->ff.as<float>() : pl->rs.as<float>();
-  if (R > 0) FFX_TRY(launch_gather_dot(pl, exact, rs));
-  FFX_HIP(hipEventRecord(pl->ev[2], st));
+  if (R > 0 && !pq_fused) FFX_TRY(launch_gather_dot(pl, exact, rs));
+  if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[2], st));
   // 3. segment aggregation + interpolation
   const float a = (float)alpha;
   const float b = (float)(1.0 - alpha);
-  if (P > 0) {
+  if (P > 0 && !pq_fused) {
     if (!single) {
       ffx::reduce_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
           rs, pl->seg_off.as<int32_t>(), P, pl->mode, pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b,

@@ -928,6 +928,60 @@ pq_adc_exact_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __re
   rs[r] = leaf[0];
 }
 
+// Exact ADC straight from the candidate lists (single-row candidates: PASSAGE, FIRSTP, or one passage per
+// document): candidate -> row -> codes -> table look-ups -> dense score -> interpolation in ONE kernel.  A
+// PQ row is 8 code bytes; the {row, query} descriptor the general pipeline writes and reads back per row is
+// 8 bytes too, and the interpolation pass re-reads the scores -- fused, none of that traffic exists.
+// q_of(p): the query of pair p (proportional guess, binary-search fallback: aux_kernels.hip.h has the same).
+template <int M>
+__global__ void __launch_bounds__(256)
+pq_adc_exact_pairs_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __restrict__ lut,
+                          const int32_t* __restrict__ pair_ids, const int64_t* __restrict__ pair_off, int n_queries,
+                          double queries_per_pair, const int32_t* __restrict__ row_of, const float* __restrict__ sparse,
+                          float a, float b, float* __restrict__ ff, float* __restrict__ interp, long n_pairs) {
+  extern __shared__ float table[];
+  auto q_of = [&](long p) -> int {
+    int q = (int)((double)p * queries_per_pair);
+    q = q < 0 ? 0 : (q > n_queries - 1 ? n_queries - 1 : q);
+    if (pair_off[q] <= p && p < pair_off[q + 1]) return q;
+    int lo = 0, hi = n_queries;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pair_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  const long p0 = (long)blockIdx.x * blockDim.x;
+  const long p = p0 + threadIdx.x;
+  const long last = (p0 + blockDim.x - 1) < n_pairs ? (p0 + blockDim.x - 1) : n_pairs - 1;
+  const int q_first = q_of(p0), q_last = q_of(last);  // block-uniform
+  const bool one_query = q_first == q_last;
+  if (one_query) {
+    const float* src = lut + (size_t)q_first * M * Ks;
+    for (int i = threadIdx.x; i < M * Ks; i += blockDim.x) table[i] = src[i];
+  }
+  __syncthreads();
+  if (p >= n_pairs) return;
+  const int q = one_query ? q_first : q_of(p);
+  const int32_t o = pair_ids[p];
+  const int32_t row = row_of ? row_of[o] : o;
+  const uint8_t* c = codes + (size_t)row * M;
+  const float* t = one_query ? table : lut + (size_t)q * M * Ks;
+  float leaf[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int code = c[m] < Ks ? c[m] : Ks - 1;
+    leaf[m] = t[(size_t)m * Ks + code];
+  }
+#pragma unroll
+  for (int s = 1; s < M; s *= 2) {
+#pragma unroll
+    for (int i = 0; i + s < M; i += 2 * s) leaf[i] = __fadd_rn(leaf[i], leaf[i + s]);
+  }
+  ff[p] = leaf[0];
+  if (sparse != nullptr) interp[p] = __fadd_rn(__fmul_rn(a, sparse[p]), __fmul_rn(b, leaf[0]));
+}
+
 // One thread per row.  Rows of a query are contiguous, so almost every block works for a single
 // query: its M*Ks-float table is staged in LDS once and the M look-ups per row hit LDS.
 __global__ void __launch_bounds__(256)

@@ -561,7 +561,9 @@ def test_pq_decode_then_dot_bit_identical_to_reference(name):
             want = np.array([exp[(case.q_names[q], n)] for q, n in zip(pair_q, names)], dtype=np.float32)
             assert np.array_equal(bits(got), bits(want)), (name, key, st["kernel_variant"])
         # subspaces == NumPy leaves (d=768, M=8): exact ADC; otherwise decode-then-dot (LDS / generic)
-        assert st["kernel_variant"] == {"pq_d768_m8": 2208, "pq_d768_m16": 2116, "pq_d1024_m32": 2132, "pq_d60_m5": 2199}[name]
+        # (single-row candidates -- PASSAGE / FIRSTP here -- take the fused pairs kernel 24xx, multi-passage modes the row-list form 22xx)
+        exact_adc = 2408 if mode in ("PASSAGE", "FIRSTP") else 2208
+        assert st["kernel_variant"] == {"pq_d768_m8": exact_adc, "pq_d768_m16": 2116, "pq_d1024_m32": 2132, "pq_d60_m5": 2199}[name]
         assert np.array_equal(order.astype(np.int64), fo.order(interp, pair_off))
         if name == "pq_d768_m8":  # the decode-then-dot kernel must give the same bits
             import os
@@ -574,7 +576,7 @@ def test_pq_decode_then_dot_bit_identical_to_reference(name):
             assert st2["kernel_variant"] == 2108 and np.array_equal(bits(ff2), bits(ff))
         # ADC (fast order): same value up to fp32 rounding of a different summation order
         fast, _, _, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=False)
-        assert st["kernel_variant"] == (2208 if name == "pq_d768_m8" else 2300)  # the exact table is the faster one where it applies
+        assert st["kernel_variant"] == (exact_adc if name == "pq_d768_m8" else 2300)  # the exact table is the faster one where it applies
         assert np.abs(fast - ff).max() <= FAST_TOL * max(1.0, float(np.abs(ff).max()))
     idx.close()
 
@@ -709,11 +711,30 @@ def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
     idx.set_psg_rows(np.arange(n))
     pair_off = np.arange(nq + 1) * k
     pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for _ in range(nq)]).astype(np.int32)
-    ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 1, exact_sum=True)
-    assert st["kernel_variant"] == 2200 + m
+    sparse = rng.random(nq * k).astype(np.float32)
+    ff, interp, _, st = native.score(idx, queries, pair_off, pair_ids, 1, sparse, 0.3, exact_sum=True)
+    assert st["kernel_variant"] == 2400 + m  # one row per candidate: candidate -> codes -> look-ups -> interpolation in one kernel
     decoded = np.concatenate([codewords[j][codes[:, j]] for j in range(m)], axis=1)
     ref = np.sum(queries[np.repeat(np.arange(nq), k)] * decoded[pair_ids], axis=1)
-    assert np.array_equal(bits(ff), bits(ref))
+    assert np.array_equal(bits(ff), bits(ref)) and np.array_equal(bits(interp), bits(fo.interpolate(sparse, ref, 0.3)))
+    # the unfused form (row list + look-up kernel + interpolation kernel) gives the same bits
+    import os
+
+    os.environ["FFX_PQ_NO_FUSE"] = "1"
+    try:
+        ff2, interp2, _, st2 = native.score(idx, queries, pair_off, pair_ids, 1, sparse, 0.3, exact_sum=True)
+    finally:
+        del os.environ["FFX_PQ_NO_FUSE"]
+    assert st2["kernel_variant"] == 2200 + m and np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp))
+    # ragged queries and documents whose first row is not their ordinal (FIRSTP through doc_first)
+    perm = rng.permutation(n).astype(np.int32)
+    idx.set_doc_rows(np.arange(n + 1), perm)
+    ragged_off = np.array([0, 1, 1, 400, 1300, 2000], dtype=np.int64)
+    ids3 = rng.integers(0, n, size=2000).astype(np.int32)
+    ff3, _, _, st3 = native.score(idx, queries, ragged_off, ids3, 3, exact_sum=True)
+    assert st3["kernel_variant"] == 2400 + m
+    ref3 = np.sum(queries[np.repeat(np.arange(nq), np.diff(ragged_off))] * decoded[perm[ids3]], axis=1)
+    assert np.array_equal(bits(ff3), bits(ref3))
     idx.close()
 
 
