@@ -40,6 +40,71 @@ count_rows_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mod
   if (c == 0) atomicMin(bad_pair, (unsigned long long)p);
 }
 
+// ---- ffx_score's single-submission path (small batches, one row per candidate) ---------------
+// The batch arrives in a page-locked host block the device can address.  One kernel moves it into the
+// plan's device buffers (four copies on the copy engine cost ~10 us each at these sizes; this is one
+// launch) and validates the ordinals on the way, as count_rows_kernel does: the smallest bad position lands in
+// *bad_pair, which holds ~0 between calls.  A bad ordinal is replaced by 0 so that the ordinal -> row tables
+// are read in bounds (the row itself is clamped where it is looked up); the call fails once *bad_pair has
+// been read back, which happens together with the results.
+__global__ void __launch_bounds__(256)
+small_in_kernel(const uint32_t* __restrict__ h_queries, const uint32_t* __restrict__ h_pair_off, const int32_t* __restrict__ h_pair_ids,
+                const uint32_t* __restrict__ h_sparse, int64_t q_words, int64_t off_words, int64_t n_pairs,
+                uint32_t* __restrict__ queries, uint32_t* __restrict__ pair_off, int32_t* __restrict__ pair_ids, uint32_t* __restrict__ sparse,
+                int mode, const int32_t* __restrict__ doc_off, int64_t n_docs, const int32_t* __restrict__ psg_row, int64_t n_psgs,
+                int64_t n_index_rows, unsigned long long* __restrict__ bad_pair) {
+  const int64_t total = q_words + off_words + n_pairs * (h_sparse ? 2 : 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t j = i;
+    if (j < q_words) {
+      queries[j] = h_queries[j];
+      continue;
+    }
+    j -= q_words;
+    if (j < off_words) {
+      pair_off[j] = h_pair_off[j];
+      continue;
+    }
+    j -= off_words;
+    if (j >= n_pairs) {
+      sparse[j - n_pairs] = h_sparse[j - n_pairs];
+      continue;
+    }
+    int32_t o = h_pair_ids[j];
+    bool ok = false;
+    if (mode == FFX_MODE_PASSAGE) {
+      if (o >= 0 && o < n_psgs) {
+        const int32_t r = psg_row[o];
+        ok = r >= 0 && r < n_index_rows;
+      }
+    } else if (o >= 0 && o < n_docs) {
+      ok = doc_off[o + 1] > doc_off[o];
+    }
+    if (!ok) {
+      atomicMin(bad_pair, (unsigned long long)j);
+      o = 0;
+    }
+    pair_ids[j] = o;
+  }
+}
+
+// ... and one kernel writes the results into the host block (each source may be absent) and re-arms *bad_pair.
+__global__ void __launch_bounds__(256)
+small_out_kernel(const uint32_t* __restrict__ ff, const uint32_t* __restrict__ interp, const uint32_t* __restrict__ order, int64_t n_pairs,
+                 uint32_t* __restrict__ h_ff, uint32_t* __restrict__ h_interp, uint32_t* __restrict__ h_order,
+                 unsigned long long* __restrict__ bad_pair, unsigned long long* __restrict__ h_bad_pair) {
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+    if (h_ff) h_ff[i] = ff[i];
+    if (h_interp) h_interp[i] = interp[i];
+    if (h_order) h_order[i] = order[i];
+  }
+  if (t0 == 0) {
+    *h_bad_pair = *bad_pair;
+    *bad_pair = ~0ull;
+  }
+}
+
 // query number of pair p: the q with pair_off[q] <= p < pair_off[q+1].  First-stage runs give
 // (nearly) every query the same number of candidates, so the proportional guess is almost
 // always right and costs two independent loads; a miss falls back to binary search.
@@ -83,12 +148,15 @@ expand_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
 __global__ void __launch_bounds__(256)
 expand_single_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs,
                      const int64_t* __restrict__ pair_off, int n_queries, double queries_per_pair,
-                     const int32_t* __restrict__ row_of, int2* __restrict__ desc) {
+                     const int32_t* __restrict__ row_of, int64_t n_index_rows, int2* __restrict__ desc) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   const int q = query_of_pair(pair_off, n_queries, p, queries_per_pair);
   const int32_t o = pair_ids[p];
-  desc[p] = make_int2(row_of ? row_of[o] : o, q);
+  const int32_t row = row_of ? row_of[o] : o;
+  // validated ordinals always give a row of the store; the clamp is for ffx_score's single-submission path,
+  // where the verdict on a bad ordinal is read back only after the kernels behind this one have run
+  desc[p] = make_int2((uint32_t)row < (uint64_t)n_index_rows ? row : 0, q);
 }
 
 // ---- groupby(["id","q_no"]).aggregate(op) (index/base.py:306-312) + ranking.py:319 ----------

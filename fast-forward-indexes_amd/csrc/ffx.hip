@@ -194,11 +194,12 @@ struct ffx_plan {
   // shares this plan's stream; pairs set "lazily" have not been validated yet
   struct ffx_plan* es_child = nullptr;
   DevBuf es_active, es_cnt, es_pos, es_scan_tmp;
+  DevBuf small_flag;  // ffx_score's single-submission path: smallest bad pair position, ~0 between calls
   bool lazy_pairs = false;
   // Small batches (a service scoring one query at a time) are latency-bound on the copies: a
   // copy between pageable memory and the device blocks the caller each time, so inputs and
   // outputs of up to kStageBytes travel through this page-locked block and only one wait remains.
-  static constexpr size_t kStageBytes = 1 << 20;
+  static constexpr size_t kStageBytes = 4 << 20;
   char* hstage = nullptr;
   size_t hstage_used = 0;
   // room for `bytes` more in the staging block (nullptr: too large, or no page-locked memory)
@@ -224,7 +225,7 @@ namespace {
 // caller's buffer is free again on return either way)
 int plan_h2d(ffx_plan* pl, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return FFX_OK;
-  if (char* st = bytes <= ffx_plan::kStageBytes / 4 ? pl->stage(bytes) : nullptr) {
+  if (char* st = bytes <= (256u << 10) ? pl->stage(bytes) : nullptr) {
     memcpy(st, src, bytes);
     src = st;
   }
@@ -671,7 +672,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
     ffx_plan_destroy(pl->es_child);
     pl->es_child = nullptr;
   }
-  for (DevBuf* b : {&pl->es_active, &pl->es_cnt, &pl->es_pos, &pl->es_scan_tmp}) b->release();
+  for (DevBuf* b : {&pl->es_active, &pl->es_cnt, &pl->es_pos, &pl->es_scan_tmp, &pl->small_flag}) b->release();
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
                     &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps,
                     &pl->flags, &pl->ff, &pl->interp, &pl->order})
@@ -1105,7 +1106,7 @@ static int launch_pq_fused(ffx_plan* pl, float a, float b) {
 #define FFX_ADCP(MM)                                                                                                               \
   ffx::pq_adc_exact_pairs_kernel<MM><<<blocks_for(P, 256), 256, lds, st>>>(static_cast<const uint8_t*>(ix->vectors), Ks, pl->lut.as<float>(), \
       pl->pair_ids.as<int32_t>(), pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of,                                    \
-      pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b, pl->ff.as<float>(), pl->interp.as<float>(), (long)P)
+      pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b, pl->ff.as<float>(), pl->interp.as<float>(), (long)P, (long)ix->capacity)
   switch (M) {
     case 1: FFX_ADCP(1); break;
     case 2: FFX_ADCP(2); break;
@@ -1301,7 +1302,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
       const int32_t* row_of = pl->mode == FFX_MODE_PASSAGE ? (ix->psgs_identity ? nullptr : ix->psg_row.as<int32_t>())
                                                            : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
       ffx::expand_single_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
-          pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of, pl->desc.as<int2>());
+          pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of, ix->capacity, pl->desc.as<int2>());
     } else {
       FFX_TRY(launch_count_scan(pl));
       ffx::expand_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
@@ -1485,7 +1486,7 @@ int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_
   if (P > 0) {
     pl->hstage_used = 0;
     const size_t each = P * sizeof(float);
-    char* back = 3 * (each + 64) <= ffx_plan::kStageBytes ? pl->stage(3 * (each + 64)) : nullptr;
+    char* back = 3 * (each + 64) <= (size_t)(1 << 20) ? pl->stage(3 * (each + 64)) : nullptr;
     if (back) {  // small result: three copies into page-locked memory, one wait, then hand the bytes over
       char* b_ff = back;
       char* b_in = back + ((each + 63) & ~size_t(63));
@@ -1755,6 +1756,111 @@ int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, i
 // candidates of slice c+1 go up and the scores of slice c-1 come down, so with page-locked host
 // buffers (ffx_host_alloc / ffx_host_pin) the call costs about one device pass plus one slice of
 // transfers.  Results do not depend on the slicing.
+// ffx_score for a small batch of single-row candidates (a service scoring one query at a time): everything
+// -- uploads out of one page-locked block, validation, expand, gather_dot, interpolation, ordering, the
+// downloads back into that block -- is queued on the plan's stream and the host waits ONCE.  The general
+// path waits three times (after the queries, after the validation read-back that sizes the row list, after
+// the results); here the row list has exactly one row per candidate, so nothing has to come back early,
+// and a bad ordinal is reported from the same final read-back.  Returns FFX_OK with *handled = false when
+// the batch does not qualify.
+static int score_small(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off, const int32_t* pair_ids,
+                       const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff, float* out_interp, int32_t* out_order,
+                       int64_t* bad_pair, ffx_stats* stats, bool* handled) {
+  *handled = false;
+  const int64_t P = pair_off[n_queries];
+  const bool one_row = mode == FFX_MODE_PASSAGE || mode == FFX_MODE_FIRSTP || idx->max_doc_rows <= 1;
+  if (!one_row || P == 0 || n_queries == 0 || !host_queries || !pair_ids || getenv("FFX_NO_SMALL_PATH")) return FFX_OK;
+  if (mode == FFX_MODE_PASSAGE ? idx->n_psgs == 0 : idx->n_docs == 0) return FFX_OK;  // the general path words that error
+  const size_t q_bytes = (size_t)n_queries * idx->qdim * sizeof(float), off_bytes = (size_t)(n_queries + 1) * sizeof(int64_t), p_bytes = (size_t)P * 4;
+  const size_t in_bytes = q_bytes + off_bytes + p_bytes * (sparse ? 2 : 1) + 4 * 64;
+  const size_t out_bytes = p_bytes * 3 + 64 * 4;
+  if (in_bytes + out_bytes > ffx_plan::kStageBytes) return FFX_OK;
+  if (!idx->score_plans[0]) FFX_TRY(ffx_plan_create(idx, &idx->score_plans[0]));
+  ffx_plan* pl = idx->score_plans[0];
+  FFX_HIP(hipSetDevice(idx->device));
+  hipStream_t st = pl->stream;
+  pl->hstage_used = 0;
+  char* s_q = pl->stage(q_bytes);
+  char* s_off = pl->stage(off_bytes);
+  char* s_ids = pl->stage(p_bytes);
+  char* s_sp = sparse ? pl->stage(p_bytes) : nullptr;
+  char* b_ff = pl->stage(p_bytes);
+  char* b_in = pl->stage(p_bytes);
+  char* b_or = pl->stage(p_bytes);
+  char* b_flag = pl->stage(sizeof(unsigned long long));
+  if (!s_q || !s_off || !s_ids || (sparse && !s_sp) || !b_ff || !b_in || !b_or || !b_flag) return FFX_OK;  // no page-locked block: general path
+  const size_t pb = (size_t)P;
+  FFX_TRY(pl->queries.ensure(std::max<size_t>(q_bytes, 16)));
+  FFX_TRY(pl->pair_off.ensure(off_bytes));
+  FFX_TRY(pl->pair_ids.ensure(p_bytes));
+  FFX_TRY(pl->ff.ensure(p_bytes));
+  FFX_TRY(pl->desc.ensure(pb * sizeof(int2)));
+  if (sparse) {
+    FFX_TRY(pl->sparse.ensure(p_bytes));
+    FFX_TRY(pl->interp.ensure(p_bytes));
+  }
+  memcpy(s_q, host_queries, q_bytes);
+  memcpy(s_off, pair_off, off_bytes);
+  memcpy(s_ids, pair_ids, p_bytes);
+  if (sparse) memcpy(s_sp, sparse, p_bytes);
+  pl->have_pairs = false;
+  pl->lazy_pairs = false;
+  pl->ran = false;
+  pl->n_queries = n_queries;
+  pl->n_queries_set = (int)n_queries;
+  pl->n_pairs = P;
+  pl->n_rows = P;
+  pl->mode = mode;
+  pl->have_sparse = sparse != nullptr;
+  pl->order_base = 0;
+  pl->host_pair_off.assign(pair_off, pair_off + n_queries + 1);
+  // page-locked memory is mapped into the device's address space: the kernels read and write the block itself
+  if (!pl->small_flag.p) {
+    FFX_TRY(pl->small_flag.ensure(sizeof(unsigned long long)));
+    FFX_HIP(hipMemsetAsync(pl->small_flag.p, 0xFF, sizeof(unsigned long long), st));
+  }
+  void* d_block = nullptr;
+  FFX_HIP(hipHostGetDevicePointer(&d_block, pl->hstage, 0));
+  auto dev = [&](char* host) { return host ? static_cast<char*>(d_block) + (host - pl->hstage) : nullptr; };
+  const int64_t q_words = (int64_t)(q_bytes / 4), off_words = (int64_t)(off_bytes / 4);
+  const int64_t in_words = q_words + off_words + P * (sparse ? 2 : 1);
+  ffx::small_in_kernel<<<(unsigned)std::min<int64_t>(blocks_for(in_words, 256), 2048), 256, 0, st>>>(
+      reinterpret_cast<const uint32_t*>(dev(s_q)), reinterpret_cast<const uint32_t*>(dev(s_off)), reinterpret_cast<const int32_t*>(dev(s_ids)),
+      reinterpret_cast<const uint32_t*>(dev(s_sp)), q_words, off_words, P, pl->queries.as<uint32_t>(), pl->pair_off.as<uint32_t>(),
+      pl->pair_ids.as<int32_t>(), pl->sparse.as<uint32_t>(), mode, idx->doc_off.as<int32_t>(), idx->n_docs, idx->psg_row.as<int32_t>(),
+      idx->n_psgs, idx->capacity, pl->small_flag.as<unsigned long long>());
+  FFX_HIP(hipGetLastError());
+  pl->have_pairs = true;
+  if (const int rc = ffx_plan_run(pl, alpha, flags)) {
+    pl->have_pairs = false;
+    const std::string keep = g_last_error;
+    (void)hipMemsetAsync(pl->small_flag.p, 0xFF, sizeof(unsigned long long), st);  // re-arm: small_out_kernel will not run
+    (void)hipStreamSynchronize(st);
+    g_last_error = keep;
+    return rc;
+  }
+  const bool want_order = out_order != nullptr;
+  ffx::small_out_kernel<<<(unsigned)std::min<int64_t>(blocks_for(P, 256), 1024), 256, 0, st>>>(
+      pl->ff.as<uint32_t>(), pl->interp.as<uint32_t>(), pl->order.as<uint32_t>(), P, reinterpret_cast<uint32_t*>(out_ff ? dev(b_ff) : nullptr),
+      reinterpret_cast<uint32_t*>(out_interp ? dev(b_in) : nullptr), reinterpret_cast<uint32_t*>(want_order ? dev(b_or) : nullptr),
+      pl->small_flag.as<unsigned long long>(), reinterpret_cast<unsigned long long*>(dev(b_flag)));
+  FFX_HIP(hipGetLastError());
+  FFX_HIP(hipStreamSynchronize(st));  // the one wait
+  unsigned long long bad = ~0ull;
+  memcpy(&bad, b_flag, sizeof bad);
+  if (bad != ~0ull) {
+    pl->have_pairs = false;
+    if (bad_pair) *bad_pair = (int64_t)bad;
+    return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad);
+  }
+  if (out_ff) memcpy(out_ff, b_ff, p_bytes);
+  if (out_interp) memcpy(out_interp, b_in, p_bytes);
+  if (want_order) memcpy(out_order, b_or, p_bytes);
+  if (stats) FFX_TRY(ffx_plan_stats(pl, stats));
+  *handled = true;
+  return FFX_OK;
+}
+
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
               const int32_t* pair_ids, const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff,
               float* out_interp, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
@@ -1767,6 +1873,13 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
   if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
   if (out_order && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "out_order needs FFX_FLAG_SORT");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  if (n_queries <= INT32_MAX - 1) {  // small batches of single-row candidates: one submission, one wait
+    bool handled = false;
+    const int rc_small = score_small(idx, host_queries, n_queries, pair_off, pair_ids, sparse, mode, alpha, flags, out_ff, out_interp, out_order,
+                                     bad_pair, stats, &handled);
+    if (rc_small != FFX_OK || handled) return rc_small;
+  }
   // slices cut at query boundaries: ~2M pairs (a ~1 ms device pass at 768-d fp32) when the caller's
   // buffers are page-locked and the copies truly overlap, ~6M when they are pageable and every copy
   // blocks the caller for its duration (measured: tools/regions.py --only-ii)

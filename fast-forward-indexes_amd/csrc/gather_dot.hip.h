@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(256)
 pq_adc_exact_pairs_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __restrict__ lut,
                           const int32_t* __restrict__ pair_ids, const int64_t* __restrict__ pair_off, int n_queries,
                           double queries_per_pair, const int32_t* __restrict__ row_of, const float* __restrict__ sparse,
-                          float a, float b, float* __restrict__ ff, float* __restrict__ interp, long n_pairs) {
+                          float a, float b, float* __restrict__ ff, float* __restrict__ interp, long n_pairs, long n_index_rows) {
   extern __shared__ float table[];
   auto q_of = [&](long p) -> int {
     int q = (int)((double)p * queries_per_pair);
@@ -964,7 +964,8 @@ pq_adc_exact_pairs_kernel(const uint8_t* __restrict__ codes, int Ks, const float
   if (p >= n_pairs) return;
   const int q = one_query ? q_first : q_of(p);
   const int32_t o = pair_ids[p];
-  const int32_t row = row_of ? row_of[o] : o;
+  int32_t row = row_of ? row_of[o] : o;
+  row = (uint32_t)row < (unsigned long)n_index_rows ? row : 0;  // see expand_single_kernel
   const uint8_t* c = codes + (size_t)row * M;
   const float* t = one_query ? table : lut + (size_t)q * M * Ks;
   float leaf[M];

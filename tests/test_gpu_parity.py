@@ -309,6 +309,65 @@ def test_ragged_and_empty_queries():
     idx.close()
 
 
+def test_single_submission_path_matches_general_path(monkeypatch):
+    """ffx_score on a small batch of single-row candidates queues uploads, validation, kernels and downloads
+    in one go and waits once; its results are those of the general path (FFX_NO_SMALL_PATH) bit for bit, for
+    every mode, with and without first-stage scores and ordering, for non-identity id -> row tables and for
+    fp16 rows; a bad ordinal (too large, negative, or a passage id whose row is gone) is the same NotFound."""
+    d, n = 768, 900
+    vectors = synth.rows(21, 0.05, 0, n, d)
+    queries = synth.rows(22, 0.05, 0, 5, d)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n).astype(np.int32)  # ordinal o lives in row perm[o]
+    lens = [0, 1, 700, 130, 64]
+    pair_off = np.concatenate([[0], np.cumsum(lens)])
+    pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for k in lens]).astype(np.int32)
+    sparse = rng.normal(size=pair_ids.shape[0]).astype(np.float32)
+    for dtype in ("f32", "f16"):
+        idx = native.DeviceIndex(n, d, dtype=np.float16 if dtype == "f16" else np.float32)
+        idx.upload(vectors.astype(np.float16) if dtype == "f16" else vectors, 0)
+        idx.set_doc_rows(np.arange(n + 1), perm)
+        idx.set_psg_rows(perm)
+        for mode in (1, 2, 3, 4):
+            for sp, sort in ((None, False), (sparse, True), (None, True)):
+                monkeypatch.delenv("FFX_NO_SMALL_PATH", raising=False)
+                a = native.score(idx, queries, pair_off, pair_ids, mode, sp, 0.3, sort=sort)
+                monkeypatch.setenv("FFX_NO_SMALL_PATH", "1")
+                b = native.score(idx, queries, pair_off, pair_ids, mode, sp, 0.3, sort=sort)
+                for x, y in zip(a[:3], b[:3]):
+                    assert (x is None) == (y is None)
+                    if x is not None:
+                        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+                assert a[3]["n_pairs"] == b[3]["n_pairs"] and a[3]["n_rows"] == b[3]["n_rows"] and a[3]["kernel_variant"] == b[3]["kernel_variant"]
+        monkeypatch.delenv("FFX_NO_SMALL_PATH", raising=False)
+        for value, at in ((n, 7), (-1, 0), (2**31 - 1, pair_ids.shape[0] - 1)):
+            bad = pair_ids.copy()
+            bad[at] = value
+            bad[-1] = value if at != pair_ids.shape[0] - 1 else bad[-1]
+            for mode in (1, 2, 3, 4):
+                with pytest.raises(native.NotFound) as e:
+                    native.score(idx, queries, pair_off, bad, mode, sparse, 0.3, sort=True)
+                assert e.value.pair == at
+        # the call after a refused one is unaffected
+        ok = native.score(idx, queries, pair_off, pair_ids, 4, None, 0.3, sort=True)
+        assert np.array_equal(ok[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(ok[2], b[2])
+        idx.close()
+    # a passage id whose row was dropped (psg_row = -1)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    holes = perm.copy()
+    holes[0] = -1
+    holes[11] = -1
+    idx.set_doc_rows(np.arange(n + 1), perm)
+    idx.set_psg_rows(holes)
+    bad = pair_ids.copy()
+    bad[3] = 11
+    with pytest.raises(native.NotFound) as e:
+        native.score(idx, queries, pair_off, bad, 1)
+    assert e.value.pair == 3
+    idx.close()
+
+
 def test_many_passages_per_document():
     """MAXP / AVEP segments from 1 to 300 rows, rows of a document NOT contiguous."""
     d, n_docs = 128, 40
