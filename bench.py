@@ -270,18 +270,73 @@ def bench_sharded(args, rank: int, world: int):
     return _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, query_partition, ShardedScorer)
 
 
+def _guarded(fn, seconds: float, what: str):
+    """fn() on a daemon thread; TimeoutError if it has not returned after `seconds` (a collective that
+    never completes cannot be cancelled, but the rank can stop waiting for it)."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:  # noqa: BLE001 - handed to the caller
+            box["error"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise TimeoutError(f"{what} did not finish within {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box["value"]
+
+
 def _connect_with_fallback(args, rank: int, world: int, device, connect):
-    try:
+    """The job's communicator.  --transport rccl on several ranks: RCCL is brought up and PROBED (barrier,
+    all-reduce, one all-to-all through the send/recv mesh, result checked) under a watchdog, and the ranks
+    then vote over a shared-memory side channel, so that either every rank continues on RCCL or every rank
+    falls back to the shared-memory transport (the line's `transport` says which and why).  A scaling run
+    never hangs on, or dies of, a fabric that will not come up on this node."""
+    if args.transport != "rccl" or world == 1:
         return connect(args.transport, rank=rank, world=world, device=device)
-    except (native.FFXError, TimeoutError) as e:
-        if args.transport != "rccl" or (isinstance(e, native.FFXError) and e.code != native.RCCL_ERROR):
-            raise
-        os.environ["FFX_COMM_TIMEOUT_S"] = "600"  # ranks may arrive here minutes apart
-        # RCCL could not be brought up on this node (the same way on every rank): the exchange falls back to
-        # the shared-memory transport so that the scaling run still measures something; the line says so
-        print(f"rank {rank}: RCCL unavailable ({e}); falling back to the shared-memory transport", file=sys.stderr, flush=True)
-        args.transport = f"host (rccl unavailable: {str(e)[:120]})"
-        return connect("host", rank=rank, world=world, device=device)
+    os.environ["FFX_COMM_TIMEOUT_S"] = "900"  # ranks may reach the vote minutes apart
+    visible = max(1, native.device_count())
+    side = connect("host", rank=rank, world=world, device=(rank if device is None else device) % visible, timeout=600.0)
+    why = ""
+
+    def bring_up():
+        comm = connect("rccl", rank=rank, world=world, device=device, timeout=300.0)
+        comm.barrier()
+        total = comm.allreduce([float(rank + 1)])[0]
+        if total != world * (world + 1) / 2:
+            raise RuntimeError(f"all-reduce over RCCL returned {total}")
+        # rank r sends (d + 1) values "1000 r + d" to every rank d and checks what the others sent to it
+        send = np.concatenate([np.full(d + 1, 1000.0 * rank + d, dtype=np.float32) for d in range(world)])
+        got = comm.exchange_host(send, [d + 1 for d in range(world)], [rank + 1] * world)
+        want = np.concatenate([np.full(rank + 1, 1000.0 * r + rank, dtype=np.float32) for r in range(world)])
+        if not np.array_equal(got, want):
+            raise RuntimeError("the all-to-all probe over RCCL returned wrong values")
+        return comm
+
+    comm = None
+    try:
+        comm = _guarded(bring_up, 420.0, "bringing RCCL up")
+    except (native.FFXError, TimeoutError, RuntimeError, OSError) as e:
+        why = f"{type(e).__name__}: {e}"
+        print(f"rank {rank}: RCCL unavailable ({why})", file=sys.stderr, flush=True)
+    votes = side.allgather_array(np.array([1.0 if comm is not None else 0.0]))
+    if votes.min() > 0:
+        side.close()
+        return comm
+    reasons = [r.rstrip(b"\0").decode(errors="replace") for r in side.allgather_bytes(why.encode()[:160].ljust(160, b"\0"))]
+    first = next((f"rank {r}: {t}" for r, t in enumerate(reasons) if t), "")
+    print(f"rank {rank}: {int(votes.shape[0] - votes.sum())} of {world} ranks could not use RCCL; every rank falls back to the shared-memory transport",
+          file=sys.stderr, flush=True)
+    args.transport = f"host (rccl unavailable: {first[:200]})"
+    args.abandoned_comm = comm  # not closed: destroying a communicator whose peers never arrived can block
+    return side
 
 
 def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, query_partition, ShardedScorer):
@@ -716,7 +771,13 @@ def main():
     if world != args.gpus:
         args.gpus = world
     if world > 1 or args.force_sharded:
-        return bench_sharded(args, rank, world)
+        bench_sharded(args, rank, world)
+        if " unavailable" in str(args.transport):
+            # a communicator that never came up may still have a thread inside RCCL; do not wait for it at exit
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        return None
     return bench_single(args)
 
 

@@ -555,6 +555,31 @@ def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding):
         assert sum(result["exchange_bytes_per_rank"]["sent"]) == sum(result["exchange_bytes_per_rank"]["received"])
 
 
+def test_sharded_bench_falls_back_together_when_rccl_cannot_come_up():
+    """The default transport on a node where RCCL cannot be used (here: two ranks masked onto the same GPU,
+    which RCCL refuses): every rank probes RCCL under a watchdog, the ranks vote over the shared-memory side
+    channel and ALL of them continue on the shared-memory transport; the line says so, the run is correct and
+    exits 0 -- a scaling run neither hangs on nor dies of a fabric that will not come up."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "3",
+           "--warmup", "1", "--cpu-sample-queries", "12", "--cpu-seconds", "0.2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = "0"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = next(ln for ln in out.stdout.splitlines() if ln.startswith("{"))
+    result = json.loads(line)
+    assert result["n_gpus"] == 2 and result["parity_on_cpu_sample"] == "bit-exact"
+    assert result["transport"].startswith("host (rccl unavailable: rank "), result["transport"]
+    assert result["rccl_ranks"] == 0
+    assert "fall" in out.stderr and "shared-memory transport" in out.stderr
+
+
 def test_sharded_bench_leg_also_runs_under_torchrun():
     """The other way the driver may start N ranks: `python -m torch.distributed.run ... bench.py --gpus N`
     (RANK / WORLD_SIZE from the launcher; the ranks find each other through the launcher's run id)."""
