@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <future>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -155,14 +157,19 @@ struct ffx_index {
   int64_t max_doc_rows = 1;  // rows of the longest document: bounds what a candidate can contribute
   bool docs_identity = false;  // document ordinal o owns exactly row o
   bool psgs_identity = false;  // passage ordinal o is row o
-  // the two plans ffx_score alternates between (created on first use, freed with the index)
-  struct ffx_plan* score_plans[2] = {nullptr, nullptr};
+  // the plans ffx_score rotates through (two; three when results leave asynchronously); created on first use, freed with the index
+  struct ffx_plan* score_plans[3] = {nullptr, nullptr, nullptr};
   // page-locked staging of ffx_index_upload_rows: two blocks, filled by host threads while the
   // other one is in flight to the device
   void* stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;
+  // ffx_score with page-locked result buffers: results leave on this stream (highest priority, so that the
+  // copy of slice c is not queued behind the scoring kernels of slice c+1), one event per plan
+  hipStream_t out_stream = nullptr;
+  hipStream_t score_stream = nullptr;  // ... and every slice's kernels run on this one, in order (see ffx_score)
+  hipEvent_t out_done[3] = {nullptr, nullptr, nullptr};
 };
 
 struct ffx_plan {
@@ -350,6 +357,10 @@ int ffx_index_destroy(ffx_index* idx) {
     if (idx->stage_ev[i]) (void)hipEventDestroy(idx->stage_ev[i]);
   }
   if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
+  if (idx->out_stream) (void)hipStreamDestroy(idx->out_stream);
+  if (idx->score_stream) (void)hipStreamDestroy(idx->score_stream);
+  for (auto& e : idx->out_done)
+    if (e) (void)hipEventDestroy(e);
   if (idx->vectors) (void)hipFree(idx->vectors);
   idx->doc_off.release();
   idx->doc_rows.release();
@@ -1887,22 +1898,58 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   {
     hipPointerAttribute_t attr;
     if (pair_ids && hipPointerGetAttributes(&attr, pair_ids) == hipSuccess && attr.type == hipMemoryTypeHost)
-      per_slice = 2 << 20;
+      per_slice = 4 << 20;
     else
       (void)hipGetLastError();  // an ordinary pointer is "invalid value" to the runtime: not an error here
   }
   if (const char* e = getenv("FFX_SCORE_SLICE_PAIRS")) per_slice = std::max<int64_t>(1, atoll(e));
+  // ... and the first and last slices are smaller (an eighth of a slice, doubling / halving): the device idles
+  // while the first slice is uploaded and the caller idles while the last one's results come back
+  const int64_t ramp_base = getenv("FFX_SCORE_NO_RAMP") ? per_slice : std::max<int64_t>(per_slice / 8, 1);
+  auto slice_target = [&](size_t i, int64_t first_pair) {
+    const int64_t up = i < 8 ? ramp_base << i : per_slice;
+    const int64_t down = std::max<int64_t>(ramp_base, (P - first_pair) / 2);
+    return std::min(per_slice, std::min(up, down));
+  };
   std::vector<int64_t> cut{0};
   for (int64_t q = 1; q < n_queries; ++q)
-    if (pair_off[q + 1] - pair_off[cut.back()] > per_slice && q > cut.back()) cut.push_back(q);
+    if (pair_off[q + 1] - pair_off[cut.back()] > slice_target(cut.size() - 1, pair_off[cut.back()]) && q > cut.back()) cut.push_back(q);
   cut.push_back(n_queries);
   const int n_slices = (int)cut.size() - 1;
-  for (int i = 0; i < (n_slices > 1 ? 2 : 1); ++i)
+  // Results: into ordinary memory a copy blocks the caller, so slice c-1 is fetched after slice c has been
+  // launched and two plans alternate.  Into page-locked memory copies are truly asynchronous: slice c's results
+  // are queued on the index's out-stream right behind its kernels and awaited only when its plan is needed
+  // again.  With two plans that wait (for slice c-2, i.e. for two slices' kernels sharing the GPU) comes before
+  // slice c can even be uploaded, and the device idles for an upload out of every two slices (measured: 25.7 ms
+  // for the headline batch); with THREE plans the upload of slice c overlaps the kernels of c-1 and c-2.
+  // The kernels of all slices are issued on ONE stream, in order: on a stream per plan they share the GPU, finish
+  // together and free their plans together, so the device again idles while the next group is uploaded (23.1 ms).
+  // Uploads stay on each plan's own stream (they are awaited by the caller before the kernels are issued).
+  bool async_out = false;
+  if (n_slices > 1 && !getenv("FFX_SCORE_NO_OUT_STREAM")) {
+    const void* any = out_ff ? (const void*)out_ff : out_interp ? (const void*)out_interp : (const void*)out_order;
+    hipPointerAttribute_t attr;
+    if (any && hipPointerGetAttributes(&attr, any) == hipSuccess && attr.type == hipMemoryTypeHost)
+      async_out = true;
+    else
+      (void)hipGetLastError();
+  }
+  if (async_out && !idx->out_stream) {
+    int least = 0, greatest = 0;
+    FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, getenv("FFX_SCORE_OUT_PRIORITY_LOW") ? least : greatest));
+    if (!idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
+    for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order) && !getenv("FFX_SCORE_BLOCKING_OUT");
+  if (threaded_out && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
+  const int n_plans = n_slices > 1 ? (async_out || threaded_out ? 3 : 2) : 1;
+  for (int i = 0; i < n_plans; ++i)
     if (!idx->score_plans[i]) FFX_TRY(ffx_plan_create(idx, &idx->score_plans[i]));
   ffx_stats acc;
   memset(&acc, 0, sizeof acc);
   auto fetch = [&](int c) -> int {
-    ffx_plan* pl = idx->score_plans[c & 1];
+    ffx_plan* pl = idx->score_plans[c % n_plans];
     const int64_t p0 = pair_off[cut[c]];
     FFX_TRY(ffx_plan_fetch(pl, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr,
                            out_order ? out_order + p0 : nullptr));
@@ -1922,12 +1969,90 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     }
     return FFX_OK;
   };
+  // FFX_SCORE_TRACE=1: host-side timeline of the slices on stderr (us since the call began)
+  const bool trace = getenv("FFX_SCORE_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+  auto add_stats = [&](ffx_plan* pl) -> int {
+    if (!stats) return FFX_OK;
+    ffx_stats s;
+    FFX_TRY(ffx_plan_stats(pl, &s));
+    acc.n_queries += s.n_queries;
+    acc.n_pairs += s.n_pairs;
+    acc.n_rows += s.n_rows;
+    acc.algorithmic_bytes += s.algorithmic_bytes;
+    acc.ms_expand += s.ms_expand;
+    acc.ms_gather_dot += s.ms_gather_dot;
+    acc.ms_reduce += s.ms_reduce;
+    acc.ms_sort += s.ms_sort;
+    acc.ms_total += s.ms_total;
+    acc.kernel_variant = s.kernel_variant;
+    return FFX_OK;
+  };
+  auto send_out = [&](int c) -> int {  // queue slice c's results behind its kernels
+    ffx_plan* pl = idx->score_plans[c % n_plans];
+    const int64_t p0 = pair_off[cut[c]];
+    const size_t bytes = (size_t)pl->n_pairs * sizeof(float);
+    hipStream_t os = idx->out_stream;
+    FFX_HIP(hipStreamWaitEvent(os, pl->ev[4], 0));
+    if (bytes) {
+      if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff + p0, pl->ff.p, bytes, hipMemcpyDeviceToHost, os));
+      if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp + p0, pl->interp.p, bytes, hipMemcpyDeviceToHost, os));
+      if (out_order) FFX_HIP(hipMemcpyAsync(out_order + p0, pl->order.p, bytes, hipMemcpyDeviceToHost, os));
+    }
+    FFX_HIP(hipEventRecord(idx->out_done[c % n_plans], os));
+    return FFX_OK;
+  };
+  auto retire = [&](int c) -> int {  // slice c's results have landed; its plan is free again
+    FFX_HIP(hipEventSynchronize(idx->out_done[c % n_plans]));
+    return add_stats(idx->score_plans[c % n_plans]);
+  };
+  // ordinary result buffers: a copy into them blocks its caller for as long as it takes, so a helper thread per
+  // slice does the waiting (three plans, kernels in order on one stream, as above) while this thread uploads
+  struct FetchResult {
+    int rc = FFX_OK;
+    std::string error;
+  };
+  std::future<FetchResult> fetching[3];
+  auto fetch_on_thread = [&](int c) -> FetchResult {
+    FetchResult r;
+    ffx_plan* pl = idx->score_plans[c % n_plans];
+    const int64_t p0 = pair_off[cut[c]];
+    const size_t bytes = (size_t)pl->n_pairs * sizeof(float);
+    auto body = [&]() -> int {
+      FFX_HIP(hipSetDevice(idx->device));
+      FFX_HIP(hipEventSynchronize(pl->ev[4]));
+      if (bytes) {
+        if (out_ff) FFX_HIP(hipMemcpy(out_ff + p0, pl->ff.p, bytes, hipMemcpyDeviceToHost));
+        if (out_interp) FFX_HIP(hipMemcpy(out_interp + p0, pl->interp.p, bytes, hipMemcpyDeviceToHost));
+        if (out_order) FFX_HIP(hipMemcpy(out_order + p0, pl->order.p, bytes, hipMemcpyDeviceToHost));
+      }
+      return FFX_OK;
+    };
+    r.rc = body();
+    if (r.rc != FFX_OK) r.error = g_last_error;  // thread-local: carried back to the caller's thread
+    return r;
+  };
+  auto join_fetch = [&](int c) -> int {
+    if (!fetching[c % n_plans].valid()) return FFX_OK;
+    const FetchResult r = fetching[c % n_plans].get();
+    if (r.rc != FFX_OK) {
+      g_last_error = r.error;
+      return r.rc;
+    }
+    return add_stats(idx->score_plans[c % n_plans]);
+  };
   auto run_all = [&]() -> int {
     std::vector<int64_t> off;
     for (int c = 0; c < n_slices; ++c) {
-      ffx_plan* pl = idx->score_plans[c & 1];
+      ffx_plan* pl = idx->score_plans[c % n_plans];
       const int64_t q0 = cut[c], q1 = cut[c + 1], p0 = pair_off[q0];
+      const double t0 = us();
+      if (async_out && c >= n_plans) FFX_TRY(retire(c - n_plans));
+      if (threaded_out && c >= n_plans) FFX_TRY(join_fetch(c - n_plans));
+      const double t0b = us();
       FFX_TRY(ffx_plan_set_queries(pl, host_queries ? host_queries + (size_t)q0 * idx->qdim : nullptr, q1 - q0));
+      const double t1 = us();
       off.resize((size_t)(q1 - q0 + 1));
       for (int64_t q = q0; q <= q1; ++q) off[(size_t)(q - q0)] = pair_off[q] - p0;
       pl->order_base = (int32_t)p0;
@@ -1938,16 +2063,43 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
         if (bad_pair && bad >= 0) *bad_pair = p0 + bad;
         return rc;
       }
-      FFX_TRY(ffx_plan_run(pl, alpha, flags));
-      if (c > 0) FFX_TRY(fetch(c - 1));
+      const double t2 = us();
+      if (async_out || threaded_out) pl->stream = idx->score_stream;
+      const int rc_run = ffx_plan_run(pl, alpha, flags);
+      pl->stream = pl->own_stream;
+      if (rc_run != FFX_OK) return rc_run;
+      const double t3 = us();
+      if (async_out)
+        FFX_TRY(send_out(c));
+      else if (threaded_out)
+        fetching[c % n_plans] = std::async(std::launch::async, fetch_on_thread, c);
+      else if (c > 0)
+        FFX_TRY(fetch(c - 1));
+      if (trace)
+        fprintf(stderr, "ffx_score slice %d/%d pairs %lld: begin %.0f wait_plan %.0f set_queries %.0f set_pairs %.0f run %.0f %s %.0f\n", c, n_slices,
+                (long long)(pair_off[q1] - p0), t0, t0b - t0, t1 - t0b, t2 - t1, t3 - t2, async_out ? "send_out" : "fetch_prev", us() - t3);
     }
-    return fetch(n_slices - 1);
+    const double t4 = us();
+    int rc = FFX_OK;
+    if (async_out) {
+      for (int c = std::max(0, n_slices - n_plans); c < n_slices && rc == FFX_OK; ++c) rc = retire(c);
+    } else if (threaded_out) {
+      for (int c = std::max(0, n_slices - n_plans); c < n_slices && rc == FFX_OK; ++c) rc = join_fetch(c);
+    } else {
+      rc = fetch(n_slices - 1);
+    }
+    if (trace) fprintf(stderr, "ffx_score last results %.0f, end %.0f\n", us() - t4, us());
+    return rc;
   };
   const int rc = run_all();
+  for (auto& f : fetching)
+    if (f.valid()) (void)f.get();  // only after a failure: no helper outlives the call
   if (rc != FFX_OK) {  // nothing may still be writing when the caller gets its buffers back
     const std::string keep = g_last_error;
     for (ffx_plan* pl : idx->score_plans)
       if (pl) (void)hipStreamSynchronize(pl->stream);
+    if (idx->score_stream) (void)hipStreamSynchronize(idx->score_stream);
+    if (idx->out_stream) (void)hipStreamSynchronize(idx->out_stream);
     g_last_error = keep;
     return rc;
   }
