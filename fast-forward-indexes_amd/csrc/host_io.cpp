@@ -367,6 +367,120 @@ int ffx_ids_blob(const ffx_ids* t, char sep, char* buf, int64_t cap, int64_t* ne
   return FFX_OK;
 }
 
+// out[i] = src[index[i]] for 4-byte elements (float32 scores, int32 id codes): what follows every device ordering
+// on the host (reordering a run's columns by the per-query order, ranking.py:115-117's sort applied to the other
+// columns).  NumPy does this on one core after widening the index to 64 bits; here threads take blocks of the
+// output.  An index outside [0, n_src) is refused (nothing is written for it).
+int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_t n, int32_t n_threads, void* out) {
+  if (n < 0 || n_src < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n > 0 && (!src || !index || !out)) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  const uint32_t* s = static_cast<const uint32_t*>(src);
+  uint32_t* o = static_cast<uint32_t*>(out);
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 18) + 1}));
+  std::atomic<int64_t> next(0), bad(-1);
+  const int64_t block = 1 << 16;
+  auto work = [&]() {
+    for (;;) {
+      const int64_t lo = next.fetch_add(block);
+      if (lo >= n) return;
+      const int64_t hi = std::min(n, lo + block);
+      for (int64_t i = lo; i < hi; ++i) {
+        const int64_t j = index[i];
+        if ((uint64_t)j >= (uint64_t)n_src) {
+          int64_t none = -1;
+          bad.compare_exchange_strong(none, i);
+          continue;
+        }
+        o[i] = s[j];
+      }
+    }
+  };
+  try {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  if (bad.load() >= 0) return ffx_fail(FFX_BAD_ARG, "index[%lld] = %d is outside [0, %lld)", (long long)bad.load(), index[bad.load()], (long long)n_src);
+  return FFX_OK;
+}
+
+// Ranking.interpolate (ranking.py:319) when the other ranking's rows are a known permutation of this one's
+// (it came out of Index.__call__ on this ranking): out[j] = f32(a * sparse[j]) + f32(b * dense_of[i]) with
+// j = source_row[i], i.e. the dense scores are put back in first-stage order and combined in one pass -- two
+// rounded float32 multiplies and one add, never fused (this file is built with -ffp-contract=off), the
+// arithmetic of NumPy's `alpha * s + (1 - alpha) * d` on float32 arrays and of the device's interp_kernel.
+// source_row must be a permutation of 0..n-1 (checked; then every out element is written exactly once, which is
+// what makes the threads independent); *any_nan reports a NaN among the results (the caller then takes the general path, which
+// drops such rows as the reference does).
+int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32_t* source_row, int64_t n, float a, float b,
+                         int32_t n_threads, float* out, int32_t* any_nan) {
+  if (any_nan) *any_nan = 0;
+  if (n < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n > 0 && (!sparse || !dense_of || !source_row || !out)) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (n == 0) return FFX_OK;
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 18) + 1}));
+  uint8_t* seen = static_cast<uint8_t*>(calloc((size_t)n, 1));  // zero pages on first touch, no initialising pass
+  if (!seen) return ffx_fail(FFX_OOM, "host allocation failed");
+  std::atomic<int64_t> next(0), bad(-1), marked(0);
+  std::atomic<int> nan(0);
+  const int64_t block = 1 << 16;
+  auto over_blocks = [&](auto&& body) -> bool {  // body(lo, hi) on blocks of 0..n, by T threads
+    next.store(0);
+    auto work = [&]() {
+      for (;;) {
+        const int64_t lo = next.fetch_add(block);
+        if (lo >= n) return;
+        body(lo, std::min(n, lo + block));
+      }
+    };
+    try {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < T; ++t) pool.emplace_back(work);
+      work();
+      for (auto& th : pool) th.join();
+    } catch (const std::system_error&) {
+      return false;
+    }
+    return true;
+  };
+  const bool ran = over_blocks([&](int64_t lo, int64_t hi) {
+    bool my_nan = false;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t j = source_row[i];
+      if ((uint64_t)j >= (uint64_t)n) {
+        int64_t none = -1;
+        bad.compare_exchange_strong(none, i);
+        continue;
+      }
+      __atomic_store_n(&seen[j], (uint8_t)1, __ATOMIC_RELAXED);  // a plain byte store (two threads may both mark a duplicate)
+      const float x = a * sparse[j];
+      const float y = b * dense_of[i];
+      const float r = x + y;
+      my_nan |= r != r;
+      out[j] = r;
+    }
+    if (my_nan) nan.store(1);
+  });
+  // n entries, all inside 0..n-1: they are a permutation exactly when they marked n different rows
+  const bool counted = ran && bad.load() < 0 && over_blocks([&](int64_t lo, int64_t hi) {
+    int64_t c = 0;
+    for (int64_t j = lo; j < hi; ++j) c += seen[j];
+    marked.fetch_add(c);
+  });
+  free(seen);
+  if (!ran || (bad.load() < 0 && !counted)) return ffx_fail(FFX_OOM, "could not start host threads");
+  if (bad.load() >= 0) return ffx_fail(FFX_BAD_ARG, "source_row is not a permutation (entry %lld is outside 0..n-1)", (long long)bad.load());
+  if (marked.load() != n)
+    return ffx_fail(FFX_BAD_ARG, "source_row is not a permutation (%lld rows are named more than once)", (long long)(n - marked.load()));
+  if (any_nan) *any_nan = nan.load();
+  return FFX_OK;
+}
+
 // Per-query order on the host: scores descending, exact ties by position (stable), -0.0 counted as
 // +0.0 -- the order FFX_FLAG_SORT produces on the device (ranking.py:115-117), for score arrays that were
 // combined on the host (Ranking.interpolate).  Threads take blocks of queries; out_order[p] is a

@@ -311,12 +311,14 @@ class Index(abc.ABC):
             codes, names = ranking._id_coding()
             dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True,
                                                 **self._reuse_kw())
-            order = order.astype(np.intp)  # a permutation inside every query: the query numbers stay as they are
+            from fast_forward_amd import native
+
+            # `order` is a permutation inside every query: the query numbers stay as they are
             LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            out = Ranking._assemble_coded("fast-forward", q_no, q_order, codes[order], names,
-                                          dense[order].astype(ranking._score_dtype(), copy=False), texts)
+            out = Ranking._assemble_coded("fast-forward", q_no, q_order, native.take32(codes, order), names,
+                                          native.take32(dense, order).astype(ranking._score_dtype(), copy=False), texts)
             # row i of the result is row order[i] of `ranking`: ranking.interpolate(result, alpha) needs no join
-            out._source_rows = (weakref.ref(ranking), order)
+            out._source_rows = (weakref.ref(ranking), order.copy())  # (`order` may be a view of the index's re-used result block)
             return out
         df = ranking._df
         if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
@@ -453,13 +455,14 @@ class Index(abc.ABC):
             sparse = np.ascontiguousarray(ranking._scores(), dtype=np.float32)
             _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False,
                                                  **self._reuse_kw())
-            order = order.astype(np.intp)
+            from fast_forward_amd import native
+
             if cutoff is not None:
                 rank = np.arange(len(order)) - np.repeat(pair_off[:-1], np.diff(pair_off))
                 keep = rank < cutoff
                 order, q_no = order[keep], q_no[keep]  # (the device order is a permutation inside every query)
-            return Ranking._assemble_coded(ranking.name, q_no, q_order, codes[order], names,
-                                           interp[order].astype(ranking._score_dtype(), copy=False), texts)
+            return Ranking._assemble_coded(ranking.name, q_no, q_order, native.take32(codes, order), names,
+                                           native.take32(interp, order).astype(ranking._score_dtype(), copy=False), texts)
         df = ranking._df
         ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         sparse = df["score"].to_numpy(dtype=np.float32)

@@ -34,7 +34,7 @@ SYMBOLS = (
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_take32", "ffx_host_interpolate",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route",
@@ -185,6 +185,8 @@ def lib() -> C.CDLL:
         "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
         "ffx_host_unpin": ([vp], C.c_int),
         "ffx_host_order": ([vp, vp, i64, i32, vp], C.c_int),
+        "ffx_host_take32": ([vp, i64, vp, i64, i32, vp], C.c_int),
+        "ffx_host_interpolate": ([vp, vp, vp, i64, C.c_float, C.c_float, i32, vp, P(i32)], C.c_int),
         "ffx_comm_unique_id": ([C.c_int, vp], C.c_int),
         "ffx_comm_init": ([C.c_int, C.c_int, C.c_int, C.c_int, vp, P(vp)], C.c_int),
         "ffx_comm_destroy": ([vp], C.c_int),
@@ -554,10 +556,11 @@ class pinned:
 
 
 def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0,
-          exact_sum: bool = True, sort: bool = False, out=None):
+          exact_sum: bool = True, sort: bool = False, out=None, want_ff: bool = True):
     """One-shot ``ffx_score``: host arrays in, host arrays out.  Returns (ff, interp, order, stats).
 
-    ``out``: optional ``(ff, interp, order)`` arrays to write into (e.g. from :func:`pinned_empty`)."""
+    ``out``: optional ``(ff, interp, order)`` arrays to write into (e.g. from :func:`pinned_empty`).
+    ``want_ff=False``: the dense scores stay on the device (``ff`` is None)."""
     queries = _arr(queries, np.float32)
     pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
     sp = None if sparse is None else _arr(sparse, np.float32)
@@ -571,7 +574,7 @@ def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=Non
             raise ValueError("out arrays must be contiguous, of the result dtype and hold every pair")
         return a[:n]
 
-    ff = _out(o_ff, np.float32)
+    ff = _out(o_ff, np.float32) if want_ff else None
     interp = None if sp is None else _out(o_interp, np.float32)
     order = _out(o_order, np.int32) if sort else None
     bad, st = C.c_int64(-1), Stats()
@@ -589,6 +592,31 @@ def host_order(scores, pair_off, threads: int = 0) -> np.ndarray:
     out = np.empty(scores.shape[0], dtype=np.int32)
     _check(lib().ffx_host_order(_ptr(scores), _ptr(pair_off), pair_off.shape[0] - 1, int(threads), _ptr(out)))
     return out
+
+
+def take32(src: np.ndarray, index: np.ndarray, threads: int = 0) -> np.ndarray:
+    """``src[index]`` for a contiguous 1-d array of 4-byte elements and an int32 index, by host threads
+    (``ffx_host_take32``); small or otherwise shaped inputs take NumPy's route."""
+    if (src.ndim != 1 or src.dtype.itemsize != 4 or not src.flags["C_CONTIGUOUS"] or index.dtype != np.int32 or index.ndim != 1
+            or not index.flags["C_CONTIGUOUS"] or index.shape[0] < (1 << 18)):
+        return src[index]
+    out = np.empty(index.shape[0], dtype=src.dtype)
+    _check(lib().ffx_host_take32(_ptr(src), src.shape[0], _ptr(index), index.shape[0], int(threads), _ptr(out)))
+    return out
+
+
+def host_interpolate(sparse: np.ndarray, dense_of: np.ndarray, source_row: np.ndarray, alpha: float, threads: int = 0):
+    """``ffx_host_interpolate``: (scores in the sparse ranking's row order, whether any is NaN) for
+    ``alpha * sparse + (1 - alpha) * dense`` where row i of the dense ranking is row ``source_row[i]`` of the
+    sparse one.  float32 arithmetic with float32-rounded weights, as NumPy does for a Python-float weight."""
+    sparse, dense_of, source_row = _arr(sparse, np.float32), _arr(dense_of, np.float32), _arr(source_row, np.int32)
+    if not (sparse.shape == dense_of.shape == source_row.shape):
+        raise ValueError("the three arrays must have one entry per row")
+    out = np.empty(sparse.shape[0], dtype=np.float32)
+    nan = C.c_int32(0)
+    _check(lib().ffx_host_interpolate(_ptr(sparse), _ptr(dense_of), _ptr(source_row), sparse.shape[0], float(np.float32(alpha)),
+                                      float(np.float32(1 - alpha)), int(threads), _ptr(out), C.byref(nan)))
+    return out, bool(nan.value)
 
 
 def _as_fixed_bytes(strings) -> np.ndarray:

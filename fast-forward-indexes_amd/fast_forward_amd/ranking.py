@@ -499,15 +499,21 @@ class Ranking:
             native.lib()
         except (ImportError, OSError):
             return None
-        dense = np.empty_like(mine)
-        dense[link[1]] = other._scores()
-        score = alpha * mine + (1 - alpha) * dense  # a Python-float weight on a float32 array multiplies in float32 (ranking.py:319)
-        if score.dtype != np.float32 or np.isnan(score).any():
-            return None
-        order = native.host_order(score, pair_off).astype(np.intp)
+        if isinstance(alpha, (int, float)) and len(mine) >= (1 << 18) and link[1].dtype == np.int32:
+            # one threaded pass: scatter back + `alpha * mine + (1 - alpha) * dense` in float32, as below
+            score, any_nan = native.host_interpolate(mine, other._scores(), link[1], alpha)
+            if any_nan:
+                return None
+        else:
+            dense = np.empty_like(mine)
+            dense[link[1]] = other._scores()
+            score = alpha * mine + (1 - alpha) * dense  # a Python-float weight on a float32 array multiplies in float32 (ranking.py:319)
+            if score.dtype != np.float32 or np.isnan(score).any():
+                return None
+        order = native.host_order(score, pair_off)
         codes, names = self._id_coding()
         texts = self._query_texts() if self.has_queries else other._query_texts()
-        return Ranking._assemble_coded(self.name, self._q_no, q_order, codes[order], names, score[order], texts)
+        return Ranking._assemble_coded(self.name, self._q_no, q_order, native.take32(codes, order), names, native.take32(score, order), texts)
 
     def interpolate(self, other: "Ranking", alpha: float, normalize: bool = False) -> "Ranking":
         """``alpha * self + (1 - alpha) * other`` per (query, id) pair (ranking.py:293-326).

@@ -334,8 +334,10 @@ class _ShardedIndex:
         dtype = ranking._score_dtype()
         if coded:
             codes, names = ranking._id_coding()
-            order = order.astype(np.intp)  # positions inside the owned block, every query ordered
-            own_codes, own_score = codes[lo:hi][order], score[order].astype(dtype, copy=False)
+            from fast_forward_amd import native
+
+            # `order`: positions inside the owned block, every query ordered
+            own_codes, own_score = native.take32(codes[lo:hi], order), native.take32(score, order).astype(dtype, copy=False)
             if not gather:
                 return Ranking._assemble_coded(name, np.asarray(q_no[lo:hi]) - q_lo, q_order[q_lo:q_hi], own_codes, names, own_score, texts[q_lo:q_hi])
             # every rank's block, in rank order = query order (queries are owned in contiguous blocks)

@@ -364,6 +364,20 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
  * combined on the host (Ranking.interpolate, ranking.py:293-326).  out_order[p]: position in the whole array. */
 int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queries, int32_t n_threads, int32_t* out_order);
 
+/* out[i] = src[index[i]] for 4-byte elements (float32 scores, int32 id codes), by host threads (n_threads <= 0:
+ * every core this process may use): reorders a run's columns by the per-query order of ffx_plan_fetch /
+ * ffx_score / ffx_host_order (the other half of ranking.py:115-117's sort).  FFX_BAD_ARG for an index
+ * outside [0, n_src). */
+int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_t n, int32_t n_threads, void* out);
+
+/* Ranking.interpolate (ranking.py:319) on the host when the dense ranking's rows are a known permutation of the
+ * first-stage ranking's (row i of the dense one is row source_row[i] of the sparse one):
+ *   out[source_row[i]] = f32(a * sparse[source_row[i]]) + f32(b * dense_of[i])      (no FMA)
+ * by host threads.  source_row must be a permutation of 0..n-1 (FFX_BAD_ARG otherwise); *any_nan (may be NULL)
+ * is set when a result is NaN. */
+int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32_t* source_row, int64_t n, float a, float b,
+                         int32_t n_threads, float* out, int32_t* any_nan);
+
 /* ---- page-locked host memory ------------------------------------------------------------
  * Host buffers handed to the calls above may live anywhere; when they are page-locked the
  * copies to and from the device run at full link rate and overlap the kernels (ffx_score

@@ -256,3 +256,60 @@ def test_host_order_equals_the_oracle_order():
     assert native.host_order(np.zeros(0, dtype=np.float32), np.array([0, 0, 0])).shape == (0,)
     with pytest.raises(native.FFXError):
         native.host_order(s, np.array([0, 5, 3]))
+
+
+def test_native_take_equals_numpy_take():
+    """ffx_host_take32 (threads over blocks of the output) against NumPy's fancy indexing, for both element
+    types it is used with; an index outside the source is refused; small inputs take NumPy's route."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(5)
+    n_src, n = 700_001, 1_300_007
+    index = rng.integers(0, n_src, size=n).astype(np.int32)
+    for src in (rng.standard_normal(n_src).astype(np.float32), rng.integers(-2**31, 2**31 - 1, size=n_src).astype(np.int32)):
+        for threads in (0, 1, 3):
+            got = native.take32(src, index, threads)
+            assert got.dtype == src.dtype and np.array_equal(got.view(np.uint32), src[index].view(np.uint32))
+    bad = index.copy()
+    bad[n // 2] = n_src
+    with pytest.raises(native.FFXError) as e:
+        native.take32(src, bad)
+    assert f"index[{n // 2}]" in str(e.value)
+    bad[n // 2] = -1
+    with pytest.raises(native.FFXError):
+        native.take32(src, bad)
+    small = index[:1000]
+    assert np.array_equal(native.take32(src, small), src[small])
+    assert np.array_equal(native.take32(src.astype(np.float64), index), src.astype(np.float64)[index])  # not 4-byte: NumPy
+
+
+def test_native_interpolate_equals_numpy_expression():
+    """ffx_host_interpolate against the NumPy statement of ranking.py:319 on float32 arrays (scatter the dense
+    scores back, then alpha * s + (1 - alpha) * d with float32-rounded weights, no fused multiply-add):
+    bit-identical; NaN is reported; a source_row that is not a permutation is refused."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(9)
+    n = 900_001
+    sparse = (rng.standard_normal(n) * 17).astype(np.float32)
+    dense_of = (rng.standard_normal(n) * 3).astype(np.float32)
+    link = rng.permutation(n).astype(np.int32)
+    for alpha in (0.1, 0.5, 0.0, 1.0, 0.3333333333333333):
+        dense = np.empty_like(sparse)
+        dense[link] = dense_of
+        want = alpha * sparse + (1 - alpha) * dense
+        assert want.dtype == np.float32
+        for threads in (0, 1, 5):
+            got, any_nan = native.host_interpolate(sparse, dense_of, link, alpha, threads)
+            assert not any_nan and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    with_nan = dense_of.copy()
+    with_nan[12345] = np.nan
+    assert native.host_interpolate(sparse, with_nan, link, 0.2)[1]
+    twice = link.copy()
+    twice[5] = twice[6]
+    with pytest.raises(native.FFXError, match="not a permutation"):
+        native.host_interpolate(sparse, dense_of, twice, 0.2)
+    outside = link.copy()
+    outside[7] = n
+    with pytest.raises(native.FFXError, match="not a permutation"):
+        native.host_interpolate(sparse, dense_of, outside, 0.2)

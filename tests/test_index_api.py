@@ -298,10 +298,15 @@ def test_partial_ids_fixture_all_modes():
             assert np.float32(have[k]).view(np.uint32) == np.float32(want[k]).view(np.uint32), (mname, k)
 
 
-@pytest.mark.parametrize("name", ["config1", "d768", "s2_sub", "d768_f16"])
-def test_end_to_end_frames_match_reference(name):
+@pytest.mark.parametrize("name,pipelined", [("config1", False), ("d768", False), ("s2_sub", False), ("d768_f16", False), ("d768", True), ("s2_sub", True)])
+def test_end_to_end_frames_match_reference(name, pipelined, monkeypatch):
     """first_stage -> index(first_stage) -> interpolate, compared frame against frame with the
-    reference's output: identical scores (bits) and identical ordering (modulo exact ties)."""
+    reference's output: identical scores (bits) and identical ordering (modulo exact ties).
+    ``pipelined``: every batch takes the route of large ones (ffx_score: whole-query slices rotating through
+    three plans, here with slices of ~300 candidates)."""
+    if pipelined:
+        monkeypatch.setattr(InMemoryIndex, "_PIPELINED_FROM", 1)
+        monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", "300")
     case = load_scoring_case(name)
     for mode in case.modes():
         qvecs = case.queries
