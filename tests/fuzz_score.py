@@ -3,7 +3,9 @@
 row lengths and stores, random slice sizes of ffx_score, sort on and off.  Not collected by pytest
 (it is a soak: `python tests/fuzz_score.py --rounds 300` on the GPU box, under a minute); prints the
 seed of any failure.  Last runs of round 1: 300 + 1000 configurations (seeds 0 and 1), all bit-exact;
-round 2 (any-d kernel, in-LDS sort): 600 + 600 configurations (seeds 2 and 3), all bit-exact."""
+round 2 (any-d kernel, in-LDS sort): 600 + 600 configurations (seeds 2 and 3), all bit-exact; round 2 later
+(ffx_score's single-submission path for small single-row batches; slices through three plans with asynchronous
+copies into page-locked results or helper threads into ordinary ones): seeds 4 and 5, see DESIGN.md."""
 import argparse
 import os
 import sys
@@ -30,7 +32,7 @@ for rnd in range(args.rounds):
     d = int(rng.choice(DIMS))
     store = np.float16 if rng.random() < 0.3 else np.float32
     n_docs = int(rng.integers(1, 400))
-    per_doc = rng.integers(1, 6, size=n_docs)
+    per_doc = rng.integers(1, 6, size=n_docs) if rng.random() < 0.7 else np.ones(n_docs, dtype=np.int64)  # single-row documents: the small path
     doc_off = np.concatenate([[0], np.cumsum(per_doc)]).astype(np.int64)
     n = int(doc_off[-1])
     doc_rows = rng.permutation(n).astype(np.int32)
@@ -46,12 +48,19 @@ for rnd in range(args.rounds):
     sparse = (rng.integers(0, 5, size=len(pair_ids)) if rng.random() < 0.5 else rng.random(len(pair_ids)) * 10).astype(np.float32)
     alpha = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
     os.environ["FFX_SCORE_SLICE_PAIRS"] = str(int(rng.choice([1, 7, 100, 10**9])))
+    if rng.random() < 0.5:
+        os.environ["FFX_NO_SMALL_PATH"] = "1"
+    else:
+        os.environ.pop("FFX_NO_SMALL_PATH", None)
+    out = None
+    if rng.random() < 0.5:  # page-locked result arrays: results leave asynchronously on the out-stream
+        out = tuple(native.pinned_empty(max(1, len(pair_ids)), t) for t in (np.float32, np.float32, np.int32))
     idx = native.DeviceIndex(n, d, dtype=store)
     idx.upload(vectors, 0)
     idx.set_doc_rows(doc_off, doc_rows)
     idx.set_psg_rows(psg_row)
     try:
-        ff, interp, order, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, alpha, exact_sum=True, sort=True)
+        ff, interp, order, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, alpha, exact_sum=True, sort=True, out=out)
         want_ff, want_in = fo.score(vectors.astype(np.float32), doc_off, doc_rows, psg_row, queries, pair_off, pair_ids, mode, sparse, alpha)
         assert np.array_equal(bits(ff), bits(want_ff)), "dense"
         assert np.array_equal(bits(interp), bits(want_in)), "interp"
