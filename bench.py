@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-queries", type=int, default=64, help="queries in the CPU-baseline sample (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work to measure for the baseline")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per gather_dot launch from a rocprofv3 --pmc pass")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false", default=True,
+                    help="do not run the rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic in the 1-GPU line")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU leg even with one rank (rehearsal)")
     ap.add_argument("--sharding", default="rows", choices=["rows", "queries"],
                     help="multi-GPU layout: rows = index row-sharded by document + all-to-all of scores (north star); "
@@ -656,7 +658,60 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
     return out
 
 
+def measure_traffic(args) -> dict:
+    """roofline.traffic of the 1-GPU line, measured in this run: HBM bytes per launch of the dominant kernel
+    from the PMC counters, as MI355X_MICROARCH.md prescribes -- each counter in its own rocprofv3 --pmc pass
+    (never combined with tracing), FETCH_SIZE is in KiB and counts 64-B units where gfx950 moves 128-B
+    ones (x2; calibrated on launches with known traffic: tools/pmc_calibrate.py), WRITE_SIZE in KiB as it is.
+    Each pass is a CHILD process (`rocprofv3 ... -- python3 bench.py --steps 2 ...` on the same workload),
+    started before this process has touched the GPU.  Anything going wrong leaves traffic null and says why."""
+    import csv
+    import shutil
+    import tempfile
+
+    if args.traffic_bytes is not None:
+        return {"traffic": args.traffic_bytes, "traffic_source": "--traffic-bytes (rocprofv3 --pmc pass of this command)"}
+    if not args.traffic:
+        return {"traffic": None, "traffic_source": None}
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return {"traffic": None, "traffic_source": "rocprofv3 not found"}
+    child = [sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--no-regions", "--cpu-sample-queries", "0", "--no-traffic",
+             "--rows", str(args.rows), "--dim", str(args.dim), "--queries", str(args.queries), "--k", str(args.k), "--mode", args.mode,
+             "--layout", args.layout, "--sum", args.sum, "--store", args.store, "--alpha", str(args.alpha), "--seed", str(args.seed),
+             "--sort" if args.sort else "--no-sort"]
+    want = "pq_adc" if (args.store == "pq" and args.sum == "exact") else "gather_dot"
+    got, launches = {}, 0
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(prefix="ffx_pmc_", dir="/tmp") as out:
+                env = dict(os.environ, TMPDIR="/tmp")
+                run = subprocess.run([tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
+                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+                if run.returncode != 0:
+                    return {"traffic": None, "traffic_source": f"rocprofv3 --pmc {counter} exited with {run.returncode}: {run.stderr.strip()[-200:]}"}
+                per_dispatch = {}
+                for f in Path(out).rglob("*counter_collection.csv"):
+                    for row in csv.DictReader(open(f)):
+                        if want in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            key = (f.name, row["Dispatch_Id"])
+                            per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
+                if not per_dispatch:
+                    return {"traffic": None, "traffic_source": f"no {want} dispatch in the {counter} pass"}
+                got[counter] = sum(per_dispatch.values()) / len(per_dispatch)
+                launches = len(per_dispatch)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return {"traffic": None, "traffic_source": f"PMC pass failed: {type(e).__name__}: {str(e)[:200]}"}
+    fetch, write = 2.0 * 1024.0 * got["FETCH_SIZE"], 1024.0 * got["WRITE_SIZE"]
+    return {"traffic": fetch + write,
+            "traffic_source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child passes of this workload, "
+                              f"{launches} launches of the {want} kernel each, {time.perf_counter() - t0:.0f} s); FETCH_SIZE KiB x 1024 x 2 (gfx950) + WRITE_SIZE KiB x 1024",
+            "traffic_fetch_bytes": fetch, "traffic_write_bytes": write}
+
+
 def bench_single(args):
+    pmc = measure_traffic(args)  # child processes, before this one touches the GPU
     native.require_device()
     dev = native.device_info(0)
     scale = float(1.0 / np.sqrt(args.dim))  # scores O(1): 1e-4 absolute ~ 1e-4 relative
@@ -726,9 +781,9 @@ def bench_single(args):
                         "(exact ADC: 34.9 M lines = 4.5 GB in 0.68 ms = 6.6 TB/s, plus 0.19 ms of table build); decode-then-dot is "
                         "bound by L2->CU codeword traffic.  The fraction of algorithmic bytes is not the figure of merit here"} if args.store == "pq" else {}),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            # PMC counters cannot be read from inside the process: null unless a rocprofv3 --pmc pass of this very command
-            # is handed in (--traffic-bytes); the committed passes live under profiles/ 
-            "traffic": args.traffic_bytes, "traffic_source": "--traffic-bytes (rocprofv3 --pmc pass of this command)" if args.traffic_bytes else None,
+            # HBM bytes per launch from the PMC counters: measured by child rocprofv3 passes of this workload (measure_traffic)
+            **pmc,
+            **({"traffic_over_algorithmic": pmc["traffic"] / (st["n_rows"] * row_bytes)} if pmc.get("traffic") else {}),
             "algorithmic_bytes_per_launch": st["n_rows"] * row_bytes, "kernel_ms_avg": kern_avg_ms,
             "kernel_ms_min": float(np.min(kern_ms)), "kernel_ms_max": float(np.max(kern_ms)),
         },

@@ -609,7 +609,7 @@ def test_single_rank_rccl_bench_leg_matches_the_plain_leg():
 
     root = Path(__file__).resolve().parent.parent
     common = ["--rows", "2000000", "--queries", "400", "--k", "5000", "--steps", "10", "--warmup", "3", "--cpu-sample-queries", "4",
-              "--cpu-seconds", "0.2", "--no-regions"]
+              "--cpu-seconds", "0.2", "--no-regions", "--no-traffic"]
     vals = {}
     for name, extra in (("plain", []), ("sharded", ["--force-sharded"])):
         out = subprocess.run([sys.executable, str(root / "bench.py"), *common, *extra], capture_output=True, text=True, timeout=600)
@@ -618,6 +618,31 @@ def test_single_rank_rccl_bench_leg_matches_the_plain_leg():
         assert vals[name]["parity_on_cpu_sample"] == "bit-exact"
     assert vals["sharded"]["rccl_ranks"] == 1
     assert vals["sharded"]["value"] > 0.9 * vals["plain"]["value"], (vals["sharded"]["value"], vals["plain"]["value"])
+
+
+def test_bench_measures_hbm_traffic_with_pmc_passes_of_its_own():
+    """The 1-GPU bench line's roofline.traffic is measured in the run itself: bench.py starts rocprofv3 --pmc
+    child passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, no tracing) of the same workload before it
+    touches the GPU.  On 2 M x 768 fp32 rows (6 GB, far beyond the 256 MB Infinity Cache) with 2 M candidates the
+    kernel must fetch what the algorithm needs and little more."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("rocprofv3 is not installed")
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, str(root / "bench.py"), "--rows", "2000000", "--queries", "400", "--k", "5000", "--steps", "5", "--warmup", "2",
+           "--cpu-sample-queries", "0", "--no-regions"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    roof = json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{")))["roofline"]
+    assert roof["traffic"] is not None, roof["traffic_source"]
+    assert roof["traffic_source"].startswith("measured in this run")
+    assert 0.9 < roof["traffic_over_algorithmic"] < 1.25, roof
+    assert roof["traffic_write_bytes"] < 0.01 * roof["traffic_fetch_bytes"]
 
 
 # ---- product-quantized rows (decode-then-dot and ADC) ------------------------------------------------
