@@ -688,7 +688,7 @@ def measure_traffic(args) -> dict:
             with tempfile.TemporaryDirectory(prefix="ffx_pmc_", dir="/tmp") as out:
                 env = dict(os.environ, TMPDIR="/tmp")
                 run = subprocess.run([tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
-                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
                 if run.returncode != 0:
                     return {"traffic": None, "traffic_source": f"rocprofv3 --pmc {counter} exited with {run.returncode}: {run.stderr.strip()[-200:]}"}
                 per_dispatch = {}
