@@ -687,10 +687,19 @@ def measure_traffic(args) -> dict:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(prefix="ffx_pmc_", dir="/tmp") as out:
                 env = dict(os.environ, TMPDIR="/tmp")
-                run = subprocess.run([tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
-                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
-                if run.returncode != 0:
-                    return {"traffic": None, "traffic_source": f"rocprofv3 --pmc {counter} exited with {run.returncode}: {run.stderr.strip()[-200:]}"}
+                # its own process group, so that a pass that hangs can be ended together with the program under it
+                proc = subprocess.Popen([tool, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+                try:
+                    _, err = proc.communicate(timeout=150)
+                except subprocess.TimeoutExpired:
+                    import signal
+
+                    os.killpg(proc.pid, signal.SIGKILL)  # the group started two lines up
+                    proc.communicate()
+                    return {"traffic": None, "traffic_source": f"rocprofv3 --pmc {counter} did not finish within 150 s"}
+                if proc.returncode != 0:
+                    return {"traffic": None, "traffic_source": f"rocprofv3 --pmc {counter} exited with {proc.returncode}: {err.strip()[-200:]}"}
                 per_dispatch = {}
                 for f in Path(out).rglob("*counter_collection.csv"):
                     for row in csv.DictReader(open(f)):
