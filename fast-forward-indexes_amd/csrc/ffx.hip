@@ -22,6 +22,7 @@
 #include <atomic>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -2071,9 +2072,18 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
       const double t3 = us();
       if (async_out)
         FFX_TRY(send_out(c));
-      else if (threaded_out)
-        fetching[c % n_plans] = std::async(std::launch::async, fetch_on_thread, c);
-      else if (c > 0)
+      else if (threaded_out) {
+        try {
+          fetching[c % n_plans] = std::async(std::launch::async, fetch_on_thread, c);
+        } catch (const std::system_error&) {  // no thread to be had: this one does the waiting
+          const FetchResult r = fetch_on_thread(c);
+          if (r.rc != FFX_OK) {
+            g_last_error = r.error;
+            return r.rc;
+          }
+          FFX_TRY(add_stats(pl));
+        }
+      } else if (c > 0)
         FFX_TRY(fetch(c - 1));
       if (trace)
         fprintf(stderr, "ffx_score slice %d/%d pairs %lld: begin %.0f wait_plan %.0f set_queries %.0f set_pairs %.0f run %.0f %s %.0f\n", c, n_slices,
