@@ -349,6 +349,176 @@ int ffx_ids_intern_packed(ffx_ids* t, const char* data, int64_t n_bytes, char se
   return FFX_OK;
 }
 
+// Numbering the strings of one joined buffer WITHOUT keeping a table (Ranking.from_file on a large run: the
+// factorisation of the id column, ranking.py:95-98 / pandas.factorize): codes[i] = number of string i, equal
+// strings get equal numbers, numbers are dense 0..n_names-1; *names_blob receives the distinct strings in
+// number order joined by `sep` (released with ffx_buffer_free).  Parallel where a table insert per string is
+// serial: offsets and hashes by row ranges, then the rows are dealt into 256 shards by hash and every shard is
+// numbered on its own (open addressing over the shard's rows in row order), so the numbering is deterministic
+// (shard-major, first appearance inside a shard) and independent of the thread count.
+int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int32_t n_threads, int32_t* codes, char** names_blob,
+                     int64_t* names_bytes, int64_t* n_names) {
+  if (names_blob) *names_blob = nullptr;
+  if (names_bytes) *names_bytes = 0;
+  if (n_names) *n_names = 0;
+  if (n < 0 || n_bytes < 0 || (n > 0 && (!data || !codes)) || !names_blob || !names_bytes || !n_names) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return n_bytes == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "bytes given for zero strings");
+  if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many strings for int32 codes");
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  constexpr int S = 256;
+  auto in_threads = [&](auto&& body) {  // body(t) for t in 0..T-1
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(body, t);
+    body(0);
+    for (auto& th : pool) th.join();
+  };
+  try {
+    // 1. where every string starts: separators counted per byte range, then written per byte range
+    std::vector<int64_t> seps_in((size_t)T + 1, 0);
+    auto byte_range = [&](int t) { return std::pair<int64_t, int64_t>(n_bytes * t / T, n_bytes * (t + 1) / T); };
+    in_threads([&](int t) {
+      const auto [lo, hi] = byte_range(t);
+      int64_t c = 0;
+      for (const char* p = data + lo; (p = static_cast<const char*>(memchr(p, sep, (size_t)(data + hi - p)))) != nullptr; ++p) ++c;
+      seps_in[(size_t)t + 1] = c;
+    });
+    for (int t = 0; t < T; ++t) seps_in[(size_t)t + 1] += seps_in[(size_t)t];
+    if (seps_in[(size_t)T] != n - 1) return ffx_fail(FFX_BAD_ARG, "the buffer does not hold exactly %lld separated strings", (long long)n);
+    std::vector<int64_t> start((size_t)n + 1);
+    start[0] = 0;
+    start[(size_t)n] = n_bytes + 1;  // string i is data[start[i] .. start[i+1] - 1)
+    in_threads([&](int t) {
+      const auto [lo, hi] = byte_range(t);
+      int64_t i = seps_in[(size_t)t] + 1;
+      for (const char* p = data + lo; (p = static_cast<const char*>(memchr(p, sep, (size_t)(data + hi - p)))) != nullptr; ++p) start[(size_t)i++] = (p - data) + 1;
+    });
+    auto view = [&](int64_t i) { return std::string_view(data + start[(size_t)i], (size_t)(start[(size_t)i + 1] - 1 - start[(size_t)i])); };
+    // 2. hashes, and how many rows of every row range fall into every shard
+    std::vector<uint64_t> hash((size_t)n);
+    std::vector<int64_t> count((size_t)T * S, 0);
+    auto row_range = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
+    in_threads([&](int t) {
+      const auto [lo, hi] = row_range(t);
+      int64_t* c = count.data() + (size_t)t * S;
+      for (int64_t i = lo; i < hi; ++i) {
+        const std::string_view v = view(i);
+        uint64_t h = fnv1a(v.data(), v.size());
+        h ^= h >> 29;
+        h *= 0xbf58476d1ce4e5b9ull;  // fnv's high bits are weak on short numeric strings: mix before taking the shard from them
+        h ^= h >> 32;
+        hash[(size_t)i] = h;
+        ++c[h >> 56];
+      }
+    });
+    // 3. rows dealt into shards, row order kept inside a shard
+    std::vector<int64_t> shard_off((size_t)S + 1, 0);
+    {
+      int64_t at = 0;
+      for (int s = 0; s < S; ++s) {
+        shard_off[(size_t)s] = at;
+        for (int t = 0; t < T; ++t) {
+          const int64_t c = count[(size_t)t * S + s];
+          count[(size_t)t * S + s] = at;  // becomes: where range t writes its rows of shard s
+          at += c;
+        }
+      }
+      shard_off[(size_t)S] = at;
+    }
+    std::vector<int32_t> rows((size_t)n);
+    in_threads([&](int t) {
+      const auto [lo, hi] = row_range(t);
+      int64_t* at = count.data() + (size_t)t * S;
+      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[hash[(size_t)i] >> 56]++] = (int32_t)i;
+    });
+    // 4. every shard numbered on its own; codes[] holds shard-local numbers for now
+    std::vector<std::vector<int32_t>> firsts((size_t)S);  // first row of every distinct string of the shard, in number order
+    std::vector<int64_t> shard_bytes((size_t)S, 0);
+    std::atomic<int> next_shard(0);
+    std::atomic<bool> oom(false);
+    in_threads([&](int) {
+      try {
+        std::vector<int32_t> slot;
+        for (;;) {
+          const int s = next_shard.fetch_add(1);
+          if (s >= S) return;
+          const int64_t lo = shard_off[(size_t)s], hi = shard_off[(size_t)s + 1];
+          size_t cap = 16;
+          while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
+          slot.assign(cap, -1);  // slot -> shard-local number
+          auto& first = firsts[(size_t)s];
+          int64_t bytes = 0;
+          for (int64_t k = lo; k < hi; ++k) {
+            const int32_t i = rows[(size_t)k];
+            const uint64_t h = hash[(size_t)i];
+            const std::string_view v = view(i);
+            size_t at = (size_t)(h >> 8) & (cap - 1);
+            for (;;) {
+              const int32_t have = slot[at];
+              if (have < 0) {
+                slot[at] = (int32_t)first.size();
+                codes[i] = (int32_t)first.size();
+                first.push_back(i);
+                bytes += (int64_t)v.size();
+                break;
+              }
+              const int32_t j = first[(size_t)have];
+              if (hash[(size_t)j] == h && view(j) == v) {
+                codes[i] = have;
+                break;
+              }
+              at = (at + 1) & (cap - 1);
+            }
+          }
+          shard_bytes[(size_t)s] = bytes;
+        }
+      } catch (const std::bad_alloc&) {
+        oom.store(true);
+      }
+    });
+    if (oom.load()) return ffx_fail(FFX_OOM, "host allocation failed");
+    // 5. shard-local numbers -> global numbers; the names written shard by shard
+    std::vector<int64_t> base((size_t)S + 1, 0), at_byte((size_t)S + 1, 0);
+    for (int s = 0; s < S; ++s) {
+      base[(size_t)s + 1] = base[(size_t)s] + (int64_t)firsts[(size_t)s].size();
+      at_byte[(size_t)s + 1] = at_byte[(size_t)s] + shard_bytes[(size_t)s] + (int64_t)firsts[(size_t)s].size();  // + one separator each
+    }
+    const int64_t total = at_byte[(size_t)S];  // one separator too many (after the last name)
+    char* blob = static_cast<char*>(malloc((size_t)std::max<int64_t>(total, 1)));
+    if (!blob) return ffx_fail(FFX_OOM, "host allocation failed");
+    next_shard.store(0);
+    in_threads([&](int) {
+      for (;;) {
+        const int s = next_shard.fetch_add(1);
+        if (s >= S) return;
+        const int32_t b = (int32_t)base[(size_t)s];
+        if (b != 0)
+          for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) codes[rows[(size_t)k]] += b;
+        char* w = blob + at_byte[(size_t)s];
+        for (const int32_t i : firsts[(size_t)s]) {
+          const std::string_view v = view(i);
+          memcpy(w, v.data(), v.size());
+          w += v.size();
+          *w++ = sep;
+        }
+      }
+    });
+    *names_blob = blob;
+    *names_bytes = total - 1;
+    *n_names = base[(size_t)S];
+    return FFX_OK;
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+}
+
+int ffx_buffer_free(void* p) {
+  free(p);
+  return FFX_OK;
+}
+
 // every string of the table, in ordinal order, joined by `sep` (needed = bytes required; the copy
 // happens only if cap >= needed)
 int ffx_ids_blob(const ffx_ids* t, char sep, char* buf, int64_t cap, int64_t* needed) {
@@ -975,38 +1145,34 @@ int ffx_run_write(const ffx_run* run, const char* path, const float* scores, con
 // columns arrive as two '\n'-joined buffers (n_queries names; n_pairs ids in frame order), pair_off
 // gives every query's rows.  Lines "q_id\tQ0\tid\trank\tscore\tname", rank = 1-based position inside
 // the query, score formatted like pandas' to_csv of a float32 column.  Formatted by threads.
-int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
-                 const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag) {
-  if (!path || !pair_off || n_queries < 0 || n_pairs < 0 || (n_pairs > 0 && (!id_blob || !scores || !q_blob)) || !tag)
-    return ffx_fail(FFX_BAD_ARG, "bad argument");
-  if (pair_off[0] != 0 || pair_off[n_queries] != n_pairs) return ffx_fail(FFX_BAD_ARG, "pair_off does not cover the rows");
-  for (int64_t q = 0; q < n_queries; ++q)
-    if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
-  auto split = [](const char* blob, int64_t bytes, int64_t n, std::vector<std::string_view>& out) -> bool {
-    out.clear();
-    if (n == 0) return bytes == 0;
-    out.reserve((size_t)n);
-    const char* p = blob;
-    const char* end = blob + bytes;
-    while ((int64_t)out.size() < n) {
-      const char* q = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-      if (!q) {
-        out.emplace_back(p, (size_t)(end - p));
-        p = end + 1;
-        break;
-      }
-      out.emplace_back(p, (size_t)(q - p));
-      p = q + 1;
+}  // extern "C" (the writers below share helpers in an unnamed namespace)
+
+namespace {
+// n strings out of a buffer where the byte '\n' stands between them
+bool split_lines(const char* blob, int64_t bytes, int64_t n, std::vector<std::string_view>& out) {
+  out.clear();
+  if (n == 0) return bytes == 0;
+  out.reserve((size_t)n);
+  const char* p = blob;
+  const char* end = blob + bytes;
+  while ((int64_t)out.size() < n) {
+    const char* q = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+    if (!q) {
+      out.emplace_back(p, (size_t)(end - p));
+      p = end + 1;
+      break;
     }
-    return (int64_t)out.size() == n && p == end + 1;
-  };
-  std::vector<std::string_view> q_names, ids;
-  try {
-    if (!split(q_blob, q_bytes, n_queries, q_names) || !split(id_blob, id_bytes, n_pairs, ids))
-      return ffx_fail(FFX_BAD_ARG, "a buffer does not hold the announced number of strings");
-  } catch (const std::bad_alloc&) {
-    return ffx_fail(FFX_OOM, "host allocation failed");
+    out.emplace_back(p, (size_t)(q - p));
+    p = q + 1;
   }
+  return (int64_t)out.size() == n && p == end + 1;
+}
+
+// Ranking.save (ranking.py:348-366): rows grouped by query, rank = position inside the query; formatted by
+// threads, written in order.  id_at(p) is the candidate id of row p.
+template <class IdAt>
+int save_rows(const char* path, const std::vector<std::string_view>& q_names, int64_t n_queries, const int64_t* pair_off, int64_t n_pairs,
+              IdAt id_at, const float* scores, const char* tag) {
   FILE* f = fopen(path, "wb");
   if (!f) return ffx_fail(FFX_BAD_ARG, "cannot create %s", path);
   const std::string name = tag;
@@ -1014,7 +1180,7 @@ int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t 
     out.clear();
     for (int64_t q = q_lo; q < q_hi; ++q) {
       for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
-        out.append(q_names[(size_t)q]).append("\tQ0\t").append(ids[(size_t)p]).push_back('\t');
+        out.append(q_names[(size_t)q]).append("\tQ0\t").append(id_at(p)).push_back('\t');
         out += std::to_string(p - pair_off[q] + 1);
         out.push_back('\t');
         append_float_repr(out, scores[p]);
@@ -1024,7 +1190,7 @@ int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t 
       }
     }
   };
-  const int T = (int)std::min<int64_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<int64_t>(1, n_pairs >> 15));
+  const int T = (int)std::min<int64_t>(std::max(1, std::min(16, usable_cores())), std::max<int64_t>(1, n_pairs >> 15));
   std::vector<std::string> bufs((size_t)T);
   bool ok = true;
   try {
@@ -1047,12 +1213,59 @@ int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t 
   } catch (const std::bad_alloc&) {
     fclose(f);
     return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
+  } catch (const std::system_error&) {
+    fclose(f);
+    return ffx_fail(FFX_OOM, "could not start host threads while writing %s", path);
   }
   if (!ok) {
     fclose(f);
     return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
   }
   return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+}
+
+int check_save_args(const char* path, const int64_t* pair_off, int64_t n_queries, int64_t n_pairs, const char* tag) {
+  if (!path || !pair_off || n_queries < 0 || n_pairs < 0 || !tag) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (pair_off[0] != 0 || pair_off[n_queries] != n_pairs) return ffx_fail(FFX_BAD_ARG, "pair_off does not cover the rows");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  return FFX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
+                 const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag) {
+  if (int rc = check_save_args(path, pair_off, n_queries, n_pairs, tag)) return rc;
+  if (n_pairs > 0 && (!id_blob || !scores || !q_blob)) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  std::vector<std::string_view> q_names, ids;
+  try {
+    if (!split_lines(q_blob, q_bytes, n_queries, q_names) || !split_lines(id_blob, id_bytes, n_pairs, ids))
+      return ffx_fail(FFX_BAD_ARG, "a buffer does not hold the announced number of strings");
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
+  return save_rows(path, q_names, n_queries, pair_off, n_pairs, [&](int64_t p) { return ids[(size_t)p]; }, scores, tag);
+}
+
+// The same for rows whose candidate ids are CODES into a table of names (a run as the device hands it back:
+// Ranking._assemble_coded): row p is written with name_blob's string number id_codes[p].
+int ffx_run_save_coded(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
+                       const char* name_blob, int64_t name_bytes, int64_t n_names, const int32_t* id_codes, int64_t n_pairs,
+                       const float* scores, const char* tag) {
+  if (int rc = check_save_args(path, pair_off, n_queries, n_pairs, tag)) return rc;
+  if (n_names < 0 || (n_pairs > 0 && (!name_blob || !id_codes || !scores || !q_blob))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  std::vector<std::string_view> q_names, names;
+  try {
+    if (!split_lines(q_blob, q_bytes, n_queries, q_names) || !split_lines(name_blob, name_bytes, n_names, names))
+      return ffx_fail(FFX_BAD_ARG, "a buffer does not hold the announced number of strings");
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
+  for (int64_t p = 0; p < n_pairs; ++p)
+    if ((uint32_t)id_codes[p] >= (uint64_t)n_names) return ffx_fail(FFX_BAD_ARG, "row %lld holds id code %d, outside the %lld names", (long long)p, id_codes[p], (long long)n_names);
+  return save_rows(path, q_names, n_queries, pair_off, n_pairs, [&](int64_t p) { return names[(size_t)id_codes[p]]; }, scores, tag);
 }
 
 }  // extern "C"

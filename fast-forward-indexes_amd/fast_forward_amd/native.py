@@ -32,8 +32,8 @@ SYMBOLS = (
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
-    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get",
-    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_flags", "ffx_run_ids_blob",
+    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_buffer_free",
+    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_take32", "ffx_host_interpolate",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
@@ -168,6 +168,8 @@ def lib() -> C.CDLL:
         "ffx_ids_lookup_packed": ([vp, C.c_char_p, i64, C.c_char, i64, vp, P(i64)], C.c_int),
         "ffx_ids_intern_packed": ([vp, C.c_char_p, i64, C.c_char, i64, vp], C.c_int),
         "ffx_ids_blob": ([vp, C.c_char, vp, i64, P(i64)], C.c_int),
+        "ffx_strings_code": ([C.c_char_p, i64, C.c_char, i64, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
+        "ffx_buffer_free": ([vp], C.c_int),
         "ffx_ids_get": ([vp, i32, P(vp), P(i32)], C.c_int),
         "ffx_run_open": ([C.c_char_p, vp, P(vp), P(i64)], C.c_int),
         "ffx_run_close": ([vp], C.c_int),
@@ -179,6 +181,7 @@ def lib() -> C.CDLL:
         "ffx_run_flags": ([vp, P(i32), P(i32), P(i32)], C.c_int),
         "ffx_run_ids_blob": ([vp, vp, i64, P(i64)], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
+        "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
         "ffx_host_alloc": ([C.c_size_t, P(vp)], C.c_int),
         "ffx_host_free": ([vp], C.c_int),
@@ -619,6 +622,20 @@ def host_interpolate(sparse: np.ndarray, dense_of: np.ndarray, source_row: np.nd
     return out, bool(nan.value)
 
 
+def code_strings(blob: bytes, n: int, threads: int = 0) -> tuple[np.ndarray, bytes, int]:
+    """``ffx_strings_code``: (int32 code of each of the ``n`` strings of the ``'\\n'``-joined ``blob``, the distinct
+    strings in code order joined by ``'\\n'``, how many there are)."""
+    codes = np.empty(int(n), dtype=np.int32)
+    names, n_bytes, n_names = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+    _check(lib().ffx_strings_code(blob, len(blob), b"\n", int(n), int(threads), _ptr(codes), C.byref(names), C.byref(n_bytes), C.byref(n_names)))
+    try:
+        joined = C.string_at(names.value, n_bytes.value) if names.value and n_bytes.value > 0 else b""
+    finally:
+        if names.value:
+            lib().ffx_buffer_free(names)
+    return codes, joined, int(n_names.value)
+
+
 def _as_fixed_bytes(strings) -> np.ndarray:
     """Strings -> contiguous NUL-padded byte fields (numpy 'S<w>'), the ABI's string-array form."""
     a = np.asarray(strings)
@@ -686,6 +703,23 @@ class IdStrings:
         if b.shape[0]:
             _check(lib().ffx_ids_intern(self._h, _ptr(b), b.dtype.itemsize, b.shape[0], _ptr(out)))
         return out
+
+    def intern_blob(self, blob: bytes, n: int) -> np.ndarray:
+        """``intern`` for ``n`` strings that already are one ``'\\n'``-joined UTF-8 buffer (no Python string each)."""
+        out = np.empty(int(n), dtype=np.int32)
+        if n:
+            _check(lib().ffx_ids_intern_packed(self._h, blob, len(blob), b"\n", int(n), _ptr(out)))
+        return out
+
+    def blob(self) -> bytes:
+        """All strings in ordinal order, joined by ``'\\n'``."""
+        need = C.c_int64(0)
+        _check(lib().ffx_ids_blob(self._h, b"\n", None, 0, C.byref(need)))
+        if len(self) == 0:
+            return b""
+        buf = C.create_string_buffer(max(1, need.value))
+        _check(lib().ffx_ids_blob(self._h, b"\n", buf, need.value, C.byref(need)))
+        return buf.raw[:need.value]
 
     def lookup(self, strings, missing_ok: bool = False) -> np.ndarray:
         """Ordinals of ``strings``; ``IndexError`` naming the first unknown one, or -1 in its place
@@ -761,6 +795,23 @@ def save_run(path, q_names, pair_off, ids, scores, tag: str) -> bool:
     return True
 
 
+def save_run_coded(path, q_names, pair_off, id_codes, id_names, scores, tag: str) -> bool:
+    """``ffx_run_save_coded``: the same for rows that hold id codes into ``id_names`` (an array / list of strings, or
+    the ``'\\n'``-joined bytes of them with their number: ``(blob, n)``)."""
+    q_blob = _joined(q_names)
+    if isinstance(id_names, tuple):
+        name_blob, n_names = id_names
+    else:
+        name_blob, n_names = _joined(id_names), len(id_names)
+    tag_b = str(tag).encode("utf-8")
+    if q_blob is None or name_blob is None or any(c in tag_b for c in (b"\t", b'"', b"\r", b"\n", b"\0")) or not tag_b:
+        return False
+    pair_off, scores, id_codes = _arr(pair_off, np.int64), _arr(scores, np.float32), _arr(id_codes, np.int32)
+    _check(lib().ffx_run_save_coded(str(path).encode(), q_blob, len(q_blob), len(pair_off) - 1, _ptr(pair_off), name_blob, len(name_blob),
+                                    int(n_names), _ptr(id_codes), scores.shape[0], _ptr(scores), tag_b))
+    return True
+
+
 class RunFile:
     """Owns one ``ffx_run``: a TREC run parsed natively into the kernels' CSR (and written back)."""
 
@@ -807,15 +858,19 @@ class RunFile:
         _check(lib().ffx_run_flags(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def id_strings(self) -> list[str]:
-        """Candidate ids of a run opened without an id table, grouped by query, file order inside."""
+    def ids_blob(self) -> bytes:
+        """Candidate ids of a run opened without an id table, grouped by query, file order inside, joined by '\\n'."""
         need = C.c_int64(0)
         _check(lib().ffx_run_ids_blob(self._h, None, 0, C.byref(need)))
         if self.n_pairs == 0:
-            return []
+            return b""
         buf = C.create_string_buffer(max(1, need.value))
         _check(lib().ffx_run_ids_blob(self._h, buf, need.value, C.byref(need)))
-        return buf.raw[:need.value].decode("utf-8").split("\n")
+        return buf.raw[:need.value]
+
+    def id_strings(self) -> list[str]:
+        """... as Python strings."""
+        return self.ids_blob().decode("utf-8").split("\n") if self.n_pairs else []
 
     def scores(self) -> tuple[np.ndarray, np.ndarray]:
         """(pair_off, first-stage scores) without touching ordinals (any run)."""

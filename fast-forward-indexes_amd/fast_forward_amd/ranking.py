@@ -27,6 +27,7 @@ LOGGER = logging.getLogger(__name__)
 
 Run = Mapping[str, Mapping[str, float]]
 _KEY = ["q_id", "id"]
+_CODED_FROM_FILE_ROWS = 1 << 16  # run files with at least this many rows are read into the coded form
 
 
 def _with_queries(df: pd.DataFrame, queries: Mapping[str, str]) -> pd.DataFrame:
@@ -552,6 +553,10 @@ class Ranking:
         """Copy of this ranking with query strings attached (``ValueError`` if incomplete)."""
         if any(q not in queries for q in self._q_order):
             raise ValueError("Queries are incomplete.")
+        if self._coded is not None:  # stays coded: only the texts are new
+            c = self._coded
+            return Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"].copy(), c["id_names"], c["score"].copy(),
+                                           [queries[q] for q in self._q_order])
         # rows, order and pairs are this ranking's own: nothing to re-check, the texts follow the
         # per-row query numbers
         cols = {c: self._df[c].to_numpy().copy() for c in (*_KEY, "score")}
@@ -568,10 +573,15 @@ class Ranking:
             starts = np.zeros(len(self._q_order) + 1, dtype=np.int64)
             np.cumsum(np.bincount(q_no, minlength=len(self._q_order)), out=starts[1:])
             keep = np.flatnonzero(np.arange(len(q_no)) - starts[q_no] < cutoff)
-            cols = {c: self._df[c].to_numpy()[keep] for c in self._df.columns}
             present = np.flatnonzero(np.bincount(q_no[keep], minlength=len(self._q_order)))
             renumber = np.full(len(self._q_order), -1, dtype=np.int64)
             renumber[present] = np.arange(present.shape[0])
+            if self._coded is not None:  # stays coded (the name table may keep names no row uses any more)
+                c = self._coded
+                texts = None if c["q_texts"] is None else [c["q_texts"][i] for i in present]
+                return Ranking._assemble_coded(self.name, renumber[q_no[keep]], [self._q_order[i] for i in present], c["id_codes"][keep],
+                                               c["id_names"], c["score"][keep], texts)
+            cols = {c: self._df[c].to_numpy()[keep] for c in self._df.columns}
             return Ranking._assemble(cols, self.name, renumber[q_no[keep]], [self._q_order[i] for i in present])
         top = self._df[_ranks_within_query(self._df) <= cutoff]
         return self._derived(top.reset_index(drop=True), is_sorted=True, copy=True)
@@ -580,6 +590,8 @@ class Ranking:
     def save(self, target: Path) -> None:
         """Write a TREC run file: ``q_id Q0 id rank score name`` (ranking.py:348-366)."""
         target = Path(target)
+        if self._coded is not None and self._score_dtype() == np.float32 and self._save_native_coded(target):
+            return
         if len(self._df) >= 4096 and self._df["score"].dtype == np.float32 and self._save_native(target):
             return
         out = self._df[_KEY + ["score"]].copy()
@@ -622,6 +634,8 @@ class Ranking:
                 return None
             pair_off, scores = run.scores()
             q_names = np.array(run.query_ids(), dtype=object)
+            if run.n_pairs >= _CODED_FROM_FILE_ROWS and not np.isnan(scores).any():
+                return cls._from_parsed_run_coded(run, native, name, pair_off, scores, q_names, queries)
             ids = np.array(run.id_strings(), dtype=object)
         finally:
             run.close()
@@ -646,6 +660,51 @@ class Ranking:
         if queries is not None:
             out._df = _with_queries(out._df, queries)
         return out
+
+    @classmethod
+    def _from_parsed_run_coded(cls, run, native, name: str, pair_off: np.ndarray, scores: np.ndarray, q_names: np.ndarray, queries) -> "Ranking":
+        """A large run file straight into the coded form: the parser's candidate ids are numbered natively (one
+        joined buffer into ``ffx_strings_code``, by threads: a Python string per DISTINCT id, none per row), every query
+        is ordered by host threads (score descending, exact ties in file order: what the constructor's stable
+        sort gives) and the queries are put in descending id order.  Same rows, order and values as the frame
+        route (``test_from_file_coded_equals_the_frame_route``)."""
+        codes, names_blob, n_names = native.code_strings(run.ids_blob(), run.n_pairs)
+        id_names = np.empty(n_names, dtype=object)
+        id_names[:] = names_blob.decode("utf-8").split("\n") if n_names else []
+        inside = native.host_order(scores, pair_off)               # positions, queries in the parser's (first-appearance) order
+        counts = np.diff(pair_off)
+        by_name = np.argsort(q_names)[::-1]                         # q_id descending (ranking.py:115-117)
+        by_name = by_name[counts[by_name] > 0]
+        new_counts = counts[by_name]
+        new_off = np.zeros(len(by_name) + 1, dtype=np.int64)
+        np.cumsum(new_counts, out=new_off[1:])
+        # row i of the result is row inside[src[i]]: the blocks of `inside`, re-arranged query by query
+        src = np.arange(int(new_off[-1]), dtype=np.int64) + np.repeat(pair_off[by_name] - new_off[:-1], new_counts)
+        order = inside[src] if len(src) else np.zeros(0, dtype=np.int32)
+        q_order = q_names[by_name].tolist()
+        if queries is not None and any(q not in queries for q in q_order):
+            raise ValueError("Queries are incomplete.")
+        texts = None if queries is None else [queries[q] for q in q_order]
+        q_no = np.repeat(np.arange(len(by_name), dtype=np.int64), new_counts)
+        return cls._assemble_coded(name, q_no, q_order, native.take32(codes, order), id_names, native.take32(scores, order), texts)
+
+    def _save_native_coded(self, target: Path) -> bool:
+        """``save`` of a coded ranking without growing its frame: codes and the name table go to libffx's
+        formatter as they are (``ffx_run_save_coded``); False when that does not apply."""
+        try:
+            from fast_forward_amd import native
+
+            native.lib()
+        except (ImportError, OSError):
+            return False
+        c = self._coded
+        q_no = np.asarray(c["q_no"])
+        if len(q_no) < 4096 or (np.diff(q_no) < 0).any():
+            return False
+        pair_off = np.zeros(len(c["q_order"]) + 1, dtype=np.int64)
+        np.cumsum(np.bincount(q_no, minlength=len(c["q_order"])), out=pair_off[1:])
+        target.parent.mkdir(parents=True, exist_ok=True)
+        return native.save_run_coded(target, c["q_order"], pair_off, c["id_codes"], c["id_names"], c["score"], str(self.name))
 
     def _save_native(self, target: Path) -> bool:
         """The same bytes through libffx's threaded formatter (pandas' to_csv spends seconds on a

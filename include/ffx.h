@@ -315,6 +315,15 @@ int ffx_ids_intern_packed(ffx_ids* table, const char* data, int64_t n_bytes, cha
 int ffx_ids_blob(const ffx_ids* table, char sep, char* buf, int64_t cap, int64_t* needed);
 int ffx_ids_get(const ffx_ids* table, int32_t ordinal, const char** str, int32_t* len);
 
+/* Numbering the n strings of one joined buffer without keeping a table (the factorisation of a run's id column,
+ * ranking.py:95-98): codes[i] = number of string i, equal strings get equal numbers, numbers are dense; *names_blob
+ * receives the distinct strings in number order, joined by `sep` (*names_bytes bytes, *n_names strings; release it
+ * with ffx_buffer_free).  By host threads (n_threads <= 0: every core this process may use); the numbering does not
+ * depend on the thread count. */
+int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int32_t n_threads, int32_t* codes, char** names_blob,
+                     int64_t* names_bytes, int64_t* n_names);
+int ffx_buffer_free(void* p);
+
 /* ffx_run: a TREC run file (q_id Q0 id rank score name) parsed straight into the CSR of
  * ffx_plan_set_pairs, and written back; replaces Ranking.from_file / cut / save
  * (ranking.py:388-409, :279-291, :348-366) on the file-to-file path.  Candidate ids are resolved
@@ -349,6 +358,11 @@ int ffx_run_write(const ffx_run* run, const char* path, const float* scores, con
  * float32. */
 int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
                  const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag);
+/* the same for rows that hold id CODES (what Index.__call__ / Index.rerank / Ranking.from_file keep for a large
+ * run): row p is written with string number id_codes[p] of name_blob (n_names strings joined by '\n') */
+int ffx_run_save_coded(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
+                       const char* name_blob, int64_t name_bytes, int64_t n_names, const int32_t* id_codes, int64_t n_pairs,
+                       const float* scores, const char* tag);
 
 /* one-shot, host buffers in, host buffers out: the batch is cut into slices of whole queries
  * that alternate between two plans kept with the index, so uploads, scoring and downloads of

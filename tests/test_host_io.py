@@ -313,3 +313,52 @@ def test_native_interpolate_equals_numpy_expression():
     outside[7] = n
     with pytest.raises(native.FFXError, match="not a permutation"):
         native.host_interpolate(sparse, dense_of, outside, 0.2)
+
+
+def test_strings_are_numbered_like_a_factorisation():
+    """ffx_strings_code: equal strings get equal codes, codes are dense, the returned names decode every row
+    (the contract of pandas.factorize that Ranking relies on), for any thread count -- and the numbering itself
+    does not depend on the thread count.  Empty strings, non-ASCII, one string, everything equal."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(3)
+    for n, pool in ((1, 1), (5, 2), (70_000, 1), (100_000, 3000), (300_000, 250_000)):
+        names = [f"D{v}" if v % 7 else (f"ü{v}" if v % 2 else "") for v in rng.integers(0, pool, size=n)]
+        blob = "\n".join(names).encode()
+        ref = None
+        for threads in (1, 3, 8):
+            codes, joined, k = native.code_strings(blob, n, threads)
+            distinct = joined.decode().split("\n") if k else []
+            assert len(distinct) == k == len(set(names)) == len(set(distinct))
+            assert codes.min() >= 0 and codes.max() == k - 1
+            assert [distinct[c] for c in codes] == names
+            if ref is None:
+                ref = codes.copy()
+            assert np.array_equal(ref, codes)
+    assert native.code_strings(b"", 0)[2] == 0
+    with pytest.raises(native.FFXError, match="separated strings"):
+        native.code_strings(b"a\nb", 3)
+
+
+def test_coded_run_writer_equals_the_string_writer(tmp_path):
+    """ffx_run_save_coded (rows hold codes into a table of names) writes the bytes ffx_run_save writes for the
+    same rows spelled out; a code outside the table is refused."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(4)
+    n_q, k, pool = 37, 300, 1000
+    names = np.array([f"doc-{i}" for i in range(pool)], dtype=object)
+    codes = np.concatenate([rng.choice(pool, size=k, replace=False) for _ in range(n_q)]).astype(np.int32)
+    scores = (rng.standard_normal(n_q * k) * 7).astype(np.float32)
+    pair_off = np.arange(n_q + 1, dtype=np.int64) * k
+    q_names = [f"q{i}" for i in range(n_q)]
+    assert native.save_run_coded(tmp_path / "coded.tsv", q_names, pair_off, codes, names, scores, "tag")
+    assert native.save_run(tmp_path / "plain.tsv", q_names, pair_off, names[codes], scores, "tag")
+    assert (tmp_path / "coded.tsv").read_bytes() == (tmp_path / "plain.tsv").read_bytes()
+    assert native.save_run_coded(tmp_path / "blob.tsv", q_names, pair_off, codes, ("\n".join(names).encode(), pool), scores, "tag")
+    assert (tmp_path / "blob.tsv").read_bytes() == (tmp_path / "plain.tsv").read_bytes()
+    bad = codes.copy()
+    bad[17] = pool
+    with pytest.raises(native.FFXError, match="row 17"):
+        native.save_run_coded(tmp_path / "bad.tsv", q_names, pair_off, bad, names, scores, "tag")
+    assert not native.save_run_coded(tmp_path / "q.tsv", q_names, pair_off, codes, np.array(['a"b'] * pool, dtype=object), scores, "tag")  # needs a CSV writer

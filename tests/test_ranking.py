@@ -392,3 +392,52 @@ def test_column_array_constructor_equals_the_general_one(monkeypatch, seed):
     with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
         Ranking(dup, **kwargs)
     assert r._df["score"].dtype == kwargs["dtype"]
+
+
+def test_from_file_coded_equals_the_frame_route(tmp_path, monkeypatch):
+    """A large run file is read straight into the coded form (ids numbered natively, every query ordered by host
+    threads); rows, order, values, query numbering and everything derived from them -- cut, attach_queries, save,
+    ==, the frame itself -- equal what the frame route (small files) gives.  Queries out of order in the file,
+    exact ties, +-0 scores, non-ASCII ids, a query with a single row."""
+    import fast_forward_amd.ranking as R
+    from fast_forward_amd import Ranking
+
+    rng = np.random.default_rng(12)
+    lines = []
+    q_ids = [f"q{i:03d}" for i in rng.permutation(140)]
+    for q in q_ids:
+        k = 1 if q == q_ids[5] else int(rng.integers(300, 900))
+        docs = rng.choice(5000, size=k, replace=False)
+        scores = np.round(rng.standard_normal(k) * 3, 1)  # many exact ties
+        scores[rng.random(k) < 0.02] = 0.0
+        scores[rng.random(k) < 0.02] = -0.0
+        for i, (d, s) in enumerate(zip(docs, scores)):
+            lines.append(f"{q}\tQ0\t{'dö' if d % 11 == 0 else 'D'}{d}\t{i + 1}\t{float(s)!r}\tbm25")
+    path = tmp_path / "run.tsv"
+    path.write_text("\n".join(lines) + "\n", encoding="utf-8")
+    assert len(lines) >= R._CODED_FROM_FILE_ROWS and path.stat().st_size >= (1 << 18)
+    queries = {q: f"text of {q}" for q in q_ids}
+
+    def both(fn):
+        coded = fn()
+        monkeypatch.setattr(R, "_CODED_FROM_FILE_ROWS", 10**15)
+        frame = fn()
+        monkeypatch.undo()
+        return coded, frame
+
+    for qs in (None, queries):
+        coded, frame = both(lambda: Ranking.from_file(path, queries=qs))
+        assert coded._coded is not None and coded._frame is None and frame._coded is None
+        assert coded._q_order == frame._q_order and np.array_equal(coded._q_no, frame._q_no) and coded.name == frame.name
+        assert coded.has_queries == frame.has_queries == (qs is not None)
+        for derive in (lambda r: r, lambda r: r.cut(100), lambda r: r.cut(1), lambda r: r.attach_queries(queries), lambda r: r.cut(7).attach_queries(queries)):
+            a, b = derive(coded), derive(frame)
+            assert a._coded is not None and (a is coded or a._frame is None)  # derived rankings stay coded, no frame is grown
+            a.save(tmp_path / "a.tsv")
+            b.save(tmp_path / "b.tsv")
+            assert a is coded or len(a._q_no) < 4096 or a._frame is None  # (tiny runs are written by pandas)
+            assert (tmp_path / "a.tsv").read_bytes() == (tmp_path / "b.tsv").read_bytes()
+            assert a._q_order == b._q_order and np.array_equal(a._q_no, b._q_no)
+            assert a == b and a._df.equals(b._df)
+    with pytest.raises(ValueError, match="Queries are incomplete"):
+        Ranking.from_file(path, queries={q: "x" for q in q_ids[:-1]})
