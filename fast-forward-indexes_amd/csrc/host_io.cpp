@@ -128,14 +128,25 @@ namespace {
 inline int token_class(std::string_view t) {
   static const char* const na_words[] = {"#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN",
                                          "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
-  for (const char* w : na_words)
-    if (t == w) return FFX_TOKEN_NA;
+  if (t.empty()) return FFX_TOKEN_TEXT;
+  // (called once per row of a run file: the common cases -- "D1234", "1234" -- are decided on their first byte)
+  const char c0 = t[0];
+  if (c0 == '#' || c0 == '-' || c0 == '1' || c0 == '<' || c0 == 'N' || c0 == 'n')
+    for (const char* w : na_words)
+      if (t == w) return FFX_TOKEN_NA;
   size_t i = 0;
   if (i < t.size() && t[i] == '-') ++i;
   const size_t digits_from = i;
   while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i;
   if (i == t.size() && i > digits_from && i - digits_from <= 18 && (t[digits_from] != '0' || (i - digits_from == 1 && digits_from == 0)))
     return FFX_TOKEN_INT;
+  {
+    // a number or boolean starts (after a sign) with a digit, a point, or the first letter of inf / nan / true / false
+    const char c1 = (c0 == '-' || c0 == '+') ? (t.size() > 1 ? t[1] : '\0') : c0;
+    const bool maybe = (c1 >= '0' && c1 <= '9') || c1 == '.' || c1 == 'i' || c1 == 'I' || c1 == 'n' || c1 == 'N' || c1 == 't' || c1 == 'T' ||
+                       c1 == 'f' || c1 == 'F';
+    if (!maybe) return FFX_TOKEN_TEXT;
+  }
   std::string tmp(t);
   for (char& c : tmp) c = (char)tolower((unsigned char)c);
   if (tmp == "true" || tmp == "false") return FFX_TOKEN_NUMBER;
@@ -150,12 +161,15 @@ inline int token_class(std::string_view t) {
 // 2 = anything else -- hexadecimal floats, "nan(123)", "NAN", ... -- which strtod would accept but
 // pandas would not read as a number: the caller rejects the file so that the pandas route decides.
 inline int score_token_kind(std::string_view t) {
-  if (token_class(t) == FFX_TOKEN_NA) return 1;
   size_t i = 0;
   if (i < t.size() && (t[i] == '-' || t[i] == '+')) ++i;
-  std::string low(t.substr(i));
-  for (char& c : low) c = (char)tolower((unsigned char)c);
-  if (low == "inf" || low == "infinity") return 0;
+  const bool digit_first = i < t.size() && ((t[i] >= '0' && t[i] <= '9') || t[i] == '.');
+  if (!digit_first) {  // words: pandas' NA spellings, infinities, anything else
+    if (token_class(t) == FFX_TOKEN_NA) return 1;
+    std::string low(t.substr(i));
+    for (char& c : low) c = (char)tolower((unsigned char)c);
+    return (low == "inf" || low == "infinity") ? 0 : 2;
+  }
   size_t digits = 0;
   while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++digits;
   if (i < t.size() && t[i] == '.') {
@@ -170,7 +184,8 @@ inline int score_token_kind(std::string_view t) {
     while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++exp_digits;
     if (exp_digits == 0) return 2;
   }
-  return i == t.size() ? 0 : 2;
+  if (i == t.size()) return 0;
+  return token_class(t) == FFX_TOKEN_NA ? 1 : 2;  // "1.#IND", "-1.#QNAN", ... start like numbers
 }
 
 inline std::string_view fixed_width(const char* base, int32_t width, int64_t i) {
@@ -221,6 +236,50 @@ void append_float_repr(std::string& out, float v) {
       out.append(digits, int_len, std::string::npos);
     }
   }
+}
+
+// The run writers format lines by threads and write them in order: queries are handed out in batches of about
+// 64K lines per thread; while one round of buffers is written to the file the next round is being formatted.
+// format(q_lo, q_hi, out) appends the lines of queries q_lo .. q_hi-1 to `out`.
+template <class Format>
+int write_formatted(FILE* f, const char* path, int64_t n_queries, int64_t n_rows, Format format) {
+  const int T = (int)std::min<int64_t>(std::max(1, std::min(32, usable_cores())), std::max<int64_t>(1, n_rows >> 15));
+  std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
+  int used[2] = {0, 0};
+  bool ok = true;
+  try {
+    const int64_t avg = std::max<int64_t>(1, n_rows / std::max<int64_t>(1, n_queries));
+    const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
+    int round = 0;
+    for (int64_t q0 = 0; (q0 < n_queries || used[(round + 1) & 1] > 0) && ok; q0 += q_per_thread * T, ++round) {
+      std::vector<std::string>& mine = bufs[round & 1];
+      std::vector<std::thread> pool;
+      used[round & 1] = 0;
+      for (int t = 0; t < T; ++t) {
+        const int64_t lo = q0 + t * q_per_thread, hi = std::min(n_queries, lo + q_per_thread);
+        if (lo >= hi) break;
+        ++used[round & 1];
+        pool.emplace_back(format, lo, hi, std::ref(mine[(size_t)t]));
+      }
+      // meanwhile: the previous round's buffers go to the file
+      std::vector<std::string>& prev = bufs[(round + 1) & 1];
+      for (int t = 0; t < used[(round + 1) & 1] && ok; ++t)
+        ok = prev[(size_t)t].empty() || fwrite(prev[(size_t)t].data(), 1, prev[(size_t)t].size(), f) == prev[(size_t)t].size();
+      used[(round + 1) & 1] = 0;
+      for (auto& th : pool) th.join();
+    }
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
+  } catch (const std::system_error&) {
+    fclose(f);
+    return ffx_fail(FFX_OOM, "could not start host threads while writing %s", path);
+  }
+  if (!ok) {
+    fclose(f);
+    return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+  }
+  return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
 }
 
 }  // namespace
@@ -803,7 +862,7 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
   const std::string& text = standalone ? run->text : data;
   const char* const base = text.data();
   const char* const end = base + text.size();
-  const int T = (int)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<size_t>(1, text.size() >> 20));
+  const int T = (int)std::min<size_t>((size_t)std::max(1, std::min(32, usable_cores())), std::max<size_t>(1, text.size() >> 20));
   std::vector<Piece> pieces((size_t)T);
   {
     const char* cut = base;
@@ -862,12 +921,25 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
             return;
           }
         }
-        // the buffer ends in NUL and a field ends at white space, so strtod cannot run past it
-        char* endp = nullptr;
-        const double sc = strtod(field[4].data(), &endp);
-        if (endp != field[4].data() + field[4].size()) {
-          pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
-          return;
+        // correctly rounded double, then float32 (what read_csv + the constructor's cast give); from_chars is
+        // several times faster than strtod and needs no terminator; it takes no leading '+'
+        double sc = 0.0;
+        {
+          const char* s0 = field[4].data();
+          const char* s1 = s0 + field[4].size();
+          if (s0 < s1 && *s0 == '+') ++s0;
+          const auto res = std::from_chars(s0, s1, sc);
+          if (res.ec == std::errc::result_out_of_range) {  // strtod's answer for these: +-inf / +-0
+            char* endp = nullptr;
+            sc = strtod(field[4].data(), &endp);  // (the buffer ends in NUL and a field ends at white space)
+            if (endp != s1) {
+              pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
+              return;
+            }
+          } else if (res.ec != std::errc() || res.ptr != s1) {
+            pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
+            return;
+          }
         }
         if (pc.tag.data() == nullptr && nf >= 6) pc.tag = field[5];
         if (pc.q_runs.empty() || pc.q_runs.back().first != field[0]) pc.q_runs.emplace_back(field[0], 0);
@@ -1109,36 +1181,7 @@ int ffx_run_write(const ffx_run* run, const char* path, const float* scores, con
     }
   };
   const int64_t n_rows = run->pair_off.empty() ? 0 : run->pair_off.back();
-  const int T = (int)std::min<int64_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), std::max<int64_t>(1, n_rows >> 15));
-  std::vector<std::string> bufs((size_t)T);
-  bool ok = true;
-  try {
-    // a batch holds about 64K lines per thread
-    const int64_t avg = std::max<int64_t>(1, n_rows / std::max<int64_t>(1, nq));
-    const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
-    for (int64_t q0 = 0; q0 < nq && ok; q0 += q_per_thread * T) {
-      std::vector<std::thread> pool;
-      int used = 0;
-      for (int t = 0; t < T; ++t) {
-        const int64_t lo = q0 + t * q_per_thread, hi = std::min(nq, lo + q_per_thread);
-        if (lo >= hi) break;
-        ++used;
-        if (t > 0) pool.emplace_back(format, lo, hi, std::ref(bufs[(size_t)t]));
-      }
-      format(q0, std::min(nq, q0 + q_per_thread), bufs[0]);
-      for (auto& th : pool) th.join();
-      for (int t = 0; t < used && ok; ++t)
-        ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
-    }
-  } catch (const std::bad_alloc&) {
-    fclose(f);
-    return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
-  }
-  if (!ok) {
-    fclose(f);
-    return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
-  }
-  return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+  return write_formatted(f, path, nq, n_rows, format);
 }
 
 // Ranking.save (ranking.py:348-366) for a frame that is already grouped by query: the q_id and id
@@ -1190,38 +1233,7 @@ int save_rows(const char* path, const std::vector<std::string_view>& q_names, in
       }
     }
   };
-  const int T = (int)std::min<int64_t>(std::max(1, std::min(16, usable_cores())), std::max<int64_t>(1, n_pairs >> 15));
-  std::vector<std::string> bufs((size_t)T);
-  bool ok = true;
-  try {
-    const int64_t avg = std::max<int64_t>(1, n_pairs / std::max<int64_t>(1, n_queries));
-    const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
-    for (int64_t q0 = 0; q0 < n_queries && ok; q0 += q_per_thread * T) {
-      std::vector<std::thread> pool;
-      int used = 0;
-      for (int t = 0; t < T; ++t) {
-        const int64_t lo = q0 + t * q_per_thread, hi = std::min(n_queries, lo + q_per_thread);
-        if (lo >= hi) break;
-        ++used;
-        if (t > 0) pool.emplace_back(format, lo, hi, std::ref(bufs[(size_t)t]));
-      }
-      format(q0, std::min(n_queries, q0 + q_per_thread), bufs[0]);
-      for (auto& th : pool) th.join();
-      for (int t = 0; t < used && ok; ++t)
-        ok = bufs[(size_t)t].empty() || fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
-    }
-  } catch (const std::bad_alloc&) {
-    fclose(f);
-    return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
-  } catch (const std::system_error&) {
-    fclose(f);
-    return ffx_fail(FFX_OOM, "could not start host threads while writing %s", path);
-  }
-  if (!ok) {
-    fclose(f);
-    return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
-  }
-  return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
+  return write_formatted(f, path, n_queries, n_pairs, format);
 }
 
 int check_save_args(const char* path, const int64_t* pair_off, int64_t n_queries, int64_t n_pairs, const char* tag) {

@@ -191,6 +191,69 @@ int main(int argc, char** argv) {
     if (ffx_run_save(out.c_str(), qb, 5, 3, off3, ib, 8, 3, sc, "name") == FFX_OK) return 1;  // fewer query ids than queries
     if (ffx_run_save(out.c_str(), qb, 5, 2, bad_off, ib, 8, 3, sc, "name") == FFX_OK) return 1;
   }
+  // ---- the coded writer, the string coder and the threaded gathers (round 2)
+  {
+    const char qb[] = "qa\nqb", names[] = "D1\nD2\nD3";
+    const int64_t off[] = {0, 2, 3};
+    const float sc[] = {1.5f, 0.25f, 1e-7f};
+    const int32_t codes[] = {2, 0, 1}, bad_codes[] = {2, 3, 1}, neg_codes[] = {2, -1, 1};
+    if (ffx_run_save_coded(out.c_str(), qb, 5, 2, off, names, 8, 3, codes, 3, sc, "name") != FFX_OK) return 1;
+    if (ffx_run_save_coded(out.c_str(), qb, 5, 2, off, names, 8, 3, bad_codes, 3, sc, "name") == FFX_OK) return 1;
+    if (ffx_run_save_coded(out.c_str(), qb, 5, 2, off, names, 8, 3, neg_codes, 3, sc, "name") == FFX_OK) return 1;
+    if (ffx_run_save_coded(out.c_str(), qb, 5, 2, off, names, 8, 4, codes, 3, sc, "name") == FFX_OK) return 1;  // fewer names than announced
+    for (int round = 0; round < 40; ++round) {
+      const int64_t n = 1 + (int64_t)(rnd() % 5000);
+      std::string blob;
+      std::vector<std::string> items;
+      for (int64_t i = 0; i < n; ++i) {
+        std::string w = rnd() % 9 == 0 ? std::string() : "k" + std::to_string(rnd() % (1 + n / 3));
+        if (rnd() % 50 == 0) w += std::string(1 + rnd() % 40, 'x');
+        items.push_back(w);
+        if (i) blob.push_back('\n');
+        blob += w;
+      }
+      std::vector<int32_t> code((size_t)n);
+      char* got = nullptr;
+      int64_t got_bytes = 0, got_n = 0;
+      const int threads = 1 + (int)(rnd() % 5);
+      if (ffx_strings_code(blob.data(), (int64_t)blob.size(), '\n', n, threads, code.data(), &got, &got_bytes, &got_n) != FFX_OK) return 1;
+      std::vector<std::string> distinct;
+      {
+        std::string cur;
+        for (int64_t b = 0; b <= got_bytes; ++b) {
+          if (b == got_bytes || got[b] == '\n') {
+            distinct.push_back(cur);
+            cur.clear();
+          } else {
+            cur.push_back(got[b]);
+          }
+        }
+      }
+      if (got_n > 0 && (int64_t)distinct.size() != got_n) return 1;
+      for (int64_t i = 0; i < n; ++i)
+        if (code[(size_t)i] < 0 || code[(size_t)i] >= got_n || distinct[(size_t)code[(size_t)i]] != items[(size_t)i]) return 1;
+      ffx_buffer_free(got);
+      if (ffx_strings_code(blob.data(), (int64_t)blob.size(), '\n', n + 1, threads, code.data(), &got, &got_bytes, &got_n) == FFX_OK) return 1;  // wrong count
+      // gathers and the join-free interpolate on the same sizes
+      std::vector<float> src((size_t)n), dense((size_t)n), res((size_t)n);
+      std::vector<int32_t> perm((size_t)n);
+      for (int64_t i = 0; i < n; ++i) src[(size_t)i] = (float)(rnd() % 1000) * 0.25f, dense[(size_t)i] = (float)(rnd() % 77), perm[(size_t)i] = (int32_t)i;
+      for (int64_t i = n - 1; i > 0; --i) std::swap(perm[(size_t)i], perm[(size_t)(rnd() % (uint64_t)(i + 1))]);
+      if (ffx_host_take32(src.data(), n, perm.data(), n, threads, res.data()) != FFX_OK) return 1;
+      for (int64_t i = 0; i < n; ++i)
+        if (res[(size_t)i] != src[(size_t)perm[(size_t)i]]) return 1;
+      int32_t nan = 0;
+      if (ffx_host_interpolate(src.data(), dense.data(), perm.data(), n, 0.25f, 0.75f, threads, res.data(), &nan) != FFX_OK || nan) return 1;
+      if (n > 1) {
+        std::vector<int32_t> twice = perm;
+        twice[0] = twice[1];
+        if (ffx_host_interpolate(src.data(), dense.data(), twice.data(), n, 0.25f, 0.75f, threads, res.data(), &nan) == FFX_OK) return 1;
+        twice[0] = (int32_t)n;
+        if (ffx_host_interpolate(src.data(), dense.data(), twice.data(), n, 0.25f, 0.75f, threads, res.data(), &nan) == FFX_OK) return 1;
+        if (ffx_host_take32(src.data(), n, twice.data(), n, threads, res.data()) == FFX_OK) return 1;
+      }
+    }
+  }
   ffx_ids_destroy(ids);
   remove(in.c_str());
   remove(out.c_str());

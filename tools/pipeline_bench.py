@@ -88,6 +88,25 @@ R._CODED_FROM_FILE_ROWS = keep
 t0 = time.perf_counter()
 index.rerank_file(run_in, work / "out_rerank_file.tsv", 0.1, queries)
 out["rerank_file_s"] = time.perf_counter() - t0
+# ... and its stages
+table = index._native_id_table(index.mode)
+t0 = time.perf_counter()
+run = native.RunFile(run_in, table)
+t1 = time.perf_counter()
+q_ids = run.query_ids()
+r_off, r_ord, r_sparse = run.export(0)
+t2 = time.perf_counter()
+qvec = np.ascontiguousarray(index.encode_queries([queries[q] for q in q_ids]))
+_, interp, order = index._score_pairs(qvec, r_off, r_ord, index.mode, r_sparse, 0.1, sort=True)
+t3 = time.perf_counter()
+run.write(work / "out_stages.tsv", interp, order, tag=None)
+t4 = time.perf_counter()
+run.close()
+t5 = time.perf_counter()
+plain = native.RunFile(run_in, None)
+t6 = time.perf_counter()
+plain.close()
+out["rerank_file_stages_s"] = {"parse_and_resolve": t1 - t0, "export": t2 - t1, "encode_and_score": t3 - t2, "write": t4 - t3, "parse_without_table": t6 - t5}
 out["coded_equals_frame"] = filecmp.cmp(work / "out_coded.tsv", work / "out_frame.tsv", shallow=False)
 a = (work / "out_coded.tsv").read_bytes().splitlines()
 b = (work / "out_rerank_file.tsv").read_bytes().splitlines()
