@@ -366,7 +366,7 @@ int ffx_ids_lookup_packed(const ffx_ids* t, const char* data, int64_t n_bytes, c
     while (mine < seen && !miss.compare_exchange_weak(seen, mine)) {
     }
   };
-  const int T = (int)std::min<int64_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)), n >> 15);  // >= 32K strings each
+  const int T = (int)std::min<int64_t>(std::max(1, std::min(32, usable_cores())), n >> 15);  // >= 32K strings each
   if (T <= 1) {
     work(0, n);
   } else {

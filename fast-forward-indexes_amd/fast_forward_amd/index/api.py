@@ -416,7 +416,9 @@ class Index(abc.ABC):
             by_code = self._lookup_optional(names, self.mode).astype(np.int32, copy=False)
             # a ranking's rows never change: the resolved candidate list is kept with it ("amortise /
             # cache the resolved CSR per run")
-            cached = (key, names, codes, by_code[codes], bool(by_code.size and by_code.min() < 0))
+            from fast_forward_amd import native
+
+            cached = (key, names, codes, native.take32(np.ascontiguousarray(by_code), codes), bool(by_code.size and by_code.min() < 0))
             ranking._ordinal_cache = cached
         ordinals = cached[3]
         if not missing_ok and cached[4]:
