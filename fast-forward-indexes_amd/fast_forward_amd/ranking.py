@@ -572,6 +572,11 @@ class Ranking:
             # rows of a query are adjacent (always, for a sorted frame): rank = position inside the run
             starts = np.zeros(len(self._q_order) + 1, dtype=np.int64)
             np.cumsum(np.bincount(q_no, minlength=len(self._q_order)), out=starts[1:])
+            if self._coded is not None and cutoff >= int(np.diff(starts).max()):
+                # nothing to cut (the usual `.cut(k)` on a run of depth k): the same rows; the arrays are shared,
+                # a Ranking never changes them
+                c = self._coded
+                return Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"], c["id_names"], c["score"], c["q_texts"])
             keep = np.flatnonzero(np.arange(len(q_no)) - starts[q_no] < cutoff)
             present = np.flatnonzero(np.bincount(q_no[keep], minlength=len(self._q_order)))
             renumber = np.full(len(self._q_order), -1, dtype=np.int64)

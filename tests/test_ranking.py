@@ -430,7 +430,7 @@ def test_from_file_coded_equals_the_frame_route(tmp_path, monkeypatch):
         assert coded._coded is not None and coded._frame is None and frame._coded is None
         assert coded._q_order == frame._q_order and np.array_equal(coded._q_no, frame._q_no) and coded.name == frame.name
         assert coded.has_queries == frame.has_queries == (qs is not None)
-        for derive in (lambda r: r, lambda r: r.cut(100), lambda r: r.cut(1), lambda r: r.attach_queries(queries), lambda r: r.cut(7).attach_queries(queries)):
+        for derive in (lambda r: r, lambda r: r.cut(100), lambda r: r.cut(1), lambda r: r.cut(10**6), lambda r: r.attach_queries(queries), lambda r: r.cut(7).attach_queries(queries)):
             a, b = derive(coded), derive(frame)
             assert a._coded is not None and (a is coded or a._frame is None)  # derived rankings stay coded, no frame is grown
             a.save(tmp_path / "a.tsv")
