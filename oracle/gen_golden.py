@@ -435,6 +435,36 @@ def coalesce_case():
     return info
 
 
+def run_file_case():
+    """Ranking.from_file (ranking.py:388-409) + cut + save on a run file large enough for the build to read it
+    natively into its coded form: the reference's rows (as codes into sorted name tables), its cut(10), and the
+    SHA-256 of what its save() writes."""
+    import tempfile
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    from _cases import run_file_text
+
+    text, queries = run_file_text()
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / "run.tsv"
+        path.write_text(text, encoding="utf-8")
+        r = Ranking.from_file(path, queries=queries)
+        for tag, rk in (("full", r), ("cut10", r.cut(10))):
+            df = rk._df
+            q_names, id_names = np.unique(df["q_id"].to_numpy().astype(str)), np.unique(df["id"].to_numpy().astype(str))
+            out[f"{tag}_q_names"], out[f"{tag}_id_names"] = q_names, id_names
+            out[f"{tag}_q_code"] = np.searchsorted(q_names, df["q_id"].to_numpy().astype(str)).astype(np.int32)
+            out[f"{tag}_id_code"] = np.searchsorted(id_names, df["id"].to_numpy().astype(str)).astype(np.int32)
+            out[f"{tag}_score"] = df["score"].to_numpy().astype(np.float32)
+            out[f"{tag}_query"] = np.array([hashlib.sha256("\n".join(df["query"].tolist()).encode()).hexdigest()])
+            rk.save(Path(tmp) / f"{tag}.tsv")
+            out[f"{tag}_saved_sha256"] = np.array([hashlib.sha256((Path(tmp) / f"{tag}.tsv").read_bytes()).hexdigest()])
+        out["name"] = np.array([str(r.name)])
+    np.savez_compressed(OUT / "run_file.npz", **out)
+    return {"rows": int(len(out["full_score"])), "text_sha256": hashlib.sha256(text.encode()).hexdigest()}
+
+
 def f64_cases():
     """The reference's DEFAULT arithmetic on any index larger than one chunk: float64 chunks after the
     first (index/memory.py:106), hence float64 products and sums, cast to float32 at the very end
@@ -473,6 +503,8 @@ def main():
             manifest["cases"]["coalesce"] = coalesce_case()
         if sys.argv[2] == "f64":
             manifest["cases"].update(f64_cases())
+        if sys.argv[2] == "run_file":
+            manifest["cases"]["run_file"] = run_file_case()
         if sys.argv[2] == "es_docs":
             manifest["cases"]["early_stopping_docs"] = early_stopping_docs_case()
         if sys.argv[2] == "sub200k":
@@ -504,6 +536,7 @@ def main():
     manifest["cases"]["early_stopping_docs"] = early_stopping_docs_case()
     manifest["cases"]["coalesce"] = coalesce_case()
     manifest["cases"].update(f64_cases())
+    manifest["cases"]["run_file"] = run_file_case()
     manifest["cases"]["sub200k"] = sub200k_case()
     (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     total = sum(f.stat().st_size for f in OUT.iterdir())

@@ -208,3 +208,23 @@ def load_pq_case(name: str) -> PQCase:
         doc_names=[f"D{d}" for d in doc_of_row], psg_names=[f"P{r}" for r in range(n_rows)], q_names=z["q_names"].tolist(),
         codes=codes, codewords=codewords, raw_vectors=raw,
     )
+
+
+def run_file_text(seed: int = 77) -> tuple[str, dict]:
+    """A TREC run file big enough (>= 65 536 rows, >= 256 KB) for ``Ranking.from_file`` to read it natively into
+    the coded form: 150 queries in shuffled order, 300-800 candidates each in shuffled order, distinct scores
+    inside a query (the reference leaves the order of exact ties open), negative and tiny scores, some non-ASCII
+    ids, integer-looking ids for some queries.  Returns (text, queries).  Used by oracle/gen_golden.py (fed to the
+    reference) and by the test that compares the build with the stored result."""
+    rng = np.random.default_rng(seed)
+    lines = []
+    q_ids = [f"q{i:03d}" for i in rng.permutation(150)]
+    for q in q_ids:
+        k = int(rng.integers(300, 800))
+        docs = rng.choice(20_000, size=k, replace=False)
+        scores = rng.permutation(k).astype(np.float64) * 0.0625 - 7.0  # distinct, exactly representable, both signs
+        scores[0] = 1e-7 * (1 + int(q[1:]))
+        for i, (d, s) in enumerate(zip(docs, scores)):
+            name = f"dö{d}" if d % 13 == 0 else (f"{d}" if int(q[1:]) % 10 == 0 else f"D{d}")
+            lines.append(f"{q} Q0 {name} {i + 1} {float(s)!r} bm25")
+    return "\n".join(lines) + "\n", {q: f"text of {q}" for q in q_ids}

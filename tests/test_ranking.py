@@ -441,3 +441,28 @@ def test_from_file_coded_equals_the_frame_route(tmp_path, monkeypatch):
             assert a == b and a._df.equals(b._df)
     with pytest.raises(ValueError, match="Queries are incomplete"):
         Ranking.from_file(path, queries={q: "x" for q in q_ids[:-1]})
+
+
+def test_from_file_cut_save_match_the_reference_on_a_large_run(tmp_path):
+    """Golden: the reference's ``Ranking.from_file(path, queries)``, ``.cut(10)`` and ``.save()`` on a 82 k-row run
+    (tests/golden/run_file.npz, oracle/gen_golden.py::run_file_case) against the build's coded route: same rows in the
+    same order, same scores (bits), same query texts, and the SAME BYTES written by ``save``."""
+    import hashlib
+
+    from _cases import GOLDEN, run_file_text
+    from fast_forward_amd import Ranking
+
+    z = np.load(GOLDEN / "run_file.npz")
+    text, queries = run_file_text()
+    path = tmp_path / "run.tsv"
+    path.write_text(text, encoding="utf-8")
+    r = Ranking.from_file(path, queries=queries)
+    assert r._coded is not None and r._frame is None and str(r.name) == str(z["name"][0])
+    for tag, rk in (("full", r), ("cut10", r.cut(10))):
+        rk.save(tmp_path / f"{tag}.tsv")
+        assert hashlib.sha256((tmp_path / f"{tag}.tsv").read_bytes()).hexdigest() == str(z[f"{tag}_saved_sha256"][0])
+        df = rk._df
+        assert df["q_id"].tolist() == z[f"{tag}_q_names"][z[f"{tag}_q_code"]].tolist()
+        assert df["id"].tolist() == z[f"{tag}_id_names"][z[f"{tag}_id_code"]].tolist()
+        assert np.array_equal(df["score"].to_numpy().view(np.uint32), z[f"{tag}_score"].view(np.uint32))
+        assert hashlib.sha256("\n".join(df["query"].tolist()).encode()).hexdigest() == str(z[f"{tag}_query"][0])
