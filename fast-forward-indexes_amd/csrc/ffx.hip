@@ -1892,9 +1892,8 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
                                      bad_pair, stats, &handled);
     if (rc_small != FFX_OK || handled) return rc_small;
   }
-  // slices cut at query boundaries: ~2M pairs (a ~1 ms device pass at 768-d fp32) when the caller's
-  // buffers are page-locked and the copies truly overlap, ~6M when they are pageable and every copy
-  // blocks the caller for its duration (measured: tools/regions.py --only-ii)
+  // slices cut at query boundaries: ~4M pairs (a ~2 ms device pass at 768-d fp32) when the caller's
+  // buffers are page-locked, ~6M when they are ordinary memory (measured: tools/score_trace.py)
   int64_t per_slice = 6 << 20;
   {
     hipPointerAttribute_t attr;
@@ -1949,31 +1948,6 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     if (!idx->score_plans[i]) FFX_TRY(ffx_plan_create(idx, &idx->score_plans[i]));
   ffx_stats acc;
   memset(&acc, 0, sizeof acc);
-  auto fetch = [&](int c) -> int {
-    ffx_plan* pl = idx->score_plans[c % n_plans];
-    const int64_t p0 = pair_off[cut[c]];
-    FFX_TRY(ffx_plan_fetch(pl, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr,
-                           out_order ? out_order + p0 : nullptr));
-    if (stats) {
-      ffx_stats s;
-      FFX_TRY(ffx_plan_stats(pl, &s));
-      acc.n_queries += s.n_queries;
-      acc.n_pairs += s.n_pairs;
-      acc.n_rows += s.n_rows;
-      acc.algorithmic_bytes += s.algorithmic_bytes;
-      acc.ms_expand += s.ms_expand;
-      acc.ms_gather_dot += s.ms_gather_dot;
-      acc.ms_reduce += s.ms_reduce;
-      acc.ms_sort += s.ms_sort;
-      acc.ms_total += s.ms_total;
-      acc.kernel_variant = s.kernel_variant;
-    }
-    return FFX_OK;
-  };
-  // FFX_SCORE_TRACE=1: host-side timeline of the slices on stderr (us since the call began)
-  const bool trace = getenv("FFX_SCORE_TRACE") != nullptr;
-  const auto t_begin = std::chrono::steady_clock::now();
-  auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
   auto add_stats = [&](ffx_plan* pl) -> int {
     if (!stats) return FFX_OK;
     ffx_stats s;
@@ -1990,6 +1964,17 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     acc.kernel_variant = s.kernel_variant;
     return FFX_OK;
   };
+  auto fetch = [&](int c) -> int {  // blocking: slice c's results into the caller's buffers
+    ffx_plan* pl = idx->score_plans[c % n_plans];
+    const int64_t p0 = pair_off[cut[c]];
+    FFX_TRY(ffx_plan_fetch(pl, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr,
+                           out_order ? out_order + p0 : nullptr));
+    return add_stats(pl);
+  };
+  // FFX_SCORE_TRACE=1: host-side timeline of the slices on stderr (us since the call began)
+  const bool trace = getenv("FFX_SCORE_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
   auto send_out = [&](int c) -> int {  // queue slice c's results behind its kernels
     ffx_plan* pl = idx->score_plans[c % n_plans];
     const int64_t p0 = pair_off[cut[c]];

@@ -364,10 +364,13 @@ int ffx_run_save_coded(const char* path, const char* q_blob, int64_t q_bytes, in
                        const char* name_blob, int64_t name_bytes, int64_t n_names, const int32_t* id_codes, int64_t n_pairs,
                        const float* scores, const char* tag);
 
-/* one-shot, host buffers in, host buffers out: the batch is cut into slices of whole queries
- * that alternate between two plans kept with the index, so uploads, scoring and downloads of
- * neighbouring slices overlap (results do not depend on the slicing; stats are summed over the
- * slices).  FFX_SCORE_SLICE_PAIRS in the environment overrides the slice size (pairs). */
+/* one-shot, host buffers in, host buffers out.  A small batch of single-row candidates is submitted in one go
+ * and waited for once.  A large batch is cut into slices of whole queries that rotate through three plans kept
+ * with the index: the slices' kernels run in order on one stream while the next slice is uploaded and the
+ * previous one's results leave (asynchronously into page-locked buffers, through helper threads into ordinary
+ * ones), so uploads, scoring and downloads overlap for either kind of memory.  Results do not depend on the
+ * slicing; stats are summed over the slices.  Environment: FFX_SCORE_SLICE_PAIRS overrides the slice size
+ * (pairs), FFX_SCORE_TRACE=1 prints the host-side timeline of the slices on stderr. */
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               const int64_t* pair_off, const int32_t* pair_ids, const float* sparse, int mode,
               double alpha, uint32_t flags, float* out_ff, float* out_interp, int32_t* out_order,
