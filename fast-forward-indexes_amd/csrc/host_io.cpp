@@ -48,6 +48,22 @@ inline int usable_cores() {
   return n;
 }
 
+// body(t) for t in 0..T-1, t = 0 on the calling thread.  If a thread cannot be started, the ones already running are
+// joined before the std::system_error goes on to the caller (a std::thread destroyed while joinable ends the process).
+template <class Body>
+void run_threads(int T, Body&& body) {
+  std::vector<std::thread> pool;
+  pool.reserve(T > 1 ? (size_t)(T - 1) : 0);
+  try {
+    for (int t = 1; t < T; ++t) pool.emplace_back([&body, t] { body(t); });
+  } catch (...) {
+    for (auto& th : pool) th.join();
+    throw;
+  }
+  body(0);
+  for (auto& th : pool) th.join();
+}
+
 inline uint64_t fnv1a(const char* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
   for (size_t i = 0; i < n; ++i) {
@@ -247,6 +263,7 @@ int write_formatted(FILE* f, const char* path, int64_t n_queries, int64_t n_rows
   std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
   int used[2] = {0, 0};
   bool ok = true;
+  std::atomic<bool> oom(false);
   try {
     const int64_t avg = std::max<int64_t>(1, n_rows / std::max<int64_t>(1, n_queries));
     const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
@@ -254,12 +271,24 @@ int write_formatted(FILE* f, const char* path, int64_t n_queries, int64_t n_rows
     for (int64_t q0 = 0; (q0 < n_queries || used[(round + 1) & 1] > 0) && ok; q0 += q_per_thread * T, ++round) {
       std::vector<std::string>& mine = bufs[round & 1];
       std::vector<std::thread> pool;
+      pool.reserve((size_t)T);
       used[round & 1] = 0;
-      for (int t = 0; t < T; ++t) {
-        const int64_t lo = q0 + t * q_per_thread, hi = std::min(n_queries, lo + q_per_thread);
-        if (lo >= hi) break;
-        ++used[round & 1];
-        pool.emplace_back(format, lo, hi, std::ref(mine[(size_t)t]));
+      try {
+        for (int t = 0; t < T; ++t) {
+          const int64_t lo = q0 + t * q_per_thread, hi = std::min(n_queries, lo + q_per_thread);
+          if (lo >= hi) break;
+          pool.emplace_back([&format, &oom, lo, hi, buf = &mine[(size_t)t]] {
+            try {
+              format(lo, hi, *buf);
+            } catch (const std::bad_alloc&) {  // (an exception leaving a thread would end the process)
+              oom.store(true);
+            }
+          });
+          ++used[round & 1];
+        }
+      } catch (...) {  // join what was started before the error goes on
+        for (auto& th : pool) th.join();
+        throw;
       }
       // meanwhile: the previous round's buffers go to the file
       std::vector<std::string>& prev = bufs[(round + 1) & 1];
@@ -267,6 +296,7 @@ int write_formatted(FILE* f, const char* path, int64_t n_queries, int64_t n_rows
         ok = prev[(size_t)t].empty() || fwrite(prev[(size_t)t].data(), 1, prev[(size_t)t].size(), f) == prev[(size_t)t].size();
       used[(round + 1) & 1] = 0;
       for (auto& th : pool) th.join();
+      if (oom.load()) throw std::bad_alloc();
     }
   } catch (const std::bad_alloc&) {
     fclose(f);
@@ -426,12 +456,7 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
   int T = n_threads > 0 ? n_threads : usable_cores();
   T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
   constexpr int S = 256;
-  auto in_threads = [&](auto&& body) {  // body(t) for t in 0..T-1
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(body, t);
-    body(0);
-    for (auto& th : pool) th.join();
-  };
+  auto in_threads = [&](auto&& body) { run_threads(T, body); };  // body(t) for t in 0..T-1
   try {
     // 1. where every string starts: separators counted per byte range, then written per byte range
     std::vector<int64_t> seps_in((size_t)T + 1, 0);
@@ -626,10 +651,7 @@ int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_
     }
   };
   try {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    run_threads(T, [&](int) { work(); });
   } catch (const std::system_error&) {
     return ffx_fail(FFX_OOM, "could not start host threads");
   }
@@ -668,10 +690,7 @@ int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32
       }
     };
     try {
-      std::vector<std::thread> pool;
-      for (int t = 1; t < T; ++t) pool.emplace_back(work);
-      work();
-      for (auto& th : pool) th.join();
+      run_threads(T, [&](int) { work(); });
     } catch (const std::system_error&) {
       return false;
     }
