@@ -368,6 +368,9 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     t_route = time.perf_counter()
     scorer.set_pairs(pair_off, ids, sparse, MODE_NO[args.mode])
     t_route = time.perf_counter() - t_route
+    t_route_again = time.perf_counter()  # a batch after the first: the scorer's host and device buffers exist already
+    scorer.set_pairs(pair_off, ids, sparse, MODE_NO[args.mode])
+    t_route_again = time.perf_counter() - t_route_again
     exact = args.sum == "exact"
 
     for _ in range(args.warmup):
@@ -438,7 +441,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                              "stream; exchange and merge (+ per-query order) on the communicator's stream.  In the timed loop batch i's exchange + merge "
                              "overlap batch i+1's scoring, so a step costs about max(local, exchange + merge)",
             "owned_pairs_per_rank": [int(t["own_pairs"]) for t in per_rank],
-            "route_and_upload_s": t_route,
+            "route_and_upload_s": t_route, "route_and_upload_next_batch_s": t_route_again,
             "device": dev["name"],
             "index_capacity_rows_per_gpu": cap, "index_capacity_rows_total": world * cap,
         }

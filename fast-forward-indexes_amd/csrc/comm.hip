@@ -26,8 +26,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -624,74 +626,116 @@ int ffx_route(const int64_t* pair_off, int64_t n_queries, const int32_t* pair_id
   const int64_t P = pair_off[n_queries];
   if (P > 0 && !pair_ids) return ffx_fail(FFX_BAD_ARG, "pair_ids is NULL");
   if (P > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
-  auto holder_of = [&](int64_t p) -> int {
-    if (holder) return holder[p];
-    const int64_t id = pair_ids[p];
-    if (id < doc_bounds[0] || id >= doc_bounds[world]) return -1;
-    return (int)(std::upper_bound(doc_bounds, doc_bounds + world + 1, id) - doc_bounds) - 1;
-  };
   const int64_t base = doc_bounds ? doc_bounds[rank] : 0;
-  // pass 1 (threads over blocks of queries): pairs of each query this rank holds
-  const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (int64_t)std::thread::hardware_concurrency(), P / (1 << 18) + 1}));
-  std::atomic<int64_t> first_bad(INT64_MAX);
-  auto for_query_blocks = [&](auto&& body) {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_thr; ++t) {
-      const int64_t q0 = n_queries * t / n_thr, q1 = n_queries * (t + 1) / n_thr;
-      if (t + 1 < n_thr) pool.emplace_back(body, q0, q1);
-      else body(q0, q1);
-    }
-    for (auto& th : pool) th.join();
-  };
-  local_pair_off[0] = 0;
-  for_query_blocks([&](int64_t q0, int64_t q1) {
-    for (int64_t q = q0; q < q1; ++q) {
-      int64_t mine = 0;
-      for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
-        const int h = holder_of(p);
-        if (h < 0 || h >= world) {
-          int64_t cur = first_bad.load();
-          while (p < cur && !first_bad.compare_exchange_weak(cur, p)) {
-          }
-        }
-        mine += h == rank;
-      }
-      local_pair_off[q + 1] = mine;  // counts now, offsets after the scan below
-    }
-  });
-  if (first_bad.load() != INT64_MAX) {
-    if (bad_pair) *bad_pair = first_bad.load();
-    return ffx_fail(FFX_NOT_FOUND, "pair %lld names a document no rank of the sharded index holds", (long long)first_bad.load());
-  }
-  for (int64_t q = 0; q < n_queries; ++q) local_pair_off[q + 1] += local_pair_off[q];
-  // pass 2: the local CSR (ordinals relative to the shard)
-  if (local_pair_ids)
-    for_query_blocks([&](int64_t q0, int64_t q1) {
-      for (int64_t q = q0; q < q1; ++q) {
-        int64_t at = local_pair_off[q];
-        for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p)
-          if (holder_of(p) == rank) local_pair_ids[at++] = (int32_t)(pair_ids[p] - (holder ? 0 : base));
-      }
-    });
   std::vector<int64_t> qb((size_t)world + 1);
   ffx_query_partition(n_queries, world, qb.data());
-  for (int r = 0; r < world; ++r) send_counts[r] = local_pair_off[qb[r + 1]] - local_pair_off[qb[r]];
-  // owner side: candidates of the owned queries arrive grouped by source rank, first-stage order inside
   const int64_t q_lo = qb[rank], q_hi = qb[rank + 1], lo = pair_off[q_lo], hi = pair_off[q_hi];
   own[0] = q_lo;
   own[1] = q_hi;
   own[2] = lo;
   own[3] = hi - lo;
-  for (int r = 0; r < world; ++r) recv_counts[r] = 0;
-  for (int64_t p = lo; p < hi; ++p) ++recv_counts[holder_of(p)];
-  if (recv_slot) {
-    int64_t next[kMaxWorld];
+  // The holder of every pair is worked out ONCE (threads over blocks of queries) and kept as a byte; the passes
+  // below -- this rank's share of every query, the local CSR, and the owner side's arrival slots -- read it.
+  int n_thr = 1;
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cores = std::min(cores, std::max(1, CPU_COUNT(&set)));
+    n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)32, (int64_t)cores, P / (1 << 18) + 1, std::max<int64_t>(n_queries, 1)}));
+  }
+  std::vector<uint8_t> who;
+  try {
+    who.resize((size_t)std::max<int64_t>(P, 1));
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
+  std::atomic<int64_t> first_bad(INT64_MAX);
+  auto in_threads = [&](auto&& body) {  // body(t) for t in 0..n_thr-1; started threads are joined whatever happens
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n_thr);
+    try {
+      for (int t = 1; t < n_thr; ++t) pool.emplace_back([&body, t] { body(t); });
+    } catch (...) {
+      for (auto& th : pool) th.join();
+      throw;
+    }
+    body(0);
+    for (auto& th : pool) th.join();
+  };
+  try {
+    // pass 1: holders, and how many pairs of each query this rank holds
+    local_pair_off[0] = 0;
+    in_threads([&](int t) {
+      int64_t bad = INT64_MAX;
+      for (int64_t q = n_queries * t / n_thr; q < n_queries * (t + 1) / n_thr; ++q) {
+        int64_t mine = 0;
+        for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
+          int h;
+          if (holder) {
+            h = holder[p];
+          } else {
+            const int64_t id = pair_ids[p];
+            h = (id < doc_bounds[0] || id >= doc_bounds[world]) ? -1 : (int)(std::upper_bound(doc_bounds, doc_bounds + world + 1, id) - doc_bounds) - 1;
+          }
+          if (h < 0 || h >= world) {
+            if (bad == INT64_MAX) bad = p;
+            h = 255;
+          }
+          who[(size_t)p] = (uint8_t)h;
+          mine += h == rank;
+        }
+        local_pair_off[q + 1] = mine;  // counts now, offsets after the scan below
+      }
+      int64_t cur = first_bad.load();
+      while (bad < cur && !first_bad.compare_exchange_weak(cur, bad)) {
+      }
+    });
+    if (first_bad.load() != INT64_MAX) {
+      if (bad_pair) *bad_pair = first_bad.load();
+      return ffx_fail(FFX_NOT_FOUND, "pair %lld names a document no rank of the sharded index holds", (long long)first_bad.load());
+    }
+    for (int64_t q = 0; q < n_queries; ++q) local_pair_off[q + 1] += local_pair_off[q];
+    for (int r = 0; r < world; ++r) send_counts[r] = local_pair_off[qb[r + 1]] - local_pair_off[qb[r]];
+    // pass 2: the local CSR (ordinals relative to the shard)
+    if (local_pair_ids)
+      in_threads([&](int t) {
+        for (int64_t q = n_queries * t / n_thr; q < n_queries * (t + 1) / n_thr; ++q) {
+          int64_t at = local_pair_off[q];
+          for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p)
+            if (who[(size_t)p] == rank) local_pair_ids[at++] = (int32_t)(pair_ids[p] - (holder ? 0 : base));
+        }
+      });
+    // owner side: candidates of the owned queries arrive grouped by source rank, first-stage order inside.  Blocks of
+    // the owned pairs are counted per source by threads; a block's first slot for a source follows from the counts
+    // of the blocks before it.
+    const int64_t n_own = hi - lo;
+    std::vector<int64_t> block_count((size_t)n_thr * kMaxWorld, 0);
+    in_threads([&](int t) {
+      int64_t* c = block_count.data() + (size_t)t * kMaxWorld;
+      for (int64_t p = lo + n_own * t / n_thr; p < lo + n_own * (t + 1) / n_thr; ++p) ++c[who[(size_t)p]];
+    });
     int64_t acc = 0;
     for (int r = 0; r < world; ++r) {
-      next[r] = acc;
-      acc += recv_counts[r];
+      int64_t total = 0;
+      for (int t = 0; t < n_thr; ++t) {
+        const int64_t c = block_count[(size_t)t * kMaxWorld + r];
+        block_count[(size_t)t * kMaxWorld + r] = acc + total;  // becomes: first slot of block t for source r
+        total += c;
+      }
+      recv_counts[r] = total;
+      acc += total;
     }
-    for (int64_t p = lo; p < hi; ++p) recv_slot[p - lo] = (int32_t)next[holder_of(p)]++;
+    if (recv_slot)
+      in_threads([&](int t) {
+        int64_t next[kMaxWorld];
+        for (int r = 0; r < world; ++r) next[r] = block_count[(size_t)t * kMaxWorld + r];
+        for (int64_t p = lo + n_own * t / n_thr; p < lo + n_own * (t + 1) / n_thr; ++p) recv_slot[p - lo] = (int32_t)next[who[(size_t)p]]++;
+      });
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
   }
   return FFX_OK;
 }
@@ -714,6 +758,9 @@ struct ffx_sharded {
   void* recv = nullptr;
   size_t recv_cap = 0;
   std::vector<int64_t> send_counts, recv_counts;
+  // routing outputs, kept between calls (a fresh 140 MB array costs more in page faults than the routing itself)
+  std::vector<int64_t> local_off;
+  std::vector<int32_t> local_ids, slot;
   int64_t own[4] = {0, 0, 0, 0};
   int64_t local_pairs = 0;
   bool have_pairs = false, have_sparse = false;
@@ -732,23 +779,32 @@ int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, cons
   C_TRY(ffx_sharded_sync(s));
   s->have_pairs = false;
   const int64_t P = pair_off[n_queries];
-  std::vector<int64_t> local_off((size_t)n_queries + 1);
   s->send_counts.assign((size_t)world, 0);
   s->recv_counts.assign((size_t)world, 0);
-  // sizes first (no id outputs), then the arrays
-  C_TRY(ffx_route(pair_off, n_queries, pair_ids, holder, holder ? nullptr : s->doc_bounds.data(), rank, world, local_off.data(), nullptr,
-                  s->send_counts.data(), s->recv_counts.data(), nullptr, s->own, bad_pair));
-  std::vector<int32_t> local_ids((size_t)std::max<int64_t>(local_off[n_queries], 1));
-  std::vector<int32_t> slot((size_t)std::max<int64_t>(s->own[3], 1));
+  // one routing pass: the outputs are sized for the worst case (every pair local; the owned block is known beforehand)
+  std::vector<int64_t> qb((size_t)world + 1);
+  ffx_query_partition(n_queries, world, qb.data());
+  std::vector<int64_t>& local_off = s->local_off;
+  std::vector<int32_t>& local_ids = s->local_ids;
+  std::vector<int32_t>& slot = s->slot;
+  try {
+    if (local_off.size() < (size_t)n_queries + 1) local_off.resize((size_t)n_queries + 1);
+    if (local_ids.size() < (size_t)std::max<int64_t>(P, 1)) local_ids.resize((size_t)std::max<int64_t>(P, 1));
+    const int64_t n_own = pair_off[qb[(size_t)rank + 1]] - pair_off[qb[(size_t)rank]];
+    if (slot.size() < (size_t)std::max<int64_t>(n_own, 1)) slot.resize((size_t)std::max<int64_t>(n_own, 1));
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  }
   C_TRY(ffx_route(pair_off, n_queries, pair_ids, holder, holder ? nullptr : s->doc_bounds.data(), rank, world, local_off.data(), local_ids.data(),
                   s->send_counts.data(), s->recv_counts.data(), slot.data(), s->own, bad_pair));
-  (void)P;
   s->local_pairs = local_off[n_queries];
   for (int i = 0; i < 2; ++i) {
     int64_t bad_local = -1;
-    int rc = ffx_plan_set_pairs(s->plans[i], local_off.data(), n_queries, local_ids.data(), nullptr, mode, &bad_local);
+    // the second plan scores the same lists: it takes them over from the first on the device
+    int rc = i == 0 ? ffx_plan_set_pairs(s->plans[0], local_off.data(), n_queries, local_ids.data(), nullptr, mode, &bad_local)
+                    : ffx_plan_copy_pairs(s->plans[1], s->plans[0]);
     if (rc == FFX_NOT_FOUND && bad_pair && bad_local >= 0) {  // local position -> position in the caller's list
-      const int64_t q = std::upper_bound(local_off.begin(), local_off.end(), bad_local) - local_off.begin() - 1;
+      const int64_t q = std::upper_bound(local_off.begin(), local_off.begin() + n_queries + 1, bad_local) - local_off.begin() - 1;  // (the vector may be longer: it is kept between calls)
       int64_t seen = local_off[q];
       for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
         const bool mine = holder ? holder[p] == rank : (pair_ids[p] >= s->doc_bounds[rank] && pair_ids[p] < s->doc_bounds[rank + 1]);

@@ -837,6 +837,52 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   return FFX_OK;
 }
 
+// Two plans of one index that are to score the same candidate lists (the sharded scorer alternates between two plans
+// as send buffers): the second one takes the validated lists of the first over device to device instead of
+// uploading and validating them again.
+int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src) {
+  if (!dst || !src || dst == src) return fail(FFX_BAD_ARG, "bad argument");
+  if (dst->idx != src->idx) return fail(FFX_BAD_ARG, "the plans belong to different indexes");
+  if (!src->have_pairs || src->lazy_pairs) return fail(FFX_BAD_ARG, "ffx_plan_set_pairs has not succeeded on the source plan");
+  FFX_HIP(hipSetDevice(dst->device));
+  const int64_t Q = src->n_queries, P = src->n_pairs;
+  dst->have_pairs = false;
+  dst->lazy_pairs = false;
+  dst->ran = false;
+  const size_t pb = std::max<size_t>((size_t)P, 1);
+  FFX_TRY(dst->pair_off.ensure((size_t)(Q + 1) * sizeof(int64_t)));
+  FFX_TRY(dst->pair_ids.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(dst->cnt.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(dst->seg_off.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(dst->ff.ensure(pb * sizeof(float)));
+  if (src->have_sparse) {
+    FFX_TRY(dst->sparse.ensure(pb * sizeof(float)));
+    FFX_TRY(dst->interp.ensure(pb * sizeof(float)));
+  }
+  const size_t rb = std::max<size_t>((size_t)src->n_rows, 1);
+  FFX_TRY(dst->desc.ensure(rb * sizeof(int2)));
+  if (src->n_rows != P) FFX_TRY(dst->rs.ensure(rb * sizeof(float)));
+  hipStream_t st = dst->stream;
+  FFX_HIP(hipStreamSynchronize(src->stream));
+  FFX_HIP(hipMemcpyAsync(dst->pair_off.p, src->pair_off.p, (size_t)(Q + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+  if (P > 0) {
+    FFX_HIP(hipMemcpyAsync(dst->pair_ids.p, src->pair_ids.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (src->have_sparse) FFX_HIP(hipMemcpyAsync(dst->sparse.p, src->sparse.p, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  FFX_HIP(hipMemcpyAsync(dst->cnt.p, src->cnt.p, (size_t)(P + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  FFX_HIP(hipMemcpyAsync(dst->seg_off.p, src->seg_off.p, (size_t)(P + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  FFX_HIP(hipStreamSynchronize(st));
+  dst->n_queries = Q;
+  dst->n_pairs = P;
+  dst->n_rows = src->n_rows;
+  dst->mode = src->mode;
+  dst->have_sparse = src->have_sparse;
+  dst->host_pair_off = src->host_pair_off;
+  dst->order_base = src->order_base;
+  dst->have_pairs = true;
+  return FFX_OK;
+}
+
 // Candidate lists for ffx_plan_early_stopping: uploaded, NOT validated.  An ordinal that names no
 // row (e.g. -1 for an id the host could not resolve) is an error only if early stopping actually
 // reaches it -- the reference looks ids up interval by interval (index/base.py:362-371).

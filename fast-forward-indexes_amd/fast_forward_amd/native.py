@@ -26,7 +26,7 @@ SYMBOLS = (
     "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
     "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
-    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs",
+    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs",
     "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
         "ffx_plan_destroy": ([vp], C.c_int),
         "ffx_plan_set_queries": ([vp, vp, i64], C.c_int),
         "ffx_plan_set_queries_device": ([vp, vp, i64], C.c_int),
+        "ffx_plan_copy_pairs": ([vp, vp], C.c_int),
         "ffx_plan_set_pairs": ([vp, vp, i64, vp, vp, C.c_int, P(i64)], C.c_int),
         "ffx_plan_run": ([vp, C.c_double, C.c_uint32], C.c_int),
         "ffx_plan_set_pairs_lazy": ([vp, vp, i64, vp, vp, C.c_int], C.c_int),

@@ -152,6 +152,9 @@ int ffx_plan_set_queries_device(ffx_plan* plan, const float* dev_queries, int64_
  * the first-stage score (may be NULL).  get_indices, index/util.py:12-42, runs here. */
 int ffx_plan_set_pairs(ffx_plan* plan, const int64_t* pair_off, int64_t n_queries,
                        const int32_t* pair_ids, const float* sparse, int mode, int64_t* bad_pair);
+/* dst is to score the same candidate lists as src (two plans of ONE index, e.g. alternating send buffers): the
+ * validated lists are taken over device to device instead of being uploaded and validated again. */
+int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src);
 int ffx_plan_run(ffx_plan* plan, double alpha, uint32_t flags);
 /* ---- early stopping: replaces Index._early_stopping, index/base.py:316-387 ------------------
  * Candidates of a query stand in first-stage rank order.  set_pairs_lazy uploads the lists without
