@@ -105,6 +105,13 @@ small_out_kernel(const uint32_t* __restrict__ ff, const uint32_t* __restrict__ i
   }
 }
 
+// *bad = smallest i with v[i] outside 0 .. limit-1 (stays ~0 when all are inside)
+__global__ void __launch_bounds__(256)
+check_range_kernel(const int32_t* __restrict__ v, int64_t n, int32_t limit, unsigned long long* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (uint32_t)v[i] >= (uint32_t)limit) atomicMin(bad, (unsigned long long)i);
+}
+
 // query number of pair p: the q with pair_off[q] <= p < pair_off[q+1].  First-stage runs give
 // (nearly) every query the same number of candidates, so the proportional guess is almost
 // always right and costs two independent loads; a miss falls back to binary search.

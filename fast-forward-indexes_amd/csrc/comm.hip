@@ -33,6 +33,9 @@
 #include <thread>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "../../include/ffx.h"
 
 int ffx_fail(int code, const char* fmt, ...);  // ffx.hip
@@ -758,6 +761,34 @@ struct ffx_sharded {
   void* recv = nullptr;
   size_t recv_cap = 0;
   std::vector<int64_t> send_counts, recv_counts;
+  // device-side routing (document-range shards): the batch's ids are uploaded once and everything else is derived
+  // in HBM; buffers grow as needed and are kept
+  struct DevArr {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+      if (bytes <= cap) return FFX_OK;
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+      const size_t want = bytes + bytes / 8 + 256;
+      if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        return ffx_fail(FFX_OOM, "hipMalloc(%zu bytes) failed", want);
+      }
+      cap = want;
+      return FFX_OK;
+    }
+    void release() {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+  };
+  DevArr d_ids, d_off, d_who, d_cnt, d_local_off, d_local_ids, d_pos, d_keys, d_arrival, d_slot, d_small, d_tmp;
   // routing outputs, kept between calls (a fresh 140 MB array costs more in page faults than the routing itself)
   std::vector<int64_t> local_off;
   std::vector<int32_t> local_ids, slot;
@@ -770,6 +801,227 @@ struct ffx_sharded {
 
 namespace {
 
+// what both routes end with: room for the scores the owned queries receive
+int sharded_finish_set(ffx_sharded* s, bool have_sparse) {
+  s->have_sparse = have_sparse;
+  const size_t need = (size_t)std::max<int64_t>(s->own[3], 1) * sizeof(float);
+  if (need > s->recv_cap) {
+    C_HIP(hipSetDevice(s->device));
+    if (s->recv) C_HIP(hipFree(s->recv));
+    s->recv = nullptr;
+    s->recv_cap = 0;
+    C_HIP(hipMalloc(&s->recv, need + need / 8));
+    s->recv_cap = need + need / 8;
+  }
+  s->have_pairs = true;
+  return FFX_OK;
+}
+
+// ---- routing on the device (document-range shards) ----------------------------------------------------------------
+// What ffx_route computes on the host, from ONE upload of the batch's ids:
+//   mark     (a workgroup per query) holder of every pair as a byte, this rank's share of the query, and -- inside the
+//            block of queries this rank owns -- how many scores every source rank will send
+//   scan     shares -> offsets of the local CSR
+//   compact  (a workgroup per query) the pairs this rank holds, in first-stage order, as shard-relative ordinals
+//   arrival  the owned pairs sorted by holder with a stable radix pass over the holder byte: position i of the sorted
+//            list is where that pair's score arrives (sources in rank order, first-stage order inside), so
+//            recv_slot[pair] = i
+struct RouteBounds {
+  int64_t b[kMaxWorld + 1];
+};
+
+__global__ void __launch_bounds__(256)
+route_mark_kernel(const int64_t* __restrict__ pair_off, const int32_t* __restrict__ ids, RouteBounds bounds, int world, int rank, int64_t own_lo,
+                  int64_t own_hi, uint8_t* __restrict__ who, int64_t* __restrict__ share, unsigned long long* __restrict__ recv_counts,
+                  unsigned long long* __restrict__ bad) {
+  __shared__ unsigned int hist[kMaxWorld];
+  __shared__ int part[4];
+  const int q = blockIdx.x;
+  if (threadIdx.x < kMaxWorld) hist[threadIdx.x] = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int64_t p = pair_off[q] + threadIdx.x; p < pair_off[q + 1]; p += blockDim.x) {
+    const int64_t id = ids[p];
+    int h = 255;
+    if (id >= bounds.b[0] && id < bounds.b[world]) {
+      int lo = 0, hi = world;  // the h with b[h] <= id < b[h+1] (empty ranges are skipped by construction)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bounds.b[mid] <= id) lo = mid; else hi = mid;
+      }
+      h = lo;
+    } else {
+      atomicMin(bad, (unsigned long long)p);
+    }
+    who[p] = (uint8_t)h;
+    mine += h == rank;
+    if (h != 255 && p >= own_lo && p < own_hi) atomicAdd(&hist[h], 1u);
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) share[q] = (int64_t)part[0] + part[1] + part[2] + part[3];
+  if (threadIdx.x < world && hist[threadIdx.x]) atomicAdd(&recv_counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+route_compact_kernel(const int64_t* __restrict__ pair_off, const int32_t* __restrict__ ids, const uint8_t* __restrict__ who, int rank, int64_t base,
+                     const int64_t* __restrict__ local_off, int32_t* __restrict__ local_ids) {
+  __shared__ int wave_total[4];
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t at = local_off[q];
+  const int64_t lo = pair_off[q], hi = pair_off[q + 1];
+  for (int64_t p0 = lo; p0 < hi; p0 += blockDim.x) {
+    const int64_t p = p0 + threadIdx.x;
+    const bool keep = p < hi && who[p] == rank;
+    const unsigned long long ballot = __ballot(keep);
+    const int before = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_total[wave] = __popcll(ballot);
+    __syncthreads();
+    int wave_base = 0, chunk = 0;
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) wave_base += wave_total[w];
+      chunk += wave_total[w];
+    }
+    if (keep) local_ids[at + wave_base + before] = (int32_t)(ids[p] - base);
+    at += chunk;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) route_iota_kernel(int32_t* __restrict__ v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(256) route_invert_kernel(const int32_t* __restrict__ arrival, int64_t n, int32_t* __restrict__ slot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slot[arrival[i]] = (int32_t)i;
+}
+
+__global__ void route_pick_kernel(const int64_t* __restrict__ local_off, const int64_t* __restrict__ q_bounds, int world, int64_t n_queries,
+                                  int64_t* __restrict__ out) {
+  const int r = threadIdx.x;
+  if (r <= world) out[r] = local_off[q_bounds[r]];
+  if (r == 0) out[world + 1] = local_off[n_queries];
+}
+
+// The device form of sharded_set's routing.  On return: the two plans hold this rank's local CSR, the merge holds the
+// owned queries' offsets / arrival slots / first-stage scores, send_counts / recv_counts / own are filled.
+int sharded_route_on_device(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids, const float* sparse, int mode,
+                            int rank, int world, int64_t* bad_pair) {
+  const int64_t P = pair_off[n_queries];
+  std::vector<int64_t> qb((size_t)world + 1);
+  ffx_query_partition(n_queries, world, qb.data());
+  const int64_t q_lo = qb[(size_t)rank], q_hi = qb[(size_t)rank + 1], lo = pair_off[q_lo], hi = pair_off[q_hi], n_own = hi - lo;
+  s->own[0] = q_lo;
+  s->own[1] = q_hi;
+  s->own[2] = lo;
+  s->own[3] = n_own;
+  C_HIP(hipSetDevice(s->device));
+  hipStream_t st = s->compute;
+  const size_t pb = (size_t)std::max<int64_t>(P, 1), ob = (size_t)std::max<int64_t>(n_own, 1);
+  C_TRY(s->d_ids.ensure(pb * 4));
+  C_TRY(s->d_off.ensure(((size_t)n_queries + 1) * 8));
+  C_TRY(s->d_who.ensure(pb));
+  C_TRY(s->d_cnt.ensure(((size_t)n_queries + 1) * 8));
+  C_TRY(s->d_local_off.ensure(((size_t)n_queries + 1) * 8));
+  C_TRY(s->d_local_ids.ensure(pb * 4));
+  C_TRY(s->d_pos.ensure(ob * 4));
+  C_TRY(s->d_keys.ensure(ob));
+  C_TRY(s->d_arrival.ensure(ob * 4));
+  C_TRY(s->d_slot.ensure(ob * 4));
+  // small block: [0] bad pair, [1 .. 1+world) recv counts, then world+1 query bounds, then world+2 picked offsets
+  const size_t small_words = 1 + (size_t)kMaxWorld + ((size_t)kMaxWorld + 1) + ((size_t)kMaxWorld + 2);
+  C_TRY(s->d_small.ensure(small_words * 8));
+  unsigned long long* d_bad = s->d_small.as<unsigned long long>();
+  unsigned long long* d_recv = d_bad + 1;
+  int64_t* d_qb = reinterpret_cast<int64_t*>(d_bad) + 1 + kMaxWorld;
+  int64_t* d_pick = d_qb + kMaxWorld + 1;
+  C_HIP(hipMemcpyAsync(s->d_off.p, pair_off, ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice, st));
+  if (P > 0) C_HIP(hipMemcpyAsync(s->d_ids.p, pair_ids, (size_t)P * 4, hipMemcpyHostToDevice, st));
+  C_HIP(hipMemcpyAsync(d_qb, qb.data(), ((size_t)world + 1) * 8, hipMemcpyHostToDevice, st));
+  C_HIP(hipMemsetAsync(d_bad, 0xFF, 8, st));
+  C_HIP(hipMemsetAsync(d_recv, 0, (size_t)kMaxWorld * 8, st));
+  C_HIP(hipMemsetAsync(s->d_cnt.p, 0, ((size_t)n_queries + 1) * 8, st));
+  RouteBounds bounds;
+  for (int r = 0; r <= world; ++r) bounds.b[r] = s->doc_bounds[(size_t)r];
+  if (n_queries > 0) {
+    route_mark_kernel<<<(unsigned)n_queries, 256, 0, st>>>(s->d_off.as<int64_t>(), s->d_ids.as<int32_t>(), bounds, world, rank, lo, hi, s->d_who.as<uint8_t>(),
+                                                         s->d_cnt.as<int64_t>(), d_recv, d_bad);
+    C_HIP(hipGetLastError());
+  }
+  {
+    size_t tmp = 0;
+    C_HIP(rocprim::exclusive_scan(nullptr, tmp, s->d_cnt.as<int64_t>(), s->d_local_off.as<int64_t>(), (int64_t)0, (size_t)n_queries + 1,
+                                  rocprim::plus<int64_t>(), st));
+    C_TRY(s->d_tmp.ensure(std::max<size_t>(tmp, 16)));
+    C_HIP(rocprim::exclusive_scan(s->d_tmp.p, tmp, s->d_cnt.as<int64_t>(), s->d_local_off.as<int64_t>(), (int64_t)0, (size_t)n_queries + 1,
+                                  rocprim::plus<int64_t>(), st));
+  }
+  if (n_queries > 0) {
+    route_compact_kernel<<<(unsigned)n_queries, 256, 0, st>>>(s->d_off.as<int64_t>(), s->d_ids.as<int32_t>(), s->d_who.as<uint8_t>(), rank,
+                                                            s->doc_bounds[(size_t)rank], s->d_local_off.as<int64_t>(), s->d_local_ids.as<int32_t>());
+    C_HIP(hipGetLastError());
+  }
+  route_pick_kernel<<<1, kMaxWorld + 1, 0, st>>>(s->d_local_off.as<int64_t>(), d_qb, world, n_queries, d_pick);
+  C_HIP(hipGetLastError());
+  if (n_own > 0) {
+    route_iota_kernel<<<(unsigned)((n_own + 255) / 256), 256, 0, st>>>(s->d_pos.as<int32_t>(), n_own);
+    C_HIP(hipGetLastError());
+    int bits = 1;
+    while ((1 << bits) < world) ++bits;
+    size_t tmp = 0;
+    const uint8_t* keys_in = s->d_who.as<uint8_t>() + lo;
+    C_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys_in, s->d_keys.as<uint8_t>(), s->d_pos.as<int32_t>(), s->d_arrival.as<int32_t>(), (size_t)n_own, 0, bits, st));
+    C_TRY(s->d_tmp.ensure(std::max<size_t>(tmp, 16)));
+    C_HIP(rocprim::radix_sort_pairs(s->d_tmp.p, tmp, keys_in, s->d_keys.as<uint8_t>(), s->d_pos.as<int32_t>(), s->d_arrival.as<int32_t>(), (size_t)n_own, 0, bits, st));
+    route_invert_kernel<<<(unsigned)((n_own + 255) / 256), 256, 0, st>>>(s->d_arrival.as<int32_t>(), n_own, s->d_slot.as<int32_t>());
+    C_HIP(hipGetLastError());
+  }
+  // what the host needs: the verdict, the counts, the local CSR offsets (the plans size their row lists from them)
+  std::vector<int64_t> small(small_words);
+  if (s->local_off.size() < (size_t)n_queries + 1) s->local_off.resize((size_t)n_queries + 1);
+  C_HIP(hipMemcpyAsync(small.data(), s->d_small.p, small_words * 8, hipMemcpyDeviceToHost, st));
+  C_HIP(hipMemcpyAsync(s->local_off.data(), s->d_local_off.p, ((size_t)n_queries + 1) * 8, hipMemcpyDeviceToHost, st));
+  C_HIP(hipStreamSynchronize(st));
+  const unsigned long long bad = (unsigned long long)small[0];
+  if (bad != ~0ull) {
+    if (bad_pair) *bad_pair = (int64_t)bad;
+    return ffx_fail(FFX_NOT_FOUND, "pair %llu names a document no rank of the sharded index holds", bad);
+  }
+  const int64_t* pick = small.data() + 1 + kMaxWorld + (kMaxWorld + 1);
+  for (int r = 0; r < world; ++r) {
+    s->recv_counts[(size_t)r] = small[1 + (size_t)r];
+    s->send_counts[(size_t)r] = pick[r + 1] - pick[r];
+  }
+  s->local_pairs = pick[world + 1];
+  // plans: the first takes the lists device to device, the second copies the first
+  int64_t bad_local = -1;
+  int rc = ffx_plan_set_pairs_device(s->plans[0], s->d_local_off.as<int64_t>(), s->local_off.data(), n_queries, s->d_local_ids.as<int32_t>(), mode, &bad_local);
+  if (rc == FFX_NOT_FOUND && bad_pair && bad_local >= 0) {  // local position -> position in the caller's list
+    const int64_t q = std::upper_bound(s->local_off.begin(), s->local_off.begin() + n_queries + 1, bad_local) - s->local_off.begin() - 1;
+    int64_t seen = s->local_off[(size_t)q];
+    for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p)
+      if (pair_ids[p] >= s->doc_bounds[(size_t)rank] && pair_ids[p] < s->doc_bounds[(size_t)rank + 1] && seen++ == bad_local) {
+        *bad_pair = p;
+        break;
+      }
+  }
+  C_TRY(rc);
+  C_TRY(ffx_plan_copy_pairs(s->plans[1], s->plans[0]));
+  for (int i = 0; i < 2; ++i) {
+    void* p = nullptr;
+    C_TRY(ffx_plan_device_ptr(s->plans[i], FFX_BUF_FF, &p, nullptr));
+    s->send_dev[i] = static_cast<float*>(p);
+  }
+  std::vector<int64_t> own_off((size_t)(q_hi - q_lo) + 1);
+  for (int64_t q = q_lo; q <= q_hi; ++q) own_off[(size_t)(q - q_lo)] = pair_off[q] - lo;
+  C_TRY(ffx_merge_set_device(s->merge, own_off.data(), q_hi - q_lo, s->d_slot.as<int32_t>(), sparse ? sparse + lo : nullptr));
+  return FFX_OK;
+}
+
 int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids, const int32_t* holder,
                 const float* sparse, int mode, int64_t* bad_pair) {
   if (bad_pair) *bad_pair = -1;
@@ -781,6 +1033,17 @@ int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, cons
   const int64_t P = pair_off[n_queries];
   s->send_counts.assign((size_t)world, 0);
   s->recv_counts.assign((size_t)world, 0);
+  if (!holder && !s->doc_bounds.empty() && !getenv("FFX_ROUTE_HOST")) {
+    // document-range shards: the batch is routed on the device from one upload of its ids
+    if (pair_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+    for (int64_t q = 0; q < n_queries; ++q)
+      if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+    if (P > 0 && !pair_ids) return ffx_fail(FFX_BAD_ARG, "pair_ids is NULL");
+    if (P > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+    if (n_queries > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many queries");
+    C_TRY(sharded_route_on_device(s, pair_off, n_queries, pair_ids, sparse, mode, rank, world, bad_pair));
+    return sharded_finish_set(s, sparse != nullptr);
+  }
   // one routing pass: the outputs are sized for the worst case (every pair local; the owned block is known beforehand)
   std::vector<int64_t> qb((size_t)world + 1);
   ffx_query_partition(n_queries, world, qb.data());
@@ -823,18 +1086,7 @@ int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, cons
   std::vector<int64_t> own_off((size_t)(q_hi - q_lo) + 1);
   for (int64_t q = q_lo; q <= q_hi; ++q) own_off[(size_t)(q - q_lo)] = pair_off[q] - lo;
   C_TRY(ffx_merge_set(s->merge, own_off.data(), q_hi - q_lo, slot.data(), sparse ? sparse + lo : nullptr));
-  s->have_sparse = sparse != nullptr;
-  const size_t need = (size_t)std::max<int64_t>(s->own[3], 1) * sizeof(float);
-  if (need > s->recv_cap) {
-    C_HIP(hipSetDevice(s->device));
-    if (s->recv) C_HIP(hipFree(s->recv));
-    s->recv = nullptr;
-    s->recv_cap = 0;
-    C_HIP(hipMalloc(&s->recv, need + need / 8));
-    s->recv_cap = need + need / 8;
-  }
-  s->have_pairs = true;
-  return FFX_OK;
+  return sharded_finish_set(s, sparse != nullptr);
 }
 
 }  // namespace
@@ -890,6 +1142,9 @@ int ffx_sharded_destroy(ffx_sharded* s) {
   for (auto* p : s->plans)
     if (p) ffx_plan_destroy(p);
   if (s->merge) ffx_merge_destroy(s->merge);
+  for (auto* a : {&s->d_ids, &s->d_off, &s->d_who, &s->d_cnt, &s->d_local_off, &s->d_local_ids, &s->d_pos, &s->d_keys, &s->d_arrival, &s->d_slot,
+                  &s->d_small, &s->d_tmp})
+    a->release();
   for (int i = 0; i < 2; ++i) {
     if (s->scored[i]) (void)hipEventDestroy(s->scored[i]);
     if (s->sent[i]) (void)hipEventDestroy(s->sent[i]);

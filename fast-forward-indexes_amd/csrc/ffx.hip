@@ -748,6 +748,8 @@ static int launch_count_scan(ffx_plan* pl) {
   return FFX_OK;
 }
 
+static int finish_set_pairs(ffx_plan* pl, int64_t* bad_pair);
+
 int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids,
                        const float* sparse, int mode, int64_t* bad_pair) {
   if (bad_pair) *bad_pair = -1;
@@ -791,7 +793,15 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
     FFX_TRY(plan_h2d(pl, pl->pair_ids.p, pair_ids, (size_t)P * sizeof(int32_t)));
     if (sparse) FFX_TRY(plan_h2d(pl, pl->sparse.p, sparse, (size_t)P * sizeof(float)));
   }
-  // validate ordinals and size the row list on the device (get_indices, index/util.py:29-41)
+  return finish_set_pairs(pl, bad_pair);
+}
+
+// the second half of ffx_plan_set_pairs: the lists are in the plan's device buffers; validate the ordinals and
+// size the row list on the device (get_indices, index/util.py:29-41)
+static int finish_set_pairs(ffx_plan* pl, int64_t* bad_pair) {
+  ffx_index* ix = pl->idx;
+  const int64_t P = pl->n_pairs;
+  const int mode = pl->mode;
   FFX_HIP(hipMemsetAsync(pl->flags.p, 0xFF, sizeof(unsigned long long), pl->stream));
   FFX_TRY(launch_count_scan(pl));
   unsigned long long bad = ~0ull;
@@ -835,6 +845,47 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   pl->have_pairs = true;
   pl->lazy_pairs = false;
   return FFX_OK;
+}
+
+// ffx_plan_set_pairs for candidate lists that already are in device memory (the sharded scorer routes a batch on the
+// device): dev_pair_off / dev_pair_ids are copied device to device; host_pair_off is the same CSR offsets on the
+// host (sizes, and the longest list for the ordering).  No first-stage scores (the owner side interpolates).
+int ffx_plan_set_pairs_device(ffx_plan* pl, const int64_t* dev_pair_off, const int64_t* host_pair_off, int64_t n_queries,
+                              const int32_t* dev_pair_ids, int mode, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!pl || !dev_pair_off || !host_pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  if (n_queries > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many queries");
+  if (host_pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (host_pair_off[q + 1] < host_pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = host_pair_off[n_queries];
+  if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  if (P > 0 && !dev_pair_ids) return fail(FFX_BAD_ARG, "pair_ids is NULL");
+  ffx_index* ix = pl->idx;
+  if ((mode == FFX_MODE_PASSAGE ? ix->n_psgs == 0 : ix->n_docs == 0) && P > 0) {
+    if (bad_pair) *bad_pair = 0;
+    return fail(FFX_NOT_FOUND, "the index holds no %s ids", mode == FFX_MODE_PASSAGE ? "passage" : "document");
+  }
+  FFX_HIP(hipSetDevice(ix->device));
+  pl->have_pairs = false;
+  pl->lazy_pairs = false;
+  pl->ran = false;
+  pl->n_queries = n_queries;
+  pl->n_pairs = P;
+  pl->mode = mode;
+  pl->have_sparse = false;
+  pl->host_pair_off.assign(host_pair_off, host_pair_off + n_queries + 1);
+  const size_t pb = std::max<size_t>((size_t)P, 1);
+  FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(pl->cnt.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(pl->seg_off.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(pl->ff.ensure(pb * sizeof(float)));
+  FFX_HIP(hipMemcpyAsync(pl->pair_off.p, dev_pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, pl->stream));
+  if (P > 0) FFX_HIP(hipMemcpyAsync(pl->pair_ids.p, dev_pair_ids, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, pl->stream));
+  pl->hstage_used = 0;
+  return finish_set_pairs(pl, bad_pair);
 }
 
 // Two plans of one index that are to score the same candidate lists (the sharded scorer alternates between two plans
@@ -1681,6 +1732,50 @@ int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, cons
     FFX_TRY(m->interp.ensure(pb * sizeof(float)));
     if (P > 0) FFX_HIP(hipMemcpy(m->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice));
   }
+  m->n_queries = n_queries;
+  m->n_pairs = P;
+  m->max_len = longest_segment(pair_off, n_queries);
+  m->ready = true;
+  return FFX_OK;
+}
+
+// ffx_merge_set with the arrival slots already in device memory (the sharded scorer routes on the device); the
+// offsets and the first-stage scores of the owned queries come from the host as before.  The slots are checked on
+// the device (each inside 0 .. P-1).
+int ffx_merge_set_device(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* dev_recv_slot, const float* sparse) {
+  if (!m || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
+  for (int64_t q = 0; q < n_queries; ++q)
+    if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
+  const int64_t P = pair_off[n_queries];
+  if (P > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many pairs");
+  if (P > 0 && !dev_recv_slot) return fail(FFX_BAD_ARG, "recv_slot is NULL");
+  FFX_HIP(hipSetDevice(m->device));
+  m->ready = m->ran = false;
+  const size_t pb = std::max<size_t>((size_t)P, 1);
+  FFX_TRY(m->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(m->slot.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(m->ff.ensure(pb * sizeof(float)));
+  FFX_TRY(m->sort_tmp.ensure(64));
+  hipStream_t st = m->own_stream;
+  FFX_HIP(hipMemcpyAsync(m->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  unsigned long long bad = ~0ull;
+  if (P > 0) {
+    FFX_HIP(hipMemcpyAsync(m->slot.p, dev_recv_slot, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    unsigned long long* flag = m->sort_tmp.as<unsigned long long>();
+    FFX_HIP(hipMemsetAsync(flag, 0xFF, sizeof *flag, st));
+    ffx::check_range_kernel<<<blocks_for(P, 256), 256, 0, st>>>(m->slot.as<int32_t>(), P, (int32_t)P, flag);
+    FFX_HIP(hipGetLastError());
+    FFX_HIP(hipMemcpyAsync(&bad, flag, sizeof bad, hipMemcpyDeviceToHost, st));
+  }
+  m->have_sparse = sparse != nullptr;
+  if (sparse) {
+    FFX_TRY(m->sparse.ensure(pb * sizeof(float)));
+    FFX_TRY(m->interp.ensure(pb * sizeof(float)));
+    if (P > 0) FFX_HIP(hipMemcpyAsync(m->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  FFX_HIP(hipStreamSynchronize(st));
+  if (bad != ~0ull) return fail(FFX_BAD_ARG, "recv_slot[%llu] out of range", bad);
   m->n_queries = n_queries;
   m->n_pairs = P;
   m->max_len = longest_segment(pair_off, n_queries);

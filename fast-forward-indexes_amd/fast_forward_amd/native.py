@@ -26,10 +26,10 @@ SYMBOLS = (
     "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
     "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
-    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs",
+    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device",
     "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
-    "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_run", "ffx_merge_sync",
+    "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_buffer_free",
@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
         "ffx_plan_set_queries": ([vp, vp, i64], C.c_int),
         "ffx_plan_set_queries_device": ([vp, vp, i64], C.c_int),
         "ffx_plan_copy_pairs": ([vp, vp], C.c_int),
+        "ffx_plan_set_pairs_device": ([vp, vp, vp, i64, vp, C.c_int, P(i64)], C.c_int),
         "ffx_plan_set_pairs": ([vp, vp, i64, vp, vp, C.c_int, P(i64)], C.c_int),
         "ffx_plan_run": ([vp, C.c_double, C.c_uint32], C.c_int),
         "ffx_plan_set_pairs_lazy": ([vp, vp, i64, vp, vp, C.c_int], C.c_int),
@@ -156,6 +157,7 @@ def lib() -> C.CDLL:
         "ffx_merge_create": ([C.c_int, P(vp)], C.c_int),
         "ffx_merge_destroy": ([vp], C.c_int),
         "ffx_merge_set": ([vp, vp, i64, vp, vp], C.c_int),
+        "ffx_merge_set_device": ([vp, vp, i64, vp, vp], C.c_int),
         "ffx_merge_run": ([vp, vp, C.c_double, C.c_uint32, vp], C.c_int),
         "ffx_merge_sync": ([vp], C.c_int),
         "ffx_merge_fetch": ([vp, vp, vp, vp], C.c_int),

@@ -155,6 +155,10 @@ int ffx_plan_set_pairs(ffx_plan* plan, const int64_t* pair_off, int64_t n_querie
 /* dst is to score the same candidate lists as src (two plans of ONE index, e.g. alternating send buffers): the
  * validated lists are taken over device to device instead of being uploaded and validated again. */
 int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src);
+/* ffx_plan_set_pairs for lists that already are in DEVICE memory (copied device to device); host_pair_off holds the
+ * same offsets on the host.  No first-stage scores.  Used by the sharded scorer, which routes a batch on the device. */
+int ffx_plan_set_pairs_device(ffx_plan* plan, const int64_t* dev_pair_off, const int64_t* host_pair_off, int64_t n_queries,
+                              const int32_t* dev_pair_ids, int mode, int64_t* bad_pair);
 int ffx_plan_run(ffx_plan* plan, double alpha, uint32_t flags);
 /* ---- early stopping: replaces Index._early_stopping, index/base.py:316-387 ------------------
  * Candidates of a query stand in first-stage rank order.  set_pairs_lazy uploads the lists without
@@ -196,6 +200,8 @@ int ffx_merge_destroy(ffx_merge* m);
  * dense score of candidate p sits in the received buffer; sparse may be NULL */
 int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* recv_slot,
                   const float* sparse);
+/* the same with the arrival slots in DEVICE memory (offsets and first-stage scores still come from the host) */
+int ffx_merge_set_device(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* dev_recv_slot, const float* sparse);
 /* recv_dev: DEVICE pointer to n_pairs floats.  stream: hipStream_t to run on (NULL: own stream) */
 int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t flags, void* stream);
 int ffx_merge_sync(ffx_merge* m);

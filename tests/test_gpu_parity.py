@@ -580,6 +580,68 @@ def test_sharded_bench_falls_back_together_when_rccl_cannot_come_up():
     assert "fall" in out.stderr and "shared-memory transport" in out.stderr
 
 
+def test_device_routing_equals_host_routing(monkeypatch):
+    """The sharded scorer routes a batch on the device when the shards are document ranges (one upload of the ids,
+    then mark / scan / compact / stable radix pass by holder in HBM).  Against the host routing (FFX_ROUTE_HOST=1)
+    on one rank: same dense, interpolated scores and order, bit for bit, for ragged batches (empty queries, one
+    candidate, several passages per document, every mode); the same NotFound for an ordinal outside every shard and
+    for one inside the range that has no rows."""
+    rng = np.random.default_rng(21)
+    d, n_docs = 96, 700
+    per_doc = rng.integers(0, 4, size=n_docs)  # some documents hold no rows at all
+    per_doc[:5] = 1
+    doc_off = np.concatenate([[0], np.cumsum(per_doc)]).astype(np.int64)
+    n = int(doc_off[-1])
+    vectors = synth.rows(31, 0.1, 0, n, d)
+    queries = synth.rows(32, 0.1, 0, 7, d)
+    shard = native.DeviceIndex(n, d)
+    shard.upload(vectors, 0)
+    shard.set_doc_rows(doc_off, rng.permutation(n).astype(np.int32))
+    shard.set_psg_rows(np.arange(n, dtype=np.int32))
+    with_rows = np.flatnonzero(per_doc > 0)
+    lens = [0, 1, 300, 0, 77, 256, 5]
+    pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pair_ids = np.concatenate([rng.choice(with_rows, size=k, replace=False) for k in lens]).astype(np.int32)
+    sparse = (rng.random(len(pair_ids)) * 9).astype(np.float32)
+    comm = native.Comm(native.COMM_HOST, 0, 0, 1, native.Comm.unique_id(native.COMM_HOST))
+    results = {}
+    for route in ("device", "host"):
+        if route == "host":
+            monkeypatch.setenv("FFX_ROUTE_HOST", "1")
+        else:
+            monkeypatch.delenv("FFX_ROUTE_HOST", raising=False)
+        sc = native.Sharded(shard, comm, np.array([0, n_docs], dtype=np.int64))
+        sc.set_queries(queries)
+        for mode in (2, 3, 4):
+            for sp in (sparse, None):
+                sc.set_pairs(pair_off, pair_ids, sp, mode)
+                sc.run(0.3, sort=True)
+                sc.sync()
+                results[(route, mode, sp is None)] = sc.fetch(ff=True, interp=sp is not None, order=True)
+        for value, at in ((n_docs, 40), (-1, 3), (int(np.flatnonzero(per_doc == 0)[0]), 100)):
+            bad = pair_ids.copy()
+            bad[at] = value
+            with pytest.raises(native.NotFound) as e:
+                sc.set_pairs(pair_off, bad, sparse, 2)
+            assert e.value.pair == at, (route, value)
+        sc.set_pairs(pair_off, pair_ids, sparse, 2)  # still usable
+        sc.run(0.3, sort=True)
+        sc.sync()
+        again = sc.fetch(ff=True, interp=True, order=True)
+        for x, y in zip(again, results[(route, 2, False)]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        sc.close()
+    for mode in (2, 3, 4):
+        for no_sparse in (False, True):
+            a, b = results[("device", mode, no_sparse)], results[("host", mode, no_sparse)]
+            for x, y in zip(a, b):
+                assert (x is None) == (y is None)
+                if x is not None:
+                    assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    comm.close()
+    shard.close()
+
+
 def test_sharded_bench_leg_also_runs_under_torchrun():
     """The other way the driver may start N ranks: `python -m torch.distributed.run ... bench.py --gpus N`
     (RANK / WORLD_SIZE from the launcher; the ranks find each other through the launcher's run id)."""
