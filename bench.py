@@ -372,6 +372,20 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     scorer.set_pairs(pair_off, ids, sparse, MODE_NO[args.mode])
     t_route_again = time.perf_counter() - t_route_again
     exact = args.sum == "exact"
+    # a whole batch from host buffers to host buffers, every rank (not the metric: the PCIe-inclusive rate next to it):
+    # route + upload, local scoring, exchange, owner merge and ordering, download of the owned queries' results
+    host_batch = []
+    n_own = int(pair_off[query_partition(args.queries, world)[rank + 1]] - pair_off[query_partition(args.queries, world)[rank]])
+    keep = (native.pinned_empty(max(1, n_own), np.float32), native.pinned_empty(max(1, n_own), np.float32), native.pinned_empty(max(1, n_own), np.int32))
+    for _ in range(3):
+        comm.barrier()
+        tb = time.perf_counter()
+        scorer.set_pairs(pair_off, ids, sparse, MODE_NO[args.mode])
+        scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
+        scorer.sync()
+        scorer.fetch(order=args.sort, out=keep)
+        host_batch.append(float(comm.allreduce([time.perf_counter() - tb], native.OP_MAX)[0]))
+    t_host_batch = min(host_batch[1:])
 
     for _ in range(args.warmup):
         scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
@@ -442,6 +456,9 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                              "overlap batch i+1's scoring, so a step costs about max(local, exchange + merge)",
             "owned_pairs_per_rank": [int(t["own_pairs"]) for t in per_rank],
             "route_and_upload_s": t_route, "route_and_upload_next_batch_s": t_route_again,
+            "host_to_host_batch_ms": t_host_batch * 1e3, "host_to_host_queries_per_s": args.queries / t_host_batch,
+            "host_to_host_note": "one batch from host buffers to host buffers on every rank, not overlapped with anything: route on the device + "
+                                 "uploads, local scoring, exchange, owner merge + ordering, download of the owned queries' results into page-locked arrays the caller re-uses (max over ranks)",
             "device": dev["name"],
             "index_capacity_rows_per_gpu": cap, "index_capacity_rows_total": world * cap,
         }

@@ -1069,11 +1069,22 @@ class Sharded:
     def sync(self) -> None:
         _check(lib().ffx_sharded_sync(self._h))
 
-    def fetch(self, ff: bool = True, interp: bool = False, order: bool = False):
+    def fetch(self, ff: bool = True, interp: bool = False, order: bool = False, out=None):
+        """Results of the owned queries.  ``out``: optional ``(ff, interp, order)`` arrays to write into (float32,
+        float32, int32, each holding at least the owned pairs; e.g. page-locked ones) instead of fresh ones."""
         n = self.own_pairs
-        a = np.empty(n, dtype=np.float32) if ff else None
-        b = np.empty(n, dtype=np.float32) if interp else None
-        c = np.empty(n, dtype=np.int32) if order else None
+
+        def buf(want: bool, given, dtype):
+            if not want:
+                return None
+            if given is None:
+                return np.empty(n, dtype=dtype)
+            if given.dtype != dtype or given.size < n or not given.flags["C_CONTIGUOUS"]:
+                raise ValueError("out arrays must be contiguous, of the result dtype and hold every owned pair")
+            return given[:n]
+
+        o = out if out is not None else (None, None, None)
+        a, b, c = buf(ff, o[0], np.float32), buf(interp, o[1], np.float32), buf(order, o[2], np.int32)
         _check(lib().ffx_sharded_fetch(self._h, _ptr(a), _ptr(b), _ptr(c)))
         return a, b, c
 

@@ -214,9 +214,9 @@ class ShardedScorer:
     def own_pairs(self) -> int:
         return self._s.own_pairs
 
-    def fetch(self, order: bool = False):
-        """(dense, interpolated|None, order|None) of the owned queries, first-stage order."""
-        return self._s.fetch(ff=True, interp=self._s.has_sparse, order=order)
+    def fetch(self, order: bool = False, out=None):
+        """(dense, interpolated|None, order|None) of the owned queries, first-stage order; ``out``: arrays to re-use."""
+        return self._s.fetch(ff=True, interp=self._s.has_sparse, order=order, out=out)
 
     def stats(self) -> dict:
         return self._s.stats()
