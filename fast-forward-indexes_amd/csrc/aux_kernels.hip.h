@@ -105,6 +105,13 @@ small_out_kernel(const uint32_t* __restrict__ ff, const uint32_t* __restrict__ i
   }
 }
 
+// out[i] = src[index[i]]
+__global__ void __launch_bounds__(256)
+take_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ index, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[index[i]];
+}
+
 // *bad = smallest i with v[i] outside 0 .. limit-1 (stays ~0 when all are inside)
 __global__ void __launch_bounds__(256)
 check_range_kernel(const int32_t* __restrict__ v, int64_t n, int32_t limit, unsigned long long* __restrict__ bad) {

@@ -16,6 +16,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
@@ -1614,6 +1616,45 @@ int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_
     if (out_order) FFX_HIP(hipMemcpyAsync(out_order, pl->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, pl->stream));
   }
   FFX_HIP(hipStreamSynchronize(pl->stream));
+  return FFX_OK;
+}
+
+// After ffx_plan_early_stopping: only the candidates that were scored, compacted on the device -- their positions in
+// the candidate list (ascending, so still grouped by query) and their dense scores.  The dense array holds NaN for
+// every candidate that was not reached; at depth 5000 and a stop after the first interval that is 98 % of it, and
+// fetching and scanning it on the host costs more than the scoring.  *n_scored = how many there are; up to `cap` are
+// written (call with cap = the count ffx_plan_early_stopping reported).
+int ffx_plan_fetch_scored(ffx_plan* pl, int64_t cap, int32_t* out_pos, float* out_ff, int64_t* n_scored) {
+  if (!pl || !n_scored || cap < 0 || (cap > 0 && (!out_pos || !out_ff))) return fail(FFX_BAD_ARG, "bad argument");
+  if (!pl->ran) return fail(FFX_BAD_ARG, "nothing has run on this plan");
+  FFX_HIP(hipSetDevice(pl->device));
+  hipStream_t st = pl->stream;
+  const int64_t P = pl->n_pairs;
+  *n_scored = 0;
+  if (P == 0) return FFX_OK;
+  const size_t pb = (size_t)P;
+  FFX_TRY(pl->es_pos.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(pl->iota.ensure(pb * sizeof(float) + 64));
+  FFX_TRY(pl->es_cnt.ensure(64));
+  auto scored = rocprim::make_transform_iterator(pl->ff.as<float>(), [] __device__(float v) { return v == v; });
+  rocprim::counting_iterator<int32_t> positions(0);
+  unsigned long long* d_count = pl->es_cnt.as<unsigned long long>();
+  size_t tmp = 0;
+  FFX_HIP(rocprim::select(nullptr, tmp, positions, scored, pl->es_pos.as<int32_t>(), d_count, pb, st));
+  FFX_TRY(pl->es_scan_tmp.ensure(std::max<size_t>(tmp, 16)));
+  FFX_HIP(rocprim::select(pl->es_scan_tmp.p, tmp, positions, scored, pl->es_pos.as<int32_t>(), d_count, pb, st));
+  unsigned long long count = 0;
+  FFX_HIP(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, st));
+  FFX_HIP(hipStreamSynchronize(st));
+  *n_scored = (int64_t)count;
+  const int64_t n = std::min<int64_t>((int64_t)count, cap);
+  if (n == 0) return FFX_OK;
+  float* packed = pl->iota.as<float>();
+  ffx::take_f32_kernel<<<blocks_for(n, 256), 256, 0, st>>>(pl->ff.as<float>(), pl->es_pos.as<int32_t>(), n, packed);
+  FFX_HIP(hipGetLastError());
+  FFX_HIP(hipMemcpyAsync(out_pos, pl->es_pos.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  FFX_HIP(hipMemcpyAsync(out_ff, packed, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  FFX_HIP(hipStreamSynchronize(st));
   return FFX_OK;
 }
 

@@ -320,6 +320,33 @@ class Index(abc.ABC):
             # row i of the result is row order[i] of `ranking`: ranking.interpolate(result, alpha) needs no join
             out._source_rows = (weakref.ref(ranking), order.copy())  # (`order` may be a view of the index's re-used result block)
             return out
+        if (early_stopping is not None and final_order and grouped is None and len(q_no) >= _CODED_MIN_ROWS and (batch_size is None or batch_size >= n_q)
+                and getattr(self, "_early_stopping_takes_ordinals", False) and ranking._score_dtype() == np.float32):
+            # a large run, early stopping resident on the device: codes in, codes out (no frame, no Python string per row)
+            from fast_forward_amd import native
+
+            codes, names = ranking._id_coding()
+            lenient = self._ordinals_of_codes(ranking, codes, names, missing_ok=True)
+            if hasattr(self, "_early_stopping_scored"):  # only the scored candidates come back, compacted on the device
+                rows, kept_scores = self._early_stopping_scored(lambda p: names[codes[p]], q_no, ranking._scores(), query_vectors, early_stopping,
+                                                                early_stopping_alpha, early_stopping_depths, lenient, (None, block_off))
+            else:
+                ff = self._early_stopping_scores(lambda p: names[codes[p]], q_no, ranking._scores(), query_vectors, early_stopping, early_stopping_alpha,
+                                                 early_stopping_depths, ordinals=lenient, grouped=(None, block_off))
+                rows = np.flatnonzero(~np.isnan(ff)).astype(np.int32)  # the candidates that were scored, still grouped by query
+                kept_scores = native.take32(np.ascontiguousarray(ff), rows)
+            q_kept = np.asarray(q_no)[rows]
+            off = np.zeros(n_q + 1, dtype=np.int64)
+            np.cumsum(np.bincount(q_kept, minlength=n_q), out=off[1:])
+            order = native.host_order(kept_scores, off)  # score descending inside every query, ties by first-stage rank
+            src = native.take32(rows, order)
+            present = np.flatnonzero(np.diff(off))
+            renumber = np.full(n_q, -1, dtype=np.int64)
+            renumber[present] = np.arange(present.shape[0])
+            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+            return Ranking._assemble_coded("fast-forward", renumber[q_kept], [q_order[i] for i in present], native.take32(codes, src), names,
+                                           native.take32(kept_scores, order).astype(ranking._score_dtype(), copy=False),
+                                           None if texts is None else [texts[i] for i in present])
         df = ranking._df
         if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
             # arrays in, arrays out: only the candidates that get scored are looked up and kept

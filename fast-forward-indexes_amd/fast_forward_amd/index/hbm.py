@@ -251,7 +251,13 @@ class InMemoryIndex(Index):
 
     _early_stopping_takes_ordinals = True
 
-    def _early_stopping_scores(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths, ordinals=None) -> np.ndarray:
+    def _early_stopping_scored(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths, ordinals, grouped):
+        """Early stopping for rows that stand grouped by query: (rows that were scored, ascending; their dense scores),
+        compacted on the device (``ffx_plan_fetch_scored``) -- nothing of the size of the candidate list comes back."""
+        return self._early_stopping_scores(ids, q_no, sparse, query_vectors, cutoff, alpha, depths, ordinals=ordinals, grouped=grouped, compact=True)
+
+    def _early_stopping_scores(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths, ordinals=None, grouped=None,
+                               compact: bool = False):
         """Early stopping (base.py:316-387) resident on the device (``ffx_plan_early_stopping``): the
         active mask, the running best dense score and the running top-``cutoff`` threshold of every
         query stay in HBM between depth intervals; one upload of the candidate lists, one download
@@ -270,8 +276,16 @@ class InMemoryIndex(Index):
             raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.query_dim}).")
         if self._rotation is not None:
             q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
-        perm, pair_off = _grouped_by_query(q_no, n_q)  # stable: the frame's order inside a query is its rank order
-        ids_g, sparse_g = (ids, sparse) if perm is None else (ids[perm], sparse[perm])
+        # ``grouped``: the ranking's cached (permutation | None, offsets); ``ids`` may be a callable position -> id string
+        # (coded rankings: no array of strings exists), used only to name an id in an error
+        perm, pair_off = _grouped_by_query(q_no, n_q) if grouped is None else grouped  # stable: the order inside a query is its rank order
+        if callable(ids):
+            id_at = ids if perm is None else (lambda p: ids(int(perm[p])))
+            ids_g = None
+        else:
+            ids_g = ids if perm is None else ids[perm]
+            id_at = lambda p: ids_g[p]  # noqa: E731
+        sparse_g = sparse if perm is None else sparse[perm]
         if ordinals is None:
             ordinals = self._ids.lookup_optional(ids_g, self.mode.value).astype(np.int32)
         elif perm is not None:
@@ -285,10 +299,14 @@ class InMemoryIndex(Index):
         try:
             scored, intervals = plan.early_stopping(cutoff, alpha, depths, exact_sum=self.exact_sum)
         except native.NotFound as e:
-            raise IndexError(f"ID {ids_g[e.pair]} not found in the index.") from None
-        ff = plan.fetch(ff=True)[0]
+            raise IndexError(f"ID {id_at(e.pair)} not found in the index.") from None
         self.last_stats = dict(plan.stats(), early_stopping_scored_pairs=scored, early_stopping_intervals=intervals)
-        LOGGER.info("early stopping: %s of %s candidates scored in %s depth intervals", scored, len(ids_g), intervals)
+        LOGGER.info("early stopping: %s of %s candidates scored in %s depth intervals", scored, len(sparse_g), intervals)
+        if compact:
+            if perm is not None:
+                raise ValueError("the compact form needs rows grouped by query")
+            return plan.fetch_scored(scored)
+        ff = plan.fetch(ff=True)[0]
         if perm is None:
             return ff
         out = np.empty_like(ff)

@@ -173,6 +173,9 @@ int ffx_plan_set_pairs_lazy(ffx_plan* plan, const int64_t* pair_off, int64_t n_q
                             const float* sparse, int mode);
 int ffx_plan_early_stopping(ffx_plan* plan, int32_t cutoff, double alpha, const int32_t* depths, int32_t n_depths,
                             uint32_t flags, int64_t* bad_pair, int64_t* n_scored_pairs, int32_t* n_intervals);
+/* after ffx_plan_early_stopping: the scored candidates only, compacted on the device -- positions in the candidate
+ * list (ascending) and dense scores; *n_scored = how many there are, up to `cap` of them are written */
+int ffx_plan_fetch_scored(ffx_plan* plan, int64_t cap, int32_t* out_pos, float* out_ff, int64_t* n_scored);
 int ffx_plan_sync(ffx_plan* plan);
 /* any of the outputs may be NULL */
 int ffx_plan_fetch(ffx_plan* plan, float* out_ff, float* out_interp, int32_t* out_order);

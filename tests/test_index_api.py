@@ -178,7 +178,13 @@ def test_early_stopping_looks_up_only_what_it_scores():
         idx(Ranking(pd.DataFrame(deep)))
 
 
-def test_early_stopping_matches_reference_frames():
+@pytest.mark.parametrize("coded", [False, True])
+def test_early_stopping_matches_reference_frames(coded, monkeypatch):
+    """``coded``: the route of large runs (integer id codes in, a coded Ranking out) forced onto this small fixture."""
+    if coded:
+        import fast_forward_amd.index.api as api_mod
+
+        monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1)
     z = np.load(GOLDEN / "early_stopping.npz")
     dim, seed, scale, n_psg = int(z["dim"]), int(z["seed"]), float(z["scale"]), int(z["n_psg"])
     q_names = z["q_names"].tolist()
@@ -192,7 +198,11 @@ def test_early_stopping_matches_reference_frames():
         pos += n
     first = Ranking(pd.DataFrame(rows, columns=["q_id", "id", "score"]), queries={q: str(i) for i, q in enumerate(q_names)})
     for ci, (cutoff, alpha, depths) in enumerate(json.loads(str(z["configs"]))):
-        got = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)._df
+        res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+        assert (res._coded is not None) == coded
+        got = res._df
+        assert got["q_id"].tolist() == z[f"es{ci}_q_id"].tolist() or not coded  # same query order as the reference's frame
+        assert got["query"].tolist() == [str(q_names.index(q)) for q in got["q_id"]]
         want = {(q, i): s for q, i, s in zip(z[f"es{ci}_q_id"].tolist(), z[f"es{ci}_id"].tolist(), z[f"es{ci}_score"])}
         have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
         assert have.keys() == want.keys(), f"config {ci}: scored sets differ"
@@ -200,7 +210,7 @@ def test_early_stopping_matches_reference_frames():
         assert np.array_equal(bits(np.array([have[k] for k in ks])), bits(np.array([want[k] for k in ks]))), ci
 
 
-@pytest.mark.parametrize("criterion", ["device", "host"])
+@pytest.mark.parametrize("criterion", ["device", "host", "device-coded"])
 def test_early_stopping_on_document_runs_matches_reference_frames(criterion, monkeypatch):
     """Frames the reference produced with early stopping on DOCUMENT runs (MaxP / AveP / FirstP over 1..6
     passages per document; oracle/gen_golden.py::early_stopping_docs_case): same scored set, same bits --
@@ -221,10 +231,16 @@ def test_early_stopping_on_document_runs_matches_reference_frames(criterion, mon
     if criterion == "host":
         monkeypatch.setattr(InMemoryIndex, "_early_stopping_scores", Index._early_stopping_scores)
         monkeypatch.setattr(InMemoryIndex, "_early_stopping_takes_ordinals", False)
+    if criterion == "device-coded":  # the route of large runs: id codes in, a coded Ranking out
+        import fast_forward_amd.index.api as api_mod
+
+        monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1)
     for ci, (mname, cutoff, alpha, depths) in enumerate(json.loads(str(z["configs"]))):
         idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mname]))
         idx.add(vectors, doc_ids=[f"D{d}" for d in z["doc_of_row"]])
-        got = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)._df
+        res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+        assert (res._coded is not None) == (criterion == "device-coded")
+        got = res._df
         want = {(q, i): s for q, i, s in zip(z[f"es{ci}_q_id"].tolist(), z[f"es{ci}_id"].tolist(), z[f"es{ci}_score"])}
         have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
         assert have.keys() == want.keys(), f"config {ci} ({mname}): scored sets differ"
