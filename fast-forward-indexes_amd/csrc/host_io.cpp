@@ -729,6 +729,94 @@ int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32
   return FFX_OK;
 }
 
+// The outer join of Ranking.interpolate / __add__ (ranking.py:293-326: merge on (q_id, id), how="outer") for two
+// rankings whose rows stand grouped by query, on integer keys: query g owns rows off_a[g] .. off_a[g+1] of A and rows
+// off_b[g] .. off_b[g+1] of B; code_a / code_b number the ids in one common table; a (query, id) pair occurs at most
+// once per side.  For every query the union of the two id sets, in ascending id code:
+//   u_code[i]  the id code          u_a[i] / u_b[i]  the row of A / B holding the pair, -1 where that side lacks it
+// and u_off[g] .. u_off[g+1] the union rows of query g.  The outputs hold off_a[n] + off_b[n] entries (the worst case);
+// u_off[n_queries] says how many are used.  Threads take blocks of queries; every query is sorted by id code on both
+// sides (64-bit words of code and row) and merged, once to count and once to write.
+int ffx_host_outer_join(const int64_t* off_a, const int32_t* code_a, const int64_t* off_b, const int32_t* code_b, int64_t n_queries,
+                        int32_t n_threads, int64_t* u_off, int32_t* u_code, int32_t* u_a, int32_t* u_b) {
+  if (!off_a || !off_b || !u_off || n_queries < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (off_a[0] != 0 || off_b[0] != 0) return ffx_fail(FFX_BAD_ARG, "offsets must start at 0");
+  for (int64_t g = 0; g < n_queries; ++g)
+    if (off_a[g + 1] < off_a[g] || off_b[g + 1] < off_b[g]) return ffx_fail(FFX_BAD_ARG, "offsets not monotone at query %lld", (long long)g);
+  const int64_t na = off_a[n_queries], nb = off_b[n_queries];
+  if (na > INT32_MAX - 1 || nb > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many rows");
+  if ((na > 0 && !code_a) || (nb > 0 && !code_b) || ((na + nb) > 0 && (!u_code || !u_a || !u_b))) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, (na + nb) / (1 << 16) + 1, std::max<int64_t>(n_queries, 1)}));
+  try {
+    std::vector<uint64_t> word_a((size_t)na), word_b((size_t)nb);  // (code << 32 | row), sorted inside every query
+    std::atomic<int64_t> next(0);
+    std::atomic<int64_t> dup(-1);
+    u_off[0] = 0;
+    run_threads(T, [&](int) {
+      for (;;) {
+        const int64_t g0 = next.fetch_add(8);
+        if (g0 >= n_queries) return;
+        for (int64_t g = g0; g < std::min(n_queries, g0 + 8); ++g) {
+          for (int64_t i = off_a[g]; i < off_a[g + 1]; ++i) word_a[(size_t)i] = ((uint64_t)(uint32_t)code_a[i] << 32) | (uint32_t)i;
+          for (int64_t i = off_b[g]; i < off_b[g + 1]; ++i) word_b[(size_t)i] = ((uint64_t)(uint32_t)code_b[i] << 32) | (uint32_t)i;
+          std::sort(word_a.begin() + off_a[g], word_a.begin() + off_a[g + 1]);
+          std::sort(word_b.begin() + off_b[g], word_b.begin() + off_b[g + 1]);
+          int64_t i = off_a[g], j = off_b[g], n = 0;
+          const int64_t ie = off_a[g + 1], je = off_b[g + 1];
+          while (i < ie && j < je) {
+            const uint32_t ca = (uint32_t)(word_a[(size_t)i] >> 32), cb = (uint32_t)(word_b[(size_t)j] >> 32);
+            i += ca <= cb;
+            j += cb <= ca;
+            ++n;
+          }
+          n += (ie - i) + (je - j);
+          for (int64_t x = off_a[g] + 1; x < ie; ++x)
+            if ((word_a[(size_t)x] >> 32) == (word_a[(size_t)x - 1] >> 32)) {
+              int64_t none = -1;
+              dup.compare_exchange_strong(none, g);
+            }
+          for (int64_t x = off_b[g] + 1; x < je; ++x)
+            if ((word_b[(size_t)x] >> 32) == (word_b[(size_t)x - 1] >> 32)) {
+              int64_t none = -1;
+              dup.compare_exchange_strong(none, g);
+            }
+          u_off[g + 1] = n;  // counts now, offsets after the scan below
+        }
+      }
+    });
+    if (dup.load() >= 0) return ffx_fail(FFX_BAD_ARG, "query %lld holds an id twice on one side", (long long)dup.load());
+    for (int64_t g = 0; g < n_queries; ++g) u_off[g + 1] += u_off[g];
+    next.store(0);
+    run_threads(T, [&](int) {
+      for (;;) {
+        const int64_t g0 = next.fetch_add(8);
+        if (g0 >= n_queries) return;
+        for (int64_t g = g0; g < std::min(n_queries, g0 + 8); ++g) {
+          int64_t i = off_a[g], j = off_b[g], at = u_off[g];
+          const int64_t ie = off_a[g + 1], je = off_b[g + 1];
+          while (i < ie || j < je) {
+            const uint64_t wa = i < ie ? word_a[(size_t)i] : ~0ull, wb = j < je ? word_b[(size_t)j] : ~0ull;
+            const uint32_t ca = (uint32_t)(wa >> 32), cb = (uint32_t)(wb >> 32);
+            const bool take_a = i < ie && (j >= je || ca <= cb), take_b = j < je && (i >= ie || cb <= ca);
+            u_code[at] = (int32_t)(take_a ? ca : cb);
+            u_a[at] = take_a ? (int32_t)(uint32_t)wa : -1;
+            u_b[at] = take_b ? (int32_t)(uint32_t)wb : -1;
+            i += take_a;
+            j += take_b;
+            ++at;
+          }
+        }
+      }
+    });
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  return FFX_OK;
+}
+
 // Per-query order on the host: scores descending, exact ties by position (stable), -0.0 counted as
 // +0.0 -- the order FFX_FLAG_SORT produces on the device (ranking.py:115-117), for score arrays that were
 // combined on the host (Ranking.interpolate).  Threads take blocks of queries; out_order[p] is a

@@ -34,7 +34,7 @@ SYMBOLS = (
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_buffer_free",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_take32", "ffx_host_interpolate",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route",
@@ -194,6 +194,7 @@ def lib() -> C.CDLL:
         "ffx_host_order": ([vp, vp, i64, i32, vp], C.c_int),
         "ffx_host_take32": ([vp, i64, vp, i64, i32, vp], C.c_int),
         "ffx_host_interpolate": ([vp, vp, vp, i64, C.c_float, C.c_float, i32, vp, P(i32)], C.c_int),
+        "ffx_host_outer_join": ([vp, vp, vp, vp, i64, i32, vp, vp, vp, vp], C.c_int),
         "ffx_comm_unique_id": ([C.c_int, vp], C.c_int),
         "ffx_comm_init": ([C.c_int, C.c_int, C.c_int, C.c_int, vp, P(vp)], C.c_int),
         "ffx_comm_destroy": ([vp], C.c_int),
@@ -648,6 +649,21 @@ def code_strings(blob: bytes, n: int, threads: int = 0) -> tuple[np.ndarray, byt
         if names.value:
             lib().ffx_buffer_free(names)
     return codes, joined, int(n_names.value)
+
+
+def outer_join(off_a, code_a, off_b, code_b, threads: int = 0):
+    """``ffx_host_outer_join``: (u_off, u_code, u_a, u_b) -- per query the union of two id-code lists in ascending
+    code, with the row of A / of B that holds each pair (-1 where a side lacks it)."""
+    off_a, off_b = _arr(off_a, np.int64), _arr(off_b, np.int64)
+    code_a, code_b = _arr(code_a, np.int32), _arr(code_b, np.int32)
+    n_q = off_a.shape[0] - 1
+    assert off_b.shape[0] == n_q + 1
+    room = int(off_a[-1] + off_b[-1])
+    u_off = np.empty(n_q + 1, dtype=np.int64)
+    u_code, u_a, u_b = (np.empty(max(1, room), dtype=np.int32) for _ in range(3))
+    _check(lib().ffx_host_outer_join(_ptr(off_a), _ptr(code_a), _ptr(off_b), _ptr(code_b), n_q, int(threads), _ptr(u_off), _ptr(u_code), _ptr(u_a), _ptr(u_b)))
+    n = int(u_off[-1])
+    return u_off, u_code[:n], u_a[:n], u_b[:n]
 
 
 def _as_fixed_bytes(strings) -> np.ndarray:

@@ -80,6 +80,17 @@ def _sorted_frame(df: pd.DataFrame) -> pd.DataFrame:
     return df.iloc[order]
 
 
+def _native_or_none():
+    """The ctypes layer if libffx can be loaded (host-side helpers need no GPU), else None."""
+    try:
+        from fast_forward_amd import native
+
+        native.lib()
+        return native
+    except (ImportError, OSError):
+        return None
+
+
 def _order_by_query_then_score(q_rank: np.ndarray, score: np.ndarray) -> np.ndarray:
     """Stable order by (query rank ascending, score descending): ``np.lexsort((-score, q_rank))``.  For float32
     scores the rows are first grouped by query (a stable integer sort: one pass when they already are, as in
@@ -391,28 +402,71 @@ class Ranking:
         gb = np.fromiter((code_of[q] for q in names_b), dtype=np.int64, count=len(names_b))[qb] if nb else np.zeros(0, dtype=np.int64)
         ca, ids_a = self._id_coding()
         cb, ids_b = other._id_coding()
+        native = _native_or_none() if na + nb >= (1 << 16) else None
         if ids_a is ids_b:
-            id_names, code_a, code_b = ids_a, ca.astype(np.int64), cb.astype(np.int64)
-        else:  # merge the two tables of distinct ids (not the rows)
-            merged, uniques = pd.factorize(np.concatenate([ids_a, ids_b]))
-            id_names = np.asarray(uniques, dtype=object)
+            id_names, code_a, code_b = ids_a, ca, cb
+        else:  # merge the two tables of DISTINCT ids (not the rows)
+            merged = None
+            if native is not None:  # numbered by threads from one joined buffer (no hash insert per string in Python)
+                packed = native._packed(np.concatenate([ids_a, ids_b]))
+                if packed is not None:
+                    codes, names_blob, n_names = native.code_strings(*packed)
+                    id_names = np.empty(n_names, dtype=object)
+                    id_names[:] = names_blob.decode("utf-8").split("\n")
+                    merged = codes
+            if merged is None:
+                merged, uniques = pd.factorize(np.concatenate([ids_a, ids_b]))
+                id_names = np.asarray(uniques, dtype=object)
             code_a, code_b = merged[:len(ids_a)][ca], merged[len(ids_a):][cb]
-        width = max(1, len(id_names))
-        keys, where = np.unique(np.concatenate([np.asarray(qa, dtype=np.int64) * width + code_a, gb * width + code_b]), return_inverse=True)
-        at_a, at_b = where[:na], where[na:]
-        n = keys.shape[0]
-        va, vb = np.zeros(n, dtype=sa.dtype), np.zeros(n, dtype=sb.dtype)
-        va[at_a], vb[at_b] = sa, sb
+        n_all = len(names)
+        joined = None
+        if native is not None:
+            # both sides grouped by query (always, for rankings the constructor sorted): per-query sort + merge by threads
+            pa, off_a = self._csr()
+            pb, off_b_own = other._csr()
+            if pa is None and pb is None:
+                cnt_a = np.zeros(n_all, dtype=np.int64)
+                cnt_a[:len(names_a)] = np.diff(off_a)
+                g_of_b = np.fromiter((code_of[q] for q in names_b), dtype=np.int64, count=len(names_b))
+                cnt_b = np.zeros(n_all, dtype=np.int64)
+                cnt_b[g_of_b] = np.diff(off_b_own)
+                # B's blocks re-arranged into the common query numbering
+                start_b = np.zeros(n_all, dtype=np.int64)
+                start_b[g_of_b] = off_b_own[:-1]
+                goff_a = np.zeros(n_all + 1, dtype=np.int64)
+                np.cumsum(cnt_a, out=goff_a[1:])
+                goff_b = np.zeros(n_all + 1, dtype=np.int64)
+                np.cumsum(cnt_b, out=goff_b[1:])
+                rows_b = (np.arange(nb, dtype=np.int64) + np.repeat(start_b - goff_b[:-1], cnt_b)).astype(np.int32) if nb else np.zeros(0, dtype=np.int32)
+                in_common_order = bool((np.diff(rows_b) == 1).all()) if nb > 1 else True
+                cb_g = np.ascontiguousarray(code_b, dtype=np.int32) if in_common_order else native.take32(np.ascontiguousarray(code_b, dtype=np.int32), rows_b)
+                u_off, u_code, u_a, u_b = native.outer_join(goff_a, np.ascontiguousarray(code_a, dtype=np.int32), goff_b, cb_g)
+                if not in_common_order:  # rows of B as B numbers them
+                    u_b = np.where(u_b >= 0, rows_b[np.maximum(u_b, 0)], -1).astype(np.int32)
+                joined = (np.repeat(np.arange(n_all, dtype=np.int64), np.diff(u_off)), u_code, u_a, u_b)
+        if joined is None:  # the NumPy statement of the same join
+            width = max(1, len(id_names))
+            keys, where = np.unique(np.concatenate([np.asarray(qa, dtype=np.int64) * width + np.asarray(code_a, dtype=np.int64),
+                                                    gb * width + np.asarray(code_b, dtype=np.int64)]), return_inverse=True)
+            u_a = np.full(keys.shape[0], -1, dtype=np.int64)
+            u_a[where[:na]] = np.arange(na)
+            u_b = np.full(keys.shape[0], -1, dtype=np.int64)
+            u_b[where[na:]] = np.arange(nb)
+            joined = (keys // width, (keys % width).astype(np.int32), u_a, u_b)
+        q_of, u_code, u_a, u_b = joined
+        n = len(u_code)
+        has_a, has_b = u_a >= 0, u_b >= 0
+        va = np.where(has_a, sa[np.maximum(u_a, 0)], sa.dtype.type(0)) if na else np.zeros(n, dtype=sa.dtype)
+        vb = np.where(has_b, sb[np.maximum(u_b, 0)], sb.dtype.type(0)) if nb else np.zeros(n, dtype=sb.dtype)
         score = np.asarray(fn(va, vb)).astype(self._score_dtype(), copy=False)
         if np.isnan(score).any():
             return None  # rows would be dropped: leave it to the general path
         # final order: q_id descending, score descending, exact ties by id ascending
-        q_of = keys // width
         rank_of = np.empty(len(names), dtype=np.int64)
         rank_of[np.argsort(np.array(names, dtype=object))[::-1]] = np.arange(len(names))
         q_rank = rank_of[q_of]
-        order = np.lexsort((-score.astype(np.float64), q_rank))
-        id_code = (keys % width)[order].astype(np.int32)
+        order = _order_by_query_then_score(q_rank, score)
+        id_code = np.asarray(u_code)[order].astype(np.int32)
         s_o, q_o = score[order], q_rank[order]
         tied = np.flatnonzero((s_o[1:] == s_o[:-1]) & (q_o[1:] == q_o[:-1]))
         if tied.size:
@@ -434,17 +488,15 @@ class Ranking:
         q_order = by_rank[present].tolist()
         # the query text comes from this ranking if it has any, else from `other`; a pair the
         # chosen side lacks gets the merge's fill value 0
-        side = (self, at_a) if self.has_queries else (other, at_b) if other.has_queries else None
-        if side is None or np.unique(side[1]).shape[0] == n:
+        side = (self, u_a) if self.has_queries else (other, u_b) if other.has_queries else None
+        if side is None or bool((side[1] >= 0).all()):
             q_texts = None
             if side is not None:  # every row has its text on that side: one text per query
                 text_of = dict(zip(side[0]._numbering()[1], side[0]._query_texts()))
                 q_texts = [text_of[q] for q in q_order]
             return Ranking._assemble_coded(self.name, renumber[q_o], q_order, id_code, id_names, s_o, q_texts)
         cols = {"q_id": q_names[q_of[order]], "id": id_names[id_code], "score": s_o}
-        src = np.full(n, -1, dtype=np.int64)
-        src[side[1]] = np.arange(len(side[1]))
-        src = src[order]
+        src = np.asarray(side[1])[order]
         query = np.zeros(n, dtype=object)
         have = src >= 0
         query[have] = side[0]._df["query"].to_numpy()[src[have]]

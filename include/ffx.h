@@ -407,6 +407,14 @@ int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_
 int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32_t* source_row, int64_t n, float a, float b,
                          int32_t n_threads, float* out, int32_t* any_nan);
 
+/* The outer join of Ranking.interpolate / + (ranking.py:293-326) on integer keys, for two rankings whose rows stand
+ * grouped by query: rows off_a[g] .. off_a[g+1] of A and off_b[g] .. off_b[g+1] of B belong to query g, code_a / code_b
+ * number the ids in one common table, a pair occurs at most once per side (FFX_BAD_ARG otherwise).  Per query the union
+ * of the id sets in ascending code: u_code, the row of A / of B holding the pair (u_a / u_b, -1 where missing); union
+ * rows of query g are u_off[g] .. u_off[g+1].  u_code / u_a / u_b must hold off_a[n] + off_b[n] entries. */
+int ffx_host_outer_join(const int64_t* off_a, const int32_t* code_a, const int64_t* off_b, const int32_t* code_b, int64_t n_queries,
+                        int32_t n_threads, int64_t* u_off, int32_t* u_code, int32_t* u_a, int32_t* u_b);
+
 /* ---- page-locked host memory ------------------------------------------------------------
  * Host buffers handed to the calls above may live anywhere; when they are page-locked the
  * copies to and from the device run at full link rate and overlap the kernels (ffx_score

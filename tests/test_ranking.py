@@ -466,3 +466,46 @@ def test_from_file_cut_save_match_the_reference_on_a_large_run(tmp_path):
         assert df["id"].tolist() == z[f"{tag}_id_names"][z[f"{tag}_id_code"]].tolist()
         assert np.array_equal(df["score"].to_numpy().view(np.uint32), z[f"{tag}_score"].view(np.uint32))
         assert hashlib.sha256("\n".join(df["query"].tolist()).encode()).hexdigest() == str(z[f"{tag}_query"][0])
+
+
+def test_threaded_outer_join_equals_the_numpy_join_and_the_merge(monkeypatch):
+    """Ranking.interpolate / + on two large rankings that are not each other's image: the id tables are merged by
+    ffx_strings_code and the outer join runs per query in host threads (ffx_host_outer_join).  Same rows, scores and
+    order as the NumPy statement of the join (forced by hiding libffx) and as the reference's own formulation (outer
+    merge of the frames, missing -> 0, constructor sort) -- partly overlapping candidate sets, queries that only one
+    side has, B's queries in another order, exact ties, query texts on either side."""
+    import fast_forward_amd.ranking as R
+    from fast_forward_amd import Ranking
+
+    rng = np.random.default_rng(17)
+    rows_a, rows_b = [], []
+    q_all = [f"q{i:03d}" for i in range(120)]
+    for q in q_all:
+        pool = rng.choice(30_000, size=700, replace=False)
+        in_a, in_b = pool[:500], pool[200:]
+        if q != "q007":
+            rows_a += [(q, f"D{d}", float(np.round(rng.random() * 20, 1))) for d in in_a]  # one decimal: many exact ties after combining
+        if q != "q011":
+            rows_b += [(q, f"D{d}", float(np.round(rng.standard_normal(), 1))) for d in in_b]
+    rng.shuffle(rows_b)
+    fa = pd.DataFrame(rows_a, columns=["q_id", "id", "score"])
+    fb = pd.DataFrame(rows_b, columns=["q_id", "id", "score"])
+    assert len(fa) + len(fb) >= (1 << 16)
+    queries = {q: f"text {q}" for q in q_all}
+    for qa, qb in ((queries, None), (None, queries), (None, None)):
+        a, b = Ranking(fa, queries=qa, name="a"), Ranking(fb, queries=qb, name="b")
+        fast_i, fast_p = a.interpolate(b, 0.3), a + b
+        monkeypatch.setattr(R, "_native_or_none", lambda: None)
+        a2, b2 = Ranking(fa, queries=qa, name="a"), Ranking(fb, queries=qb, name="b")
+        slow_i, slow_p = a2.interpolate(b2, 0.3), a2 + b2
+        monkeypatch.undo()
+        assert fast_i == slow_i and fast_p == slow_p
+        assert fast_i._df.equals(slow_i._df) and fast_p._df.equals(slow_p._df)
+        # the reference's formulation
+        both = a._df.merge(b._df, on=["q_id", "id"], how="outer", suffixes=(None, "_other")).fillna(0)
+        both["score"] = 0.3 * both["score"] + (1 - 0.3) * both["score_other"]
+        want = Ranking(both[["q_id", "id", "score"]], name="a")
+        assert fast_i == want
+        got = fast_i._df
+        assert got["q_id"].tolist() == want._df["q_id"].tolist()
+        assert np.array_equal(got["score"].to_numpy().view(np.uint32), want._df["score"].to_numpy().view(np.uint32))
