@@ -254,6 +254,58 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // ---- the threaded outer join
+  for (int round = 0; round < 30; ++round) {
+    const int64_t nq = (int64_t)(rnd() % 40);
+    std::vector<int64_t> oa{0}, ob{0};
+    std::vector<int32_t> ca, cb;
+    for (int64_t g = 0; g < nq; ++g) {
+      const int pool = 1 + (int)(rnd() % 300);
+      std::vector<int32_t> all((size_t)pool);
+      for (int i = 0; i < pool; ++i) all[(size_t)i] = i * 3 + (int)(rnd() % 3);
+      for (int side = 0; side < 2; ++side) {
+        std::vector<int32_t>& dst = side ? cb : ca;
+        std::vector<int32_t> pick;
+        for (int32_t c : all)
+          if (rnd() % 3) pick.push_back(c);
+        for (size_t i = pick.size(); i > 1; --i) std::swap(pick[i - 1], pick[(size_t)(rnd() % i)]);
+        if (rnd() % 7 == 0) pick.clear();
+        dst.insert(dst.end(), pick.begin(), pick.end());
+        (side ? ob : oa).push_back((int64_t)dst.size());
+      }
+    }
+    const size_t room = ca.size() + cb.size();
+    std::vector<int64_t> uoff((size_t)nq + 1);
+    std::vector<int32_t> uc(room + 1), ua(room + 1), ub(room + 1);
+    if (ffx_host_outer_join(oa.data(), ca.data(), ob.data(), cb.data(), nq, 1 + (int)(rnd() % 4), uoff.data(), uc.data(), ua.data(), ub.data()) != FFX_OK) return 1;
+    for (int64_t g = 0; g < nq; ++g) {
+      int64_t prev = -1;
+      int64_t seen_a = 0, seen_b = 0;
+      for (int64_t i = uoff[(size_t)g]; i < uoff[(size_t)g + 1]; ++i) {
+        if (uc[(size_t)i] <= prev) return 1;  // ascending, no duplicate
+        prev = uc[(size_t)i];
+        if (ua[(size_t)i] < 0 && ub[(size_t)i] < 0) return 1;
+        if (ua[(size_t)i] >= 0) {
+          if (ua[(size_t)i] < oa[(size_t)g] || ua[(size_t)i] >= oa[(size_t)g + 1] || ca[(size_t)ua[(size_t)i]] != uc[(size_t)i]) return 1;
+          ++seen_a;
+        }
+        if (ub[(size_t)i] >= 0) {
+          if (ub[(size_t)i] < ob[(size_t)g] || ub[(size_t)i] >= ob[(size_t)g + 1] || cb[(size_t)ub[(size_t)i]] != uc[(size_t)i]) return 1;
+          ++seen_b;
+        }
+      }
+      if (seen_a != oa[(size_t)g + 1] - oa[(size_t)g] || seen_b != ob[(size_t)g + 1] - ob[(size_t)g]) return 1;
+    }
+    if (!ca.empty() && oa.size() > 1) {  // an id twice on one side is refused
+      for (int64_t g = 0; g < nq; ++g)
+        if (oa[(size_t)g + 1] - oa[(size_t)g] >= 2) {
+          std::vector<int32_t> twice = ca;
+          twice[(size_t)oa[(size_t)g]] = twice[(size_t)oa[(size_t)g] + 1];
+          if (ffx_host_outer_join(oa.data(), twice.data(), ob.data(), cb.data(), nq, 2, uoff.data(), uc.data(), ua.data(), ub.data()) == FFX_OK) return 1;
+          break;
+        }
+    }
+  }
   ffx_ids_destroy(ids);
   remove(in.c_str());
   remove(out.c_str());
