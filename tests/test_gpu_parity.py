@@ -526,8 +526,9 @@ def test_sharded_scorer_single_rank_nccl():
     assert "sharded 1-rank ok" in out.stdout
 
 
-@pytest.mark.parametrize("world,sharding", [(2, "rows"), (3, "rows"), (2, "queries")])
-def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding):
+@pytest.mark.parametrize("world,sharding,spelling", [(2, "rows", "--transport host"), (3, "rows", "--transport host"), (2, "queries", "--transport host"),
+                                                     (2, "rows", "--dist-backend gloo")])
+def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding, spelling):
     """`python bench.py --gpus N` exactly as the driver starts it (no outer launcher: bench.py starts
     its own ranks): rows sharded by document, two plans alternating between a compute and a
     communication stream, owner-side merge, with `world` ranks on this one GPU; the exchange goes
@@ -539,7 +540,7 @@ def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding):
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(world), "--transport", "host",
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(world), *spelling.split(),  # (--dist-backend gloo: round 1's spelling of the same)
            "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "12",
            "--cpu-seconds", "0.2", "--sharding", sharding]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
