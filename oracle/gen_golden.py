@@ -465,6 +465,26 @@ def run_file_case():
     return {"rows": int(len(out["full_score"])), "text_sha256": hashlib.sha256(text.encode()).hexdigest()}
 
 
+def join_case():
+    """Ranking.interpolate (alpha 0.25; ranking.py:293-326) and + (ranking.py:270-291) of two large rankings that only
+    partly overlap: the reference's result rows as codes into sorted name tables + scores."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from _cases import two_runs
+
+    fa, fb = two_runs()
+    a, b = Ranking(fa, name="a"), Ranking(fb, name="b")
+    out = {}
+    for tag, rk in (("interp", a.interpolate(b, 0.25)), ("plus", a + b)):
+        df = rk._df
+        q_names, id_names = np.unique(df["q_id"].to_numpy().astype(str)), np.unique(df["id"].to_numpy().astype(str))
+        out[f"{tag}_q_names"], out[f"{tag}_id_names"] = q_names, id_names
+        out[f"{tag}_q_code"] = np.searchsorted(q_names, df["q_id"].to_numpy().astype(str)).astype(np.int32)
+        out[f"{tag}_id_code"] = np.searchsorted(id_names, df["id"].to_numpy().astype(str)).astype(np.int32)
+        out[f"{tag}_score"] = df["score"].to_numpy().astype(np.float32)
+    np.savez_compressed(OUT / "join.npz", **out)
+    return {"rows_a": int(len(fa)), "rows_b": int(len(fb)), "rows_out": int(len(out["interp_score"]))}
+
+
 def f64_cases():
     """The reference's DEFAULT arithmetic on any index larger than one chunk: float64 chunks after the
     first (index/memory.py:106), hence float64 products and sums, cast to float32 at the very end
@@ -505,6 +525,8 @@ def main():
             manifest["cases"].update(f64_cases())
         if sys.argv[2] == "run_file":
             manifest["cases"]["run_file"] = run_file_case()
+        if sys.argv[2] == "join":
+            manifest["cases"]["join"] = join_case()
         if sys.argv[2] == "es_docs":
             manifest["cases"]["early_stopping_docs"] = early_stopping_docs_case()
         if sys.argv[2] == "sub200k":
@@ -537,6 +559,7 @@ def main():
     manifest["cases"]["coalesce"] = coalesce_case()
     manifest["cases"].update(f64_cases())
     manifest["cases"]["run_file"] = run_file_case()
+    manifest["cases"]["join"] = join_case()
     manifest["cases"]["sub200k"] = sub200k_case()
     (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     total = sum(f.stat().st_size for f in OUT.iterdir())

@@ -228,3 +228,27 @@ def run_file_text(seed: int = 77) -> tuple[str, dict]:
             name = f"dö{d}" if d % 13 == 0 else (f"{d}" if int(q[1:]) % 10 == 0 else f"D{d}")
             lines.append(f"{q} Q0 {name} {i + 1} {float(s)!r} bm25")
     return "\n".join(lines) + "\n", {q: f"text of {q}" for q in q_ids}
+
+
+def two_runs(seed: int = 91):
+    """Two first-stage runs as frames of (q_id, id, score) that are NOT each other's image -- partly overlapping
+    candidate sets, a query only the first has, one only the second has, the second one shuffled -- with more than
+    65 536 rows together, so that ``Ranking.interpolate`` / ``+`` take the threaded outer join.  Scores are multiples
+    of 1/8 (exact in float32, many exact ties after combining).  Used by oracle/gen_golden.py (fed to the reference)
+    and by the test that compares the build with the stored result."""
+    import pandas as pd
+
+    rng = np.random.default_rng(seed)
+    rows_a, rows_b = [], []
+    for i in range(110):
+        q = f"q{i:03d}"
+        pool = rng.choice(25_000, size=650, replace=False)
+        if i != 7:
+            rows_a += [(q, f"D{d}", float(rng.integers(0, 160)) / 8.0) for d in pool[:450]]
+        if i != 11:
+            rows_b += [(q, f"D{d}", float(rng.integers(-24, 24)) / 8.0) for d in pool[200:]]
+    order = rng.permutation(len(rows_b))
+    rows_b = [rows_b[j] for j in order]
+    fa = pd.DataFrame(rows_a, columns=["q_id", "id", "score"])
+    fb = pd.DataFrame(rows_b, columns=["q_id", "id", "score"])
+    return fa, fb
