@@ -318,7 +318,14 @@ class Index(abc.ABC):
             out = Ranking._assemble_coded("fast-forward", q_no, q_order, native.take32(codes, order), names,
                                           native.take32(dense, order).astype(ranking._score_dtype(), copy=False), texts)
             # row i of the result is row order[i] of `ranking`: ranking.interpolate(result, alpha) needs no join
-            out._source_rows = (weakref.ref(ranking), order.copy())  # (`order` may be a view of the index's re-used result block)
+            if order.base is not None and getattr(self, "_result_buffers", None) is not None:
+                # `order` is a view of the index's re-used result block: the result borrows it until the index needs the
+                # block again (then it gets its own copy, InMemoryIndex._result_buffers) -- the interpolate that usually
+                # follows at once reads it in place
+                out._source_rows = (weakref.ref(ranking), order)
+                self._order_borrower = weakref.ref(out)
+            else:
+                out._source_rows = (weakref.ref(ranking), order.copy())
             return out
         if (early_stopping is not None and final_order and grouped is None and len(q_no) >= _CODED_MIN_ROWS and (batch_size is None or batch_size >= n_q)
                 and getattr(self, "_early_stopping_takes_ordinals", False) and ranking._score_dtype() == np.float32):

@@ -208,6 +208,13 @@ class InMemoryIndex(Index):
         them at link rate and without a page fault per 4 KB (a fresh 140 MB array costs ~10 ms just to touch).
         Only for callers that consume the results before the next call (the coded paths of ``__call__`` /
         ``rerank`` gather out of them at once)."""
+        # a ranking handed out by the previous call may still look into the block (Index.__call__ leaves the device's
+        # order there for the interpolate that usually follows at once): give it its own copy before the block is re-used
+        holder = getattr(self, "_order_borrower", None)
+        holder = holder() if holder is not None else None
+        if holder is not None and getattr(holder, "_source_rows", None) is not None and holder._source_rows[1].base is not None:
+            holder._source_rows = (holder._source_rows[0], holder._source_rows[1].copy())
+        self._order_borrower = None
         have = getattr(self, "_out_cache", None)
         if have is None or have[0].size < n:
             cap = n + n // 8

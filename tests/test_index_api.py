@@ -631,3 +631,33 @@ def test_adopting_rows_that_are_already_on_the_device():
     assert store.gather(np.array([7], dtype=np.int32)).shape == (1, d)  # still alive
     store.close()
     plain.close()
+
+
+def test_a_result_keeps_its_row_link_when_the_index_reuses_its_result_block():
+    """Index.__call__ on a large run leaves the device's order in the index's re-used page-locked block and lends it to
+    the result (for the interpolate that usually follows at once).  A later large call on the same index must not
+    disturb an earlier result: it gets its own copy first.  1.2 M pairs per call (the block is used from 1 M)."""
+    rng = np.random.default_rng(5)
+    n, d, n_q, k = 60_000, 32, 300, 4000
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qv = rng.standard_normal((n_q, d)).astype(np.float32)
+    index = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=Mode.PASSAGE)
+    index.add(rows, psg_ids=[f"P{i}" for i in range(n)])
+
+    def run(seed):
+        r = np.random.default_rng(seed)
+        ids = np.concatenate([r.choice(n, size=k, replace=False) for _ in range(n_q)])
+        frame = pd.DataFrame({"q_id": np.repeat([f"q{i:03d}" for i in range(n_q)], k), "id": [f"P{x}" for x in ids],
+                              "score": (r.random(n_q * k) * 20).astype(np.float32)})
+        return Ranking(frame, queries={f"q{i:03d}": str(i) for i in range(n_q)})
+
+    first, second = run(1), run(2)
+    dense_first = index(first)
+    borrowed = dense_first._source_rows[1]
+    assert borrowed.base is not None  # a view of the index's block
+    keep = borrowed.copy()
+    dense_second = index(second)       # re-uses the block
+    assert dense_first._source_rows[1].base is None and np.array_equal(dense_first._source_rows[1], keep)  # its own copy now, same content
+    assert first.interpolate(dense_first, 0.2) == index.rerank(first, 0.2)
+    assert second.interpolate(dense_second, 0.2) == index.rerank(second, 0.2)
+    index.close()
