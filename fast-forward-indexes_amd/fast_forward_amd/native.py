@@ -223,8 +223,8 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = restype
-    if L.ffx_abi_version() != 1:
-        raise ImportError(f"libffx ABI {L.ffx_abi_version()} does not match this binding (1)")
+    if L.ffx_abi_version() != 2:
+        raise ImportError(f"libffx ABI {L.ffx_abi_version()} does not match this binding (2)")
     _lib = L
     return L
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 1
+#define FFX_ABI_VERSION 2  /* 2: ffx_shard_stats grew (ms_exchange, ms_merge); everything else added since 1 is additive */
 
 /* status codes */
 #define FFX_OK 0
