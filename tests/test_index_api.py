@@ -661,3 +661,33 @@ def test_a_result_keeps_its_row_link_when_the_index_reuses_its_result_block():
     assert first.interpolate(dense_first, 0.2) == index.rerank(first, 0.2)
     assert second.interpolate(dense_second, 0.2) == index.rerank(second, 0.2)
     index.close()
+
+
+def test_early_stopping_on_a_large_run_edge_cases():
+    """The coded early-stopping route (>= 4096 rows: id codes in, only the scored candidates back, a coded Ranking out)
+    on the edges: depths all below the cutoff (nothing is scored: an empty ranking), an unknown id that IS reached
+    (IndexError naming it) and one that is not (fine, as in the reference), a cutoff beyond every list (everything
+    scored once: equals the plain call)."""
+    rng = np.random.default_rng(0)
+    n, d, n_q, k = 5000, 32, 10, 600
+    qv = rng.standard_normal((n_q, d)).astype(np.float32)
+    idx = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=Mode.PASSAGE)
+    idx.add(rng.standard_normal((n, d)).astype(np.float32), psg_ids=[f"P{i}" for i in range(n)])
+    frame = pd.DataFrame({"q_id": np.repeat([f"q{i}" for i in range(n_q)], k),
+                          "id": np.concatenate([[f"P{x}" for x in rng.choice(n, size=k, replace=False)] for _ in range(n_q)]),
+                          "score": -np.sort(-(rng.random((n_q, k)) * 20).astype(np.float32), axis=1).reshape(-1)})
+    queries = {f"q{i}": str(i) for i in range(n_q)}
+    first = Ranking(frame, queries=queries)
+    nothing = idx(first, early_stopping=50, early_stopping_alpha=0.2, early_stopping_depths=(5, 10))
+    assert nothing._coded is not None and len(nothing) == 0 and len(nothing._df) == 0
+    bad = frame.copy()
+    bad.loc[3, "id"] = "nowhere"
+    with pytest.raises(IndexError, match="nowhere"):
+        idx(Ranking(bad, queries=queries), early_stopping=5, early_stopping_alpha=0.2, early_stopping_depths=(5, 50))
+    bad = frame.copy()
+    bad.loc[590, "id"] = "nowhere"
+    fine = idx(Ranking(bad, queries=queries), early_stopping=5, early_stopping_alpha=0.2, early_stopping_depths=(5, 50))
+    assert 0 < len(fine._df) < len(frame)
+    everything = idx(first, early_stopping=10**6, early_stopping_alpha=0.2, early_stopping_depths=(10**6,))
+    assert everything == idx(first) and len(everything._df) == len(frame)
+    idx.close()
