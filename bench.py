@@ -590,7 +590,7 @@ def side_regions(args, index, plan, queries, pair_off, ids, sparse, exact: bool)
     out["ii_pinned_queries_per_s"] = args.queries / (out["ii_pinned_ms"] * 1e-3)
     out["ii_note"] = ("ffx_score: candidate CSR + sparse scores + query vectors in host memory -> dense + interpolated scores"
                       f"{' + per-query order' if args.sort else ''} in host memory ({(n * (8 + 4 * (3 if args.sort else 2)) + queries.nbytes) / 1e6:.0f} MB over PCIe "
-                      "per step); slices of whole queries alternate between two plans so copies overlap the kernels")
+                      "per step); slices of whole queries rotate through three plans, their kernels run in order on one stream, so uploads, kernels and downloads of successive slices overlap")
     # what the box streams: every row once, in order and in a random permutation
     if args.store != "pq" and args.layout == "single":
         row_bytes = args.dim * index.dtype.itemsize + 4
