@@ -181,6 +181,11 @@ struct ffx_plan {
   hipStream_t stream = nullptr;      // the stream work is issued on
   hipStream_t own_stream = nullptr;  // created with the plan; `stream` may point elsewhere
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // gather_dot's start / end of the most recent runs, so that a caller who queues runs back to back (no wait in
+  // between) can still read every run's kernel time afterwards (ffx_plan_recent_gather_ms); created on first use
+  static constexpr int kRecent = 256;
+  hipEvent_t recent[kRecent][2] = {};
+  uint64_t n_runs = 0;
   // inputs
   DevBuf queries, pair_off, pair_ids, sparse;
   // workspace
@@ -693,6 +698,9 @@ int ffx_plan_destroy(ffx_plan* pl) {
     b->release();
   for (auto& e : pl->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& pair : pl->recent)
+    for (auto& e : pair)
+      if (e) (void)hipEventDestroy(e);
   if (pl->own_stream) (void)hipStreamDestroy(pl->own_stream);
   if (pl->hstage) (void)hipHostFree(pl->hstage);
   delete pl;
@@ -1402,9 +1410,16 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
   const bool pq_fused = single && P > 0 && !getenv("FFX_PQ_NO_FUSE") && pq_exact_adc_applies(pl);
   if (pq_fused) {
+    hipEvent_t* recent_pq = pl->recent[pl->n_runs % ffx_plan::kRecent];
+    if (!recent_pq[0]) {
+      FFX_HIP(hipEventCreate(&recent_pq[0]));
+      FFX_HIP(hipEventCreate(&recent_pq[1]));
+    }
     FFX_HIP(hipEventRecord(pl->ev[1], st));
+    FFX_HIP(hipEventRecord(recent_pq[0], st));
     FFX_TRY(launch_pq_fused(pl, (float)alpha, (float)(1.0 - alpha)));
     FFX_HIP(hipEventRecord(pl->ev[2], st));
+    FFX_HIP(hipEventRecord(recent_pq[1], st));
   }
   if (P > 0 && !pq_fused) {
     // 1. candidates -> row list
@@ -1424,10 +1439,17 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
     FFX_HIP(hipGetLastError());
   }
   if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[1], st));
+  hipEvent_t* recent = pl->recent[pl->n_runs % ffx_plan::kRecent];
+  if (!recent[0]) {
+    FFX_HIP(hipEventCreate(&recent[0]));
+    FFX_HIP(hipEventCreate(&recent[1]));
+  }
+  if (!pq_fused) FFX_HIP(hipEventRecord(recent[0], st));
   // 2. gather + inner product (the hot kernel)
   float* rs = single ? pl->ff.as<float>() : pl->rs.as<float>();
   if (R > 0 && !pq_fused) FFX_TRY(launch_gather_dot(pl, exact, rs));
   if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[2], st));
+  if (!pq_fused) FFX_HIP(hipEventRecord(recent[1], st));
   // 3. segment aggregation + interpolation
   const float a = (float)alpha;
   const float b = (float)(1.0 - alpha);
@@ -1454,6 +1476,21 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   FFX_HIP(hipEventRecord(pl->ev[4], st));
   pl->ran = true;
   pl->ran_sort = do_sort;
+  ++pl->n_runs;
+  return FFX_OK;
+}
+
+// gather_dot's duration (HIP events on the plan's stream) of the last n runs of ffx_plan_run, oldest first, for a caller
+// that queued them without waiting in between; waits for the stream.  n <= 256 and <= the runs so far.
+int ffx_plan_recent_gather_ms(ffx_plan* pl, int32_t n, float* out_ms) {
+  if (!pl || n < 0 || (n > 0 && !out_ms)) return fail(FFX_BAD_ARG, "bad argument");
+  if (n > ffx_plan::kRecent || (uint64_t)n > pl->n_runs) return fail(FFX_BAD_ARG, "only the last %d runs are kept (%llu so far)", ffx_plan::kRecent, (unsigned long long)pl->n_runs);
+  FFX_HIP(hipSetDevice(pl->device));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  for (int32_t i = 0; i < n; ++i) {
+    hipEvent_t* pair = pl->recent[(pl->n_runs - (uint64_t)n + (uint64_t)i) % ffx_plan::kRecent];
+    FFX_HIP(hipEventElapsedTime(&out_ms[i], pair[0], pair[1]));
+  }
   return FFX_OK;
 }
 

@@ -27,7 +27,7 @@ SYMBOLS = (
     "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device",
-    "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
+    "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_recent_gather_ms", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
     "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
         "ffx_plan_set_pairs_lazy": ([vp, vp, i64, vp, vp, C.c_int], C.c_int),
         "ffx_plan_early_stopping": ([vp, i32, C.c_double, vp, i32, C.c_uint32, P(i64), P(i64), P(i32)], C.c_int),
         "ffx_plan_fetch_scored": ([vp, i64, vp, vp, P(i64)], C.c_int),
+        "ffx_plan_recent_gather_ms": ([vp, i32, vp], C.c_int),
         "ffx_plan_sync": ([vp], C.c_int),
         "ffx_plan_fetch": ([vp, vp, vp, vp], C.c_int),
         "ffx_plan_stats": ([vp, P(Stats)], C.c_int),
@@ -438,6 +439,12 @@ class Plan:
         if got.value != n:
             raise FFXError(BAD_ARG, f"{got.value} candidates were scored, {n} expected")
         return pos, ff
+
+    def recent_gather_ms(self, n: int) -> np.ndarray:
+        """gather_dot's duration of the last ``n`` runs (HIP events), oldest first; the runs may have been queued back to back."""
+        out = np.empty(int(n), dtype=np.float32)
+        _check(lib().ffx_plan_recent_gather_ms(self._h, int(n), _ptr(out)))
+        return out
 
     def sync(self) -> None:
         _check(lib().ffx_plan_sync(self._h))

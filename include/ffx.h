@@ -160,6 +160,9 @@ int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src);
 int ffx_plan_set_pairs_device(ffx_plan* plan, const int64_t* dev_pair_off, const int64_t* host_pair_off, int64_t n_queries,
                               const int32_t* dev_pair_ids, int mode, int64_t* bad_pair);
 int ffx_plan_run(ffx_plan* plan, double alpha, uint32_t flags);
+/* gather_dot's duration (HIP events on the plan's stream) of the last n runs, oldest first, for a caller that queues
+ * runs back to back without waiting in between (n <= 256 and <= the runs so far); waits for the stream */
+int ffx_plan_recent_gather_ms(ffx_plan* plan, int32_t n, float* out_ms);
 /* ---- early stopping: replaces Index._early_stopping, index/base.py:316-387 ------------------
  * Candidates of a query stand in first-stage rank order.  set_pairs_lazy uploads the lists without
  * validating ordinals (use -1 for an id the host could not resolve): as in the reference, an unknown
