@@ -1427,7 +1427,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
     if (single) {
       const int32_t* row_of = pl->mode == FFX_MODE_PASSAGE ? (ix->psgs_identity ? nullptr : ix->psg_row.as<int32_t>())
                                                            : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
-      ffx::expand_single_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
+      ffx::expand_single_kernel<<<blocks_for((P + 3) / 4, 256), 256, 0, st>>>(
           pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of, ix->capacity, pl->desc.as<int2>());
     } else {
       FFX_TRY(launch_count_scan(pl));
@@ -1459,7 +1459,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
           rs, pl->seg_off.as<int32_t>(), P, pl->mode, pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b,
           pl->ff.as<float>(), pl->interp.as<float>());
     } else if (pl->have_sparse) {
-      ffx::interp_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->ff.as<float>(), pl->sparse.as<float>(), P, a, b,
+      ffx::interp_kernel<<<blocks_for((P + 3) / 4, 256), 256, 0, st>>>(pl->ff.as<float>(), pl->sparse.as<float>(), P, a, b,
                                                             pl->interp.as<float>());
     }
     FFX_HIP(hipGetLastError());
