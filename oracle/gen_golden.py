@@ -196,14 +196,15 @@ def interpolate_case():
     return {"rows_a": len(rows_a), "rows_b": len(rows_b)}
 
 
-def early_stopping_case():
-    """index/base.py:316-387 on passage runs; cut-off, alpha and depths as fixture data."""
-    dim, seed, scale, n_psg, n_q = 32, 77, 0.35, 300, 6
+def early_stopping_case(large: bool = False):
+    """index/base.py:316-387 on passage runs; cut-off, alpha and depths as fixture data.  ``large``: a run of more
+    than 4096 rows (the build then takes its coded route by itself)."""
+    dim, seed, scale, n_psg, n_q = (32, 78, 0.35, 6000, 24) if large else (32, 77, 0.35, 300, 6)
     vectors = synth.rows(seed, scale, 0, n_psg, dim)
     qvecs = synth.rows(seed + 1000, scale, 0, n_q, dim)
     rng = np.random.default_rng(seed)
-    q_names = [f"q{i}" for i in range(n_q)]
-    lens = [300, 250, 120, 300, 40, 9]
+    q_names = [f"q{i:02d}" for i in range(n_q)] if large else [f"q{i}" for i in range(n_q)]
+    lens = [int(x) for x in rng.integers(150, 520, size=n_q)] if large else [300, 250, 120, 300, 40, 9]
     cands = [rng.choice(n_psg, size=n, replace=False).astype(np.int32) for n in lens]
     sparse = [np.sort(rng.random(n).astype(np.float32) * 4)[::-1].copy() for n in lens]
     first = run_frame(q_names, [[f"P{c}" for c in row] for row in cands], sparse)
@@ -216,8 +217,8 @@ def early_stopping_case():
         res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
         for key, val in frame_arrays(res).items():
             out[f"es{ci}_{key}"] = val
-    np.savez_compressed(OUT / "early_stopping.npz", **out)
-    return {"configs": len(configs)}
+    np.savez_compressed(OUT / ("early_stopping_large.npz" if large else "early_stopping.npz"), **out)
+    return {"configs": len(configs), "rows": int(sum(lens))}
 
 
 def early_stopping_docs_case():
@@ -527,6 +528,8 @@ def main():
             manifest["cases"]["run_file"] = run_file_case()
         if sys.argv[2] == "join":
             manifest["cases"]["join"] = join_case()
+        if sys.argv[2] == "es_large":
+            manifest["cases"]["early_stopping_large"] = early_stopping_case(large=True)
         if sys.argv[2] == "es_docs":
             manifest["cases"]["early_stopping_docs"] = early_stopping_docs_case()
         if sys.argv[2] == "sub200k":
@@ -560,6 +563,7 @@ def main():
     manifest["cases"].update(f64_cases())
     manifest["cases"]["run_file"] = run_file_case()
     manifest["cases"]["join"] = join_case()
+    manifest["cases"]["early_stopping_large"] = early_stopping_case(large=True)
     manifest["cases"]["sub200k"] = sub200k_case()
     (OUT / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True) + "\n")
     total = sum(f.stat().st_size for f in OUT.iterdir())

@@ -178,14 +178,15 @@ def test_early_stopping_looks_up_only_what_it_scores():
         idx(Ranking(pd.DataFrame(deep)))
 
 
-@pytest.mark.parametrize("coded", [False, True])
-def test_early_stopping_matches_reference_frames(coded, monkeypatch):
-    """``coded``: the route of large runs (integer id codes in, a coded Ranking out) forced onto this small fixture."""
-    if coded:
+@pytest.mark.parametrize("fixture,coded", [("early_stopping", False), ("early_stopping", True), ("early_stopping_large", True)])
+def test_early_stopping_matches_reference_frames(fixture, coded, monkeypatch):
+    """``coded``: the route of large runs (integer id codes in, a coded Ranking out) -- forced onto the small fixture,
+    taken by itself on the large one (7730 rows, 24 queries of 150 - 520 candidates)."""
+    if coded and fixture == "early_stopping":
         import fast_forward_amd.index.api as api_mod
 
         monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1)
-    z = np.load(GOLDEN / "early_stopping.npz")
+    z = np.load(GOLDEN / f"{fixture}.npz")
     dim, seed, scale, n_psg = int(z["dim"]), int(z["seed"]), float(z["scale"]), int(z["n_psg"])
     q_names = z["q_names"].tolist()
     qvecs = synth.rows(seed + 1000, scale, 0, len(q_names), dim)
