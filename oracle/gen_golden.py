@@ -555,6 +555,16 @@ def main():
         manifest["cases"]["odd_dims"][str(dim)] = scoring_case(
             f"dim{dim}", seed=100 + dim, dim=dim, n_docs=40, psg_lo=1, psg_hi=3, n_q=4, k=12, scale=1.0,
             sparse_hi=10.0, modes=["MAXP", "AVEP"])
+    manifest["cases"]["d768_f16"] = scoring_case(
+        "d768_f16", seed=3, dim=768, n_docs=64, psg_lo=1, psg_hi=8, n_q=8, k=32, scale=1.0,
+        sparse_hi=25.0, modes=["PASSAGE", "FIRSTP", "AVEP", "MAXP"], store=np.float16)
+    manifest["cases"]["dim100_f16"] = scoring_case(
+        "dim100_f16", seed=200, dim=100, n_docs=40, psg_lo=1, psg_hi=3, n_q=4, k=12, scale=1.0,
+        sparse_hi=10.0, modes=["MAXP", "AVEP"], store=np.float16)
+    manifest["cases"]["dim128_f16"] = scoring_case(
+        "dim128_f16", seed=201, dim=128, n_docs=60, psg_lo=1, psg_hi=3, n_q=4, k=20, scale=1.0,
+        sparse_hi=10.0, modes=["MAXP"], store=np.float16)
+    manifest["cases"]["pq"] = {name: pq_case(name, **kw) for name, kw in PQ_CASES.items()}
     manifest["cases"]["partial_ids"] = partial_ids_case()
     manifest["cases"]["interpolate"] = interpolate_case()
     manifest["cases"]["early_stopping"] = early_stopping_case()
