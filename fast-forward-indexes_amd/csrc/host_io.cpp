@@ -729,6 +729,67 @@ int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32
   return FFX_OK;
 }
 
+// The distinct row numbers a batch gathers (each is read from the index file once, disk.py:309-336 reads them per
+// batch too) in ascending order, and for every gathered row its position in that list: numpy.unique(rows,
+// return_inverse=True) for values in 0 .. n_index_rows-1, without the sort -- a bitmap over the index's rows is marked by
+// threads, ranked by a prefix over its 64-bit words, and read back.  uniq must hold min(n, n_index_rows) entries.
+int ffx_host_unique_rows(const int64_t* rows, int64_t n, int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse) {
+  if (n_uniq) *n_uniq = 0;
+  if (n < 0 || n_index_rows < 0 || !n_uniq || (n > 0 && (!rows || !uniq || !inverse))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return FFX_OK;
+  if (n_index_rows > (int64_t)INT32_MAX) return ffx_fail(FFX_BAD_ARG, "too many index rows for int32 positions");
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  const int64_t n_words = (n_index_rows + 63) / 64;
+  try {
+    std::vector<std::atomic<uint64_t>> bits((size_t)std::max<int64_t>(n_words, 1));
+    for (auto& w : bits) w.store(0, std::memory_order_relaxed);
+    std::vector<int64_t> before((size_t)n_words + 1);
+    std::atomic<int64_t> bad(-1);
+    run_threads(T, [&](int t) {
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+        const int64_t r = rows[i];
+        if ((uint64_t)r >= (uint64_t)n_index_rows) {
+          int64_t none = -1;
+          bad.compare_exchange_strong(none, i);
+          continue;
+        }
+        bits[(size_t)(r >> 6)].fetch_or(1ull << (r & 63), std::memory_order_relaxed);
+      }
+    });
+    if (bad.load() >= 0) return ffx_fail(FFX_BAD_ARG, "rows[%lld] = %lld is outside the index", (long long)bad.load(), (long long)rows[bad.load()]);
+    int64_t total = 0;
+    for (int64_t w = 0; w < n_words; ++w) {
+      before[(size_t)w] = total;
+      total += __builtin_popcountll(bits[(size_t)w].load(std::memory_order_relaxed));
+    }
+    before[(size_t)n_words] = total;
+    *n_uniq = total;
+    run_threads(T, [&](int t) {
+      for (int64_t w = n_words * t / T; w < n_words * (t + 1) / T; ++w) {
+        uint64_t m = bits[(size_t)w].load(std::memory_order_relaxed);
+        int64_t at = before[(size_t)w];
+        while (m) {
+          uniq[at++] = (w << 6) + __builtin_ctzll(m);
+          m &= m - 1;
+        }
+      }
+    });
+    run_threads(T, [&](int t) {
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+        const int64_t r = rows[i];
+        const uint64_t m = bits[(size_t)(r >> 6)].load(std::memory_order_relaxed);
+        inverse[i] = (int32_t)(before[(size_t)(r >> 6)] + __builtin_popcountll(m & ((1ull << (r & 63)) - 1ull)));
+      }
+    });
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  return FFX_OK;
+}
+
 // The outer join of Ranking.interpolate / __add__ (ranking.py:293-326: merge on (q_id, id), how="outer") for two
 // rankings whose rows stand grouped by query, on integer keys: query g owns rows off_a[g] .. off_a[g+1] of A and rows
 // off_b[g] .. off_b[g+1] of B; code_a / code_b number the ids in one common table; a (query, id) pair occurs at most

@@ -412,7 +412,11 @@ class OnDiskIndex(Index):
         n_q = q.shape[0]
         pair_off = np.asarray(pair_off, dtype=np.int64)
         rows, row_q, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
-        uniq, slot_row = np.unique(rows, return_inverse=True)  # each needed row is read once
+        # each needed row is read once: the distinct rows, ascending, and every gathered row's slot among them
+        if rows.shape[0] >= (1 << 16):
+            uniq, slot_row = native.unique_rows(rows, len(self))
+        else:
+            uniq, slot_row = np.unique(rows, return_inverse=True)
         store_dtype = np.dtype(self._meta["dtype"])
         if host_decode or store_dtype not in (np.dtype(np.float16), np.dtype(np.uint8)):
             store_dtype = np.dtype(np.float32)  # float64 files of the reference are scored in fp32 (DESIGN.md divergence 1)

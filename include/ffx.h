@@ -410,6 +410,11 @@ int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_
 int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32_t* source_row, int64_t n, float a, float b,
                          int32_t n_threads, float* out, int32_t* any_nan);
 
+/* numpy.unique(rows, return_inverse=True) for row numbers in 0 .. n_index_rows-1 without a sort (a bitmap over the
+ * index's rows, marked and ranked by host threads): the distinct rows a streamed batch reads from the index file, ascending,
+ * and every gathered row's position among them.  uniq must hold min(n, n_index_rows) entries. */
+int ffx_host_unique_rows(const int64_t* rows, int64_t n, int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse);
+
 /* The outer join of Ranking.interpolate / + (ranking.py:293-326) on integer keys, for two rankings whose rows stand
  * grouped by query: rows off_a[g] .. off_a[g+1] of A and off_b[g] .. off_b[g+1] of B belong to query g, code_a / code_b
  * number the ids in one common table, a pair occurs at most once per side (FFX_BAD_ARG otherwise).  Per query the union

@@ -362,3 +362,23 @@ def test_coded_run_writer_equals_the_string_writer(tmp_path):
     with pytest.raises(native.FFXError, match="row 17"):
         native.save_run_coded(tmp_path / "bad.tsv", q_names, pair_off, bad, names, scores, "tag")
     assert not native.save_run_coded(tmp_path / "q.tsv", q_names, pair_off, codes, np.array(['a"b'] * pool, dtype=object), scores, "tag")  # needs a CSV writer
+
+
+def test_native_unique_rows_equals_numpy_unique():
+    """ffx_host_unique_rows (a bitmap over the index's rows, marked and ranked by host threads) against
+    numpy.unique(rows, return_inverse=True): same distinct rows in the same order, same inverse; a row outside the
+    index is refused."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(0)
+    for n, n_index in ((1, 10), (1000, 50), (200_000, 150_000), (300_000, 40_000_000), (70_000, 64), (70_000, 65)):
+        rows = rng.integers(0, n_index, size=n).astype(np.int64)
+        want_u, want_inv = np.unique(rows, return_inverse=True)
+        for threads in (0, 1, 5):
+            u, inv = native.unique_rows(rows, n_index, threads)
+            assert inv.dtype == np.int32 and np.array_equal(u, want_u) and np.array_equal(inv, want_inv), (n, n_index, threads)
+    with pytest.raises(native.FFXError, match="outside the index"):
+        native.unique_rows(np.array([5, 10], dtype=np.int64), 10)
+    with pytest.raises(native.FFXError, match="outside the index"):
+        native.unique_rows(np.array([5, -1], dtype=np.int64), 10)
+    assert native.unique_rows(np.zeros(0, dtype=np.int64), 10)[0].shape == (0,)
