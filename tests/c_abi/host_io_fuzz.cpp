@@ -306,6 +306,21 @@ int main(int argc, char** argv) {
         }
     }
   }
+  // ---- distinct rows of a streamed batch
+  for (int round = 0; round < 30; ++round) {
+    const int64_t n = 1 + (int64_t)(rnd() % 4000), n_index = 1 + (int64_t)(rnd() % 3000);
+    std::vector<int64_t> rows((size_t)n), uniq((size_t)std::min(n, n_index));
+    for (auto& r : rows) r = (int64_t)(rnd() % (uint64_t)n_index);
+    std::vector<int32_t> inv((size_t)n);
+    int64_t count = 0;
+    if (ffx_host_unique_rows(rows.data(), n, n_index, 1 + (int)(rnd() % 4), uniq.data(), &count, inv.data()) != FFX_OK) return 1;
+    for (int64_t i = 1; i < count; ++i)
+      if (uniq[(size_t)i] <= uniq[(size_t)i - 1]) return 1;
+    for (int64_t i = 0; i < n; ++i)
+      if (inv[(size_t)i] < 0 || inv[(size_t)i] >= count || uniq[(size_t)inv[(size_t)i]] != rows[(size_t)i]) return 1;
+    rows[0] = n_index;  // outside the index: refused
+    if (ffx_host_unique_rows(rows.data(), n, n_index, 2, uniq.data(), &count, inv.data()) == FFX_OK) return 1;
+  }
   ffx_ids_destroy(ids);
   remove(in.c_str());
   remove(out.c_str());
