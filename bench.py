@@ -84,9 +84,24 @@ def parse_args():
                     help="rccl (default): RCCL over xGMI, one GPU per rank; host: the exchange staged through shared "
                          "memory, so N ranks can rehearse on ONE GPU (RCCL refuses ranks that share a device)")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"], help="older spelling of --transport (gloo = host)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1: exit non-zero if RCCL cannot be brought up on every rank instead of falling back to the shared-memory "
+                         "transport (a fallback line is marked `\"scaling\": \"invalid: host transport\"` and `\"value_is_rccl\": false`)")
+    ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
+                    help="single-GPU REHEARSAL of one rank of an N-rank row-sharded run: this process holds rank --as-rank's shard "
+                         "(rows/N by doc_partition), scores its local share (~P/N pairs), owns ~Q/N queries, and the exchange moves the "
+                         "same bytes through this GPU's memory (peers do not exist; their scores arrive as zeros).  Times one rank's "
+                         "step; the line is marked as a rehearsal and is not a scaling measurement")
+    ap.add_argument("--as-rank", type=int, default=0, metavar="R", help="which rank --as-rank-of N rehearses (default 0)")
     args = ap.parse_args()
     if args.transport is None:
         args.transport = "host" if args.dist_backend == "gloo" else "rccl"
+    if args.as_rank_of:
+        if args.as_rank_of < 1 or not 0 <= args.as_rank < args.as_rank_of:
+            ap.error("--as-rank-of N needs N >= 1 and 0 <= --as-rank < N")
+        if args.gpus != 1:
+            ap.error("--as-rank-of is a single-process rehearsal: leave --gpus at 1")
+        args.transport = "rehearsal"
     return args
 
 
@@ -150,7 +165,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(args, doc_off, n_docs, scale):
+def cpu_baseline(args, doc_off, n_docs, scale, q_first: int = 0):
     """Reference-equivalent CPU path (oracle/ffx_oracle.py numpy_port_score: the reference's
     own three NumPy ops, index/base.py:301-303) on the first `cpu_sample_queries` queries of
     the same workload.  The rows those queries touch are re-derived on the host with the same
@@ -160,7 +175,7 @@ def cpu_baseline(args, doc_off, n_docs, scale):
     import ffx_oracle as fo
 
     nq = args.cpu_sample_queries
-    ids, sparse = candidates(n_docs, nq, args.k, args.seed)
+    ids, sparse = candidates(n_docs, nq, args.k, args.seed, q_first=q_first)
     pair_off = np.arange(nq + 1, dtype=np.int64) * args.k
     # compact the touched documents into a small host index (same row values, renumbered)
     uniq, inv = np.unique(ids, return_inverse=True)
@@ -177,7 +192,7 @@ def cpu_baseline(args, doc_off, n_docs, scale):
         vecs = fo.synth_row_list(args.seed, scale, rows_global, args.dim)
     if args.store == "f16":  # the index rounds rows to float16 once; NumPy then widens them back
         vecs = vecs.astype(np.float16).astype(np.float32)
-    queries = synth.rows(args.seed + 3, scale, 0, nq, args.dim)
+    queries = synth.rows(args.seed + 3, scale, q_first, nq, args.dim)
     sub_rows = np.arange(rows_global.shape[0], dtype=np.int32)
     mode = MODE_NO[args.mode]
     # repeat whole passes over the sample until ~10 s of CPU work has been measured
@@ -250,6 +265,10 @@ def bench_sharded(args, rank: int, world: int):
     communicator (RCCL, or shared memory with --transport host)."""
     from fast_forward_amd.sharded import ShardedScorer, connect, doc_partition, query_partition
 
+    if args.as_rank_of:  # one process standing in for one rank: no peers, no rendezvous
+        native.require_device()
+        comm = connect("rehearsal", rank=args.as_rank, world=args.as_rank_of, device=0)
+        return _bench_sharded_body(args, comm.rank, comm.world, comm, comm.device, doc_partition, query_partition, ShardedScorer)
     visible = native.device_count()
     masked = any(os.environ.get(v) for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
     device = None
@@ -332,6 +351,13 @@ def _connect_with_fallback(args, rank: int, world: int, device, connect):
     if votes.min() > 0:
         side.close()
         return comm
+    if args.require_rccl:
+        # every rank leaves here (the vote was collective), none re-executes itself: the launcher sees a non-zero status
+        print(f"rank {rank}: --require-rccl and {int(votes.shape[0] - votes.sum())} of {world} ranks could not use RCCL ({why or 'this rank could'})",
+              file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)  # a communicator that never came up may hold a thread inside RCCL: do not wait for it
     reasons = [r.rstrip(b"\0").decode(errors="replace") for r in side.allgather_bytes(why.encode()[:160].ljust(160, b"\0"))]
     first = next((f"rank {r}: {t}" for r, t in enumerate(reasons) if t), "")
     print(f"rank {rank}: {int(votes.shape[0] - votes.sum())} of {world} ranks could not use RCCL; every rank falls back to the shared-memory transport",
@@ -394,6 +420,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
+    t_issued = time.perf_counter() - t0  # the host only queues work: it must stay ahead of the device
     scorer.sync()       # this rank's streams have drained ...
     comm.barrier()      # ... and so have everybody else's
     elapsed = float(comm.allreduce([time.perf_counter() - t0], native.OP_MAX)[0])
@@ -405,20 +432,28 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     per_rank = gather_stats(comm, scorer.stats())
     row_bytes = args.dim * np.dtype(store).itemsize + 4
 
-    # parity: owned queries' interpolated scores vs the oracle on a small sample (rank 0 only)
+    # parity: owned queries' interpolated scores vs the oracle on a small sample (the rank that prints the line)
+    rehearsal = bool(args.as_rank_of)
+    lead = rank == 0 or rehearsal
     parity = base = None
-    if rank == 0 and args.cpu_sample_queries > 0:
+    if lead and args.cpu_sample_queries > 0 and scorer.q_hi > scorer.q_lo:
         # the CPU baseline proper is a figure of the N = 1 line; here the oracle only checks a few owned queries
-        args.cpu_sample_queries = min(args.cpu_sample_queries, scorer.q_hi, 16 if world > 1 else args.cpu_sample_queries)
+        args.cpu_sample_queries = min(args.cpu_sample_queries, scorer.q_hi - scorer.q_lo, 16 if world > 1 else args.cpu_sample_queries)
         if world > 1:
             args.cpu_seconds = min(args.cpu_seconds, 0.5)
-        base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale)
+        base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale, q_first=scorer.q_lo)
         _, interp, _ = scorer.fetch()
         n_s = s_ids.shape[0]
-        ok = np.array_equal(interp[:n_s].view(np.uint32), s_interp.view(np.uint32)) if exact else bool(np.abs(interp[:n_s] - s_interp).max() <= 1e-4)
+        got, want = interp[:n_s], s_interp
+        if rehearsal:  # only the candidates this rank holds were scored: the peers' scores arrive as zeros
+            held = (s_ids >= doc_bounds[rank]) & (s_ids < doc_bounds[rank + 1])
+            got, want = got[held], want[held]
+        ok = np.array_equal(got.view(np.uint32), want.view(np.uint32)) if exact else bool(np.abs(got - want).max() <= 1e-4)
         parity = ("bit-exact" if exact else "within 1e-4") if ok else "MISMATCH"
+        if rehearsal and ok:
+            parity += f" on the {int(held.sum())} of {n_s} sampled pairs this rank holds"
     failed = parity == "MISMATCH"
-    if rank == 0:
+    if lead:
         slowest = max(per_rank, key=lambda t: t["ms_gather_dot"])
         achieved = slowest["n_rows"] * row_bytes / (slowest["ms_gather_dot"] * 1e-3) / 1e9
         dev = native.device_info(local_rank)
@@ -427,13 +462,19 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
         result = {
             "metric": metric_name(args),
             "value": args.queries / (ms_per_step * 1e-3), "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": compute_dtype(args), "data": "synthetic",
+            "n_gpus": 1 if rehearsal else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            # a scaling point is only what ran over RCCL on N GPUs: anything else says so here, where a reader of the
+            # line (or a driver computing efficiencies from `value`) looks first
+            "scaling": ("invalid: single-GPU rehearsal of one rank" if rehearsal else
+                        "strong" if (world == 1 or args.transport == "rccl") else "invalid: host transport"),
+            "value_is_rccl": bool(args.transport == "rccl" and not rehearsal),
+            "vs_baseline": None, "dtype": compute_dtype(args), "data": "synthetic",
             "config": {
                 "workload": f"MS MARCO passage-scale synthetic: {args.rows}x{args.dim} {'fp16' if args.store == 'f16' else 'fp32'} index row-sharded by document over "
-                            f"{world} GPUs ({n_local} rows on rank 0), {args.queries} queries, k={args.k}, Mode.{args.mode}, "
+                            f"{world} {'ranks, of which ONE (rank ' + str(rank) + ') is rehearsed on one GPU' if rehearsal else 'GPUs'} ({n_local} rows on rank {rank}), {args.queries} queries, k={args.k}, Mode.{args.mode}, "
                             f"alpha={args.alpha}, sum={args.sum}; per step: local gather_dot, all-to-all of dense scores to "
-                            f"the owning rank ({'ncclSend/ncclRecv full mesh' if args.transport == 'rccl' else 'shared-memory transport'}), "
+                            f"the owning rank ({'ncclSend/ncclRecv full mesh' if args.transport == 'rccl' else 'one copy kernel standing in for the peers' if rehearsal else 'shared-memory transport'}), "
                             f"owner-side interpolation{' + per-query ordering' if args.sort else ''}",
                 "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
                 "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": int(pair_off[-1]), "store": args.store,
@@ -450,6 +491,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                              "max_over_mean": max(rows_per_rank) / max(1.0, float(np.mean(rows_per_rank)))},
             "exchange_bytes_per_rank": {"sent": [int(t["send_bytes"]) for t in per_rank], "received": [int(t["recv_bytes"]) for t in per_rank]},
             "local_step_ms_per_rank": [t["ms_total"] for t in per_rank],
+            "host_issue_ms_per_step": t_issued * 1e3 / args.steps,
             "exchange_ms_per_rank": [t["ms_exchange"] for t in per_rank], "merge_ms_per_rank": [t["ms_merge"] for t in per_rank],
             "per_rank_note": "HIP events of one step run alone after the timed loop (nothing to overlap with): local = expand + gather_dot on the compute "
                              "stream; exchange and merge (+ per-query order) on the communicator's stream.  In the timed loop batch i's exchange + merge "
@@ -462,6 +504,16 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
             "device": dev["name"],
             "index_capacity_rows_per_gpu": cap, "index_capacity_rows_total": world * cap,
         }
+        if rehearsal:
+            me = per_rank[rank]
+            result["rehearsal"] = {
+                "as_rank": rank, "of": world,
+                "step_ms": ms_per_step, "ideal_ms": me["ms_gather_dot"], "step_over_ideal": ms_per_step / max(me["ms_gather_dot"], 1e-9),
+                "local_pairs": int(me["n_pairs"]), "owned_pairs": int(me["own_pairs"]), "owned_queries": int(me["own_queries"]),
+                "note": "step_ms: K back-to-back steps of this one rank (batch i's exchange + merge overlap batch i+1's scoring); ideal_ms: this "
+                        "rank's gather_dot alone (HIP events of a step run by itself).  `value` = queries / step_ms is what N such ranks would "
+                        "deliver if the fabric added nothing: a prediction, not a measurement of N GPUs",
+            }
         if parity is not None:
             if world == 1:
                 result["cpu_baseline"] = base
@@ -853,7 +905,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.as_rank_of:
         bench_sharded(args, rank, world)
         if " unavailable" in str(args.transport):
             # a communicator that never came up may still have a thread inside RCCL; do not wait for it at exit

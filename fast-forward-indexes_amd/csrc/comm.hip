@@ -167,6 +167,13 @@ struct ffx_comm {
   ncclComm_t nccl = nullptr;
   void* ctl_dev = nullptr;   // kSmall * (world + 1) bytes of device scratch for the control collectives
   void* ctl_host = nullptr;  // page-locked mirror
+  float* stage_dev = nullptr;  // ffx_comm_exchange_host over RCCL: device staging, grown as needed and kept
+  size_t stage_cap = 0;        // (floats)
+  // rehearsal: what stands in for the peers' memory -- a zeroed source the "received" slices come out of and a sink
+  // the "sent" slices go into (floats each, grown as needed)
+  float* reh_src = nullptr;
+  float* reh_sink = nullptr;
+  size_t reh_cap = 0;
   // shared memory
   std::string name;
   ShmHeader* hdr = nullptr;
@@ -287,6 +294,10 @@ int allgather_small(ffx_comm* c, const void* mine, size_t bytes, void* all) {
     memcpy(all, mine, bytes);
     return FFX_OK;
   }
+  if (c->transport == FFX_COMM_REHEARSAL) {  // the peers do not exist: every slot holds this rank's contribution
+    for (int r = 0; r < c->world; ++r) memcpy(static_cast<char*>(all) + (size_t)r * bytes, mine, bytes);
+    return FFX_OK;
+  }
   return c->transport == FFX_COMM_RCCL ? rccl_allgather_small(c, mine, bytes, all) : shm_allgather_small(c, mine, bytes, all);
 }
 
@@ -297,6 +308,9 @@ void destroy_comm(ffx_comm* c) {
   if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
   if (c->ctl_dev) (void)hipFree(c->ctl_dev);
   if (c->ctl_host) (void)hipHostFree(c->ctl_host);
+  if (c->stage_dev) (void)hipFree(c->stage_dev);
+  if (c->reh_src) (void)hipFree(c->reh_src);
+  if (c->reh_sink) (void)hipFree(c->reh_sink);
   if (c->hdr) {
     if (c->seg[c->rank].p) shm_unlink(seg_name(c, c->rank, c->seg[c->rank].gen).c_str());
     for (int r = 0; r < c->world; ++r) c->seg[r].unmap();
@@ -336,6 +350,7 @@ int ffx_comm_unique_id(int transport, void* id) {
     for (unsigned char b : rnd) n += snprintf(out + n, FFX_COMM_ID_BYTES - n, "%02x", b);
     return FFX_OK;
   }
+  if (transport == FFX_COMM_REHEARSAL) return FFX_OK;  // nobody to hand it to
   return ffx_fail(FFX_BAD_ARG, "unknown transport %d", transport);
 }
 
@@ -343,8 +358,8 @@ int ffx_comm_init(int transport, int device, int rank, int world, const void* id
   if (!out || !id) return ffx_fail(FFX_BAD_ARG, "NULL argument");
   *out = nullptr;
   if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return ffx_fail(FFX_BAD_ARG, "bad rank %d / world %d (at most %d ranks)", rank, world, kMaxWorld);
-  if (transport != FFX_COMM_RCCL && transport != FFX_COMM_HOST) return ffx_fail(FFX_BAD_ARG, "unknown transport %d", transport);
-  if (transport == FFX_COMM_RCCL && device < 0) return ffx_fail(FFX_BAD_ARG, "the RCCL transport needs a device");
+  if (transport != FFX_COMM_RCCL && transport != FFX_COMM_HOST && transport != FFX_COMM_REHEARSAL) return ffx_fail(FFX_BAD_ARG, "unknown transport %d", transport);
+  if (transport != FFX_COMM_HOST && device < 0) return ffx_fail(FFX_BAD_ARG, "the %s transport needs a device", transport == FFX_COMM_RCCL ? "RCCL" : "rehearsal");
   ffx_comm* c = new (std::nothrow) ffx_comm();
   if (!c) return ffx_fail(FFX_OOM, "host allocation failed");
   c->transport = transport;
@@ -379,7 +394,7 @@ int ffx_comm_init(int transport, int device, int rank, int world, const void* id
     const size_t ctl = kSmall * (size_t)(world + 1);
     if (hipMalloc(&c->ctl_dev, ctl) != hipSuccess || hipHostMalloc(&c->ctl_host, ctl, hipHostMallocDefault) != hipSuccess)
       return bail(ffx_fail(FFX_OOM, "control buffers"));
-  } else {
+  } else if (transport == FFX_COMM_HOST) {
     const char* nm = static_cast<const char*>(id);
     if (nm[0] != '/' || memchr(nm, 0, FFX_COMM_ID_BYTES) == nullptr) return bail(ffx_fail(FFX_BAD_ARG, "not an id of ffx_comm_unique_id(FFX_COMM_HOST)"));
     c->name = nm;
@@ -462,7 +477,7 @@ int ffx_comm_allgather(ffx_comm* c, const void* mine, int64_t bytes, void* all) 
 
 int ffx_comm_barrier(ffx_comm* c) {
   if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
-  if (c->world == 1) return FFX_OK;
+  if (c->world == 1 || c->transport == FFX_COMM_REHEARSAL) return FFX_OK;
   if (c->transport == FFX_COMM_HOST) return shm_barrier(c);
   char one = 1;
   std::vector<char> all((size_t)c->world);
@@ -501,16 +516,13 @@ static int check_counts(const ffx_comm* c, const int64_t* send_counts, const int
 
 // host transport: publish the send buffer, then pull this rank's slice out of every peer's segment.
 // `device`: buffers are device pointers (copies ordered on `st`); else plain host memory.
-static int shm_exchange(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts,
-                        bool device, hipStream_t st) {
+// Once this rank's counts are published, EVERY failure marks the communicator failed before returning, so that
+// the peers waiting at a barrier fail promptly instead of spinning out their timeout.
+static int shm_exchange_body(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts,
+                             bool device, hipStream_t st) {
   int64_t n_send = 0, n_recv = 0;
-  // an error on one rank must not leave the others waiting at the barrier: mark the communicator failed
-  int pre = check_counts(c, send_counts, recv_counts, &n_send, &n_recv);
-  if (pre == FFX_OK) pre = shm_own_segment(c, (size_t)n_send * sizeof(float));
-  if (pre != FFX_OK) {
-    c->hdr->failed.store(1);
-    return pre;
-  }
+  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
+  C_TRY(shm_own_segment(c, (size_t)n_send * sizeof(float)));
   ShmSlot& mine = c->hdr->slot[c->rank];
   for (int r = 0; r < c->world; ++r) mine.counts[r] = send_counts[r];
   if (n_send > 0) {
@@ -523,46 +535,123 @@ static int shm_exchange(ffx_comm* c, const float* send, const int64_t* send_coun
   }
   C_TRY(shm_barrier(c));  // every send segment is complete
   int64_t at = 0;
-  int rc = FFX_OK;
-  for (int r = 0; r < c->world && rc == FFX_OK; ++r) {
+  for (int r = 0; r < c->world; ++r) {
     const ShmSlot& peer = c->hdr->slot[r];
-    if (peer.counts[c->rank] != recv_counts[r]) {
-      rc = ffx_fail(FFX_BAD_ARG, "rank %d sends %lld scores to rank %d, which expects %lld", r, (long long)peer.counts[c->rank], c->rank, (long long)recv_counts[r]);
-      break;
-    }
+    if (peer.counts[c->rank] != recv_counts[r])
+      return ffx_fail(FFX_BAD_ARG, "rank %d sends %lld scores to rank %d, which expects %lld", r, (long long)peer.counts[c->rank], c->rank, (long long)recv_counts[r]);
     if (recv_counts[r] > 0) {
-      rc = shm_peer_segment(c, r);
-      if (rc != FFX_OK) break;
+      C_TRY(shm_peer_segment(c, r));
       int64_t off = 0;
-      for (int i = 0; i < c->rank; ++i) off += peer.counts[i];
+      for (int i = 0; i < c->rank; ++i) {
+        if (peer.counts[i] < 0) return ffx_fail(FFX_RCCL_ERROR, "host transport: rank %d published a negative count", r);
+        off += peer.counts[i];
+      }
+      // what the peer claims to send must lie inside the segment this rank mapped (counts come from shared memory)
+      if (r != c->rank && ((uint64_t)off + (uint64_t)recv_counts[r]) * sizeof(float) > c->seg[r].bytes)
+        return ffx_fail(FFX_RCCL_ERROR, "host transport: rank %d's slice for rank %d lies outside its %zu-byte segment", r, c->rank, c->seg[r].bytes);
       const float* src = static_cast<const float*>(c->seg[r].p) + off;
       const size_t bytes = (size_t)recv_counts[r] * sizeof(float);
-      if (device) {
-        if (hipMemcpyAsync(recv + at, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "copy of peer %d's scores to the device failed", r);
-      } else {
+      if (device)
+        C_HIP(hipMemcpyAsync(recv + at, src, bytes, hipMemcpyHostToDevice, st));
+      else
         memcpy(recv + at, src, bytes);
-      }
     }
     at += recv_counts[r];
   }
-  if (rc == FFX_OK && device && hipStreamSynchronize(st) != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream synchronisation failed");
-  if (rc != FFX_OK) {
-    c->hdr->failed.store(1);
-    return rc;
-  }
+  if (device) C_HIP(hipStreamSynchronize(st));
   return shm_barrier(c);  // every rank has read: the segments may be overwritten
+}
+
+static int shm_exchange(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts,
+                        bool device, hipStream_t st) {
+  const int rc = shm_exchange_body(c, send, send_counts, recv, recv_counts, device, st);
+  if (rc != FFX_OK) c->hdr->failed.store(1);
+  return rc;
+}
+
+// rehearsal: the bytes of one exchange through this GPU's memory in ONE kernel (RCCL groups its sends and receives
+// into one kernel on a handful of workgroups too): piece i copies n[i] floats from src[i] to dst[i]
+struct RehearsalPieces {
+  const float* src[2 * kMaxWorld];
+  float* dst[2 * kMaxWorld];
+  long n[2 * kMaxWorld];
+  int count;
+};
+
+__global__ void __launch_bounds__(256) rehearsal_exchange_kernel(RehearsalPieces pc) {
+  for (int i = 0; i < pc.count; ++i) {
+    const float* __restrict__ s = pc.src[i];
+    float* __restrict__ d = pc.dst[i];
+    const long n = pc.n[i];
+    // slices start at arbitrary float offsets: scalar head up to 16-byte alignment of the destination is not worth it
+    // for a stand-in; 4-byte accesses, fully coalesced
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) d[e] = s[e];
+  }
+}
+
+static int rehearsal_exchange(ffx_comm* c, const float* send_dev, const int64_t* send_counts, float* recv_dev, const int64_t* recv_counts,
+                              hipStream_t st) {
+  int64_t n_send = 0, n_recv = 0;
+  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
+  const size_t need = (size_t)std::max<int64_t>(std::max(n_send, n_recv), 1);
+  if (need > c->reh_cap) {
+    C_HIP(hipStreamSynchronize(st));
+    if (c->reh_src) (void)hipFree(c->reh_src);
+    if (c->reh_sink) (void)hipFree(c->reh_sink);
+    c->reh_src = c->reh_sink = nullptr;
+    c->reh_cap = 0;
+    const size_t want = need + need / 8;
+    C_HIP(hipMalloc(reinterpret_cast<void**>(&c->reh_src), want * sizeof(float)));
+    C_HIP(hipMalloc(reinterpret_cast<void**>(&c->reh_sink), want * sizeof(float)));
+    C_HIP(hipMemset(c->reh_src, 0, want * sizeof(float)));
+    c->reh_cap = want;
+  }
+  RehearsalPieces pc;
+  pc.count = 0;
+  int64_t s_at = 0, r_at = 0;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) {  // exactly what the RCCL path does with the slice a rank keeps
+      if (send_counts[p] > 0)
+        C_HIP(hipMemcpyAsync(recv_dev + r_at, send_dev + s_at, (size_t)send_counts[p] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+      if (send_counts[p] > 0) {  // what peer p would read out of this GPU
+        pc.src[pc.count] = send_dev + s_at;
+        pc.dst[pc.count] = c->reh_sink + s_at;
+        pc.n[pc.count++] = (long)send_counts[p];
+      }
+      if (recv_counts[p] > 0) {  // what peer p would write into this GPU (zeros: it does not exist)
+        pc.src[pc.count] = c->reh_src + r_at;
+        pc.dst[pc.count] = recv_dev + r_at;
+        pc.n[pc.count++] = (long)recv_counts[p];
+      }
+    }
+    s_at += send_counts[p];
+    r_at += recv_counts[p];
+  }
+  if (pc.count > 0) {
+    rehearsal_exchange_kernel<<<16, 256, 0, st>>>(pc);
+    C_HIP(hipGetLastError());
+  }
+  return FFX_OK;
 }
 
 int ffx_comm_exchange_host(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts) {
   if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
   if (c->transport == FFX_COMM_HOST) return shm_exchange(c, send, send_counts, recv, recv_counts, false, nullptr);
-  // RCCL: the same all-to-all-v, staged through device scratch (a streamed index produces its local
-  // scores on the host: they are PCIe-bound already)
+  // RCCL: the same all-to-all-v, staged through device scratch kept with the communicator (a streamed index
+  // produces its local scores on the host: they are PCIe-bound already)
   int64_t n_send = 0, n_recv = 0;
   C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
   C_HIP(hipSetDevice(c->device));
-  float* dev = nullptr;
-  C_HIP(hipMalloc(reinterpret_cast<void**>(&dev), (size_t)std::max<int64_t>(n_send + n_recv, 1) * sizeof(float)));
+  const size_t need = (size_t)std::max<int64_t>(n_send + n_recv, 1);
+  if (need > c->stage_cap) {
+    if (c->stage_dev) (void)hipFree(c->stage_dev);
+    c->stage_dev = nullptr;
+    c->stage_cap = 0;
+    C_HIP(hipMalloc(reinterpret_cast<void**>(&c->stage_dev), (need + need / 4) * sizeof(float)));
+    c->stage_cap = need + need / 4;
+  }
+  float* dev = c->stage_dev;
   int rc = FFX_OK;
   if (n_send > 0 && hipMemcpyAsync(dev, send, (size_t)n_send * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess)
     rc = ffx_fail(FFX_HIP_ERROR, "upload of the local scores failed");
@@ -570,7 +659,6 @@ int ffx_comm_exchange_host(ffx_comm* c, const float* send, const int64_t* send_c
   if (rc == FFX_OK && n_recv > 0 && hipMemcpyAsync(recv, dev + n_send, (size_t)n_recv * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
     rc = ffx_fail(FFX_HIP_ERROR, "download of the received scores failed");
   if (hipStreamSynchronize(c->stream) != hipSuccess && rc == FFX_OK) rc = ffx_fail(FFX_HIP_ERROR, "stream synchronisation failed");
-  (void)hipFree(dev);
   return rc;
 }
 
@@ -581,6 +669,7 @@ int ffx_comm_exchange(ffx_comm* c, const float* send_dev, const int64_t* send_co
   C_HIP(hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (c->transport == FFX_COMM_HOST) return shm_exchange(c, send_dev, send_counts, recv_dev, recv_counts, true, st);
+  if (c->transport == FFX_COMM_REHEARSAL) return rehearsal_exchange(c, send_dev, send_counts, recv_dev, recv_counts, st);
   int64_t n_send = 0, n_recv = 0;
   C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
   if ((n_send > 0 && !send_dev) || (n_recv > 0 && !recv_dev)) return ffx_fail(FFX_BAD_ARG, "NULL buffer");
@@ -755,11 +844,17 @@ struct ffx_sharded {
   ffx_merge* merge = nullptr;
   hipStream_t compute = nullptr;
   hipEvent_t scored[2] = {nullptr, nullptr}, sent[2] = {nullptr, nullptr}, merged = nullptr;
-  hipEvent_t x_begin = nullptr, x_end = nullptr;  // timing of the last step's exchange (merge: x_end .. merged)
+  hipEvent_t x_begin = nullptr, x_end = nullptr, m_begin = nullptr;  // timing of the last step's exchange and merge
   bool sent_valid[2] = {false, false};
   float* send_dev[2] = {nullptr, nullptr};
-  void* recv = nullptr;
+  // scores arriving for the owned queries: one buffer per plan, because the exchange of batch i runs (on the
+  // communicator's stream) while batch i-1 is still being merged out of the other one (on the compute stream)
+  void* recv[2] = {nullptr, nullptr};
   size_t recv_cap = 0;
+  // the batch whose exchange has been issued but whose owner-side merge has not (-1: none), with its arguments
+  int pending = -1;
+  double pending_alpha = 0.0;
+  uint32_t pending_flags = 0;
   std::vector<int64_t> send_counts, recv_counts;
   // device-side routing (document-range shards): the batch's ids are uploaded once and everything else is derived
   // in HBM; buffers grow as needed and are kept
@@ -807,10 +902,12 @@ int sharded_finish_set(ffx_sharded* s, bool have_sparse) {
   const size_t need = (size_t)std::max<int64_t>(s->own[3], 1) * sizeof(float);
   if (need > s->recv_cap) {
     C_HIP(hipSetDevice(s->device));
-    if (s->recv) C_HIP(hipFree(s->recv));
-    s->recv = nullptr;
+    for (void*& r : s->recv) {
+      if (r) C_HIP(hipFree(r));
+      r = nullptr;
+    }
     s->recv_cap = 0;
-    C_HIP(hipMalloc(&s->recv, need + need / 8));
+    for (void*& r : s->recv) C_HIP(hipMalloc(&r, need + need / 8));
     s->recv_cap = need + need / 8;
   }
   s->have_pairs = true;
@@ -1120,6 +1217,7 @@ int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_boun
   if (e == hipSuccess) e = hipEventCreate(&s->merged);
   if (e == hipSuccess) e = hipEventCreate(&s->x_begin);
   if (e == hipSuccess) e = hipEventCreate(&s->x_end);
+  if (e == hipSuccess) e = hipEventCreate(&s->m_begin);
   if (e != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
   for (int i = 0; i < 2 && rc == FFX_OK; ++i) {
     rc = ffx_plan_create(shard, &s->plans[i]);
@@ -1152,7 +1250,9 @@ int ffx_sharded_destroy(ffx_sharded* s) {
   if (s->merged) (void)hipEventDestroy(s->merged);
   if (s->x_begin) (void)hipEventDestroy(s->x_begin);
   if (s->x_end) (void)hipEventDestroy(s->x_end);
-  if (s->recv) (void)hipFree(s->recv);
+  if (s->m_begin) (void)hipEventDestroy(s->m_begin);
+  for (void* r : s->recv)
+    if (r) (void)hipFree(r);
   if (s->compute) (void)hipStreamDestroy(s->compute);
   delete s;
   return FFX_OK;
@@ -1177,6 +1277,19 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
   return sharded_set(s, pair_off, n_queries, local_ids, holder, sparse, mode, bad_pair);
 }
 
+// The owner-side half of batch `s->pending` (scatter to first-stage order, interpolation, per-query order) on the
+// COMPUTE stream, behind whatever has been queued there, once that batch's scores have arrived.
+static int sharded_merge_pending(ffx_sharded* s) {
+  if (s->pending < 0) return FFX_OK;
+  const int i = s->pending;
+  s->pending = -1;
+  C_HIP(hipStreamWaitEvent(s->compute, s->sent[i], 0));
+  C_HIP(hipEventRecord(s->m_begin, s->compute));
+  C_TRY(ffx_merge_run(s->merge, static_cast<const float*>(s->recv[i]), s->pending_alpha, s->pending_flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), s->compute));
+  C_HIP(hipEventRecord(s->merged, s->compute));
+  return FFX_OK;
+}
+
 int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags) {
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
   if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_set_pairs has not succeeded on this handle");
@@ -1185,27 +1298,37 @@ int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags) {
   ++s->runs;
   s->last = i;
   hipStream_t cs = s->comm->stream;
-  // Two plans alternate as send buffers: batch i is scored on the compute stream while the scores of
-  // batch i-1 are exchanged and merged on the communicator's stream.
+  // Everything that needs the CUs runs in order on the compute stream; only the exchange -- link-bound, a handful of
+  // workgroups -- runs beside it on the communicator's stream:
+  //   compute:  expand, gather_dot (batch i)   | merge + order (batch i-1) | expand, gather_dot (batch i+1) | ...
+  //   comm:                                      exchange (batch i)                                          ...
+  // so the exchange of batch i is hidden behind the merge of batch i-1 and the scoring of batch i+1, and the merge
+  // of batch i-1 never shares the CUs with a gather_dot.  (Round 2 ran merge + order on the communicator's stream
+  // NEXT TO the following gather_dot: beside a kernel that fills every CU the LDS-heavy ordering got no slots and
+  // stretched from 0.07 ms to the gather's whole 2.0 ms at an eighth of the batch, and the next exchange queued
+  // behind it: profiles/r03/rehearsal_trace_n8_before.csv.)  Two plans and two receive buffers alternate.
   if (s->sent_valid[i]) C_HIP(hipStreamWaitEvent(s->compute, s->sent[i], 0));  // the exchange of two runs ago has read this plan's scores
   C_TRY(ffx_plan_run(s->plans[i], 0.0, flags & FFX_FLAG_EXACT_SUM));
   C_HIP(hipEventRecord(s->scored[i], s->compute));
   C_HIP(hipStreamWaitEvent(cs, s->scored[i], 0));
   C_HIP(hipEventRecord(s->x_begin, cs));
-  C_TRY(ffx_comm_exchange(s->comm, s->send_dev[i], s->send_counts.data(), static_cast<float*>(s->recv), s->recv_counts.data(), cs));
+  C_TRY(ffx_comm_exchange(s->comm, s->send_dev[i], s->send_counts.data(), static_cast<float*>(s->recv[i]), s->recv_counts.data(), cs));
   C_HIP(hipEventRecord(s->x_end, cs));
   C_HIP(hipEventRecord(s->sent[i], cs));
   s->sent_valid[i] = true;
-  C_TRY(ffx_merge_run(s->merge, static_cast<const float*>(s->recv), alpha, flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), cs));
-  C_HIP(hipEventRecord(s->merged, cs));
+  C_TRY(sharded_merge_pending(s));  // batch i-1, behind batch i's gather_dot
+  s->pending = i;
+  s->pending_alpha = alpha;
+  s->pending_flags = flags;
   return FFX_OK;
 }
 
 int ffx_sharded_sync(ffx_sharded* s) {
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
   C_HIP(hipSetDevice(s->device));
-  C_HIP(hipStreamSynchronize(s->compute));
+  C_TRY(sharded_merge_pending(s));  // the last batch has nothing behind it to hide its merge
   C_HIP(hipStreamSynchronize(s->comm->stream));
+  C_HIP(hipStreamSynchronize(s->compute));
   return FFX_OK;
 }
 
@@ -1241,7 +1364,7 @@ int ffx_sharded_stats(ffx_sharded* s, ffx_shard_stats* out) {
   }
   out->transport = s->comm->transport;
   C_HIP(hipEventElapsedTime(&out->ms_exchange, s->x_begin, s->x_end));
-  C_HIP(hipEventElapsedTime(&out->ms_merge, s->x_end, s->merged));
+  C_HIP(hipEventElapsedTime(&out->ms_merge, s->m_begin, s->merged));
   return FFX_OK;
 }
 

@@ -41,7 +41,7 @@ SYMBOLS = (
     "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs", "ffx_sharded_set_pairs_held",
     "ffx_sharded_run", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
 )
-COMM_RCCL, COMM_HOST, COMM_ID_BYTES = 0, 1, 128
+COMM_RCCL, COMM_HOST, COMM_REHEARSAL, COMM_ID_BYTES = 0, 1, 2, 128
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 
 

@@ -116,7 +116,8 @@ def connect(transport: str | int = "rccl", rank: int | None = None, world: int |
     LOCAL_RANK (what ``python -m torch.distributed.run`` and ``bench.py --gpus N`` export).
 
     ``transport``: "rccl" (one GPU per rank) or "host" (shared memory: ranks may share a GPU;
-    ``device=-1`` for none at all)."""
+    ``device=-1`` for none at all); "rehearsal": this ONE process stands in for rank ``rank`` of
+    ``world`` ranks that do not exist (timing of one rank's step on one GPU; not for results)."""
     from fast_forward_amd import native
 
     # one node by construction (one process per GPU of the same host): RCCL's bootstrap sockets can use
@@ -125,7 +126,9 @@ def connect(transport: str | int = "rccl", rank: int | None = None, world: int |
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the driver supports dmabuf IPC only
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
-    code = {"rccl": native.COMM_RCCL, "nccl": native.COMM_RCCL, "host": native.COMM_HOST}.get(transport, transport)
+    code = {"rccl": native.COMM_RCCL, "nccl": native.COMM_RCCL, "host": native.COMM_HOST, "rehearsal": native.COMM_REHEARSAL}.get(transport, transport)
+    if code == native.COMM_REHEARSAL:  # no peers, nothing to rendezvous with
+        return native.Comm(code, 0 if device is None else device, rank, world, native.Comm.unique_id(code))
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", str(rank)))
         if code == native.COMM_HOST:

@@ -226,6 +226,12 @@ int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems);
  * rank calls ffx_comm_init (collective). */
 #define FFX_COMM_RCCL 0 /* ncclSend/ncclRecv full mesh over xGMI on a HIP stream; one GPU per rank        */
 #define FFX_COMM_HOST 1 /* staged through POSIX shared memory: ranks may share a GPU, or have none (-1) */
+/* ONE process standing in for rank `rank` of `world` ranks that do not exist: a timing rehearsal of one rank's step
+ * on one GPU (bench.py --as-rank-of N).  Control collectives return this rank's own contribution in every slot; the
+ * exchange keeps the slice the rank sends itself and moves, through this GPU's memory, the bytes the peers' slices
+ * would move (one kernel: sent slices are copied into a sink, received slices arrive as zeros out of a scratch
+ * source).  Scores of candidates other ranks would hold are therefore 0 -- never use this transport for results. */
+#define FFX_COMM_REHEARSAL 2
 #define FFX_COMM_ID_BYTES 128
 #define FFX_OP_SUM 0
 #define FFX_OP_MAX 1

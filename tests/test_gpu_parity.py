@@ -554,6 +554,8 @@ def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding, spelling)
         assert result["transport"] == "host" and len(result["exchange_bytes_per_rank"]["sent"]) == world
         assert sum(result["owned_pairs_per_rank"]) == 90 * 700
         assert sum(result["exchange_bytes_per_rank"]["sent"]) == sum(result["exchange_bytes_per_rank"]["received"])
+        # ranks that share a GPU over shared memory are a rehearsal: the line must not read as a scaling point
+        assert result["scaling"] == "invalid: host transport" and result["value_is_rccl"] is False
 
 
 def test_sharded_bench_falls_back_together_when_rccl_cannot_come_up():
@@ -579,6 +581,35 @@ def test_sharded_bench_falls_back_together_when_rccl_cannot_come_up():
     assert result["transport"].startswith("host (rccl unavailable: rank "), result["transport"]
     assert result["rccl_ranks"] == 0
     assert "fall" in out.stderr and "shared-memory transport" in out.stderr
+    # ... and the line cannot be mistaken for a measurement of the xGMI path
+    assert result["scaling"] == "invalid: host transport" and result["value_is_rccl"] is False
+    # --require-rccl: no fallback, every rank leaves with a non-zero status and no JSON line is printed
+    out = subprocess.run(cmd + ["--require-rccl"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode != 0
+    assert not any(ln.startswith("{") for ln in out.stdout.splitlines())
+    assert "--require-rccl" in out.stderr
+
+
+def test_rehearsal_of_one_rank_of_eight_on_one_gpu():
+    """`bench.py --as-rank-of 8 --as-rank 5`: one process stands in for rank 5 of 8 (its eighth of the rows, the candidates
+    it holds, the block of queries it owns; the exchange moves the same bytes through this GPU's memory).  The pairs the
+    rank holds are checked against the oracle inside bench.py; the line is marked as a rehearsal."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, str(root / "bench.py"), "--as-rank-of", "8", "--as-rank", "5", "--rows", "400000", "--queries", "160", "--k", "900",
+           "--steps", "6", "--warmup", "2", "--cpu-sample-queries", "6", "--cpu-seconds", "0.2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    result = json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{")))
+    assert result["n_gpus"] == 1 and result["scaling"].startswith("invalid: single-GPU rehearsal") and result["value_is_rccl"] is False
+    reh = result["rehearsal"]
+    assert (reh["as_rank"], reh["of"]) == (5, 8) and reh["owned_queries"] == 20 and reh["owned_pairs"] == 20 * 900
+    assert abs(reh["local_pairs"] - 160 * 900 / 8) < 0.1 * 160 * 900 / 8
+    assert result["parity_on_cpu_sample"].startswith("bit-exact on the ")
 
 
 def test_device_routing_equals_host_routing(monkeypatch):
