@@ -246,12 +246,16 @@ __device__ __forceinline__ float image_float(unsigned k) {
 // The continue-criterion of base.py:350-358 for every query at once, one block per query: the
 // cutoff-th best interpolated score so far (the worst one if fewer were scored) must be below
 //   alpha * (sparse score of the last scored candidate) + (1 - alpha) * (best dense score so far)
-// in float32 as NumPy >= 2 evaluates it (python_float * np.float32 stays float32).  The k-th
-// largest comes from a 4-pass radix select on the float images: exact, independent of cutoff.
+// The reference's expression multiplies a Python float by a np.float32 SCALAR, so what it computes depends on
+// NumPy's scalar promotion (pinned by tests/golden/early_stopping_np1.npz / _np2.npz, both produced by the reference):
+//   bound_f64 (default)  NumPy < 2, the reference's pinned range: both products and the sum in float64 -- the
+//                        cutoff-th score (float32) is compared with a double
+//   !bound_f64           NumPy >= 2 (NEP 50): python_float * np.float32 stays float32, everything in float32
+// The k-th largest comes from a 4-pass radix select on the float images: exact, independent of cutoff.
 __global__ void __launch_bounds__(256)
 es_criterion_kernel(const float* __restrict__ interp, const float* __restrict__ ff, const float* __restrict__ sparse,
-                    const int64_t* __restrict__ pair_off, int scored_depth, int cutoff, float a, float b,
-                    int32_t* __restrict__ active) {
+                    const int64_t* __restrict__ pair_off, int scored_depth, int cutoff, float a, float b, double a64, double b64,
+                    int bound_f64, int32_t* __restrict__ active) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_k;
   __shared__ float s_max[4];
@@ -308,8 +312,14 @@ es_criterion_kernel(const float* __restrict__ interp, const float* __restrict__ 
     best = s_max[0];
     for (int w = 1; w < 4; ++w) best = s_max[w] > best ? s_max[w] : best;
     const float kth = image_float(s_prefix);
-    const float bound = __fadd_rn(__fmul_rn(a, sparse[lo + n - 1]), __fmul_rn(b, best));
-    active[q] = kth < bound ? 1 : 0;
+    const float last = sparse[lo + n - 1];
+    if (bound_f64) {
+      const double bound = __dadd_rn(__dmul_rn(a64, (double)last), __dmul_rn(b64, (double)best));
+      active[q] = (double)kth < bound ? 1 : 0;
+    } else {
+      const float bound = __fadd_rn(__fmul_rn(a, last), __fmul_rn(b, best));
+      active[q] = kth < bound ? 1 : 0;
+    }
   }
   (void)any_nan;
 }

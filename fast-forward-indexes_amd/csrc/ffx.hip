@@ -1549,10 +1549,11 @@ int ffx_plan_early_stopping(ffx_plan* pl, int32_t cutoff, double alpha, const in
   int64_t scored = 0, rows_total = 0;
   for (int32_t b : ds) {
     if (b < cutoff || Q == 0 || P == 0) continue;
-    if (b <= a) continue;
+    if (b <= a) break;  // a repeated depth: the reference asks for ranks [a, a), gets no rows and leaves the loop (base.py:362-369)
     if (a > 0) {
       ffx::es_criterion_kernel<<<(unsigned)Q, 256, 0, st>>>(pl->interp.as<float>(), pl->ff.as<float>(), pl->sparse.as<float>(),
-                                                           pl->pair_off.as<int64_t>(), a, cutoff, fa, fb, pl->es_active.as<int32_t>());
+                                                           pl->pair_off.as<int64_t>(), a, cutoff, fa, fb, alpha, 1.0 - alpha,
+                                                           (flags & FFX_FLAG_ES_BOUND_F32) ? 0 : 1, pl->es_active.as<int32_t>());
       FFX_HIP(hipGetLastError());
     }
     ffx::es_count_kernel<<<blocks_for(Q + 1, 256), 256, 0, st>>>(pl->pair_off.as<int64_t>(), (int)Q, pl->es_active.as<int32_t>(), a, b,

@@ -67,6 +67,18 @@ class Index(abc.ABC):
     _query_encoder: Encoder | None = None
     _quantizer = None
 
+    #: How early stopping evaluates ``alpha * s_last + (1 - alpha) * max_dense`` (base.py:353-355: a Python float times a
+    #: ``np.float32`` SCALAR, so the reference's own result depends on NumPy's scalar promotion).  ``"numpy1"`` (default):
+    #: in float64, as under the reference's pinned ``numpy>=1.24,<2`` (pyproject.toml:16); ``"numpy2"``: in float32, as
+    #: under NumPy >= 2 (NEP 50).  Both are pinned by fixtures the reference produced under either NumPy
+    #: (tests/golden/early_stopping_np1.npz, early_stopping_np2.npz); a flipped decision changes which rows exist.
+    early_stopping_promotion: str = "numpy1"
+
+    def _es_bound_f32(self) -> bool:
+        if self.early_stopping_promotion not in ("numpy1", "numpy2"):
+            raise ValueError('early_stopping_promotion must be "numpy1" or "numpy2"')
+        return self.early_stopping_promotion == "numpy2"
+
     def __init__(self, query_encoder: Encoder | None = None, quantizer=None, mode: Mode = Mode.MAXP,
                  encoder_batch_size: int = 32) -> None:
         super().__init__()
@@ -243,10 +255,10 @@ class Index(abc.ABC):
             rank_in_q = np.arange(n, dtype=np.int64) - pair_off[q_no]
         else:
             rank_in_q = pd.Series(q_no).groupby(q_no, sort=False).cumcount().to_numpy()
-        # dense scores are float32 (as the reference's np.sum over float32 vectors); the criterion
-        # below then follows NumPy's promotion for `python_float * np.float32` exactly as the
-        # reference's expression does (NEP 50: stays float32 on numpy >= 2, the version the golden
-        # fixtures were generated with)
+        # dense scores are float32 (as the reference's np.sum over float32 vectors); the criterion below is the
+        # reference's SCALAR expression `python_float * np.float32` under the chosen NumPy promotion
+        # (early_stopping_promotion): float64 products and sum under numpy < 2, float32 throughout under numpy >= 2
+        bound_f32 = self._es_bound_f32()
         ff = np.full(n, np.nan, dtype=np.float32)
         interp = np.full(n, np.nan, dtype=np.result_type(sparse.dtype, np.float32))
         active = np.ones(n_q, dtype=bool)
@@ -269,7 +281,10 @@ class Index(abc.ABC):
                 # (1 - alpha) * (best dense score so far) -- NumPy scalar promotion as in the reference
                 last_sparse = sparse[rows[ends - 1]]
                 best_dense = np.maximum.reduceat(ff[rows], starts)
-                bound = alpha * last_sparse + (1 - alpha) * best_dense
+                if bound_f32:  # (arrays times a Python float keep their dtype under either NumPy)
+                    bound = alpha * last_sparse + (1 - alpha) * best_dense
+                else:
+                    bound = np.float64(alpha) * last_sparse.astype(np.float64) + np.float64(1 - alpha) * best_dense.astype(np.float64)
                 keep = np.zeros(n_q, dtype=bool)
                 keep[present] = kth < bound
                 active &= keep

@@ -304,7 +304,7 @@ class InMemoryIndex(Index):
         plan.set_queries(q)
         plan.set_pairs_lazy(pair_off, ordinals, sparse_g, self.mode.value)
         try:
-            scored, intervals = plan.early_stopping(cutoff, alpha, depths, exact_sum=self.exact_sum)
+            scored, intervals = plan.early_stopping(cutoff, alpha, depths, exact_sum=self.exact_sum, bound_f32=self._es_bound_f32())
         except native.NotFound as e:
             raise IndexError(f"ID {id_at(e.pair)} not found in the index.") from None
         self.last_stats = dict(plan.stats(), early_stopping_scored_pairs=scored, early_stopping_intervals=intervals)

@@ -15,7 +15,7 @@ import numpy as np
 LIB_PATH = Path(__file__).resolve().parent / "libffx.so"
 
 OK, BAD_ARG, OOM, HIP_ERROR, RCCL_ERROR, NOT_FOUND, NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
-FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF = 1, 2, 4
+FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF, FLAG_ES_BOUND_F32 = 1, 2, 4, 8
 TOKEN_INT, TOKEN_NUMBER, TOKEN_NA, TOKEN_TEXT = 1, 2, 4, 8
 RUN_SHORT_LINE, RUN_LONG_LINE, RUN_QUOTES = 1, 2, 4
 BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 3, 4, 5
@@ -420,13 +420,15 @@ class Plan:
         _check(lib().ffx_plan_set_pairs_lazy(self._h, _ptr(pair_off), pair_off.shape[0] - 1, _ptr(pair_ids), _ptr(sp), int(mode)))
         self.n_pairs, self.has_sparse = int(pair_off[-1]), True
 
-    def early_stopping(self, cutoff: int, alpha: float, depths, exact_sum: bool = True) -> tuple[int, int]:
+    def early_stopping(self, cutoff: int, alpha: float, depths, exact_sum: bool = True, bound_f32: bool = False) -> tuple[int, int]:
         """``ffx_plan_early_stopping``: returns (scored pairs, depth intervals run); afterwards
         ``fetch(ff=True, interp=True)`` holds NaN where a candidate was not scored.  ``NotFound``
-        (with ``.pair``) when an unresolved ordinal is reached."""
+        (with ``.pair``) when an unresolved ordinal is reached.  ``bound_f32``: the criterion's bound in float32
+        (NumPy >= 2 scalar promotion) instead of float64 (NumPy < 2, the reference's pinned range)."""
         d = _arr(sorted(int(x) for x in depths), np.int32)
         bad, scored, intervals = C.c_int64(-1), C.c_int64(0), C.c_int32(0)
-        rc = lib().ffx_plan_early_stopping(self._h, int(cutoff), float(alpha), _ptr(d), d.shape[0], FLAG_EXACT_SUM if exact_sum else 0,
+        flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_ES_BOUND_F32 if bound_f32 else 0)
+        rc = lib().ffx_plan_early_stopping(self._h, int(cutoff), float(alpha), _ptr(d), d.shape[0], flags,
                                            C.byref(bad), C.byref(scored), C.byref(intervals))
         _check(rc, bad.value)
         return scored.value, intervals.value

@@ -419,25 +419,51 @@ class ShardedInMemoryIndex(_ShardedIndex):
         if any(d is None and p is None for d, p in zip(doc_ids, psg_ids)):
             raise ValueError("Vector has neither document nor passage ID.")
         mine = [i for i in range(n) if _owner_of(doc_ids[i], psg_ids[i], self.world) == self.rank]
-        if self._scorer is not None:  # its plans belong to the store, which add() may re-allocate
+        if self._scorer is not None:  # its plans belong to the store, which add() may re-allocate (on every rank alike)
             self._scorer.close()
             self._scorer = self._scorer_store = None
+            self._drop_placeholder()
         if mine:
             self.local.add(vectors[mine], doc_ids=[doc_ids[i] for i in mine], psg_ids=[psg_ids[i] for i in mine])
         self._n_global += n
 
     # ---- scoring ---------------------------------------------------------------------------------------------
     def _sharded(self) -> ShardedScorer:
-        """The native scorer over the local store (rebuilt when the store was re-allocated by add)."""
-        if not len(self.local):
-            raise RuntimeError(f"rank {self.rank} holds no rows: a sharded index needs at least one row per rank")
-        self.local._sync_ids()
-        store = self.local._store
-        if self._scorer is None or self._scorer_store is not store:
-            if self._scorer is not None:
-                self._scorer.close()
-            self._scorer, self._scorer_store = ShardedScorer(store, None, self.comm), store
+        """The native scorer over the local store (rebuilt after ``add``, which every rank calls alike, so every rank
+        rebuilds in the same call).  A rank whose hash bucket is empty -- crc32 placement of a small collection over
+        8 ranks easily leaves one -- takes part with a one-row placeholder store and empty candidate lists: what a
+        rank does about "no rows here" is decided TOGETHER (one small all-gather), never by one rank raising between
+        two collectives while the others wait for it in the exchange."""
+        from fast_forward_amd import native
+
+        if self._scorer is not None:
+            return self._scorer
+        store = self.local._store if len(self.local) else None
+        mine = np.array([len(self.local), 0 if store is None else store.dim, -1 if store is None else native._DTYPE_CODE[np.dtype(store.dtype)]], dtype=np.int64)
+        everyone = self.comm.allgather_array(mine)
+        if int(everyone[:, 0].max()) == 0:
+            raise RuntimeError("the sharded index is empty on every rank")  # every rank raises: nobody is left waiting
+        if store is None:
+            donor = everyone[int(np.argmax(everyone[:, 0] > 0))]
+            dtype = next(dt for dt, code in native._DTYPE_CODE.items() if code == int(donor[2]))
+            store = native.DeviceIndex(1, int(donor[1]), self.device, dtype=dtype)
+            if dtype == np.uint8:  # product-quantized rows: the kernels are picked from the codebook's shape
+                book = self.local._quantizer.device_codebook() if self.local._quantizer is not None else None
+                if book is None:
+                    raise RuntimeError("a rank without rows needs the index's quantizer to take part in a quantized sharded index")
+                store.set_codebook(book[0])
+            store.set_doc_rows(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+            store.set_psg_rows(np.zeros(0, dtype=np.int32))
+            self._placeholder = store
+        else:
+            self.local._sync_ids()
+        self._scorer, self._scorer_store = ShardedScorer(store, None, self.comm), store
         return self._scorer
+
+    def _drop_placeholder(self) -> None:
+        if getattr(self, "_placeholder", None) is not None:
+            self._placeholder.close()
+            self._placeholder = None
 
     def _holders_by_code(self, names: np.ndarray):
         # which ids do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
@@ -452,6 +478,7 @@ class ShardedInMemoryIndex(_ShardedIndex):
         if self._scorer is not None:
             self._scorer.close()
             self._scorer = None
+        self._drop_placeholder()
         self.local.close()
 
 
@@ -523,6 +550,10 @@ class ShardedOnDiskIndex(_ShardedIndex):
         # every rank must take the same branch (the exchange differs): resident only if it is for all
         self.resident = bool(self.comm.allreduce([1.0 if resident else 0.0], native.OP_MIN)[0])
         self._store = self._scorer = None
+        # (every rank computed rows_per_rank alike, so what follows is the same decision everywhere: nobody raises alone
+        # between two collectives)
+        if int(self.rows_per_rank.sum()) == 0 and self.resident:
+            raise RuntimeError("the index file holds no rows")
         if self.resident and self._my_rows.shape[0]:
             chunk_maps = [m[0] for m in disk._maps]
             if direct and all(isinstance(c, np.ndarray) and c.flags["C_CONTIGUOUS"] for c in chunk_maps):
@@ -542,7 +573,16 @@ class ShardedOnDiskIndex(_ShardedIndex):
             self._store.set_psg_rows(self._local_psg_row if self._local_psg_row.size else np.zeros(0, dtype=np.int32))
             self._scorer = ShardedScorer(self._store, None, self.comm)
         elif self.resident:
-            raise RuntimeError(f"rank {self.rank} holds no rows: a sharded index needs at least one row per rank")
+            # fewer documents than ranks: this rank takes part with a one-row placeholder and empty candidate lists
+            quantized = disk._quantizer is not None and book is not None and direct
+            self._store = native.DeviceIndex(1, int(disk._meta["dim"]) if direct else int(disk.dim), self.device,
+                                             dtype=stored if direct else np.float32)
+            if quantized:
+                self._store.set_codebook(book[0])
+            self._rotation = book[1] if quantized else None
+            self._store.set_doc_rows(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+            self._store.set_psg_rows(np.zeros(0, dtype=np.int32))
+            self._scorer = ShardedScorer(self._store, None, self.comm)
 
     def __len__(self) -> int:
         return len(self.local)

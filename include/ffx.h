@@ -62,6 +62,12 @@ extern "C" {
 #define FFX_FLAG_EXACT_SUM 1u /* NumPy summation order: scores bit-identical to index/base.py:303 */
 #define FFX_FLAG_SORT 2u      /* also produce the per-query order of ranking.py:115-117 */
 #define FFX_FLAG_SORT_FF 4u   /* with SORT: order by the dense score even if sparse scores are set */
+/* ffx_plan_early_stopping only: evaluate the continue-criterion's bound alpha*s_last + (1-alpha)*max_dense in float32,
+ * as NumPy >= 2 (NEP 50) evaluates the reference's expression (index/base.py:353-355: Python float x np.float32 scalar).
+ * Default (flag absent): in float64 and compared with the float32 cut-off-th score as a double -- what the reference
+ * computes under its pinned numpy>=1.24,<2 (pyproject.toml:16).  The two differ when a decision sits within float32
+ * rounding of the bound (always, e.g., at cut-off 1 after a first depth of 1). */
+#define FFX_FLAG_ES_BOUND_F32 8u
 
 /* ffx_plan_device_ptr selectors */
 #define FFX_BUF_FF 0       /* float[P]   aggregated dense scores                         */
@@ -167,9 +173,11 @@ int ffx_plan_recent_gather_ms(ffx_plan* plan, int32_t n, float* out_ms);
  * Candidates of a query stand in first-stage rank order.  set_pairs_lazy uploads the lists without
  * validating ordinals (use -1 for an id the host could not resolve): as in the reference, an unknown
  * id is an error only if it is reached (FFX_NOT_FOUND + *bad_pair).  early_stopping scores depth
- * intervals [a, b) over the sorted depths >= cutoff; after the first interval a query continues only
- * while its cutoff-th best interpolated score is below alpha * (first-stage score of its last scored
- * candidate) + (1 - alpha) * (its best dense score so far).  All per-query state stays on the device;
+ * intervals [a, b) over the sorted depths >= cutoff (a repeated depth ends the loop, as in the reference); after
+ * the first interval a query continues only while its cutoff-th best interpolated score is below
+ * alpha * (first-stage score of its last scored candidate) + (1 - alpha) * (its best dense score so far),
+ * evaluated in float64 (NumPy < 2 scalar promotion, the reference's pinned range) or, with
+ * FFX_FLAG_ES_BOUND_F32, in float32 (NumPy >= 2).  All per-query state stays on the device;
  * per interval two counters come back to size the launches.  Afterwards ffx_plan_fetch gives the
  * dense and interpolated scores of ALL pairs, NaN where a candidate was never scored. */
 int ffx_plan_set_pairs_lazy(ffx_plan* plan, const int64_t* pair_off, int64_t n_queries, const int32_t* pair_ids,

@@ -220,3 +220,59 @@ def numpy_port_score(vectors, doc_off, doc_rows, psg_row, queries, pair_off, pai
         # ranking.py:319 with a Python-float alpha on float32 columns
         interp = alpha * np.asarray(sparse, dtype=np.float32) + (1 - alpha) * ff
     return ff, interp
+
+
+# --------------------------------------------------------------------------------------
+# Early stopping (index/base.py:316-387), stated per query with plain loops (small cases).
+# --------------------------------------------------------------------------------------
+def early_stopping_mask(dense, sparse, pair_off, cutoff: int, alpha: float, depths, promotion: str = "numpy1") -> np.ndarray:
+    """Which candidates ``Index._early_stopping`` scores (and therefore keeps): a bool per pair.
+
+    ``dense``: the dense score every candidate WOULD get (a candidate's score does not depend on early
+    stopping); candidates of a query stand in first-stage rank order.  Depth intervals ``[a, b)`` over the
+    sorted depths ``>= cutoff`` (base.py:339-342); after the first interval a query continues only while
+
+        int_score.nlargest(cutoff).iat[-1] < alpha * score.iat[-1] + (1 - alpha) * ff_score.max()    (base.py:353-355)
+
+    over the rows scored so far; no rows in an interval (every query stopped, or a repeated depth) ends the
+    loop (base.py:368-369).  The right-hand side multiplies a Python float by np.float32 SCALARS, so its
+    arithmetic is NumPy's scalar promotion: ``promotion="numpy1"`` (numpy < 2, the reference's pinned range):
+    float64 products and sum; ``"numpy2"`` (NEP 50): float32 throughout.  ``int_score`` is a Series
+    expression (base.py:377-379): float32 under either.  Pinned by tests/golden/early_stopping_np1.npz and
+    early_stopping_np2.npz, which the reference produced under numpy 1.26.4 and 2.2.6."""
+    if promotion not in ("numpy1", "numpy2"):
+        raise ValueError(promotion)
+    dense, sparse = _f32(dense), _f32(sparse)
+    pair_off = np.asarray(pair_off, dtype=np.int64)
+    n_q = pair_off.shape[0] - 1
+    interp = interpolate(sparse, dense, alpha)
+    scored = np.zeros(dense.shape[0], dtype=bool)
+    active = [True] * n_q
+    a = 0
+    for b in sorted(int(d) for d in depths):
+        if b < cutoff:
+            continue
+        if a > 0:
+            for q in range(n_q):
+                lo = int(pair_off[q])
+                n = min(int(pair_off[q + 1]) - lo, a)
+                if not active[q] or n == 0:
+                    active[q] = False  # (a query without scored rows never reaches the reference's filter)
+                    continue
+                kth = np.sort(interp[lo:lo + n])[::-1][min(cutoff, n) - 1]
+                last, best = sparse[lo + n - 1], dense[lo:lo + n].max()
+                if promotion == "numpy1":
+                    keep = float(kth) < float(alpha) * float(last) + float(1 - alpha) * float(best)  # Python floats are doubles
+                else:
+                    keep = kth < np.float32(np.float32(alpha) * last) + np.float32(np.float32(1 - alpha) * best)
+                active[q] = bool(keep)
+        took = False
+        for q in range(n_q):
+            lo, n = int(pair_off[q]), int(pair_off[q + 1] - pair_off[q])
+            if active[q] and min(n, b) > min(n, a):
+                scored[lo + min(n, a):lo + min(n, b)] = True
+                took = True
+        if not took:
+            break
+        a = b
+    return scored

@@ -252,3 +252,29 @@ def two_runs(seed: int = 91):
     fa = pd.DataFrame(rows_a, columns=["q_id", "id", "score"])
     fb = pd.DataFrame(rows_b, columns=["q_id", "id", "score"])
     return fa, fb
+
+
+# ---- early stopping under both NumPy scalar-promotion regimes (oracle/gen_golden_promotion.py) ------------------
+ES_PROMOTIONS = {"numpy1": "early_stopping_np1.npz", "numpy2": "early_stopping_np2.npz"}
+ES_PARTS = ("small", "large", "docs")
+
+
+def load_es_promotion_part(promotion: str, part: str) -> dict:
+    """Inputs (from the early_stopping*.npz fixtures) and, per configuration, the rows the REFERENCE kept under the
+    given NumPy (``{(q_id, id): score}``).  ``docs``: document runs with a mode per configuration."""
+    import json
+
+    from fast_forward_amd import synth
+
+    out_file = np.load(GOLDEN / ES_PROMOTIONS[promotion])
+    assert str(out_file["numpy"]).startswith("1." if promotion == "numpy1" else "2.")
+    z = np.load(GOLDEN / {"small": "early_stopping.npz", "large": "early_stopping_large.npz", "docs": "early_stopping_docs.npz"}[part])
+    dim, seed, scale = int(z["dim"]), int(z["seed"]), float(z["scale"])
+    q_names, lens = z["q_names"].tolist(), z["lens"].tolist()
+    n_rows = int(z["n_rows"] if part == "docs" else z["n_psg"])
+    configs = [tuple(c) if part == "docs" else ("PASSAGE", *c) for c in json.loads(str(out_file[f"{part}_configs"]))]
+    expected = [{(q, i): s for q, i, s in zip(out_file[f"{part}_es{ci}_q_id"].tolist(), out_file[f"{part}_es{ci}_id"].tolist(), out_file[f"{part}_es{ci}_score"])}
+                for ci in range(len(configs))]
+    return {"q_names": q_names, "lens": lens, "cands": z["cands"], "sparse": z["sparse"], "prefix": "D" if part == "docs" else "P",
+            "vectors": synth.rows(seed, scale, 0, n_rows, dim), "queries": synth.rows(seed + 1000, scale, 0, len(q_names), dim),
+            "doc_of_row": z["doc_of_row"] if part == "docs" else None, "n_rows": n_rows, "configs": configs, "expected": expected}

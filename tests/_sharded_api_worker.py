@@ -53,6 +53,32 @@ for mode in ("MAXP", "PASSAGE", "AVEP"):
     else:
         raise AssertionError("unknown id accepted")
     idx.close()
+# a collection whose hash placement leaves the LAST rank without a single row: that rank takes part with empty lists
+# (decided collectively -- a rank raising alone between two collectives would leave the others hanging in the exchange)
+from fast_forward_amd.index import InMemoryIndex  # noqa: E402
+from fast_forward_amd.sharded import _owner_of  # noqa: E402
+
+keep = [i for i in range(len(case.vectors)) if _owner_of(case.doc_names[i], case.psg_names[i], world) != world - 1][:40]
+sub = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode.MAXP, comm=comm)
+sub.add(case.vectors[keep], doc_ids=[case.doc_names[i] for i in keep], psg_ids=[case.psg_names[i] for i in keep])
+assert (len(sub.local) == 0) == (rank == world - 1)
+whole = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode.MAXP)
+whole.add(case.vectors[keep], doc_ids=[case.doc_names[i] for i in keep], psg_ids=[case.psg_names[i] for i in keep])
+docs = sorted({case.doc_names[i] for i in keep})
+run = {f"q{q}": {d: float(1 + (7 * q + j) % 5) for j, d in enumerate(docs) if (q + j) % 2 == 0} for q in range(5)}
+small = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(5)})
+assert sub(small, gather=True) == whole(small)
+assert sub.rerank(small, 0.3, gather=True) == whole.rerank(small, 0.3)
+sub.close()
+whole.close()
+empty = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode.MAXP, comm=comm)
+try:
+    empty(small)
+except (RuntimeError, IndexError):
+    pass  # on EVERY rank (nobody is left waiting at a collective)
+else:
+    raise AssertionError("an index that is empty on every rank scored something")
+empty.close()
 total = int(comm.allreduce([checked])[0])
 assert "torch" not in sys.modules
 if rank == 0:

@@ -113,6 +113,24 @@ for resident in (True, False):
     assert sharded(first_psg, gather=True) == mem(first_psg)
     checked += len(first_psg._df)
     sharded.close()
+mem.close()
+
+# ---- 3. fewer documents than ranks: some rank's document range is empty; it takes part with empty candidate lists
+#         (the constructor's "no rows here" is the same decision on every rank, nobody raises between two collectives)
+tiny = work / "tiny.ffx"
+if rank == 0:
+    w = OnDiskIndex(tiny, enc, mode=Mode.MAXP, chunk_size=8, overwrite=True)
+    w.add(case.vectors[:3].astype(np.float32), doc_ids=["only"] * 3, psg_ids=["t0", "t1", "t2"])
+    del w
+comm.barrier()
+mem = InMemoryIndex(enc)
+mem.add(case.vectors[:3].astype(np.float32), doc_ids=["only"] * 3, psg_ids=["t0", "t1", "t2"])
+one = Ranking.from_run({"q0": {"only": 1.5}, "q1": {"only": 0.5}}, queries={"q0": "0", "q1": "1"})
+sharded = ShardedOnDiskIndex(tiny, comm, enc, resident=True)
+assert sharded.rows_per_rank.min() == 0 and sharded.rows_per_rank.sum() == 3
+assert sharded(one, gather=True) == mem(one) and sharded.rerank(one, 0.5, gather=True) == mem.rerank(one, 0.5)
+checked += 2
+sharded.close()
 total = int(comm.allreduce([checked])[0])
 assert "torch" not in sys.modules
 if rank == 0:

@@ -191,6 +191,7 @@ def test_early_stopping_matches_reference_frames(fixture, coded, monkeypatch):
     q_names = z["q_names"].tolist()
     qvecs = synth.rows(seed + 1000, scale, 0, len(q_names), dim)
     idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode.PASSAGE)
+    idx.early_stopping_promotion = "numpy2"  # these frames came out of the reference under numpy 2.2.6 (both regimes: next test but one)
     idx.add(synth.rows(seed, scale, 0, n_psg, dim), psg_ids=[f"P{r}" for r in range(n_psg)])
     rows, pos = [], 0
     for qi, n in enumerate(z["lens"].tolist()):
@@ -238,6 +239,7 @@ def test_early_stopping_on_document_runs_matches_reference_frames(criterion, mon
         monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1)
     for ci, (mname, cutoff, alpha, depths) in enumerate(json.loads(str(z["configs"]))):
         idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mname]))
+        idx.early_stopping_promotion = "numpy2"  # (frames of the reference under numpy 2.2.6)
         idx.add(vectors, doc_ids=[f"D{d}" for d in z["doc_of_row"]])
         res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
         assert (res._coded is not None) == (criterion == "device-coded")
@@ -248,6 +250,62 @@ def test_early_stopping_on_document_runs_matches_reference_frames(criterion, mon
         ks = sorted(want)
         assert np.array_equal(bits(np.array([have[k] for k in ks])), bits(np.array([want[k] for k in ks]))), (ci, mname)
         idx.close()
+
+
+@pytest.mark.parametrize("route", ["device", "device-coded", "host"])
+@pytest.mark.parametrize("part", ["small", "large", "docs"])
+@pytest.mark.parametrize("promotion", ["numpy1", "numpy2"])
+def test_early_stopping_matches_the_reference_under_both_numpy_promotions(promotion, part, route, monkeypatch):
+    """What the reference keeps depends on NumPy's scalar promotion (base.py:353-355 multiplies a Python float by a
+    np.float32 scalar): float64 under its pinned numpy < 2 (the default here, ``early_stopping_promotion = "numpy1"``),
+    float32 under numpy >= 2.  Both are pinned by frames the REFERENCE produced under numpy 1.26.4 and 2.2.6
+    (oracle/gen_golden_promotion.py): ordinary configurations (one of which the two regimes already disagree on),
+    repeated depths, and cut-off 1 after a first depth of 1, where numpy >= 2 never continues.  Same rows, same bits,
+    through the device-resident criterion (frame and coded route) and through its NumPy statement."""
+    from _cases import load_es_promotion_part
+    from fast_forward_amd.index.api import Index
+    import fast_forward_amd.index.api as api_mod
+
+    c = load_es_promotion_part(promotion, part)
+    if route == "host":
+        monkeypatch.setattr(InMemoryIndex, "_early_stopping_scores", Index._early_stopping_scores)
+        monkeypatch.setattr(InMemoryIndex, "_early_stopping_takes_ordinals", False)
+    monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1 if route == "device-coded" else 10**9)
+    rows, pos = [], 0
+    for qi, n in enumerate(c["lens"]):
+        rows += [(c["q_names"][qi], f"{c['prefix']}{cand}", s) for cand, s in zip(c["cands"][pos:pos + n], c["sparse"][pos:pos + n])]
+        pos += n
+    first = Ranking(pd.DataFrame(rows, columns=["q_id", "id", "score"]), queries={q: str(i) for i, q in enumerate(c["q_names"])})
+    qvecs = c["queries"]
+    indexes = {}
+    for (mname, cutoff, alpha, depths), want in zip(c["configs"], c["expected"]):
+        if mname not in indexes:
+            idx = indexes[mname] = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mname]))
+            idx.early_stopping_promotion = promotion
+            if part == "docs":
+                idx.add(c["vectors"], doc_ids=[f"D{d}" for d in c["doc_of_row"]])
+            else:
+                idx.add(c["vectors"], psg_ids=[f"P{r}" for r in range(c["n_rows"])])
+        res = indexes[mname](first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+        assert (res._coded is not None) == (route == "device-coded")
+        got = res._df
+        have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
+        assert have.keys() == want.keys(), (promotion, part, route, mname, cutoff, alpha, depths, len(have), len(want))
+        ks = sorted(want)
+        assert np.array_equal(bits(np.array([have[k] for k in ks], dtype=np.float32)), bits(np.array([want[k] for k in ks], dtype=np.float32)))
+    for idx in indexes.values():
+        idx.close()
+
+
+def test_early_stopping_promotion_must_be_one_of_the_two():
+    idx = InMemoryIndex(LambdaEncoder(lambda q: np.array([10, 10])), mode=Mode.PASSAGE)
+    idx.add(np.stack([[1, 0], [1, 1]] * 10), psg_ids=[f"p{i}" for i in range(20)])
+    r = Ranking(pd.DataFrame([{"q_id": "q", "query": "q", "id": f"p{i}", "score": i} for i in range(20)]))
+    assert InMemoryIndex.early_stopping_promotion == "numpy1"  # the reference's pinned range is the default
+    idx.early_stopping_promotion = "numpy3"
+    with pytest.raises(ValueError):
+        idx(r, early_stopping=5, early_stopping_alpha=0.5, early_stopping_depths=(5, 10))
+    idx.close()
 
 
 @pytest.mark.parametrize("mode", ["MAXP", "PASSAGE", "AVEP"])
@@ -276,8 +334,10 @@ def test_device_resident_early_stopping_equals_the_host_criterion(mode):
     for q in range(n_q):  # a first-stage run is sorted by score inside a query
         sel = q_no == q
         sp[sel] = -np.sort(-sparse[keep][sel])
-    for cutoff, alpha, depths in ((10, 0.2, (20, 50, 100, 400)), (1, 0.5, (1, 2, 3, 5, 8, 13, 400)), (25, 0.05, (100, 30, 1000)),
-                                  (7, 0.9, (400, 8)), (500, 0.3, (600, 700)), (3, 0.0, (5, 50)), (3, 1.0, (5, 50))):
+    for promotion, (cutoff, alpha, depths) in itertools.product(("numpy1", "numpy2"), (
+            (10, 0.2, (20, 50, 100, 400)), (1, 0.5, (1, 2, 3, 5, 8, 13, 400)), (25, 0.05, (100, 30, 1000)),
+            (7, 0.9, (400, 8)), (500, 0.3, (600, 700)), (3, 0.0, (5, 50)), (3, 1.0, (5, 50)), (2, 0.4, (2, 6, 6, 90)))):
+        idx.early_stopping_promotion = promotion
         got = idx._early_stopping_scores(ids, q_no, sp, qvecs, cutoff, alpha, depths)
         stats = dict(idx.last_stats)
         assert stats["early_stopping_intervals"] >= 1

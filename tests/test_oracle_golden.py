@@ -174,3 +174,34 @@ def test_sub_sampled_config2_200k_rows_against_both_reference_runs():
     ff_np, _ = fo.numpy_port_score(vectors, c["doc_off"], rows, rows, c["queries"][:n_q], c["pair_off"][:n_q + 1], c["pair_ids"][:hi],
                                    MODE_NO["MAXP"], c["sparse"][:hi], 0.1, batch_queries=4)
     assert np.array_equal(bits(ff_np), bits(c["ff_f32chunk"][:hi]))
+
+
+@pytest.mark.parametrize("part", ["small", "large", "docs"])
+@pytest.mark.parametrize("promotion", ["numpy1", "numpy2"])
+def test_early_stopping_statement_matches_the_reference_under_both_numpy_promotions(promotion, part):
+    """oracle.early_stopping_mask (base.py:316-387 restated per query) against what the REFERENCE ITSELF kept, run under
+    numpy 1.26.4 (its pinned range: the criterion's bound is float64) and under numpy 2.2.6 (float32): same rows, same
+    score bits, for the ordinary configurations, for repeated depths (the loop ends), and for the boundary
+    configurations (cut-off 1 after a first depth of 1) where the two regimes keep DIFFERENT rows."""
+    from _cases import load_es_promotion_part
+
+    c = load_es_promotion_part(promotion, part)
+    n_q, lens = len(c["q_names"]), c["lens"]
+    pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pair_q = np.repeat(np.arange(n_q), lens)
+    if part == "docs":
+        doc_off = np.concatenate([[0], np.cumsum(np.bincount(c["doc_of_row"]))]).astype(np.int64)
+    else:
+        doc_off = np.arange(c["n_rows"] + 1, dtype=np.int64)
+    rows = np.arange(c["n_rows"], dtype=np.int32)
+    differs = 0
+    for (mode, cutoff, alpha, depths), want in zip(c["configs"], c["expected"]):
+        ff, _ = fo.score(c["vectors"], doc_off, rows, rows, c["queries"], pair_off, c["cands"], MODE_NO[mode])
+        kept = fo.early_stopping_mask(ff, c["sparse"], pair_off, cutoff, alpha, depths, promotion)
+        have = {(c["q_names"][pair_q[p]], f"{c['prefix']}{c['cands'][p]}"): ff[p] for p in np.flatnonzero(kept)}
+        assert have.keys() == want.keys(), (promotion, part, mode, cutoff, alpha, depths)
+        ks = sorted(want)
+        assert np.array_equal(bits(np.array([have[k] for k in ks])), bits(np.array([want[k] for k in ks], dtype=np.float32)))
+        other = fo.early_stopping_mask(ff, c["sparse"], pair_off, cutoff, alpha, depths, "numpy2" if promotion == "numpy1" else "numpy1")
+        differs += int((other != kept).any())
+    assert differs >= 3  # the fixture does separate the two regimes

@@ -44,7 +44,7 @@ def main():
                          "local_pairs": reh["local_pairs"], "owned_pairs": reh["owned_pairs"],
                          "exchange_ms": line["exchange_ms_per_rank"][r], "merge_ms": line["merge_ms_per_rank"][r],
                          "local_step_ms": line["local_step_ms_per_rank"][r], "parity": line.get("parity_on_cpu_sample"),
-                         "route_and_upload_next_batch_s": line["route_and_upload_next_batch_s"], "host_to_host_batch_ms": line["host_to_host_batch_ms"],
+                         "route_and_upload_next_batch_s": line["route_and_upload_next_batch_s"], "host_issue_ms_per_step": line.get("host_issue_ms_per_step"), "host_to_host_batch_ms": line["host_to_host_batch_ms"],
                          "queries": line["config"]["queries"]})
             print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
     base = next((x["step_ms"] for x in rows if x["N"] == 1), None)
