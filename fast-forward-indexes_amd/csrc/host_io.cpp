@@ -400,10 +400,11 @@ int ffx_ids_lookup_packed(const ffx_ids* t, const char* data, int64_t n_bytes, c
   if (T <= 1) {
     work(0, n);
   } else {
-    std::vector<std::thread> pool;
-    for (int k = 1; k < T; ++k) pool.emplace_back(work, n * k / T, n * (k + 1) / T);
-    work(0, n / T);
-    for (auto& th : pool) th.join();
+    try {
+      run_threads(T, [&](int k) { work(n * k / T, n * (k + 1) / T); });
+    } catch (const std::system_error&) {
+      return ffx_fail(FFX_OOM, "could not start host threads");
+    }
   }
   const int64_t m = miss.load();
   if (m == INT64_MAX) return FFX_OK;
@@ -952,10 +953,7 @@ int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queri
     }
   };
   try {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    run_threads(T, [&](int) { work(); });  // (threads that did start are joined before a start-up error gets here)
   } catch (const std::system_error&) {
     return ffx_fail(FFX_OOM, "could not start host threads");
   }
@@ -1123,12 +1121,7 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
     }
   };
   try {
-    {
-      std::vector<std::thread> pool;
-      for (int t = 1; t < T; ++t) pool.emplace_back(parse, std::ref(pieces[(size_t)t]));
-      parse(pieces[0]);
-      for (auto& th : pool) th.join();
-    }
+    run_threads(T, [&](int t) { parse(pieces[(size_t)t]); });
     int64_t lines_before = 0;
     for (Piece& pc : pieces) {
       if (pc.oom) throw std::bad_alloc();
@@ -1200,17 +1193,14 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
         }
       };
       const int TD = (int)std::min<int64_t>(T, std::max<int64_t>(1, n >> 16));
-      {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < TD; ++t) pool.emplace_back(scan, nq * t / TD, nq * (t + 1) / TD);
-        scan(0, nq / TD);
-        for (auto& th : pool) th.join();
-      }
+      run_threads(TD, [&](int t) { scan(nq * t / TD, nq * (t + 1) / TD); });
       if (scan_oom.load()) throw std::bad_alloc();
       if (dup.load()) rc = ffx_fail(FFX_BAD_ARG, "Only one score per query-document/passage pair is allowed.");
     }
   } catch (const std::bad_alloc&) {
     rc = ffx_fail(FFX_OOM, "host allocation failed while parsing %s", path);
+  } catch (const std::system_error&) {
+    rc = ffx_fail(FFX_OOM, "could not start host threads while parsing %s", path);
   }
   if (rc != FFX_OK) {
     delete run;

@@ -108,11 +108,50 @@ def _rendezvous_key() -> str:
                                      os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
 
 
+def _rendezvous_dir() -> str:
+    """Where rank 0 publishes the communicator id: ``FFX_RDZV_DIR`` if set, else a directory of this user alone
+    (mode 0700, owned by the effective uid -- checked, not assumed: the id names the shared-memory segment the other
+    ranks will attach to, so nobody else may place or replace that file)."""
+    given = os.environ.get("FFX_RDZV_DIR")
+    if given:
+        return given
+    base = os.environ.get("XDG_RUNTIME_DIR") or tempfile.gettempdir()
+    path = os.path.join(base, f"ffx-rdzv-{os.geteuid()}")
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    import stat
+
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"{path} must be a directory owned by uid {os.geteuid()} with mode 0700 (set FFX_RDZV_DIR to choose another)")
+    return path
+
+
+def _read_rendezvous(path: str) -> bytes:
+    """The id rank 0 published, or b"" if it is not there yet.  Only a fresh regular file owned by this user counts
+    (no symlinks; a leftover of a crashed job is ignored)."""
+    import stat
+
+    try:
+        fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    except OSError:
+        return b""
+    try:
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.geteuid() or time.time() - st.st_mtime >= 600:
+            return b""
+        return os.read(fd, 4096)
+    finally:
+        os.close(fd)
+
+
 def connect(transport: str | int = "rccl", rank: int | None = None, world: int | None = None, device: int | None = None,
             key: str | None = None, timeout: float = 120.0):
     """Collective: build this job's communicator.  Rank 0 draws the id (``ffx_comm_unique_id``) and
-    publishes it in a file under ``FFX_RDZV_DIR`` (default /tmp) named after the job's key; the other
-    ranks wait for that file.  ``rank`` / ``world`` / ``device`` default to RANK / WORLD_SIZE /
+    publishes it in a file named after the job's key under ``FFX_RDZV_DIR`` (default: a directory only this user
+    can write, ``_rendezvous_dir``); the other ranks wait for that file (a regular file of this user, no symlinks).  ``rank`` / ``world`` / ``device`` default to RANK / WORLD_SIZE /
     LOCAL_RANK (what ``python -m torch.distributed.run`` and ``bench.py --gpus N`` export).
 
     ``transport``: "rccl" (one GPU per rank) or "host" (shared memory: ranks may share a GPU;
@@ -135,21 +174,18 @@ def connect(transport: str | int = "rccl", rank: int | None = None, world: int |
             device %= max(1, native.device_count())
     if world == 1:
         return native.Comm(code, device, 0, 1, native.Comm.unique_id(code))
-    path = os.path.join(os.environ.get("FFX_RDZV_DIR", tempfile.gettempdir()), f"ffx_rdzv_{key or _rendezvous_key()}_{code}")
+    path = os.path.join(_rendezvous_dir(), f"ffx_rdzv_{key or _rendezvous_key()}_{code}")
     if rank == 0:
         uid = native.Comm.unique_id(code)
         tmp = f"{path}.{os.getpid()}"
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)  # atomic: a reader sees all 128 bytes or no file
     else:
         t0, uid = time.monotonic(), b""
         while len(uid) != native.COMM_ID_BYTES:
-            try:
-                fresh = time.time() - os.stat(path).st_mtime < 600  # not a leftover of some crashed job
-                uid = open(path, "rb").read() if fresh else b""
-            except OSError:
-                uid = b""
+            uid = _read_rendezvous(path)
             if len(uid) != native.COMM_ID_BYTES:
                 if time.monotonic() - t0 > timeout:
                     raise TimeoutError(f"rank {rank}: rank 0 never published the communicator id at {path}")
@@ -170,9 +206,10 @@ class ShardedScorer:
     """One rank of a row-sharded index (``ffx_sharded``): local ``gather_dot`` + all-to-all of scores
     + owner-side merge, all native.
 
-    Two HIP streams and two plans: batch i is scored on the compute stream while the scores of
-    batch i-1 are still being exchanged and merged on the communicator's stream, so back-to-back
-    ``run`` calls cost max(scoring, exchange + merge) instead of their sum."""
+    Two HIP streams and two plans: everything that needs the CUs (scoring of batch i, then the merge + ordering
+    of batch i-1) runs in order on the compute stream, only the exchange of batch i runs beside it on the
+    communicator's stream, so back-to-back ``run`` calls hide the exchange and nothing competes with
+    ``gather_dot`` for the CUs; ``sync`` / ``fetch`` finish the last batch's merge."""
 
     def __init__(self, shard, doc_bounds, comm):
         from fast_forward_amd import native
