@@ -314,6 +314,129 @@ int write_formatted(FILE* f, const char* path, int64_t n_queries, int64_t n_rows
 
 }  // namespace
 
+// steps 2 - 5 of ffx_strings_code for n strings given as view(i) -> std::string_view (hashes, shards, per-shard
+// numbering, global numbers + the distinct strings joined by sep)
+template <class View>
+static int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, char** names_blob, int64_t* names_bytes, int64_t* n_names) {
+  constexpr int S = 256;
+  auto in_threads = [&](auto&& body) { run_threads(T, body); };
+  {
+    // 2. hashes, and how many rows of every row range fall into every shard
+    std::vector<uint64_t> hash((size_t)n);
+    std::vector<int64_t> count((size_t)T * S, 0);
+    auto row_range = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
+    in_threads([&](int t) {
+      const auto [lo, hi] = row_range(t);
+      int64_t* c = count.data() + (size_t)t * S;
+      for (int64_t i = lo; i < hi; ++i) {
+        const std::string_view v = view(i);
+        uint64_t h = fnv1a(v.data(), v.size());
+        h ^= h >> 29;
+        h *= 0xbf58476d1ce4e5b9ull;  // fnv's high bits are weak on short numeric strings: mix before taking the shard from them
+        h ^= h >> 32;
+        hash[(size_t)i] = h;
+        ++c[h >> 56];
+      }
+    });
+    // 3. rows dealt into shards, row order kept inside a shard
+    std::vector<int64_t> shard_off((size_t)S + 1, 0);
+    {
+      int64_t at = 0;
+      for (int s = 0; s < S; ++s) {
+        shard_off[(size_t)s] = at;
+        for (int t = 0; t < T; ++t) {
+          const int64_t c = count[(size_t)t * S + s];
+          count[(size_t)t * S + s] = at;  // becomes: where range t writes its rows of shard s
+          at += c;
+        }
+      }
+      shard_off[(size_t)S] = at;
+    }
+    std::vector<int32_t> rows((size_t)n);
+    in_threads([&](int t) {
+      const auto [lo, hi] = row_range(t);
+      int64_t* at = count.data() + (size_t)t * S;
+      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[hash[(size_t)i] >> 56]++] = (int32_t)i;
+    });
+    // 4. every shard numbered on its own; codes[] holds shard-local numbers for now
+    std::vector<std::vector<int32_t>> firsts((size_t)S);  // first row of every distinct string of the shard, in number order
+    std::vector<int64_t> shard_bytes((size_t)S, 0);
+    std::atomic<int> next_shard(0);
+    std::atomic<bool> oom(false);
+    in_threads([&](int) {
+      try {
+        std::vector<int32_t> slot;
+        for (;;) {
+          const int s = next_shard.fetch_add(1);
+          if (s >= S) return;
+          const int64_t lo = shard_off[(size_t)s], hi = shard_off[(size_t)s + 1];
+          size_t cap = 16;
+          while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
+          slot.assign(cap, -1);  // slot -> shard-local number
+          auto& first = firsts[(size_t)s];
+          int64_t bytes = 0;
+          for (int64_t k = lo; k < hi; ++k) {
+            const int32_t i = rows[(size_t)k];
+            const uint64_t h = hash[(size_t)i];
+            const std::string_view v = view(i);
+            size_t at = (size_t)(h >> 8) & (cap - 1);
+            for (;;) {
+              const int32_t have = slot[at];
+              if (have < 0) {
+                slot[at] = (int32_t)first.size();
+                codes[i] = (int32_t)first.size();
+                first.push_back(i);
+                bytes += (int64_t)v.size();
+                break;
+              }
+              const int32_t j = first[(size_t)have];
+              if (hash[(size_t)j] == h && view(j) == v) {
+                codes[i] = have;
+                break;
+              }
+              at = (at + 1) & (cap - 1);
+            }
+          }
+          shard_bytes[(size_t)s] = bytes;
+        }
+      } catch (const std::bad_alloc&) {
+        oom.store(true);
+      }
+    });
+    if (oom.load()) return ffx_fail(FFX_OOM, "host allocation failed");
+    // 5. shard-local numbers -> global numbers; the names written shard by shard
+    std::vector<int64_t> base((size_t)S + 1, 0), at_byte((size_t)S + 1, 0);
+    for (int s = 0; s < S; ++s) {
+      base[(size_t)s + 1] = base[(size_t)s] + (int64_t)firsts[(size_t)s].size();
+      at_byte[(size_t)s + 1] = at_byte[(size_t)s] + shard_bytes[(size_t)s] + (int64_t)firsts[(size_t)s].size();  // + one separator each
+    }
+    const int64_t total = at_byte[(size_t)S];  // one separator too many (after the last name)
+    char* blob = static_cast<char*>(malloc((size_t)std::max<int64_t>(total, 1)));
+    if (!blob) return ffx_fail(FFX_OOM, "host allocation failed");
+    next_shard.store(0);
+    in_threads([&](int) {
+      for (;;) {
+        const int s = next_shard.fetch_add(1);
+        if (s >= S) return;
+        const int32_t b = (int32_t)base[(size_t)s];
+        if (b != 0)
+          for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) codes[rows[(size_t)k]] += b;
+        char* w = blob + at_byte[(size_t)s];
+        for (const int32_t i : firsts[(size_t)s]) {
+          const std::string_view v = view(i);
+          memcpy(w, v.data(), v.size());
+          w += v.size();
+          *w++ = sep;
+        }
+      }
+    });
+    *names_blob = blob;
+    *names_bytes = total - 1;
+    *n_names = base[(size_t)S];
+    return FFX_OK;
+  }
+}
+
 extern "C" {
 
 int ffx_ids_create(ffx_ids** out) {
@@ -456,7 +579,6 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
   if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many strings for int32 codes");
   int T = n_threads > 0 ? n_threads : usable_cores();
   T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
-  constexpr int S = 256;
   auto in_threads = [&](auto&& body) { run_threads(T, body); };  // body(t) for t in 0..T-1
   try {
     // 1. where every string starts: separators counted per byte range, then written per byte range
@@ -479,24 +601,75 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
       for (const char* p = data + lo; (p = static_cast<const char*>(memchr(p, sep, (size_t)(data + hi - p)))) != nullptr; ++p) start[(size_t)i++] = (p - data) + 1;
     });
     auto view = [&](int64_t i) { return std::string_view(data + start[(size_t)i], (size_t)(start[(size_t)i + 1] - 1 - start[(size_t)i])); };
-    // 2. hashes, and how many rows of every row range fall into every shard
-    std::vector<uint64_t> hash((size_t)n);
-    std::vector<int64_t> count((size_t)T * S, 0);
+    return strings_code_views(n, T, view, sep, codes, names_blob, names_bytes, n_names);
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+}
+
+// ffx_strings_code for strings that lie back to back in `data` with their boundaries given: string i is
+// data[offsets[i] .. offsets[i+1]) (what an Arrow string array holds; no separator inside `data`, none needed).
+// `sep` only joins the distinct strings in *names_blob.
+int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes, char** names_blob,
+                             int64_t* names_bytes, int64_t* n_names) {
+  if (names_blob) *names_blob = nullptr;
+  if (names_bytes) *names_bytes = 0;
+  if (n_names) *n_names = 0;
+  if (n < 0 || (n > 0 && (!offsets || !codes)) || !names_blob || !names_bytes || !n_names) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return FFX_OK;
+  if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many strings for int32 codes");
+  if (offsets[0] < 0 || (offsets[n] > offsets[0] && !data)) return ffx_fail(FFX_BAD_ARG, "bad offsets");
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  try {
+    std::atomic<bool> bad(false);
+    run_threads(T, [&](int t) {
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i)
+        if (offsets[i + 1] < offsets[i]) bad.store(true);
+    });
+    if (bad.load()) return ffx_fail(FFX_BAD_ARG, "offsets are not monotone");
+    auto view = [&](int64_t i) { return std::string_view(data + offsets[i], (size_t)(offsets[i + 1] - offsets[i])); };
+    return strings_code_views(n, T, view, sep, codes, names_blob, names_bytes, n_names);
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+}
+
+// Numbering n 8-byte values (equal values get equal numbers, numbers are dense): the same sharded scheme as
+// ffx_strings_code with the value itself as the key.  What it is for: a column of a pandas frame is an array of
+// POINTERS to Python strings, and a run of millions of rows names each query / document through the same few
+// objects (pandas' readers intern the strings of a column; frames built from arrays of names share them by
+// construction) -- numbering the pointers first leaves only the DISTINCT objects to be read as strings
+// (Ranking.__init__, ranking.py:95-116, on 34.9 M rows).  first_row[c] = a row holding number c (the first one
+// inside its shard); first_row must hold min(n, cap_distinct) entries, numbering is shard-major and independent of
+// the thread count.
+int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int32_t* codes, int64_t* first_row, int64_t* n_distinct) {
+  if (n_distinct) *n_distinct = 0;
+  if (n < 0 || !n_distinct || (n > 0 && (!values || !codes || !first_row))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return FFX_OK;
+  if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many values for int32 codes");
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  constexpr int S = 256;
+  auto mix = [](uint64_t v) {
+    v ^= v >> 33;
+    v *= 0xff51afd7ed558ccdull;
+    v ^= v >> 33;
+    v *= 0xc4ceb9fe1a85ec53ull;
+    return v ^ (v >> 33);
+  };
+  try {
     auto row_range = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
-    in_threads([&](int t) {
+    std::vector<int64_t> count((size_t)T * S, 0);
+    run_threads(T, [&](int t) {
       const auto [lo, hi] = row_range(t);
       int64_t* c = count.data() + (size_t)t * S;
-      for (int64_t i = lo; i < hi; ++i) {
-        const std::string_view v = view(i);
-        uint64_t h = fnv1a(v.data(), v.size());
-        h ^= h >> 29;
-        h *= 0xbf58476d1ce4e5b9ull;  // fnv's high bits are weak on short numeric strings: mix before taking the shard from them
-        h ^= h >> 32;
-        hash[(size_t)i] = h;
-        ++c[h >> 56];
-      }
+      for (int64_t i = lo; i < hi; ++i) ++c[mix(values[i]) >> 56];
     });
-    // 3. rows dealt into shards, row order kept inside a shard
     std::vector<int64_t> shard_off((size_t)S + 1, 0);
     {
       int64_t at = 0;
@@ -504,24 +677,22 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
         shard_off[(size_t)s] = at;
         for (int t = 0; t < T; ++t) {
           const int64_t c = count[(size_t)t * S + s];
-          count[(size_t)t * S + s] = at;  // becomes: where range t writes its rows of shard s
+          count[(size_t)t * S + s] = at;
           at += c;
         }
       }
       shard_off[(size_t)S] = at;
     }
     std::vector<int32_t> rows((size_t)n);
-    in_threads([&](int t) {
+    run_threads(T, [&](int t) {
       const auto [lo, hi] = row_range(t);
       int64_t* at = count.data() + (size_t)t * S;
-      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[hash[(size_t)i] >> 56]++] = (int32_t)i;
+      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[mix(values[i]) >> 56]++] = (int32_t)i;
     });
-    // 4. every shard numbered on its own; codes[] holds shard-local numbers for now
-    std::vector<std::vector<int32_t>> firsts((size_t)S);  // first row of every distinct string of the shard, in number order
-    std::vector<int64_t> shard_bytes((size_t)S, 0);
+    std::vector<std::vector<int32_t>> firsts((size_t)S);
     std::atomic<int> next_shard(0);
     std::atomic<bool> oom(false);
-    in_threads([&](int) {
+    run_threads(T, [&](int) {
       try {
         std::vector<int32_t> slot;
         for (;;) {
@@ -530,67 +701,48 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
           const int64_t lo = shard_off[(size_t)s], hi = shard_off[(size_t)s + 1];
           size_t cap = 16;
           while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
-          slot.assign(cap, -1);  // slot -> shard-local number
+          slot.assign(cap, -1);
           auto& first = firsts[(size_t)s];
-          int64_t bytes = 0;
           for (int64_t k = lo; k < hi; ++k) {
             const int32_t i = rows[(size_t)k];
-            const uint64_t h = hash[(size_t)i];
-            const std::string_view v = view(i);
-            size_t at = (size_t)(h >> 8) & (cap - 1);
+            const uint64_t v = values[i];
+            size_t at = (size_t)(mix(v) >> 8) & (cap - 1);
             for (;;) {
               const int32_t have = slot[at];
               if (have < 0) {
                 slot[at] = (int32_t)first.size();
                 codes[i] = (int32_t)first.size();
                 first.push_back(i);
-                bytes += (int64_t)v.size();
                 break;
               }
-              const int32_t j = first[(size_t)have];
-              if (hash[(size_t)j] == h && view(j) == v) {
+              if (values[first[(size_t)have]] == v) {
                 codes[i] = have;
                 break;
               }
               at = (at + 1) & (cap - 1);
             }
           }
-          shard_bytes[(size_t)s] = bytes;
         }
       } catch (const std::bad_alloc&) {
         oom.store(true);
       }
     });
     if (oom.load()) return ffx_fail(FFX_OOM, "host allocation failed");
-    // 5. shard-local numbers -> global numbers; the names written shard by shard
-    std::vector<int64_t> base((size_t)S + 1, 0), at_byte((size_t)S + 1, 0);
-    for (int s = 0; s < S; ++s) {
-      base[(size_t)s + 1] = base[(size_t)s] + (int64_t)firsts[(size_t)s].size();
-      at_byte[(size_t)s + 1] = at_byte[(size_t)s] + shard_bytes[(size_t)s] + (int64_t)firsts[(size_t)s].size();  // + one separator each
-    }
-    const int64_t total = at_byte[(size_t)S];  // one separator too many (after the last name)
-    char* blob = static_cast<char*>(malloc((size_t)std::max<int64_t>(total, 1)));
-    if (!blob) return ffx_fail(FFX_OOM, "host allocation failed");
+    std::vector<int64_t> base((size_t)S + 1, 0);
+    for (int s = 0; s < S; ++s) base[(size_t)s + 1] = base[(size_t)s] + (int64_t)firsts[(size_t)s].size();
     next_shard.store(0);
-    in_threads([&](int) {
+    run_threads(T, [&](int) {
       for (;;) {
         const int s = next_shard.fetch_add(1);
         if (s >= S) return;
-        const int32_t b = (int32_t)base[(size_t)s];
+        const int64_t b = base[(size_t)s];
         if (b != 0)
-          for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) codes[rows[(size_t)k]] += b;
-        char* w = blob + at_byte[(size_t)s];
-        for (const int32_t i : firsts[(size_t)s]) {
-          const std::string_view v = view(i);
-          memcpy(w, v.data(), v.size());
-          w += v.size();
-          *w++ = sep;
-        }
+          for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) codes[rows[(size_t)k]] += (int32_t)b;
+        int64_t w = b;
+        for (const int32_t i : firsts[(size_t)s]) first_row[w++] = i;
       }
     });
-    *names_blob = blob;
-    *names_bytes = total - 1;
-    *n_names = base[(size_t)S];
+    *n_distinct = base[(size_t)S];
     return FFX_OK;
   } catch (const std::bad_alloc&) {
     return ffx_fail(FFX_OOM, "host allocation failed");
@@ -884,7 +1036,19 @@ int ffx_host_outer_join(const int64_t* off_a, const int32_t* code_a, const int64
 // combined on the host (Ranking.interpolate).  Threads take blocks of queries; out_order[p] is a
 // position inside the whole array, as ffx_plan_fetch hands it out.
 int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queries, int32_t n_threads, int32_t* out_order) {
+  return ffx_host_order_blocks(scores, pair_off, nullptr, n_queries, n_threads, out_order);
+}
+
+// ffx_host_order with the queries' blocks laid out anew: the order of query q (positions in the input, as before) is
+// written from out_order[dst_off[q]] on -- ordering every query AND putting the queries into another sequence (the
+// constructor's "q_id descending") in the one pass.  dst_off NULL: where the query stands (ffx_host_order).  The
+// caller sees to it that the destination blocks do not overlap.
+int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries, int32_t n_threads,
+                          int32_t* out_order) {
   if (!pair_off || n_queries < 0 || pair_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (dst_off)
+    for (int64_t q = 0; q < n_queries; ++q)
+      if (dst_off[q] < 0 || dst_off[q] + (pair_off[q + 1] - pair_off[q]) > pair_off[n_queries]) return ffx_fail(FFX_BAD_ARG, "destination of query %lld lies outside the output", (long long)q);
   for (int64_t q = 0; q < n_queries; ++q)
     if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
   const int64_t P = pair_off[n_queries];
@@ -945,7 +1109,8 @@ int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queri
             }
             if (from != keys.data()) keys.swap(other);
           }
-          for (int64_t i = 0; i < n; ++i) out_order[lo + i] = (int32_t)(lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu));
+          int32_t* dst = out_order + (dst_off ? dst_off[q] : lo);
+          for (int64_t i = 0; i < n; ++i) dst[i] = (int32_t)(lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu));
         }
       }
     } catch (const std::bad_alloc&) {

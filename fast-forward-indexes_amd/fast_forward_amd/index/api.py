@@ -461,14 +461,18 @@ class Index(abc.ABC):
         ``missing_ok`` unknown ids come back as -1 instead (early stopping looks ids up leniently)."""
         key = (id(self), getattr(getattr(self, "_ids", None), "version", None), self.mode)
         cached = getattr(ranking, "_ordinal_cache", None)
+        self._last_lookup_timings = {}
         if cached is None or cached[0] != key or cached[1] is not names or cached[2] is not codes:
-            by_code = self._lookup_optional(names, self.mode).astype(np.int32, copy=False)
+            t0 = perf_counter()
+            by_code = self._lookup_optional(names, self.mode, ranking._id_blob(names)).astype(np.int32, copy=False)
+            t1 = perf_counter()
             # a ranking's rows never change: the resolved candidate list is kept with it (SURVEY.md 8e: "amortise /
             # cache the resolved CSR per run")
             from fast_forward_amd import native
 
             cached = (key, names, codes, native.take32(np.ascontiguousarray(by_code), codes), bool(by_code.size and by_code.min() < 0))
             ranking._ordinal_cache = cached
+            self._last_lookup_timings = {"distinct_ids": int(len(names)), "distinct_id_lookup_s": t1 - t0, "ordinals_of_rows_s": perf_counter() - t1}
         ordinals = cached[3]
         if not missing_ok and cached[4]:
             unknown = np.flatnonzero(ordinals < 0)
@@ -481,9 +485,9 @@ class Index(abc.ABC):
         caller gathers out of them before the next call)."""
         return {"reuse_outputs": True} if getattr(self, "_result_buffers", None) is not None else {}
 
-    def _lookup_optional(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
-        """Ordinals of ``ids``, -1 where unknown."""
-        return self._ids.lookup_optional(ids, mode.value)
+    def _lookup_optional(self, ids: np.ndarray, mode: Mode, packed=None) -> np.ndarray:
+        """Ordinals of ``ids``, -1 where unknown (``packed``: the ids once more as one joined buffer, see ``IdTable``)."""
+        return self._ids.lookup_optional(ids, mode.value, packed)
 
     @abc.abstractmethod
     def _native_id_table(self, mode: Mode):
@@ -496,24 +500,34 @@ class Index(abc.ABC):
         (optionally cut to the best ``cutoff`` per query).  Same scores, bit for bit."""
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
+        t = [perf_counter()]
         q_no, q_order, texts = self._numbered_queries(ranking)
         query_vectors = np.ascontiguousarray(self.encode_queries(texts))
         perm, pair_off = ranking._csr()
+        t.append(perf_counter())
         if perm is None and len(q_no) >= _CODED_MIN_ROWS and _in_final_order(q_order):
             # a large run in the constructor's order: integer codes in, integer codes out, no Python string per row
             codes, names = ranking._id_coding()
+            t.append(perf_counter())
             ordinals = self._ordinals_of_codes(ranking, codes, names)
+            t.append(perf_counter())
             sparse = np.ascontiguousarray(ranking._scores(), dtype=np.float32)
             _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False,
                                                  **self._reuse_kw())
+            t.append(perf_counter())
             from fast_forward_amd import native
 
             if cutoff is not None:
                 rank = np.arange(len(order)) - np.repeat(pair_off[:-1], np.diff(pair_off))
                 keep = rank < cutoff
                 order, q_no = order[keep], q_no[keep]  # (the device order is a permutation inside every query)
-            return Ranking._assemble_coded(ranking.name, q_no, q_order, native.take32(codes, order), names,
-                                           native.take32(interp, order).astype(ranking._score_dtype(), copy=False), texts)
+            out = Ranking._assemble_coded(ranking.name, q_no, q_order, native.take32(codes, order), names,
+                                          native.take32(interp, order).astype(ranking._score_dtype(), copy=False), texts)
+            t.append(perf_counter())
+            # where a call's time went (seconds): a first call on a ranking pays for the distinct-id look-up, later ones do not
+            self.last_timings = dict(zip(("queries_numbered_and_encoded_s", "id_coding_s", "ids_to_ordinals_s", "upload_device_download_s", "result_gathers_s"),
+                                         np.diff(t).tolist()), **getattr(self, "_last_lookup_timings", {}))
+            return out
         df = ranking._df
         ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
         sparse = df["score"].to_numpy(dtype=np.float32)

@@ -141,10 +141,11 @@ class IdTable:
         exactly like the reference (util.py:38-39)."""
         return self.native_table(mode).lookup(ids if isinstance(ids, np.ndarray) else np.asarray(ids, dtype=object))
 
-    def lookup_optional(self, ids, mode: int) -> np.ndarray:
-        """Ordinals (int64) of ``ids`` for ``mode``, -1 where the id is not in the table."""
+    def lookup_optional(self, ids, mode: int, packed=None) -> np.ndarray:
+        """Ordinals (int64) of ``ids`` for ``mode``, -1 where the id is not in the table.  ``packed``: the ids once more
+        as (one ``'\n'``-joined UTF-8 buffer, their number), when the caller holds them that way."""
         ids = ids if isinstance(ids, np.ndarray) else np.asarray(ids, dtype=object)
-        return self.native_table(mode).lookup(ids, missing_ok=True).astype(np.int64)
+        return self.native_table(mode).lookup(ids, missing_ok=True, packed=packed).astype(np.int64)
 
     def native_table(self, mode: int):
         """The native (libffx) doc- or passage-id table; ordinals agree with ``resolve``.  Also used by

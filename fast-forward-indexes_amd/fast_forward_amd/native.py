@@ -32,9 +32,9 @@ SYMBOLS = (
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
-    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_buffer_free",
+    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_host_code_u64", "ffx_buffer_free",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route",
@@ -174,7 +174,9 @@ def lib() -> C.CDLL:
         "ffx_ids_intern_packed": ([vp, C.c_char_p, i64, C.c_char, i64, vp], C.c_int),
         "ffx_ids_blob": ([vp, C.c_char, vp, i64, P(i64)], C.c_int),
         "ffx_strings_code": ([C.c_char_p, i64, C.c_char, i64, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
+        "ffx_strings_code_offsets": ([vp, vp, i64, C.c_char, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
         "ffx_buffer_free": ([vp], C.c_int),
+        "ffx_host_code_u64": ([vp, i64, i32, vp, vp, P(i64)], C.c_int),
         "ffx_ids_get": ([vp, i32, P(vp), P(i32)], C.c_int),
         "ffx_run_open": ([C.c_char_p, vp, P(vp), P(i64)], C.c_int),
         "ffx_run_close": ([vp], C.c_int),
@@ -193,6 +195,7 @@ def lib() -> C.CDLL:
         "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
         "ffx_host_unpin": ([vp], C.c_int),
         "ffx_host_order": ([vp, vp, i64, i32, vp], C.c_int),
+        "ffx_host_order_blocks": ([vp, vp, vp, i64, i32, vp], C.c_int),
         "ffx_host_take32": ([vp, i64, vp, i64, i32, vp], C.c_int),
         "ffx_host_interpolate": ([vp, vp, vp, i64, C.c_float, C.c_float, i32, vp, P(i32)], C.c_int),
         "ffx_host_outer_join": ([vp, vp, vp, vp, i64, i32, vp, vp, vp, vp], C.c_int),
@@ -613,12 +616,18 @@ def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=Non
     return ff, interp, order, st.as_dict()
 
 
-def host_order(scores, pair_off, threads: int = 0) -> np.ndarray:
+def host_order(scores, pair_off, threads: int = 0, dst_off=None) -> np.ndarray:
     """``ffx_host_order``: per-query order (scores descending, exact ties by position) computed by host
-    threads; positions are indices into ``scores``."""
+    threads; positions are indices into ``scores``.  ``dst_off``: where every query's block starts in the output
+    (``ffx_host_order_blocks``: the queries laid out in another sequence in the same pass)."""
     scores, pair_off = _arr(scores, np.float32), _arr(pair_off, np.int64)
     out = np.empty(scores.shape[0], dtype=np.int32)
-    _check(lib().ffx_host_order(_ptr(scores), _ptr(pair_off), pair_off.shape[0] - 1, int(threads), _ptr(out)))
+    if dst_off is None:
+        _check(lib().ffx_host_order(_ptr(scores), _ptr(pair_off), pair_off.shape[0] - 1, int(threads), _ptr(out)))
+    else:
+        dst = _arr(dst_off, np.int64)
+        assert dst.shape[0] >= pair_off.shape[0] - 1
+        _check(lib().ffx_host_order_blocks(_ptr(scores), _ptr(pair_off), _ptr(dst), pair_off.shape[0] - 1, int(threads), _ptr(out)))
     return out
 
 
@@ -659,6 +668,88 @@ def code_strings(blob: bytes, n: int, threads: int = 0) -> tuple[np.ndarray, byt
         if names.value:
             lib().ffx_buffer_free(names)
     return codes, joined, int(n_names.value)
+
+
+def code_u64(address: int, n: int, threads: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    """``ffx_host_code_u64`` on the ``n`` 8-byte values at ``address``: (int32 number of every value, a row holding
+    each number)."""
+    codes, first = np.empty(int(n), dtype=np.int32), np.empty(int(n), dtype=np.int64)
+    n_distinct = C.c_int64(0)
+    _check(lib().ffx_host_code_u64(C.c_void_p(int(address)), int(n), int(threads), _ptr(codes), _ptr(first), C.byref(n_distinct)))
+    return codes, first[:n_distinct.value].copy()
+
+
+def code_object_column(col: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, np.ndarray, tuple[bytes, int] | None] | None":
+    """(int32 code of every element, the distinct strings by code, those strings once more as one ``'\n'``-joined
+    UTF-8 buffer with their number -- or None if one of them holds a newline) of an object array of Python
+    strings; None when some element is not a ``str``.  The array holds POINTERS: they are numbered first
+    (rows that share an object share a code at once, no string is looked at), then only the distinct objects are
+    read as strings and numbered by value (``ffx_strings_code``) -- a run of 34.9 M rows names 8.7 M documents
+    and 7 k queries, and pandas' own hash of 34.9 M Python strings is what the constructor used to wait for."""
+    if col.dtype != object or col.ndim != 1 or not col.flags["C_CONTIGUOUS"] or col.itemsize != 8:
+        return None
+    n = col.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int32), np.empty(0, dtype=object), None
+    by_object, first = code_u64(col.ctypes.data, n, threads)
+    distinct = col[first]
+    if distinct.shape[0] < 4096:  # few objects: a dict does it
+        table: dict = {}
+        of_object = np.empty(distinct.shape[0], dtype=np.int32)
+        for j, s in enumerate(distinct.tolist()):
+            if type(s) is not str:
+                return None
+            of_object[j] = table.setdefault(s, len(table))
+        names = np.empty(len(table), dtype=object)
+        names[:] = list(table)
+        blob = "\n".join(table).encode("utf-8")
+    else:
+        got = _code_distinct_objects(distinct, threads)
+        if got is None:
+            return None
+        of_object, blob = got
+        names = np.empty(int(of_object.max()) + 1, dtype=object)
+        names[of_object] = distinct  # the strings themselves: any object of a value stands for it
+    packed = (blob, len(names)) if (blob.count(b"\n") == len(names) - 1 and b"\0" not in blob) else None
+    return take32(of_object, by_object), names, packed
+
+
+def _code_distinct_objects(distinct: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, bytes] | None":
+    """(int32 number of every string of an object array -- equal strings, equal numbers; dense --, the distinct strings in
+    number order joined by ``'\n'``), None if some element is not a ``str``.  With pyarrow at hand the strings are laid back to back by its converter (one C++ pass, no joined
+    Python string, no separator to check for) and numbered from there (``ffx_strings_code_offsets``); otherwise
+    through one ``'\n'``-joined buffer (``ffx_strings_code``)."""
+    n = distinct.shape[0]
+    try:
+        import pyarrow as pa
+    except ImportError:
+        pa = None
+    if pa is not None:
+        try:
+            arr = pa.array(distinct, type=pa.large_string() if n > (1 << 26) else pa.string(), from_pandas=False)
+        except (pa.ArrowInvalid, pa.ArrowTypeError, TypeError, ValueError, UnicodeError):
+            return None
+        if arr.null_count:
+            return None
+        bufs = arr.buffers()  # [validity, offsets, data]
+        off_t = np.int64 if pa.types.is_large_string(arr.type) else np.int32
+        offsets = np.frombuffer(bufs[1], dtype=off_t, count=n + 1 + arr.offset)[arr.offset:].astype(np.int64)
+        data_address = bufs[2].address if bufs[2] is not None else 0
+        codes = np.empty(n, dtype=np.int32)
+        names, n_bytes, n_names = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        _check(lib().ffx_strings_code_offsets(C.c_void_p(data_address), _ptr(offsets), n, b"\n", int(threads), _ptr(codes), C.byref(names),
+                                              C.byref(n_bytes), C.byref(n_names)))
+        try:
+            joined = C.string_at(names.value, n_bytes.value) if names.value and n_bytes.value > 0 else b""
+        finally:
+            if names.value:
+                lib().ffx_buffer_free(names)
+        return codes, joined
+    packed = _packed(distinct)
+    if packed is None:
+        return None
+    codes, joined, _ = code_strings(*packed, threads)
+    return codes, joined
 
 
 def unique_rows(rows: np.ndarray, n_index_rows: int, threads: int = 0) -> tuple[np.ndarray, np.ndarray]:
@@ -773,10 +864,12 @@ class IdStrings:
         _check(lib().ffx_ids_blob(self._h, b"\n", buf, need.value, C.byref(need)))
         return buf.raw[:need.value]
 
-    def lookup(self, strings, missing_ok: bool = False) -> np.ndarray:
+    def lookup(self, strings, missing_ok: bool = False, packed: "tuple[bytes, int] | None" = None) -> np.ndarray:
         """Ordinals of ``strings``; ``IndexError`` naming the first unknown one, or -1 in its place
-        with ``missing_ok``."""
-        packed = _packed(strings)
+        with ``missing_ok``.  ``packed``: the same strings as one ``'\n'``-joined buffer and their number, if the
+        caller already holds them that way (the name table of a coded ranking)."""
+        if packed is None or packed[1] != len(strings):
+            packed = _packed(strings)
         if packed is not None:
             blob, n = packed
             out = np.empty(n, dtype=np.int32)

@@ -93,9 +93,10 @@ def _native_or_none():
 
 def _order_by_query_then_score(q_rank: np.ndarray, score: np.ndarray) -> np.ndarray:
     """Stable order by (query rank ascending, score descending): ``np.lexsort((-score, q_rank))``.  For float32
-    scores the rows are first grouped by query (a stable integer sort: one pass when they already are, as in
-    any run file) and every query is then ordered by libffx's host threads (``ffx_host_order``) -- 34.9 M rows:
-    ~1 s instead of ~8 s."""
+    scores every query is ordered by libffx's host threads (``ffx_host_order``) and the queries' blocks are then
+    put in rank order: rows that stand grouped by query (any run file, any frame made from one -- in whatever
+    order the queries come) need no sort over all rows at all; only rows of one query scattered over the input
+    are first gathered by a stable integer sort.  34.9 M rows: ~0.5 s instead of ~8 s."""
     if score.dtype == np.float32 and score.shape[0] >= (1 << 16):
         try:
             from fast_forward_amd import native
@@ -104,11 +105,22 @@ def _order_by_query_then_score(q_rank: np.ndarray, score: np.ndarray) -> np.ndar
         except (ImportError, OSError):
             native = None
         if native is not None:
-            n_q = int(q_rank.max()) + 1 if q_rank.size else 0
+            n = q_rank.shape[0]
+            starts = np.flatnonzero(q_rank[1:] != q_rank[:-1]) + 1
+            starts = np.concatenate([[0], starts])
+            run_rank = q_rank[starts]
+            if np.unique(run_rank).shape[0] == run_rank.shape[0]:
+                # one contiguous block per query: order inside every block, then lay the blocks out by rank
+                off = np.concatenate([starts, [n]]).astype(np.int64)
+                if (run_rank[1:] > run_rank[:-1]).all():
+                    return native.host_order(score, off)
+                by_rank = np.argsort(run_rank, kind="stable")
+                dst = np.empty(len(by_rank), dtype=np.int64)
+                dst[by_rank] = np.concatenate([[0], np.cumsum(np.diff(off)[by_rank])[:-1]])  # where block q lands
+                return native.host_order(score, off, dst_off=dst)
+            n_q = int(q_rank.max()) + 1
             off = np.zeros(n_q + 1, dtype=np.int64)
             np.cumsum(np.bincount(q_rank, minlength=n_q), out=off[1:])
-            if (q_rank[1:] >= q_rank[:-1]).all():
-                return native.host_order(score, off).astype(np.intp)
             grouped = np.argsort(q_rank, kind="stable")
             return grouped[native.host_order(score[grouped], off)]
     return np.lexsort((-score.astype(np.float64), q_rank))
@@ -151,13 +163,13 @@ class Ranking:
 
     @classmethod
     def _assemble_coded(cls, name, q_no: np.ndarray, q_order: list, id_codes: np.ndarray, id_names: np.ndarray, score: np.ndarray,
-                        q_texts: "list | None") -> "Ranking":
+                        q_texts: "list | None", id_blob: "tuple[bytes, int] | None" = None) -> "Ranking":
         """Ranking from device results in coded form (rows in final order, pairs unique, nothing missing);
-        the frame is built on first use."""
+        the frame is built on first use.  ``id_blob``: ``id_names`` once more as one joined buffer (``_id_blob``)."""
         out = cls.__new__(cls)
         out.name = name
         out._coded = {"q_no": q_no, "q_order": list(q_order), "id_codes": id_codes, "id_names": id_names, "score": score,
-                      "q_texts": None if q_texts is None else list(q_texts)}
+                      "q_texts": None if q_texts is None else list(q_texts), "id_blob": id_blob}
         out._q_no, out._q_order = q_no, list(q_order)
         out._q_ids = set(out._q_order)
         return out
@@ -170,6 +182,15 @@ class Ranking:
             codes, names = pd.factorize(self._frame["id"].to_numpy())
             self._id_cache = (codes.astype(np.int32), np.asarray(names, dtype=object))
         return self._id_cache
+
+    def _id_blob(self, names: np.ndarray) -> "tuple[bytes, int] | None":
+        """The id strings of ``_id_coding`` once more as (one ``'\n'``-joined UTF-8 buffer, their number), if this
+        ranking was built from such a buffer (the native constructors number ids out of one): an index resolves
+        the distinct ids from it without touching a Python string."""
+        c = self._coded
+        if c is not None and c.get("id_blob") is not None and names is c["id_names"]:
+            return c["id_blob"]
+        return None
 
     def _scores(self) -> np.ndarray:
         return self._coded["score"] if self._coded is not None else self._frame["score"].to_numpy()
@@ -252,59 +273,83 @@ class Ranking:
             self._df = _with_queries(self._df, queries)
 
     def _init_from_columns(self, df: pd.DataFrame, queries, dtype: np.dtype, copy: bool, is_sorted: bool) -> bool:
-        """The constructor for the ordinary large frame -- string ids, numeric scores, nothing missing
-        but possibly some scores -- on column arrays: each id column is numbered once and the
-        duplicate check, the NaN drop, the sort and the per-row query numbers all work on integers.
-        Returns False (nothing done) for anything else; the general code below then decides."""
-        from pandas.api.types import infer_dtype, is_bool_dtype, is_numeric_dtype
+        """The constructor for the ordinary large frame -- string ids, numeric scores, nothing missing but possibly
+        some scores -- without a pandas hash of a Python string per row: every text column is numbered natively
+        (``native.code_object_column``: the column's object POINTERS first, then only the distinct strings), and the
+        duplicate check, the NaN drop, the sort and the per-row query numbers all work on those integers.  The
+        result is kept in the coded form (query number, id code, score per row + the two string tables); the frame
+        of strings is built if and when somebody asks for it.  34.9 M rows: seconds where three ``pd.factorize``
+        passes and three object-column gathers took ~20.  Returns False (nothing done) for anything else -- a
+        non-string cell, a query id with two different texts, no native library -- and the general code decides."""
+        from pandas.api.types import is_bool_dtype, is_numeric_dtype
 
         if len(df) < 2048 or any(c not in df.columns for c in (*_KEY, "score")):
             return False
         s_col = df["score"]
         if not is_numeric_dtype(s_col.dtype) or is_bool_dtype(s_col.dtype) or not isinstance(s_col.dtype, np.dtype):
             return False
-        text_cols = [*_KEY] + (["query"] if "query" in df.columns else [])
-        if any(df[c].dtype != object or infer_dtype(df[c], skipna=False) != "string" for c in text_cols):
+        native = _native_or_none()
+        if native is None:
             return False
-        q, ids, score = df["q_id"].to_numpy(), df["id"].to_numpy(), s_col.to_numpy()
-        query = df["query"].to_numpy() if "query" in df.columns else None
-        q_code, q_names = pd.factorize(q)
+        text_cols = [*_KEY] + (["query"] if "query" in df.columns else [])
+        if any(df[c].dtype != object for c in text_cols):
+            return False
+        coded = {}
+        for c in text_cols:  # (None: some cell is not a str -- missing values, numbers: the general path knows what to do)
+            coded[c] = native.code_object_column(np.ascontiguousarray(df[c].to_numpy()))
+            if coded[c] is None:
+                return False
+        (q_code, q_names, _), (id_code, id_names, id_blob) = coded["q_id"], coded["id"]
+        n_q = len(q_names)
+        text_of_q = None
+        if "query" in coded:
+            t_code, t_names, _ = coded["query"]
+            text_of_q = np.full(n_q, -1, dtype=np.int32)
+            text_of_q[q_code] = t_code
+            if not np.array_equal(text_of_q[q_code], t_code):
+                return False  # one query id with two different texts: leave it to the frame path
+        score = s_col.to_numpy()
         if not getattr(df, "_ffx_pairs_unique", False):
-            id_code, id_names = pd.factorize(ids)
             key = q_code.astype(np.int64) * max(1, len(id_names)) + id_code
             key.sort()
             if (key[1:] == key[:-1]).any():
                 raise ValueError("Only one score per query-document/passage pair is allowed.")
+            del key
         rows = None  # None: every row, in frame order
         if score.dtype.kind == "f":
             missing = np.isnan(score)
             if missing.any():
-                rows = np.flatnonzero(~missing)
+                rows = np.flatnonzero(~missing).astype(np.int32)
         score = score.astype(dtype, copy=True) if rows is None else score[rows].astype(dtype)
         codes = q_code if rows is None else q_code[rows]
         if not is_sorted:
-            rank_of = np.empty(len(q_names), dtype=np.int64)
-            rank_of[np.argsort(np.asarray(q_names, dtype=object))[::-1]] = np.arange(len(q_names))
-            order = _order_by_query_then_score(rank_of[codes], score)
+            rank_of = np.empty(n_q, dtype=np.int64)
+            rank_of[np.argsort(q_names)[::-1]] = np.arange(n_q)
+            order = np.ascontiguousarray(_order_by_query_then_score(rank_of[codes], score), dtype=np.int32)
             rows = order if rows is None else rows[order]
-            score, codes = score[order], codes[order]
-
-        def column(a: np.ndarray) -> np.ndarray:
-            return a[rows] if rows is not None else (a.copy() if copy else a)
-
-        cols = {"q_id": column(q), "id": column(ids), "score": score}
-        if query is not None:
-            cols["query"] = column(query)
-        self._df = pd.DataFrame(cols, copy=False)
-        if not getattr(df, "_ffx_pairs_unique", False):  # the ids were numbered for the duplicate check: keep that
-            self._id_cache = ((id_code if rows is None else id_code[rows]).astype(np.int32), np.asarray(id_names, dtype=object))
-        self._q_no, firsts = pd.factorize(codes)
-        self._q_order = [q_names[i] for i in firsts]
-        self._q_ids = set(self._q_order)
+            score, codes = native.take32(score, order) if score.dtype.itemsize == 4 else score[order], native.take32(codes, order)
+        id_codes = id_code if rows is None else native.take32(id_code, rows)
+        # query numbers: order of first appearance in the final row order (base.py:418-421)
+        starts = np.concatenate([[0], np.flatnonzero(codes[1:] != codes[:-1]) + 1]) if len(codes) else np.zeros(0, dtype=np.int64)
+        if len(codes) and np.unique(codes[starts]).shape[0] == starts.shape[0]:
+            firsts = codes[starts]  # rows of a query adjacent: the numbers follow the blocks
+            q_no = np.repeat(np.arange(len(starts), dtype=np.int64), np.diff(np.concatenate([starts, [len(codes)]])))
+        else:
+            q_no, firsts = pd.factorize(codes)
+            q_no = q_no.astype(np.int64, copy=False)
+        q_order = [q_names[i] for i in firsts]
         if queries is not None:
-            keep = self._id_cache
-            self._df = _with_queries(self._df, queries)
-            self._id_cache = keep  # same rows, one more column
+            if any(q not in queries for q in q_order):
+                raise ValueError("Queries are incomplete.")
+            q_texts = [queries[q] for q in q_order]
+        else:
+            q_texts = None if text_of_q is None else [t_names[text_of_q[i]] for i in firsts]
+        self._frame = None
+        self._id_cache = None
+        self._coded = {"q_no": q_no, "q_order": q_order, "id_codes": np.ascontiguousarray(id_codes, dtype=np.int32), "id_names": id_names,
+                       "score": score, "q_texts": q_texts, "id_blob": id_blob}
+        self._q_no, self._q_order = q_no, q_order
+        self._q_ids = set(q_order)
         return True
 
     @classmethod
@@ -608,7 +653,7 @@ class Ranking:
         if self._coded is not None:  # stays coded: only the texts are new
             c = self._coded
             return Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"].copy(), c["id_names"], c["score"].copy(),
-                                           [queries[q] for q in self._q_order])
+                                           [queries[q] for q in self._q_order], c.get("id_blob"))
         # rows, order and pairs are this ranking's own: nothing to re-check, the texts follow the
         # per-row query numbers
         cols = {c: self._df[c].to_numpy().copy() for c in (*_KEY, "score")}
@@ -628,7 +673,7 @@ class Ranking:
                 # nothing to cut (the usual `.cut(k)` on a run of depth k): the same rows; the arrays are shared,
                 # a Ranking never changes them
                 c = self._coded
-                return Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"], c["id_names"], c["score"], c["q_texts"])
+                return Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"], c["id_names"], c["score"], c["q_texts"], c.get("id_blob"))
             keep = np.flatnonzero(np.arange(len(q_no)) - starts[q_no] < cutoff)
             present = np.flatnonzero(np.bincount(q_no[keep], minlength=len(self._q_order)))
             renumber = np.full(len(self._q_order), -1, dtype=np.int64)
@@ -637,7 +682,7 @@ class Ranking:
                 c = self._coded
                 texts = None if c["q_texts"] is None else [c["q_texts"][i] for i in present]
                 return Ranking._assemble_coded(self.name, renumber[q_no[keep]], [self._q_order[i] for i in present], c["id_codes"][keep],
-                                               c["id_names"], c["score"][keep], texts)
+                                               c["id_names"], c["score"][keep], texts, c.get("id_blob"))
             cols = {c: self._df[c].to_numpy()[keep] for c in self._df.columns}
             return Ranking._assemble(cols, self.name, renumber[q_no[keep]], [self._q_order[i] for i in present])
         top = self._df[_ranks_within_query(self._df) <= cutoff]
@@ -743,7 +788,8 @@ class Ranking:
             raise ValueError("Queries are incomplete.")
         texts = None if queries is None else [queries[q] for q in q_order]
         q_no = np.repeat(np.arange(len(by_name), dtype=np.int64), new_counts)
-        return cls._assemble_coded(name, q_no, q_order, native.take32(codes, order), id_names, native.take32(scores, order), texts)
+        blob = (names_blob, n_names) if n_names else None  # (the parser's ids cannot hold a newline)
+        return cls._assemble_coded(name, q_no, q_order, native.take32(codes, order), id_names, native.take32(scores, order), texts, blob)
 
     def _save_native_coded(self, target: Path) -> bool:
         """``save`` of a coded ranking without growing its frame: codes and the name table go to libffx's

@@ -351,7 +351,16 @@ int ffx_ids_get(const ffx_ids* table, int32_t ordinal, const char** str, int32_t
  * depend on the thread count. */
 int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int32_t n_threads, int32_t* codes, char** names_blob,
                      int64_t* names_bytes, int64_t* n_names);
+/* ffx_strings_code for strings lying back to back in `data`, string i = data[offsets[i] .. offsets[i+1]) (the layout of
+ * an Arrow string array: nothing to join, nothing to scan for separators); `sep` only joins *names_blob */
+int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes,
+                             char** names_blob, int64_t* names_bytes, int64_t* n_names);
 int ffx_buffer_free(void* p);
+/* The same numbering for n 8-byte values (the key is the value itself): codes[i] = number of values[i], dense;
+ * first_row[c] = a row that holds number c (first_row must hold n entries at most).  A column of a pandas frame is an
+ * array of pointers to string objects shared by many rows: numbering the pointers leaves only the distinct objects to
+ * be read as strings (the Ranking constructor, ranking.py:95-116, at tens of millions of rows). */
+int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int32_t* codes, int64_t* first_row, int64_t* n_distinct);
 
 /* ffx_run: a TREC run file (q_id Q0 id rank score name) parsed straight into the CSR of
  * ffx_plan_set_pairs, and written back; replaces Ranking.from_file / cut / save
@@ -409,6 +418,10 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
  * -0.0 == +0.0 -- the same order FFX_FLAG_SORT gives on the device (ranking.py:115-117), for scores that were
  * combined on the host (Ranking.interpolate, ranking.py:293-326).  out_order[p]: position in the whole array. */
 int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queries, int32_t n_threads, int32_t* out_order);
+/* the same with the queries' blocks laid out anew: query q's order is written from out_order[dst_off[q]] on (every query
+ * ordered and the queries put into the constructor's "q_id descending" sequence in one pass); dst_off NULL = in place */
+int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries, int32_t n_threads,
+                          int32_t* out_order);
 
 /* out[i] = src[index[i]] for 4-byte elements (float32 scores, int32 id codes), by host threads (n_threads <= 0:
  * every core this process may use): reorders a run's columns by the per-query order of ffx_plan_fetch /

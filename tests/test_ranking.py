@@ -394,6 +394,55 @@ def test_column_array_constructor_equals_the_general_one(monkeypatch, seed):
     assert r._df["score"].dtype == kwargs["dtype"]
 
 
+@pytest.mark.parametrize("variant", ["shuffled rows", "one object per cell", "shared objects", "two texts for one query", "a cell that is no string",
+                                     "a missing id", "float64 scores"])
+def test_coded_constructor_equals_the_general_one_on_awkward_frames(monkeypatch, variant):
+    """The constructor numbers the text columns natively (object pointers first, then the distinct strings) and keeps
+    the result coded.  Whatever the frame looks like -- rows of a query scattered over it, every cell its own string
+    object or all cells of a value sharing one, a query id with two texts, cells that are not strings -- the rows,
+    their order, the numbering and the errors are those of the general pandas route."""
+    rng = np.random.default_rng(11)
+    n_q, k = 40, 90
+    q_names = np.array([f"q{q:02d}" for q in range(n_q)], dtype=object)
+    d_names = np.array([f"doc{d}" for d in range(4000)], dtype=object)
+    q_of = np.repeat(rng.permutation(n_q), k)
+    d_of = np.concatenate([rng.choice(4000, size=k, replace=False) for _ in range(n_q)])
+    score = rng.standard_normal(n_q * k).astype(np.float64 if variant == "float64 scores" else np.float32)
+    score[rng.choice(len(score), 30, replace=False)] = np.nan
+    cols = {"q_id": q_names[q_of], "id": d_names[d_of], "score": score, "query": np.array(["text " + q for q in q_names], dtype=object)[q_of]}
+    if variant == "one object per cell":
+        cols = {c: (np.array([(x + " ")[:-1] for x in v.tolist()], dtype=object) if v.dtype == object else v) for c, v in cols.items()}
+        assert cols["q_id"][0] is not cols["q_id"][1]
+    df = pd.DataFrame(cols)
+    if variant == "shuffled rows":
+        df = df.iloc[rng.permutation(len(df))].reset_index(drop=True)
+    if variant == "two texts for one query":
+        df.loc[5, "query"] = "another text"
+    if variant == "a cell that is no string":
+        df.loc[7, "id"] = 12345
+    if variant == "a missing id":
+        df.loc[9, "id"] = None
+    took = {}
+    real = Ranking._init_from_columns
+    monkeypatch.setattr(Ranking, "_init_from_columns", lambda self, *a: took.setdefault("fast", real(self, *a)))
+    fast = Ranking(df, name="x", dtype=np.dtype(score.dtype))
+    assert took["fast"] == (variant not in ("two texts for one query", "a cell that is no string", "a missing id"))
+    assert (fast._coded is not None) == took["fast"]
+    monkeypatch.setattr(Ranking, "_init_from_columns", lambda self, *a: False)
+    slow = Ranking(df, name="x", dtype=np.dtype(score.dtype))
+    pd.testing.assert_frame_equal(fast._df, slow._df)
+    assert fast._numbering()[1] == slow._numbering()[1] and np.array_equal(fast._numbering()[0], slow._numbering()[0])
+    assert fast.has_queries and fast._query_texts() == slow._query_texts()
+    assert fast == slow and fast.cut(7) == slow.cut(7)
+    monkeypatch.setattr(Ranking, "_init_from_columns", real)
+    dup = pd.concat([df, df.iloc[[100]]], ignore_index=True)
+    if not np.isnan(dup["score"].iloc[-1]) or True:
+        with pytest.raises(ValueError, match="Only one score per query-document/passage pair"):
+            Ranking(dup)
+    with pytest.raises(ValueError, match="Queries are incomplete"):
+        Ranking(df.drop(columns=["query"]), queries={"q00": "only one"})
+
+
 def test_from_file_coded_equals_the_frame_route(tmp_path, monkeypatch):
     """A large run file is read straight into the coded form (ids numbered natively, every query ordered by host
     threads); rows, order, values, query numbering and everything derived from them -- cut, attach_queries, save,
