@@ -415,12 +415,32 @@ static int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* 
     if (!blob) return ffx_fail(FFX_OOM, "host allocation failed");
     next_shard.store(0);
     in_threads([&](int) {
+      try {
       for (;;) {
         const int s = next_shard.fetch_add(1);
         if (s >= S) return;
         const int32_t b = (int32_t)base[(size_t)s];
-        if (b != 0)
-          for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) codes[rows[(size_t)k]] += b;
+        // Inside the shard the strings are numbered by (hash, bytes), not by first appearance: the numbering then
+        // depends on the SET of strings only -- not on the order of the rows, the thread count or (for strings that
+        // were gathered through their object addresses first) the process.  Ranks of a sharded index number the same
+        // ids alike and can talk about them by number.
+        auto& first = firsts[(size_t)s];
+        std::vector<int32_t> by_content(first.size()), renumber(first.size());
+        for (size_t j = 0; j < first.size(); ++j) by_content[j] = (int32_t)j;
+        std::sort(by_content.begin(), by_content.end(), [&](int32_t x, int32_t y) {
+          const uint64_t hx = hash[(size_t)first[(size_t)x]], hy = hash[(size_t)first[(size_t)y]];
+          return hx != hy ? hx < hy : view(first[(size_t)x]) < view(first[(size_t)y]);
+        });
+        for (size_t j = 0; j < first.size(); ++j) renumber[(size_t)by_content[j]] = (int32_t)j;
+        {
+          std::vector<int32_t> sorted(first.size());
+          for (size_t j = 0; j < first.size(); ++j) sorted[j] = first[(size_t)by_content[j]];
+          first.swap(sorted);
+        }
+        for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) {
+          int32_t& c = codes[rows[(size_t)k]];
+          c = renumber[(size_t)c] + b;
+        }
         char* w = blob + at_byte[(size_t)s];
         for (const int32_t i : firsts[(size_t)s]) {
           const std::string_view v = view(i);
@@ -429,7 +449,14 @@ static int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* 
           *w++ = sep;
         }
       }
+      } catch (const std::bad_alloc&) {  // (an exception leaving a thread would end the process)
+        oom.store(true);
+      }
     });
+    if (oom.load()) {
+      free(blob);
+      return ffx_fail(FFX_OOM, "host allocation failed");
+    }
     *names_blob = blob;
     *names_bytes = total - 1;
     *n_names = base[(size_t)S];
@@ -567,8 +594,8 @@ int ffx_ids_intern_packed(ffx_ids* t, const char* data, int64_t n_bytes, char se
 // strings get equal numbers, numbers are dense 0..n_names-1; *names_blob receives the distinct strings in
 // number order joined by `sep` (released with ffx_buffer_free).  Parallel where a table insert per string is
 // serial: offsets and hashes by row ranges, then the rows are dealt into 256 shards by hash and every shard is
-// numbered on its own (open addressing over the shard's rows in row order), so the numbering is deterministic
-// (shard-major, first appearance inside a shard) and independent of the thread count.
+// numbered on its own (open addressing over the shard's rows, then the shard's distinct strings put in (hash, bytes)
+// order), so the numbering depends on the SET of strings only: not on the row order, not on the thread count.
 int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int32_t n_threads, int32_t* codes, char** names_blob,
                      int64_t* names_bytes, int64_t* n_names) {
   if (names_blob) *names_blob = nullptr;

@@ -693,16 +693,19 @@ def code_object_column(col: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, 
         return np.zeros(0, dtype=np.int32), np.empty(0, dtype=object), None
     by_object, first = code_u64(col.ctypes.data, n, threads)
     distinct = col[first]
-    if distinct.shape[0] < 4096:  # few objects: a dict does it
-        table: dict = {}
-        of_object = np.empty(distinct.shape[0], dtype=np.int32)
-        for j, s in enumerate(distinct.tolist()):
-            if type(s) is not str:
+    if distinct.shape[0] < 4096:  # few objects: joined in Python, numbered by the same coder (one numbering rule for any size)
+        items = distinct.tolist()
+        if any(type(s) is not str or "\n" in s or "\0" in s for s in items):
+            if any(type(s) is not str for s in items):
                 return None
-            of_object[j] = table.setdefault(s, len(table))
-        names = np.empty(len(table), dtype=object)
-        names[:] = list(table)
-        blob = "\n".join(table).encode("utf-8")
+            table = {s: j for j, s in enumerate(sorted(set(items)))}  # (a newline in an id: no joined buffer; numbered in sorted order)
+            of_object = np.fromiter((table[s] for s in items), dtype=np.int32, count=len(items))
+            names = np.empty(len(table), dtype=object)
+            names[:] = list(table)
+            return take32(of_object, by_object), names, None
+        of_object, blob, n_names = code_strings("\n".join(items).encode("utf-8"), len(items), threads)
+        names = np.empty(n_names, dtype=object)
+        names[of_object] = distinct
     else:
         got = _code_distinct_objects(distinct, threads)
         if got is None:

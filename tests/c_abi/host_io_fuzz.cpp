@@ -232,8 +232,64 @@ int main(int argc, char** argv) {
       if (got_n > 0 && (int64_t)distinct.size() != got_n) return 1;
       for (int64_t i = 0; i < n; ++i)
         if (code[(size_t)i] < 0 || code[(size_t)i] >= got_n || distinct[(size_t)code[(size_t)i]] != items[(size_t)i]) return 1;
+      // the same strings back to back with their offsets, in ANOTHER row order: the numbering depends on the set of
+      // strings only, so string for string the numbers must agree with the joined-buffer call above
+      {
+        std::vector<int64_t> order((size_t)n), offs((size_t)n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+        for (int64_t i = n - 1; i > 0; --i) std::swap(order[(size_t)i], order[(size_t)(rnd() % (uint64_t)(i + 1))]);
+        std::string packed;
+        for (int64_t i = 0; i < n; ++i) {
+          packed += items[(size_t)order[(size_t)i]];
+          offs[(size_t)i + 1] = (int64_t)packed.size();
+        }
+        std::vector<int32_t> code2((size_t)n);
+        char* got2 = nullptr;
+        int64_t bytes2 = 0, n2 = 0;
+        if (ffx_strings_code_offsets(packed.data(), offs.data(), n, '\n', 1 + (int)(rnd() % 5), code2.data(), &got2, &bytes2, &n2) != FFX_OK) return 1;
+        if (n2 != got_n || bytes2 != got_bytes || (got_bytes > 0 && memcmp(got, got2, (size_t)got_bytes) != 0)) return 1;
+        for (int64_t i = 0; i < n; ++i)
+          if (code2[(size_t)i] != code[(size_t)order[(size_t)i]]) return 1;
+        ffx_buffer_free(got2);
+        offs[(size_t)(n / 2) + 1] = offs[(size_t)(n / 2)] - 1;  // not monotone: refused
+        if (n > 2 && offs[(size_t)(n / 2)] > 0 && ffx_strings_code_offsets(packed.data(), offs.data(), n, '\n', 2, code2.data(), &got2, &bytes2, &n2) == FFX_OK) return 1;
+      }
       ffx_buffer_free(got);
       if (ffx_strings_code(blob.data(), (int64_t)blob.size(), '\n', n + 1, threads, code.data(), &got, &got_bytes, &got_n) == FFX_OK) return 1;  // wrong count
+      // numbering 8-byte values (object addresses of a frame's column): equal values share a number, first_row names a holder
+      {
+        std::vector<uint64_t> vals((size_t)n);
+        for (auto& v : vals) v = 0x7f0000000000ull + 48 * (rnd() % (uint64_t)(1 + n / 4));
+        std::vector<int32_t> vc((size_t)n);
+        std::vector<int64_t> first((size_t)n);
+        int64_t nd = 0;
+        if (ffx_host_code_u64(vals.data(), n, 1 + (int)(rnd() % 5), vc.data(), first.data(), &nd) != FFX_OK || nd < 1 || nd > n) return 1;
+        for (int64_t i = 0; i < n; ++i)
+          if (vc[(size_t)i] < 0 || vc[(size_t)i] >= nd || vals[(size_t)first[(size_t)vc[(size_t)i]]] != vals[(size_t)i]) return 1;
+        for (int64_t c = 0; c < nd; ++c)
+          if (vc[(size_t)first[(size_t)c]] != c) return 1;
+      }
+      // every query ordered and the queries' blocks laid out in reverse in one pass
+      {
+        const int64_t nq = 1 + (int64_t)(rnd() % 7);
+        std::vector<int64_t> off((size_t)nq + 1, 0), dst((size_t)nq);
+        for (int64_t q = 0; q < nq; ++q) off[(size_t)q + 1] = off[(size_t)q] + (q + 1 == nq ? n - off[(size_t)q] : (int64_t)(rnd() % (uint64_t)(1 + (n - off[(size_t)q]) / 2)));
+        int64_t at = 0;
+        for (int64_t q = nq - 1; q >= 0; --q) {
+          dst[(size_t)q] = at;
+          at += off[(size_t)q + 1] - off[(size_t)q];
+        }
+        std::vector<float> sc((size_t)n);
+        for (auto& v : sc) v = (float)(rnd() % 50) * 0.5f;
+        std::vector<int32_t> plain((size_t)n), moved((size_t)n);
+        if (ffx_host_order(sc.data(), off.data(), nq, 1 + (int)(rnd() % 4), plain.data()) != FFX_OK) return 1;
+        if (ffx_host_order_blocks(sc.data(), off.data(), dst.data(), nq, 1 + (int)(rnd() % 4), moved.data()) != FFX_OK) return 1;
+        for (int64_t q = 0; q < nq; ++q)
+          for (int64_t i = 0; i < off[(size_t)q + 1] - off[(size_t)q]; ++i)
+            if (moved[(size_t)(dst[(size_t)q] + i)] != plain[(size_t)(off[(size_t)q] + i)]) return 1;
+        dst[0] = n;  // outside the output: refused
+        if (off[1] > 0 && ffx_host_order_blocks(sc.data(), off.data(), dst.data(), nq, 2, moved.data()) == FFX_OK) return 1;
+      }
       // gathers and the join-free interpolate on the same sizes
       std::vector<float> src((size_t)n), dense((size_t)n), res((size_t)n);
       std::vector<int32_t> perm((size_t)n);

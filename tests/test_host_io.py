@@ -382,3 +382,31 @@ def test_native_unique_rows_equals_numpy_unique():
     with pytest.raises(native.FFXError, match="outside the index"):
         native.unique_rows(np.array([5, -1], dtype=np.int64), 10)
     assert native.unique_rows(np.zeros(0, dtype=np.int64), 10)[0].shape == (0,)
+
+
+@pytest.mark.parametrize("n_values", [50, 20000])
+def test_object_column_numbering_depends_on_the_strings_only(n_values):
+    """``native.code_object_column`` numbers a frame column through its object POINTERS first and the distinct strings
+    second.  Whatever the objects' addresses and the row order, the name table comes out the same (ranks of a sharded
+    index number the same ids alike), ``names[codes]`` gives the column back, and the joined name buffer matches."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(3)
+    values = np.array([f"doc-{i * 7919 % 100003}" for i in range(n_values)] + ["", "ünï"], dtype=object)
+    col = values[rng.integers(0, len(values), size=60000)]
+    codes, names, packed = native.code_object_column(col)
+    assert codes.dtype == np.int32 and np.array_equal(names[codes], col)
+    assert len(set(names.tolist())) == len(names) == len(set(col.tolist()))
+    assert packed is not None and packed[1] == len(names) and packed[0].decode("utf-8").split("\n") == names.tolist()
+    # fresh objects for every cell, rows shuffled: the same table
+    own = np.array([(s + " ")[:-1] for s in col[rng.permutation(len(col))].tolist()], dtype=object)
+    codes2, names2, packed2 = native.code_object_column(own)
+    assert names2.tolist() == names.tolist() and packed2 == packed and np.array_equal(names2[codes2], own)
+    # a cell that is no string: not this function's business
+    bad = col.copy()
+    bad[17] = 3.5
+    assert native.code_object_column(bad) is None
+    # a name holding the separator cannot be handed on as a joined buffer
+    odd = col.copy()
+    odd[5] = "two\nlines"
+    assert native.code_object_column(odd)[2] is None
