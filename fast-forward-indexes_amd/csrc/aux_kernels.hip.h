@@ -230,6 +230,23 @@ reduce_kernel(const float* __restrict__ rs, const int32_t* __restrict__ seg_off,
   if (sparse != nullptr) interp[p] = interp_one(a, b, sparse[p], out);
 }
 
+// Row sum of a long row from the sums of its segments (gather_dot_exact_anyd_kernel, one launch per segment):
+// part[g * n_rows + r] is segment g of row r; the steps "sum[a] += sum[b]" replay NumPy's recursion above the
+// segments (the total ends in segment 0).  One thread per row, its partial sums in its own column of LDS.
+__global__ void __launch_bounds__(256)
+combine_tree_kernel(const float* __restrict__ part, int n_rows, int n_segments, const int* __restrict__ steps, int n_steps,
+                    float* __restrict__ out) {
+  extern __shared__ float seg_sum[];  // [n_segments][256]
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  for (int g = 0; g < n_segments; ++g) seg_sum[g * 256 + threadIdx.x] = part[(size_t)g * n_rows + r];
+  for (int t = 0; t < n_steps; ++t) {
+    const int a = steps[2 * t], b = steps[2 * t + 1];
+    seg_sum[a * 256 + threadIdx.x] = __fadd_rn(seg_sum[a * 256 + threadIdx.x], seg_sum[b * 256 + threadIdx.x]);
+  }
+  out[r] = seg_sum[threadIdx.x];
+}
+
 // ---- early stopping (index/base.py:316-387) on the device ---------------------------------------------
 // State: active[q] (the query is still being scored), full-length ff / interp (NaN = not scored).
 // Candidates of a query stand in first-stage rank order, so "ranks a..b-1" is a slice of its list.

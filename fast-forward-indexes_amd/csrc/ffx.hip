@@ -125,6 +125,26 @@ void numpy_leaf_plan(int start, int n, std::vector<int>& bounds) {
 
 // The order in which NumPy's recursion adds the leaf sums, as a list of (a, b) steps
 // "sum[a] += sum[b]" over the in-order leaf indices; the total ends up in sum[0].
+// A long row cut into segments of at most 8 leaves each: NumPy's recursion is followed from the top until a piece
+// has <= 8 leaves (its sub-tree then is what gather_dot_exact_anyd_kernel sums); `steps` replays the recursion above
+// the pieces ("sum[a] += sum[b]" over segment numbers, the total ending in segment 0).  Returns the number of the
+// segment that holds the sum of [start, start + n).
+int long_row_plan(int start, int n, std::vector<std::pair<int, int>>& pieces, std::vector<int>& steps) {
+  std::vector<int> bounds;
+  numpy_leaf_plan(0, n, bounds);
+  if (bounds.size() <= 8) {
+    pieces.emplace_back(start, n);
+    return (int)pieces.size() - 1;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const int a = long_row_plan(start, n2, pieces, steps);
+  const int b = long_row_plan(start + n2, n - n2, pieces, steps);
+  steps.push_back(a);
+  steps.push_back(b);
+  return a;
+}
+
 int numpy_combine_plan(int n, int& next_leaf, std::vector<int>& steps) {
   if (n <= 128) return next_leaf++;
   int n2 = n / 2;
@@ -201,6 +221,15 @@ struct ffx_plan {
   bool have_sparse = false, have_pairs = false, ran = false, ran_sort = false;
   int n_leaves = 0;
   bool anyd_ok = false, anyd_tails = false;  // every leaf has 8..128 elements; some leaf has len % 8 != 0
+  // a row of more than 8 leaves, cut along NumPy's recursion into segments of at most 8 leaves each (long_row_plan):
+  // per segment where it starts, how long it is, and where its leaf table / combine steps lie in seg_tables
+  struct Segment {
+    int col0, len, n_leaves, table_at, steps_at;
+    bool tails;
+  };
+  std::vector<Segment> segments;
+  DevBuf seg_tables;   // int: per segment its leaf bounds (n_leaves + 1, relative to the segment) then its combine steps
+  int seg_steps_at = 0, seg_n_steps = 0;  // the steps that add the segment sums (in seg_tables)
   bool last_interp = false;
   int32_t variant = 0;
   int32_t order_base = 0;  // added to the positions the per-query order is made of (slices of a larger batch)
@@ -673,6 +702,47 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
     if (rc == FFX_OK && hipMemcpy(pl->combine_steps.p, steps.data(), steps.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
       rc = fail(FFX_HIP_ERROR, "combine plan upload failed");
   }
+  if (rc == FFX_OK && pl->n_leaves > 8 && idx->dtype != FFX_DTYPE_PQ8) {
+    // more than 8 leaves: segments of <= 8 leaves, each with its own leaf table and combine steps
+    std::vector<std::pair<int, int>> pieces;
+    std::vector<int> above, tables;
+    long_row_plan(0, idx->qdim, pieces, above);
+    bool ok = pieces.size() <= 64;
+    for (const auto& [col0, len] : pieces) {
+      ffx_plan::Segment sg{};
+      sg.col0 = col0;
+      sg.len = len;
+      std::vector<int> b;
+      numpy_leaf_plan(0, len, b);
+      b.push_back(len);
+      sg.n_leaves = (int)b.size() - 1;
+      for (size_t l = 0; l + 1 < b.size(); ++l) {
+        const int ll = b[l + 1] - b[l];
+        ok = ok && ll >= 8 && ll <= 128;
+        sg.tails = sg.tails || (ll % 8) != 0;
+      }
+      sg.table_at = (int)tables.size();
+      tables.insert(tables.end(), b.begin(), b.end());
+      std::vector<int> st;
+      int next = 0;
+      numpy_combine_plan(len, next, st);
+      st.push_back(0);
+      sg.steps_at = (int)tables.size();
+      tables.insert(tables.end(), st.begin(), st.end());
+      pl->segments.push_back(sg);
+    }
+    pl->seg_steps_at = (int)tables.size();
+    pl->seg_n_steps = (int)above.size() / 2;
+    tables.insert(tables.end(), above.begin(), above.end());
+    tables.push_back(0);
+    if (!ok) {
+      pl->segments.clear();  // (rows beyond ~64 K elements: the staged generic kernel)
+    } else {
+      rc = pl->seg_tables.ensure(tables.size() * sizeof(int));
+      if (rc == FFX_OK && hipMemcpy(pl->seg_tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(FFX_HIP_ERROR, "segment plan upload failed");
+    }
+  }
   if (rc == FFX_OK) rc = pl->flags.ensure(64);
   if (rc != FFX_OK) {
     ffx_plan_destroy(pl);
@@ -693,7 +763,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
   }
   for (DevBuf* b : {&pl->es_active, &pl->es_cnt, &pl->es_pos, &pl->es_scan_tmp, &pl->small_flag}) b->release();
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
-                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps,
+                    &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps, &pl->seg_tables,
                     &pl->flags, &pl->ff, &pl->interp, &pl->order})
     b->release();
   for (auto& e : pl->ev)
@@ -1115,35 +1185,63 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         if (pl->n_leaves > 8192) return fail(FFX_BAD_ARG, "dim %d too large for the exact kernel", d);
         // any other row length with at most 8 leaves (8 <= d <= 1024): the strided form with a run-time leaf
         // table -- every lane loads what it sums, nothing is staged or combined serially
+        // the any-d kernel on one segment of the row: SEG_LEN elements from column COL0 on, leaf table LS (relative to the
+        // segment), NL leaves, combine steps CS, row sums to OUT
+#define FFX_ANYD(LG, U, TAILS_, COL0, LS, NL, CS, OUT)                                                                        \
+  do {                                                                                                                        \
+    constexpr int TILE_ = ffx::exact_default_passes(LG) * (64 / (8 * LG));                                                    \
+    if (TAILS_)                                                                                                               \
+      ffx::gather_dot_exact_anyd_kernel<T, LG, U, true><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, OUT, R, d, COL0, LS, NL, CS);  \
+    else                                                                                                                      \
+      ffx::gather_dot_exact_anyd_kernel<T, LG, U, false><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, OUT, R, d, COL0, LS, NL, CS); \
+  } while (0)
+#define FFX_ANYD_LG(LG, U_SEL, TAILS_, COL0, LS, NL, CS, OUT)            \
+  do {                                                                   \
+    if (U_SEL == 2) FFX_ANYD(LG, 2, TAILS_, COL0, LS, NL, CS, OUT);      \
+    else if (U_SEL == 8) FFX_ANYD(LG, 8, TAILS_, COL0, LS, NL, CS, OUT); \
+    else FFX_ANYD(LG, 4, TAILS_, COL0, LS, NL, CS, OUT);                 \
+  } while (0)
+#define FFX_ANYD_ANY(U_SEL, TAILS_, COL0, LS, NL, CS, OUT)                     \
+  do {                                                                         \
+    if (NL == 1) FFX_ANYD_LG(1, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);         \
+    else if (NL == 2) FFX_ANYD_LG(2, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);    \
+    else if (NL <= 4) FFX_ANYD_LG(4, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);    \
+    else FFX_ANYD_LG(8, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);                 \
+  } while (0)
+        const char* u_env = getenv("FFX_ANYD_U");  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
         if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !getenv("FFX_GENERIC_STAGED")) {
           const int* LS = pl->leaf_start.as<int>();
           const int* CS = pl->combine_steps.as<int>();
           const int nl = pl->n_leaves;
-#define FFX_ANYD(LG, U)                                                                                                       \
-  do {                                                                                                                        \
-    constexpr int TILE_ = ffx::exact_default_passes(LG) * (64 / (8 * LG));                                                    \
-    if (pl->anyd_tails)                                                                                                       \
-      ffx::gather_dot_exact_anyd_kernel<T, LG, U, true><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R, d, LS, nl, CS);  \
-    else                                                                                                                      \
-      ffx::gather_dot_exact_anyd_kernel<T, LG, U, false><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R, d, LS, nl, CS); \
-  } while (0)
-          const char* u_env = getenv("FFX_ANYD_U");  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
           // measured (profiles/r02/anyd_kernel_dims.json): 2 passes in flight win for 3 .. 7 leaves (d = 300: 5.09 vs
           // 4.59 TB/s, d = 520: 5.61 vs 5.20), 4 for one or two leaves and for long rows (d = 1000: 5.85 vs 5.65)
           const int u_sel = u_env ? atoi(u_env) : ((nl >= 3 && d < 768) ? 2 : 4);
-#define FFX_ANYD_LG(LG)                    \
-  do {                                     \
-    if (u_sel == 2) FFX_ANYD(LG, 2);       \
-    else if (u_sel == 8) FFX_ANYD(LG, 8);  \
-    else FFX_ANYD(LG, 4);                  \
-  } while (0)
-          if (nl == 1) FFX_ANYD_LG(1);
-          else if (nl == 2) FFX_ANYD_LG(2);
-          else if (nl <= 4) FFX_ANYD_LG(4);
-          else FFX_ANYD_LG(8);
-#undef FFX_ANYD_LG
-#undef FFX_ANYD
+          FFX_ANYD_ANY(u_sel, pl->anyd_tails, 0, LS, nl, CS, rs);
           pl->variant = 130 + nl + HALF;
+          break;
+        }
+        // more than 8 leaves (d > 1024 that is not S x a specialised length: 1100, 1280, 2000, 5000 ...): the row is
+        // cut along NumPy's recursion into segments of <= 8 leaves (ffx_plan_create), every segment is summed by the
+        // any-d kernel (one launch per segment over all rows: a segment is >= 2 KB of consecutive bytes of a row),
+        // and combine_tree_kernel adds the segment sums in the order of the recursion.  Bit-identical to NumPy; the
+        // staged generic kernel it replaces walked every row out of LDS with one wave (1 - 3.5 TB/s).
+        if (!pl->ov_dim && !pl->segments.empty() && !getenv("FFX_GENERIC_STAGED")) {
+          const int G = (int)pl->segments.size();
+          FFX_TRY(pl->rs_v.ensure((size_t)G * (size_t)R * sizeof(float)));
+          const int* tab = pl->seg_tables.as<int>();
+          for (int g = 0; g < G; ++g) {
+            const ffx_plan::Segment& sg = pl->segments[(size_t)g];
+            const int* LS = tab + sg.table_at;
+            const int* CS = tab + sg.steps_at;
+            const int nl = sg.n_leaves;
+            const int u_sel = u_env ? atoi(u_env) : ((nl >= 3 && sg.len < 768) ? 2 : 4);
+            float* out = pl->rs_v.as<float>() + (size_t)g * R;
+            FFX_ANYD_ANY(u_sel, sg.tails, sg.col0, LS, nl, CS, out);
+            FFX_HIP(hipGetLastError());
+          }
+          ffx::combine_tree_kernel<<<blocks_for(R, 256), 256, (size_t)G * 256 * sizeof(float), st>>>(pl->rs_v.as<float>(), R, G, tab + pl->seg_steps_at,
+                                                                                                 pl->seg_n_steps, rs);
+          pl->variant = 140 + HALF + 10000 * G;  // e.g. 20140: two segments through the any-d kernel
           break;
         }
         // any other row length: the row is staged in LDS (coalesced, independent loads) and the
@@ -1184,6 +1282,9 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         }
     }
   }
+#undef FFX_ANYD_ANY
+#undef FFX_ANYD_LG
+#undef FFX_ANYD
 #undef FFX_EXACT
   FFX_HIP(hipGetLastError());
   return FFX_OK;

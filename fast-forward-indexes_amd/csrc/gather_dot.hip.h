@@ -467,8 +467,11 @@ gather_dot_fast_generic_kernel(const T* __restrict__ vectors, const float* __res
 template <typename T, int LG, int U, bool TAILS>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_anyd_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
-                             const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int d,
+                             const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, int stride, int col0,
                              const int* __restrict__ leaf_start, int n_leaves, const int* __restrict__ combine_steps) {
+  // stride: elements from one row (and one query vector) to the next; col0: first element of the SEGMENT of the row this
+  // launch sums (0 and the whole row for d <= 1024; a longer row is cut along NumPy's recursion into segments of at
+  // most 8 leaves each, one launch per segment: ffx.hip, long_row_plan)
   constexpr int LPR = 8 * LG;
   constexpr int RPW = 64 / LPR;
   constexpr int PASSES = exact_default_passes(LG);
@@ -512,7 +515,7 @@ gather_dot_exact_anyd_kernel(const T* __restrict__ vectors, const float* __restr
       t = t < n_here ? t : n_here - 1;
       const int rid = __shfl(my.x, t, 64);
       qn[u] = __shfl(my.y, t, 64);
-      const T* rowp = vectors + (size_t)rid * d;
+      const T* rowp = vectors + (size_t)rid * stride + col0;
 #pragma unroll
       for (int i = 0; i < NMAX; ++i) v[u][i] = i < cnt ? load1<T, false>(rowp + lane_off + 8 * i) : 0.f;
       if constexpr (TAILS) tv[u] = j < tail ? load1<T, false>(rowp + tail_off) : 0.f;
@@ -522,7 +525,7 @@ gather_dot_exact_anyd_kernel(const T* __restrict__ vectors, const float* __restr
       const int q0 = __builtin_amdgcn_readfirstlane(qn[u]);
       const bool one_query = __all(qn[u] == q0);  // wave-uniform
       if (!one_query || q0 != cur_q) {
-        const float* qp = queries + (size_t)qn[u] * d;  // L2-resident
+        const float* qp = queries + (size_t)qn[u] * stride + col0;  // L2-resident
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) q[i] = i < cnt ? qp[lane_off + 8 * i] : 0.f;
         if constexpr (TAILS) tq = j < tail ? qp[tail_off] : 0.f;

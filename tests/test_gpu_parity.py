@@ -460,8 +460,51 @@ def test_any_row_length_up_to_eight_leaves_is_bit_exact(store):
         shape = leaves(d)
         if len(shape) <= 8 and min(shape) >= 8:
             assert variant == 130 + len(shape), (d, variant, shape)
-        else:
+        elif d < 8:
             assert variant == 198, (d, variant, shape)  # the staged generic kernel
+        else:  # more than 8 leaves: segments of <= 8 leaves through the same kernel (next test)
+            assert st["kernel_variant"] % 1000 == 140 and 2 <= st["kernel_variant"] // 10000 <= 64, (d, st["kernel_variant"])
+        idx.close()
+
+
+@pytest.mark.parametrize("store", [np.float32, np.float16])
+def test_long_rows_of_any_length_are_bit_exact_through_segments(store):
+    """Rows of more than 8 NumPy leaves that are not S x a specialised length (d = 1100, 1280, 2000, 5000 ...): cut along
+    NumPy's pairwise recursion into segments of at most 8 leaves each -- unbalanced cuts included (1100 -> 544 | 556) --,
+    every segment summed by the any-d kernel, the segment sums added in the order of the recursion.  Bit for bit
+    against NumPy itself for 26 lengths in (1024, 8192]; the staged generic kernel no longer runs for them."""
+    rng = np.random.default_rng(123)
+    dims = [1025, 1032, 1100, 1280, 1281, 1500, 1537, 1999, 2000, 2047, 2049, 2500, 2560, 3000, 3073, 3500, 4000, 4100, 4097, 5000, 5555,
+            6000, 7000, 7777, 8000, 8191]
+
+    def leaves(n):
+        if n <= 128:
+            return [n]
+        n2 = n // 2 - (n // 2) % 8
+        return leaves(n2) + leaves(n - n2)
+
+    def pieces(n):  # the segments: follow the recursion until a piece has <= 8 leaves
+        if len(leaves(n)) <= 8:
+            return [n]
+        n2 = n // 2 - (n // 2) % 8
+        return pieces(n2) + pieces(n - n2)
+
+    for d in dims:
+        n, nq, k = 70, 3, 60
+        vectors = (rng.standard_normal((n, d)) * 1.5).astype(store)
+        queries = rng.standard_normal((nq, d)).astype(np.float32)
+        idx = native.DeviceIndex(n, d, dtype=store)
+        idx.upload(vectors, 0)
+        idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+        idx.set_psg_rows(np.arange(n))
+        pair_off = np.array([0, 1, k + 1, 2 * k + 1 - 7], dtype=np.int64)
+        pair_ids = rng.integers(0, n, size=int(pair_off[-1])).astype(np.int32)
+        ff, _, _, st = native.score(idx, queries, pair_off, pair_ids, 1, exact_sum=True)
+        ref = np.sum(queries[np.repeat(np.arange(nq), np.diff(pair_off))] * vectors[pair_ids].astype(np.float32), axis=1)
+        assert ref.dtype == np.float32
+        assert np.array_equal(bits(ff), bits(ref)), f"d={d} variant {st['kernel_variant']}"
+        assert st["kernel_variant"] % 1000 == 140 and st["kernel_variant"] // 10000 == len(pieces(d)), (d, st["kernel_variant"], pieces(d))
+        assert (st["kernel_variant"] % 10000 >= 1000) == (store == np.float16)
         idx.close()
 
 
