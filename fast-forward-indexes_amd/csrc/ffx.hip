@@ -22,6 +22,7 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <atomic>
+#include <memory>
 #include <new>
 #include <string>
 #include <system_error>
@@ -187,6 +188,8 @@ struct ffx_index {
   void* stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};  // a copy out of the block may still be in flight (ffx_index_upload_rows_async)
+  int64_t pending_row = 0, pending_rows = 0;  // rows whose codes ffx_index_upload_wait still has to check (PQ rows)
   hipStream_t copy_stream = nullptr;
   // ffx_score with page-locked result buffers: results leave on this stream (highest priority, so that the
   // copy of slice c is not queued behind the scoring kernels of slice c+1), one event per plan
@@ -475,6 +478,15 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
 // device (the streaming half of OnDiskIndex: disk.py:100-121 reads the same chunk maps).
 int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
                           const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads) {
+  FFX_TRY(ffx_index_upload_rows_async(idx, chunks, n_chunks, chunk_rows, rows, n_rows, dst_row, n_threads));
+  return ffx_index_upload_wait(idx);
+}
+
+// The same without waiting for the last blocks to land: returns once every row has been gathered and its copy queued,
+// so that the caller's next gather (another index's rows, e.g. the next window of a streamed index) overlaps the tail
+// of this one's copies.  ffx_index_upload_wait(idx) before the rows are used.
+int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
+                                const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads) {
   if (!idx || n_rows < 0 || dst_row < 0 || n_chunks < 0 || chunk_rows <= 0) return fail(FFX_BAD_ARG, "bad argument");
   if (n_rows == 0) return FFX_OK;
   if (!chunks || !rows) return fail(FFX_BAD_ARG, "NULL argument");
@@ -509,35 +521,85 @@ int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_c
     if (!idx->stage_ev[i]) FFX_HIP(hipEventCreateWithFlags(&idx->stage_ev[i], hipEventDisableTiming));
   const int64_t per = (int64_t)(idx->stage_bytes / rb);
   const int T = std::max(1, std::min<int>(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency() / 2, 64));
-  bool used[2] = {false, false};
-  int k = 0;
-  for (int64_t b0 = 0; b0 < n_rows; b0 += per, ++k) {
-    const int s = k & 1;
-    if (used[s]) FFX_HIP(hipEventSynchronize(idx->stage_ev[s]));
-    const int64_t nb = std::min(per, n_rows - b0);
-    char* dst = static_cast<char*>(idx->stage[s]);
-    auto work = [&](int64_t lo, int64_t hi) {
-      for (int64_t i = lo; i < hi; ++i) {
-        const int64_t r = rows[b0 + i];
-        memcpy(dst + (size_t)i * rb, static_cast<const char*>(chunks[r / chunk_rows]) + (size_t)(r % chunk_rows) * rb, rb);
-      }
-    };
-    const int t_use = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)(nb * rb) >> 20));  // >= 1 MiB per thread
-    if (t_use <= 1) {
-      work(0, nb);
-    } else {
-      std::vector<std::thread> pool;
-      pool.reserve(t_use - 1);
-      for (int t = 1; t < t_use; ++t) pool.emplace_back(work, nb * t / t_use, nb * (t + 1) / t_use);
-      work(0, nb / t_use);
-      for (auto& th : pool) th.join();
+  if (idx->pending_rows > 0) FFX_TRY(ffx_index_upload_wait(idx));  // (an earlier asynchronous upload nobody waited for)
+  // Helper threads live for the whole call (starting a set of threads per 64 MiB block cost about as much as copying the
+  // block): block k is gathered by all of them, slice by slice, once the main thread has seen the copy out of its
+  // staging block finish (go >= k); the main thread takes slice 0, queues the block's copy when every slice is in
+  // (done[k]) and moves on, so the gather of block k + 1 overlaps the copy of block k.
+  const int64_t n_blocks = (n_rows + per - 1) / per;
+  const int t_use = (int)std::min<int64_t>(T, std::max<int64_t>(1, (int64_t)(std::min(per, n_rows) * (int64_t)rb) >> 20));  // >= 1 MiB per thread and block
+  std::atomic<int64_t> go(-1);
+  std::atomic<bool> give_up(false);
+  std::unique_ptr<std::atomic<int>[]> done(new (std::nothrow) std::atomic<int>[(size_t)n_blocks]);
+  if (!done) return fail(FFX_OOM, "host allocation failed");
+  for (int64_t k = 0; k < n_blocks; ++k) done[(size_t)k].store(0);
+  auto gather = [&](int64_t k, int t) {
+    const int64_t b0 = k * per, nb = std::min(per, n_rows - b0);
+    char* dst = static_cast<char*>(idx->stage[k & 1]);
+    for (int64_t i = nb * t / t_use; i < nb * (t + 1) / t_use; ++i) {
+      const int64_t r = rows[b0 + i];
+      memcpy(dst + (size_t)i * rb, static_cast<const char*>(chunks[r / chunk_rows]) + (size_t)(r % chunk_rows) * rb, rb);
     }
-    FFX_HIP(hipMemcpyAsync(idx->row_ptr(dst_row + b0), dst, (size_t)nb * rb, hipMemcpyHostToDevice, idx->copy_stream));
-    FFX_HIP(hipEventRecord(idx->stage_ev[s], idx->copy_stream));
-    used[s] = true;
+  };
+  auto helper = [&](int t) {
+    for (int64_t k = 0; k < n_blocks; ++k) {
+      for (unsigned spin = 0; go.load(std::memory_order_acquire) < k; ++spin) {
+        if (give_up.load()) return;
+        // (waiting for a staging block's copy to finish: up to a millisecond -- sleep, a dozen spinning threads
+        // would eat the CPU quota the gather itself needs)
+        if (spin > 256) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+      if (give_up.load()) return;
+      gather(k, t);
+      done[(size_t)k].fetch_add(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)std::max(0, t_use - 1));
+  try {
+    for (int t = 1; t < t_use; ++t) pool.emplace_back(helper, t);
+  } catch (const std::system_error&) {
+    // fewer helpers than hoped for: the main thread takes the slices nobody was started for
   }
+  const int helpers = (int)pool.size();
+  int rc = FFX_OK;
+  for (int64_t k = 0; k < n_blocks && rc == FFX_OK; ++k) {
+    const int s = (int)(k & 1);
+    if (idx->stage_busy[s]) {
+      if (hipEventSynchronize(idx->stage_ev[s]) != hipSuccess) rc = fail(FFX_HIP_ERROR, "waiting for a staging block failed");
+      idx->stage_busy[s] = false;
+      if (rc != FFX_OK) break;
+    }
+    go.store(k, std::memory_order_release);
+    gather(k, 0);
+    for (int t = helpers + 1; t < t_use; ++t) gather(k, t);
+    for (unsigned spin = 0; done[(size_t)k].load(std::memory_order_acquire) < helpers; ++spin)
+      if (spin > 256) std::this_thread::sleep_for(std::chrono::microseconds(5));
+    const int64_t b0 = k * per, nb = std::min(per, n_rows - b0);
+    if (hipMemcpyAsync(idx->row_ptr(dst_row + b0), idx->stage[s], (size_t)nb * rb, hipMemcpyHostToDevice, idx->copy_stream) != hipSuccess ||
+        hipEventRecord(idx->stage_ev[s], idx->copy_stream) != hipSuccess)
+      rc = fail(FFX_HIP_ERROR, "copy of a staged block to the device failed: %s", hipGetErrorString(hipGetLastError()));
+    else
+      idx->stage_busy[s] = true;
+  }
+  give_up.store(true);
+  go.store(n_blocks, std::memory_order_release);
+  for (auto& th : pool) th.join();
+  if (rc != FFX_OK) return rc;
+  idx->pending_row = dst_row;
+  idx->pending_rows = n_rows;
+  return FFX_OK;
+}
+
+int ffx_index_upload_wait(ffx_index* idx) {
+  if (!idx) return fail(FFX_BAD_ARG, "NULL argument");
+  if (!idx->copy_stream) return FFX_OK;
+  FFX_HIP(hipSetDevice(idx->device));
   FFX_HIP(hipStreamSynchronize(idx->copy_stream));
-  return check_pq_codes(idx, dst_row, n_rows);
+  idx->stage_busy[0] = idx->stage_busy[1] = false;
+  const int64_t row = idx->pending_row, n = idx->pending_rows;
+  idx->pending_rows = 0;
+  return n > 0 ? check_pq_codes(idx, row, n) : FFX_OK;
 }
 
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows) {

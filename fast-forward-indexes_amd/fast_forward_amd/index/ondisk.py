@@ -52,7 +52,11 @@ LOGGER = logging.getLogger(__name__)
 _MAGIC = b"FFXD0001"
 _HEADER_BYTES = 1 << 20
 _FORMAT_VERSION = 1
-_READ_THREADS = max(1, min(16, (os.cpu_count() or 2) // 2))
+# gather threads of a streamed window: by default three quarters of what this process may use (cgroup quota included --
+# busy threads beyond the quota get the whole group throttled, and the scoring thread and the copy engine's driver
+# thread need their share: on a 16-core quota 12 threads gather at 53 GB/s, 16 at 45, 8 at 42: profiles/r03/
+# ondisk_stream_threads.json); FFX_READ_THREADS overrides
+_READ_THREADS = int(os.environ.get("FFX_READ_THREADS", "0")) or max(1, min(24, native.usable_cores() * 3 // 4))
 
 
 class OnDiskIndex(Index):
@@ -385,18 +389,34 @@ class OnDiskIndex(Index):
         (row numbers [R], query of each row [R], segment offsets [P+1])."""
         n_pairs = int(pair_off[-1])
         pair_q = np.repeat(np.arange(pair_off.shape[0] - 1, dtype=np.int64), np.diff(pair_off))
-        ids = pair_ids.astype(np.int64)
+        # the id tables as int64 arrays, made once per state of the index (a copy of a table of millions of rows per
+        # call cost more than the candidates' own look-ups)
+        cache = getattr(self, "_expand_tables", None)
+        if cache is None or cache[0] != self._ids.version:
+            doc_off, doc_rows = self._ids.doc_csr()
+            doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+            doc_rows, psg_rows = np.ascontiguousarray(doc_rows, dtype=np.int64), np.ascontiguousarray(self._ids.psg_rows(), dtype=np.int64)
+            small = len(self) < 2**31 - 1  # 4-byte copies for the threaded gathers (FirstP, PASSAGE, one row per document)
+            tables32 = (doc_off[:-1].astype(np.int32), doc_rows.astype(np.int32), psg_rows.astype(np.int32)) if small else None
+            cache = (self._ids.version, doc_off, doc_rows, psg_rows, bool(doc_off.shape[0] > 1 and (np.diff(doc_off) == 1).all()), tables32)
+            self._expand_tables = cache
+        _, doc_off, doc_rows, psg_rows, one_row_each, tables32 = cache
+        one_each = np.arange(n_pairs + 1, dtype=np.int64)
+        ids32 = np.ascontiguousarray(pair_ids, dtype=np.int32)
         if mode == PASSAGE:
-            return self._ids.psg_rows().astype(np.int64)[ids], pair_q, np.arange(n_pairs + 1, dtype=np.int64)
-        doc_off, doc_rows = self._ids.doc_csr()
-        start = doc_off[ids]
-        if mode == FIRSTP:
-            return doc_rows.astype(np.int64)[start], pair_q, np.arange(n_pairs + 1, dtype=np.int64)
-        cnt = doc_off[ids + 1] - start
+            if tables32 is not None:  # (the gathers by host threads: a million random reads of a table of millions)
+                return native.take32(tables32[2], ids32).astype(np.int64), pair_q, one_each
+            return psg_rows[pair_ids], pair_q, one_each
+        if (mode == FIRSTP or one_row_each) and tables32 is not None:
+            return native.take32(tables32[1], native.take32(tables32[0], ids32)).astype(np.int64), pair_q, one_each
+        start = doc_off[pair_ids]
+        if mode == FIRSTP or one_row_each:
+            return doc_rows[start], pair_q, one_each
+        cnt = doc_off[pair_ids.astype(np.int64) + 1] - start
         seg_off = np.zeros(n_pairs + 1, dtype=np.int64)
         np.cumsum(cnt, out=seg_off[1:])
         within = np.arange(int(seg_off[-1]), dtype=np.int64) - np.repeat(seg_off[:-1], cnt)
-        return doc_rows.astype(np.int64)[np.repeat(start, cnt) + within], np.repeat(pair_q, cnt), seg_off
+        return doc_rows[np.repeat(start, cnt) + within], np.repeat(pair_q, cnt), seg_off
 
     def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False, want_dense=True):
         if len(self) == 0:
@@ -411,7 +431,9 @@ class OnDiskIndex(Index):
             q = np.ascontiguousarray(q @ book[1], dtype=np.float32)  # OPQ: rotate the queries (see hbm.py)
         n_q = q.shape[0]
         pair_off = np.asarray(pair_off, dtype=np.int64)
+        t_call = time.perf_counter()
         rows, row_q, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
+        t_expanded = time.perf_counter()
         # each needed row is read once: the distinct rows, ascending, and every gathered row's slot among them
         if rows.shape[0] >= (1 << 16):
             uniq, slot_row = native.unique_rows(rows, len(self))
@@ -462,8 +484,10 @@ class OnDiskIndex(Index):
                         return
                     want = uniq[w * per_window:(w + 1) * per_window]
                     t_up = time.perf_counter()
-                    if native_gather:  # threads of libffx: chunk maps -> page-locked staging -> HBM, overlapped
-                        bufs[i].upload_rows(chunk_maps, want, 0, _READ_THREADS)
+                    if native_gather:  # threads of libffx: chunk maps -> page-locked staging -> HBM, overlapped; the last
+                        # copies are still in flight when this returns (the scorer waits for them), so the next window's
+                        # gather starts right away
+                        bufs[i].upload_rows(chunk_maps, want, 0, _READ_THREADS, wait=False)
                     else:
                         data = self._read_rows(want)
                         if host_decode:
@@ -484,6 +508,8 @@ class OnDiskIndex(Index):
                 if w < 0:
                     raise failure[0]
                 t_sc = time.perf_counter()
+                if native_gather:
+                    bufs[i].upload_wait()
                 slots = np.flatnonzero(window_of_slot == w)  # ascending: grouped by query already
                 local_off = np.zeros(n_q + 1, dtype=np.int64)
                 np.cumsum(np.bincount(row_q[slots], minlength=n_q), out=local_off[1:])
@@ -499,5 +525,9 @@ class OnDiskIndex(Index):
             free.put(None)  # unblock the uploader if the scoring thread failed first
             t.join()
         stats["s_windows"] = time.perf_counter() - t_begin
+        stats["s_expand"], stats["s_unique_rows"] = t_expanded - t_call, t_begin - t_expanded
+        t_agg = time.perf_counter()
+        out = native.aggregate(rs, seg_off, mode.value, sparse, 0.0 if alpha is None else alpha, pair_off, sort=sort, device=self._device)
+        stats["s_aggregate"] = time.perf_counter() - t_agg
         self.last_stats = stats
-        return native.aggregate(rs, seg_off, mode.value, sparse, 0.0 if alpha is None else alpha, pair_off, sort=sort, device=self._device)
+        return out

@@ -24,7 +24,7 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
     "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
-    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
+    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_upload_rows_async", "ffx_index_upload_wait", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device",
     "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_recent_gather_ms", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
@@ -133,6 +133,8 @@ def lib() -> C.CDLL:
         "ffx_index_device_ptr": ([vp, P(vp)], C.c_int),
         "ffx_index_upload": ([vp, vp, i64, i64], C.c_int),
         "ffx_index_upload_rows": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
+        "ffx_index_upload_rows_async": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
+        "ffx_index_upload_wait": ([vp], C.c_int),
         "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
         "ffx_index_gather": ([vp, vp, i64, vp], C.c_int),
         "ffx_index_fill_synthetic": ([vp, C.c_uint64, f32, i64, i64, i64], C.c_int),
@@ -234,6 +236,26 @@ def lib() -> C.CDLL:
     return L
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a
+    256-core host is often allowed 16: more busy threads than that get the whole group throttled)."""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            quota, period = parse(open(path).read())
+            if period is None:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def _close_quietly(self) -> None:
     """``__del__`` of the handle classes: at interpreter shutdown the module's globals may already be
     gone (the process is ending and the driver frees everything anyway), which is not worth a
@@ -324,17 +346,23 @@ class DeviceIndex:
         assert rows.ndim == 2 and rows.shape[1] == self.dim
         _check(lib().ffx_index_upload(self._h, _ptr(rows), row_offset, rows.shape[0]))
 
-    def upload_rows(self, chunks, rows, dst_row: int = 0, threads: int = 0) -> None:
+    def upload_wait(self) -> None:
+        """Wait for an ``upload_rows(..., wait=False)`` to land."""
+        _check(lib().ffx_index_upload_wait(self._h))
+
+    def upload_rows(self, chunks, rows, dst_row: int = 0, threads: int = 0, wait: bool = True) -> None:
         """Stored rows ``rows`` (numbers over the concatenation of the equally sized 2-D arrays
         ``chunks``, e.g. the memory maps of an on-disk index) -> device rows from ``dst_row`` on,
-        gathered by native threads through page-locked staging (``ffx_index_upload_rows``)."""
+        gathered by native threads through page-locked staging (``ffx_index_upload_rows``).  ``wait=False``:
+        return when the last copies are queued (``upload_wait`` before the rows are used)."""
         chunk_rows = int(chunks[0].shape[0]) if len(chunks) else 1
         for c in chunks:
             if c.dtype != self.dtype or c.ndim != 2 or c.shape != (chunk_rows, self.dim) or not c.flags["C_CONTIGUOUS"]:
                 raise ValueError("chunks must be contiguous (chunk_rows, dim) arrays of the index dtype")
         ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
         rows = _arr(rows, np.int64)
-        _check(lib().ffx_index_upload_rows(self._h, ptrs, len(chunks), chunk_rows, _ptr(rows), rows.shape[0], int(dst_row), int(threads)))
+        fn = lib().ffx_index_upload_rows if wait else lib().ffx_index_upload_rows_async
+        _check(fn(self._h, ptrs, len(chunks), chunk_rows, _ptr(rows), rows.shape[0], int(dst_row), int(threads)))
 
     def device_ptr(self) -> int:
         """Device address of row 0 (rows contiguous, in the index dtype)."""

@@ -124,6 +124,11 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
  * (n_threads; 0 = half the cores) fill page-locked staging while the previous block is copied. */
 int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
                           const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads);
+/* the same, returning once every row is gathered and its copy queued (not landed): the caller's next gather overlaps the
+ * tail of the copies; ffx_index_upload_wait before the rows are used (it also finishes the code check of PQ rows) */
+int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
+                                const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads);
+int ffx_index_upload_wait(ffx_index* idx);
 /* device copy between two indexes on the same device (growing an index) */
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows);
 /* read rows back: InMemoryIndex._get_vectors, memory.py:139-140 / index/util.py:97-98 */

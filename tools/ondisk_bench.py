@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+from fast_forward_amd import native  # noqa: E402
 from fast_forward_amd.index import Mode, OnDiskIndex  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -27,6 +28,30 @@ args = ap.parse_args()
 
 rng = np.random.default_rng(0)
 out = {"rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "window_mb": args.window_mb}
+
+
+def h2d_ceiling() -> dict:
+    """What this box moves from page-locked host memory to HBM: 1 GiB in 64 MiB blocks (hipMemcpy from ffx_host_alloc
+    memory, the blocks a streamed window travels in), best of 5 -- the roofline of the streamed path (every gathered
+    row crosses PCIe once); and the same out of ordinary pageable memory."""
+    rows_per_block = (64 << 20) // (args.dim * 4)
+    blocks = 16
+    dev = native.DeviceIndex(rows_per_block * blocks, args.dim)
+    res = {}
+    for label, src in (("pinned", native.pinned_empty((rows_per_block, args.dim), np.float32)), ("pageable", np.empty((rows_per_block, args.dim), dtype=np.float32))):
+        src[...] = 1.0
+        best = float("inf")
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for b in range(blocks):
+                dev.upload(src, b * rows_per_block)
+            best = min(best, time.perf_counter() - t0)
+        res[f"{label}_GBs"] = blocks * src.nbytes / best / 1e9
+    dev.close()
+    return res
+
+
+out["h2d_ceiling"] = h2d_ceiling()
 with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
     idx = OnDiskIndex(Path(tmp) / "index.ffx", mode=Mode.MAXP, chunk_size=2**16, max_id_length=12, window_bytes=args.window_mb << 20)
     t0 = time.perf_counter()
@@ -40,7 +65,7 @@ with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
     pair_ids = np.concatenate([rng.choice(args.rows, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
     pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
     sparse = rng.random(pair_ids.shape[0], dtype=np.float32) * 25
-    for label in ("cold", "warm", "warm2"):
+    for label in ("cold", "warm", "warm2", "warm3"):
         t0 = time.perf_counter()
         ff, interp, order = idx._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
         dt = time.perf_counter() - t0
@@ -49,7 +74,10 @@ with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
                                   "unique_rows": st["unique_rows"], "streamed_gb": st["bytes_streamed"] / 1e9,
                                   "streamed_gb_per_s": st["bytes_streamed"] / 1e9 / dt, "kernel_ms_total": st["ms_gather_dot"],
                                   "upload_s": st["s_upload"], "upload_gb_per_s": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9),
-                                  "score_s": st["s_score"], "windows_s": st["s_windows"]}
+                                  "score_s": st["s_score"], "windows_s": st["s_windows"], "expand_s": st["s_expand"], "unique_rows_s": st["s_unique_rows"],
+                                  "aggregate_s": st["s_aggregate"],
+                                  "upload_over_ceiling": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9) / out["h2d_ceiling"]["pinned_GBs"],
+                                  "call_over_ceiling": st["bytes_streamed"] / 1e9 / dt / out["h2d_ceiling"]["pinned_GBs"]}
     t0 = time.perf_counter()
     mem = idx.to_memory(batch_size=2**18)
     out["to_memory_s"] = time.perf_counter() - t0
