@@ -778,6 +778,51 @@ int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int3
   }
 }
 
+// Which rank of a sharded index holds row i: crc32 (the zlib / IEEE one, so that Python's zlib.crc32 names the same
+// rank) of its document id -- or, for a row without one, of its passage id -- modulo `world`.  Ids arrive as the
+// NUL-padded fixed-width fields an index file stores them in (numpy 'S<width>'; an empty field = no id).  Every rank
+// of a ShardedOnDiskIndex runs this over the file's id columns block by block and interns only the ids of ITS rows: the
+// string tables are sharded with the rows instead of being replicated (reference: OnDiskIndex.load reads every id into
+// the one process there is, index/disk.py:355-418).  owner[i] = 255 for a row with neither id.
+int ffx_host_owner_crc32(const char* doc_ids, int32_t doc_width, const char* psg_ids, int32_t psg_width, int64_t n, int32_t world, int32_t n_threads,
+                         uint8_t* owner) {
+  if (n < 0 || world < 1 || world > 254 || doc_width < 0 || psg_width < 0 || (n > 0 && (!owner || (!doc_ids && !psg_ids)))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if ((doc_ids && doc_width < 1) || (psg_ids && psg_width < 1)) return ffx_fail(FFX_BAD_ARG, "a column of ids needs a width");
+  static uint32_t table[256];
+  static std::atomic<bool> ready(false);
+  if (!ready.load(std::memory_order_acquire)) {  // (idempotent: concurrent first callers write the same values)
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready.store(true, std::memory_order_release);
+  }
+  auto crc = [&](const char* p, size_t len) {
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < len; ++i) c = table[(c ^ (unsigned char)p[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+  };
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  try {
+    run_threads(T, [&](int t) {
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+        const char* f = doc_ids ? doc_ids + (size_t)i * (size_t)doc_width : nullptr;
+        size_t len = f ? strnlen(f, (size_t)doc_width) : 0;
+        if (len == 0 && psg_ids) {
+          f = psg_ids + (size_t)i * (size_t)psg_width;
+          len = strnlen(f, (size_t)psg_width);
+        }
+        owner[i] = len == 0 ? (uint8_t)255 : (uint8_t)(crc(f, len) % (uint32_t)world);
+      }
+    });
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  return FFX_OK;
+}
+
 int ffx_buffer_free(void* p) {
   free(p);
   return FFX_OK;

@@ -97,6 +97,9 @@ class OnDiskIndex(Index):
         self._device, self.exact_sum, self._window_bytes = int(device), bool(exact_sum), int(window_bytes)
         self.last_stats: dict | None = None
         self._windows: tuple | None = None  # (key, device buffers, plans) kept between scoring calls
+        # a SHARD VIEW of the file (load(..., shard=(rank, world))): only the rows this rank of a sharded index holds are
+        # known here -- row numbers are local (0 .. len-1, file order), _row_map[local] is the row of the file
+        self._row_map: np.ndarray | None = None
 
     def _release_windows(self) -> None:
         if getattr(self, "_windows", None):
@@ -190,7 +193,12 @@ class OnDiskIndex(Index):
 
     # ---- Index storage interface ------------------------------------------------------------------------
     def _get_num_vectors(self) -> int:
-        return int(self._meta["num_vectors"])
+        return int(self._meta["num_vectors"]) if self._row_map is None else int(self._row_map.shape[0])
+
+    def _file_rows(self, rows: np.ndarray) -> np.ndarray:
+        """Row numbers of the FILE for this index's row numbers (the same, unless this is a shard view)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        return rows if self._row_map is None else self._row_map[rows]
 
     def _get_internal_dim(self) -> int | None:
         return self._meta["dim"]
@@ -203,6 +211,8 @@ class OnDiskIndex(Index):
 
     def _add(self, vectors: np.ndarray, doc_ids: IDSequence, psg_ids: IDSequence) -> None:
         m = self._meta
+        if self._row_map is not None:
+            raise RuntimeError("a shard view of an index file is read-only")
         if m.get("read_only"):
             raise RuntimeError("HDF5 index files of the reference are opened read-only; use to_memory() or copy into a new OnDiskIndex")
         limit = m["max_id_length"]
@@ -244,7 +254,7 @@ class OnDiskIndex(Index):
         """Stored rows (vectors or codes) for global row numbers, in the order given.  Large reads
         are split over a few threads: the gather out of the page cache is a plain memory copy
         (NumPy releases the GIL for it) and one core moves only ~3 GB/s."""
-        rows = np.asarray(rows, dtype=np.int64)
+        rows = self._file_rows(rows)
         out = np.empty((rows.shape[0], self._meta["dim"]), dtype=np.dtype(self._meta["dtype"]))
         cs = self._meta["chunk_size"]
 
@@ -287,16 +297,23 @@ class OnDiskIndex(Index):
     @classmethod
     def load(cls, index_file: Path, query_encoder: Encoder | None = None, mode: Mode = Mode.MAXP, encoder_batch_size: int = 32,
              memory_mapped: bool = False, max_indexing_size: int = 2**10, device: int = 0, exact_sum: bool = True,
-             window_bytes: int = 1 << 30) -> "OnDiskIndex":
+             window_bytes: int = 1 << 30, shard: "tuple[int, int] | None" = None) -> "OnDiskIndex":
         """Open an existing index file (disk.py:355-418): ids are read back into the host tables,
-        the stored quantizer (if any) is reconstructed."""
+        the stored quantizer (if any) is reconstructed.
+
+        ``shard=(rank, world)``: a SHARD VIEW for one rank of a sharded index -- only the rows whose document id
+        (passage id, for rows without one) hashes to ``rank`` (crc32 % world, ``sharded._owner_of``) are kept: their ids
+        are the only strings interned (host memory ~ N / world per rank, where the reference -- one process -- reads
+        all N, disk.py:355-418), row numbers are local, read-only."""
         index_file = Path(index_file)
         native.lib()
         index = cls.__new__(cls)
         index._index_file = index_file.absolute()
         index._init_state(device, exact_sum, window_bytes)
+        if shard is not None and not (0 <= int(shard[0]) < int(shard[1]) <= 254):
+            raise ValueError("shard must be (rank, world) with 0 <= rank < world <= 254")
         if h5read.is_hdf5(index_file):  # an index written by the reference (h5py): opened read-only
-            index._load_hdf5(query_encoder, mode, encoder_batch_size)
+            index._load_hdf5(query_encoder, mode, encoder_batch_size, shard)
             return index
         index._meta = cls._read_header(index_file)
         Index.__init__(index, query_encoder=query_encoder, quantizer=None, mode=mode, encoder_batch_size=encoder_batch_size)
@@ -305,17 +322,29 @@ class OnDiskIndex(Index):
             index._quantizer._attached = True
         index._open_maps()
         n, cs = index._meta["num_vectors"], index._meta["chunk_size"]
+        kept: list[np.ndarray] = []
         for c, (_, dmap, pmap) in enumerate(index._maps):
             lo = c * cs
             take = min(cs, n - lo)
             if take <= 0:
                 break
-            docs = [d.decode() or None for d in np.asarray(dmap[:take])]
-            psgs = [p.decode() or None for p in np.asarray(pmap[:take])]
-            index._ids.add(docs, psgs, lo)
+            kept.append(index._register_ids(np.asarray(dmap[:take]), np.asarray(pmap[:take]), lo, shard))
+        if shard is not None:
+            index._row_map = np.concatenate(kept) if kept else np.zeros(0, dtype=np.int64)
         return index
 
-    def _load_hdf5(self, query_encoder, mode, encoder_batch_size) -> None:
+    def _register_ids(self, docs: np.ndarray, psgs: np.ndarray, first_file_row: int, shard) -> np.ndarray:
+        """One block of the file's id columns (fixed-width bytes, "" = no id) into the id tables; with ``shard`` only the
+        rows this rank holds (``ffx_host_owner_crc32``: no Python string is made of anybody else's ids).  Returns the
+        file rows that were registered."""
+        rows = np.arange(first_file_row, first_file_row + docs.shape[0], dtype=np.int64)
+        if shard is not None:
+            mine = np.flatnonzero(native.owner_of_rows(docs, psgs, int(shard[1])) == int(shard[0]))
+            docs, psgs, rows = docs[mine], psgs[mine], rows[mine]
+        self._ids.add([d.decode() or None for d in docs], [p.decode() or None for p in psgs], self._ids._n_rows)
+        return rows
+
+    def _load_hdf5(self, query_encoder, mode, encoder_batch_size, shard=None) -> None:
         """Open an HDF5 index file of the reference (layout: disk.py:83-85, :123-165).  The chunk
         B-tree gives the byte offset of every ``vectors`` chunk, which is memory-mapped exactly as
         the reference's own mmap mode does (disk.py:100-121); ids are read once into the host
@@ -352,7 +381,9 @@ class OnDiskIndex(Index):
             self._maps.append((rows, None, None))
         docs = root.datasets["doc_ids"].read(self._index_file)[:n]
         psgs = root.datasets["psg_ids"].read(self._index_file)[:n]
-        self._ids.add([d.decode() or None for d in docs], [p.decode() or None for p in psgs], 0)
+        kept = [self._register_ids(docs[lo:lo + (1 << 20)], psgs[lo:lo + (1 << 20)], lo, shard) for lo in range(0, n, 1 << 20)]
+        if shard is not None:
+            self._row_map = np.concatenate(kept) if kept else np.zeros(0, dtype=np.int64)
 
     def to_memory(self, batch_size: int | None = None) -> InMemoryIndex:
         """The whole index resident in HBM (disk.py:177-205)."""
@@ -378,7 +409,7 @@ class OnDiskIndex(Index):
 
                 shape = SimpleNamespace(shape=(hi - lo, self._meta["dim"]), dtype=stored)
                 index._add(shape, docs[lo:hi], psgs[lo:hi],
-                           _uploader=lambda store, at, lo=lo, hi=hi: store.upload_rows(chunk_maps, np.arange(lo, hi), at, _READ_THREADS))
+                           _uploader=lambda store, at, lo=lo, hi=hi: store.upload_rows(chunk_maps, self._file_rows(np.arange(lo, hi)), at, _READ_THREADS))
             else:
                 index._add(self._read_rows(np.arange(lo, hi)), docs[lo:hi], psgs[lo:hi])
         return index
@@ -487,7 +518,7 @@ class OnDiskIndex(Index):
                     if native_gather:  # threads of libffx: chunk maps -> page-locked staging -> HBM, overlapped; the last
                         # copies are still in flight when this returns (the scorer waits for them), so the next window's
                         # gather starts right away
-                        bufs[i].upload_rows(chunk_maps, want, 0, _READ_THREADS, wait=False)
+                        bufs[i].upload_rows(chunk_maps, self._file_rows(want), 0, _READ_THREADS, wait=False)
                     else:
                         data = self._read_rows(want)
                         if host_decode:

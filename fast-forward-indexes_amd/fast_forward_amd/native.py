@@ -32,7 +32,7 @@ SYMBOLS = (
     "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync",
     "ffx_merge_fetch", "ffx_merge_device_ptr",
     "ffx_aggregate",
-    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_host_code_u64", "ffx_buffer_free",
+    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_host_code_u64", "ffx_host_owner_crc32", "ffx_buffer_free",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
@@ -179,6 +179,7 @@ def lib() -> C.CDLL:
         "ffx_strings_code_offsets": ([vp, vp, i64, C.c_char, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
         "ffx_buffer_free": ([vp], C.c_int),
         "ffx_host_code_u64": ([vp, i64, i32, vp, vp, P(i64)], C.c_int),
+        "ffx_host_owner_crc32": ([vp, i32, vp, i32, i64, i32, i32, vp], C.c_int),
         "ffx_ids_get": ([vp, i32, P(vp), P(i32)], C.c_int),
         "ffx_run_open": ([C.c_char_p, vp, P(vp), P(i64)], C.c_int),
         "ffx_run_close": ([vp], C.c_int),
@@ -696,6 +697,25 @@ def code_strings(blob: bytes, n: int, threads: int = 0) -> tuple[np.ndarray, byt
         if names.value:
             lib().ffx_buffer_free(names)
     return codes, joined, int(n_names.value)
+
+
+def owner_of_rows(doc_ids: "np.ndarray | None", psg_ids: "np.ndarray | None", world: int, threads: int = 0) -> np.ndarray:
+    """``ffx_host_owner_crc32``: the rank holding every row, from fixed-width byte arrays (numpy ``S``) of document and
+    passage ids (either may be None); equals ``zlib.crc32(id.encode()) % world`` on the row's document id, or on its
+    passage id when it has no document id; 255 where a row has neither."""
+    cols = []
+    for a in (doc_ids, psg_ids):
+        if a is None:
+            cols.append((None, 0))
+        else:
+            a = np.ascontiguousarray(a)
+            if a.dtype.kind != "S" or a.ndim != 1:
+                raise ValueError("ids must be a 1-d array of fixed-width bytes")
+            cols.append((a, a.dtype.itemsize))
+    n = next(a.shape[0] for a, _ in cols if a is not None)
+    out = np.empty(n, dtype=np.uint8)
+    _check(lib().ffx_host_owner_crc32(_ptr(cols[0][0]), cols[0][1], _ptr(cols[1][0]), cols[1][1], n, int(world), int(threads), _ptr(out)))
+    return out
 
 
 def code_u64(address: int, n: int, threads: int = 0) -> tuple[np.ndarray, np.ndarray]:

@@ -296,10 +296,17 @@ class _ShardedIndex:
     def dim(self):
         return self.local.dim
 
-    def _holders_by_code(self, names: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    def _holders_by_code(self, names: np.ndarray, packed=None) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
         """For the DISTINCT candidate ids of a ranking: (holder rank, ordinal on this rank where this rank is
-        the holder, "no rank holds it" mask).  Collective (every rank calls it with the same ids)."""
-        raise NotImplementedError
+        the holder, "no rank holds it" mask).  Collective (every rank calls it with the same ids, in the same
+        order: a ranking's id numbering depends on its strings only).  Every rank knows only the ids of the rows it
+        holds: it looks the names up in its own table, and one small control message -- the bit mask of what each
+        rank holds -- tells everybody the holder of every id, or that nobody holds it."""
+        ord_u = self.local._ids.lookup_optional(names, self.local.mode.value, packed)
+        held = self.comm.allgather_array(np.packbits(ord_u >= 0))
+        held = np.unpackbits(held, axis=1, count=len(names)).astype(bool) if len(names) else np.zeros((self.world, 0), dtype=bool)
+        holder = held.argmax(axis=0).astype(np.int32) if len(names) else np.zeros(0, dtype=np.int32)
+        return holder, np.maximum(ord_u, 0), ~held.any(axis=0)
 
     def _holders(self, ranking, perm) -> tuple[np.ndarray, np.ndarray]:
         """(holder rank, ordinal on that rank) of every candidate, rows grouped by query.  The distinct ids are
@@ -309,7 +316,7 @@ class _ShardedIndex:
         key = (id(self), self.local.mode, getattr(self, "_n_global", None), getattr(self.local._ids, "version", None))
         cached = getattr(ranking, "_holder_cache", None)
         if cached is None or cached[0] != key or cached[1] is not names or cached[2] is not codes:
-            holder_c, local_c, missing_c = self._holders_by_code(names)
+            holder_c, local_c, missing_c = self._holders_by_code(names, ranking._id_blob(names))
             if missing_c.any():
                 bad = np.flatnonzero(missing_c[codes])
                 if bad.size:
@@ -502,15 +509,6 @@ class ShardedInMemoryIndex(_ShardedIndex):
             self._placeholder.close()
             self._placeholder = None
 
-    def _holders_by_code(self, names: np.ndarray):
-        # which ids do I hold?  (local look-up; unknown here = held elsewhere or nowhere)
-        ord_u = self.local._ids.lookup_optional(names, self.local.mode.value)
-        # one small control message: the bit mask of the distinct ids every rank holds
-        held = self.comm.allgather_array(np.packbits(ord_u >= 0))
-        held = np.unpackbits(held, axis=1, count=len(names)).astype(bool) if len(names) else np.zeros((self.world, 0), dtype=bool)
-        holder = held.argmax(axis=0).astype(np.int32) if len(names) else np.zeros(0, dtype=np.int32)
-        return holder, np.maximum(ord_u, 0), ~held.any(axis=0)
-
     def close(self) -> None:
         if self._scorer is not None:
             self._scorer.close()
@@ -524,12 +522,16 @@ class ShardedOnDiskIndex(_ShardedIndex):
     the ranks of a communicator: BASELINE config 5 (100 M x 768 fp32 = 307 GB does not fit one GPU;
     over 8 GPUs a shard is 38.4 GB and is simply resident).
 
-    Every rank opens the same file and reads the id tables; documents are cut into ``world``
-    contiguous ordinal ranges of ~equal row count (``doc_partition``; rows without a document id are
-    dealt out in contiguous blocks), and rank r moves ITS rows from the chunk maps to its HBM through
-    ``ffx_index_upload_rows`` (native threads, page-locked staging) -- the sharded form of
-    ``OnDiskIndex.to_memory`` (reference disk.py:177-205).  Scoring is then exactly the resident
-    sharded path (local gather_dot, one all-to-all of scores, owner-side merge).
+    Every rank opens the same file as a SHARD VIEW (``OnDiskIndex.load(..., shard=(rank, world))``): a row belongs to
+    the rank its document id (its passage id, if it has no document id) hashes to -- crc32 % world, the placement
+    ``ShardedInMemoryIndex`` uses, so a document's passages share a rank -- and a rank reads the file's id columns
+    block by block, keeps and interns ONLY the ids of its own rows (host memory ~ N / world per rank; the reference,
+    one process, reads all N: disk.py:355-418), and moves ITS rows from the chunk maps to its HBM through
+    ``ffx_index_upload_rows`` (native threads, page-locked staging) -- the sharded form of ``OnDiskIndex.to_memory``
+    (disk.py:177-205).  Who holds a candidate is settled per call as in ``ShardedInMemoryIndex``: every rank looks the
+    ranking's distinct ids up in its own table and one small collective (a bit mask per rank) tells everybody the
+    holder, or that nobody holds the id (``IndexError`` on every rank).  Scoring is then exactly the resident sharded
+    path (local gather_dot, one all-to-all of scores, owner-side merge).
 
     ``resident=False`` (or a shard larger than the free HBM): the shard stays in the file and each
     call streams the rows its local candidates need through two HBM windows, as the 1-GPU
@@ -546,99 +548,62 @@ class ShardedOnDiskIndex(_ShardedIndex):
         self.rank, self.world, self.device = self.comm.rank, self.comm.world, self.comm.device
         self.exact_sum = exact_sum
         self.local = OnDiskIndex.load(index_file, query_encoder=query_encoder, mode=mode or Mode.MAXP, encoder_batch_size=encoder_batch_size,
-                                      device=self.device, exact_sum=exact_sum, window_bytes=window_bytes)
+                                      device=self.device, exact_sum=exact_sum, window_bytes=window_bytes, shard=(self.rank, self.world))
         disk, ids = self.local, self.local._ids
-        n = len(disk)
-        doc_off, doc_rows = ids.doc_csr()
-        psg_rows = ids.psg_rows().astype(np.int64)
-        self.doc_bounds = doc_partition(doc_off, self.world)
-        # who holds which stored row: the rows of a rank's documents, then its share of the rows that
-        # belong to no document (passage-only rows), both in a fixed order every rank derives alike
-        row_holder = np.full(n, -1, dtype=np.int32)
-        for r in range(self.world):
-            row_holder[doc_rows[doc_off[self.doc_bounds[r]]:doc_off[self.doc_bounds[r + 1]]]] = r
-        orphans = np.flatnonzero(row_holder < 0)
-        cuts = (np.arange(self.world + 1, dtype=np.int64) * orphans.shape[0]) // self.world
-        for r in range(self.world):
-            row_holder[orphans[cuts[r]:cuts[r + 1]]] = r
-        d_lo, d_hi = int(self.doc_bounds[self.rank]), int(self.doc_bounds[self.rank + 1])
-        my_doc_rows = doc_rows[doc_off[d_lo]:doc_off[d_hi]].astype(np.int64)  # grouped by document, insertion order inside
-        self._my_rows = np.concatenate([my_doc_rows, orphans[cuts[self.rank]:cuts[self.rank + 1]]])
-        self._local_doc_off = (doc_off[d_lo:d_hi + 1] - doc_off[d_lo]).astype(np.int64)
-        local_row = np.full(n, -1, dtype=np.int64)
-        local_row[self._my_rows] = np.arange(self._my_rows.shape[0])
-        # passage ordinal -> (holder, ordinal on the holder): a rank numbers its passages in global ordinal order
-        self._psg_holder = row_holder[psg_rows] if psg_rows.size else np.zeros(0, dtype=np.int32)
-        order = np.argsort(self._psg_holder, kind="stable")
-        starts = np.searchsorted(self._psg_holder[order], np.arange(self.world))
-        self._psg_local = np.empty(psg_rows.shape[0], dtype=np.int32)
-        self._psg_local[order] = (np.arange(psg_rows.shape[0]) - starts[self._psg_holder[order]]).astype(np.int32)
-        mine_psg = np.flatnonzero(self._psg_holder == self.rank)
-        self._my_psg_global = mine_psg                                   # local passage ordinal -> global passage ordinal
-        self._local_psg_row = local_row[psg_rows[mine_psg]].astype(np.int32)
-        self.rows_per_rank = np.bincount(row_holder, minlength=self.world)
+        n_local = len(disk)
+        self._n_file = int(disk._meta["num_vectors"])
+        self.rows_per_rank = self.comm.allgather_array(np.array([n_local], dtype=np.int64))[:, 0]
         stored = np.dtype(disk._meta["dtype"]) if disk._meta["dtype"] else np.dtype(np.float32)
         book = disk._quantizer.device_codebook() if disk._quantizer is not None else None
         direct = (stored in (np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.uint8)) and (disk._quantizer is None) == (stored != np.dtype(np.uint8))
                   and (disk._quantizer is None or book is not None))
-        shard_bytes = int(self._my_rows.shape[0]) * int(disk._meta["dim"] or 0) * (stored.itemsize if direct else 4)
+        shard_bytes = n_local * int(disk._meta["dim"] or 0) * (stored.itemsize if direct else 4)
         if resident is None:
             resident = shard_bytes <= 0.8 * native.device_info(self.device)["free_bytes"]
         # every rank must take the same branch (the exchange differs): resident only if it is for all
         self.resident = bool(self.comm.allreduce([1.0 if resident else 0.0], native.OP_MIN)[0])
         self._store = self._scorer = None
-        # (every rank computed rows_per_rank alike, so what follows is the same decision everywhere: nobody raises alone
+        self._rotation = None
+        # (every rank holds the same rows_per_rank, so what follows is the same decision everywhere: nobody raises alone
         # between two collectives)
         if int(self.rows_per_rank.sum()) == 0 and self.resident:
             raise RuntimeError("the index file holds no rows")
-        if self.resident and self._my_rows.shape[0]:
+        if not self.resident:
+            return
+        quantized = disk._quantizer is not None and book is not None and direct
+        if n_local:
             chunk_maps = [m[0] for m in disk._maps]
             if direct and all(isinstance(c, np.ndarray) and c.flags["C_CONTIGUOUS"] for c in chunk_maps):
-                self._store = native.DeviceIndex(self._my_rows.shape[0], int(disk._meta["dim"]), self.device, dtype=stored)
+                self._store = native.DeviceIndex(n_local, int(disk._meta["dim"]), self.device, dtype=stored)
                 if book is not None:
                     self._store.set_codebook(book[0])
-                self._store.upload_rows(chunk_maps, self._my_rows, 0, _READ_THREADS)
+                self._store.upload_rows(chunk_maps, disk._row_map, 0, _READ_THREADS)
             else:  # float64 files of the reference, or a quantizer the kernels cannot read: decoded fp32 rows
-                data = disk._read_rows(self._my_rows)
+                data = disk._read_rows(np.arange(n_local))
                 if disk._quantizer is not None:
                     data = disk._quantizer.decode(data)
-                self._store = native.DeviceIndex(self._my_rows.shape[0], data.shape[1], self.device, dtype=np.float32)
+                self._store = native.DeviceIndex(n_local, data.shape[1], self.device, dtype=np.float32)
                 self._store.upload(np.ascontiguousarray(data, dtype=np.float32), 0)
             self._rotation = book[1] if (book is not None and self._store.dtype == np.uint8) else None
-            n_doc_rows = int(self._local_doc_off[-1])
-            self._store.set_doc_rows(self._local_doc_off, np.arange(n_doc_rows, dtype=np.int32))
-            self._store.set_psg_rows(self._local_psg_row if self._local_psg_row.size else np.zeros(0, dtype=np.int32))
-            self._scorer = ShardedScorer(self._store, None, self.comm)
-        elif self.resident:
-            # fewer documents than ranks: this rank takes part with a one-row placeholder and empty candidate lists
-            quantized = disk._quantizer is not None and book is not None and direct
-            self._store = native.DeviceIndex(1, int(disk._meta["dim"]) if direct else int(disk.dim), self.device,
-                                             dtype=stored if direct else np.float32)
+            doc_off, doc_rows = ids.doc_csr()  # rows of a document: local row numbers, insertion order
+            self._store.set_doc_rows(doc_off, doc_rows)
+            self._store.set_psg_rows(ids.psg_rows())
+        else:
+            # this rank's hash bucket is empty (fewer documents than ranks): it takes part with a one-row placeholder and
+            # empty candidate lists
+            self._store = native.DeviceIndex(1, int(disk._meta["dim"]) if direct else int(disk.dim), self.device, dtype=stored if direct else np.float32)
             if quantized:
                 self._store.set_codebook(book[0])
             self._rotation = book[1] if quantized else None
             self._store.set_doc_rows(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
             self._store.set_psg_rows(np.zeros(0, dtype=np.int32))
-            self._scorer = ShardedScorer(self._store, None, self.comm)
+        self._scorer = ShardedScorer(self._store, None, self.comm)
 
     def __len__(self) -> int:
-        return len(self.local)
+        return self._n_file
 
     def _sharded(self) -> ShardedScorer:
         return self._scorer
-
-    def _holders_by_code(self, names: np.ndarray):
-        # every rank has the whole id table: an unknown id is unknown everywhere
-        ordinals = self.local._ids.lookup_optional(names, self.local.mode.value)
-        known = np.maximum(ordinals, 0)
-        if self.local.mode.value == 1:
-            n_psg = self._psg_holder.shape[0]
-            safe = np.minimum(known, max(n_psg - 1, 0))
-            holder = self._psg_holder[safe] if n_psg else np.zeros(len(names), dtype=np.int32)
-            local = self._psg_local[safe] if n_psg else np.zeros(len(names), dtype=np.int32)
-            return holder, local, ordinals < 0
-        holder = np.clip(np.searchsorted(self.doc_bounds, known, side="right") - 1, 0, self.world - 1).astype(np.int32)
-        return holder, (known - self.doc_bounds[holder]).astype(np.int32), ordinals < 0
 
     def _rank(self, ranking, alpha, name, gather):
         if self.resident and getattr(self, "_rotation", None) is not None:
@@ -655,12 +620,8 @@ class ShardedOnDiskIndex(_ShardedIndex):
         np.cumsum(np.bincount(pair_q[mine], minlength=n_q), out=local_off[1:])
         if mine.size == 0:
             return np.zeros(0, dtype=np.float32)
-        # back to the file's own ordinals: the 1-GPU streaming path takes it from there
-        if mode == 1:
-            global_ids = self._my_psg_global[local_ids[mine]]
-        else:
-            global_ids = local_ids[mine].astype(np.int64) + self.doc_bounds[self.rank]
-        ff, _, _ = self.local._score_pairs(query_vectors, local_off, global_ids.astype(np.int32), self.local.mode)
+        # the shard view numbers its documents / passages itself: the 1-GPU streaming path takes it from there
+        ff, _, _ = self.local._score_pairs(query_vectors, local_off, np.ascontiguousarray(local_ids[mine], dtype=np.int32), self.local.mode)
         return ff
 
     def close(self) -> None:

@@ -361,6 +361,11 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
 int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes,
                              char** names_blob, int64_t* names_bytes, int64_t* n_names);
 int ffx_buffer_free(void* p);
+/* owner[i] = crc32 (zlib's) of row i's document id -- its passage id if it has no document id -- modulo world: the rank of a
+ * sharded index that holds the row (255: the row has neither id).  Ids as NUL-padded fixed-width fields (the id columns of
+ * an index file, index/disk.py:145-165); either column may be NULL.  Each rank keeps and interns only its own rows' ids. */
+int ffx_host_owner_crc32(const char* doc_ids, int32_t doc_width, const char* psg_ids, int32_t psg_width, int64_t n, int32_t world,
+                         int32_t n_threads, uint8_t* owner);
 /* The same numbering for n 8-byte values (the key is the value itself): codes[i] = number of values[i], dense;
  * first_row[c] = a row that holds number c (first_row must hold n entries at most).  A column of a pandas frame is an
  * array of pointers to string objects shared by many rows: numbering the pointers leaves only the distinct objects to

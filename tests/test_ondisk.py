@@ -270,6 +270,52 @@ def test_hdf5_index_scores_like_the_same_data_in_memory():
             assert np.float32(s) == fo.dot_f32(qv2[qi], decoded[int(doc[1:])])
 
 
+@pytest.mark.parametrize("kind", ["container", "hdf5"])
+def test_shard_views_partition_the_file_and_its_id_tables(tmp_path, kind):
+    """``OnDiskIndex.load(..., shard=(rank, world))``: the view a rank of a sharded index opens.  Over all ranks the views
+    partition the rows (by crc32 of the document id, of the passage id for rows without one -- the placement of
+    ``sharded._owner_of``, so a document's passages share a rank); a view interns ONLY the ids of its own rows (the id
+    tables are sharded with the rows: ~N / world strings per rank, not N), numbers its rows locally in file order, reads
+    them through its row map, and refuses ``add``.  CPU only."""
+    from fast_forward_amd.sharded import _owner_of
+
+    if kind == "hdf5":
+        path, n = H5 / "big_f64.h5", 1400
+        whole = OnDiskIndex.load(path)
+    else:
+        rng = np.random.default_rng(8)
+        n = 1000
+        path = tmp_path / "i.ffx"
+        w = OnDiskIndex(path, chunk_size=128, max_id_length=10, overwrite=True)
+        docs = [f"doc{rng.integers(0, 300)}" if i % 9 else None for i in range(n)]
+        w.add(rng.standard_normal((n, 16)).astype(np.float32), doc_ids=docs, psg_ids=[f"psg{i}" for i in range(n)])
+        del w
+        whole = OnDiskIndex.load(path)
+    all_docs, all_psgs = whole._ids.row_ids(n)
+    world = 3
+    seen = np.zeros(n, dtype=int)
+    strings = 0
+    for rank in range(world):
+        view = OnDiskIndex.load(path, shard=(rank, world))
+        rows = view._row_map
+        assert len(view) == rows.shape[0] and (np.diff(rows) > 0).all()
+        seen[rows] += 1
+        want = [r for r in range(n) if _owner_of(all_docs[r], all_psgs[r], world) == rank]
+        assert rows.tolist() == want
+        docs_v, psgs_v = view._ids.row_ids(len(view))
+        assert list(docs_v) == [all_docs[r] for r in want] and list(psgs_v) == [all_psgs[r] for r in want]
+        assert view.doc_ids <= whole.doc_ids and view.psg_ids <= whole.psg_ids
+        strings += len(view.doc_ids) + len(view.psg_ids)
+        some = np.arange(0, len(view), 7)
+        assert np.array_equal(view._read_rows(some), whole._read_rows(rows[some]))
+        with pytest.raises(RuntimeError):
+            view.add(np.zeros((1, view.dim), dtype=np.float32), doc_ids=["x"], psg_ids=["y"])
+    assert (seen == 1).all()
+    assert strings == len(whole.doc_ids) + len(whole.psg_ids)  # every id string lives on exactly one rank
+    with pytest.raises(ValueError):
+        OnDiskIndex.load(path, shard=(3, 3))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_on_disk_index_equals_the_in_memory_index(tmp_path, world):

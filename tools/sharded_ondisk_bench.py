@@ -52,6 +52,15 @@ from fast_forward_amd.encoder import ArrayEncoder  # noqa: E402
 from fast_forward_amd.index import Mode, OnDiskIndex  # noqa: E402
 from fast_forward_amd.sharded import ShardedOnDiskIndex, connect  # noqa: E402
 
+def rss_mb() -> float:
+    """Resident set of this process (host memory), MB."""
+    with open("/proc/self/status") as f:
+        for line in f:
+            if line.startswith("VmRSS:"):
+                return int(line.split()[1]) / 1024.0
+    return 0.0
+
+
 comm = connect("host")
 rank, world = comm.rank, comm.world
 rng = np.random.default_rng(0)
@@ -69,11 +78,14 @@ comm.barrier()
 qv = np.random.default_rng(1).standard_normal((args.queries, args.dim), dtype=np.float32) * np.float32(0.036)
 enc = ArrayEncoder({f"q{i:04d}": qv[i] for i in range(args.queries)})
 first = make_run(np.random.default_rng(2), args.rows, args.queries, args.k)
+rss_before = rss_mb()
 t0 = time.perf_counter()
 sharded = ShardedOnDiskIndex(args.file, comm, enc, resident=True)
 t_load = time.perf_counter() - t0
 shard_gb = int(sharded.rows_per_rank[rank]) * args.dim * 4 / 1e9
-loads = comm.allgather_array(np.array([t_load, shard_gb]))
+# host memory the opened shard costs this rank: its id tables (only the ids of its own rows) + its row map
+ids_held = len(sharded.local.doc_ids) + len(sharded.local.psg_ids)
+loads = comm.allgather_array(np.array([t_load, shard_gb, rss_mb() - rss_before, float(ids_held)]))
 sharded.rerank(first, 0.1)  # warm-up: plans, resolved candidates
 comm.barrier()
 t0 = time.perf_counter()
@@ -93,8 +105,11 @@ stats = streamed.local.last_stats or {}
 streamed.close()
 agree = comm.allreduce([1.0 if same else 0.0], 2)[0] == 1.0  # OP_MIN
 if rank == 0:
-    out["open_and_load_shard_s_per_rank (ids of the whole file + this rank's rows to HBM)"] = loads[:, 0].tolist()
+    out["open_and_load_shard_s_per_rank (the file's id columns scanned, this rank's ids interned, its rows to HBM)"] = loads[:, 0].tolist()
     out["shard_gb_per_rank"] = loads[:, 1].tolist()
+    out["host_rss_growth_mb_per_rank"] = loads[:, 2].tolist()
+    out["id_strings_interned_per_rank"] = [int(x) for x in loads[:, 3]]
+    out["id_strings_in_the_file"] = args.rows
     out["resident_rerank_s"] = t_resident
     out["resident_queries_per_s"] = args.queries / t_resident
     out["streamed_rerank_s"] = t_streamed
