@@ -53,10 +53,11 @@ from fast_forward_amd.index import Mode, OnDiskIndex  # noqa: E402
 from fast_forward_amd.sharded import ShardedOnDiskIndex, connect  # noqa: E402
 
 def rss_mb() -> float:
-    """Resident set of this process (host memory), MB."""
+    """Private (anonymous) resident memory of this process, MB: what its tables and strings cost.  Pages of the mapped
+    index file are shared page cache (RssFile) and would only say how much of the file the rank has touched."""
     with open("/proc/self/status") as f:
         for line in f:
-            if line.startswith("VmRSS:"):
+            if line.startswith("RssAnon:"):
                 return int(line.split()[1]) / 1024.0
     return 0.0
 
@@ -107,7 +108,7 @@ agree = comm.allreduce([1.0 if same else 0.0], 2)[0] == 1.0  # OP_MIN
 if rank == 0:
     out["open_and_load_shard_s_per_rank (the file's id columns scanned, this rank's ids interned, its rows to HBM)"] = loads[:, 0].tolist()
     out["shard_gb_per_rank"] = loads[:, 1].tolist()
-    out["host_rss_growth_mb_per_rank"] = loads[:, 2].tolist()
+    out["host_private_memory_growth_mb_per_rank"] = loads[:, 2].tolist()
     out["id_strings_interned_per_rank"] = [int(x) for x in loads[:, 3]]
     out["id_strings_in_the_file"] = args.rows
     out["resident_rerank_s"] = t_resident
