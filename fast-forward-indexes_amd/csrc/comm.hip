@@ -39,6 +39,7 @@
 #include "../../include/ffx.h"
 
 int ffx_fail(int code, const char* fmt, ...);  // ffx.hip
+bool ffx_debug_variant(const char* name, long long* value);  // ffx.hip: the FFX_DEBUG_VARIANT list of A/B switches
 
 namespace {
 
@@ -1130,7 +1131,7 @@ int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, cons
   const int64_t P = pair_off[n_queries];
   s->send_counts.assign((size_t)world, 0);
   s->recv_counts.assign((size_t)world, 0);
-  if (!holder && !s->doc_bounds.empty() && !getenv("FFX_ROUTE_HOST")) {
+  if (!holder && !s->doc_bounds.empty() && !ffx_debug_variant("route_host", nullptr)) {
     // document-range shards: the batch is routed on the device from one upload of its ids
     if (pair_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "pair_off[0] must be 0");
     for (int64_t q = 0; q < n_queries; ++q)

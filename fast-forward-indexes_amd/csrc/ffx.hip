@@ -60,6 +60,38 @@ int ffx_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// FFX_DEBUG_VARIANT -- the ONE environment knob for A/B switches (tests, tools/*.py; never needed in production).
+// A comma-separated list of words, `name` or `name=N`:
+//   no_small_path          ffx_score never takes the single-submission path of small batches
+//   route_host             the sharded scorer routes a batch on the host even for document-range shards
+//   pq_no_fuse, pq_no_adc  product-quantized rows: unfused exact ADC / decode-then-dot instead of exact ADC
+//   generic_staged, generic_plain   the round-1 generic exact kernels instead of the any-d / segment kernels
+//   anyd_u=N               loads in flight per wave of the any-d kernel (2, 4, 8)
+//   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
+//   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N   where the per-query sort switches form
+//   score_slice_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out
+//                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py)
+//   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
+// (FFX_SCORE_TRACE=1 -- a timeline on stderr -- and the operational settings FFX_COMM_TIMEOUT_S, FFX_RDZV_DIR,
+// FFX_RDZV_KEY, FFX_READ_THREADS are not variants and keep their own names.)
+// True if `name` is in the list; *value (if given) receives N, or stays untouched for a bare word.
+bool ffx_debug_variant(const char* name, long long* value) {
+  const char* list = getenv("FFX_DEBUG_VARIANT");
+  if (!list || !*list) return false;
+  const size_t len = strlen(name);
+  for (const char* p = list; *p;) {
+    const char* end = strchr(p, ',');
+    const size_t n = end ? (size_t)(end - p) : strlen(p);
+    if (n >= len && strncmp(p, name, len) == 0 && (n == len || p[len] == '=')) {
+      if (value && n > len) *value = atoll(p + len + 1);
+      return true;
+    }
+    if (!end) break;
+    p = end + 1;
+  }
+  return false;
+}
+
 namespace {
 
 #define FFX_HIP(expr)                                                                         \
@@ -499,7 +531,7 @@ int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64
   FFX_HIP(hipSetDevice(idx->device));
   const size_t rb = (size_t)idx->dim * idx->elem;
   size_t want = (size_t)64 << 20;
-  if (const char* e = getenv("FFX_STAGE_BYTES")) want = std::max<size_t>(rb, (size_t)atoll(e));
+  if (long long v = 0; ffx_debug_variant("stage_bytes", &v)) want = std::max<size_t>(rb, (size_t)v);
   want = std::max(want, rb);
   if (idx->stage_bytes < want) {
     for (int i = 0; i < 2; ++i) {
@@ -1173,9 +1205,9 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     ffx::gather_dot_exact_kernel<T, LEAVES, NPER, U><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R); \
     pl->variant = ID + HALF;                                                                      \
   } while (0)
-  // tuning hook (tools/kernel_ab.py): FFX_GATHER_VARIANT selects an experimental d=768 instantiation
-  const char* exp_env = getenv("FFX_GATHER_VARIANT");
-  const int exp_variant = exp_env ? atoi(exp_env) : 0;
+  // tuning hook (tools/kernel_ab.py): FFX_DEBUG_VARIANT=gather=N selects an experimental d=768 instantiation
+  long long exp_value = 0;
+  const int exp_variant = ffx_debug_variant("gather", &exp_value) ? (int)exp_value : 0;  // tuning hook (tools/kernel_ab.py)
   if (exp_variant >= 800 && exp_variant < 900) {  // the strided-load form of the small-row dims, for A/B
     switch (d) {
       case 512: FFX_EXACT(4, 16, 2, 803); break;
@@ -1212,7 +1244,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 958: ffx::gather_dot_fast_kernel<T, 3, 8, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 959: ffx::gather_dot_fast_kernel<T, 3, 16, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      default: return fail(FFX_BAD_ARG, "unknown FFX_GATHER_VARIANT %d", exp_variant);
+      default: return fail(FFX_BAD_ARG, "unknown gather variant %d (FFX_DEBUG_VARIANT)", exp_variant);
     }
     pl->variant = exp_variant;
     FFX_HIP(hipGetLastError());
@@ -1270,14 +1302,15 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     else if (NL <= 4) FFX_ANYD_LG(4, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);    \
     else FFX_ANYD_LG(8, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);                 \
   } while (0)
-        const char* u_env = getenv("FFX_ANYD_U");  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
-        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !getenv("FFX_GENERIC_STAGED")) {
+        long long u_value = 0;  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
+        const bool u_env = ffx_debug_variant("anyd_u", &u_value);
+        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !ffx_debug_variant("generic_staged", nullptr)) {
           const int* LS = pl->leaf_start.as<int>();
           const int* CS = pl->combine_steps.as<int>();
           const int nl = pl->n_leaves;
           // measured (profiles/r02/anyd_kernel_dims.json): 2 passes in flight win for 3 .. 7 leaves (d = 300: 5.09 vs
           // 4.59 TB/s, d = 520: 5.61 vs 5.20), 4 for one or two leaves and for long rows (d = 1000: 5.85 vs 5.65)
-          const int u_sel = u_env ? atoi(u_env) : ((nl >= 3 && d < 768) ? 2 : 4);
+          const int u_sel = u_env ? (int)u_value : ((nl >= 3 && d < 768) ? 2 : 4);
           FFX_ANYD_ANY(u_sel, pl->anyd_tails, 0, LS, nl, CS, rs);
           pl->variant = 130 + nl + HALF;
           break;
@@ -1287,7 +1320,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         // any-d kernel (one launch per segment over all rows: a segment is >= 2 KB of consecutive bytes of a row),
         // and combine_tree_kernel adds the segment sums in the order of the recursion.  Bit-identical to NumPy; the
         // staged generic kernel it replaces walked every row out of LDS with one wave (1 - 3.5 TB/s).
-        if (!pl->ov_dim && !pl->segments.empty() && !getenv("FFX_GENERIC_STAGED")) {
+        if (!pl->ov_dim && !pl->segments.empty() && !ffx_debug_variant("generic_staged", nullptr)) {
           const int G = (int)pl->segments.size();
           FFX_TRY(pl->rs_v.ensure((size_t)G * (size_t)R * sizeof(float)));
           const int* tab = pl->seg_tables.as<int>();
@@ -1296,7 +1329,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
             const int* LS = tab + sg.table_at;
             const int* CS = tab + sg.steps_at;
             const int nl = sg.n_leaves;
-            const int u_sel = u_env ? atoi(u_env) : ((nl >= 3 && sg.len < 768) ? 2 : 4);
+            const int u_sel = u_env ? (int)u_value : ((nl >= 3 && sg.len < 768) ? 2 : 4);
             float* out = pl->rs_v.as<float>() + (size_t)g * R;
             FFX_ANYD_ANY(u_sel, sg.tails, sg.col0, LS, nl, CS, out);
             FFX_HIP(hipGetLastError());
@@ -1314,7 +1347,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         while (RP > 1 && (size_t)RP * (2 * dp + lp) * sizeof(float) > (12 << 10)) RP /= 2;  // keep 4 waves per block
         const size_t per_wave = (size_t)RP * (2 * dp + lp) * sizeof(float);
         const int waves = (int)std::min<size_t>(4, (48 << 10) / per_wave);
-        if (waves >= 1 && !getenv("FFX_GENERIC_PLAIN")) {
+        if (waves >= 1 && !ffx_debug_variant("generic_plain", nullptr)) {
           const int rows_per_wave = 8 * RP;
           ffx::gather_dot_exact_generic_staged_kernel<T><<<blocks_for(R, waves * rows_per_wave), 64 * waves, per_wave * waves, st>>>(
               V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>(), dp, lp, rows_per_wave, RP);
@@ -1354,12 +1387,12 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
 
 // product-quantized rows: decode-then-dot (exact, variants 21xx) or ADC (fast, 2300)
 // subspaces == leaves of NumPy's tree (every leaf has length Ds, M in {1,2,4,8,16}): exact ADC applies
-// (FFX_PQ_NO_ADC forces decode-then-dot: tests and A/B)
+// (FFX_DEBUG_VARIANT=pq_no_adc forces decode-then-dot: tests and A/B)
 static bool pq_exact_adc_applies(const ffx_plan* pl) {
   const ffx_index* ix = pl->idx;
   if (ix->dtype != FFX_DTYPE_PQ8) return false;
   const int d = ix->qdim, M = ix->dim, Ds = ix->pq_ds;
-  bool aligned = !getenv("FFX_PQ_NO_ADC") && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
+  bool aligned = !ffx_debug_variant("pq_no_adc", nullptr) && Ds <= 128 && pl->n_leaves == M && (M == 1 || M == 2 || M == 4 || M == 8 || M == 16);
   if (aligned) {
     std::vector<int> bounds;
     numpy_leaf_plan(0, d, bounds);
@@ -1506,7 +1539,7 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
   int64_t device_wide_from = 16 << 10;
-  if (const char* e = getenv("FFX_SORT_DEVICE_WIDE_FROM")) device_wide_from = atoll(e);  // A/B hook
+  if (long long v = 0; ffx_debug_variant("sort_device_wide_from", &v)) device_wide_from = (int64_t)v;  // A/B hook
   if (max_len > device_wide_from) {
     // words in / words out share `sorted_keys` (2 x 8 bytes per pair)
     FFX_TRY(sorted_keys.ensure(2 * pb * sizeof(unsigned long long)));
@@ -1527,10 +1560,10 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
   // rocPRIM's segmented sort at 7 M pairs (tools/sort_ab.py): k = 256: 0.078 vs 0.214 ms, 1000: 0.090 vs
   // 0.150, 5000: 0.102 vs 0.365 (6980 x 5000: 0.45 vs 1.37 ms); rocPRIM wins below ~128 candidates per
   // query (k = 100: 0.115 vs 0.179, k = 10: 0.77 vs 1.63) where it packs many queries into a workgroup.
-  // FFX_SORT_BLOCK_FROM / _TO move the window (A/B hook)
+  // FFX_DEBUG_VARIANT=sort_block_from=N / sort_block_to=N move the window (A/B hook)
   int64_t block_from = 129, block_to = 8192;
-  if (const char* e = getenv("FFX_SORT_BLOCK_FROM")) block_from = atoll(e);
-  if (const char* e = getenv("FFX_SORT_BLOCK_TO")) block_to = atoll(e);
+  if (long long v = 0; ffx_debug_variant("sort_block_from", &v)) block_from = (int64_t)v;
+  if (long long v = 0; ffx_debug_variant("sort_block_to", &v)) block_to = (int64_t)v;
   if (max_len >= block_from && max_len <= std::min<int64_t>(block_to, 8192) && n_queries > 0) {
     const unsigned nq = (unsigned)n_queries;
     if (max_len <= 256) ffx::block_sort_desc_kernel<64, 4><<<nq, 64, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
@@ -1571,7 +1604,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   pl->ran = false;
   FFX_HIP(hipEventRecord(pl->ev[0], st));
   // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
-  const bool pq_fused = single && P > 0 && !getenv("FFX_PQ_NO_FUSE") && pq_exact_adc_applies(pl);
+  const bool pq_fused = single && P > 0 && !ffx_debug_variant("pq_no_fuse", nullptr) && pq_exact_adc_applies(pl);
   if (pq_fused) {
     hipEvent_t* recent_pq = pl->recent[pl->n_runs % ffx_plan::kRecent];
     if (!recent_pq[0]) {
@@ -2164,7 +2197,7 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
   *handled = false;
   const int64_t P = pair_off[n_queries];
   const bool one_row = mode == FFX_MODE_PASSAGE || mode == FFX_MODE_FIRSTP || idx->max_doc_rows <= 1;
-  if (!one_row || P == 0 || n_queries == 0 || !host_queries || !pair_ids || getenv("FFX_NO_SMALL_PATH")) return FFX_OK;
+  if (!one_row || P == 0 || n_queries == 0 || !host_queries || !pair_ids || ffx_debug_variant("no_small_path", nullptr)) return FFX_OK;
   if (mode == FFX_MODE_PASSAGE ? idx->n_psgs == 0 : idx->n_docs == 0) return FFX_OK;  // the general path words that error
   const size_t q_bytes = (size_t)n_queries * idx->qdim * sizeof(float), off_bytes = (size_t)(n_queries + 1) * sizeof(int64_t), p_bytes = (size_t)P * 4;
   const size_t in_bytes = q_bytes + off_bytes + p_bytes * (sparse ? 2 : 1) + 4 * 64;
@@ -2285,10 +2318,10 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     else
       (void)hipGetLastError();  // an ordinary pointer is "invalid value" to the runtime: not an error here
   }
-  if (const char* e = getenv("FFX_SCORE_SLICE_PAIRS")) per_slice = std::max<int64_t>(1, atoll(e));
+  if (long long v = 0; ffx_debug_variant("score_slice_pairs", &v)) per_slice = std::max<int64_t>(1, (int64_t)v);
   // ... and the first and last slices are smaller (an eighth of a slice, doubling / halving): the device idles
   // while the first slice is uploaded and the caller idles while the last one's results come back
-  const int64_t ramp_base = getenv("FFX_SCORE_NO_RAMP") ? per_slice : std::max<int64_t>(per_slice / 8, 1);
+  const int64_t ramp_base = ffx_debug_variant("score_no_ramp", nullptr) ? per_slice : std::max<int64_t>(per_slice / 8, 1);
   auto slice_target = [&](size_t i, int64_t first_pair) {
     const int64_t up = i < 8 ? ramp_base << i : per_slice;
     const int64_t down = std::max<int64_t>(ramp_base, (P - first_pair) / 2);
@@ -2309,7 +2342,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   // together and free their plans together, so the device again idles while the next group is uploaded (23.1 ms).
   // Uploads stay on each plan's own stream (they are awaited by the caller before the kernels are issued).
   bool async_out = false;
-  if (n_slices > 1 && !getenv("FFX_SCORE_NO_OUT_STREAM")) {
+  if (n_slices > 1 && !ffx_debug_variant("score_no_out_stream", nullptr)) {
     const void* any = out_ff ? (const void*)out_ff : out_interp ? (const void*)out_interp : (const void*)out_order;
     hipPointerAttribute_t attr;
     if (any && hipPointerGetAttributes(&attr, any) == hipSuccess && attr.type == hipMemoryTypeHost)
@@ -2320,11 +2353,11 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   if (async_out && !idx->out_stream) {
     int least = 0, greatest = 0;
     FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, getenv("FFX_SCORE_OUT_PRIORITY_LOW") ? least : greatest));
+    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
     if (!idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
     for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order) && !getenv("FFX_SCORE_BLOCKING_OUT");
+  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order) && !ffx_debug_variant("score_blocking_out", nullptr);
   if (threaded_out && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
   const int n_plans = n_slices > 1 ? (async_out || threaded_out ? 3 : 2) : 1;
   for (int i = 0; i < n_plans; ++i)

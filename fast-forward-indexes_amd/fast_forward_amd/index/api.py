@@ -41,9 +41,6 @@ class Mode(Enum):
     AVEP = 4
 
 
-_CODED_MIN_ROWS = 4096  # from here on results are returned in coded form (the frame is built on first use)
-
-
 def _in_final_order(q_order: Sequence[str]) -> bool:
     """Query ids strictly descending: the order a ``Ranking`` the constructor sorted has
     (ranking.py:115-117).  A user-built ``Ranking(..., is_sorted=True)`` need not be."""
@@ -59,6 +56,64 @@ def _grouped_by_query(q_no: np.ndarray, n_queries: int):
     if (np.diff(q_no) >= 0).all():
         return None, pair_off
     return np.argsort(q_no, kind="stable"), pair_off
+
+
+class _Run:
+    """A ranking as an index scores it: integers only.  Queries numbered in order of first appearance (base.py:418-421)
+    with their vectors, rows GROUPED by query number (``perm``: the rows of ``ranking`` in that layout, None when they
+    already stand so; ``pair_off``: where every query's candidates start), ids as codes into a table of distinct
+    strings.  Whatever the ranking holds inside (a coded form or a pandas frame), this is the one form the scoring
+    routes see, and ``result`` is the one way back: a coded ``Ranking`` (its frame of strings is built if and when
+    somebody asks for it)."""
+
+    def __init__(self, index: "Index", ranking: Ranking):
+        self.ranking = ranking
+        self.q_no, self.q_order, self.texts = index._numbered_queries(ranking)
+        self.n_q = len(self.q_order)
+        self.query_vectors = np.ascontiguousarray(index.encode_queries(self.texts)) if self.n_q else np.zeros((0, index.dim or 0), dtype=np.float32)
+        self.perm, self.pair_off = ranking._csr() if len(self.q_no) else (None, np.zeros(self.n_q + 1, dtype=np.int64))
+        self.codes, self.names = ranking._id_coding()
+
+    def grouped(self, per_row: np.ndarray) -> np.ndarray:
+        """A per-row array of the ranking in the grouped layout."""
+        if self.perm is None:
+            return per_row
+        from fast_forward_amd import native
+
+        return native.take32(np.ascontiguousarray(per_row), self.perm.astype(np.int32)) if per_row.dtype.itemsize == 4 else per_row[self.perm]
+
+    def batches(self, batch_size: "int | None"):
+        """(first query, one past the last) of every device call: all queries at once, or ``batch_size`` at a time
+        (base.py:445-459; an empty batch is a no-op here, the reference raises on one)."""
+        step = self.n_q if (batch_size is None or batch_size >= self.n_q) else max(1, int(batch_size))
+        return [(qa, min(self.n_q, qa + step)) for qa in range(0, self.n_q, max(1, step))]
+
+    def result(self, name, kept: np.ndarray, scores: np.ndarray, off: np.ndarray, q_range: "tuple[int, int] | None" = None) -> Ranking:
+        """The ``Ranking`` of the rows ``kept`` (positions in the grouped layout; query after query in query-number
+        order, ``off[q]`` .. ``off[q+1]`` those of query q of ``q_range``, inside a query in their final order) with
+        ``scores``.  Queries without a kept row disappear; the queries are put in descending id order if they do not
+        stand so already (ranking.py:115-117)."""
+        from fast_forward_amd import native
+
+        q_lo, q_hi = q_range if q_range is not None else (0, self.n_q)
+        counts = np.diff(off)
+        present = np.flatnonzero(counts)
+        q_order = [self.q_order[q_lo + i] for i in present]
+        src = kept if self.perm is None else self.perm[kept]  # rows of the ranking
+        if not _in_final_order(q_order):  # lay the queries' blocks out in descending id order
+            by_name = sorted(range(len(present)), key=lambda i: q_order[i], reverse=True)
+            blocks = present[by_name]
+            pick = np.concatenate([np.arange(off[q], off[q + 1]) for q in blocks]) if len(blocks) else np.zeros(0, dtype=np.int64)
+            src, scores, present, q_order = src[pick], scores[pick], blocks, [q_order[i] for i in by_name]
+            counts_out = counts[blocks]
+        else:
+            counts_out = counts[present]
+        q_no = np.repeat(np.arange(len(present), dtype=np.int64), counts_out)
+        texts = None if self.texts is None else [self.texts[q_lo + i] for i in present]
+        codes = native.take32(self.codes, src) if src.dtype == np.int32 else self.codes[src]
+        out = Ranking._assemble_coded(name, q_no, q_order, codes, self.names, scores.astype(self.ranking._score_dtype(), copy=False), texts,
+                                      self.ranking._id_blob(self.names))
+        return out, src
 
 
 class Index(abc.ABC):
@@ -212,15 +267,14 @@ class Index(abc.ABC):
 
     def _compute_scores(self, data: pd.DataFrame, query_vectors: np.ndarray) -> pd.DataFrame:
         """``data`` (columns ``id``, ``q_no``, ...) plus an ``ff_score`` column: the dense score of
-        every row in the current mode (the contract of base.py:279-314, computed on the device)."""
+        every row in the current mode (the contract of base.py:279-314, computed on the device).  The frame form of
+        ``_score_pairs`` for code written against the reference's internals; ``__call__`` itself works on integers."""
         out = data.copy()
         if len(out) == 0:
             out["ff_score"] = np.zeros(0, dtype=np.float32)
             return out
         q_no = out["q_no"].to_numpy(dtype=np.int64)
-        # __call__ resolves the whole ranking once and passes the ordinals along
-        ordinals = out.pop("_ord").to_numpy(dtype=np.int32) if "_ord" in out.columns else \
-            self._resolve_ids(out["id"].to_numpy(), self.mode)
+        ordinals = self._resolve_ids(out["id"].to_numpy(), self.mode)
         perm, pair_off = _grouped_by_query(q_no, query_vectors.shape[0])
         dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals if perm is None else ordinals[perm], self.mode)
         if perm is not None:
@@ -234,30 +288,40 @@ class Index(abc.ABC):
                         depths: Iterable[int]) -> pd.DataFrame:
         """Frame form of :meth:`_early_stopping_scores` (columns ``id``, ``q_no``, ``score`` in,
         plus ``ff_score`` out; NaN where a candidate was not scored)."""
-        out = df.drop(columns=["_ord"], errors="ignore")
+        out = df.copy()
         out["ff_score"] = self._early_stopping_scores(df["id"].to_numpy(), df["q_no"].to_numpy(dtype=np.int64), df["score"].to_numpy(),
                                                       query_vectors, cutoff, alpha, depths)
         return out
 
     def _early_stopping_scores(self, ids: np.ndarray, q_no: np.ndarray, sparse: np.ndarray, query_vectors: np.ndarray,
                                cutoff: int, alpha: float, depths: Iterable[int]) -> np.ndarray:
-        """Score each query only as deep as needed for its top-``cutoff`` (base.py:316-387).
+        """Array form of early stopping (base.py:316-387): the dense scores in row order, NaN for the candidates that
+        were never scored.  Rows of a query need not be adjacent; inside a query they stand in first-stage rank order."""
+        n_q = query_vectors.shape[0]
+        perm, pair_off = _grouped_by_query(np.asarray(q_no), n_q)
+        ids_g = ids if perm is None else ids[perm]
+        rows, kept = self._early_stopping_kept(lambda p: ids_g[p], sparse if perm is None else sparse[perm], pair_off, query_vectors, cutoff, alpha,
+                                               depths, self._lookup_optional(ids_g, self.mode).astype(np.int32))
+        ff = np.full(len(q_no), np.nan, dtype=np.float32)
+        ff[rows if perm is None else perm[rows]] = kept
+        return ff
 
-        Depth intervals ``[a, b)`` over the sorted depths ``>= cutoff``; after the first
-        interval a query continues only while its ``cutoff``-th best interpolated score is below
-        the best it could still reach, ``alpha * s_last + (1 - alpha) * max_dense`` (``s_last``:
-        sparse score of the last scored candidate).  Returns the dense scores in row order, NaN
-        for candidates that were never scored.  Ids are resolved interval by interval, so -- as in
-        the reference -- an id that is never reached is never looked up."""
-        n, n_q = q_no.shape[0], query_vectors.shape[0]
-        perm, pair_off = _grouped_by_query(q_no, n_q)
-        if perm is None:
-            rank_in_q = np.arange(n, dtype=np.int64) - pair_off[q_no]
-        else:
-            rank_in_q = pd.Series(q_no).groupby(q_no, sort=False).cumcount().to_numpy()
-        # dense scores are float32 (as the reference's np.sum over float32 vectors); the criterion below is the
-        # reference's SCALAR expression `python_float * np.float32` under the chosen NumPy promotion
-        # (early_stopping_promotion): float64 products and sum under numpy < 2, float32 throughout under numpy >= 2
+    def _early_stopping_kept(self, id_at, sparse: np.ndarray, pair_off: np.ndarray, query_vectors: np.ndarray, cutoff: int, alpha: float,
+                             depths: Iterable[int], ordinals: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """Score each query only as deep as needed for its top-``cutoff`` (base.py:316-387): (the candidates that got
+        scored, ascending; their dense scores).  Candidates stand grouped by query (``pair_off``), in first-stage rank
+        order inside a query; ``ordinals`` may hold -1 for an id the index does not know -- as in the reference (which
+        looks ids up chunk by chunk, base.py:362-370) that is an ``IndexError`` only if the candidate is reached
+        (``id_at(position)`` names it).
+
+        Depth intervals ``[a, b)`` over the sorted depths ``>= cutoff``; after the first interval a query continues only
+        while its ``cutoff``-th best interpolated score is below the best it could still reach,
+        ``alpha * s_last + (1 - alpha) * max_dense`` (``s_last``: first-stage score of its last scored candidate),
+        evaluated under ``early_stopping_promotion``; an interval without candidates ends the loop.  This is the NumPy
+        statement; ``InMemoryIndex`` keeps all of it on the device."""
+        n, n_q = int(pair_off[-1]), query_vectors.shape[0]
+        q_of = np.repeat(np.arange(n_q, dtype=np.int64), np.diff(pair_off))
+        rank_in_q = np.arange(n, dtype=np.int64) - pair_off[q_of]
         bound_f32 = self._es_bound_f32()
         ff = np.full(n, np.nan, dtype=np.float32)
         interp = np.full(n, np.nan, dtype=np.result_type(sparse.dtype, np.float32))
@@ -267,19 +331,16 @@ class Index(abc.ABC):
             if b < cutoff:
                 continue
             if a > 0:
-                # continue-criterion for all queries at once.  Scored rows, grouped by query:
-                rows = np.flatnonzero(~np.isnan(ff))
-                rows = rows[np.argsort(q_no[rows], kind="stable")]          # frame order kept inside a query
-                qs = q_no[rows]
+                # continue-criterion for all queries at once, over the scored prefix [0, min(len, a)) of every query
+                ends = np.minimum(pair_off[1:], pair_off[:-1] + a)
+                present = np.flatnonzero(active & (pair_off[1:] > pair_off[:-1]))
+                rows = np.flatnonzero(active[q_of] & (rank_in_q < a))  # (every row of a still-active query below depth a has been scored)
+                qs = q_of[rows]
                 starts = np.flatnonzero(np.r_[True, qs[1:] != qs[:-1]])
-                ends = np.r_[starts[1:], rows.size]
-                present = qs[starts]
-                # cutoff-th best interpolated score so far (the worst one if fewer were scored)
+                stops = np.r_[starts[1:], rows.size]
                 by_score = rows[np.lexsort((-interp[rows].astype(np.float64), qs))]
-                kth = interp[by_score[np.minimum(starts + cutoff, ends) - 1]]
-                # best it could still reach: alpha * (sparse score of the last scored candidate) +
-                # (1 - alpha) * (best dense score so far) -- NumPy scalar promotion as in the reference
-                last_sparse = sparse[rows[ends - 1]]
+                kth = interp[by_score[np.minimum(starts + cutoff, stops) - 1]]  # cutoff-th best so far (the worst, if fewer)
+                last_sparse = sparse[ends[present] - 1]
                 best_dense = np.maximum.reduceat(ff[rows], starts)
                 if bound_f32:  # (arrays times a Python float keep their dtype under either NumPy)
                     bound = alpha * last_sparse + (1 - alpha) * best_dense
@@ -289,170 +350,80 @@ class Index(abc.ABC):
                 keep[present] = kth < bound
                 active &= keep
             LOGGER.info("depth %s: %s queries left", b, int(active.sum()))
-            take = np.flatnonzero(active[q_no] & (rank_in_q >= a) & (rank_in_q < b))
+            take = np.flatnonzero(active[q_of] & (rank_in_q >= a) & (rank_in_q < b))
             if take.size == 0:
                 break
-            part_perm, part_off = _grouped_by_query(q_no[take], n_q)
-            if part_perm is not None:
-                take = take[part_perm]
-            chunk_ff, _, _ = self._score_pairs(query_vectors, part_off, self._resolve_ids(ids[take], self.mode), self.mode)
+            unknown = np.flatnonzero(ordinals[take] < 0)
+            if unknown.size:
+                raise IndexError(f"ID {id_at(int(take[unknown[0]]))} not found in the index.")
+            part_off = np.zeros(n_q + 1, dtype=np.int64)
+            np.cumsum(np.bincount(q_of[take], minlength=n_q), out=part_off[1:])
+            chunk_ff, _, _ = self._score_pairs(query_vectors, part_off, np.ascontiguousarray(ordinals[take], dtype=np.int32), self.mode)
             ff[take] = chunk_ff
             interp[take] = alpha * sparse[take] + (1 - alpha) * chunk_ff
             a = b
-        return ff
+        rows = np.flatnonzero(~np.isnan(ff))
+        return rows, ff[rows]
 
     def __call__(self, ranking: Ranking, early_stopping: int | None = None, early_stopping_alpha: float | None = None,
                  early_stopping_depths: Iterable[int] | None = None, batch_size: int | None = None) -> Ranking:
         """Dense scores for every (query, candidate) of ``ranking`` (base.py:389-469).
 
         ``ValueError``: ranking without queries; early stopping without alpha/depths.
-        ``IndexError``: a candidate id that is not in the index (raised before any device work).
-        """
+        ``IndexError``: a candidate id that is not in the index (raised before any device work; with early stopping, as
+        in the reference, only for a candidate that gets scored).
+
+        One route for every ranking: ids travel as integer codes (``_Run``), every batch of queries is one device call
+        that scores and orders (``_score_pairs``, or ``_early_stopping_kept``), and the result is assembled in coded
+        form -- no Python string per row on the way in or out; its frame is built on first use."""
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
         if early_stopping is not None and (early_stopping_alpha is None or early_stopping_depths is None):
             raise ValueError("Early stopping requires alpha and depths.")
+        from fast_forward_amd import native
+
         t0 = perf_counter()
-
-        q_no, q_order, texts = self._numbered_queries(ranking)
-        query_vectors = np.ascontiguousarray(self.encode_queries(texts))
-        n_q = len(texts)
-        grouped, block_off = ranking._csr() if len(q_no) > 0 else (0, None)
-        final_order = _in_final_order(q_order)
-        if (early_stopping is None and grouped is None and final_order and len(q_no) >= _CODED_MIN_ROWS
-                and (batch_size is None or batch_size >= n_q)):
-            # a large run in the constructor's order: integer codes in, integer codes out -- no Python string
-            # per row on the way to the device, none on the way back (the frame is built on first use)
-            codes, names = ranking._id_coding()
-            dense, _, order = self._score_pairs(query_vectors, block_off, self._ordinals_of_codes(ranking, codes, names), self.mode, sort=True,
-                                                **self._reuse_kw())
-            from fast_forward_amd import native
-
-            # `order` is a permutation inside every query: the query numbers stay as they are
-            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            out = Ranking._assemble_coded("fast-forward", q_no, q_order, native.take32(codes, order), names,
-                                          native.take32(dense, order).astype(ranking._score_dtype(), copy=False), texts)
-            # row i of the result is row order[i] of `ranking`: ranking.interpolate(result, alpha) needs no join
-            if order.base is not None and getattr(self, "_result_buffers", None) is not None:
-                # `order` is a view of the index's re-used result block: the result borrows it until the index needs the
-                # block again (then it gets its own copy, InMemoryIndex._result_buffers) -- the interpolate that usually
-                # follows at once reads it in place
-                out._source_rows = (weakref.ref(ranking), order)
-                self._order_borrower = weakref.ref(out)
-            else:
-                out._source_rows = (weakref.ref(ranking), order.copy())
-            return out
-        if (early_stopping is not None and final_order and grouped is None and len(q_no) >= _CODED_MIN_ROWS and (batch_size is None or batch_size >= n_q)
-                and getattr(self, "_early_stopping_takes_ordinals", False) and ranking._score_dtype() == np.float32):
-            # a large run, early stopping resident on the device: codes in, codes out (no frame, no Python string per row)
-            from fast_forward_amd import native
-
-            codes, names = ranking._id_coding()
-            lenient = self._ordinals_of_codes(ranking, codes, names, missing_ok=True)
-            if hasattr(self, "_early_stopping_scored"):  # only the scored candidates come back, compacted on the device
-                rows, kept_scores = self._early_stopping_scored(lambda p: names[codes[p]], q_no, ranking._scores(), query_vectors, early_stopping,
-                                                                early_stopping_alpha, early_stopping_depths, lenient, (None, block_off))
-            else:
-                ff = self._early_stopping_scores(lambda p: names[codes[p]], q_no, ranking._scores(), query_vectors, early_stopping, early_stopping_alpha,
-                                                 early_stopping_depths, ordinals=lenient, grouped=(None, block_off))
-                rows = np.flatnonzero(~np.isnan(ff)).astype(np.int32)  # the candidates that were scored, still grouped by query
-                kept_scores = native.take32(np.ascontiguousarray(ff), rows)
-            q_kept = np.asarray(q_no)[rows]
-            off = np.zeros(n_q + 1, dtype=np.int64)
-            np.cumsum(np.bincount(q_kept, minlength=n_q), out=off[1:])
-            order = native.host_order(kept_scores, off)  # score descending inside every query, ties by first-stage rank
-            src = native.take32(rows, order)
-            present = np.flatnonzero(np.diff(off))
-            renumber = np.full(n_q, -1, dtype=np.int64)
-            renumber[present] = np.arange(present.shape[0])
-            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            return Ranking._assemble_coded("fast-forward", renumber[q_kept], [q_order[i] for i in present], native.take32(codes, src), names,
-                                           native.take32(kept_scores, order).astype(ranking._score_dtype(), copy=False),
-                                           None if texts is None else [texts[i] for i in present])
-        df = ranking._df
-        if early_stopping is not None and len(df) > 0 and final_order and (batch_size is None or batch_size >= n_q or grouped is None):
-            # arrays in, arrays out: only the candidates that get scored are looked up and kept
-            ids_col, sparse_col = df["id"].to_numpy(), df["score"].to_numpy()
-            lenient = None
-            if len(df) >= _CODED_MIN_ROWS and getattr(self, "_early_stopping_takes_ordinals", False):
-                # a large run: its distinct ids are looked up once (unknown -> -1: an error only if reached)
-                lenient = self._ordinals_of_codes(ranking, *ranking._id_coding(), missing_ok=True)
-            extra = (lambda lo, hi: {}) if lenient is None else (lambda lo, hi: {"ordinals": lenient[lo:hi]})
-            if batch_size is None or batch_size >= n_q:
-                ff = self._early_stopping_scores(ids_col, q_no, sparse_col, query_vectors, early_stopping, early_stopping_alpha,
-                                                 early_stopping_depths, **extra(0, len(df)))
-            else:  # `batch_size` queries at a time
-                ff = np.full(len(df), np.nan, dtype=np.float32)
-                for qa in range(0, n_q, batch_size):
-                    pa, pb = int(block_off[qa]), int(block_off[min(n_q, qa + batch_size)])
-                    if pb > pa:
-                        ff[pa:pb] = self._early_stopping_scores(ids_col[pa:pb], q_no[pa:pb], sparse_col[pa:pb], query_vectors,
-                                                                early_stopping, early_stopping_alpha, early_stopping_depths, **extra(pa, pb))
-            rows = np.flatnonzero(~np.isnan(ff))
-            rows = rows[np.lexsort((-ff[rows].astype(np.float64), q_no[rows]))]  # q_no ascending = q_id descending
-            cols = {c: df[c].to_numpy()[rows] for c in ("q_id", "id")}
-            cols["score"] = ff[rows].astype(df.dtypes["score"], copy=False)
-            cols["query"] = df["query"].to_numpy()[rows]
-            present = np.flatnonzero(np.bincount(q_no[rows], minlength=n_q))
-            renumber = np.full(n_q, -1, dtype=np.int64)
-            renumber[present] = np.arange(present.shape[0])
-            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            return Ranking._assemble(cols, "fast-forward", renumber[q_no[rows]], [q_order[i] for i in present])
-        # ids -> ordinals once, for the whole ranking: an unknown id fails here, before any device
-        # work (the reference raises from its first batch; either way no partial result is returned)
-        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode) if early_stopping is None else None
-        if early_stopping is None and len(df) > 0 and (batch_size is None or batch_size >= n_q or _grouped_by_query(q_no, n_q)[0] is None):
-            # the common case without the intermediate frames: CSR in, scores out
-            perm, pair_off = _grouped_by_query(q_no, n_q)
-            if perm is None and final_order:
-                # rows of a query are adjacent and the queries already stand in their final order
-                # (a Ranking the constructor sorted: checked above), so the device's per-query order
-                # is the whole sort
-                if batch_size is None or batch_size >= n_q:
-                    dense, _, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sort=True)
-                else:
-                    # `batch_size` queries per device call (bounds the workspace, base.py:445-459)
-                    dense, order = np.empty(len(df), dtype=np.float32), np.empty(len(df), dtype=np.int64)
-                    for qa in range(0, n_q, batch_size):
-                        qb = min(n_q, qa + batch_size)
-                        pa, pb = int(pair_off[qa]), int(pair_off[qb])
-                        if pb > pa:
-                            part, _, part_order = self._score_pairs(query_vectors[qa:qb], pair_off[qa:qb + 1] - pa, ordinals[pa:pb],
-                                                                    self.mode, sort=True)
-                            dense[pa:pb], order[pa:pb] = part, part_order.astype(np.int64) + pa
-                cols = {c: df[c].to_numpy()[order] for c in ("q_id", "id")}
-                cols["score"] = dense[order].astype(df.dtypes["score"], copy=False)
-                cols["query"] = df["query"].to_numpy()[order]
-                LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-                return Ranking._assemble(cols, "fast-forward", q_no, q_order)
-            if perm is None:
-                dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals, self.mode)
-            else:
-                dense, _, _ = self._score_pairs(query_vectors, pair_off, ordinals[perm], self.mode)
-                unperm = np.empty_like(dense)
-                unperm[perm] = dense
-                dense = unperm
-            result = df.copy()
-            result["score"] = dense.astype(df.dtypes["score"], copy=False)
-            LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-            return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
-        work = df.assign(q_no=q_no) if ordinals is None else df.assign(q_no=q_no, _ord=ordinals)
-
-        def score(part: pd.DataFrame) -> pd.DataFrame:
-            if early_stopping is None:
-                return self._compute_scores(part, query_vectors)
-            return self._early_stopping(part, query_vectors, early_stopping, early_stopping_alpha, early_stopping_depths)
-
-        if batch_size is None or batch_size >= n_q:
-            result = score(work)
+        run = _Run(self, ranking)
+        off = run.pair_off
+        kept_parts, score_parts = [], []
+        if early_stopping is None:
+            ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
+            whole = len(run.batches(batch_size)) == 1
+            for qa, qb in run.batches(batch_size):
+                pa, pb = int(off[qa]), int(off[qb])
+                dense, _, order = self._score_pairs(run.query_vectors[qa:qb], off[qa:qb + 1] - pa, ordinals[pa:pb], self.mode, sort=True,
+                                                    **(self._reuse_kw() if whole else {}))
+                kept_parts.append(order if pa == 0 else order + np.int32(pa))
+                score_parts.append(native.take32(dense, order))
+            kept_off = off
         else:
-            # bound device workspace: `batch_size` queries per launch; an empty batch is a no-op
-            batch_of = work["q_no"].to_numpy() // batch_size
-            result = pd.concat([score(work[batch_of == b]) for b in range((n_q + batch_size - 1) // batch_size)])
-        result["score"] = result["ff_score"]
+            lenient = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names, missing_ok=True))
+            sparse, codes_g = run.grouped(ranking._scores()), run.grouped(run.codes)
+            for qa, qb in run.batches(batch_size):
+                pa, pb = int(off[qa]), int(off[qb])
+                rows, kept = self._early_stopping_kept(lambda p, pa=pa: run.names[codes_g[pa + p]], sparse[pa:pb], off[qa:qb + 1] - pa,
+                                                       run.query_vectors[qa:qb], early_stopping, early_stopping_alpha, early_stopping_depths, lenient[pa:pb])
+                kept_parts.append(rows.astype(np.int32) + np.int32(pa))
+                score_parts.append(kept)
+            rows = np.concatenate(kept_parts) if kept_parts else np.zeros(0, dtype=np.int32)
+            scores = np.concatenate(score_parts).astype(np.float32, copy=False) if score_parts else np.zeros(0, dtype=np.float32)
+            kept_off = np.searchsorted(rows, off).astype(np.int64)  # rows ascend: still grouped by query
+            order = native.host_order(scores, kept_off)  # score descending inside every query, exact ties by first-stage rank
+            kept_parts, score_parts = [native.take32(rows, order)], [native.take32(scores, order)]
+        kept = kept_parts[0] if len(kept_parts) == 1 else (np.concatenate(kept_parts) if kept_parts else np.zeros(0, dtype=np.int32))
+        scores = score_parts[0] if len(score_parts) == 1 else (np.concatenate(score_parts) if score_parts else np.zeros(0, dtype=np.float32))
+        out, src = run.result("fast-forward", kept, scores, kept_off)
         LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
-        # the pairs are those of `ranking`, already known to be unique
-        return Ranking(Ranking._trusted(result), name="fast-forward", dtype=df.dtypes["score"], copy=False, is_sorted=False)
+        if early_stopping is None:
+            # row i of the result is row src[i] of `ranking`: ranking.interpolate(result, alpha) needs no join.  When `src`
+            # still looks into the index's re-used result block, the result borrows it until the index needs the block
+            # again (InMemoryIndex._result_buffers then gives it its own copy): the interpolate that usually follows at once
+            # reads it in place
+            borrowed = src.base is not None and getattr(self, "_result_buffers", None) is not None and src is kept
+            out._source_rows = (weakref.ref(ranking), src if (borrowed or src.base is None) else np.array(src, dtype=np.int32))
+            if borrowed:
+                self._order_borrower = weakref.ref(out)
+        return out
 
     def _ordinals_of_codes(self, ranking: Ranking, codes: np.ndarray, names: np.ndarray, missing_ok: bool = False) -> np.ndarray:
         """Index ordinals of a ranking's rows through its id codes: the DISTINCT id strings are looked
@@ -500,55 +471,28 @@ class Index(abc.ABC):
         (optionally cut to the best ``cutoff`` per query).  Same scores, bit for bit."""
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
-        t = [perf_counter()]
-        q_no, q_order, texts = self._numbered_queries(ranking)
-        query_vectors = np.ascontiguousarray(self.encode_queries(texts))
-        perm, pair_off = ranking._csr()
-        t.append(perf_counter())
-        if perm is None and len(q_no) >= _CODED_MIN_ROWS and _in_final_order(q_order):
-            # a large run in the constructor's order: integer codes in, integer codes out, no Python string per row
-            codes, names = ranking._id_coding()
-            t.append(perf_counter())
-            ordinals = self._ordinals_of_codes(ranking, codes, names)
-            t.append(perf_counter())
-            sparse = np.ascontiguousarray(ranking._scores(), dtype=np.float32)
-            _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False,
-                                                 **self._reuse_kw())
-            t.append(perf_counter())
-            from fast_forward_amd import native
+        from fast_forward_amd import native
 
-            if cutoff is not None:
-                rank = np.arange(len(order)) - np.repeat(pair_off[:-1], np.diff(pair_off))
-                keep = rank < cutoff
-                order, q_no = order[keep], q_no[keep]  # (the device order is a permutation inside every query)
-            out = Ranking._assemble_coded(ranking.name, q_no, q_order, native.take32(codes, order), names,
-                                          native.take32(interp, order).astype(ranking._score_dtype(), copy=False), texts)
-            t.append(perf_counter())
-            # where a call's time went (seconds): a first call on a ranking pays for the distinct-id look-up, later ones do not
-            self.last_timings = dict(zip(("queries_numbered_and_encoded_s", "id_coding_s", "ids_to_ordinals_s", "upload_device_download_s", "result_gathers_s"),
-                                         np.diff(t).tolist()), **getattr(self, "_last_lookup_timings", {}))
-            return out
-        df = ranking._df
-        ordinals = self._resolve_ids(df["id"].to_numpy(), self.mode)
-        sparse = df["score"].to_numpy(dtype=np.float32)
-        if perm is not None:
-            ordinals, sparse = ordinals[perm], sparse[perm]
-        _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
-        src = order if perm is None else perm[order]
-        if cutoff is not None:
-            rank = np.arange(len(src)) - np.repeat(pair_off[:-1], np.diff(pair_off))
-            keep = rank < cutoff
-            src, order = src[keep], order[keep]
-        if perm is None and _in_final_order(q_order):
-            # the queries already stand in their final order (a Ranking the constructor sorted) and
-            # the device ordered each one: nothing is left to sort or to check
-            cols = {c: df[c].to_numpy()[src] for c in ("q_id", "id")}
-            cols["score"] = interp[order].astype(df.dtypes["score"], copy=False)
-            cols["query"] = df["query"].to_numpy()[src]
-            return Ranking._assemble(cols, ranking.name, q_no[src], q_order)
-        out = df.iloc[src].reset_index(drop=True)
-        out["score"] = interp[order].astype(df.dtypes["score"])
-        return Ranking(Ranking._trusted(out), name=ranking.name, dtype=df.dtypes["score"], copy=False, is_sorted=False)
+        t = [perf_counter()]
+        run = _Run(self, ranking)
+        t.append(perf_counter())
+        ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
+        t.append(perf_counter())
+        sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
+        _, interp, order = self._score_pairs(run.query_vectors, run.pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False,
+                                             **self._reuse_kw())
+        t.append(perf_counter())
+        off = run.pair_off
+        if cutoff is not None:  # (the device order is a permutation inside every query)
+            keep = np.arange(len(order)) - np.repeat(off[:-1], np.diff(off)) < cutoff
+            order = order[keep]
+            off = np.concatenate([[0], np.cumsum(np.minimum(np.diff(off), cutoff))]).astype(np.int64)
+        out, _ = run.result(ranking.name, order, native.take32(interp, order), off)
+        t.append(perf_counter())
+        # where a call's time went (seconds): a first call on a ranking pays for the distinct-id look-up, later ones do not
+        self.last_timings = dict(zip(("queries_numbered_and_encoded_s", "ids_to_ordinals_s", "upload_device_download_s", "result_gathers_s"),
+                                     np.diff(t).tolist()), **getattr(self, "_last_lookup_timings", {}))
+        return out
 
     def rerank_file(self, run_in, run_out, alpha: float, queries, cutoff: int | None = None, name: str | None = None) -> dict:
         """The README pipeline of the reference, file to file, with no pandas in between:

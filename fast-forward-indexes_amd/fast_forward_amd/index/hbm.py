@@ -256,69 +256,35 @@ class InMemoryIndex(Index):
 
     _PIPELINED_FROM = 6 << 20  # pairs: below this ffx_score would run a single slice anyway
 
-    _early_stopping_takes_ordinals = True
-
-    def _early_stopping_scored(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths, ordinals, grouped):
-        """Early stopping for rows that stand grouped by query: (rows that were scored, ascending; their dense scores),
-        compacted on the device (``ffx_plan_fetch_scored``) -- nothing of the size of the candidate list comes back."""
-        return self._early_stopping_scores(ids, q_no, sparse, query_vectors, cutoff, alpha, depths, ordinals=ordinals, grouped=grouped, compact=True)
-
-    def _early_stopping_scores(self, ids, q_no, sparse, query_vectors, cutoff: int, alpha: float, depths, ordinals=None, grouped=None,
-                               compact: bool = False):
-        """Early stopping (base.py:316-387) resident on the device (``ffx_plan_early_stopping``): the
-        active mask, the running best dense score and the running top-``cutoff`` threshold of every
-        query stay in HBM between depth intervals; one upload of the candidate lists, one download
-        of the final scores.  Ids are resolved once, leniently: an unknown id raises ``IndexError``
-        only if some interval reaches it, as in the reference."""
+    def _early_stopping_kept(self, id_at, sparse, pair_off, query_vectors, cutoff: int, alpha: float, depths, ordinals):
+        """Early stopping (base.py:316-387) resident on the device (``ffx_plan_early_stopping``): the active mask, the
+        running best dense score and the running top-``cutoff`` threshold of every query stay in HBM between depth
+        intervals; one upload of the candidate lists (unknown ids as -1: an ``IndexError`` only if some interval reaches
+        one, as in the reference), and only the candidates that got scored come back, compacted on the device
+        (``ffx_plan_fetch_scored``).  Float64 first-stage scores take the NumPy statement (``Index._early_stopping_kept``)."""
+        sparse = np.asarray(sparse)
         if self._store is None:
             raise IndexError("the index is empty")
-        sparse = np.asarray(sparse)
         if sparse.dtype != np.float32:
-            return super()._early_stopping_scores(ids, q_no, sparse, query_vectors, cutoff, alpha, depths)  # float64 rankings: host criterion
-        from fast_forward_amd.index.api import _grouped_by_query
-
-        n_q = query_vectors.shape[0]
+            return super()._early_stopping_kept(id_at, sparse, pair_off, query_vectors, cutoff, alpha, depths, ordinals)
         q = np.ascontiguousarray(query_vectors, dtype=np.float32)
         if q.ndim != 2 or q.shape[1] != self._store.query_dim:
             raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.query_dim}).")
         if self._rotation is not None:
             q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
-        # ``grouped``: the ranking's cached (permutation | None, offsets); ``ids`` may be a callable position -> id string
-        # (coded rankings: no array of strings exists), used only to name an id in an error
-        perm, pair_off = _grouped_by_query(q_no, n_q) if grouped is None else grouped  # stable: the order inside a query is its rank order
-        if callable(ids):
-            id_at = ids if perm is None else (lambda p: ids(int(perm[p])))
-            ids_g = None
-        else:
-            ids_g = ids if perm is None else ids[perm]
-            id_at = lambda p: ids_g[p]  # noqa: E731
-        sparse_g = sparse if perm is None else sparse[perm]
-        if ordinals is None:
-            ordinals = self._ids.lookup_optional(ids_g, self.mode.value).astype(np.int32)
-        elif perm is not None:
-            ordinals = ordinals[perm]
         self._sync_ids()
         if self._plan is None:
             self._plan = native.Plan(self._store)
         plan = self._plan
         plan.set_queries(q)
-        plan.set_pairs_lazy(pair_off, ordinals, sparse_g, self.mode.value)
+        plan.set_pairs_lazy(pair_off, ordinals, sparse, self.mode.value)
         try:
             scored, intervals = plan.early_stopping(cutoff, alpha, depths, exact_sum=self.exact_sum, bound_f32=self._es_bound_f32())
         except native.NotFound as e:
             raise IndexError(f"ID {id_at(e.pair)} not found in the index.") from None
         self.last_stats = dict(plan.stats(), early_stopping_scored_pairs=scored, early_stopping_intervals=intervals)
-        LOGGER.info("early stopping: %s of %s candidates scored in %s depth intervals", scored, len(sparse_g), intervals)
-        if compact:
-            if perm is not None:
-                raise ValueError("the compact form needs rows grouped by query")
-            return plan.fetch_scored(scored)
-        ff = plan.fetch(ff=True)[0]
-        if perm is None:
-            return ff
-        out = np.empty_like(ff)
-        out[perm] = ff
-        return out
+        LOGGER.info("early stopping: %s of %s candidates scored in %s depth intervals", scored, len(sparse), intervals)
+        return plan.fetch_scored(scored)
 
     def _native_id_table(self, mode: Mode):
         return self._ids.native_table(mode.value)

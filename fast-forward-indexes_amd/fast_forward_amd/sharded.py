@@ -335,33 +335,25 @@ class _ShardedIndex:
         return None
 
     def _rank(self, ranking, alpha: float | None, name, gather: bool):
-        """Score, exchange, finish the owned queries; the ``Ranking`` of this rank's queries (or of all)."""
+        """Score, exchange, finish the owned queries; the ``Ranking`` of this rank's queries (or of all).  The same one
+        route as ``Index.__call__``: integers in (``_Run``), a coded ``Ranking`` out."""
         from fast_forward_amd import native
-        from fast_forward_amd.index.api import _in_final_order
-        from fast_forward_amd.ranking import Ranking
+        from fast_forward_amd.index.api import _Run
 
         if not ranking.has_queries:
             raise ValueError("Input ranking has no queries attached.")
-        q_no, q_order, texts = self.local._numbered_queries(ranking)
-        n_q = len(texts)
-        query_vectors = np.ascontiguousarray(self.local.encode_queries(texts), dtype=np.float32)
-        perm, pair_off = ranking._csr()
-        sparse = np.asarray(ranking._scores(), dtype=np.float32)
-        if perm is not None:
-            sparse = sparse[perm]
-        holder, local_ids = self._holders(ranking, perm)
+        run = _Run(self.local, ranking)
+        pair_off = run.pair_off
+        sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
+        holder, local_ids = self._holders(ranking, run.perm)
         mode = self.local.mode.value
-        # rows of a query adjacent and the queries in the constructor's order: the device's per-query order is the
-        # whole sort and the result can stay in integer codes; otherwise the frame route below re-sorts on the host
-        coded = perm is None and _in_final_order(q_order)
-        sort = coded or alpha is not None
-        streamed = self._local_scores(query_vectors, pair_off, holder, local_ids, mode)
+        streamed = self._local_scores(run.query_vectors, pair_off, holder, local_ids, mode)
         if streamed is None:
             scorer = self._sharded()
-            scorer.set_queries(query_vectors)
+            scorer.set_queries(run.query_vectors)
             scorer.set_pairs(pair_off, local_ids, sparse if alpha is not None else None, mode, holder=holder)
-            scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=sort)
-            ff, interp, order = scorer.fetch(order=sort)
+            scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=True)
+            ff, interp, order = scorer.fetch(order=True)
             q_lo, q_hi = scorer.q_lo, scorer.q_hi
             lo, hi = scorer.own_first_pair, scorer.own_first_pair + scorer.own_pairs
         else:
@@ -371,49 +363,25 @@ class _ShardedIndex:
             dense = recv[r["recv_slot"]]
             q_lo, q_hi = r["q_lo"], r["q_hi"]
             lo, hi = r["own_first_pair"], r["own_first_pair"] + r["own_pairs"]
-            own_off = pair_off[q_lo:q_hi + 1] - lo
             if hi > lo:
                 ff, interp, order = native.aggregate(dense, np.arange(hi - lo + 1, dtype=np.int64), 1, sparse[lo:hi] if alpha is not None else None,
-                                                     0.0 if alpha is None else alpha, own_off, sort=sort, device=self.comm.device)
+                                                     0.0 if alpha is None else alpha, pair_off[q_lo:q_hi + 1] - lo, sort=True, device=self.comm.device)
             else:
                 ff, interp, order = dense, (dense if alpha is not None else None), np.zeros(0, dtype=np.int32)
         score = interp if alpha is not None else ff
-        dtype = ranking._score_dtype()
-        if coded:
-            codes, names = ranking._id_coding()
-            from fast_forward_amd import native
-
-            # `order`: positions inside the owned block, every query ordered
-            own_codes, own_score = native.take32(codes[lo:hi], order), native.take32(score, order).astype(dtype, copy=False)
-            if not gather:
-                return Ranking._assemble_coded(name, np.asarray(q_no[lo:hi]) - q_lo, q_order[q_lo:q_hi], own_codes, names, own_score, texts[q_lo:q_hi])
-            # every rank's block, in rank order = query order (queries are owned in contiguous blocks)
-            sizes = self.comm.allgather_array(np.array([hi - lo], dtype=np.int64))[:, 0]
-            room = int(sizes.max())
-            pad_c, pad_s = np.zeros(room, dtype=np.int32), np.zeros(room, dtype=np.float32)
-            pad_c[:hi - lo], pad_s[:hi - lo] = own_codes, own_score.astype(np.float32, copy=False)
-            all_c, all_s = self.comm.allgather_array(pad_c), self.comm.allgather_array(pad_s)
-            full_c = np.concatenate([all_c[r, :int(sizes[r])] for r in range(self.comm.world)])
-            full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(self.comm.world)]).astype(dtype, copy=False)
-            return Ranking._assemble_coded(name, q_no, q_order, full_c, names, full_s, texts)
-        df = ranking._df
-        rows = np.arange(lo, hi) if perm is None else perm[lo:hi]
-        if sort:
-            rows, score = rows[order], score[order]
-        frame = df.iloc[rows].reset_index(drop=True)
-        frame["score"] = score.astype(df.dtypes["score"])
-        if gather:  # every rank's frame, through the control plane (sizes first, then padded payloads)
-            import pickle
-
-            import pandas as pd
-
-            blob = pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL)
-            sizes = self.comm.allgather_array(np.array([len(blob)], dtype=np.int64))[:, 0]
-            padded = np.zeros(int(sizes.max()), dtype=np.uint8)
-            padded[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
-            blobs = self.comm.allgather_array(padded)
-            frame = pd.concat([pickle.loads(blobs[r, :int(sizes[r])].tobytes()) for r in range(self.comm.world)], ignore_index=True)
-        return Ranking(Ranking._trusted(frame), name=name, dtype=dtype, copy=False, is_sorted=False)
+        # `order`: positions inside the owned block, every query ordered -> positions in the grouped layout
+        kept, kept_scores = order.astype(np.int32, copy=False) + np.int32(lo), native.take32(score, order).astype(np.float32, copy=False)
+        if not gather:
+            return run.result(name, kept, kept_scores, pair_off[q_lo:q_hi + 1] - lo, q_range=(q_lo, q_hi))[0]
+        # every rank's block, in rank order = query order (queries are owned in contiguous blocks)
+        sizes = self.comm.allgather_array(np.array([hi - lo], dtype=np.int64))[:, 0]
+        room = int(sizes.max())
+        pad_k, pad_s = np.zeros(room, dtype=np.int32), np.zeros(room, dtype=np.float32)
+        pad_k[:hi - lo], pad_s[:hi - lo] = kept, kept_scores
+        all_k, all_s = self.comm.allgather_array(pad_k), self.comm.allgather_array(pad_s)
+        full_k = np.concatenate([all_k[r, :int(sizes[r])] for r in range(self.comm.world)])
+        full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(self.comm.world)])
+        return run.result(name, full_k, full_s, pair_off)[0]
 
     def __call__(self, ranking, gather: bool = False):
         """Dense scores (``Index.__call__``) of the queries this rank owns, or of all with ``gather``."""

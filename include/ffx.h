@@ -417,7 +417,7 @@ int ffx_run_save_coded(const char* path, const char* q_blob, int64_t q_bytes, in
  * with the index: the slices' kernels run in order on one stream while the next slice is uploaded and the
  * previous one's results leave (asynchronously into page-locked buffers, through helper threads into ordinary
  * ones), so uploads, scoring and downloads overlap for either kind of memory.  Results do not depend on the
- * slicing; stats are summed over the slices.  Environment: FFX_SCORE_SLICE_PAIRS overrides the slice size
+ * slicing; stats are summed over the slices.  Environment: FFX_DEBUG_VARIANT=score_slice_pairs=N overrides the slice size
  * (pairs), FFX_SCORE_TRACE=1 prints the host-side timeline of the slices on stderr. */
 int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               const int64_t* pair_off, const int32_t* pair_ids, const float* sparse, int mode,

@@ -47,11 +47,10 @@ for rnd in range(args.rounds):
     pair_ids = np.concatenate([rng.choice(pool, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
     sparse = (rng.integers(0, 5, size=len(pair_ids)) if rng.random() < 0.5 else rng.random(len(pair_ids)) * 10).astype(np.float32)
     alpha = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
-    os.environ["FFX_SCORE_SLICE_PAIRS"] = str(int(rng.choice([1, 7, 100, 10**9])))
+    variant = [f"score_slice_pairs={int(rng.choice([1, 7, 100, 10**9]))}"]
     if rng.random() < 0.5:
-        os.environ["FFX_NO_SMALL_PATH"] = "1"
-    else:
-        os.environ.pop("FFX_NO_SMALL_PATH", None)
+        variant.append("no_small_path")
+    os.environ["FFX_DEBUG_VARIANT"] = ",".join(variant)
     out = None
     if rng.random() < 0.5:  # page-locked result arrays: results leave asynchronously on the out-stream
         out = tuple(native.pinned_empty(max(1, len(pair_ids)), t) for t in (np.float32, np.float32, np.int32))

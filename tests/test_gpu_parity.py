@@ -311,7 +311,7 @@ def test_ragged_and_empty_queries():
 
 def test_single_submission_path_matches_general_path(monkeypatch):
     """ffx_score on a small batch of single-row candidates queues uploads, validation, kernels and downloads
-    in one go and waits once; its results are those of the general path (FFX_NO_SMALL_PATH) bit for bit, for
+    in one go and waits once; its results are those of the general path (FFX_DEBUG_VARIANT=no_small_path) bit for bit, for
     every mode, with and without first-stage scores and ordering, for non-identity id -> row tables and for
     fp16 rows; a bad ordinal (too large, negative, or a passage id whose row is gone) is the same NotFound."""
     d, n = 768, 900
@@ -330,16 +330,16 @@ def test_single_submission_path_matches_general_path(monkeypatch):
         idx.set_psg_rows(perm)
         for mode in (1, 2, 3, 4):
             for sp, sort in ((None, False), (sparse, True), (None, True)):
-                monkeypatch.delenv("FFX_NO_SMALL_PATH", raising=False)
+                monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
                 a = native.score(idx, queries, pair_off, pair_ids, mode, sp, 0.3, sort=sort)
-                monkeypatch.setenv("FFX_NO_SMALL_PATH", "1")
+                monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_small_path")
                 b = native.score(idx, queries, pair_off, pair_ids, mode, sp, 0.3, sort=sort)
                 for x, y in zip(a[:3], b[:3]):
                     assert (x is None) == (y is None)
                     if x is not None:
                         assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
                 assert a[3]["n_pairs"] == b[3]["n_pairs"] and a[3]["n_rows"] == b[3]["n_rows"] and a[3]["kernel_variant"] == b[3]["kernel_variant"]
-        monkeypatch.delenv("FFX_NO_SMALL_PATH", raising=False)
+        monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
         for value, at in ((n, 7), (-1, 0), (2**31 - 1, pair_ids.shape[0] - 1)):
             bad = pair_ids.copy()
             bad[at] = value
@@ -657,7 +657,7 @@ def test_rehearsal_of_one_rank_of_eight_on_one_gpu():
 
 def test_device_routing_equals_host_routing(monkeypatch):
     """The sharded scorer routes a batch on the device when the shards are document ranges (one upload of the ids,
-    then mark / scan / compact / stable radix pass by holder in HBM).  Against the host routing (FFX_ROUTE_HOST=1)
+    then mark / scan / compact / stable radix pass by holder in HBM).  Against the host routing (FFX_DEBUG_VARIANT=route_host)
     on one rank: same dense, interpolated scores and order, bit for bit, for ragged batches (empty queries, one
     candidate, several passages per document, every mode); the same NotFound for an ordinal outside every shard and
     for one inside the range that has no rows."""
@@ -682,9 +682,9 @@ def test_device_routing_equals_host_routing(monkeypatch):
     results = {}
     for route in ("device", "host"):
         if route == "host":
-            monkeypatch.setenv("FFX_ROUTE_HOST", "1")
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", "route_host")
         else:
-            monkeypatch.delenv("FFX_ROUTE_HOST", raising=False)
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
         sc = native.Sharded(shard, comm, np.array([0, n_docs], dtype=np.int64))
         sc.set_queries(queries)
         for mode in (2, 3, 4):
@@ -815,11 +815,11 @@ def test_pq_decode_then_dot_bit_identical_to_reference(name):
         if name == "pq_d768_m8":  # the decode-then-dot kernel must give the same bits
             import os
 
-            os.environ["FFX_PQ_NO_ADC"] = "1"
+            os.environ["FFX_DEBUG_VARIANT"] = "pq_no_adc"
             try:
                 ff2, _, _, st2 = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=True)
             finally:
-                del os.environ["FFX_PQ_NO_ADC"]
+                del os.environ["FFX_DEBUG_VARIANT"]
             assert st2["kernel_variant"] == 2108 and np.array_equal(bits(ff2), bits(ff))
         # ADC (fast order): same value up to fp32 rounding of a different summation order
         fast, _, _, st = native.score(idx, case.queries, pair_off, pair_ids, MODE_NO[mode], exact_sum=False)
@@ -967,11 +967,11 @@ def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
     # the unfused form (row list + look-up kernel + interpolation kernel) gives the same bits
     import os
 
-    os.environ["FFX_PQ_NO_FUSE"] = "1"
+    os.environ["FFX_DEBUG_VARIANT"] = "pq_no_fuse"
     try:
         ff2, interp2, _, st2 = native.score(idx, queries, pair_off, pair_ids, 1, sparse, 0.3, exact_sum=True)
     finally:
-        del os.environ["FFX_PQ_NO_FUSE"]
+        del os.environ["FFX_DEBUG_VARIANT"]
     assert st2["kernel_variant"] == 2200 + m and np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp))
     # ragged queries and documents whose first row is not their ordinal (FIRSTP through doc_first)
     perm = rng.permutation(n).astype(np.int32)
@@ -1007,7 +1007,7 @@ def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
     sparse = rng.random(len(pair_ids), dtype=np.float32) * 20
     for mode in (2, 3, 4):
         want_ff, want_in = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, pair_ids, mode, sparse, 0.3)
-        monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", str(slice_pairs))
+        monkeypatch.setenv("FFX_DEBUG_VARIANT", f"score_slice_pairs={slice_pairs}")
         ff, interp, order, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.3, sort=True)
         assert np.array_equal(bits(ff), bits(want_ff)) and np.array_equal(bits(interp), bits(want_in))
         assert np.array_equal(order.astype(np.int64), fo.order(want_in, pair_off))
@@ -1019,7 +1019,7 @@ def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
         assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(in2), bits(interp)) and np.array_equal(or2, order)
         assert ff2.base is not None  # views of the page-locked block
     # arrays large enough to be locked in place (native.pinned skips those under 1 MiB)
-    monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", "60000")
+    monkeypatch.setenv("FFX_DEBUG_VARIANT", "score_slice_pairs=60000")
     big_off = np.arange(10, dtype=np.int64) * 40_000
     big_ids = rng.integers(0, 300, size=int(big_off[-1])).astype(np.int32)
     big_sp = rng.random(len(big_ids), dtype=np.float32)
@@ -1028,7 +1028,7 @@ def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
         assert len(pin._done) == 2
         ff, interp, _, _ = native.score(idx, queries, big_off, big_ids, 2, big_sp, 0.1)
     assert np.array_equal(bits(ff), bits(want_ff)) and np.array_equal(bits(interp), bits(want_in))
-    monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", str(slice_pairs))
+    monkeypatch.setenv("FFX_DEBUG_VARIANT", f"score_slice_pairs={slice_pairs}")
     bad = pair_ids.copy()
     bad[600] = 10**6
     with pytest.raises(native.NotFound) as e:
@@ -1056,7 +1056,7 @@ def test_upload_rows_gathers_from_chunk_maps(monkeypatch, dtype):
     idx = native.DeviceIndex(len(want) + 7, d, dtype=dtype)
     if dtype == np.uint8:
         idx.set_codebook(rng.standard_normal((d, 4, 2)).astype(np.float32))
-    monkeypatch.setenv("FFX_STAGE_BYTES", str(40 * d * np.dtype(dtype).itemsize))  # 40 rows per staging block
+    monkeypatch.setenv("FFX_DEBUG_VARIANT", f"stage_bytes={40 * d * np.dtype(dtype).itemsize}")  # 40 rows per staging block
     idx.upload_rows(chunks, want, 7, threads=3)
     got = idx.gather(np.arange(7, 7 + len(want)))
     assert np.array_equal(got, stored[want])

@@ -178,14 +178,11 @@ def test_early_stopping_looks_up_only_what_it_scores():
         idx(Ranking(pd.DataFrame(deep)))
 
 
-@pytest.mark.parametrize("fixture,coded", [("early_stopping", False), ("early_stopping", True), ("early_stopping_large", True)])
-def test_early_stopping_matches_reference_frames(fixture, coded, monkeypatch):
-    """``coded``: the route of large runs (integer id codes in, a coded Ranking out) -- forced onto the small fixture,
-    taken by itself on the large one (7730 rows, 24 queries of 150 - 520 candidates)."""
-    if coded and fixture == "early_stopping":
-        import fast_forward_amd.index.api as api_mod
-
-        monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1)
+@pytest.mark.parametrize("fixture", ["early_stopping", "early_stopping_large"])
+def test_early_stopping_matches_reference_frames(fixture):
+    """Frames the reference produced with early stopping on passage runs (a small run and one of 7730 rows, 24 queries of
+    150 - 520 candidates): same rows, same bits, same order of the queries.  Every ranking takes the one route: integer id
+    codes in, a coded ``Ranking`` out."""
     z = np.load(GOLDEN / f"{fixture}.npz")
     dim, seed, scale, n_psg = int(z["dim"]), int(z["seed"]), float(z["scale"]), int(z["n_psg"])
     q_names = z["q_names"].tolist()
@@ -201,9 +198,9 @@ def test_early_stopping_matches_reference_frames(fixture, coded, monkeypatch):
     first = Ranking(pd.DataFrame(rows, columns=["q_id", "id", "score"]), queries={q: str(i) for i, q in enumerate(q_names)})
     for ci, (cutoff, alpha, depths) in enumerate(json.loads(str(z["configs"]))):
         res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
-        assert (res._coded is not None) == coded
+        assert res._coded is not None
         got = res._df
-        assert got["q_id"].tolist() == z[f"es{ci}_q_id"].tolist() or not coded  # same query order as the reference's frame
+        assert got["q_id"].tolist() == z[f"es{ci}_q_id"].tolist()  # same query order as the reference's frame
         assert got["query"].tolist() == [str(q_names.index(q)) for q in got["q_id"]]
         want = {(q, i): s for q, i, s in zip(z[f"es{ci}_q_id"].tolist(), z[f"es{ci}_id"].tolist(), z[f"es{ci}_score"])}
         have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
@@ -212,7 +209,7 @@ def test_early_stopping_matches_reference_frames(fixture, coded, monkeypatch):
         assert np.array_equal(bits(np.array([have[k] for k in ks])), bits(np.array([want[k] for k in ks]))), ci
 
 
-@pytest.mark.parametrize("criterion", ["device", "host", "device-coded"])
+@pytest.mark.parametrize("criterion", ["device", "host"])
 def test_early_stopping_on_document_runs_matches_reference_frames(criterion, monkeypatch):
     """Frames the reference produced with early stopping on DOCUMENT runs (MaxP / AveP / FirstP over 1..6
     passages per document; oracle/gen_golden.py::early_stopping_docs_case): same scored set, same bits --
@@ -230,19 +227,13 @@ def test_early_stopping_on_document_runs_matches_reference_frames(criterion, mon
             rows.append((q_names[qi], f"D{c}", s))
         pos += n
     first = Ranking(pd.DataFrame(rows, columns=["q_id", "id", "score"]), queries={q: str(i) for i, q in enumerate(q_names)})
-    if criterion == "host":
-        monkeypatch.setattr(InMemoryIndex, "_early_stopping_scores", Index._early_stopping_scores)
-        monkeypatch.setattr(InMemoryIndex, "_early_stopping_takes_ordinals", False)
-    if criterion == "device-coded":  # the route of large runs: id codes in, a coded Ranking out
-        import fast_forward_amd.index.api as api_mod
-
-        monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1)
+    if criterion == "host":  # the NumPy statement of the criterion instead of the device-resident one
+        monkeypatch.setattr(InMemoryIndex, "_early_stopping_kept", Index._early_stopping_kept)
     for ci, (mname, cutoff, alpha, depths) in enumerate(json.loads(str(z["configs"]))):
         idx = InMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mname]))
         idx.early_stopping_promotion = "numpy2"  # (frames of the reference under numpy 2.2.6)
         idx.add(vectors, doc_ids=[f"D{d}" for d in z["doc_of_row"]])
         res = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
-        assert (res._coded is not None) == (criterion == "device-coded")
         got = res._df
         want = {(q, i): s for q, i, s in zip(z[f"es{ci}_q_id"].tolist(), z[f"es{ci}_id"].tolist(), z[f"es{ci}_score"])}
         have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
@@ -252,7 +243,7 @@ def test_early_stopping_on_document_runs_matches_reference_frames(criterion, mon
         idx.close()
 
 
-@pytest.mark.parametrize("route", ["device", "device-coded", "host"])
+@pytest.mark.parametrize("route", ["device", "host"])
 @pytest.mark.parametrize("part", ["small", "large", "docs"])
 @pytest.mark.parametrize("promotion", ["numpy1", "numpy2"])
 def test_early_stopping_matches_the_reference_under_both_numpy_promotions(promotion, part, route, monkeypatch):
@@ -261,16 +252,13 @@ def test_early_stopping_matches_the_reference_under_both_numpy_promotions(promot
     float32 under numpy >= 2.  Both are pinned by frames the REFERENCE produced under numpy 1.26.4 and 2.2.6
     (oracle/gen_golden_promotion.py): ordinary configurations (one of which the two regimes already disagree on),
     repeated depths, and cut-off 1 after a first depth of 1, where numpy >= 2 never continues.  Same rows, same bits,
-    through the device-resident criterion (frame and coded route) and through its NumPy statement."""
+    through the device-resident criterion and through its NumPy statement."""
     from _cases import load_es_promotion_part
     from fast_forward_amd.index.api import Index
-    import fast_forward_amd.index.api as api_mod
 
     c = load_es_promotion_part(promotion, part)
     if route == "host":
-        monkeypatch.setattr(InMemoryIndex, "_early_stopping_scores", Index._early_stopping_scores)
-        monkeypatch.setattr(InMemoryIndex, "_early_stopping_takes_ordinals", False)
-    monkeypatch.setattr(api_mod, "_CODED_MIN_ROWS", 1 if route == "device-coded" else 10**9)
+        monkeypatch.setattr(InMemoryIndex, "_early_stopping_kept", Index._early_stopping_kept)
     rows, pos = [], 0
     for qi, n in enumerate(c["lens"]):
         rows += [(c["q_names"][qi], f"{c['prefix']}{cand}", s) for cand, s in zip(c["cands"][pos:pos + n], c["sparse"][pos:pos + n])]
@@ -287,7 +275,6 @@ def test_early_stopping_matches_the_reference_under_both_numpy_promotions(promot
             else:
                 idx.add(c["vectors"], psg_ids=[f"P{r}" for r in range(c["n_rows"])])
         res = indexes[mname](first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
-        assert (res._coded is not None) == (route == "device-coded")
         got = res._df
         have = {(q, i): s for q, i, s in zip(got["q_id"], got["id"], got["score"])}
         assert have.keys() == want.keys(), (promotion, part, route, mname, cutoff, alpha, depths, len(have), len(want))
@@ -309,12 +296,17 @@ def test_early_stopping_promotion_must_be_one_of_the_two():
 
 
 @pytest.mark.parametrize("mode", ["MAXP", "PASSAGE", "AVEP"])
-def test_device_resident_early_stopping_equals_the_host_criterion(mode):
+def test_device_resident_early_stopping_equals_the_host_criterion(mode, monkeypatch):
     """ffx_plan_early_stopping (per-query state in HBM between depth intervals, radix-select of the
-    cutoff-th best score) against the NumPy statement of base.py:316-387 in Index._early_stopping_scores,
+    cutoff-th best score) against the NumPy statement of base.py:316-387 in Index._early_stopping_kept,
     which the golden frames pin: same scored set, same bits -- ragged queries, documents of 1..8
     passages, depths in any order, cutoffs from 1 to beyond the list length."""
     from fast_forward_amd.index.api import Index
+
+    def host_statement(*args):  # the same call with the NumPy statement of the criterion
+        with monkeypatch.context() as m:
+            m.setattr(InMemoryIndex, "_early_stopping_kept", Index._early_stopping_kept)
+            return idx._early_stopping_scores(*args)
 
     case = load_scoring_case("s2_sub")
     qvecs = case.queries
@@ -341,14 +333,14 @@ def test_device_resident_early_stopping_equals_the_host_criterion(mode):
         got = idx._early_stopping_scores(ids, q_no, sp, qvecs, cutoff, alpha, depths)
         stats = dict(idx.last_stats)
         assert stats["early_stopping_intervals"] >= 1
-        want = Index._early_stopping_scores(idx, ids, q_no, sp, qvecs, cutoff, alpha, depths)
+        want = host_statement(ids, q_no, sp, qvecs, cutoff, alpha, depths)
         assert np.array_equal(np.isnan(got), np.isnan(want)), (cutoff, alpha, depths)
         assert np.array_equal(bits(got[~np.isnan(got)]), bits(want[~np.isnan(want)])), (cutoff, alpha, depths)
         assert stats["early_stopping_scored_pairs"] == int((~np.isnan(want)).sum())
     # rows of a query interleaved with other queries' rows (frame not grouped): same scores per row
     order = np.argsort(rng.integers(0, 3, size=len(ids)), kind="stable")  # three interleaved blocks, rank order kept inside a query
     got = idx._early_stopping_scores(ids[order], q_no[order], sp[order], qvecs, 10, 0.2, (20, 50, 100))
-    want = Index._early_stopping_scores(idx, ids[order], q_no[order], sp[order], qvecs, 10, 0.2, (20, 50, 100))
+    want = host_statement(ids[order], q_no[order], sp[order], qvecs, 10, 0.2, (20, 50, 100))
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got[~np.isnan(got)]), bits(want[~np.isnan(want)]))
     idx.close()
 
@@ -383,7 +375,7 @@ def test_end_to_end_frames_match_reference(name, pipelined, monkeypatch):
     three plans, here with slices of ~300 candidates)."""
     if pipelined:
         monkeypatch.setattr(InMemoryIndex, "_PIPELINED_FROM", 1)
-        monkeypatch.setenv("FFX_SCORE_SLICE_PAIRS", "300")
+        monkeypatch.setenv("FFX_DEBUG_VARIANT", "score_slice_pairs=300")
     case = load_scoring_case(name)
     for mode in case.modes():
         qvecs = case.queries
@@ -613,11 +605,10 @@ def test_call_on_a_ranking_the_user_declared_sorted_still_comes_back_sorted():
 
 
 def test_coded_results_equal_frame_results(monkeypatch):
-    """Large runs travel as integer codes (Ranking._assemble_coded; the frame of strings is built on
-    first use): same rows, scores and order as the small-run path that works on the frame itself --
-    for __call__, rerank (with and without cutoff), early stopping, a repeated call (cached candidate
-    list), and an unknown id named exactly as before."""
-    from fast_forward_amd.index import api
+    """Every ranking travels through the index as integer codes and comes back coded (Ranking._assemble_coded; the frame
+    of strings is built on first use), whether it holds a coded form itself (the native constructor) or a pandas frame
+    (the general constructor): same rows, scores and order either way -- for __call__, rerank (with and without cutoff),
+    early stopping, a repeated call (cached candidate list), and an unknown id named exactly as before."""
 
     rng = np.random.default_rng(12)
     n, d, n_q, k = 3000, 64, 9, 700
@@ -629,12 +620,13 @@ def test_coded_results_equal_frame_results(monkeypatch):
                           "id": np.concatenate([[f"D{x}" for x in rng.choice(n // 2, size=k, replace=False)] for _ in range(n_q)]),
                           "score": (rng.random(n_q * k) * 20).astype(np.float32)})
     first = Ranking(frame, queries={f"q{i}": str(i) for i in range(n_q)})
-    assert len(first._df) >= api._CODED_MIN_ROWS
+    assert first._coded is not None and first._frame is None
     coded = {"call": index(first), "rerank": index.rerank(first, 0.3), "cut": index.rerank(first, 0.3, cutoff=10),
              "again": index.rerank(first, 0.3), "es": index(first, early_stopping=5, early_stopping_alpha=0.3, early_stopping_depths=(5, 50, 200))}
     assert coded["rerank"]._frame is None and coded["rerank"]._coded is not None  # nothing materialised yet
-    monkeypatch.setattr(api, "_CODED_MIN_ROWS", 10**9)
+    monkeypatch.setattr(Ranking, "_init_from_columns", lambda self, *a: False)  # the general constructor: a ranking that holds a frame
     fresh = Ranking(frame, queries={f"q{i}": str(i) for i in range(n_q)})
+    assert fresh._coded is None and fresh._frame is not None
     plain = {"call": index(fresh), "rerank": index.rerank(fresh, 0.3), "cut": index.rerank(fresh, 0.3, cutoff=10),
              "again": index.rerank(fresh, 0.3), "es": index(fresh, early_stopping=5, early_stopping_alpha=0.3, early_stopping_depths=(5, 50, 200))}
     for key in coded:
@@ -662,7 +654,7 @@ def test_coded_results_equal_frame_results(monkeypatch):
     for call in (lambda: index.rerank(broken, 0.3), lambda: index(broken)):
         with pytest.raises(IndexError, match=f"ID {first_unknown} not found in the index."):
             call()
-    monkeypatch.setattr(api, "_CODED_MIN_ROWS", 10**9)
+    monkeypatch.setattr(Ranking, "_init_from_columns", lambda self, *a: False)
     with pytest.raises(IndexError, match=f"ID {first_unknown} not found in the index."):
         index.rerank(Ranking(bad, queries={f"q{i}": str(i) for i in range(n_q)}), 0.3)
     index.close()

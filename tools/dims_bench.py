@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gather_dot at row lengths that have no kernel of their own (the "any d" strided kernel, and the staged
-generic kernel it replaces: FFX_GENERIC_STAGED=1), index ~13 GB each, 2000 queries x k=5000."""
+generic kernel it replaces: FFX_DEBUG_VARIANT=generic_staged), index ~13 GB each, 2000 queries x k=5000."""
 import json
 import os
 import sys
@@ -29,12 +29,11 @@ for d in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "32,100,200,300
     plan.set_pairs(np.arange(nq + 1, dtype=np.int64) * k, ids, sparse, 1)
     res = {}
     for label, env in ((("anyd", None),) if ONLY_SHIPPING else (("anyd", None), ("anyd_u2", "u2"), ("anyd_u8", "u8"), ("staged", "1"))):
-        os.environ.pop("FFX_ANYD_U", None)
-        os.environ.pop("FFX_GENERIC_STAGED", None)
+        os.environ.pop("FFX_DEBUG_VARIANT", None)
         if env == "1":
-            os.environ["FFX_GENERIC_STAGED"] = env
+            os.environ["FFX_DEBUG_VARIANT"] = "generic_staged"
         elif env:
-            os.environ["FFX_ANYD_U"] = env[1:]
+            os.environ["FFX_DEBUG_VARIANT"] = f"anyd_u={env[1:]}"
         ms = []
         for _ in range(3 if ONLY_SHIPPING else 6):
             plan.run(0.1, exact_sum=True)
@@ -43,7 +42,7 @@ for d in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "32,100,200,300
         ff = plan.fetch()[0]
         res[label] = {"ms": float(np.mean(ms[1:])), "GBs": nq * k * (d * 4 + 4) / float(np.mean(ms[1:])) / 1e6, "variant": st["kernel_variant"],
                       "checksum": float(ff.astype(np.float64).sum())}
-    os.environ.pop("FFX_GENERIC_STAGED", None)
+    os.environ.pop("FFX_DEBUG_VARIANT", None)
     res["rows_per_launch"], res["algorithmic_bytes_per_launch"] = nq * k, nq * k * (d * 4 + 4)
     res["same_bits"] = ONLY_SHIPPING or res["anyd"]["checksum"] == res["staged"]["checksum"]
     out[str(d)] = res

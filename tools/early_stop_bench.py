@@ -57,14 +57,12 @@ out["early_stopping_device_stats"] = {k: index.last_stats[k] for k in ("early_st
 from fast_forward_amd.index.api import Index  # noqa: E402
 from fast_forward_amd.index.hbm import InMemoryIndex as _IMI  # noqa: E402
 
-device_impl = _IMI._early_stopping_scores
-_IMI._early_stopping_scores = Index._early_stopping_scores
-_IMI._early_stopping_takes_ordinals = False
+device_impl = _IMI._early_stopping_kept
+_IMI._early_stopping_kept = Index._early_stopping_kept
 t0 = time.perf_counter()
 es_host = index(first, early_stopping=args.cutoff, early_stopping_alpha=args.alpha, early_stopping_depths=depths)
 out["early_stopping_host_criterion_s"] = time.perf_counter() - t0
-_IMI._early_stopping_scores = device_impl
-_IMI._early_stopping_takes_ordinals = True
+_IMI._early_stopping_kept = device_impl
 out["host_and_device_criterion_agree"] = bool(es_host == es)
 if "--profile" in sys.argv:
     import cProfile

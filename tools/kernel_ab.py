@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of gather_dot instantiations in ONE process on ONE box (box-to-box spread is
-larger than the effects being measured).  Variants are selected with FFX_GATHER_VARIANT
+larger than the effects being measured).  Variants are selected with FFX_DEBUG_VARIANT=gather=N
 (csrc/ffx.hip, launch_gather_dot); 0 = the shipping kernel for the chosen --sum."""
 import argparse
 import json
@@ -46,13 +46,13 @@ for rnd in range(args.rounds + 1):
     for v in variants:
         exact = True
         if v == "fast":
-            os.environ["FFX_GATHER_VARIANT"] = "0"
+            os.environ["FFX_DEBUG_VARIANT"] = "gather=0"
             exact = False
         else:
-            os.environ["FFX_GATHER_VARIANT"] = v
+            os.environ["FFX_DEBUG_VARIANT"] = f"gather={v}"
             exact = not (v.startswith("95"))
         if v == "strided":  # small-row dims: the strided-load form
-            os.environ["FFX_GATHER_VARIANT"] = "800"
+            os.environ["FFX_DEBUG_VARIANT"] = "gather=800"
         plan.run(0.1, exact_sum=exact)
         st = plan.stats()
         if rnd == 0:  # warm-up round doubles as a correctness check of every exact variant

@@ -43,45 +43,40 @@ def best(n=4):
     return min(ts) * 1e3
 
 
-for env_label, env in (("ramp", {}), ("no_ramp", {"FFX_SCORE_NO_RAMP": "1"}), ("no_out_stream", {"FFX_SCORE_NO_OUT_STREAM": "1"})):
+def variant(*words):
+    """FFX_DEBUG_VARIANT: libffx's one knob for A/B switches (csrc/ffx.hip, ffx_debug_variant)."""
+    words = [w for w in words if w]
+    if words:
+        os.environ["FFX_DEBUG_VARIANT"] = ",".join(words)
+    else:
+        os.environ.pop("FFX_DEBUG_VARIANT", None)
+
+
+for env_label, word in (("ramp", None), ("no_ramp", "score_no_ramp"), ("no_out_stream", "score_no_out_stream")):
     for label, pairs in (("default", None), ("1M", 1 << 20), ("4M", 4 << 20), ("8M", 8 << 20)):
-        for k_, v_ in env.items():
-            os.environ[k_] = v_
-        if pairs is None:
-            os.environ.pop("FFX_SCORE_SLICE_PAIRS", None)
-        else:
-            os.environ["FFX_SCORE_SLICE_PAIRS"] = str(pairs)
+        variant(word, None if pairs is None else f"score_slice_pairs={pairs}")
         out[f"{env_label}/{label}"] = best()
-        for k_ in env:
-            os.environ.pop(k_, None)
-os.environ.pop("FFX_SCORE_SLICE_PAIRS", None)
+variant()
 print(json.dumps(out))
 # ordinary (pageable) arrays, written before
 mine = (np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.int32))
 run_pinned = run
 run = lambda: native.score(idx, queries, pair_off, ids, 2, sparse, 0.1, exact_sum=True, sort=True, out=mine)  # noqa: E731
 pg = {}
-for env_label, env in (("blocking", {}), ("threaded", {"FFX_SCORE_THREADED_OUT": "1"})):
+for env_label, word in (("threaded", None), ("blocking", "score_blocking_out")):
     for label, pairs in (("default", None), ("2M", 2 << 20), ("4M", 4 << 20), ("8M", 8 << 20)):
-        for k_, v_ in env.items():
-            os.environ[k_] = v_
-        if pairs is None:
-            os.environ.pop("FFX_SCORE_SLICE_PAIRS", None)
-        else:
-            os.environ["FFX_SCORE_SLICE_PAIRS"] = str(pairs)
+        variant(word, None if pairs is None else f"score_slice_pairs={pairs}")
         pg[f"pageable/{env_label}/{label}"] = best(3)
-        for k_ in env:
-            os.environ.pop(k_, None)
-os.environ.pop("FFX_SCORE_SLICE_PAIRS", None)
+variant()
 print(json.dumps(pg))
 same = all(np.array_equal(a, b) for a, b in zip(mine, outs))
 print(json.dumps({"pageable_equals_pinned": bool(same)}))
 run = run_pinned
 print(json.dumps({"one_shot_stats_default_slices": run()[3]}))
-os.environ["FFX_SCORE_SLICE_PAIRS"] = str(4 << 20)
+variant(f"score_slice_pairs={4 << 20}")
 run()
 print(json.dumps({"one_shot_stats_4M_slices": run()[3]}))
-os.environ.pop("FFX_SCORE_SLICE_PAIRS", None)
+variant()
 run()
 os.environ["FFX_SCORE_TRACE"] = "1"
 run()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-query ordering: rocPRIM's segmented radix sort vs the in-LDS block sort, per candidate-list length
-(6980 queries each).  FFX_SORT_BLOCK_FROM / _TO select which one a plan uses."""
+(6980 queries each).  FFX_DEBUG_VARIANT=sort_block_from=N / sort_block_to=N select which one a plan uses."""
 import json
 import os
 import sys
@@ -30,7 +30,7 @@ for k in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "10,50,100,256,
     plan.set_queries(queries)
     plan.set_pairs(pair_off, ids, sparse, 1)
     res = {}
-    for label, env in (("rocprim_segmented", {"FFX_SORT_BLOCK_FROM": "1000000"}), ("block_lds", {"FFX_SORT_BLOCK_FROM": "1"})):
+    for label, env in (("rocprim_segmented", {"FFX_DEBUG_VARIANT": "sort_block_from=1000000"}), ("block_lds", {"FFX_DEBUG_VARIANT": "sort_block_from=1"})):
         os.environ.update(env)
         ms = []
         for _ in range(6):

@@ -55,9 +55,9 @@ tplan.set_queries_device(docs.device_ptr(), n)
 tplan.set_pairs(t_off, t_ids, None, 1)
 for variant in ("", "914", "913", "911", "900"):
     if variant:
-        os.environ["FFX_GATHER_VARIANT"] = variant
+        os.environ["FFX_DEBUG_VARIANT"] = f"gather={variant}"
     else:
-        os.environ.pop("FFX_GATHER_VARIANT", None)
+        os.environ.pop("FFX_DEBUG_VARIANT", None)
     ms = []
     for _ in range(6):
         tplan.run(0.0, exact_sum=True)
@@ -66,5 +66,5 @@ for variant in ("", "914", "913", "911", "900"):
     same = bool(np.array_equal(got.view(np.uint32), ff[by_doc].view(np.uint32)))
     out[f"docs_in_registers_queries_gathered_variant_{variant or 'default'}"] = {"ms": float(np.mean(ms[1:])), "bit_identical": same,
                                                                                "kernel_variant": tplan.stats()["kernel_variant"]}
-os.environ.pop("FFX_GATHER_VARIANT", None)
+os.environ.pop("FFX_DEBUG_VARIANT", None)
 print(json.dumps(out, indent=1))
