@@ -105,10 +105,14 @@ class _Run:
             blocks = present[by_name]
             pick = np.concatenate([np.arange(off[q], off[q + 1]) for q in blocks]) if len(blocks) else np.zeros(0, dtype=np.int64)
             src, scores, present, q_order = src[pick], scores[pick], blocks, [q_order[i] for i in by_name]
-            counts_out = counts[blocks]
+            counts_out, moved = counts[blocks], True
         else:
-            counts_out = counts[present]
-        q_no = np.repeat(np.arange(len(present), dtype=np.int64), counts_out)
+            counts_out, moved = counts[present], False
+        if q_range is None and self.perm is None and not moved and len(present) == self.n_q and len(src) == len(self.q_no) \
+                and np.array_equal(off, self.pair_off):
+            q_no = self.q_no  # every row kept, the queries' blocks where they were: the ranking's own numbering (35 M int64 not written again)
+        else:
+            q_no = np.repeat(np.arange(len(present), dtype=np.int64), counts_out)
         texts = None if self.texts is None else [self.texts[q_lo + i] for i in present]
         codes = native.take32(self.codes, src) if src.dtype == np.int32 else self.codes[src]
         out = Ranking._assemble_coded(name, q_no, q_order, codes, self.names, scores.astype(self.ranking._score_dtype(), copy=False), texts,

@@ -507,6 +507,8 @@ def test_opq_and_generic_quantizers_score_decoded_rows():
     want = oracle_scores(wide.decode(wide.encode(x)))
     for q, i, s in zip(got["q_id"], got["id"], got["score"]):
         assert np.float32(s).view(np.uint32) == np.float32(want[(q, i)]).view(np.uint32)
+    idx.close()
+    idx2.close()
 
 
 # ---- file-to-file path and PyTerrier adapters ----------------------------------
