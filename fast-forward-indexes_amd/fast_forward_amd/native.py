@@ -739,20 +739,19 @@ def code_object_column(col: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, 
     n = col.shape[0]
     if n == 0:
         return np.zeros(0, dtype=np.int32), np.empty(0, dtype=object), None
-    if n >= (1 << 16):
-        # every cell its own object (a frame converted from fixed-width arrays, a JSON dump)?  Then numbering the pointers
-        # finds nothing to share and only costs two passes: a sample tells, and the strings are numbered directly
-        probe = col[:: max(1, n // 4096)][:4096].tolist()
-        if len({id(x) for x in probe}) > 0.9 * len(probe):
-            got = _code_distinct_objects(col, threads)
-            if got is None:
-                return None
-            codes, blob = got
-            n_names = int(codes.max()) + 1
-            names = np.empty(n_names, dtype=object)
-            names[codes] = col
-            return codes, names, ((blob, n_names) if (blob.count(b"\n") == n_names - 1 and b"\0" not in blob) else None)
     by_object, first = code_u64(col.ctypes.data, n, threads)
+    if n >= (1 << 16) and first.shape[0] > n // 2:
+        # (nearly) every cell its own object -- a frame converted from fixed-width arrays, a JSON dump: the pointers share
+        # nothing worth a second level, the strings of all rows are numbered directly, in row order (objects made one
+        # after the other lie one after the other in memory: a sequential read)
+        got = _code_distinct_objects(col, threads)
+        if got is None:
+            return None
+        codes, blob = got
+        n_names = int(codes.max()) + 1
+        names = np.empty(n_names, dtype=object)
+        names[codes] = col
+        return codes, names, ((blob, n_names) if (blob.count(b"\n") == n_names - 1 and b"\0" not in blob) else None)
     distinct = col[first]
     if distinct.shape[0] < 4096:  # few objects: joined in Python, numbered by the same coder (one numbering rule for any size)
         items = distinct.tolist()
