@@ -115,18 +115,25 @@ def _rendezvous_dir() -> str:
     given = os.environ.get("FFX_RDZV_DIR")
     if given:
         return given
-    base = os.environ.get("XDG_RUNTIME_DIR") or tempfile.gettempdir()
-    path = os.path.join(base, f"ffx-rdzv-{os.geteuid()}")
-    try:
-        os.mkdir(path, 0o700)
-    except FileExistsError:
-        pass
-    st = os.lstat(path)
     import stat
 
-    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o077):
-        raise PermissionError(f"{path} must be a directory owned by uid {os.geteuid()} with mode 0700 (set FFX_RDZV_DIR to choose another)")
-    return path
+    problem = None
+    for base in (os.environ.get("XDG_RUNTIME_DIR"), tempfile.gettempdir()):
+        if not base:
+            continue
+        path = os.path.join(base, f"ffx-rdzv-{os.geteuid()}")
+        try:
+            os.mkdir(path, 0o700)
+        except FileExistsError:
+            pass
+        except OSError as e:  # (a runtime directory that is announced but not writable: try the next place)
+            problem = e
+            continue
+        st = os.lstat(path)
+        if stat.S_ISDIR(st.st_mode) and st.st_uid == os.geteuid() and not (st.st_mode & 0o077):
+            return path
+        problem = PermissionError(f"{path} must be a directory owned by uid {os.geteuid()} with mode 0700")
+    raise PermissionError(f"no private directory for the communicator id ({problem}); set FFX_RDZV_DIR to choose one")
 
 
 def _read_rendezvous(path: str) -> bytes:
