@@ -433,8 +433,8 @@ def test_any_row_length_up_to_eight_leaves_is_bit_exact(store):
     unbalanced recursions (d = 260 gives leaves 128 | 64 + 68) -- against NumPy itself, bit for bit;
     beyond 8 leaves (d > 1024) and below 8 elements the staged generic kernel still answers."""
     rng = np.random.default_rng(77)
-    dims = [8, 9, 15, 16, 17, 31, 100, 127, 129, 130, 136, 200, 255, 257, 260, 300, 383, 385, 500, 513, 640, 700, 767, 769, 900,
-            1000, 1016, 1023, 5, 1032, 1100]
+    dims = [8, 9, 12, 15, 16, 17, 20, 31, 36, 100, 124, 127, 129, 130, 132, 136, 200, 255, 257, 260, 300, 383, 385, 388, 500, 513, 516, 640, 700,
+            767, 769, 772, 900, 1000, 1016, 1020, 1023, 5, 1032, 1100]
     for d in dims:
         n, nq, k = 140, 3, 90
         vectors = (rng.standard_normal((n, d)) * 1.5).astype(store)
