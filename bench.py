@@ -711,6 +711,7 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
     t0 = time.perf_counter()
     final = api.rerank(first, args.alpha)
     out["iii_rerank_s"] = time.perf_counter() - t0
+    out["iii_warm_call_breakdown"] = dict(getattr(api, "last_timings", {}))
     out["iii_pairs"] = int(nq * args.k)
     out["iii_queries_per_s_rerank"] = nq / out["iii_rerank_s"]
     t0 = time.perf_counter()

@@ -220,6 +220,7 @@ int ffo_score(const float* vectors, int64_t n_rows, int64_t d, const int64_t* do
         }
         float* s = n <= 64 ? stack_buf : (float*)malloc((size_t)n * sizeof(float));
         if (!s) {
+#pragma omp atomic write
           err = 1;
           continue;
         }
