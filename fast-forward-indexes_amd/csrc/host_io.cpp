@@ -671,9 +671,8 @@ int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n
 // POINTERS to Python strings, and a run of millions of rows names each query / document through the same few
 // objects (pandas' readers intern the strings of a column; frames built from arrays of names share them by
 // construction) -- numbering the pointers first leaves only the DISTINCT objects to be read as strings
-// (Ranking.__init__, ranking.py:95-116, on 34.9 M rows).  first_row[c] = a row holding number c (the first one
-// inside its shard); first_row must hold min(n, cap_distinct) entries, numbering is shard-major and independent of
-// the thread count.
+// (Ranking.__init__, ranking.py:95-116, on 34.9 M rows).  Numbers ascend with the values (they depend on the set of
+// values only); first_row[c] = a row holding number c; first_row must hold n entries at most.
 int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int32_t* codes, int64_t* first_row, int64_t* n_distinct) {
   if (n_distinct) *n_distinct = 0;
   if (n < 0 || !n_distinct || (n > 0 && (!values || !codes || !first_row))) return ffx_fail(FFX_BAD_ARG, "bad argument");
@@ -690,12 +689,27 @@ int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int3
     return v ^ (v >> 33);
   };
   try {
+    // Shards are RANGES of values (splitters from a sample), and inside a shard the distinct values are numbered in
+    // ascending order: the numbers come out in ascending order of the values altogether.  For object addresses that is
+    // the order in which the objects lie in memory -- whoever reads the distinct objects next (first_row) walks the heap
+    // front to back instead of jumping around in it (8.7 M strings: a cache miss per object less, twice) -- and the
+    // numbering depends on the set of values only.
+    std::vector<uint64_t> split;
+    {
+      const int64_t m = std::min<int64_t>(n, 1 << 16);
+      std::vector<uint64_t> sample((size_t)m);
+      for (int64_t i = 0; i < m; ++i) sample[(size_t)i] = values[(size_t)((__int128)i * n / m)];
+      std::sort(sample.begin(), sample.end());
+      for (int s = 1; s < S; ++s) split.push_back(sample[(size_t)((int64_t)s * m / S)]);
+    }
+    auto shard_of = [&](uint64_t v) { return (int)(std::upper_bound(split.begin(), split.end(), v) - split.begin()); };
     auto row_range = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
+    std::vector<uint8_t> shard((size_t)n);
     std::vector<int64_t> count((size_t)T * S, 0);
     run_threads(T, [&](int t) {
       const auto [lo, hi] = row_range(t);
       int64_t* c = count.data() + (size_t)t * S;
-      for (int64_t i = lo; i < hi; ++i) ++c[mix(values[i]) >> 56];
+      for (int64_t i = lo; i < hi; ++i) ++c[shard[(size_t)i] = (uint8_t)shard_of(values[i])];
     });
     std::vector<int64_t> shard_off((size_t)S + 1, 0);
     {
@@ -714,14 +728,14 @@ int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int3
     run_threads(T, [&](int t) {
       const auto [lo, hi] = row_range(t);
       int64_t* at = count.data() + (size_t)t * S;
-      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[mix(values[i]) >> 56]++] = (int32_t)i;
+      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[shard[(size_t)i]]++] = (int32_t)i;
     });
     std::vector<std::vector<int32_t>> firsts((size_t)S);
     std::atomic<int> next_shard(0);
     std::atomic<bool> oom(false);
     run_threads(T, [&](int) {
       try {
-        std::vector<int32_t> slot;
+        std::vector<int32_t> slot, by_value, renumber;
         for (;;) {
           const int s = next_shard.fetch_add(1);
           if (s >= S) return;
@@ -748,6 +762,19 @@ int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int3
               }
               at = (at + 1) & (cap - 1);
             }
+          }
+          // the shard's distinct values in ascending order
+          by_value.resize(first.size());
+          renumber.resize(first.size());
+          for (size_t j = 0; j < first.size(); ++j) by_value[j] = (int32_t)j;
+          std::sort(by_value.begin(), by_value.end(), [&](int32_t x, int32_t y) { return values[first[(size_t)x]] < values[first[(size_t)y]]; });
+          for (size_t j = 0; j < first.size(); ++j) renumber[(size_t)by_value[j]] = (int32_t)j;
+          std::vector<int32_t> sorted(first.size());
+          for (size_t j = 0; j < first.size(); ++j) sorted[j] = first[(size_t)by_value[j]];
+          first.swap(sorted);
+          for (int64_t k = lo; k < hi; ++k) {
+            int32_t& c = codes[rows[(size_t)k]];
+            c = renumber[(size_t)c];
           }
         }
       } catch (const std::bad_alloc&) {

@@ -366,8 +366,8 @@ int ffx_buffer_free(void* p);
  * an index file, index/disk.py:145-165); either column may be NULL.  Each rank keeps and interns only its own rows' ids. */
 int ffx_host_owner_crc32(const char* doc_ids, int32_t doc_width, const char* psg_ids, int32_t psg_width, int64_t n, int32_t world,
                          int32_t n_threads, uint8_t* owner);
-/* The same numbering for n 8-byte values (the key is the value itself): codes[i] = number of values[i], dense;
- * first_row[c] = a row that holds number c (first_row must hold n entries at most).  A column of a pandas frame is an
+/* Numbering n 8-byte values (the key is the value itself): codes[i] = number of values[i], dense, ascending with the
+ * values; first_row[c] = a row that holds number c (first_row must hold n entries at most).  A column of a pandas frame is an
  * array of pointers to string objects shared by many rows: numbering the pointers leaves only the distinct objects to
  * be read as strings (the Ranking constructor, ranking.py:95-116, at tens of millions of rows). */
 int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int32_t* codes, int64_t* first_row, int64_t* n_distinct);

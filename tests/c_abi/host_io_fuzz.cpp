@@ -267,7 +267,7 @@ int main(int argc, char** argv) {
         for (int64_t i = 0; i < n; ++i)
           if (vc[(size_t)i] < 0 || vc[(size_t)i] >= nd || vals[(size_t)first[(size_t)vc[(size_t)i]]] != vals[(size_t)i]) return 1;
         for (int64_t c = 0; c < nd; ++c)
-          if (vc[(size_t)first[(size_t)c]] != c) return 1;
+          if (vc[(size_t)first[(size_t)c]] != c || (c > 0 && vals[(size_t)first[(size_t)c]] <= vals[(size_t)first[(size_t)c - 1]])) return 1;  // ascending with the values
       }
       // every query ordered and the queries' blocks laid out in reverse in one pass
       {
