@@ -754,7 +754,8 @@ int ffx_index_set_psg_rows(ffx_index* idx, const int32_t* psg_row, int64_t n_psg
 }
 
 // ---- plan -------------------------------------------------------------------------------------
-int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
+// with_stream = false: a plan that only ever runs on streams lent to it (slices 1 and 2 of ffx_score)
+static int plan_create(ffx_index* idx, ffx_plan** out, bool with_stream) {
   if (!idx || !out) return fail(FFX_BAD_ARG, "NULL argument");
   *out = nullptr;
   FFX_HIP(hipSetDevice(idx->device));
@@ -762,7 +763,7 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
   if (!pl) return fail(FFX_OOM, "host allocation failed");
   pl->idx = idx;
   pl->device = idx->device;
-  hipError_t e = hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking);
+  hipError_t e = with_stream ? hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking) : hipSuccess;
   pl->stream = pl->own_stream;
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&pl->ev[i]);
   if (e != hipSuccess) {
@@ -845,6 +846,8 @@ int ffx_plan_create(ffx_index* idx, ffx_plan** out) {
   *out = pl;
   return FFX_OK;
 }
+
+int ffx_plan_create(ffx_index* idx, ffx_plan** out) { return plan_create(idx, out, true); }
 
 int ffx_plan_destroy(ffx_plan* pl) {
   if (!pl) return FFX_OK;
@@ -2340,7 +2343,12 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   // for the headline batch); with THREE plans the upload of slice c overlaps the kernels of c-1 and c-2.
   // The kernels of all slices are issued on ONE stream, in order: on a stream per plan they share the GPU, finish
   // together and free their plans together, so the device again idles while the next group is uploaded (23.1 ms).
-  // Uploads stay on each plan's own stream (they are awaited by the caller before the kernels are issued).
+  // Uploads (and the ordinal check that follows each) go on ONE more stream, plan 0's own, whichever plan the slice
+  // uses: the caller awaits each before the next begins, so nothing is lost, and the call then occupies three
+  // streams (uploads, kernels, results) instead of five.  The device has four hardware queues for ordinary
+  // streams; with a stream per plan two of the five shared one, and when that pair was an upload stream and the
+  // kernel stream the upload queued behind a slice's kernels (3.9 ms instead of 0.9 ms for set_pairs: 20.9 ms
+  // instead of 18.4 ms for the headline batch, depending on which other streams the process had created).
   bool async_out = false;
   if (n_slices > 1 && !ffx_debug_variant("score_no_out_stream", nullptr)) {
     const void* any = out_ff ? (const void*)out_ff : out_interp ? (const void*)out_interp : (const void*)out_order;
@@ -2354,14 +2362,24 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     int least = 0, greatest = 0;
     FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
-    if (!idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
     for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order) && !ffx_debug_variant("score_blocking_out", nullptr);
-  if (threaded_out && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
   const int n_plans = n_slices > 1 ? (async_out || threaded_out ? 3 : 2) : 1;
   for (int i = 0; i < n_plans; ++i)
-    if (!idx->score_plans[i]) FFX_TRY(ffx_plan_create(idx, &idx->score_plans[i]));
+    if (!idx->score_plans[i]) FFX_TRY(plan_create(idx, &idx->score_plans[i], i == 0));
+  if (n_slices > 1 && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
+  // where a plan's uploads go; with blocking result copies (two plans alternate, each complete on its stream)
+  // the second plan lives on the kernel stream
+  hipStream_t home[3];
+  for (int i = 0; i < 3; ++i) home[i] = (i == 1 && !async_out && !threaded_out) ? idx->score_stream : idx->score_plans[0]->own_stream;
+  struct LentStreams {  // plans 1 and 2 own no stream: they hold none between calls
+    ffx_index* idx;
+    ~LentStreams() {
+      for (int i = 1; i < 3; ++i)
+        if (idx->score_plans[i]) idx->score_plans[i]->stream = nullptr;
+    }
+  } lent{idx};
   ffx_stats acc;
   memset(&acc, 0, sizeof acc);
   auto add_stats = [&](ffx_plan* pl) -> int {
@@ -2453,6 +2471,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
       if (async_out && c >= n_plans) FFX_TRY(retire(c - n_plans));
       if (threaded_out && c >= n_plans) FFX_TRY(join_fetch(c - n_plans));
       const double t0b = us();
+      pl->stream = home[c % n_plans];
       FFX_TRY(ffx_plan_set_queries(pl, host_queries ? host_queries + (size_t)q0 * idx->qdim : nullptr, q1 - q0));
       const double t1 = us();
       off.resize((size_t)(q1 - q0 + 1));
@@ -2468,7 +2487,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
       const double t2 = us();
       if (async_out || threaded_out) pl->stream = idx->score_stream;
       const int rc_run = ffx_plan_run(pl, alpha, flags);
-      pl->stream = pl->own_stream;
+      pl->stream = home[c % n_plans];
       if (rc_run != FFX_OK) return rc_run;
       const double t3 = us();
       if (async_out)
@@ -2507,8 +2526,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     if (f.valid()) (void)f.get();  // only after a failure: no helper outlives the call
   if (rc != FFX_OK) {  // nothing may still be writing when the caller gets its buffers back
     const std::string keep = g_last_error;
-    for (ffx_plan* pl : idx->score_plans)
-      if (pl) (void)hipStreamSynchronize(pl->stream);
+    (void)hipStreamSynchronize(idx->score_plans[0]->own_stream);
     if (idx->score_stream) (void)hipStreamSynchronize(idx->score_stream);
     if (idx->out_stream) (void)hipStreamSynchronize(idx->out_stream);
     g_last_error = keep;
