@@ -204,7 +204,7 @@ reduce_kernel(const float* __restrict__ rs, const int32_t* __restrict__ seg_off,
               float* __restrict__ ff, float* __restrict__ interp) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
-  const int32_t s = seg_off[p], e = seg_off[p + 1];
+  const int32_t s = seg_off ? seg_off[p] : (int32_t)p, e = seg_off ? seg_off[p + 1] : s + 1;  // no offsets: one row each
   float out;
   if (mode == FFX_MODE_MAXP) {
     out = rs[s];

@@ -2128,18 +2128,23 @@ int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems) 
 int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, int64_t n_pairs, int mode,
                   const float* sparse, double alpha, const int64_t* pair_off, int64_t n_queries, uint32_t flags,
                   float* out_ff, float* out_interp, int32_t* out_order) {
-  if (n_pairs < 0 || !seg_off || (n_pairs > 0 && (!row_scores || !out_ff))) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_pairs < 0 || (n_pairs > 0 && (!row_scores || !out_ff))) return fail(FFX_BAD_ARG, "bad argument");
   if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
   if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores: nothing to interpolate");
   const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
   if (do_sort && (!pair_off || !out_order || n_queries < 0)) return fail(FFX_BAD_ARG, "sorting needs pair_off and out_order");
   if (n_pairs == 0) return FFX_OK;
-  const int64_t R = seg_off[n_pairs];
-  if (seg_off[0] != 0 || R > INT32_MAX || n_pairs > INT32_MAX - 1) return fail(FFX_BAD_ARG, "bad segment offsets");
-  std::vector<int32_t> off32((size_t)n_pairs + 1);
-  for (int64_t p = 0; p <= n_pairs; ++p) {
-    if (p > 0 && seg_off[p] <= seg_off[p - 1]) return fail(FFX_BAD_ARG, "candidate %lld has no rows", (long long)(p - 1));
-    off32[(size_t)p] = (int32_t)seg_off[p];
+  if (n_pairs > INT32_MAX - 1) return fail(FFX_BAD_ARG, "bad segment offsets");
+  // seg_off == NULL: one row per candidate (the row scores are the candidates' scores)
+  const int64_t R = seg_off ? seg_off[n_pairs] : n_pairs;
+  std::vector<int32_t> off32;
+  if (seg_off) {
+    if (seg_off[0] != 0 || R > INT32_MAX) return fail(FFX_BAD_ARG, "bad segment offsets");
+    off32.resize((size_t)n_pairs + 1);
+    for (int64_t p = 0; p <= n_pairs; ++p) {
+      if (p > 0 && seg_off[p] <= seg_off[p - 1]) return fail(FFX_BAD_ARG, "candidate %lld has no rows", (long long)(p - 1));
+      off32[(size_t)p] = (int32_t)seg_off[p];
+    }
   }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
@@ -2147,38 +2152,47 @@ int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, i
     return fail(FFX_NO_DEVICE, "no HIP device: libffx has no CPU fallback");
   }
   FFX_HIP(hipSetDevice(device));
-  DevBuf rs, so, sp, ff, in, po, order, iota, keys, tmp;
+  // the inputs and results of the call share ONE device block (an allocation and a release per buffer cost more
+  // than the kernels of a million candidates); the ordering keeps its own work buffers
+  auto padded = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+  const size_t b_rs = padded((size_t)R * sizeof(float)), b_so = padded(off32.size() * sizeof(int32_t)), b_p = padded((size_t)n_pairs * sizeof(float));
+  const size_t b_po = do_sort ? padded((size_t)(n_queries + 1) * sizeof(int64_t)) : 0;
+  DevBuf block, order, iota, keys, tmp;
   int rc = FFX_OK;
   auto run = [&]() -> int {
-    FFX_TRY(rs.ensure((size_t)R * sizeof(float)));
-    FFX_TRY(so.ensure(off32.size() * sizeof(int32_t)));
-    FFX_TRY(ff.ensure((size_t)n_pairs * sizeof(float)));
-    FFX_HIP(hipMemcpy(rs.p, row_scores, (size_t)R * sizeof(float), hipMemcpyHostToDevice));
-    FFX_HIP(hipMemcpy(so.p, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    FFX_TRY(block.ensure(b_rs + b_so + (sparse ? 3 : 1) * b_p + b_po));
+    char* at = block.as<char>();
+    float* d_rs = (float*)at;
+    at += b_rs;
+    int32_t* d_so = seg_off ? (int32_t*)at : nullptr;
+    at += b_so;
+    float* d_ff = (float*)at;
+    at += b_p;
+    float *d_sp = nullptr, *d_in = nullptr;
     if (sparse) {
-      FFX_TRY(sp.ensure((size_t)n_pairs * sizeof(float)));
-      FFX_TRY(in.ensure((size_t)n_pairs * sizeof(float)));
-      FFX_HIP(hipMemcpy(sp.p, sparse, (size_t)n_pairs * sizeof(float), hipMemcpyHostToDevice));
+      d_sp = (float*)at;
+      d_in = (float*)(at + b_p);
+      at += 2 * b_p;
     }
-    ffx::reduce_kernel<<<blocks_for(n_pairs, 256), 256>>>(rs.as<float>(), so.as<int32_t>(), n_pairs, mode,
-                                                         sparse ? sp.as<float>() : nullptr, (float)alpha, (float)(1.0 - alpha),
-                                                         ff.as<float>(), in.as<float>());
+    int64_t* d_po = (int64_t*)at;
+    FFX_HIP(hipMemcpy(d_rs, row_scores, (size_t)R * sizeof(float), hipMemcpyHostToDevice));
+    if (seg_off) FFX_HIP(hipMemcpy(d_so, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (sparse) FFX_HIP(hipMemcpy(d_sp, sparse, (size_t)n_pairs * sizeof(float), hipMemcpyHostToDevice));
+    ffx::reduce_kernel<<<blocks_for(n_pairs, 256), 256>>>(d_rs, d_so, n_pairs, mode, d_sp, (float)alpha, (float)(1.0 - alpha), d_ff, d_in);
     FFX_HIP(hipGetLastError());
     if (do_sort) {
-      FFX_TRY(po.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
-      FFX_HIP(hipMemcpy(po.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-      const float* k = (sparse && !(flags & FFX_FLAG_SORT_FF)) ? in.as<float>() : ff.as<float>();
-      FFX_TRY(launch_segmented_sort(k, n_pairs, po.as<int64_t>(), n_queries, order, iota, keys, tmp, nullptr,
-                                    longest_segment(pair_off, n_queries)));
+      FFX_HIP(hipMemcpy(d_po, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+      const float* k = (sparse && !(flags & FFX_FLAG_SORT_FF)) ? d_in : d_ff;
+      FFX_TRY(launch_segmented_sort(k, n_pairs, d_po, n_queries, order, iota, keys, tmp, nullptr, longest_segment(pair_off, n_queries)));
     }
     FFX_HIP(hipDeviceSynchronize());
-    FFX_HIP(hipMemcpy(out_ff, ff.p, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_interp) FFX_HIP(hipMemcpy(out_interp, in.p, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    FFX_HIP(hipMemcpy(out_ff, d_ff, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_interp) FFX_HIP(hipMemcpy(out_interp, d_in, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
     if (do_sort) FFX_HIP(hipMemcpy(out_order, order.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
     return FFX_OK;
   };
   rc = run();
-  for (DevBuf* b : {&rs, &so, &sp, &ff, &in, &po, &order, &iota, &keys, &tmp}) b->release();
+  for (DevBuf* b : {&block, &order, &iota, &keys, &tmp}) b->release();
   return rc;
 }
 

@@ -883,7 +883,7 @@ int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_
   const uint32_t* s = static_cast<const uint32_t*>(src);
   uint32_t* o = static_cast<uint32_t*>(out);
   int T = n_threads > 0 ? n_threads : usable_cores();
-  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 18) + 1}));
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
   std::atomic<int64_t> next(0), bad(-1);
   const int64_t block = 1 << 16;
   auto work = [&]() {
@@ -926,7 +926,7 @@ int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32
   if (n > 0 && (!sparse || !dense_of || !source_row || !out)) return ffx_fail(FFX_BAD_ARG, "NULL argument");
   if (n == 0) return FFX_OK;
   int T = n_threads > 0 ? n_threads : usable_cores();
-  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 18) + 1}));
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
   uint8_t* seen = static_cast<uint8_t*>(calloc((size_t)n, 1));  // zero pages on first touch, no initialising pass
   if (!seen) return ffx_fail(FFX_OOM, "host allocation failed");
   std::atomic<int64_t> next(0), bad(-1), marked(0);

@@ -416,10 +416,9 @@ class OnDiskIndex(Index):
 
     # ---- scoring: stream the needed rows through two HBM windows --------------------------------------------
     def _expand(self, pair_off: np.ndarray, pair_ids: np.ndarray, mode: int):
-        """Pairs -> gathered rows on the host (get_indices, index/util.py:29-41):
-        (row numbers [R], query of each row [R], segment offsets [P+1])."""
+        """Pairs -> gathered rows on the host (get_indices, index/util.py:29-41): (row numbers [R], segment offsets
+        [P+1]); the offsets are None when every candidate contributes exactly one row (rows and pairs coincide)."""
         n_pairs = int(pair_off[-1])
-        pair_q = np.repeat(np.arange(pair_off.shape[0] - 1, dtype=np.int64), np.diff(pair_off))
         # the id tables as int64 arrays, made once per state of the index (a copy of a table of millions of rows per
         # call cost more than the candidates' own look-ups)
         cache = getattr(self, "_expand_tables", None)
@@ -432,22 +431,21 @@ class OnDiskIndex(Index):
             cache = (self._ids.version, doc_off, doc_rows, psg_rows, bool(doc_off.shape[0] > 1 and (np.diff(doc_off) == 1).all()), tables32)
             self._expand_tables = cache
         _, doc_off, doc_rows, psg_rows, one_row_each, tables32 = cache
-        one_each = np.arange(n_pairs + 1, dtype=np.int64)
         ids32 = np.ascontiguousarray(pair_ids, dtype=np.int32)
         if mode == PASSAGE:
             if tables32 is not None:  # (the gathers by host threads: a million random reads of a table of millions)
-                return native.take32(tables32[2], ids32).astype(np.int64), pair_q, one_each
-            return psg_rows[pair_ids], pair_q, one_each
+                return native.take32(tables32[2], ids32), None
+            return psg_rows[pair_ids], None
         if (mode == FIRSTP or one_row_each) and tables32 is not None:
-            return native.take32(tables32[1], native.take32(tables32[0], ids32)).astype(np.int64), pair_q, one_each
+            return native.take32(tables32[1], native.take32(tables32[0], ids32)), None
         start = doc_off[pair_ids]
         if mode == FIRSTP or one_row_each:
-            return doc_rows[start], pair_q, one_each
+            return doc_rows[start], None
         cnt = doc_off[pair_ids.astype(np.int64) + 1] - start
         seg_off = np.zeros(n_pairs + 1, dtype=np.int64)
         np.cumsum(cnt, out=seg_off[1:])
         within = np.arange(int(seg_off[-1]), dtype=np.int64) - np.repeat(seg_off[:-1], cnt)
-        return doc_rows[np.repeat(start, cnt) + within], np.repeat(pair_q, cnt), seg_off
+        return doc_rows[np.repeat(start, cnt) + within], seg_off
 
     def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False, want_dense=True):
         if len(self) == 0:
@@ -463,7 +461,8 @@ class OnDiskIndex(Index):
         n_q = q.shape[0]
         pair_off = np.asarray(pair_off, dtype=np.int64)
         t_call = time.perf_counter()
-        rows, row_q, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
+        rows, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
+        row_off = pair_off if seg_off is None else seg_off[pair_off]  # first gathered row of every query
         t_expanded = time.perf_counter()
         # each needed row is read once: the distinct rows, ascending, and every gathered row's slot among them
         if rows.shape[0] >= (1 << 16):
@@ -533,7 +532,13 @@ class OnDiskIndex(Index):
         t = threading.Thread(target=uploader, name="ffx-ondisk-uploader", daemon=True)
         t.start()
         try:
-            window_of_slot = slot_row // per_window
+            # a window's gathered rows: their positions in the row list (ascending, so grouped by query), the queries'
+            # offsets among them and the rows' places in the window.  Made while the window is still on its way.
+            def candidates_of(w: int):
+                slots = np.flatnonzero((slot_row >= w * per_window) & (slot_row < (w + 1) * per_window))
+                return slots, np.searchsorted(slots, row_off).astype(np.int64), (slot_row[slots] - w * per_window).astype(np.int32)
+
+            upcoming = candidates_of(0)
             for _ in range(n_win):
                 w, i = ready.get()
                 if w < 0:
@@ -541,11 +546,11 @@ class OnDiskIndex(Index):
                 t_sc = time.perf_counter()
                 if native_gather:
                     bufs[i].upload_wait()
-                slots = np.flatnonzero(window_of_slot == w)  # ascending: grouped by query already
-                local_off = np.zeros(n_q + 1, dtype=np.int64)
-                np.cumsum(np.bincount(row_q[slots], minlength=n_q), out=local_off[1:])
-                plans[i].set_pairs(local_off, (slot_row[slots] - w * per_window).astype(np.int32), None, PASSAGE)
+                slots, local_off, local_rows = upcoming
+                plans[i].set_pairs(local_off, local_rows, None, PASSAGE)
                 plans[i].run(0.0, exact_sum=self.exact_sum)
+                if w + 1 < n_win:
+                    upcoming = candidates_of(w + 1)  # (windows come in order: one uploader)
                 rs[slots] = plans[i].fetch()[0]
                 stats["ms_gather_dot"] += plans[i].stats()["ms_gather_dot"]
                 stats["kernel_variant"] = plans[i].stats()["kernel_variant"]

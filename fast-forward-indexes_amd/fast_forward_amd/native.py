@@ -1112,9 +1112,10 @@ class RunFile:
 
 def aggregate(row_scores, seg_off, mode: int, sparse=None, alpha: float = 0.0, pair_off=None, sort: bool = False, device: int = 0):
     """``ffx_aggregate``: segment max/first/mean of host row scores, interpolation and per-query
-    order on the device.  Returns (dense, interpolated|None, order|None)."""
-    row_scores, seg_off = _arr(row_scores, np.float32), _arr(seg_off, np.int64)
-    n = seg_off.shape[0] - 1
+    order on the device; ``seg_off`` None = one row per candidate.  Returns (dense, interpolated|None, order|None)."""
+    row_scores = _arr(row_scores, np.float32)
+    seg_off = None if seg_off is None else _arr(seg_off, np.int64)
+    n = row_scores.shape[0] if seg_off is None else seg_off.shape[0] - 1
     sp = None if sparse is None else _arr(sparse, np.float32)
     po = None if pair_off is None else _arr(pair_off, np.int64)
     ff = np.empty(n, dtype=np.float32)

@@ -323,7 +323,8 @@ int ffx_sharded_device_ptr(ffx_sharded* s, int which, void** ptr, int64_t* n_ele
 /* ---- stand-alone epilogue: the reduce / interpolate / sort stages of ffx_plan_run applied to row
  * scores held by the caller (host arrays in, host arrays out).  A streamed (on-disk) index scores
  * its rows window by window and aggregates once at the end: candidate p owns row scores
- * seg_off[p] .. seg_off[p+1] (index/base.py:306-312, ranking.py:319, ranking.py:115-117). */
+ * seg_off[p] .. seg_off[p+1] (index/base.py:306-312, ranking.py:319, ranking.py:115-117);
+ * seg_off == NULL means one row per candidate. */
 int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, int64_t n_pairs, int mode,
                   const float* sparse, double alpha, const int64_t* pair_off, int64_t n_queries, uint32_t flags,
                   float* out_ff, float* out_interp, int32_t* out_order);
