@@ -419,6 +419,38 @@ merge_kernel(const float* __restrict__ recv, const int32_t* __restrict__ slot, c
   if (sparse != nullptr) interp[p] = interp_one(a, b, sparse[p], dense);
 }
 
+// Rows of an on-disk index pulled by the device itself: `chunks` are DEVICE addresses of page-locked chunk maps in host
+// memory (ffx_host_pin + hipHostGetDevicePointer), so every load below is a read over PCIe and no host thread touches
+// the rows.  Row rows[r] (chunk rows[r] / chunk_rows, row rows[r] % chunk_rows of it) lands in row r of `dst`.  A group
+// of G lanes (a power of two, 64 for rows of 64 units and more) moves one row, four loads of V in flight per lane
+// before the stores: 59 - 61 GB/s for 3072-byte rows from 64 - 1024 workgroups (tools/probes/host_pull_probe.hip;
+// a page-locked hipMemcpy of one contiguous block: 57 GB/s on the same box).
+template <typename V>
+__global__ void __launch_bounds__(256)
+pull_rows_kernel(const char* const* __restrict__ chunks, int64_t chunk_rows, const int64_t* __restrict__ rows, int64_t n_rows,
+                 int row_units, int G, char* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1), per_wave = 64 / G;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t r = wave * per_wave + lane / G; r < n_rows; r += n_waves * per_wave) {
+    const int64_t row = rows[r];
+    const V* s = reinterpret_cast<const V*>(chunks[row / chunk_rows]) + (size_t)(row % chunk_rows) * row_units;
+    V* d = reinterpret_cast<V*>(dst) + (size_t)r * row_units;
+    for (int u0 = 0; u0 < row_units; u0 += 4 * G) {
+      V v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int u = u0 + j * G + gl;
+        if (u < row_units) v[j] = s[u];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int u = u0 + j * G + gl;
+        if (u < row_units) d[u] = v[j];
+      }
+    }
+  }
+}
+
 // ---- row copy-out for _get_vectors (index/memory.py:139-140) --------------------------------
 template <typename W>
 __global__ void __launch_bounds__(256)

@@ -222,6 +222,12 @@ struct ffx_index {
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
   bool stage_busy[2] = {false, false};  // a copy out of the block may still be in flight (ffx_index_upload_rows_async)
   int64_t pending_row = 0, pending_rows = 0;  // rows whose codes ffx_index_upload_wait still has to check (PQ rows)
+  // ffx_index_pull_rows_async: the row list and the chunk maps' device addresses (kept while the maps stay the same)
+  DevBuf pull_list, pull_chunks;
+  std::vector<const void*> pull_chunk_hosts;
+  int64_t* pull_list_host = nullptr;  // page-locked, pull_list_room entries
+  hipEvent_t order_ev = nullptr;      // ffx_index_upload_after
+  int64_t pull_list_room = 0;
   hipStream_t copy_stream = nullptr;
   // ffx_score with page-locked result buffers: results leave on this stream (highest priority, so that the
   // copy of slice c is not queued behind the scoring kernels of slice c+1), one event per plan
@@ -429,6 +435,10 @@ int ffx_index_destroy(ffx_index* idx) {
     if (idx->stage_ev[i]) (void)hipEventDestroy(idx->stage_ev[i]);
   }
   if (idx->copy_stream) (void)hipStreamDestroy(idx->copy_stream);
+  if (idx->pull_list_host) (void)hipHostFree(idx->pull_list_host);
+  if (idx->order_ev) (void)hipEventDestroy(idx->order_ev);
+  idx->pull_list.release();
+  idx->pull_chunks.release();
   if (idx->out_stream) (void)hipStreamDestroy(idx->out_stream);
   if (idx->score_stream) (void)hipStreamDestroy(idx->score_stream);
   for (auto& e : idx->out_done)
@@ -620,6 +630,91 @@ int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64
   if (rc != FFX_OK) return rc;
   idx->pending_row = dst_row;
   idx->pending_rows = n_rows;
+  return FFX_OK;
+}
+
+// The rows of ffx_index_upload_rows_async pulled by the device: every chunk map must be page-locked (ffx_host_pin), the
+// kernel reads the rows out of host memory over PCIe on the copy stream.  No staging block, no host threads.
+int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
+                              const int64_t* rows, int64_t n_rows, int64_t dst_row) {
+  if (!idx || n_rows < 0 || dst_row < 0 || n_chunks < 0 || chunk_rows <= 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_rows == 0) return FFX_OK;
+  if (!chunks || !rows) return fail(FFX_BAD_ARG, "NULL argument");
+  if (dst_row + n_rows > idx->capacity) return fail(FFX_BAD_ARG, "rows [%lld, %lld) exceed the capacity %lld", (long long)dst_row, (long long)(dst_row + n_rows), (long long)idx->capacity);
+  const int64_t n_src = n_chunks * chunk_rows;
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (rows[i] < 0 || rows[i] >= n_src) return fail(FFX_BAD_ARG, "rows[%lld] = %lld is outside the %lld stored rows", (long long)i, (long long)rows[i], (long long)n_src);
+  FFX_HIP(hipSetDevice(idx->device));
+  if (!idx->copy_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
+  if (idx->pending_rows > 0) FFX_TRY(ffx_index_upload_wait(idx));  // (an earlier asynchronous upload nobody waited for)
+  const size_t rb = (size_t)idx->dim * idx->elem;
+  size_t align = 16;
+  while (align > 1 && rb % align) align >>= 1;
+  if (idx->pull_chunk_hosts.size() != (size_t)n_chunks || !std::equal(chunks, chunks + n_chunks, idx->pull_chunk_hosts.begin())) {
+    std::vector<const void*> dev((size_t)n_chunks);
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      void* d = nullptr;
+      if (!chunks[c] || hipHostGetDevicePointer(&d, const_cast<void*>(chunks[c]), 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        return fail(FFX_BAD_ARG, "chunk %lld is not page-locked host memory (ffx_host_pin it first)", (long long)c);
+      }
+      dev[(size_t)c] = d;
+    }
+    idx->pull_chunk_hosts.clear();
+    FFX_TRY(idx->pull_chunks.ensure((size_t)n_chunks * sizeof(void*)));
+    FFX_HIP(hipStreamSynchronize(idx->copy_stream));  // (a kernel of an earlier call may still read the old table)
+    FFX_HIP(hipMemcpy(idx->pull_chunks.p, dev.data(), (size_t)n_chunks * sizeof(void*), hipMemcpyHostToDevice));
+    idx->pull_chunk_hosts.assign(chunks, chunks + n_chunks);
+  }
+  for (int64_t c = 0; c < n_chunks; ++c)  // the widest unit every row starts on
+    while (align > 1 && reinterpret_cast<uintptr_t>(chunks[c]) % align) align >>= 1;
+  FFX_TRY(idx->pull_list.ensure((size_t)n_rows * sizeof(int64_t)));
+  if (idx->pull_list_room < n_rows) {  // (nothing is in flight out of the old block: pending_rows was 0 or has been waited for)
+    if (idx->pull_list_host) (void)hipHostFree(idx->pull_list_host);
+  if (idx->order_ev) (void)hipEventDestroy(idx->order_ev);
+    idx->pull_list_host = nullptr;
+    idx->pull_list_room = 0;
+    const int64_t room = std::max<int64_t>(n_rows + n_rows / 4, 1 << 16);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&idx->pull_list_host), (size_t)room * sizeof(int64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+      idx->pull_list_host = nullptr;
+      return fail(FFX_OOM, "hipHostMalloc(%zu bytes) failed: %s", (size_t)room * sizeof(int64_t), hipGetErrorString(e));
+    }
+    idx->pull_list_room = room;
+  }
+  memcpy(idx->pull_list_host, rows, (size_t)n_rows * sizeof(int64_t));
+  FFX_HIP(hipMemcpyAsync(idx->pull_list.p, idx->pull_list_host, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, idx->copy_stream));
+  const int units = (int)(rb / align);
+  int G = 64;
+  while (G > 1 && G / 2 >= units) G >>= 1;
+  const int64_t waves = (n_rows + 64 / G - 1) / (64 / G);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(256, (waves + 3) / 4));
+  const char* const* table = idx->pull_chunks.as<const char*>();
+  char* dst = static_cast<char*>(idx->row_ptr(dst_row));
+  if (align == 16)
+    ffx::pull_rows_kernel<uint4><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, units, G, dst);
+  else if (align >= 4)
+    ffx::pull_rows_kernel<uint32_t><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, (int)(rb / 4), G = 64, dst);
+  else
+    ffx::pull_rows_kernel<unsigned char><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, (int)rb, G = 64, dst);
+  FFX_HIP(hipGetLastError());
+  idx->pending_row = dst_row;
+  idx->pending_rows = n_rows;
+  return FFX_OK;
+}
+
+// Orders what is queued on idx's copy stream from now on behind what `before`'s copy stream holds so far: the windows
+// of a streamed index are filled one after the other instead of sharing the link (the first one is ready -- and
+// scored, and free again -- while the second is still on its way).
+int ffx_index_upload_after(ffx_index* idx, ffx_index* before) {
+  if (!idx || !before) return fail(FFX_BAD_ARG, "NULL argument");
+  if (idx == before || !before->copy_stream) return FFX_OK;
+  if (idx->device != before->device) return fail(FFX_BAD_ARG, "the indexes live on different devices");
+  FFX_HIP(hipSetDevice(idx->device));
+  if (!idx->copy_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->copy_stream, hipStreamNonBlocking));
+  if (!before->order_ev) FFX_HIP(hipEventCreateWithFlags(&before->order_ev, hipEventDisableTiming));
+  FFX_HIP(hipEventRecord(before->order_ev, before->copy_stream));
+  FFX_HIP(hipStreamWaitEvent(idx->copy_stream, before->order_ev, 0));
   return FFX_OK;
 }
 

@@ -56,6 +56,23 @@ _FORMAT_VERSION = 1
 # busy threads beyond the quota get the whole group throttled, and the scoring thread and the copy engine's driver
 # thread need their share: on a 16-core quota 12 threads gather at 53 GB/s, 16 at 45, 8 at 42: profiles/r03/
 # ondisk_stream_threads.json); FFX_READ_THREADS overrides
+def _available_host_bytes() -> int | None:
+    """What the kernel says could still be used without swapping (/proc/meminfo MemAvailable), capped by what the
+    container's memory limit leaves (cgroup v2 memory.max - memory.current)."""
+    available = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                available = int(line.split()[1]) << 10
+                break
+        limit, used = open("/sys/fs/cgroup/memory.max").read().strip(), open("/sys/fs/cgroup/memory.current").read().strip()
+        if limit != "max" and available is not None:
+            available = min(available, max(0, int(limit) - int(used)))
+    except (OSError, ValueError):
+        pass
+    return available
+
+
 _READ_THREADS = int(os.environ.get("FFX_READ_THREADS", "0")) or max(1, min(24, native.usable_cores() * 3 // 4))
 
 
@@ -66,7 +83,7 @@ class OnDiskIndex(Index):
                  mode: Mode = Mode.MAXP, encoder_batch_size: int = 32, init_size: int = 2**16, chunk_size: int = 2**16,
                  max_id_length: int = 8, overwrite: bool = False, memory_mapped: bool = False,
                  max_indexing_size: int = 2**10, device: int = 0, exact_sum: bool = True,
-                 window_bytes: int = 1 << 30) -> None:
+                 window_bytes: int = 1 << 30, page_lock: bool | None = None) -> None:
         """Create (or overwrite) an index file.
 
         :param init_size: kept for API compatibility (chunks are allocated as rows arrive).
@@ -75,6 +92,9 @@ class OnDiskIndex(Index):
         :param memory_mapped, max_indexing_size: kept for API compatibility; rows are always read
             through memory maps of the chunk blocks.
         :param window_bytes: HBM staging budget per window while scoring (two windows are resident).
+        :param page_lock: page-lock the file's vector maps at the first streamed call, so that the device reads the rows
+            it needs straight out of the mapped file (no host threads, no staging copy).  The file's pages then stay in
+            host memory.  None (default): when the vectors fit in half of the memory that is available.
         :raises ValueError: when the file exists and ``overwrite`` is false.
         """
         index_file = Path(index_file)
@@ -82,7 +102,7 @@ class OnDiskIndex(Index):
             raise ValueError(f"File {index_file} exists.")
         native.lib()
         self._index_file = index_file.absolute()
-        self._init_state(device, exact_sum, window_bytes)
+        self._init_state(device, exact_sum, window_bytes, page_lock)
         self._meta = {"version": _FORMAT_VERSION, "ff_version": "0.8.0+amd", "num_vectors": 0, "dim": None, "dtype": None,
                       "chunk_size": int(chunk_size), "max_id_length": int(max_id_length), "chunks": [], "quantizer": None}
         self._index_file.parent.mkdir(parents=True, exist_ok=True)
@@ -91,7 +111,8 @@ class OnDiskIndex(Index):
         self._write_header()
         super().__init__(query_encoder=query_encoder, quantizer=quantizer, mode=mode, encoder_batch_size=encoder_batch_size)
 
-    def _init_state(self, device: int, exact_sum: bool, window_bytes: int) -> None:
+    def _init_state(self, device: int, exact_sum: bool, window_bytes: int, page_lock: bool | None = None) -> None:
+        self._page_lock, self._locked_maps, self._lock_refused = page_lock, None, None
         self._ids = IdTable()
         self._maps: list[tuple[np.memmap, np.memmap, np.memmap]] = []
         self._device, self.exact_sum, self._window_bytes = int(device), bool(exact_sum), int(window_bytes)
@@ -110,9 +131,38 @@ class OnDiskIndex(Index):
                 b.close()
         self._windows = None
 
+    def _unlock_maps(self) -> None:
+        if getattr(self, "_locked_maps", None) is not None:
+            self._release_windows()  # (their chunk tables name the maps' device addresses)
+            self._locked_maps.close()
+        self._locked_maps = None
+
+    def _device_readable_maps(self, chunk_maps: list) -> bool:
+        """Page-lock the vector maps (once per set of maps) if the policy allows: True when the device can pull rows out
+        of them itself.  A refusal (policy, or the driver's) is remembered in ``last_stats['row_source']``."""
+        if self._locked_maps is not None:
+            return True
+        if self._page_lock is False or self._lock_refused is not None:
+            return False
+        total = sum(c.nbytes for c in chunk_maps)
+        if self._page_lock is None:
+            available = _available_host_bytes()
+            if available is None or total > available // 2:
+                self._lock_refused = f"host gather threads (vector maps of {total >> 20} MiB not page-locked: more than half of the available host memory)"
+                return False
+        try:
+            self._locked_maps = native.PinnedMaps(chunk_maps)
+        except (RuntimeError, MemoryError) as e:
+            if self._page_lock:
+                raise
+            self._lock_refused = f"host gather threads (page-locking the vector maps failed: {e})"
+            return False
+        return True
+
     def __del__(self):
         try:
             self._release_windows()
+            self._unlock_maps()
         except Exception:  # interpreter shutdown
             pass
 
@@ -141,6 +191,8 @@ class OnDiskIndex(Index):
     def _open_maps(self) -> None:
         """(Re)create one memory map triple per chunk block (the reference's per-chunk np.memmap)."""
         m = self._meta
+        self._unlock_maps()  # before the old maps go away
+        self._lock_refused = None
         self._maps = []
         if not m["chunks"]:
             return
@@ -297,7 +349,7 @@ class OnDiskIndex(Index):
     @classmethod
     def load(cls, index_file: Path, query_encoder: Encoder | None = None, mode: Mode = Mode.MAXP, encoder_batch_size: int = 32,
              memory_mapped: bool = False, max_indexing_size: int = 2**10, device: int = 0, exact_sum: bool = True,
-             window_bytes: int = 1 << 30, shard: "tuple[int, int] | None" = None) -> "OnDiskIndex":
+             window_bytes: int = 1 << 30, shard: "tuple[int, int] | None" = None, page_lock: bool | None = None) -> "OnDiskIndex":
         """Open an existing index file (disk.py:355-418): ids are read back into the host tables,
         the stored quantizer (if any) is reconstructed.
 
@@ -309,7 +361,7 @@ class OnDiskIndex(Index):
         native.lib()
         index = cls.__new__(cls)
         index._index_file = index_file.absolute()
-        index._init_state(device, exact_sum, window_bytes)
+        index._init_state(device, exact_sum, window_bytes, page_lock)
         if shard is not None and not (0 <= int(shard[0]) < int(shard[1]) <= 254):
             raise ValueError("shard must be (rank, world) with 0 <= rank < world <= 254")
         if h5read.is_hdf5(index_file):  # an index written by the reference (h5py): opened read-only
@@ -500,6 +552,9 @@ class OnDiskIndex(Index):
         chunk_maps = [m[0] for m in self._maps]
         native_gather = (not host_decode and np.dtype(self._meta["dtype"]) == store_dtype
                          and all(isinstance(c, np.ndarray) and c.flags["C_CONTIGUOUS"] for c in chunk_maps))
+        device_pull = native_gather and self._device_readable_maps(chunk_maps)
+        stats["row_source"] = ("device pull out of the page-locked file maps" if device_pull else self._lock_refused or
+                               ("host gather threads" if native_gather else "host reads (NumPy)"))
         free, ready = queue.Queue(), queue.Queue()
         for i in range(len(bufs)):
             free.put(i)
@@ -507,6 +562,7 @@ class OnDiskIndex(Index):
         stop = threading.Event()
 
         def uploader() -> None:
+            last_pull = None
             try:
                 for w in range(n_win):
                     i = free.get()
@@ -514,7 +570,13 @@ class OnDiskIndex(Index):
                         return
                     want = uniq[w * per_window:(w + 1) * per_window]
                     t_up = time.perf_counter()
-                    if native_gather:  # threads of libffx: chunk maps -> page-locked staging -> HBM, overlapped; the last
+                    if device_pull:  # the device reads the rows out of the page-locked maps itself, over PCIe; one window
+                        # after the other (sharing the link they would both arrive late, and the link would idle while both are scored)
+                        if last_pull is not None and last_pull != i:
+                            bufs[i].upload_after(bufs[last_pull])
+                        bufs[i].pull_rows(chunk_maps, self._file_rows(want), 0)
+                        last_pull = i
+                    elif native_gather:  # threads of libffx: chunk maps -> page-locked staging -> HBM, overlapped; the last
                         # copies are still in flight when this returns (the scorer waits for them), so the next window's
                         # gather starts right away
                         bufs[i].upload_rows(chunk_maps, self._file_rows(want), 0, _READ_THREADS, wait=False)

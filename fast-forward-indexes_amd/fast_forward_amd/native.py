@@ -24,7 +24,7 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
     "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
-    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_upload_rows_async", "ffx_index_upload_wait", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
+    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_after", "ffx_index_upload_wait", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
     "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device",
     "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_recent_gather_ms", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
@@ -134,6 +134,8 @@ def lib() -> C.CDLL:
         "ffx_index_upload": ([vp, vp, i64, i64], C.c_int),
         "ffx_index_upload_rows": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_upload_rows_async": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
+        "ffx_index_pull_rows_async": ([vp, vp, i64, i64, vp, i64, i64], C.c_int),
+        "ffx_index_upload_after": ([vp, vp], C.c_int),
         "ffx_index_upload_wait": ([vp], C.c_int),
         "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
         "ffx_index_gather": ([vp, vp, i64, vp], C.c_int),
@@ -364,6 +366,24 @@ class DeviceIndex:
         rows = _arr(rows, np.int64)
         fn = lib().ffx_index_upload_rows if wait else lib().ffx_index_upload_rows_async
         _check(fn(self._h, ptrs, len(chunks), chunk_rows, _ptr(rows), rows.shape[0], int(dst_row), int(threads)))
+
+    def upload_after(self, before: "DeviceIndex") -> None:
+        """Asynchronous uploads of this index queued from now on run after those ``before`` has queued so far."""
+        _check(lib().ffx_index_upload_after(self._h, before._h))
+
+    def pull_rows(self, chunks, rows, dst_row: int = 0) -> None:
+        """The rows of :meth:`upload_rows` pulled by the device itself out of PAGE-LOCKED chunk maps
+        (:func:`pin_maps`): ``ffx_index_pull_rows_async``; ``upload_wait`` before the rows are used."""
+        chunk_rows = int(chunks[0].shape[0]) if len(chunks) else 1
+        key = tuple(c.ctypes.data for c in chunks)
+        cached = getattr(self, "_pull_ptrs", None)
+        if cached is None or cached[0] != key:
+            for c in chunks:
+                if c.dtype != self.dtype or c.ndim != 2 or c.shape != (chunk_rows, self.dim) or not c.flags["C_CONTIGUOUS"]:
+                    raise ValueError("chunks must be contiguous (chunk_rows, dim) arrays of the index dtype")
+            cached = self._pull_ptrs = (key, (C.c_void_p * max(1, len(chunks)))(*key))
+        rows = _arr(rows, np.int64)
+        _check(lib().ffx_index_pull_rows_async(self._h, cached[1], len(chunks), chunk_rows, _ptr(rows), rows.shape[0], int(dst_row)))
 
     def device_ptr(self) -> int:
         """Device address of row 0 (rows contiguous, in the index dtype)."""
@@ -613,6 +633,42 @@ class pinned:
             lib().ffx_host_unpin(_ptr(a))
         self._done = []
         return False
+
+
+class PinnedMaps:
+    """Arrays page-locked for as long as this object lives (``ffx_host_pin`` on the pages each one spans).  Memory maps
+    of a file qualify: the file's pages then stay in host memory and the device can read them
+    (:meth:`DeviceIndex.pull_rows`)."""
+
+    def __init__(self, arrays):
+        self._done: list[tuple[int, int]] = []
+        page = 4096
+        spans = []
+        for a in arrays:
+            if not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("only contiguous arrays can be page-locked")
+            if a.nbytes:
+                spans.append((a.ctypes.data // page * page, -(-(a.ctypes.data + a.nbytes) // page) * page))
+        merged: list[list[int]] = []  # views of one map may share pages: every page is locked once
+        for lo, hi in sorted(spans):
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        try:
+            for lo, hi in merged:
+                _check(lib().ffx_host_pin(C.c_void_p(lo), hi - lo))
+                self._done.append((lo, hi - lo))
+        except BaseException:
+            self.close()
+            raise
+
+    def close(self) -> None:
+        for lo, _ in reversed(getattr(self, "_done", [])):
+            lib().ffx_host_unpin(C.c_void_p(lo))
+        self._done = []
+
+    __del__ = _close_quietly
 
 
 def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0,

@@ -128,7 +128,15 @@ int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_c
  * tail of the copies; ffx_index_upload_wait before the rows are used (it also finishes the code check of PQ rows) */
 int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
                                 const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads);
+/* the same rows pulled by the DEVICE itself: every chunk map is page-locked host memory (ffx_host_pin each map once; a
+ * memory-mapped file may be page-locked), a kernel on the index's copy stream reads the rows over PCIe.  No staging
+ * block and no host thread touches the rows.  Asynchronous; ffx_index_upload_wait before the rows are used. */
+int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
+                              const int64_t* rows, int64_t n_rows, int64_t dst_row);
 int ffx_index_upload_wait(ffx_index* idx);
+/* whatever is queued on idx's copy stream from now on runs after what `before`'s copy stream holds so far (the windows
+ * of a streamed index arrive one after the other instead of sharing the link) */
+int ffx_index_upload_after(ffx_index* idx, ffx_index* before);
 /* device copy between two indexes on the same device (growing an index) */
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows);
 /* read rows back: InMemoryIndex._get_vectors, memory.py:139-140 / index/util.py:97-98 */

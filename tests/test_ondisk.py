@@ -173,6 +173,39 @@ def test_to_memory_and_quantized_streaming(tmp_path):
     assert loaded(first) == ref and loaded.to_memory()(first) == ref
 
 
+@pytest.mark.gpu
+def test_device_pull_and_host_gather_stream_the_same_rows(tmp_path):
+    """A streamed window is filled either by the device reading the page-locked file maps itself
+    (ffx_index_pull_rows_async) or by host threads through a staging block (ffx_index_upload_rows_async): same frames,
+    for fp32 rows, fp16 rows, PQ codes (8-byte rows, several rows per wave) and chunk blocks that start on odd
+    addresses (a stored quantizer shifts them)."""
+    for name, quantizer, chunk, window in (("d768", None, 96, 50_000), ("d768_f16", None, 64, 50_000), ("d768", "pq", 50, 400), ("config1", None, 333, 50_000)):
+        case = load_scoring_case(name)
+        qvecs = case.queries
+        enc = LambdaEncoder(lambda t: qvecs[int(t)])
+        pq = None
+        if quantizer:
+            pq = NanoPQ(8, 16)
+            pq.fit(case.vectors, iter=2)
+        path = tmp_path / f"{name}_{quantizer}.ffx"
+        made = OnDiskIndex(path, enc, quantizer=pq, mode=Mode.MAXP, chunk_size=chunk, window_bytes=window, page_lock=True)
+        made.add(case.vectors, doc_ids=case.doc_names, psg_ids=case.psg_names)
+        pair_off, _, sparse, names = case.pairs("MAXP")
+        pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
+        first = Ranking(pd.DataFrame({"q_id": [case.q_names[q] for q in pair_q], "id": names, "score": sparse}),
+                        queries={q: str(i) for i, q in enumerate(case.q_names)})
+        pulled = made.rerank(first, 0.2)
+        assert made.last_stats["row_source"].startswith("device pull") and made.last_stats["windows"] > 3
+        made.add(case.vectors[:7], doc_ids=[f"extra{i}" for i in range(7)])  # the maps change: locked again on the next call
+        assert made.rerank(first, 0.2) == pulled and made.last_stats["row_source"].startswith("device pull")
+        threads = OnDiskIndex.load(path, enc, window_bytes=window, page_lock=False)
+        assert threads.rerank(first, 0.2) == pulled and threads.last_stats["row_source"] == "host gather threads"
+        auto = OnDiskIndex.load(path, enc, window_bytes=window)
+        assert auto.rerank(first, 0.2) == pulled and auto.last_stats["row_source"].startswith("device pull")
+        assert auto.to_memory().rerank(first, 0.2) == pulled
+        del made, threads, auto
+
+
 # ---- HDF5 files of the reference ---------------------------------------------------------------------------
 import json  # noqa: E402
 from pathlib import Path  # noqa: E402

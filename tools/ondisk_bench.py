@@ -2,7 +2,9 @@
 """Streaming throughput of OnDiskIndex (BASELINE config 5 scaled to one box):
 an index file larger than the staging windows is scored through two HBM windows while an uploader
 thread reads the next window from the memory-mapped file.  Reports GB/s of rows streamed, queries/s,
-and the same run on the HBM-resident copy (to_memory) for comparison and equality."""
+and the same run on the HBM-resident copy (to_memory) for comparison and equality.  `upload_s` is the time the
+uploader thread spent handing windows over: with host gather threads the gather + staging copies themselves, with the
+device pulling the rows only the submission -- `windows_gb_per_s` (bytes over the whole windowed section) compares both."""
 import argparse
 import json
 import sys
@@ -75,27 +77,41 @@ with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
                 continue
         return None
 
-    for label in ("cold", "warm", "warm2", "warm3", "warm4", "warm5"):
-        held = throttled_ms()
-        t0 = time.perf_counter()
-        ff, interp, order = idx._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
-        dt = time.perf_counter() - t0
-        held = None if held is None else throttled_ms() - held
-        st = idx.last_stats
-        out[f"stream_{label}"] = {"seconds": dt, "queries_per_s": args.queries / dt, "windows": st["windows"],
-                                  "unique_rows": st["unique_rows"], "streamed_gb": st["bytes_streamed"] / 1e9,
-                                  "streamed_gb_per_s": st["bytes_streamed"] / 1e9 / dt, "kernel_ms_total": st["ms_gather_dot"],
-                                  "upload_s": st["s_upload"], "upload_gb_per_s": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9),
-                                  "score_s": st["s_score"], "windows_s": st["s_windows"], "expand_s": st["s_expand"], "unique_rows_s": st["s_unique_rows"],
-                                  "aggregate_s": st["s_aggregate"],
-                                  "upload_over_ceiling": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9) / out["h2d_ceiling"]["pinned_GBs"],
-                                  "call_over_ceiling": st["bytes_streamed"] / 1e9 / dt / out["h2d_ceiling"]["pinned_GBs"]}
-        out[f"stream_{label}"]["cpu_quota_throttled_ms"] = held
-    # the second and third calls of a process still pay a one-off wait of 10 - 35 ms in their first upload (gone from the
-    # fourth on): the steady state is the median of the later calls
-    late = sorted((out[f"stream_{label}"] for label in ("warm3", "warm4", "warm5")), key=lambda x: x["seconds"])[1]
-    out["stream_steady"] = {k: late[k] for k in ("seconds", "queries_per_s", "streamed_gb_per_s", "upload_gb_per_s", "upload_over_ceiling", "call_over_ceiling",
-                                                 "expand_s", "unique_rows_s", "windows_s", "aggregate_s")}
+    def measure(index, tag):
+        """Six calls; the second and third of a process still pay a one-off wait of 10 - 35 ms in their first upload (gone
+        from the fourth on): the steady state is the median of the later calls."""
+        res = None
+        for label in ("cold", "warm", "warm2", "warm3", "warm4", "warm5"):
+            held = throttled_ms()
+            t0 = time.perf_counter()
+            res = index._score_pairs(qv, pair_off, pair_ids, Mode.MAXP, sparse, 0.1, sort=True)
+            dt = time.perf_counter() - t0
+            held = None if held is None else throttled_ms() - held
+            st = index.last_stats
+            out[f"{tag}_{label}"] = {"seconds": dt, "queries_per_s": args.queries / dt, "windows": st["windows"], "row_source": st["row_source"],
+                                     "unique_rows": st["unique_rows"], "streamed_gb": st["bytes_streamed"] / 1e9,
+                                     "streamed_gb_per_s": st["bytes_streamed"] / 1e9 / dt, "kernel_ms_total": st["ms_gather_dot"],
+                                     "upload_s": st["s_upload"], "upload_gb_per_s": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9),
+                                     "windows_gb_per_s": st["bytes_streamed"] / 1e9 / st["s_windows"],
+                                     "score_s": st["s_score"], "windows_s": st["s_windows"], "expand_s": st["s_expand"], "unique_rows_s": st["s_unique_rows"],
+                                     "aggregate_s": st["s_aggregate"],
+                                     "upload_over_ceiling": st["bytes_streamed"] / 1e9 / max(st["s_upload"], 1e-9) / out["h2d_ceiling"]["pinned_GBs"],
+                                     "windows_over_ceiling": st["bytes_streamed"] / 1e9 / st["s_windows"] / out["h2d_ceiling"]["pinned_GBs"],
+                                     "call_over_ceiling": st["bytes_streamed"] / 1e9 / dt / out["h2d_ceiling"]["pinned_GBs"],
+                                     "cpu_quota_throttled_ms": held}
+        late = sorted((out[f"{tag}_{label}"] for label in ("warm3", "warm4", "warm5")), key=lambda x: x["seconds"])[1]
+        out[f"{tag}_steady"] = {k: late[k] for k in ("row_source", "seconds", "queries_per_s", "streamed_gb_per_s", "windows_gb_per_s", "windows_over_ceiling",
+                                                     "call_over_ceiling", "expand_s", "unique_rows_s", "windows_s", "aggregate_s")}
+        return res
+
+    # the device pulls the rows out of the page-locked file maps itself / host threads gather them through staging blocks
+    t0 = time.perf_counter()
+    ff, interp, order = measure(idx, "stream")
+    threads_idx = OnDiskIndex.load(Path(tmp) / "index.ffx", mode=Mode.MAXP, window_bytes=args.window_mb << 20, page_lock=False)
+    ff_t, interp_t, order_t = measure(threads_idx, "stream_host_threads")
+    out["row_sources_agree"] = bool(np.array_equal(ff.view(np.uint32), ff_t.view(np.uint32)) and np.array_equal(interp.view(np.uint32), interp_t.view(np.uint32))
+                                    and np.array_equal(order, order_t))
+    del threads_idx
     t0 = time.perf_counter()
     mem = idx.to_memory(batch_size=2**18)
     out["to_memory_s"] = time.perf_counter() - t0
