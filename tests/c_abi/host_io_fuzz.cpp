@@ -4,6 +4,7 @@
 // of hand-written adversarial files, and a few thousand seeded mutations of both (truncations, NUL
 // bytes, huge fields, missing columns, non-numeric scores) go through every entry point.  Any
 // out-of-bounds access, use-after-free, overflow or misaligned access aborts the process.
+#include <algorithm>
 #include <cinttypes>
 #include <cstdarg>
 #include <cstdio>
@@ -376,6 +377,85 @@ int main(int argc, char** argv) {
       if (inv[(size_t)i] < 0 || inv[(size_t)i] >= count || uniq[(size_t)inv[(size_t)i]] != rows[(size_t)i]) return 1;
     rows[0] = n_index;  // outside the index: refused
     if (ffx_host_unique_rows(rows.data(), n, n_index, 2, uniq.data(), &count, inv.data()) == FFX_OK) return 1;
+  }
+  // ---- every threaded native once at a size where several threads really run (the pools take a thread per 64 Ki
+  // elements): the answer with 4 threads equals the answer with 1.  Under -fsanitize=thread this is the data-race check.
+  {
+    const int64_t n = 400000, nq = 900;
+    std::vector<int64_t> off((size_t)nq + 1, 0);
+    for (int64_t q = 1; q <= nq; ++q) off[(size_t)q] = q == nq ? n : std::min<int64_t>(n, off[(size_t)q - 1] + (int64_t)(rnd() % 900));
+    std::vector<float> sc((size_t)n), dense((size_t)n);
+    std::vector<int32_t> perm((size_t)n);
+    for (int64_t i = 0; i < n; ++i) sc[(size_t)i] = (float)(rnd() % 4096) * 0.125f, dense[(size_t)i] = (float)(rnd() % 977), perm[(size_t)i] = (int32_t)i;
+    for (int64_t i = n - 1; i > 0; --i) std::swap(perm[(size_t)i], perm[(size_t)(rnd() % (uint64_t)(i + 1))]);
+    std::vector<int32_t> o1((size_t)n), o4((size_t)n);
+    if (ffx_host_order(sc.data(), off.data(), nq, 1, o1.data()) != FFX_OK || ffx_host_order(sc.data(), off.data(), nq, 4, o4.data()) != FFX_OK || o1 != o4) return 1;
+    std::vector<int64_t> dst((size_t)nq);
+    for (int64_t q = 0; q < nq; ++q) dst[(size_t)q] = n - off[(size_t)q + 1];  // the queries in reverse
+    if (ffx_host_order_blocks(sc.data(), off.data(), dst.data(), nq, 1, o1.data()) != FFX_OK || ffx_host_order_blocks(sc.data(), off.data(), dst.data(), nq, 4, o4.data()) != FFX_OK || o1 != o4) return 1;
+    std::vector<float> t1((size_t)n), t4((size_t)n);
+    if (ffx_host_take32(sc.data(), n, perm.data(), n, 1, t1.data()) != FFX_OK || ffx_host_take32(sc.data(), n, perm.data(), n, 4, t4.data()) != FFX_OK || t1 != t4) return 1;
+    int32_t nan = 0;
+    if (ffx_host_interpolate(sc.data(), dense.data(), perm.data(), n, 0.25f, 0.75f, 1, t1.data(), &nan) != FFX_OK || ffx_host_interpolate(sc.data(), dense.data(), perm.data(), n, 0.25f, 0.75f, 4, t4.data(), &nan) != FFX_OK || t1 != t4) return 1;
+    // distinct rows
+    const int64_t n_index = 250000;
+    std::vector<int64_t> rows((size_t)n), u1((size_t)n_index), u4((size_t)n_index);
+    for (auto& r : rows) r = (int64_t)(rnd() % (uint64_t)n_index);
+    int64_t c1 = 0, c4 = 0;
+    if (ffx_host_unique_rows(rows.data(), n, n_index, 1, u1.data(), &c1, o1.data()) != FFX_OK || ffx_host_unique_rows(rows.data(), n, n_index, 4, u4.data(), &c4, o4.data()) != FFX_OK) return 1;
+    if (c1 != c4 || o1 != o4 || !std::equal(u1.begin(), u1.begin() + c1, u4.begin())) return 1;
+    // 8-byte values (pointers of an object column) numbered in ascending order
+    std::vector<uint64_t> vals((size_t)n);
+    for (auto& v : vals) v = 0x7f0000000000ull + 48 * (uint64_t)(rnd() % 50000);
+    std::vector<int64_t> f1((size_t)n), f4((size_t)n);
+    if (ffx_host_code_u64(vals.data(), n, 1, o1.data(), f1.data(), &c1) != FFX_OK || ffx_host_code_u64(vals.data(), n, 4, o4.data(), f4.data(), &c4) != FFX_OK || c1 != c4 || o1 != o4) return 1;
+    for (int64_t c = 0; c < c1; ++c)
+      if (vals[(size_t)f4[(size_t)c]] != vals[(size_t)f1[(size_t)c]] || (c > 0 && vals[(size_t)f4[(size_t)c]] <= vals[(size_t)f4[(size_t)c - 1]])) return 1;
+    // strings: joined by a separator and back to back with offsets; the numbering depends on the set of strings only
+    std::string blob, packed;
+    std::vector<int64_t> soff{0};
+    const int64_t ns = 300000;
+    for (int64_t i = 0; i < ns; ++i) {
+      const std::string w = "doc" + std::to_string(rnd() % 70000);
+      if (i) blob.push_back('\n');
+      blob += w;
+      packed += w;
+      soff.push_back((int64_t)packed.size());
+    }
+    std::vector<int32_t> s1((size_t)ns), s4((size_t)ns), s5((size_t)ns);
+    char *b1 = nullptr, *b4 = nullptr, *b5 = nullptr;
+    int64_t nb1 = 0, nb4 = 0, nb5 = 0, nn1 = 0, nn4 = 0, nn5 = 0;
+    if (ffx_strings_code(blob.data(), (int64_t)blob.size(), '\n', ns, 1, s1.data(), &b1, &nb1, &nn1) != FFX_OK) return 1;
+    if (ffx_strings_code(blob.data(), (int64_t)blob.size(), '\n', ns, 4, s4.data(), &b4, &nb4, &nn4) != FFX_OK) return 1;
+    if (ffx_strings_code_offsets(packed.data(), soff.data(), ns, '\n', 4, s5.data(), &b5, &nb5, &nn5) != FFX_OK) return 1;
+    if (nn1 != nn4 || nn1 != nn5 || nb1 != nb4 || nb1 != nb5 || s1 != s4 || s1 != s5 || memcmp(b1, b4, (size_t)nb1) != 0 || memcmp(b1, b5, (size_t)nb1) != 0) return 1;
+    ffx_buffer_free(b1);
+    ffx_buffer_free(b4);
+    ffx_buffer_free(b5);
+    // owners of fixed-width id columns
+    const int width = 12;
+    std::vector<char> ids_col((size_t)ns * width, 0);
+    for (int64_t i = 0; i < ns; ++i) snprintf(&ids_col[(size_t)i * width], width, "D%d", (int)(rnd() % 90000));
+    std::vector<uint8_t> w1((size_t)ns), w4((size_t)ns);
+    if (ffx_host_owner_crc32(ids_col.data(), width, nullptr, 0, ns, 8, 1, w1.data()) != FFX_OK || ffx_host_owner_crc32(ids_col.data(), width, nullptr, 0, ns, 8, 4, w4.data()) != FFX_OK || w1 != w4) return 1;
+    // the outer join over many queries
+    std::vector<int64_t> oa{0}, ob{0};
+    std::vector<int32_t> ca, cb;
+    for (int64_t g = 0; g < 2000; ++g) {
+      for (int side = 0; side < 2; ++side) {
+        std::vector<int32_t>& d = side ? cb : ca;
+        for (int32_t c = 0; c < 300; ++c)
+          if (rnd() % 3) d.push_back(c * 7 + (int32_t)g % 5);
+        (side ? ob : oa).push_back((int64_t)d.size());
+      }
+    }
+    const size_t room = ca.size() + cb.size() + 1;
+    std::vector<int64_t> uo1(2001), uo4(2001);
+    std::vector<int32_t> uc1(room), ua1(room), ub1(room), uc4(room), ua4(room), ub4(room);
+    if (ffx_host_outer_join(oa.data(), ca.data(), ob.data(), cb.data(), 2000, 1, uo1.data(), uc1.data(), ua1.data(), ub1.data()) != FFX_OK) return 1;
+    if (ffx_host_outer_join(oa.data(), ca.data(), ob.data(), cb.data(), 2000, 4, uo4.data(), uc4.data(), ua4.data(), ub4.data()) != FFX_OK) return 1;
+    const size_t nu = (size_t)uo1[2000];
+    if (uo1 != uo4 || !std::equal(uc1.begin(), uc1.begin() + nu, uc4.begin()) || !std::equal(ua1.begin(), ua1.begin() + nu, ua4.begin()) || !std::equal(ub1.begin(), ub1.begin() + nu, ub4.begin())) return 1;
   }
   ffx_ids_destroy(ids);
   remove(in.c_str());

@@ -236,6 +236,25 @@ def test_host_natives_under_address_and_undefined_behaviour_sanitizers(tmp_path)
     assert "host_io sanitizer run ok" in run.stdout
 
 
+def test_host_natives_under_thread_sanitizer(tmp_path):
+    """The same driver built with g++ -fsanitize=thread: every threaded native of csrc/host_io.cpp (order, gathers,
+    interpolate, distinct rows, pointer and string numbering, crc32 owners, outer join) runs with four threads at sizes where
+    the pools really start several, and must give the single-thread answer.  A data race aborts the driver."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ here")
+    csrc = Path(__file__).resolve().parent.parent / "fast-forward-indexes_amd" / "csrc"
+    build = subprocess.run(["make", "-C", str(csrc), "host_tsan"], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stdout[-2000:] + build.stderr[-4000:]
+    run = subprocess.run([str(csrc / "build" / "host_io_tsan"), str(tmp_path), "200"], capture_output=True, text=True, timeout=900,
+                         env={"TSAN_OPTIONS": "halt_on_error=1:exitcode=66", "PATH": "/usr/bin:/bin"})
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-6000:]
+    assert "host_io sanitizer run ok" in run.stdout
+
+
 def test_host_order_equals_the_oracle_order():
     """ffx_host_order (threads over queries, 64-bit words of inverted score image and position): scores
     descending, exact ties by position, -0.0 == +0.0, infinities -- the order the device's FFX_FLAG_SORT gives."""
