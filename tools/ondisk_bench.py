@@ -64,7 +64,17 @@ with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
     out["build_s"] = time.perf_counter() - t0
     out["file_gb"] = (Path(tmp) / "index.ffx").stat().st_size / 1e9
     qv = rng.standard_normal((args.queries, args.dim), dtype=np.float32) * np.float32(0.036)
-    pair_ids = np.concatenate([rng.choice(args.rows, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
+    if args.k * args.k > args.rows // 8:  # small index: a permutation per query is affordable
+        pair_ids = np.concatenate([rng.choice(args.rows, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
+    else:  # k distinct rows per query: drawn with replacement, the few queries that drew a row twice drawn again
+        picks = rng.integers(0, args.rows, size=(args.queries, args.k), dtype=np.int64)
+        while True:
+            ordered = np.sort(picks, axis=1)
+            again = np.flatnonzero((ordered[:, 1:] == ordered[:, :-1]).any(axis=1))
+            if again.size == 0:
+                break
+            picks[again] = rng.integers(0, args.rows, size=(again.size, args.k), dtype=np.int64)
+        pair_ids = picks.reshape(-1).astype(np.int32)
     pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
     sparse = rng.random(pair_ids.shape[0], dtype=np.float32) * 25
     def throttled_ms():  # time this container's threads spent held back by its CPU quota so far (cgroup v2 / v1)
