@@ -73,6 +73,33 @@ def _available_host_bytes() -> int | None:
     return available
 
 
+def _resident_fraction(maps: list, samples: int = 1024) -> float:
+    """Share of the maps' pages that are in memory already (mincore on evenly spaced sample pages): page-locking a
+    file that is NOT cached reads all of it from its disk first."""
+    import ctypes
+
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        mincore = libc.mincore
+    except (OSError, AttributeError):
+        return 0.0
+    mincore.argtypes, mincore.restype = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p], ctypes.c_int
+    page, total = 4096, sum(c.nbytes for c in maps)
+    if total == 0:
+        return 1.0
+    seen = hit = 0
+    flag = ctypes.create_string_buffer(1)
+    for c in maps:
+        n_here = max(1, samples * c.nbytes // total)
+        lo, n_pages = c.ctypes.data // page * page, max(1, c.nbytes // page)
+        for k in range(n_here):
+            if mincore(lo + (k * n_pages // n_here) * page, page, flag) != 0:
+                return 0.0
+            seen += 1
+            hit += flag.raw[0] & 1
+    return hit / max(1, seen)
+
+
 _READ_THREADS = int(os.environ.get("FFX_READ_THREADS", "0")) or max(1, min(24, native.usable_cores() * 3 // 4))
 
 
@@ -94,7 +121,8 @@ class OnDiskIndex(Index):
         :param window_bytes: HBM staging budget per window while scoring (two windows are resident).
         :param page_lock: page-lock the file's vector maps at the first streamed call, so that the device reads the rows
             it needs straight out of the mapped file (no host threads, no staging copy).  The file's pages then stay in
-            host memory.  None (default): when the vectors fit in half of the memory that is available.
+            host memory.  None (default): when the vectors fit in half of the memory that is available and at least
+            90 % of the file is in memory already (page cache or tmpfs).
         :raises ValueError: when the file exists and ``overwrite`` is false.
         """
         index_file = Path(index_file)
@@ -149,6 +177,10 @@ class OnDiskIndex(Index):
             available = _available_host_bytes()
             if available is None or total > available // 2:
                 self._lock_refused = f"host gather threads (vector maps of {total >> 20} MiB not page-locked: more than half of the available host memory)"
+                return False
+            cached = _resident_fraction(chunk_maps)
+            if cached < 0.9:  # page-locking would read the rest of the file from its disk first
+                self._lock_refused = f"host gather threads (vector maps not page-locked: {cached:.0%} of the file is in memory)"
                 return False
         try:
             self._locked_maps = native.PinnedMaps(chunk_maps)

@@ -173,6 +173,22 @@ def test_to_memory_and_quantized_streaming(tmp_path):
     assert loaded(first) == ref and loaded.to_memory()(first) == ref
 
 
+def test_page_lock_policy_inputs(tmp_path):
+    """What the default page-lock policy looks at: how much of the mapped file is in memory (mincore on sample pages) and
+    how much host memory is available (MemAvailable under the container's limit)."""
+    from fast_forward_amd.index import ondisk
+
+    written = np.memmap(tmp_path / "all", mode="w+", dtype=np.float32, shape=(20000, 256))
+    written[:] = 1.0
+    assert ondisk._resident_fraction([written]) == 1.0
+    sparse = np.memmap(tmp_path / "holes", mode="w+", dtype=np.float32, shape=(200000, 256))  # a file of holes: nothing cached
+    assert ondisk._resident_fraction([sparse]) == 0.0
+    sparse[:60000] = 1.0
+    assert 0.2 < ondisk._resident_fraction([sparse]) < 0.6 and 0.2 < ondisk._resident_fraction([sparse, written]) < 0.7
+    available = ondisk._available_host_bytes()
+    assert available is None or available > 0
+
+
 @pytest.mark.gpu
 def test_device_pull_and_host_gather_stream_the_same_rows(tmp_path):
     """A streamed window is filled either by the device reading the page-locked file maps itself
