@@ -116,6 +116,7 @@ if rank == 0:
     out["streamed_rerank_s"] = t_streamed
     out["streamed_queries_per_s"] = args.queries / t_streamed
     out["rank0_streamed_gb"] = stats.get("bytes_streamed", 0) / 1e9
+    out["rank0_row_source"] = stats.get("row_source")
     out["streamed_equals_resident_on_every_rank"] = bool(agree)
     single = OnDiskIndex.load(args.file, enc).to_memory()
     want = single.rerank(first, 0.1)
