@@ -421,16 +421,64 @@ merge_kernel(const float* __restrict__ recv, const int32_t* __restrict__ slot, c
 
 // Rows of an on-disk index pulled by the device itself: `chunks` are DEVICE addresses of page-locked chunk maps in host
 // memory (ffx_host_pin + hipHostGetDevicePointer), so every load below is a read over PCIe and no host thread touches
-// the rows.  Row rows[r] (chunk rows[r] / chunk_rows, row rows[r] % chunk_rows of it) lands in row r of `dst`.  A group
-// of G lanes (a power of two, 64 for rows of 64 units and more) moves one row, four loads of V in flight per lane
-// before the stores: 59 - 61 GB/s for 3072-byte rows from 64 - 1024 workgroups (tools/probes/host_pull_probe.hip;
-// a page-locked hipMemcpy of one contiguous block: 57 GB/s on the same box).
+// the rows.  Row rows[r] (chunk rows[r] / chunk_rows, row rows[r] % chunk_rows of it) lands in row r of `dst`.  A wave
+// (G = 64, rows of 64 units and more) or a group of G lanes (a power of two) moves one row, up to four loads of V in flight
+// per lane and row before the stores: 59 - 61 GB/s for 3072-byte rows from 16 - 1024 workgroups (tools/probes/host_pull_probe.hip;
+// a page-locked hipMemcpy of one contiguous block: 57 GB/s on the same box).  Launched with 64 workgroups: more move no
+// more bytes and their outstanding reads hold up every other kernel's loads (ffx_index_pull_rows_async).
 template <typename V>
 __global__ void __launch_bounds__(256)
 pull_rows_kernel(const char* const* __restrict__ chunks, int64_t chunk_rows, const int64_t* __restrict__ rows, int64_t n_rows,
                  int row_units, int G, char* __restrict__ dst) {
-  const int lane = threadIdx.x & 63, gl = lane & (G - 1), per_wave = 64 / G;
+  const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * 256) >> 6;
+  if (G == 64) {
+    // A wave takes 64 consecutive rows at a time: every lane looks up ONE row's address (row number, chunk table, the
+    // 64-bit division -- once per 64 rows, off the per-row path), then the rows are moved two at a time with the
+    // addresses handed round by lane shuffles, so nothing but the reads over the link stands between two rows.
+    for (int64_t base = wave * 64; base < n_rows; base += n_waves * 64) {
+      const int cnt = (int)(n_rows - base < 64 ? n_rows - base : 64);
+      unsigned long long mine = 0;
+      if (lane < cnt) {
+        const int64_t row = rows[base + lane];
+        mine = (unsigned long long)(reinterpret_cast<uintptr_t>(chunks[row / chunk_rows]) + (size_t)(row % chunk_rows) * row_units * sizeof(V));
+      }
+      const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+      for (int i = 0; i < cnt; i += 2) {
+        const bool two = i + 1 < cnt;
+        const V* s0 = reinterpret_cast<const V*>(((unsigned long long)(unsigned)__shfl((int)hi, i) << 32) | (unsigned)__shfl((int)lo, i));
+        const V* s1 = reinterpret_cast<const V*>(((unsigned long long)(unsigned)__shfl((int)hi, two ? i + 1 : i) << 32) | (unsigned)__shfl((int)lo, two ? i + 1 : i));
+        V* d0 = reinterpret_cast<V*>(dst) + (size_t)(base + i) * row_units;
+        V* d1 = d0 + row_units;
+        for (int u0 = 0; u0 < row_units; u0 += 4 * 64) {
+          V a[4], b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int u = u0 + j * 64 + lane;
+            if (u < row_units) a[j] = s0[u];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int u = u0 + j * 64 + lane;
+            if (two && u < row_units) b[j] = s1[u];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int u = u0 + j * 64 + lane;
+            if (u < row_units) d0[u] = a[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int u = u0 + j * 64 + lane;
+            if (two && u < row_units) d1[u] = b[j];
+          }
+        }
+      }
+    }
+    return;
+  }
+  // short rows (fewer than 64 units): a group of G lanes per row, several rows per wave
+  const int gl = lane & (G - 1), per_wave = 64 / G;
   for (int64_t r = wave * per_wave + lane / G; r < n_rows; r += n_waves * per_wave) {
     const int64_t row = rows[r];
     const V* s = reinterpret_cast<const V*>(chunks[row / chunk_rows]) + (size_t)(row % chunk_rows) * row_units;

@@ -69,7 +69,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 //   anyd_u=N               loads in flight per wave of the any-d kernel (2, 4, 8)
 //   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
 //   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N   where the per-query sort switches form
-//   score_slice_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out
+//   score_slice_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N
 //                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py)
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
 // (FFX_SCORE_TRACE=1 -- a timeline on stderr -- and the operational settings FFX_COMM_TIMEOUT_S, FFX_RDZV_DIR,
@@ -310,7 +310,7 @@ namespace {
 // caller's buffer is free again on return either way)
 int plan_h2d(ffx_plan* pl, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return FFX_OK;
-  if (char* st = bytes <= (256u << 10) ? pl->stage(bytes) : nullptr) {
+  if (char* st = bytes <= (1u << 20) ? pl->stage(bytes) : nullptr) {
     memcpy(st, src, bytes);
     src = st;
   }
@@ -688,7 +688,13 @@ int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t
   int G = 64;
   while (G > 1 && G / 2 >= units) G >>= 1;
   const int64_t waves = (n_rows + 64 / G - 1) / (64 / G);
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(256, (waves + 3) / 4));
+  // 64 workgroups keep the link full (windows of a streamed index: 54 GB/s; 32: 51, 16: 35) and hardly slow the scoring
+  // kernels running beside them (0.75 vs 0.55 ms); 256 move no more bytes and slow those kernels 10 - 15 x -- their
+  // outstanding reads fill the queues every kernel's loads go through (tools/probes/host_pull_probe.hip: an HBM-bound
+  // kernel beside a pull of 16 / 64 / 256 workgroups runs 1.6 / 5.5 / 8 x longer)
+  int64_t grid_cap = 64;
+  if (long long v = 0; ffx_debug_variant("pull_grid", &v)) grid_cap = std::max<long long>(1, v);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid_cap, (waves + 3) / 4));
   const char* const* table = idx->pull_chunks.as<const char*>();
   char* dst = static_cast<char*>(idx->row_ptr(dst_row));
   if (align == 16)

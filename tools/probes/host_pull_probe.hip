@@ -77,9 +77,50 @@ int main(int argc, char** argv) {
     void* anon;
     CK(hipHostMalloc(&anon, bytes, hipHostMallocDefault));
     for (size_t r = 0; r < n_file_rows; ++r) memset((char*)anon + r * row_bytes, (int)(r & 0xff), row_bytes);
-    for (int grid : {64, 256, 1024, 4096}) {
+    for (int grid : {4, 8, 16, 32, 64, 256, 1024, 4096}) {
       const double s = time_pull(anon, d_rows, n, d_dst, grid);
       printf("{\"source\": \"hipHostMalloc\", \"grid\": %d, \"pull_GBs\": %.2f}\n", grid, s > 0 ? gb / s : -1.0);
+    }
+    // what a pull of each size does to an HBM-bound kernel running beside it on another stream (the same row copy, HBM
+    // to HBM, 20 launches back to back), and what that kernel does to the pull
+    {
+      uint4 *v_src, *v_dst;
+      CK(hipMalloc(&v_src, (size_t)n * row_bytes));
+      CK(hipMalloc(&v_dst, (size_t)n * row_bytes));
+      CK(hipMemset(v_src, 1, (size_t)n * row_bytes));
+      std::vector<int64_t> ident(n);
+      for (int i = 0; i < n; ++i) ident[i] = (int64_t)(rng() % n);
+      int64_t* d_ident;
+      CK(hipMalloc(&d_ident, n * sizeof(int64_t)));
+      CK(hipMemcpy(d_ident, ident.data(), n * sizeof(int64_t), hipMemcpyHostToDevice));
+      hipStream_t s_pull, s_victim;
+      CK(hipStreamCreateWithFlags(&s_pull, hipStreamNonBlocking));
+      CK(hipStreamCreateWithFlags(&s_victim, hipStreamNonBlocking));
+      hipEvent_t e0, e1, p0, p1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&p0)); CK(hipEventCreate(&p1));
+      auto victim = [&](float* ms) {
+        CK(hipEventRecord(e0, s_victim));
+        for (int i = 0; i < 20; ++i) pull_rows<<<2048, 256, 0, s_victim>>>(v_src, d_ident, n, v_dst);
+        CK(hipEventRecord(e1, s_victim));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(ms, e0, e1));
+        return 0;
+      };
+      float alone = 0;
+      if (victim(&alone)) return 1;
+      if (victim(&alone)) return 1;
+      printf("{\"victim_alone_ms_per_launch\": %.4f}\n", alone / 20);
+      for (int grid : {4, 8, 16, 32, 64, 256, 1024}) {
+        float beside = 0, pull_ms = 0;
+        CK(hipEventRecord(p0, s_pull));
+        for (int i = 0; i < 3; ++i) pull_rows<<<grid, 256, 0, s_pull>>>((const uint4*)anon, d_rows, n, d_dst);
+        CK(hipEventRecord(p1, s_pull));
+        if (victim(&beside)) return 1;
+        CK(hipEventSynchronize(p1));
+        CK(hipEventElapsedTime(&pull_ms, p0, p1));
+        printf("{\"pull_grid\": %d, \"pull_GBs_beside_victim\": %.2f, \"victim_ms_per_launch_beside_pull\": %.4f}\n", grid, gb * 3 / (pull_ms * 1e-3), beside / 20);
+      }
+      CK(hipDeviceSynchronize());
     }
     std::vector<unsigned char> back(row_bytes);
     CK(hipMemcpy(back.data(), (char*)d_dst + (size_t)(n - 1) * row_bytes, row_bytes, hipMemcpyDeviceToHost));
