@@ -1934,12 +1934,14 @@ int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_
   if (out_order && !pl->ran_sort) return fail(FFX_BAD_ARG, "the last run did not request FFX_FLAG_SORT");
   if (P > 0) {
     pl->hstage_used = 0;
-    const size_t each = P * sizeof(float);
-    char* back = 3 * (each + 64) <= (size_t)(1 << 20) ? pl->stage(3 * (each + 64)) : nullptr;
-    if (back) {  // small result: three copies into page-locked memory, one wait, then hand the bytes over
+    const size_t each = P * sizeof(float), slot = (each + 63) & ~size_t(63);
+    const size_t wanted = (out_ff ? 1 : 0) + (out_interp ? 1 : 0) + (out_order ? 1 : 0);
+    char* back = wanted * slot <= ffx_plan::kStageBytes / 2 ? pl->stage(3 * slot <= ffx_plan::kStageBytes ? 3 * slot : wanted * slot) : nullptr;
+    if (back) {  // small result: up to three copies into page-locked memory, one wait, then hand the bytes over
+      const bool all_slots = 3 * slot <= ffx_plan::kStageBytes;
       char* b_ff = back;
-      char* b_in = back + ((each + 63) & ~size_t(63));
-      char* b_or = b_in + ((each + 63) & ~size_t(63));
+      char* b_in = all_slots ? back + slot : back + (out_ff ? slot : 0);
+      char* b_or = all_slots ? back + 2 * slot : b_in + (out_interp ? slot : 0);
       if (out_ff) FFX_HIP(hipMemcpyAsync(b_ff, pl->ff.p, each, hipMemcpyDeviceToHost, pl->stream));
       if (out_interp) FFX_HIP(hipMemcpyAsync(b_in, pl->interp.p, each, hipMemcpyDeviceToHost, pl->stream));
       if (out_order) FFX_HIP(hipMemcpyAsync(b_or, pl->order.p, each, hipMemcpyDeviceToHost, pl->stream));
