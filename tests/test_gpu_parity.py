@@ -1160,3 +1160,41 @@ def test_sharded_c_example_runs_against_the_oracle(tmp_path, args, ranks):
     run = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300, env=dict(os.environ, FFX_COMM_TIMEOUT_S="60"))
     assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-3000:]
     assert f"rerank_sharded.c ok: {ranks} rank(s)" in run.stdout and "702 owned pairs checked" in run.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,dim,shift", [(np.float32, 768, 0), (np.float32, 1100, 0), (np.float32, 100, 0), (np.float32, 8, 0), (np.float32, 4, 0),
+                                             (np.float32, 3, 0), (np.float32, 768, 4), (np.float16, 768, 0), (np.float16, 5, 0), (np.float16, 64, 2),
+                                             (np.uint8, 8, 0), (np.uint8, 5, 0), (np.uint8, 96, 1), (np.uint8, 700, 3)])
+def test_device_pull_of_rows_out_of_page_locked_chunks(dtype, dim, shift):
+    """ffx_index_pull_rows_async: the device copies scattered rows out of page-locked host chunks itself.  Every unit
+    width the kernel chooses (16-byte, 4-byte, single bytes: by row length and by where the chunks start), rows shorter
+    than a wave (several rows per wave) and longer than one pass, chunk counts that do not divide the row list, a
+    destination offset, an empty list, a row outside the chunks, and chunks that are NOT page-locked (refused)."""
+    rng = np.random.default_rng(dim * 7 + shift)
+    item = np.dtype(dtype).itemsize
+    chunk_rows, n_chunks = 37, 5
+    chunk_bytes = chunk_rows * dim * item
+    stride = -(-(chunk_bytes + shift) // 64) * 64
+    block = native.pinned_empty(n_chunks * stride + 64, np.uint8)
+    block[:] = rng.integers(0, 256, size=block.shape[0], dtype=np.uint8)
+    chunks = [block[c * stride + shift:c * stride + shift + chunk_bytes].view(dtype).reshape(chunk_rows, dim) for c in range(n_chunks)]
+    n_src = chunk_rows * n_chunks
+    dev = native.DeviceIndex(400, dim, dtype=dtype)
+    try:
+        for n, at in ((0, 0), (1, 0), (63, 3), (64, 0), (65, 11), (300, 100)):
+            rows = rng.integers(0, n_src, size=n)
+            dev.pull_rows(chunks, rows, at)
+            dev.upload_wait()
+            got = dev.gather(np.arange(at, at + n, dtype=np.int32))
+            want = np.stack([chunks[r // chunk_rows][r % chunk_rows] for r in rows]) if n else np.zeros((0, dim), dtype=dtype)
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (n, at)
+        with pytest.raises(native.FFXError, match="outside"):
+            dev.pull_rows(chunks, np.array([n_src]), 0)
+        with pytest.raises(native.FFXError, match="capacity"):
+            dev.pull_rows(chunks, np.zeros(10, dtype=np.int64), 395)
+        ordinary = [np.array(c) for c in chunks]
+        with pytest.raises(native.FFXError, match="page-locked"):
+            dev.pull_rows(ordinary, np.array([0]), 0)
+    finally:
+        dev.close()
