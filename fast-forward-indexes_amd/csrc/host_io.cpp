@@ -1042,6 +1042,84 @@ int ffx_host_unique_rows(const int64_t* rows, int64_t n, int64_t n_index_rows, i
   return FFX_OK;
 }
 
+// get_indices (index/util.py:29-41) for candidates that contribute ONE row each, and numpy.unique of those rows, in one go:
+//   row(i) = table2 ? table2[table1[ids[i]]] : table1[ids[i]]
+// (PASSAGE: table1 = the passages' rows; FIRSTP / one-row documents: table1 = the documents' first entry, table2 = the
+// entries' rows), then what ffx_host_unique_rows returns for them.  A streamed index does this once per call before its
+// first window can start: two thread pools instead of five, no intermediate arrays.
+int ffx_host_rows_unique(const int32_t* ids, int64_t n, const int32_t* table1, int64_t n1, const int32_t* table2, int64_t n2,
+                         int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse) {
+  if (n_uniq) *n_uniq = 0;
+  if (n < 0 || n1 < 0 || n2 < 0 || n_index_rows < 0 || !n_uniq || (n > 0 && (!ids || !table1 || !uniq || !inverse))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return FFX_OK;
+  if (n_index_rows > (int64_t)INT32_MAX) return ffx_fail(FFX_BAD_ARG, "too many index rows for int32 positions");
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  const int64_t n_words = (n_index_rows + 63) / 64;
+  try {
+    std::vector<std::atomic<uint64_t>> bits((size_t)std::max<int64_t>(n_words, 1));
+    for (auto& w : bits) w.store(0, std::memory_order_relaxed);
+    std::vector<int64_t> before((size_t)n_words + 1);
+    std::unique_ptr<int32_t[]> row_of(new int32_t[(size_t)n]);
+    std::atomic<int64_t> bad(-1);
+    run_threads(T, [&](int t) {
+      // block by block: first the look-ups alone (independent loads, many in flight), then the bitmap -- an atomic
+      // read-modify-write between two look-ups would make every one of them wait for the one before
+      const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+      for (int64_t b0 = lo; b0 < hi; b0 += 4096) {
+        const int64_t b1 = std::min(hi, b0 + 4096);
+        for (int64_t i = b0; i < b1; ++i) {  // one table per loop: one cache miss per iteration, none waiting for another
+          const int64_t r = ids[i];
+          row_of[(size_t)i] = (uint64_t)r < (uint64_t)n1 ? table1[r] : -1;
+        }
+        if (table2)
+          for (int64_t i = b0; i < b1; ++i) {
+            const int64_t r = row_of[(size_t)i];
+            row_of[(size_t)i] = (uint64_t)r < (uint64_t)n2 ? table2[r] : -1;
+          }
+        for (int64_t i = b0; i < b1; ++i)
+          if ((uint64_t)(int64_t)row_of[(size_t)i] >= (uint64_t)n_index_rows) {
+            int64_t none = -1;
+            bad.compare_exchange_strong(none, i);
+            row_of[(size_t)i] = -1;
+          }
+        for (int64_t i = b0; i < b1; ++i) {
+          const int32_t r = row_of[(size_t)i];
+          if (r >= 0) bits[(size_t)(r >> 6)].fetch_or(1ull << (r & 63), std::memory_order_relaxed);
+        }
+      }
+    });
+    if (bad.load() >= 0) return ffx_fail(FFX_BAD_ARG, "ids[%lld] = %d names no row of the index", (long long)bad.load(), ids[bad.load()]);
+    int64_t total = 0;
+    for (int64_t w = 0; w < n_words; ++w) {
+      before[(size_t)w] = total;
+      total += __builtin_popcountll(bits[(size_t)w].load(std::memory_order_relaxed));
+    }
+    before[(size_t)n_words] = total;
+    *n_uniq = total;
+    run_threads(T, [&](int t) {
+      for (int64_t w = n_words * t / T; w < n_words * (t + 1) / T; ++w) {
+        uint64_t m = bits[(size_t)w].load(std::memory_order_relaxed);
+        int64_t at = before[(size_t)w];
+        while (m) {
+          uniq[at++] = (w << 6) + __builtin_ctzll(m);
+          m &= m - 1;
+        }
+      }
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+        const int64_t r = row_of[(size_t)i];
+        const uint64_t m = bits[(size_t)(r >> 6)].load(std::memory_order_relaxed);
+        inverse[i] = (int32_t)(before[(size_t)(r >> 6)] + __builtin_popcountll(m & ((1ull << (r & 63)) - 1ull)));
+      }
+    });
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  return FFX_OK;
+}
+
 // The outer join of Ranking.interpolate / __add__ (ranking.py:293-326: merge on (q_id, id), how="outer") for two
 // rankings whose rows stand grouped by query, on integer keys: query g owns rows off_a[g] .. off_a[g+1] of A and rows
 // off_b[g] .. off_b[g+1] of B; code_a / code_b number the ids in one common table; a (query, id) pair occurs at most

@@ -499,9 +499,11 @@ class OnDiskIndex(Index):
         return index
 
     # ---- scoring: stream the needed rows through two HBM windows --------------------------------------------
-    def _expand(self, pair_off: np.ndarray, pair_ids: np.ndarray, mode: int):
+    def _expand(self, pair_off: np.ndarray, pair_ids: np.ndarray, mode: int, distinct: bool = False):
         """Pairs -> gathered rows on the host (get_indices, index/util.py:29-41): (row numbers [R], segment offsets
-        [P+1]); the offsets are None when every candidate contributes exactly one row (rows and pairs coincide)."""
+        [P+1]); the offsets are None when every candidate contributes exactly one row (rows and pairs coincide).
+        ``distinct=True``: where one native pass can do both, the first item is the pair (distinct rows ascending, slot
+        of every gathered row among them) instead of the row numbers."""
         n_pairs = int(pair_off[-1])
         # the id tables as int64 arrays, made once per state of the index (a copy of a table of millions of rows per
         # call cost more than the candidates' own look-ups)
@@ -516,11 +518,16 @@ class OnDiskIndex(Index):
             self._expand_tables = cache
         _, doc_off, doc_rows, psg_rows, one_row_each, tables32 = cache
         ids32 = np.ascontiguousarray(pair_ids, dtype=np.int32)
+        fused = distinct and tables32 is not None and n_pairs >= (1 << 16)
         if mode == PASSAGE:
+            if fused:
+                return native.rows_unique(ids32, tables32[2], None, len(self)), None
             if tables32 is not None:  # (the gathers by host threads: a million random reads of a table of millions)
                 return native.take32(tables32[2], ids32), None
             return psg_rows[pair_ids], None
         if (mode == FIRSTP or one_row_each) and tables32 is not None:
+            if fused:
+                return native.rows_unique(ids32, tables32[0], tables32[1], len(self)), None
             return native.take32(tables32[1], native.take32(tables32[0], ids32)), None
         start = doc_off[pair_ids]
         if mode == FIRSTP or one_row_each:
@@ -545,23 +552,26 @@ class OnDiskIndex(Index):
         n_q = q.shape[0]
         pair_off = np.asarray(pair_off, dtype=np.int64)
         t_call = time.perf_counter()
-        rows, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value)
+        rows, seg_off = self._expand(pair_off, np.asarray(pair_ids), mode.value, distinct=True)
         row_off = pair_off if seg_off is None else seg_off[pair_off]  # first gathered row of every query
         t_expanded = time.perf_counter()
         # each needed row is read once: the distinct rows, ascending, and every gathered row's slot among them
-        if rows.shape[0] >= (1 << 16):
+        if isinstance(rows, tuple):  # (one native pass did the expansion and this)
+            uniq, slot_row = rows
+        elif rows.shape[0] >= (1 << 16):
             uniq, slot_row = native.unique_rows(rows, len(self))
         else:
             uniq, slot_row = np.unique(rows, return_inverse=True)
+        n_rows_gathered = int(slot_row.shape[0])
         store_dtype = np.dtype(self._meta["dtype"])
         if host_decode or store_dtype not in (np.dtype(np.float16), np.dtype(np.uint8)):
             store_dtype = np.dtype(np.float32)  # float64 files of the reference are scored in fp32 (DESIGN.md divergence 1)
         store_dim = dim_q if host_decode else self._meta["dim"]
         per_window = max(1, self._window_bytes // max(1, store_dim * store_dtype.itemsize))
         n_win = -(-uniq.shape[0] // per_window)
-        rs = np.empty(rows.shape[0], dtype=np.float32)
+        rs = np.empty(n_rows_gathered, dtype=np.float32)
         t_begin = time.perf_counter()
-        stats = {"s_upload": 0.0, "s_score": 0.0, "windows": n_win, "unique_rows": int(uniq.shape[0]), "gathered_rows": int(rows.shape[0]), "ms_gather_dot": 0.0,
+        stats = {"s_upload": 0.0, "s_score": 0.0, "windows": n_win, "unique_rows": int(uniq.shape[0]), "gathered_rows": n_rows_gathered, "ms_gather_dot": 0.0,
                  "bytes_streamed": int(uniq.shape[0]) * store_dim * store_dtype.itemsize}
 
         # the two HBM windows (and their plans, page-locked staging included) live on between calls

@@ -34,7 +34,7 @@ SYMBOLS = (
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_host_code_u64", "ffx_host_owner_crc32", "ffx_buffer_free",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows", "ffx_host_rows_unique",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route",
@@ -205,6 +205,7 @@ def lib() -> C.CDLL:
         "ffx_host_interpolate": ([vp, vp, vp, i64, C.c_float, C.c_float, i32, vp, P(i32)], C.c_int),
         "ffx_host_outer_join": ([vp, vp, vp, vp, i64, i32, vp, vp, vp, vp], C.c_int),
         "ffx_host_unique_rows": ([vp, i64, i64, i32, vp, P(i64), vp], C.c_int),
+        "ffx_host_rows_unique": ([vp, i64, vp, i64, vp, i64, i64, i32, vp, P(i64), vp], C.c_int),
         "ffx_comm_unique_id": ([C.c_int, vp], C.c_int),
         "ffx_comm_init": ([C.c_int, C.c_int, C.c_int, C.c_int, vp, P(vp)], C.c_int),
         "ffx_comm_destroy": ([vp], C.c_int),
@@ -880,6 +881,20 @@ def unique_rows(rows: np.ndarray, n_index_rows: int, threads: int = 0) -> tuple[
     inverse = np.empty(n, dtype=np.int32)
     count = C.c_int64(0)
     _check(lib().ffx_host_unique_rows(_ptr(rows), n, int(n_index_rows), int(threads), _ptr(uniq), C.byref(count), _ptr(inverse)))
+    return uniq[:count.value], inverse
+
+
+def rows_unique(ids, table1: np.ndarray, table2: np.ndarray | None, n_index_rows: int, threads: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    """``unique_rows(table2[table1[ids]])`` (``table1[ids]`` without ``table2``) in one native pass
+    (``ffx_host_rows_unique``): (distinct rows ascending, int32 slot of every id's row among them)."""
+    ids = _arr(ids, np.int32)
+    assert table1.dtype == np.int32 and table1.flags["C_CONTIGUOUS"] and (table2 is None or (table2.dtype == np.int32 and table2.flags["C_CONTIGUOUS"]))
+    n = ids.shape[0]
+    uniq = np.empty(max(1, min(n, int(n_index_rows))), dtype=np.int64)
+    inverse = np.empty(n, dtype=np.int32)
+    count = C.c_int64(0)
+    _check(lib().ffx_host_rows_unique(_ptr(ids), n, _ptr(table1), table1.shape[0], _ptr(table2), 0 if table2 is None else table2.shape[0],
+                                      int(n_index_rows), int(threads), _ptr(uniq), C.byref(count), _ptr(inverse)))
     return uniq[:count.value], inverse
 
 

@@ -461,6 +461,13 @@ int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32
  * and every gathered row's position among them.  uniq must hold min(n, n_index_rows) entries. */
 int ffx_host_unique_rows(const int64_t* rows, int64_t n, int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse);
 
+/* get_indices (index/util.py:29-41) for candidates that contribute one row each, fused with the above:
+ * row(i) = table2 ? table2[table1[ids[i]]] : table1[ids[i]] (PASSAGE: table1 = rows of the passages; FIRSTP / one-row
+ * documents: table1 = first entry of each document, table2 = rows of the entries), then the distinct rows ascending and
+ * every candidate's slot among them.  An id or entry outside its table, or a row outside the index, is refused. */
+int ffx_host_rows_unique(const int32_t* ids, int64_t n, const int32_t* table1, int64_t n1, const int32_t* table2, int64_t n2,
+                         int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse);
+
 /* The outer join of Ranking.interpolate / + (ranking.py:293-326) on integer keys, for two rankings whose rows stand
  * grouped by query: rows off_a[g] .. off_a[g+1] of A and off_b[g] .. off_b[g+1] of B belong to query g, code_a / code_b
  * number the ids in one common table, a pair occurs at most once per side (FFX_BAD_ARG otherwise).  Per query the union

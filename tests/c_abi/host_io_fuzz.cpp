@@ -404,6 +404,33 @@ int main(int argc, char** argv) {
     int64_t c1 = 0, c4 = 0;
     if (ffx_host_unique_rows(rows.data(), n, n_index, 1, u1.data(), &c1, o1.data()) != FFX_OK || ffx_host_unique_rows(rows.data(), n, n_index, 4, u4.data(), &c4, o4.data()) != FFX_OK) return 1;
     if (c1 != c4 || o1 != o4 || !std::equal(u1.begin(), u1.begin() + c1, u4.begin())) return 1;
+    // ids -> rows -> distinct rows in one pass: equals the two steps done apart, whatever the thread count
+    {
+      const int64_t n1 = 180000, n2 = 200000;
+      std::vector<int32_t> t1((size_t)n1), t2((size_t)n2), ids((size_t)n), two((size_t)n);
+      for (auto& v : t1) v = (int32_t)(rnd() % (uint64_t)n2);
+      for (auto& v : t2) v = (int32_t)(rnd() % (uint64_t)n_index);
+      for (auto& v : ids) v = (int32_t)(rnd() % (uint64_t)n1);
+      std::vector<int64_t> apart((size_t)n), ua((size_t)n_index), ub((size_t)n_index);
+      for (int64_t i = 0; i < n; ++i) apart[(size_t)i] = t2[(size_t)t1[(size_t)ids[(size_t)i]]];
+      int64_t ca = 0, cb = 0;
+      if (ffx_host_unique_rows(apart.data(), n, n_index, 1, ua.data(), &ca, o1.data()) != FFX_OK) return 1;
+      for (int threads : {1, 4}) {
+        if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, t2.data(), n2, n_index, threads, ub.data(), &cb, two.data()) != FFX_OK) return 1;
+        if (ca != cb || o1 != two || !std::equal(ua.begin(), ua.begin() + ca, ub.begin())) return 1;
+      }
+      for (int64_t i = 0; i < n; ++i) apart[(size_t)i] = t1[(size_t)ids[(size_t)i]];  // one table only
+      if (ffx_host_unique_rows(apart.data(), n, n2, 1, ua.data(), &ca, o1.data()) != FFX_OK) return 1;
+      if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, nullptr, 0, n2, 4, ub.data(), &cb, two.data()) != FFX_OK || ca != cb || o1 != two) return 1;
+      ids[7] = (int32_t)n1;  // an id outside the table, an entry outside the second table, a row outside the index: refused
+      if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, t2.data(), n2, n_index, 4, ub.data(), &cb, two.data()) == FFX_OK) return 1;
+      ids[7] = 0;
+      const int32_t keep = t1[0];
+      t1[0] = (int32_t)n2;
+      if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, t2.data(), n2, n_index, 4, ub.data(), &cb, two.data()) == FFX_OK) return 1;
+      t1[0] = keep;
+      if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, t2.data(), n2, n_index / 2, 4, ub.data(), &cb, two.data()) == FFX_OK) return 1;
+    }
     // 8-byte values (pointers of an object column) numbered in ascending order
     std::vector<uint64_t> vals((size_t)n);
     for (auto& v : vals) v = 0x7f0000000000ull + 48 * (uint64_t)(rnd() % 50000);

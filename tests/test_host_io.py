@@ -215,6 +215,23 @@ def test_run_parser_drops_rows_with_missing_scores_and_refuses_non_decimal_ones(
             native.RunFile(p, table)
 
 
+def test_rows_unique_equals_numpy():
+    """ffx_host_rows_unique: table look-ups + numpy.unique(return_inverse=True) in one native pass."""
+    rng = np.random.default_rng(3)
+    t1 = rng.integers(0, 5000, size=4000).astype(np.int32)
+    t2 = rng.integers(0, 9000, size=5000).astype(np.int32)
+    for n in (0, 1, 300, 200_000):
+        ids = rng.integers(0, 4000, size=n).astype(np.int32)
+        for tables, rows, n_index in (((t1, t2), t2[t1[ids]], 9000), ((t1, None), t1[ids], 5000)):
+            uniq, inverse = native.rows_unique(ids, tables[0], tables[1], n_index, threads=3)
+            want_u, want_i = np.unique(rows, return_inverse=True)
+            assert np.array_equal(uniq, want_u) and np.array_equal(inverse, want_i)
+    with pytest.raises(native.FFXError, match="names no row"):
+        native.rows_unique(np.array([4000], dtype=np.int32), t1, t2, 9000)
+    with pytest.raises(native.FFXError, match="names no row"):
+        native.rows_unique(np.array([0], dtype=np.int32), t1, t2, int(t2[t1[0]]))
+
+
 def test_host_natives_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     """csrc/host_io.cpp -- the code that parses untrusted run files -- built alone with
     g++ -fsanitize=address,undefined and driven by tests/c_abi/host_io_fuzz.cpp: a well-formed run,
