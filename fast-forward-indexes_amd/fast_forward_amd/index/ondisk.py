@@ -664,6 +664,12 @@ class OnDiskIndex(Index):
             stop.set()
             free.put(None)  # unblock the uploader if the scoring thread failed first
             t.join()
+            if device_pull:  # after a failure a pull may still be reading the maps: nothing outlives the call
+                for b in bufs:
+                    try:
+                        b.upload_wait()
+                    except native.FFXError:
+                        pass
         stats["s_windows"] = time.perf_counter() - t_begin
         stats["s_expand"], stats["s_unique_rows"] = t_expanded - t_call, t_begin - t_expanded
         t_agg = time.perf_counter()
