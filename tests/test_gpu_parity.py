@@ -1198,3 +1198,16 @@ def test_device_pull_of_rows_out_of_page_locked_chunks(dtype, dim, shift):
             dev.pull_rows(ordinary, np.array([0]), 0)
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+def test_randomised_configurations_against_the_oracle():
+    """tests/fuzz_score.py (the soak tool: ragged batches, every mode, 27 row lengths, both stores, random slicing of
+    ffx_score, sort on and off, every result compared with the oracle bit for bit), 80 configurations of one fixed seed."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    run = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "fuzz_score.py"), "--rounds", "80", "--seed", "11"],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "fuzz ok: 80 configurations" in run.stdout, run.stdout[-2000:] + run.stderr[-3000:]
