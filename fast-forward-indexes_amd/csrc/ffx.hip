@@ -699,6 +699,8 @@ int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t
   char* dst = static_cast<char*>(idx->row_ptr(dst_row));
   if (align == 16)
     ffx::pull_rows_kernel<uint4><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, units, G, dst);
+  else if (align == 8)  // (where an HDF5 file's allocator usually puts a chunk)
+    ffx::pull_rows_kernel<uint2><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, (int)(rb / 8), G = 64, dst);
   else if (align >= 4)
     ffx::pull_rows_kernel<uint32_t><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, (int)(rb / 4), G = 64, dst);
   else

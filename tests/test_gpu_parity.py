@@ -1164,11 +1164,11 @@ def test_sharded_c_example_runs_against_the_oracle(tmp_path, args, ranks):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,dim,shift", [(np.float32, 768, 0), (np.float32, 1100, 0), (np.float32, 100, 0), (np.float32, 8, 0), (np.float32, 4, 0),
-                                             (np.float32, 3, 0), (np.float32, 768, 4), (np.float16, 768, 0), (np.float16, 5, 0), (np.float16, 64, 2),
+                                             (np.float32, 3, 0), (np.float32, 768, 4), (np.float32, 768, 8), (np.float32, 1100, 8), (np.float16, 768, 0), (np.float16, 5, 0), (np.float16, 64, 2),
                                              (np.uint8, 8, 0), (np.uint8, 5, 0), (np.uint8, 96, 1), (np.uint8, 700, 3)])
 def test_device_pull_of_rows_out_of_page_locked_chunks(dtype, dim, shift):
     """ffx_index_pull_rows_async: the device copies scattered rows out of page-locked host chunks itself.  Every unit
-    width the kernel chooses (16-byte, 4-byte, single bytes: by row length and by where the chunks start), rows shorter
+    width the kernel chooses (16-, 8-, 4-byte, single bytes: by row length and by where the chunks start), rows shorter
     than a wave (several rows per wave) and longer than one pass, chunk counts that do not divide the row list, a
     destination offset, an empty list, a row outside the chunks, and chunks that are NOT page-locked (refused)."""
     rng = np.random.default_rng(dim * 7 + shift)
