@@ -25,7 +25,7 @@ for shift in (0, 8, 4, 2, 1):
     chunks = [block[c * stride + shift:c * stride + shift + chunk_bytes].view(np.float32).reshape(chunk_rows, dim) if shift % 4 == 0 else None for c in range(n_chunks)]
     if chunks[0] is None:  # float32 views need 4-byte alignment in NumPy: use a float16 / uint8 index for the odd starts
         continue
-    rows = np.sort(rng.integers(0, chunk_rows * n_chunks, size=n))
+    rows = np.sort(rng.permutation(chunk_rows * n_chunks)[:n])  # distinct rows: a row fetched twice is served by the L2
     for _ in range(2):
         dev.pull_rows(chunks, rows, 0)
         dev.upload_wait()
@@ -44,7 +44,7 @@ for shift in (1, 2):
     block = native.pinned_empty(n_chunks * stride + 64, np.uint8)
     block[:] = 1
     chunks = [block[c * stride + shift:c * stride + shift + chunk_rows * 3072].reshape(chunk_rows, 3072) for c in range(n_chunks)]
-    rows = np.sort(rng.integers(0, chunk_rows * n_chunks, size=n))
+    rows = np.sort(rng.permutation(chunk_rows * n_chunks)[:n])
     dev.pull_rows(chunks, rows, 0)
     dev.upload_wait()
     t0 = time.perf_counter()
