@@ -423,7 +423,7 @@ merge_kernel(const float* __restrict__ recv, const int32_t* __restrict__ slot, c
 // memory (ffx_host_pin + hipHostGetDevicePointer), so every load below is a read over PCIe and no host thread touches
 // the rows.  Row rows[r] (chunk rows[r] / chunk_rows, row rows[r] % chunk_rows of it) lands in row r of `dst`.  A wave
 // (G = 64, rows of 64 units and more) or a group of G lanes (a power of two) moves one row, up to four loads of V in flight
-// per lane and row before the stores: 59 - 61 GB/s for 3072-byte rows from 16 - 1024 workgroups (tools/probes/host_pull_probe.hip;
+// per lane and row before the stores: ~55 GB/s of distinct 3072-byte rows (tools/pull_bench.py, tools/probes/host_pull_probe.hip;
 // a page-locked hipMemcpy of one contiguous block: 57 GB/s on the same box).  Launched with 64 workgroups: more move no
 // more bytes and their outstanding reads hold up every other kernel's loads (ffx_index_pull_rows_async).
 template <typename V>
