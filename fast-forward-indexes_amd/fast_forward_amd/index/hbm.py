@@ -203,9 +203,10 @@ class InMemoryIndex(Index):
     def _resolve_ids(self, ids: np.ndarray, mode: Mode) -> np.ndarray:
         return self._ids.resolve(ids, mode.value)
 
-    def _result_buffers(self, n: int):
+    def _result_buffers(self, n: int, wanted=(True, True, True)):
         """Page-locked (ff, interp, order) arrays of at least ``n`` elements, kept with the index: results land in
         them at link rate and without a page fault per 4 KB (a fresh 140 MB array costs ~10 ms just to touch).
+        Only the ``wanted`` ones are made (page-locking 157 MB takes ~40 ms); the others come back as None.
         Only for callers that consume the results before the next call (the coded paths of ``__call__`` /
         ``rerank`` gather out of them at once)."""
         # a ranking handed out by the previous call may still look into the block (Index.__call__ leaves the device's
@@ -216,11 +217,13 @@ class InMemoryIndex(Index):
             holder._source_rows = (holder._source_rows[0], holder._source_rows[1].copy())
         self._order_borrower = None
         have = getattr(self, "_out_cache", None)
-        if have is None or have[0].size < n:
-            cap = n + n // 8
-            have = (native.pinned_empty(cap, np.float32), native.pinned_empty(cap, np.float32), native.pinned_empty(cap, np.int32))
-            self._out_cache = have
-        return have
+        if have is None:
+            have = self._out_cache = [None, None, None]
+        for i, dtype in enumerate((np.float32, np.float32, np.int32)):
+            if wanted[i] and (have[i] is None or have[i].size < n):
+                have[i] = None  # (the old block goes first)
+                have[i] = native.pinned_empty(n + n // 8, dtype)
+        return tuple(a if w else None for a, w in zip(have, wanted))
 
     def _score_pairs(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse=None, alpha=None, sort=False, want_dense=True,
                      reuse_outputs=False):
@@ -235,7 +238,8 @@ class InMemoryIndex(Index):
             q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
         self._sync_ids()
         n_pairs = int(pair_off[-1])
-        out = self._result_buffers(n_pairs) if (reuse_outputs and n_pairs >= (1 << 20)) else None
+        out = (self._result_buffers(n_pairs, (want_dense or sparse is None, sparse is not None, bool(sort)))
+               if (reuse_outputs and n_pairs >= (1 << 20)) else None)
         if n_pairs >= self._PIPELINED_FROM:
             # large batches go through ffx_score: whole-query slices rotate through three plans, so the upload of
             # one slice, the kernels of the one before and the download of the one before that overlap
