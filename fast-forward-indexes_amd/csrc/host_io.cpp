@@ -519,42 +519,82 @@ int ffx_ids_lookup_packed(const ffx_ids* t, const char* data, int64_t n_bytes, c
   if (first_missing) *first_missing = -1;
   if (!t || n < 0 || n_bytes < 0 || (n > 0 && (!data || !out_ordinals))) return ffx_fail(FFX_BAD_ARG, "bad argument");
   if (n == 0) return n_bytes == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "bytes given for zero strings");
-  std::vector<int64_t> start;
-  try {
-    start.reserve((size_t)n + 1);
-  } catch (const std::bad_alloc&) {
-    return ffx_fail(FFX_OOM, "host allocation failed");
-  }
-  start.push_back(0);
-  for (const char* p = data; (int64_t)start.size() <= n;) {
-    const char* q = static_cast<const char*>(memchr(p, sep, (size_t)(data + n_bytes - p)));
-    if (!q) break;
-    start.push_back(q - data + 1);
-    p = q + 1;
-  }
-  if ((int64_t)start.size() != n) return ffx_fail(FFX_BAD_ARG, "the buffer does not hold exactly %lld separated strings", (long long)n);
-  start.push_back(n_bytes + 1);  // as if a separator followed the last string
+  // Threads take byte ranges of the buffer: the separators of every range are counted first (that numbers the strings),
+  // then every thread looks up the strings that START in its range, eight at a time -- a look-up is three dependent
+  // cache misses (slot, offsets, bytes of the candidate) in a table of millions, and eight of each are in flight at once.
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1, std::min(32, usable_cores())), n >> 15, n_bytes >> 16}));
+  std::vector<int64_t> seps((size_t)T + 1, 0);
+  auto range_lo = [&](int k) { return n_bytes * k / T; };
+  auto count = [&](int k) {
+    int64_t c = 0;
+    const char *p = data + range_lo(k), *end = data + range_lo(k + 1);
+    while (p < end) {
+      const char* q = static_cast<const char*>(memchr(p, sep, (size_t)(end - p)));
+      if (!q) break;
+      ++c;
+      p = q + 1;
+    }
+    seps[(size_t)k + 1] = c;
+  };
   std::atomic<int64_t> miss{INT64_MAX};
-  auto work = [&](int64_t lo, int64_t hi) {
+  auto lookup = [&](int k) {
+    // a string belongs to the range that holds the separator in front of it (string 0 to range 0): range k owns strings
+    // first .. first + owned - 1
+    const int64_t first = seps[(size_t)k] + (k == 0 ? 0 : 1);
+    const int64_t owned = seps[(size_t)k + 1] - seps[(size_t)k] + (k == 0 ? 1 : 0);
+    if (owned <= 0) return;
+    const char* const buf_end = data + n_bytes;
+    const char* p = data + range_lo(k);
+    if (k > 0) p = static_cast<const char*>(memchr(p, sep, (size_t)(buf_end - p))) + 1;  // (there is one: owned > 0)
     int64_t mine = INT64_MAX;
-    for (int64_t i = lo; i < hi; ++i) {
-      const int32_t o = t->find(std::string_view(data + start[(size_t)i], (size_t)(start[(size_t)i + 1] - 1 - start[(size_t)i])));
-      out_ordinals[i] = o;
-      if (o < 0 && mine == INT64_MAX) mine = i;
+    constexpr int B = 8;
+    std::string_view sv[B];
+    size_t h[B];
+    int32_t cand[B];
+    for (int64_t done = 0; done < owned;) {
+      const int nb = (int)std::min<int64_t>(B, owned - done);
+      for (int b2 = 0; b2 < nb; ++b2) {
+        const char* q = static_cast<const char*>(memchr(p, sep, (size_t)(buf_end - p)));
+        const char* e = q ? q : buf_end;
+        sv[b2] = std::string_view(p, (size_t)(e - p));
+        h[b2] = fnv1a(p, (size_t)(e - p)) & t->mask;
+        __builtin_prefetch(&t->slots[h[b2]]);
+        p = e + 1;
+      }
+      for (int b2 = 0; b2 < nb; ++b2) {
+        cand[b2] = t->slots[h[b2]];
+        if (cand[b2] >= 0) __builtin_prefetch(&t->off[(size_t)cand[b2]]);
+      }
+      for (int b2 = 0; b2 < nb; ++b2)
+        if (cand[b2] >= 0) __builtin_prefetch(t->arena.data() + t->off[(size_t)cand[b2]]);
+      for (int b2 = 0; b2 < nb; ++b2) {
+        size_t hh = h[b2];
+        int32_t o = -1;
+        while (true) {
+          const int32_t c = t->slots[hh];
+          if (c < 0) break;
+          if (t->get(c) == sv[b2]) {
+            o = c;
+            break;
+          }
+          hh = (hh + 1) & t->mask;
+        }
+        out_ordinals[first + done + b2] = o;
+        if (o < 0 && mine == INT64_MAX) mine = first + done + b2;
+      }
+      done += nb;
     }
     int64_t seen = miss.load();
     while (mine < seen && !miss.compare_exchange_weak(seen, mine)) {
     }
   };
-  const int T = (int)std::min<int64_t>(std::max(1, std::min(32, usable_cores())), n >> 15);  // >= 32K strings each
-  if (T <= 1) {
-    work(0, n);
-  } else {
-    try {
-      run_threads(T, [&](int k) { work(n * k / T, n * (k + 1) / T); });
-    } catch (const std::system_error&) {
-      return ffx_fail(FFX_OOM, "could not start host threads");
-    }
+  try {
+    run_threads(T, count);
+    for (int k = 0; k < T; ++k) seps[(size_t)k + 1] += seps[(size_t)k];
+    if (seps[(size_t)T] != n - 1) return ffx_fail(FFX_BAD_ARG, "the buffer does not hold exactly %lld separated strings", (long long)n);
+    run_threads(T, lookup);
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
   }
   const int64_t m = miss.load();
   if (m == INT64_MAX) return FFX_OK;

@@ -431,6 +431,44 @@ int main(int argc, char** argv) {
       t1[0] = keep;
       if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, t2.data(), n2, n_index / 2, 4, ub.data(), &cb, two.data()) == FFX_OK) return 1;
     }
+    // look-ups of a packed buffer large enough for several threads (byte ranges, strings numbered by the separators in
+    // front of them): every ordinal right, empty strings and strings nobody interned reported as -1, the first one named
+    {
+      ffx_ids* big = nullptr;
+      if (ffx_ids_create(&big) != FFX_OK) return 1;
+      const int64_t n_ids = 150000, n_q = 400000;
+      std::string all;
+      for (int64_t i = 0; i < n_ids; ++i) {
+        if (i) all.push_back('\n');
+        all += "doc" + std::to_string(i * 7);
+      }
+      std::vector<int32_t> got((size_t)n_ids);
+      if (ffx_ids_intern_packed(big, all.data(), (int64_t)all.size(), '\n', n_ids, got.data()) != FFX_OK) return 1;
+      std::string asked;
+      std::vector<int32_t> want((size_t)n_q), found((size_t)n_q);
+      int64_t first_bad = -1;
+      for (int64_t i = 0; i < n_q; ++i) {
+        if (i) asked.push_back('\n');
+        const uint64_t r = rnd();
+        if (r % 1000 == 0 && i > 5000) {
+          want[(size_t)i] = -1;
+          if (first_bad < 0) first_bad = i;
+          if (r % 2000 == 0) asked += "nobody" + std::to_string(i);  // (else: an empty string)
+        } else {
+          const int64_t o = (int64_t)(r % (uint64_t)n_ids);
+          want[(size_t)i] = (int32_t)o;
+          asked += "doc" + std::to_string(o * 7);
+        }
+      }
+      int64_t miss = -1;
+      const int rc = ffx_ids_lookup_packed(big, asked.data(), (int64_t)asked.size(), '\n', n_q, found.data(), &miss);
+      if (rc != FFX_NOT_FOUND || miss != first_bad || found != want) return 1;
+      if (ffx_ids_lookup_packed(big, asked.data(), (int64_t)asked.size(), '\n', n_q - 1, found.data(), &miss) != FFX_BAD_ARG) return 1;
+      asked.push_back('\n');  // one more (empty) string at the very end
+      found.push_back(0);
+      if (ffx_ids_lookup_packed(big, asked.data(), (int64_t)asked.size(), '\n', n_q + 1, found.data(), &miss) != FFX_NOT_FOUND || found[(size_t)n_q] != -1) return 1;
+      ffx_ids_destroy(big);
+    }
     // 8-byte values (pointers of an object column) numbered in ascending order
     std::vector<uint64_t> vals((size_t)n);
     for (auto& v : vals) v = 0x7f0000000000ull + 48 * (uint64_t)(rnd() % 50000);
