@@ -671,7 +671,6 @@ int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t
   FFX_TRY(idx->pull_list.ensure((size_t)n_rows * sizeof(int64_t)));
   if (idx->pull_list_room < n_rows) {  // (nothing is in flight out of the old block: pending_rows was 0 or has been waited for)
     if (idx->pull_list_host) (void)hipHostFree(idx->pull_list_host);
-  if (idx->order_ev) (void)hipEventDestroy(idx->order_ev);
     idx->pull_list_host = nullptr;
     idx->pull_list_room = 0;
     const int64_t room = std::max<int64_t>(n_rows + n_rows / 4, 1 << 16);

@@ -1201,6 +1201,32 @@ def test_device_pull_of_rows_out_of_page_locked_chunks(dtype, dim, shift):
 
 
 @pytest.mark.gpu
+def test_pulls_of_two_windows_stay_ordered_when_a_row_list_grows():
+    """ffx_index_upload_after between two windows, before and after one of them needs a longer row list than it has
+    page-locked room for (the list's block is replaced; the ordering event must survive that)."""
+    rng = np.random.default_rng(5)
+    chunk_rows, dim = 50_000, 4
+    block = native.pinned_empty((2 * chunk_rows, dim), np.float32)
+    block[:] = rng.standard_normal(block.shape, dtype=np.float32)
+    chunks = [block[:chunk_rows], block[chunk_rows:]]
+    a, b = native.DeviceIndex(90_000, dim), native.DeviceIndex(90_000, dim)
+    try:
+        for n in (100, 80_000, 300, 90_000):
+            rows_a, rows_b = rng.integers(0, 2 * chunk_rows, size=n), rng.integers(0, 2 * chunk_rows, size=n)
+            a.pull_rows(chunks, rows_a, 0)
+            b.upload_after(a)
+            b.pull_rows(chunks, rows_b, 0)
+            a.upload_after(b)
+            a.upload_wait()
+            b.upload_wait()
+            assert np.array_equal(a.gather(np.arange(n, dtype=np.int32)), block[rows_a])
+            assert np.array_equal(b.gather(np.arange(n, dtype=np.int32)), block[rows_b])
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.gpu
 def test_randomised_configurations_against_the_oracle():
     """tests/fuzz_score.py (the soak tool: ragged batches, every mode, 27 row lengths, both stores, random slicing of
     ffx_score, sort on and off, every result compared with the oracle bit for bit), 80 configurations of one fixed seed."""
