@@ -1189,6 +1189,14 @@ def test_device_pull_of_rows_out_of_page_locked_chunks(dtype, dim, shift):
             got = dev.gather(np.arange(at, at + n, dtype=np.int32))
             want = np.stack([chunks[r // chunk_rows][r % chunk_rows] for r in rows]) if n else np.zeros((0, dim), dtype=dtype)
             assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (n, at)
+        # the host rewrites the chunks (an index file that is appended to): the next pull sees the new bytes, whatever
+        # lines of the old ones an earlier kernel left in the caches
+        block[:] = ~block
+        rows = rng.integers(0, n_src, size=200)
+        dev.pull_rows(chunks, rows, 0)
+        dev.upload_wait()
+        want = np.stack([chunks[r // chunk_rows][r % chunk_rows] for r in rows])
+        assert np.array_equal(dev.gather(np.arange(200, dtype=np.int32)).view(np.uint8), want.view(np.uint8))
         with pytest.raises(native.FFXError, match="outside"):
             dev.pull_rows(chunks, np.array([n_src]), 0)
         with pytest.raises(native.FFXError, match="capacity"):
