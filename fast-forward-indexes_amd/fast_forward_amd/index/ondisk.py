@@ -513,7 +513,7 @@ class OnDiskIndex(Index):
             doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
             doc_rows, psg_rows = np.ascontiguousarray(doc_rows, dtype=np.int64), np.ascontiguousarray(self._ids.psg_rows(), dtype=np.int64)
             small = len(self) < 2**31 - 1  # 4-byte copies for the threaded gathers (FirstP, PASSAGE, one row per document)
-            tables32 = (doc_off[:-1].astype(np.int32), doc_rows.astype(np.int32), psg_rows.astype(np.int32)) if small else None
+            tables32 = (doc_off.astype(np.int32), doc_rows.astype(np.int32), psg_rows.astype(np.int32)) if small else None
             cache = (self._ids.version, doc_off, doc_rows, psg_rows, bool(doc_off.shape[0] > 1 and (np.diff(doc_off) == 1).all()), tables32)
             self._expand_tables = cache
         _, doc_off, doc_rows, psg_rows, one_row_each, tables32 = cache
@@ -527,8 +527,11 @@ class OnDiskIndex(Index):
             return psg_rows[pair_ids], None
         if (mode == FIRSTP or one_row_each) and tables32 is not None:
             if fused:
-                return native.rows_unique(ids32, tables32[0], tables32[1], len(self)), None
+                return native.rows_unique(ids32, tables32[0][:-1], tables32[1], len(self)), None
             return native.take32(tables32[1], native.take32(tables32[0], ids32)), None
+        if fused:  # every row of every candidate's document: offsets, rows, distinct rows and slots natively
+            seg_off, uniq, inverse = native.segment_rows_unique(ids32, tables32[0], tables32[1], len(self))
+            return (uniq, inverse), seg_off
         start = doc_off[pair_ids]
         if mode == FIRSTP or one_row_each:
             return doc_rows[start], None

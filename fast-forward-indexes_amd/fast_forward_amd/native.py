@@ -34,7 +34,7 @@ SYMBOLS = (
     "ffx_aggregate",
     "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_host_code_u64", "ffx_host_owner_crc32", "ffx_buffer_free",
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows", "ffx_host_rows_unique",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets", "ffx_host_segment_rows_unique",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
     "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route",
@@ -206,6 +206,8 @@ def lib() -> C.CDLL:
         "ffx_host_outer_join": ([vp, vp, vp, vp, i64, i32, vp, vp, vp, vp], C.c_int),
         "ffx_host_unique_rows": ([vp, i64, i64, i32, vp, P(i64), vp], C.c_int),
         "ffx_host_rows_unique": ([vp, i64, vp, i64, vp, i64, i64, i32, vp, P(i64), vp], C.c_int),
+        "ffx_host_segment_offsets": ([vp, i64, vp, i64, i32, vp], C.c_int),
+        "ffx_host_segment_rows_unique": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, P(i64), vp], C.c_int),
         "ffx_comm_unique_id": ([C.c_int, vp], C.c_int),
         "ffx_comm_init": ([C.c_int, C.c_int, C.c_int, C.c_int, vp, P(vp)], C.c_int),
         "ffx_comm_destroy": ([vp], C.c_int),
@@ -896,6 +898,24 @@ def rows_unique(ids, table1: np.ndarray, table2: np.ndarray | None, n_index_rows
     _check(lib().ffx_host_rows_unique(_ptr(ids), n, _ptr(table1), table1.shape[0], _ptr(table2), 0 if table2 is None else table2.shape[0],
                                       int(n_index_rows), int(threads), _ptr(uniq), C.byref(count), _ptr(inverse)))
     return uniq[:count.value], inverse
+
+
+def segment_rows_unique(ids, entry_off: np.ndarray, entry_row: np.ndarray, n_index_rows: int, threads: int = 0):
+    """Candidates that contribute all rows of their document (``entry_off[id] .. entry_off[id + 1]`` index ``entry_row``):
+    (segment offsets [n + 1], distinct rows ascending, int32 slot of every gathered row among them) in two native passes
+    (``ffx_host_segment_offsets``, ``ffx_host_segment_rows_unique``)."""
+    ids = _arr(ids, np.int32)
+    assert entry_off.dtype == np.int32 and entry_row.dtype == np.int32 and entry_off.flags["C_CONTIGUOUS"] and entry_row.flags["C_CONTIGUOUS"]
+    n = ids.shape[0]
+    seg_off = np.empty(n + 1, dtype=np.int64)
+    _check(lib().ffx_host_segment_offsets(_ptr(ids), n, _ptr(entry_off), entry_off.shape[0] - 1, int(threads), _ptr(seg_off)))
+    total = int(seg_off[-1])
+    uniq = np.empty(max(1, min(total, int(n_index_rows))), dtype=np.int64)
+    inverse = np.empty(total, dtype=np.int32)
+    count = C.c_int64(0)
+    _check(lib().ffx_host_segment_rows_unique(_ptr(ids), n, _ptr(entry_off), entry_off.shape[0] - 1, _ptr(entry_row), entry_row.shape[0], _ptr(seg_off),
+                                              int(n_index_rows), int(threads), _ptr(uniq), C.byref(count), _ptr(inverse)))
+    return seg_off, uniq[:count.value], inverse
 
 
 def outer_join(off_a, code_a, off_b, code_b, threads: int = 0):

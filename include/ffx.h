@@ -468,6 +468,15 @@ int ffx_host_unique_rows(const int64_t* rows, int64_t n, int64_t n_index_rows, i
 int ffx_host_rows_unique(const int32_t* ids, int64_t n, const int32_t* table1, int64_t n1, const int32_t* table2, int64_t n2,
                          int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse);
 
+/* the same for candidates that contribute ALL rows of their document (MaxP / AveP over multi-passage documents):
+ * entry_off[id] .. entry_off[id + 1] (n_docs + 1 offsets) are the document's entries, entry_row[] (n_entries) their rows.
+ * ffx_host_segment_offsets: seg_off[0 .. n], seg_off[n] = R gathered rows; ffx_host_segment_rows_unique (seg_off as
+ * returned): the distinct rows ascending and, in inverse[0 .. R), the slot of every gathered row among them. */
+int ffx_host_segment_offsets(const int32_t* ids, int64_t n, const int32_t* entry_off, int64_t n_docs, int32_t n_threads, int64_t* seg_off);
+int ffx_host_segment_rows_unique(const int32_t* ids, int64_t n, const int32_t* entry_off, int64_t n_docs, const int32_t* entry_row,
+                                 int64_t n_entries, const int64_t* seg_off, int64_t n_index_rows, int32_t n_threads, int64_t* uniq,
+                                 int64_t* n_uniq, int32_t* inverse);
+
 /* The outer join of Ranking.interpolate / + (ranking.py:293-326) on integer keys, for two rankings whose rows stand
  * grouped by query: rows off_a[g] .. off_a[g+1] of A and off_b[g] .. off_b[g+1] of B belong to query g, code_a / code_b
  * number the ids in one common table, a pair occurs at most once per side (FFX_BAD_ARG otherwise).  Per query the union

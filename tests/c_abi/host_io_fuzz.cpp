@@ -431,6 +431,36 @@ int main(int argc, char** argv) {
       t1[0] = keep;
       if (ffx_host_rows_unique(ids.data(), n, t1.data(), n1, t2.data(), n2, n_index / 2, 4, ub.data(), &cb, two.data()) == FFX_OK) return 1;
     }
+    // all rows of every candidate's document: offsets, then rows -> distinct rows + slots, against the steps done apart
+    {
+      const int64_t nd = 60000;
+      std::vector<int32_t> eoff((size_t)nd + 1, 0), ids((size_t)n);
+      for (int64_t d = 0; d < nd; ++d) eoff[(size_t)d + 1] = eoff[(size_t)d] + 1 + (int32_t)(rnd() % 5);
+      const int64_t ne = eoff[(size_t)nd];
+      std::vector<int32_t> erow((size_t)ne);
+      for (auto& v : erow) v = (int32_t)(rnd() % (uint64_t)n_index);
+      for (auto& v : ids) v = (int32_t)(rnd() % (uint64_t)nd);
+      std::vector<int64_t> so1((size_t)n + 1), so4((size_t)n + 1);
+      if (ffx_host_segment_offsets(ids.data(), n, eoff.data(), nd, 1, so1.data()) != FFX_OK || ffx_host_segment_offsets(ids.data(), n, eoff.data(), nd, 4, so4.data()) != FFX_OK || so1 != so4) return 1;
+      const int64_t R2 = so1[(size_t)n];
+      std::vector<int64_t> apart((size_t)R2), ua((size_t)n_index), ub((size_t)n_index);
+      for (int64_t i = 0; i < n; ++i)
+        for (int64_t k = so1[(size_t)i]; k < so1[(size_t)i + 1]; ++k) apart[(size_t)k] = erow[(size_t)(eoff[(size_t)ids[(size_t)i]] + (k - so1[(size_t)i]))];
+      std::vector<int32_t> ia((size_t)R2), ib((size_t)R2);
+      int64_t ca = 0, cb = 0;
+      if (ffx_host_unique_rows(apart.data(), R2, n_index, 1, ua.data(), &ca, ia.data()) != FFX_OK) return 1;
+      for (int threads : {1, 4}) {
+        if (ffx_host_segment_rows_unique(ids.data(), n, eoff.data(), nd, erow.data(), ne, so1.data(), n_index, threads, ub.data(), &cb, ib.data()) != FFX_OK) return 1;
+        if (ca != cb || ia != ib || !std::equal(ua.begin(), ua.begin() + ca, ub.begin())) return 1;
+      }
+      ids[3] = (int32_t)nd;  // a document outside the table; offsets that do not belong to the ids; a row outside the index: refused
+      if (ffx_host_segment_offsets(ids.data(), n, eoff.data(), nd, 4, so4.data()) == FFX_OK) return 1;
+      if (ffx_host_segment_rows_unique(ids.data(), n, eoff.data(), nd, erow.data(), ne, so1.data(), n_index, 4, ub.data(), &cb, ib.data()) == FFX_OK) return 1;
+      ids[3] = 0;
+      if (ffx_host_segment_offsets(ids.data(), n, eoff.data(), nd, 4, so4.data()) != FFX_OK) return 1;
+      std::vector<int32_t> ic((size_t)so4[(size_t)n]);
+      if (ffx_host_segment_rows_unique(ids.data(), n, eoff.data(), nd, erow.data(), ne, so4.data(), n_index / 2, 4, ub.data(), &cb, ic.data()) == FFX_OK) return 1;
+    }
     // look-ups of a packed buffer large enough for several threads (byte ranges, strings numbered by the separators in
     // front of them): every ordinal right, empty strings and strings nobody interned reported as -1, the first one named
     {

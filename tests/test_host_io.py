@@ -232,6 +232,30 @@ def test_rows_unique_equals_numpy():
         native.rows_unique(np.array([0], dtype=np.int32), t1, t2, int(t2[t1[0]]))
 
 
+def test_segment_rows_unique_equals_numpy():
+    """ffx_host_segment_offsets + ffx_host_segment_rows_unique: every row of every candidate's document, the distinct
+    rows and the slots, against the NumPy statement of get_indices (index/util.py:29-41) + numpy.unique."""
+    rng = np.random.default_rng(4)
+    n_docs = 3000
+    per = rng.integers(1, 7, size=n_docs)
+    entry_off = np.concatenate([[0], np.cumsum(per)]).astype(np.int32)
+    entry_row = rng.permutation(int(entry_off[-1]) + 50)[:int(entry_off[-1])].astype(np.int32)
+    n_index = int(entry_off[-1]) + 50
+    for n in (0, 1, 700, 150_000):
+        ids = rng.integers(0, n_docs, size=n).astype(np.int32)
+        seg_off, uniq, inverse = native.segment_rows_unique(ids, entry_off, entry_row, n_index, threads=3)
+        start = entry_off[ids].astype(np.int64)
+        cnt = entry_off[ids.astype(np.int64) + 1] - start
+        want_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        rows = entry_row[np.repeat(start, cnt) + np.arange(int(want_off[-1])) - np.repeat(want_off[:-1], cnt)] if n else np.zeros(0, dtype=np.int32)
+        want_u, want_i = np.unique(rows, return_inverse=True)
+        assert np.array_equal(seg_off, want_off) and np.array_equal(uniq, want_u) and np.array_equal(inverse, want_i)
+    with pytest.raises(native.FFXError, match="names no document"):
+        native.segment_rows_unique(np.array([n_docs], dtype=np.int32), entry_off, entry_row, n_index)
+    with pytest.raises(native.FFXError, match="outside the index"):
+        native.segment_rows_unique(np.array([0], dtype=np.int32), entry_off, entry_row, int(entry_row[0]))
+
+
 def test_host_natives_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     """csrc/host_io.cpp -- the code that parses untrusted run files -- built alone with
     g++ -fsanitize=address,undefined and driven by tests/c_abi/host_io_fuzz.cpp: a well-formed run,

@@ -222,6 +222,38 @@ def test_device_pull_and_host_gather_stream_the_same_rows(tmp_path):
         del made, threads, auto
 
 
+@pytest.mark.gpu
+def test_streamed_batches_large_enough_for_the_native_expansion(tmp_path):
+    """Above 65536 candidates a streamed call expands and de-duplicates its candidates natively (one row per
+    candidate: ffx_host_rows_unique; all rows of a document: ffx_host_segment_offsets / _segment_rows_unique).
+    Multi-passage documents, every mode, several windows: the streamed frames equal the resident index's."""
+    rng = np.random.default_rng(11)
+    n_docs, dim, n_q, k = 20_000, 32, 180, 400
+    per = rng.integers(1, 6, size=n_docs)
+    doc_of_row = np.repeat(np.arange(n_docs), per)
+    order = rng.permutation(doc_of_row.shape[0])  # a document's passages are scattered over the file
+    doc_of_row = doc_of_row[order]
+    n_rows = doc_of_row.shape[0]
+    vectors = (rng.standard_normal((n_rows, dim)) * 0.3).astype(np.float32)
+    qv = (rng.standard_normal((n_q, dim)) * 0.3).astype(np.float32)
+    enc = LambdaEncoder(lambda t: qv[int(t)])
+    disk = OnDiskIndex(tmp_path / "multi.ffx", enc, mode=Mode.MAXP, chunk_size=4096, window_bytes=1 << 18)
+    disk.add(vectors, doc_ids=[f"D{d}" for d in doc_of_row], psg_ids=[f"P{r}" for r in range(n_rows)])
+    mem = disk.to_memory()
+    docs = np.concatenate([rng.choice(n_docs, size=k, replace=False) for _ in range(n_q)])
+    frame = pd.DataFrame({"q_id": np.repeat([f"q{i}" for i in range(n_q)], k), "id": [f"D{d}" for d in docs],
+                          "score": rng.random(n_q * k).astype(np.float32) * 20})
+    first = Ranking(frame, queries={f"q{i}": str(i) for i in range(n_q)})
+    psgs = np.concatenate([rng.choice(n_rows, size=k, replace=False) for _ in range(n_q)])
+    first_psg = Ranking(frame.assign(id=[f"P{r}" for r in psgs]), queries={f"q{i}": str(i) for i in range(n_q)})
+    for mode, run in ((Mode.MAXP, first), (Mode.AVEP, first), (Mode.FIRSTP, first), (Mode.PASSAGE, first_psg)):
+        disk.mode = mem.mode = mode
+        assert disk.rerank(run, 0.2) == mem.rerank(run, 0.2)
+        assert disk.last_stats["windows"] > 3 and disk.last_stats["gathered_rows"] >= n_q * k
+        assert disk(run) == mem(run)
+    mem.close()
+
+
 # ---- HDF5 files of the reference ---------------------------------------------------------------------------
 import json  # noqa: E402
 from pathlib import Path  # noqa: E402
