@@ -26,6 +26,7 @@ ap.add_argument("--queries", type=int, default=200)
 ap.add_argument("--k", type=int, default=5000)
 ap.add_argument("--window-mb", type=int, default=512)
 ap.add_argument("--dir", default=None)
+ap.add_argument("--passages-max", type=int, default=1, help="documents of 1 .. N passages (consecutive rows); candidates are documents, MaxP over all their rows")
 args = ap.parse_args()
 
 rng = np.random.default_rng(0)
@@ -58,22 +59,29 @@ with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
     idx = OnDiskIndex(Path(tmp) / "index.ffx", mode=Mode.MAXP, chunk_size=2**16, max_id_length=12, window_bytes=args.window_mb << 20)
     t0 = time.perf_counter()
     step = 2**17
+    if args.passages_max > 1:
+        per = rng.integers(1, args.passages_max + 1, size=args.rows)
+        doc_of_row = np.repeat(np.arange(args.rows), per)[:args.rows]
+    else:
+        doc_of_row = np.arange(args.rows)
+    n_docs = int(doc_of_row[-1]) + 1
     for lo in range(0, args.rows, step):
         hi = min(args.rows, lo + step)
-        idx.add((rng.standard_normal((hi - lo, args.dim), dtype=np.float32) * np.float32(0.036)), doc_ids=[f"D{i}" for i in range(lo, hi)])
+        idx.add((rng.standard_normal((hi - lo, args.dim), dtype=np.float32) * np.float32(0.036)), doc_ids=[f"D{d}" for d in doc_of_row[lo:hi]])
     out["build_s"] = time.perf_counter() - t0
     out["file_gb"] = (Path(tmp) / "index.ffx").stat().st_size / 1e9
     qv = rng.standard_normal((args.queries, args.dim), dtype=np.float32) * np.float32(0.036)
-    if args.k * args.k > args.rows // 8:  # small index: a permutation per query is affordable
-        pair_ids = np.concatenate([rng.choice(args.rows, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
-    else:  # k distinct rows per query: drawn with replacement, the few queries that drew a row twice drawn again
-        picks = rng.integers(0, args.rows, size=(args.queries, args.k), dtype=np.int64)
+    out["documents"] = n_docs
+    if args.k * args.k > n_docs // 8:  # small index: a permutation per query is affordable
+        pair_ids = np.concatenate([rng.choice(n_docs, size=args.k, replace=False) for _ in range(args.queries)]).astype(np.int32)
+    else:  # k distinct documents per query: drawn with replacement, the few queries that drew one twice drawn again
+        picks = rng.integers(0, n_docs, size=(args.queries, args.k), dtype=np.int64)
         while True:
             ordered = np.sort(picks, axis=1)
             again = np.flatnonzero((ordered[:, 1:] == ordered[:, :-1]).any(axis=1))
             if again.size == 0:
                 break
-            picks[again] = rng.integers(0, args.rows, size=(again.size, args.k), dtype=np.int64)
+            picks[again] = rng.integers(0, n_docs, size=(again.size, args.k), dtype=np.int64)
         pair_ids = picks.reshape(-1).astype(np.int32)
     pair_off = np.arange(args.queries + 1, dtype=np.int64) * args.k
     sparse = rng.random(pair_ids.shape[0], dtype=np.float32) * 25
