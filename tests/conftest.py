@@ -16,6 +16,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # if the runtime ever aborts the process (one run in ~25 of round 3 ended in a SIGABRT inside hipMemcpy), the log
+    # should say which test and which Python line it was in
+    import faulthandler
+
+    if not faulthandler.is_enabled():
+        faulthandler.enable(all_threads=True)
     # a fresh checkout has no built libraries (they are git-ignored): build them once, as
     # __graft_entry__.build() does, so the suite does not depend on a step having been run before it
     lib = ROOT / "fast-forward-indexes_amd" / "fast_forward_amd" / "libffx.so"
