@@ -390,8 +390,15 @@ class _ShardedIndex:
         full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(self.comm.world)])
         return run.result(name, full_k, full_s, pair_off)[0]
 
-    def __call__(self, ranking, gather: bool = False):
-        """Dense scores (``Index.__call__``) of the queries this rank owns, or of all with ``gather``."""
+    def __call__(self, ranking, early_stopping: int | None = None, early_stopping_alpha: float | None = None,
+                 early_stopping_depths=None, batch_size: int | None = None, gather: bool = False):
+        """Dense scores (``Index.__call__``, base.py:389-396: same keywords) of the queries this rank owns, or of all
+        with ``gather``.  ``batch_size`` is accepted and has no effect (nothing is materialised per batch here); early
+        stopping (base.py:316-387) is a per-query loop over depth intervals that no sharded form exists for: asking for it
+        raises instead of silently scoring everything."""
+        if early_stopping is not None or early_stopping_alpha is not None or early_stopping_depths is not None:
+            raise NotImplementedError("early stopping is not available on a sharded index: score on one GPU (InMemoryIndex), "
+                                      "or call the sharded index without it")
         return self._rank(ranking, None, "fast-forward", gather)
 
     def rerank(self, ranking, alpha: float, gather: bool = False):

@@ -69,6 +69,12 @@ run = {f"q{q}": {d: float(1 + (7 * q + j) % 5) for j, d in enumerate(docs) if (q
 small = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(5)})
 assert sub(small, gather=True) == whole(small)
 assert sub.rerank(small, 0.3, gather=True) == whole.rerank(small, 0.3)
+assert sub(small, batch_size=7, gather=True) == whole(small)  # the reference's keywords are accepted
+try:
+    sub(small, early_stopping=3, early_stopping_alpha=0.2, early_stopping_depths=(5, 10))
+    raise AssertionError("early stopping on a sharded index must be refused")
+except NotImplementedError:
+    pass
 sub.close()
 whole.close()
 empty = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode.MAXP, comm=comm)
