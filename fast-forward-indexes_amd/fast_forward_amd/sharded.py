@@ -315,22 +315,24 @@ class _ShardedIndex:
         holder = held.argmax(axis=0).astype(np.int32) if len(names) else np.zeros(0, dtype=np.int32)
         return holder, np.maximum(ord_u, 0), ~held.any(axis=0)
 
-    def _holders(self, ranking, perm) -> tuple[np.ndarray, np.ndarray]:
+    def _holders(self, ranking, perm, missing_ok: bool = False) -> tuple[np.ndarray, np.ndarray]:
         """(holder rank, ordinal on that rank) of every candidate, rows grouped by query.  The distinct ids are
         looked up once per (ranking, index, mode) and remembered with the ranking; ``IndexError`` on EVERY rank
-        for an id no rank holds (the reference's util.py:38-39), naming the first one in row order."""
+        for an id no rank holds (the reference's util.py:38-39), naming the first one in row order -- or, with
+        ``missing_ok`` (early stopping: an unknown id only matters if it is reached), holder -1 for such rows."""
         codes, names = ranking._id_coding()
         key = (id(self), self.local.mode, getattr(self, "_n_global", None), getattr(self.local._ids, "version", None))
         cached = getattr(ranking, "_holder_cache", None)
         if cached is None or cached[0] != key or cached[1] is not names or cached[2] is not codes:
             holder_c, local_c, missing_c = self._holders_by_code(names, ranking._id_blob(names))
-            if missing_c.any():
-                bad = np.flatnonzero(missing_c[codes])
-                if bad.size:
-                    raise IndexError(f"ID {names[codes[int(bad[0])]]} not found in the index.")
-            cached = (key, names, codes, holder_c.astype(np.int32)[codes], local_c.astype(np.int32)[codes])
+            holder_c = np.where(missing_c, -1, holder_c).astype(np.int32)
+            cached = (key, names, codes, holder_c[codes], local_c.astype(np.int32)[codes])
             ranking._holder_cache = cached
         holder, local_ids = cached[3], cached[4]
+        if not missing_ok:
+            bad = np.flatnonzero(holder < 0)
+            if bad.size:
+                raise IndexError(f"ID {names[codes[int(bad[0])]]} not found in the index.")
         return (holder, local_ids) if perm is None else (holder[perm], local_ids[perm])
 
     def _sharded(self) -> ShardedScorer:
@@ -390,15 +392,77 @@ class _ShardedIndex:
         full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(self.comm.world)])
         return run.result(name, full_k, full_s, pair_off)[0]
 
+    def _dense_everywhere(self, query_vectors, pair_off, holder, local_ids) -> np.ndarray:
+        """Dense scores of EVERY candidate of a CSR, on every rank (collective): the sharded step -- local scores, exchange
+        to the owners -- and one all-gather of the owners' blocks, which stand in query order."""
+        from fast_forward_amd import native
+
+        mode = self.local.mode.value
+        streamed = self._local_scores(query_vectors, pair_off, holder, local_ids, mode)
+        if streamed is None:
+            scorer = self._sharded()
+            scorer.set_queries(query_vectors)
+            scorer.set_pairs(pair_off, local_ids, None, mode, holder=holder)
+            scorer.run(0.0, exact_sum=self.exact_sum, sort=False)
+            mine = scorer.fetch(order=False)[0]
+            n_own = scorer.own_pairs
+        else:
+            r = native.route(pair_off, local_ids, self.comm.rank, self.comm.world, holder=holder)
+            mine = self.comm.exchange_host(streamed, r["send_counts"], r["recv_counts"])[r["recv_slot"]]
+            n_own = r["own_pairs"]
+        mine = np.ascontiguousarray(mine[:n_own], dtype=np.float32)
+        sizes = self.comm.allgather_array(np.array([n_own], dtype=np.int64))[:, 0]
+        pad = np.zeros(max(1, int(sizes.max())), dtype=np.float32)
+        pad[:n_own] = mine
+        blocks = self.comm.allgather_array(pad)
+        return np.concatenate([blocks[r, :int(sizes[r])] for r in range(self.comm.world)])
+
+    def _early_stopping(self, ranking, cutoff: int, alpha: float, depths, gather: bool):
+        """``Index._early_stopping`` (base.py:316-387) over the shards: the reference's loop over depth intervals, as
+        stated in ``Index._early_stopping_kept``, where scoring an interval is one sharded step whose dense scores every
+        rank receives -- so every rank takes the same decisions on the same numbers and no further message is needed.
+        Returns the ranking of the candidates that were scored (of all queries on every rank; ``gather=False`` keeps this
+        rank's owned queries)."""
+        from fast_forward_amd import native
+        from fast_forward_amd.index.api import Index, _Run
+
+        run = _Run(self.local, ranking)
+        off = run.pair_off
+        holder, local_ids = self._holders(ranking, run.perm, missing_ok=True)
+        sparse, codes_g = run.grouped(ranking._scores()), run.grouped(run.codes)
+        me = self
+
+        class Scored:  # what Index._early_stopping_kept needs of an index
+            mode = self.local.mode
+
+            def _es_bound_f32(self):
+                return me.local._es_bound_f32()
+
+            def _score_pairs(self, query_vectors, part_off, positions, mode):
+                return me._dense_everywhere(query_vectors, part_off, holder[positions], local_ids[positions]), None, None
+
+        positions = np.where(holder >= 0, np.arange(holder.shape[0], dtype=np.int64), -1)  # -1: no rank holds the id (an error if reached)
+        rows, scores = Index._early_stopping_kept(Scored(), lambda p: run.names[codes_g[p]], sparse, off, run.query_vectors, cutoff, alpha, depths, positions)
+        rows, scores = rows.astype(np.int32), np.ascontiguousarray(scores, dtype=np.float32)
+        kept_off = np.searchsorted(rows, off).astype(np.int64)
+        order = native.host_order(scores, kept_off)
+        out = run.result("fast-forward", native.take32(rows, order), native.take32(scores, order), kept_off)[0]
+        if gather:
+            return out
+        q_lo, q_hi = native.query_partition(off.shape[0] - 1, self.comm.world)[self.comm.rank:self.comm.rank + 2]
+        lo, hi = int(kept_off[q_lo]), int(kept_off[q_hi])
+        return run.result("fast-forward", native.take32(rows, order)[lo:hi], native.take32(scores, order)[lo:hi], kept_off[q_lo:q_hi + 1] - lo, q_range=(int(q_lo), int(q_hi)))[0]
+
     def __call__(self, ranking, early_stopping: int | None = None, early_stopping_alpha: float | None = None,
                  early_stopping_depths=None, batch_size: int | None = None, gather: bool = False):
         """Dense scores (``Index.__call__``, base.py:389-396: same keywords) of the queries this rank owns, or of all
-        with ``gather``.  ``batch_size`` is accepted and has no effect (nothing is materialised per batch here); early
-        stopping (base.py:316-387) is a per-query loop over depth intervals that no sharded form exists for: asking for it
-        raises instead of silently scoring everything."""
-        if early_stopping is not None or early_stopping_alpha is not None or early_stopping_depths is not None:
-            raise NotImplementedError("early stopping is not available on a sharded index: score on one GPU (InMemoryIndex), "
-                                      "or call the sharded index without it")
+        with ``gather``.  ``batch_size`` is accepted and has no effect (nothing is materialised per batch here)."""
+        if not ranking.has_queries:
+            raise ValueError("Input ranking has no queries attached.")
+        if early_stopping is not None:
+            if early_stopping_alpha is None or early_stopping_depths is None:
+                raise ValueError("Early stopping requires alpha and depths.")
+            return self._early_stopping(ranking, early_stopping, early_stopping_alpha, early_stopping_depths, gather)
         return self._rank(ranking, None, "fast-forward", gather)
 
     def rerank(self, ranking, alpha: float, gather: bool = False):

@@ -52,6 +52,33 @@ for mode in ("MAXP", "PASSAGE", "AVEP"):
         assert "missing-id" in str(e)
     else:
         raise AssertionError("unknown id accepted")
+    # early stopping over the shards (base.py:316-387): the frames of the one-GPU index, for every rank's owned
+    # queries and gathered; an id nobody holds is an error only if the loop reaches it
+    from fast_forward_amd.index import InMemoryIndex as _One
+
+    one = _One(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode(MODE_NO[mode]))
+    one.add(case.vectors, doc_ids=case.doc_names, psg_ids=case.psg_names)
+    for cutoff, es_alpha, depths in ((3, 0.2, (5, 20, 100)), (1, 0.5, (1, 4, 30)), (10, 0.0, (10, 50))):
+        want = one(first, early_stopping=cutoff, early_stopping_alpha=es_alpha, early_stopping_depths=depths)
+        assert idx(first, early_stopping=cutoff, early_stopping_alpha=es_alpha, early_stopping_depths=depths, gather=True) == want
+        mine = idx(first, early_stopping=cutoff, early_stopping_alpha=es_alpha, early_stopping_depths=depths)
+        assert 0 < len(mine.q_ids) < len(want.q_ids) and all(mine[q] == want[q] for q in mine.q_ids)
+    tail = Ranking.from_run({"q000": {names[0]: 9.0, names[1]: 8.0, "missing-id": 0.5}}, queries={"q000": "0"})
+    assert idx(tail, early_stopping=1, early_stopping_alpha=1.0, early_stopping_depths=(2, 3), gather=True) == \
+        one(tail, early_stopping=1, early_stopping_alpha=1.0, early_stopping_depths=(2, 3))
+    try:
+        idx(tail, early_stopping=3, early_stopping_alpha=0.2, early_stopping_depths=(3,), gather=True)
+    except IndexError as e:
+        assert "missing-id" in str(e)
+    else:
+        raise AssertionError("unknown id reached and accepted")
+    try:
+        idx(first, early_stopping=3)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("early stopping without alpha / depths accepted")
+    one.close()
     idx.close()
 # a collection whose hash placement leaves the LAST rank without a single row: that rank takes part with empty lists
 # (decided collectively -- a rank raising alone between two collectives would leave the others hanging in the exchange)
@@ -70,11 +97,8 @@ small = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(5)})
 assert sub(small, gather=True) == whole(small)
 assert sub.rerank(small, 0.3, gather=True) == whole.rerank(small, 0.3)
 assert sub(small, batch_size=7, gather=True) == whole(small)  # the reference's keywords are accepted
-try:
-    sub(small, early_stopping=3, early_stopping_alpha=0.2, early_stopping_depths=(5, 10))
-    raise AssertionError("early stopping on a sharded index must be refused")
-except NotImplementedError:
-    pass
+assert sub(small, early_stopping=2, early_stopping_alpha=0.2, early_stopping_depths=(2, 5), gather=True) == \
+    whole(small, early_stopping=2, early_stopping_alpha=0.2, early_stopping_depths=(2, 5))  # (one rank holds no rows)
 sub.close()
 whole.close()
 empty = ShardedInMemoryIndex(LambdaEncoder(lambda t: qvecs[int(t)]), mode=Mode.MAXP, comm=comm)

@@ -43,6 +43,8 @@ for resident in (True, False):
     for mode in (Mode.MAXP, Mode.FIRSTP, Mode.AVEP):
         sharded.mode = mem.mode = mode
         assert sharded(first, gather=True) == mem(first), (resident, mode)
+        es = dict(early_stopping=4, early_stopping_alpha=0.3, early_stopping_depths=(4, 20, 200))  # over shards, resident and streamed
+        assert sharded(first, gather=True, **es) == mem(first, **es), (resident, mode, "early stopping")
         own = sharded.rerank(first, 0.3)
         want = mem.rerank(first, 0.3)
         assert 0 < len(own.q_ids) < 5
