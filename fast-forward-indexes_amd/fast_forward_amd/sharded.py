@@ -338,6 +338,10 @@ class _ShardedIndex:
     def _sharded(self) -> ShardedScorer:
         raise NotImplementedError
 
+    def _scorer_queries(self, query_vectors: np.ndarray) -> np.ndarray:
+        """The query vectors as the resident scorer wants them (an OPQ shard: rotated once, see InMemoryIndex)."""
+        return query_vectors
+
     def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode) -> np.ndarray | None:
         """Dense scores of this rank's candidates computed outside ``ffx_sharded`` (a shard that is
         streamed from its file instead of resident), or None when the resident scorer does it."""
@@ -359,7 +363,7 @@ class _ShardedIndex:
         streamed = self._local_scores(run.query_vectors, pair_off, holder, local_ids, mode)
         if streamed is None:
             scorer = self._sharded()
-            scorer.set_queries(run.query_vectors)
+            scorer.set_queries(self._scorer_queries(run.query_vectors))
             scorer.set_pairs(pair_off, local_ids, sparse if alpha is not None else None, mode, holder=holder)
             scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=True)
             ff, interp, order = scorer.fetch(order=True)
@@ -401,7 +405,7 @@ class _ShardedIndex:
         streamed = self._local_scores(query_vectors, pair_off, holder, local_ids, mode)
         if streamed is None:
             scorer = self._sharded()
-            scorer.set_queries(query_vectors)
+            scorer.set_queries(self._scorer_queries(query_vectors))
             scorer.set_pairs(pair_off, local_ids, None, mode, holder=holder)
             scorer.run(0.0, exact_sum=self.exact_sum, sort=False)
             mine = scorer.fetch(order=False)[0]
@@ -651,10 +655,10 @@ class ShardedOnDiskIndex(_ShardedIndex):
     def _sharded(self) -> ShardedScorer:
         return self._scorer
 
-    def _rank(self, ranking, alpha, name, gather):
-        if self.resident and getattr(self, "_rotation", None) is not None:
-            raise NotImplementedError("OPQ-rotated queries on a sharded on-disk index: use to_memory() on one GPU")
-        return super()._rank(ranking, alpha, name, gather)
+    def _scorer_queries(self, query_vectors):
+        # OPQ decodes to c @ R.T, and <q, c R^T> = <q R, c>: the queries are rotated once (as InMemoryIndex does)
+        rotation = getattr(self, "_rotation", None)
+        return query_vectors if rotation is None else np.ascontiguousarray(np.asarray(query_vectors, dtype=np.float32) @ rotation, dtype=np.float32)
 
     def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode):
         if self.resident:

@@ -117,6 +117,30 @@ for resident in (True, False):
     sharded.close()
 mem.close()
 
+# ---- 2b. an OPQ-quantized container: codes in the shards, the queries rotated once on every rank ------------------
+from fast_forward_amd.quantizer import NanoOPQ  # noqa: E402
+
+opq_path = work / "opq.ffx"
+x32 = case.vectors.astype(np.float32)
+if rank == 0:
+    opq = NanoOPQ(8, 16)
+    opq.fit(x32, pq_iter=2, rotation_iter=2)
+    w = OnDiskIndex(opq_path, enc, quantizer=opq, mode=Mode.MAXP, chunk_size=64, overwrite=True)
+    w.add(x32, doc_ids=case.doc_names, psg_ids=case.psg_names)
+    del w
+comm.barrier()
+opq_single = OnDiskIndex.load(opq_path, enc).to_memory()
+opq_docs = sorted(set(case.doc_names))
+opq_run = Ranking.from_run({f"q{q}": {d: float(rng.random() * 20) for d in rng.choice(opq_docs, size=25, replace=False)} for q in range(len(case.q_names))},
+                           queries={f"q{q}": str(q) for q in range(len(case.q_names))})
+for resident in (True, False):
+    sharded = ShardedOnDiskIndex(opq_path, comm, enc, resident=resident, window_bytes=300)
+    assert sharded(opq_run, gather=True) == opq_single(opq_run), resident
+    assert sharded.rerank(opq_run, 0.2, gather=True) == opq_single.rerank(opq_run, 0.2), resident
+    checked += len(opq_run._df)
+    sharded.close()
+opq_single.close()
+
 # ---- 3. fewer documents than ranks: some rank's document range is empty; it takes part with empty candidate lists
 #         (the constructor's "no rows here" is the same decision on every rank, nobody raises between two collectives)
 tiny = work / "tiny.ffx"
