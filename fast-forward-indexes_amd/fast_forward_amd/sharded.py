@@ -303,6 +303,43 @@ class _ShardedIndex:
     def dim(self):
         return self.local.dim
 
+    @property
+    def query_encoder(self):
+        return self.local.query_encoder
+
+    @query_encoder.setter
+    def query_encoder(self, encoder) -> None:
+        self.local.query_encoder = encoder
+
+    @property
+    def quantizer(self):
+        return self.local.quantizer
+
+    def encode_queries(self, queries):
+        """``Index.encode_queries`` (base.py:58-72): every rank encodes the same queries."""
+        return self.local.encode_queries(queries)
+
+    def _all_ids(self, mine: set) -> set:
+        """The union of every rank's id strings (collective; the ids travel once, as one joined buffer per rank)."""
+        blob = "\n".join(sorted(mine)).encode()
+        sizes = self.comm.allgather_array(np.array([len(blob), len(mine)], dtype=np.int64))
+        room = max(1, int(sizes[:, 0].max()))
+        out: set = set()
+        for r, part in enumerate(self.comm.allgather_bytes(blob.ljust(room, b"\0"))):
+            if sizes[r, 1]:
+                out.update(part[:int(sizes[r, 0])].decode().split("\n"))
+        return out
+
+    @property
+    def doc_ids(self) -> set:
+        """All document ids, of every shard (``Index.doc_ids``; collective: every rank asks together)."""
+        return self._all_ids(self.local.doc_ids)
+
+    @property
+    def psg_ids(self) -> set:
+        """All passage ids, of every shard (``Index.psg_ids``; collective)."""
+        return self._all_ids(self.local.psg_ids)
+
     def _holders_by_code(self, names: np.ndarray, packed=None) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
         """For the DISTINCT candidate ids of a ranking: (holder rank, ordinal on this rank where this rank is
         the holder, "no rank holds it" mask).  Collective (every rank calls it with the same ids, in the same

@@ -29,6 +29,8 @@ for mode in ("MAXP", "PASSAGE", "AVEP"):
     for lo, hi in ((0, third), (third, len(case.vectors))):
         idx.add(case.vectors[lo:hi], doc_ids=case.doc_names[lo:hi], psg_ids=case.psg_names[lo:hi])
     assert len(idx) == len(case.vectors) and 0 < len(idx.local) < len(case.vectors)
+    assert idx.doc_ids == {d for d in case.doc_names if d is not None} and idx.psg_ids == {p for p in case.psg_names if p is not None}
+    assert idx.dim == case.vectors.shape[1] and idx.quantizer is None and np.array_equal(idx.encode_queries(["1", "0"]), qvecs[[1, 0]])
     pair_off, _, sparse, names = case.pairs(mode)
     pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
     first = Ranking(pd.DataFrame({"q_id": [case.q_names[q] for q in pair_q], "id": names, "score": sparse}),
