@@ -165,7 +165,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(args, doc_off, n_docs, scale, q_first: int = 0):
+def cpu_baseline(args, doc_off, n_docs, scale, q_first: int = 0, batch_seed: int | None = None):
     """Reference-equivalent CPU path (oracle/ffx_oracle.py numpy_port_score: the reference's
     own three NumPy ops, index/base.py:301-303) on the first `cpu_sample_queries` queries of
     the same workload.  The rows those queries touch are re-derived on the host with the same
@@ -175,7 +175,7 @@ def cpu_baseline(args, doc_off, n_docs, scale, q_first: int = 0):
     import ffx_oracle as fo
 
     nq = args.cpu_sample_queries
-    ids, sparse = candidates(n_docs, nq, args.k, args.seed, q_first=q_first)
+    ids, sparse = candidates(n_docs, nq, args.k, args.seed if batch_seed is None else batch_seed, q_first=q_first)
     pair_off = np.arange(nq + 1, dtype=np.int64) * args.k
     # compact the touched documents into a small host index (same row values, renumbered)
     uniq, inv = np.unique(ids, return_inverse=True)
@@ -431,6 +431,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
     per_rank = gather_stats(comm, scorer.stats())
     row_bytes = args.dim * np.dtype(store).itemsize + 4
+    fresh = fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exact, rank, world, query_partition)
 
     # parity: owned queries' interpolated scores vs the oracle on a small sample (the rank that prints the line)
     rehearsal = bool(args.as_rank_of)
@@ -441,8 +442,10 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
         args.cpu_sample_queries = min(args.cpu_sample_queries, scorer.q_hi - scorer.q_lo, 16 if world > 1 else args.cpu_sample_queries)
         if world > 1:
             args.cpu_seconds = min(args.cpu_seconds, 0.5)
-        base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale, q_first=scorer.q_lo)
-        _, interp, _ = scorer.fetch()
+        base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale, q_first=scorer.q_lo, batch_seed=fresh["last_batch_seed"])
+        interp = fresh.get("interp")  # of the last fresh batch: out of ffx_sharded_score's host buffers, or (rehearsal) out of the device
+        if interp is None:
+            _, interp, _ = scorer.fetch()
         n_s = s_ids.shape[0]
         got, want = interp[:n_s], s_interp
         if rehearsal:  # only the candidates this rank holds were scored: the peers' scores arrive as zeros
@@ -498,9 +501,10 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                              "overlap batch i+1's scoring, so a step costs about max(local, exchange + merge)",
             "owned_pairs_per_rank": [int(t["own_pairs"]) for t in per_rank],
             "route_and_upload_s": t_route, "route_and_upload_next_batch_s": t_route_again,
-            "host_to_host_batch_ms": t_host_batch * 1e3, "host_to_host_queries_per_s": args.queries / t_host_batch,
-            "host_to_host_note": "one batch from host buffers to host buffers on every rank, not overlapped with anything: route on the device + "
-                                 "uploads, local scoring, exchange, owner merge + ordering, download of the owned queries' results into page-locked arrays the caller re-uses (max over ranks)",
+            "set_once_host_to_host_batch_ms": t_host_batch * 1e3,
+            "set_once_note": "ffx_sharded_set_pairs (every rank uploads and routes the WHOLE batch) + run + fetch, nothing overlapped: the form for a batch that is re-run; "
+                             "a fresh batch goes through ffx_sharded_stage_owned / ffx_sharded_score below",
+            **fresh["line"],
             "device": dev["name"],
             "index_capacity_rows_per_gpu": cap, "index_capacity_rows_total": world * cap,
         }
@@ -510,6 +514,8 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                 "as_rank": rank, "of": world,
                 "step_ms": ms_per_step, "ideal_ms": me["ms_gather_dot"], "step_over_ideal": ms_per_step / max(me["ms_gather_dot"], 1e-9),
                 "local_pairs": int(me["n_pairs"]), "owned_pairs": int(me["own_pairs"]), "owned_queries": int(me["own_queries"]),
+                "fresh_batch_step_ms": fresh["line"]["fresh_batch_step_ms"],
+                "fresh_batch_step_over_ideal": fresh["line"]["fresh_batch_step_ms"] / max(me["ms_gather_dot"], 1e-9),
                 "note": "step_ms: K back-to-back steps of this one rank (batch i's exchange + merge overlap batch i+1's scoring); ideal_ms: this "
                         "rank's gather_dot alone (HIP events of a step run by itself).  `value` = queries / step_ms is what N such ranks would "
                         "deliver if the fabric added nothing: a prediction, not a measurement of N GPUs",
@@ -524,6 +530,107 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     comm.close()
     if failed:
         sys.exit("sharded GPU scores disagree with the CPU oracle on the sampled queries")
+
+
+def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exact, rank, world, query_partition) -> dict:
+    """K DIFFERENT batches back to back, every rank handed only the queries it owns (ffx_sharded_stage_owned): while batch i
+    is scored, batch i+1 goes up (this rank's ~P/world candidates), is routed on the device and its ordinals travel to the
+    holders.  What the reference does on every call -- a new set of queries (index/base.py:418-429, 445-459) -- and what a
+    serving loop would issue.  Then the same through ffx_sharded_score: host buffers in, host buffers out."""
+    qb = query_partition(args.queries, world)
+    q_lo, q_hi = int(qb[rank]), int(qb[rank + 1])
+    n_own_q, n_own = q_hi - q_lo, (q_hi - q_lo) * args.k
+    mode = MODE_NO[args.mode]
+    rehearsal = bool(args.as_rank_of)
+    n_distinct = max(2, min(args.steps, 3))
+    own_off = np.arange(n_own_q + 1, dtype=np.int64) * args.k
+    own_q = native.pinned_empty((max(n_own_q, 1), args.dim), np.float32)[:n_own_q]
+    own_q[...] = queries[q_lo:q_hi]
+    batches, inboxes, keep_alive = [], [], []
+    for b in range(n_distinct):
+        seed = args.seed + 1000 * (b + 1)
+        ids, sparse = candidates(n_docs, n_own_q, args.k, seed, q_first=q_lo)
+        p_ids, p_sp = native.pinned_empty(max(n_own, 1), np.int32)[:n_own], native.pinned_empty(max(n_own, 1), np.float32)[:n_own]
+        p_ids[...], p_sp[...] = ids, sparse
+        batches.append((seed, p_ids, p_sp))
+        if rehearsal and world > 1:
+            # what the ranks that do not exist would send this one on the routing lane, in the order the lane receives it:
+            # per-query counts, their query vectors, the ordinals of the candidates this rank holds
+            parts_cnt, parts_q, parts_ids = [], [], []
+            for o in range(world):
+                if o == rank:
+                    continue
+                o_ids, _ = candidates(n_docs, int(qb[o + 1] - qb[o]), args.k, seed, q_first=int(qb[o]))
+                mine = (o_ids >= doc_bounds[rank]) & (o_ids < doc_bounds[rank + 1])
+                parts_cnt.append(mine.reshape(-1, args.k).sum(axis=1).astype(np.int32))
+                parts_q.append(queries[int(qb[o]):int(qb[o + 1])].reshape(-1).view(np.int32))
+                parts_ids.append((o_ids[mine] - doc_bounds[rank]).astype(np.int32))
+            words = np.concatenate(parts_cnt + parts_q + parts_ids)
+            box = native.DeviceIndex(max(1, -(-words.shape[0] // 256)), 256, device=comm.device, dtype=np.float32)
+            padded = np.zeros(box.capacity * 256, dtype=np.int32)
+            padded[:words.shape[0]] = words
+            box.upload(padded.view(np.float32).reshape(-1, 256), 0)
+            inboxes.append((box.device_ptr(), int(words.shape[0])))
+            keep_alive.append(box)
+
+    def stage(b):
+        seed, p_ids, p_sp = batches[b % n_distinct]
+        if inboxes:
+            comm.rehearsal_inbox(*inboxes[b % n_distinct])
+        scorer.stage_owned(qb, own_q, own_off, p_ids, p_sp, mode)
+        return seed
+
+    seed = stage(0)
+    for b in range(args.warmup):
+        scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
+        seed = stage(b + 1)
+    scorer.sync()
+    comm.barrier()
+    t0 = time.perf_counter()
+    t_stage = 0.0
+    for b in range(args.steps):
+        scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
+        if b + 1 < args.steps:
+            ts = time.perf_counter()
+            seed = stage(args.warmup + b + 1)
+            t_stage += time.perf_counter() - ts
+    scorer.sync()
+    comm.barrier()
+    elapsed = float(comm.allreduce([time.perf_counter() - t0], native.OP_MAX)[0])
+    st = scorer.stats()
+    keys = ("stage_h2d_bytes", "stage_route_send_bytes", "stage_route_recv_bytes", "ms_stage_host", "ms_stage_device", "ms_gather_dot")
+    rows = comm.allgather_array(np.array([float(st[k]) for k in keys], dtype=np.float64))
+    line = {
+        "fresh_batch_step_ms": elapsed * 1e3 / args.steps,
+        "fresh_batch_queries_per_s": args.queries / (elapsed / args.steps),
+        "fresh_batch_note": f"{args.steps} DIFFERENT batches back to back ({n_distinct} distinct candidate sets in page-locked host memory, cycled), every rank handed only "
+                            "the queries it owns: upload of the rank's block, holders found on the device, ordinals to the holders in a first all-to-all on the routing "
+                            "lane while the previous batch is scored; then local gather_dot, all-to-all of scores, owner-side merge + order.  Results stay in HBM",
+        "stage_h2d_bytes_per_rank": [int(r[0]) for r in rows], "stage_route_sent_bytes_per_rank": [int(r[1]) for r in rows],
+        "stage_route_received_bytes_per_rank": [int(r[2]) for r in rows],
+        "stage_host_ms_per_rank": [r[3] for r in rows], "stage_device_ms_per_rank": [r[4] for r in rows],
+        "stage_host_ms_mean_in_loop": t_stage * 1e3 / max(1, args.steps - 1),
+        "fresh_batch_gather_dot_ms_per_rank": [r[5] for r in rows],
+    }
+    if not rehearsal:
+        # host buffers -> host buffers (the PCIe-inclusive rate): ffx_sharded_score slices the rank's block and pipelines the slices
+        outs = (native.pinned_empty(max(1, n_own), np.float32), native.pinned_empty(max(1, n_own), np.float32), native.pinned_empty(max(1, n_own), np.int32))
+        times = []
+        for b in range(3):
+            sd, p_ids, p_sp = batches[b % n_distinct]
+            comm.barrier()
+            tb = time.perf_counter()
+            scorer.score_owned(qb, own_q, own_off, p_ids, p_sp, mode, args.alpha, exact_sum=exact, sort=args.sort, out=outs)
+            times.append(float(comm.allreduce([time.perf_counter() - tb], native.OP_MAX)[0]))
+            seed = sd
+        line.update({"host_to_host_batch_ms": min(times[1:]) * 1e3, "host_to_host_queries_per_s": args.queries / min(times[1:]),
+                     "host_to_host_note": "ffx_sharded_score: one fresh batch from page-locked host buffers to page-locked host buffers on every rank (each its own block), "
+                                          "sliced and pipelined: uploads, routing, scoring, exchange, merge + order and downloads of successive slices overlap (max over ranks)"})
+    for box in keep_alive:
+        box.close()
+    if inboxes:
+        comm.rehearsal_inbox(None, 0)
+    return {"line": line, "last_batch_seed": seed, "interp": None if rehearsal else outs[1]}
 
 
 def bench_replicas(args, comm):

@@ -35,11 +35,10 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/ffx.h"
-
-int ffx_fail(int code, const char* fmt, ...);  // ffx.hip
-bool ffx_debug_variant(const char* name, long long* value);  // ffx.hip: the FFX_DEBUG_VARIANT list of A/B switches
+#include "ffx_internal.h"  // ffx_fail, ffx_debug_variant, in-place hooks of plans and merges (ffx.hip)
 
 namespace {
 
@@ -170,11 +169,22 @@ struct ffx_comm {
   void* ctl_host = nullptr;  // page-locked mirror
   float* stage_dev = nullptr;  // ffx_comm_exchange_host over RCCL: device staging, grown as needed and kept
   size_t stage_cap = 0;        // (floats)
+  // The ROUTING lane (ffx_sharded_stage_owned): candidate ids of batch i+1 travel from the ranks that own its queries to
+  // the ranks that hold the rows while batch i is being scored.  The score exchange of batch i is queued on `stream`
+  // BEHIND batch i's gather_dot (an event wait), so anything queued on that stream afterwards would wait too; the
+  // routing traffic therefore has a stream of its own and, over RCCL, a communicator of its own (operations of one
+  // communicator execute in issue order).  Created on first use (collective).
+  ncclComm_t nccl_route = nullptr;
+  hipStream_t route_stream = nullptr;
   // rehearsal: what stands in for the peers' memory -- a zeroed source the "received" slices come out of and a sink
   // the "sent" slices go into (floats each, grown as needed)
   float* reh_src = nullptr;
   float* reh_sink = nullptr;
   size_t reh_cap = 0;
+  // rehearsal of the routing lane: what the peers WOULD have sent (made by the caller, who knows the whole batch),
+  // consumed piece by piece by the exchanges of that lane; zeros once it is used up (ffx_comm_rehearsal_inbox)
+  const uint32_t* inbox = nullptr;
+  size_t inbox_words = 0, inbox_at = 0;
   // shared memory
   std::string name;
   ShmHeader* hdr = nullptr;
@@ -306,6 +316,8 @@ void destroy_comm(ffx_comm* c) {
   if (!c) return;
   if (c->device >= 0) (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->route_stream) (void)hipStreamSynchronize(c->route_stream);
+  if (c->nccl_route) (void)rccl()->CommDestroy(c->nccl_route);
   if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
   if (c->ctl_dev) (void)hipFree(c->ctl_dev);
   if (c->ctl_host) (void)hipHostFree(c->ctl_host);
@@ -318,6 +330,7 @@ void destroy_comm(ffx_comm* c) {
     // (rank 0 unlinked the header's name right after start-up, when everybody had attached)
     munmap(c->hdr, c->hdr_bytes);
   }
+  if (c->route_stream) (void)hipStreamDestroy(c->route_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -503,44 +516,77 @@ int ffx_comm_allreduce_f64(ffx_comm* c, double* inout, int32_t n, int op) {
   return FFX_OK;
 }
 
-static int check_counts(const ffx_comm* c, const int64_t* send_counts, const int64_t* recv_counts, int64_t* n_send, int64_t* n_recv) {
-  if (!send_counts || !recv_counts) return ffx_fail(FFX_BAD_ARG, "counts are NULL");
+// ---- the all-to-all-v underneath every exchange ----------------------------------------------------------------------
+// One piece per peer, in 4-byte words (fp32 scores, int32 candidate ordinals, per-query counts, query vectors: nothing is
+// ever reduced on the way, so the word is the unit): what this rank sends to the peer and what it receives from it.
+// Two lanes: 0 = the score exchange (communicator's stream), 1 = the routing lane (its own stream and, over RCCL, its
+// own communicator: see ffx_comm).
+struct Piece {
+  const void* send = nullptr;
+  int64_t n_send = 0;
+  void* recv = nullptr;
+  int64_t n_recv = 0;
+};
+
+static int check_pieces(const ffx_comm* c, const Piece* pc, int64_t* n_send, int64_t* n_recv) {
   *n_send = *n_recv = 0;
   for (int r = 0; r < c->world; ++r) {
-    if (send_counts[r] < 0 || recv_counts[r] < 0) return ffx_fail(FFX_BAD_ARG, "negative count for peer %d", r);
-    *n_send += send_counts[r];
-    *n_recv += recv_counts[r];
+    if (pc[r].n_send < 0 || pc[r].n_recv < 0) return ffx_fail(FFX_BAD_ARG, "negative count for peer %d", r);
+    if ((pc[r].n_send > 0 && !pc[r].send) || (pc[r].n_recv > 0 && !pc[r].recv)) return ffx_fail(FFX_BAD_ARG, "NULL buffer for peer %d", r);
+    *n_send += pc[r].n_send;
+    *n_recv += pc[r].n_recv;
   }
-  if (send_counts[c->rank] != recv_counts[c->rank]) return ffx_fail(FFX_BAD_ARG, "a rank sends itself %lld and expects %lld", (long long)send_counts[c->rank], (long long)recv_counts[c->rank]);
+  if (pc[c->rank].n_send != pc[c->rank].n_recv)
+    return ffx_fail(FFX_BAD_ARG, "a rank sends itself %lld and expects %lld", (long long)pc[c->rank].n_send, (long long)pc[c->rank].n_recv);
   return FFX_OK;
 }
 
-// host transport: publish the send buffer, then pull this rank's slice out of every peer's segment.
-// `device`: buffers are device pointers (copies ordered on `st`); else plain host memory.
+static int check_counts(const ffx_comm* c, const int64_t* send_counts, const int64_t* recv_counts) {
+  if (!send_counts || !recv_counts) return ffx_fail(FFX_BAD_ARG, "counts are NULL");
+  return FFX_OK;
+}
+
+// contiguous buffers with the slices in rank order (the public form) -> pieces
+static void pieces_of(const ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts, Piece* pc) {
+  int64_t s_at = 0, r_at = 0;
+  for (int r = 0; r < c->world; ++r) {
+    pc[r].send = send ? send + s_at : nullptr;
+    pc[r].n_send = send_counts[r];
+    pc[r].recv = recv ? recv + r_at : nullptr;
+    pc[r].n_recv = recv_counts[r];
+    s_at += send_counts[r];
+    r_at += recv_counts[r];
+  }
+}
+
+// host transport: publish what this rank sends (packed in rank order into its segment), then pull this rank's piece out
+// of every peer's segment.  `device`: the pieces are device pointers (copies ordered on `st`); else plain host memory.
 // Once this rank's counts are published, EVERY failure marks the communicator failed before returning, so that
 // the peers waiting at a barrier fail promptly instead of spinning out their timeout.
-static int shm_exchange_body(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts,
-                             bool device, hipStream_t st) {
+static int shm_exchange_body(ffx_comm* c, const Piece* pc, bool device, hipStream_t st) {
   int64_t n_send = 0, n_recv = 0;
-  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
-  C_TRY(shm_own_segment(c, (size_t)n_send * sizeof(float)));
+  C_TRY(check_pieces(c, pc, &n_send, &n_recv));
+  C_TRY(shm_own_segment(c, (size_t)n_send * 4));
   ShmSlot& mine = c->hdr->slot[c->rank];
-  for (int r = 0; r < c->world; ++r) mine.counts[r] = send_counts[r];
-  if (n_send > 0) {
-    if (device) {
-      C_HIP(hipMemcpyAsync(c->seg[c->rank].p, send, (size_t)n_send * sizeof(float), hipMemcpyDeviceToHost, st));
-      C_HIP(hipStreamSynchronize(st));
-    } else {
-      memcpy(c->seg[c->rank].p, send, (size_t)n_send * sizeof(float));
-    }
-  }
-  C_TRY(shm_barrier(c));  // every send segment is complete
+  for (int r = 0; r < c->world; ++r) mine.counts[r] = pc[r].n_send;
   int64_t at = 0;
   for (int r = 0; r < c->world; ++r) {
+    if (pc[r].n_send > 0) {
+      char* dst = static_cast<char*>(c->seg[c->rank].p) + (size_t)at * 4;
+      if (device)
+        C_HIP(hipMemcpyAsync(dst, pc[r].send, (size_t)pc[r].n_send * 4, hipMemcpyDeviceToHost, st));
+      else
+        memcpy(dst, pc[r].send, (size_t)pc[r].n_send * 4);
+    }
+    at += pc[r].n_send;
+  }
+  if (device && n_send > 0) C_HIP(hipStreamSynchronize(st));
+  C_TRY(shm_barrier(c));  // every send segment is complete
+  for (int r = 0; r < c->world; ++r) {
     const ShmSlot& peer = c->hdr->slot[r];
-    if (peer.counts[c->rank] != recv_counts[r])
-      return ffx_fail(FFX_BAD_ARG, "rank %d sends %lld scores to rank %d, which expects %lld", r, (long long)peer.counts[c->rank], c->rank, (long long)recv_counts[r]);
-    if (recv_counts[r] > 0) {
+    if (peer.counts[c->rank] != pc[r].n_recv)
+      return ffx_fail(FFX_BAD_ARG, "rank %d sends %lld words to rank %d, which expects %lld", r, (long long)peer.counts[c->rank], c->rank, (long long)pc[r].n_recv);
+    if (pc[r].n_recv > 0) {
       C_TRY(shm_peer_segment(c, r));
       int64_t off = 0;
       for (int i = 0; i < c->rank; ++i) {
@@ -548,52 +594,77 @@ static int shm_exchange_body(ffx_comm* c, const float* send, const int64_t* send
         off += peer.counts[i];
       }
       // what the peer claims to send must lie inside the segment this rank mapped (counts come from shared memory)
-      if (r != c->rank && ((uint64_t)off + (uint64_t)recv_counts[r]) * sizeof(float) > c->seg[r].bytes)
-        return ffx_fail(FFX_RCCL_ERROR, "host transport: rank %d's slice for rank %d lies outside its %zu-byte segment", r, c->rank, c->seg[r].bytes);
-      const float* src = static_cast<const float*>(c->seg[r].p) + off;
-      const size_t bytes = (size_t)recv_counts[r] * sizeof(float);
+      if (r != c->rank && ((uint64_t)off + (uint64_t)pc[r].n_recv) * 4 > c->seg[r].bytes)
+        return ffx_fail(FFX_RCCL_ERROR, "host transport: rank %d's piece for rank %d lies outside its %zu-byte segment", r, c->rank, c->seg[r].bytes);
+      const char* src = static_cast<const char*>(c->seg[r].p) + (size_t)off * 4;
+      const size_t bytes = (size_t)pc[r].n_recv * 4;
       if (device)
-        C_HIP(hipMemcpyAsync(recv + at, src, bytes, hipMemcpyHostToDevice, st));
+        C_HIP(hipMemcpyAsync(pc[r].recv, src, bytes, hipMemcpyHostToDevice, st));
       else
-        memcpy(recv + at, src, bytes);
+        memcpy(pc[r].recv, src, bytes);
     }
-    at += recv_counts[r];
   }
   if (device) C_HIP(hipStreamSynchronize(st));
   return shm_barrier(c);  // every rank has read: the segments may be overwritten
 }
 
-static int shm_exchange(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts,
-                        bool device, hipStream_t st) {
-  const int rc = shm_exchange_body(c, send, send_counts, recv, recv_counts, device, st);
+static int shm_exchange(ffx_comm* c, const Piece* pc, bool device, hipStream_t st) {
+  const int rc = shm_exchange_body(c, pc, device, st);
   if (rc != FFX_OK) c->hdr->failed.store(1);
   return rc;
 }
 
-// rehearsal: the bytes of one exchange through this GPU's memory in ONE kernel (RCCL groups its sends and receives
-// into one kernel on a handful of workgroups too): piece i copies n[i] floats from src[i] to dst[i]
+// rehearsal: the bytes of one exchange through this GPU's memory: piece i copies n[i] words from src[i] to dst[i]
 struct RehearsalPieces {
-  const float* src[2 * kMaxWorld];
-  float* dst[2 * kMaxWorld];
+  const uint32_t* src[2 * kMaxWorld];
+  uint32_t* dst[2 * kMaxWorld];
   long n[2 * kMaxWorld];
   int count;
+  // paced form: ns per KiB of a piece (what a link would need for it), and a flag word to poll while waiting
+  float ns_per_kib;
+  const uint32_t* flag;
 };
 
+// ONE kernel on a handful of workgroups (RCCL groups its sends and receives into one kernel on a handful of workgroups too)
 __global__ void __launch_bounds__(256) rehearsal_exchange_kernel(RehearsalPieces pc) {
   for (int i = 0; i < pc.count; ++i) {
-    const float* __restrict__ s = pc.src[i];
-    float* __restrict__ d = pc.dst[i];
+    const uint32_t* __restrict__ s = pc.src[i];
+    uint32_t* __restrict__ d = pc.dst[i];
     const long n = pc.n[i];
-    // slices start at arbitrary float offsets: scalar head up to 16-byte alignment of the destination is not worth it
+    // pieces start at arbitrary word offsets: scalar head up to 16-byte alignment of the destination is not worth it
     // for a stand-in; 4-byte accesses, fully coalesced
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) d[e] = s[e];
   }
 }
 
-static int rehearsal_exchange(ffx_comm* c, const float* send_dev, const int64_t* send_counts, float* recv_dev, const int64_t* recv_counts,
-                              hipStream_t st) {
+// The harsher stand-in (FFX_DEBUG_VARIANT=rehearsal_paced[=GB/s per link]): what RCCL's send/recv kernel looks like to
+// its neighbours -- ONE PERSISTENT workgroup per peer and direction (2 (N - 1) workgroups of 256 threads), each moving
+// its piece in 64 KiB chunks and, between chunks, SPINNING on a flag in memory until the chunk "would have arrived" over
+// a link of the given rate (default 50 GB/s, a third of an xGMI link's peak).  The workgroups therefore hold their CU
+// slots and keep issuing polls for as long as the fabric would take, next to whatever the compute stream runs.
+__global__ void __launch_bounds__(256) rehearsal_exchange_paced_kernel(RehearsalPieces pc) {
+  const int i = blockIdx.x;
+  if (i >= pc.count) return;
+  const uint32_t* __restrict__ s = pc.src[i];
+  uint32_t* __restrict__ d = pc.dst[i];
+  const long n = pc.n[i];
+  constexpr long kChunk = 16384;  // words = 64 KiB
+  const long long t0 = wall_clock64();  // 100 MHz
+  long done = 0;
+  while (done < n) {
+    const long m = n - done < kChunk ? n - done : kChunk;
+    for (long e = threadIdx.x; e < m; e += blockDim.x) d[done + e] = s[done + e];
+    done += m;
+    const long long due = t0 + (long long)((float)(done >> 8) * pc.ns_per_kib * 0.1f);  // ticks of 10 ns
+    unsigned int seen = 0;
+    while (wall_clock64() < due) seen += __builtin_nontemporal_load(pc.flag);  // poll memory, as a receiver waiting for its peer does
+    if (seen == 0xFFFFFFFFu && threadIdx.x == 0) d[0] = s[0];  // (never: keeps the polls alive)
+  }
+}
+
+static int rehearsal_exchange(ffx_comm* c, int lane, const Piece* pc, hipStream_t st) {
   int64_t n_send = 0, n_recv = 0;
-  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
+  C_TRY(check_pieces(c, pc, &n_send, &n_recv));
   const size_t need = (size_t)std::max<int64_t>(std::max(n_send, n_recv), 1);
   if (need > c->reh_cap) {
     C_HIP(hipStreamSynchronize(st));
@@ -607,42 +678,136 @@ static int rehearsal_exchange(ffx_comm* c, const float* send_dev, const int64_t*
     C_HIP(hipMemset(c->reh_src, 0, want * sizeof(float)));
     c->reh_cap = want;
   }
-  RehearsalPieces pc;
-  pc.count = 0;
+  RehearsalPieces k;
+  k.count = 0;
   int64_t s_at = 0, r_at = 0;
   for (int p = 0; p < c->world; ++p) {
-    if (p == c->rank) {  // exactly what the RCCL path does with the slice a rank keeps
-      if (send_counts[p] > 0)
-        C_HIP(hipMemcpyAsync(recv_dev + r_at, send_dev + s_at, (size_t)send_counts[p] * sizeof(float), hipMemcpyDeviceToDevice, st));
-    } else {
-      if (send_counts[p] > 0) {  // what peer p would read out of this GPU
-        pc.src[pc.count] = send_dev + s_at;
-        pc.dst[pc.count] = c->reh_sink + s_at;
-        pc.n[pc.count++] = (long)send_counts[p];
-      }
-      if (recv_counts[p] > 0) {  // what peer p would write into this GPU (zeros: it does not exist)
-        pc.src[pc.count] = c->reh_src + r_at;
-        pc.dst[pc.count] = recv_dev + r_at;
-        pc.n[pc.count++] = (long)recv_counts[p];
-      }
+    if (p == c->rank) {  // exactly what the RCCL path does with the piece a rank keeps
+      if (pc[p].n_send > 0 && pc[p].recv != pc[p].send)
+        C_HIP(hipMemcpyAsync(pc[p].recv, pc[p].send, (size_t)pc[p].n_send * 4, hipMemcpyDeviceToDevice, st));
+      continue;
     }
-    s_at += send_counts[p];
-    r_at += recv_counts[p];
+    if (pc[p].n_send > 0) {  // what peer p would read out of this GPU
+      k.src[k.count] = static_cast<const uint32_t*>(pc[p].send);
+      k.dst[k.count] = reinterpret_cast<uint32_t*>(c->reh_sink) + s_at;
+      k.n[k.count++] = (long)pc[p].n_send;
+      s_at += pc[p].n_send;
+    }
+    if (pc[p].n_recv > 0) {  // what peer p would write into this GPU: out of the inbox (routing lane), else zeros
+      const uint32_t* from = reinterpret_cast<const uint32_t*>(c->reh_src) + r_at;
+      if (lane == 1 && c->inbox && c->inbox_at + (size_t)pc[p].n_recv <= c->inbox_words) {
+        from = c->inbox + c->inbox_at;
+        c->inbox_at += (size_t)pc[p].n_recv;
+      }
+      k.src[k.count] = from;
+      k.dst[k.count] = static_cast<uint32_t*>(pc[p].recv);
+      k.n[k.count++] = (long)pc[p].n_recv;
+      r_at += pc[p].n_recv;
+    }
   }
-  if (pc.count > 0) {
-    rehearsal_exchange_kernel<<<16, 256, 0, st>>>(pc);
+  if (k.count > 0) {
+    long long gbs = 50;
+    if (ffx_debug_variant("rehearsal_paced", &gbs)) {
+      k.ns_per_kib = 1024.0f / (float)std::max<long long>(gbs, 1);  // 1 KiB at g GB/s = 1024 / g ns
+      k.flag = reinterpret_cast<const uint32_t*>(c->reh_src);
+      rehearsal_exchange_paced_kernel<<<k.count, 256, 0, st>>>(k);
+    } else {
+      k.ns_per_kib = 0.0f;
+      k.flag = nullptr;
+      rehearsal_exchange_kernel<<<16, 256, 0, st>>>(k);
+    }
     C_HIP(hipGetLastError());
   }
   return FFX_OK;
 }
 
+// The routing lane, on first use (collective): a stream of its own and, over RCCL with peers, a second communicator whose
+// id travels from rank 0 to the others through the first one.
+static int comm_route_lane(ffx_comm* c) {
+  if (c->route_stream || c->device < 0) return FFX_OK;
+  C_HIP(hipSetDevice(c->device));
+  hipStream_t st = nullptr;
+  if (ffx_debug_variant("route_high_priority", nullptr)) {
+    int least = 0, greatest = 0;
+    C_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    C_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+  } else {
+    C_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
+  if (c->transport == FFX_COMM_RCCL && c->world > 1) {
+    Rccl* r = rccl();
+    ncclUniqueId uid;
+    memset(&uid, 0, sizeof uid);
+    int rc = FFX_OK;
+    if (c->rank == 0 && r->GetUniqueId(&uid) != ncclSuccess) rc = ffx_fail(FFX_RCCL_ERROR, "ncclGetUniqueId failed for the routing lane");
+    std::vector<char> all(sizeof uid * (size_t)c->world);
+    if (rc == FFX_OK) rc = rccl_allgather_small(c, &uid, sizeof uid, all.data());
+    if (rc == FFX_OK) {
+      memcpy(&uid, all.data(), sizeof uid);  // rank 0's
+      const ncclResult_t nr = r->CommInitRank(&c->nccl_route, c->world, uid, c->rank);
+      if (nr != ncclSuccess) {
+        c->nccl_route = nullptr;
+        rc = ffx_fail(FFX_RCCL_ERROR, "ncclCommInitRank for the routing lane (rank %d of %d): %s", c->rank, c->world, r->GetErrorString(nr));
+      }
+    }
+    if (rc != FFX_OK) {
+      (void)hipStreamDestroy(st);
+      return rc;
+    }
+  }
+  c->route_stream = st;
+  return FFX_OK;
+}
+
+// all-to-all-v of 4-byte words between DEVICE buffers on lane 0 / 1.  RCCL: asynchronous on `st`; host transport: blocks
+// until the words have arrived.
+static int comm_alltoallv(ffx_comm* c, int lane, const Piece* pc, hipStream_t st) {
+  if (c->device < 0) return ffx_fail(FFX_BAD_ARG, "this communicator has no device: use ffx_comm_exchange_host");
+  C_HIP(hipSetDevice(c->device));
+  if (c->transport == FFX_COMM_HOST) return shm_exchange(c, pc, true, st);
+  if (c->transport == FFX_COMM_REHEARSAL) return rehearsal_exchange(c, lane, pc, st);
+  int64_t n_send = 0, n_recv = 0;
+  C_TRY(check_pieces(c, pc, &n_send, &n_recv));
+  // full mesh: one send and one receive per peer inside one group; the piece a rank keeps is a
+  // device copy.  Zero-length pieces are skipped on both sides (the counts are symmetric by
+  // construction: n_send for peer j here == n_recv for this rank on j).
+  Rccl* r = rccl();
+  ncclComm_t nc = lane == 0 ? c->nccl : c->nccl_route;
+  bool grouped = false;
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) {
+      if (pc[p].n_send > 0 && pc[p].recv != pc[p].send)
+        C_HIP(hipMemcpyAsync(pc[p].recv, pc[p].send, (size_t)pc[p].n_send * 4, hipMemcpyDeviceToDevice, st));
+    } else if (pc[p].n_send > 0 || pc[p].n_recv > 0) {
+      if (!nc) return ffx_fail(FFX_RCCL_ERROR, "lane %d of the communicator has not been brought up", lane);
+      if (!grouped) {
+        C_NCCL(r->GroupStart());
+        grouped = true;
+      }
+      if (pc[p].n_send > 0) C_NCCL(r->Send(pc[p].send, (size_t)pc[p].n_send, ncclInt32, p, nc, st));
+      if (pc[p].n_recv > 0) C_NCCL(r->Recv(pc[p].recv, (size_t)pc[p].n_recv, ncclInt32, p, nc, st));
+    }
+  }
+  if (grouped) C_NCCL(r->GroupEnd());
+  return FFX_OK;
+}
+
 int ffx_comm_exchange_host(ffx_comm* c, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts) {
   if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
-  if (c->transport == FFX_COMM_HOST) return shm_exchange(c, send, send_counts, recv, recv_counts, false, nullptr);
+  C_TRY(check_counts(c, send_counts, recv_counts));
+  Piece pc[kMaxWorld];
+  if (c->transport == FFX_COMM_HOST) {
+    pieces_of(c, send, send_counts, recv, recv_counts, pc);
+    return shm_exchange(c, pc, false, nullptr);
+  }
   // RCCL: the same all-to-all-v, staged through device scratch kept with the communicator (a streamed index
   // produces its local scores on the host: they are PCIe-bound already)
   int64_t n_send = 0, n_recv = 0;
-  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
+  for (int r = 0; r < c->world; ++r) {
+    if (send_counts[r] < 0 || recv_counts[r] < 0) return ffx_fail(FFX_BAD_ARG, "negative count for peer %d", r);
+    n_send += send_counts[r];
+    n_recv += recv_counts[r];
+  }
   C_HIP(hipSetDevice(c->device));
   const size_t need = (size_t)std::max<int64_t>(n_send + n_recv, 1);
   if (need > c->stage_cap) {
@@ -667,35 +832,20 @@ int ffx_comm_exchange(ffx_comm* c, const float* send_dev, const int64_t* send_co
                       void* stream) {
   if (!c) return ffx_fail(FFX_BAD_ARG, "NULL comm");
   if (c->device < 0) return ffx_fail(FFX_BAD_ARG, "this communicator has no device: use ffx_comm_exchange_host");
-  C_HIP(hipSetDevice(c->device));
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  if (c->transport == FFX_COMM_HOST) return shm_exchange(c, send_dev, send_counts, recv_dev, recv_counts, true, st);
-  if (c->transport == FFX_COMM_REHEARSAL) return rehearsal_exchange(c, send_dev, send_counts, recv_dev, recv_counts, st);
-  int64_t n_send = 0, n_recv = 0;
-  C_TRY(check_counts(c, send_counts, recv_counts, &n_send, &n_recv));
-  if ((n_send > 0 && !send_dev) || (n_recv > 0 && !recv_dev)) return ffx_fail(FFX_BAD_ARG, "NULL buffer");
-  // full mesh: one send and one receive per peer inside one group; the slice a rank keeps is a
-  // device copy.  Zero-length slices are skipped on both sides (the counts are symmetric by
-  // construction: send_counts[j] here == recv_counts[me] on j).
-  Rccl* r = rccl();
-  int64_t s_at = 0, r_at = 0;
-  bool grouped = false;
-  for (int p = 0; p < c->world; ++p) {
-    if (p == c->rank) {
-      if (send_counts[p] > 0)
-        C_HIP(hipMemcpyAsync(recv_dev + r_at, send_dev + s_at, (size_t)send_counts[p] * sizeof(float), hipMemcpyDeviceToDevice, st));
-    } else if (send_counts[p] > 0 || recv_counts[p] > 0) {
-      if (!grouped) {
-        C_NCCL(r->GroupStart());
-        grouped = true;
-      }
-      if (send_counts[p] > 0) C_NCCL(r->Send(send_dev + s_at, (size_t)send_counts[p], ncclFloat, p, c->nccl, st));
-      if (recv_counts[p] > 0) C_NCCL(r->Recv(recv_dev + r_at, (size_t)recv_counts[p], ncclFloat, p, c->nccl, st));
-    }
-    s_at += send_counts[p];
-    r_at += recv_counts[p];
-  }
-  if (grouped) C_NCCL(r->GroupEnd());
+  C_TRY(check_counts(c, send_counts, recv_counts));
+  Piece pc[kMaxWorld];
+  pieces_of(c, send_dev, send_counts, recv_dev, recv_counts, pc);
+  return comm_alltoallv(c, 0, pc, stream ? (hipStream_t)stream : c->stream);
+}
+
+// rehearsal only: what the peers would send on the routing lane from now on (n_words 4-byte words of DEVICE memory the
+// caller keeps alive; NULL: zeros again).  The exchanges of that lane take their received pieces from it, front to back.
+int ffx_comm_rehearsal_inbox(ffx_comm* c, const void* dev_words, int64_t n_words) {
+  if (!c || n_words < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (c->transport != FFX_COMM_REHEARSAL) return ffx_fail(FFX_BAD_ARG, "only the rehearsal transport has an inbox");
+  c->inbox = static_cast<const uint32_t*>(dev_words);
+  c->inbox_words = dev_words ? (size_t)n_words : 0;
+  c->inbox_at = 0;
   return FFX_OK;
 }
 
@@ -836,28 +986,52 @@ int ffx_route(const int64_t* pair_off, int64_t n_queries, const int32_t* pair_id
 }  // extern "C"
 
 // ---- one rank of a row-sharded index: local gather_dot + exchange + owner merge ------------------------
+// A batch lives in a SLOT: the plan that scores this rank's share of it, the merge that holds the owner-side state of
+// the queries this rank owns, and the buffer their scores arrive in.  Three slots rotate when every batch is new
+// (ffx_sharded_stage_owned): while batch i is scored, batch i-1 is exchanged and then merged BEHIND batch i's
+// gather_dot, and batch i+1 is routed into the third slot.  A batch that is set once and re-run (ffx_sharded_set_pairs)
+// sits in slots 0 and 1, which alternate as send buffers and share one merge.
+constexpr int kSlots = 3;
+
 struct ffx_sharded {
   ffx_index* shard = nullptr;
   ffx_comm* comm = nullptr;
   int device = 0;
   std::vector<int64_t> doc_bounds;
-  ffx_plan* plans[2] = {nullptr, nullptr};
-  ffx_merge* merge = nullptr;
+  ffx_plan* plans[kSlots] = {nullptr, nullptr, nullptr};
+  ffx_merge* merges[kSlots] = {nullptr, nullptr, nullptr};
   hipStream_t compute = nullptr;
-  hipEvent_t scored[2] = {nullptr, nullptr}, sent[2] = {nullptr, nullptr}, merged = nullptr;
-  hipEvent_t x_begin = nullptr, x_end = nullptr, m_begin = nullptr;  // timing of the last step's exchange and merge
-  bool sent_valid[2] = {false, false};
-  float* send_dev[2] = {nullptr, nullptr};
-  // scores arriving for the owned queries: one buffer per plan, because the exchange of batch i runs (on the
-  // communicator's stream) while batch i-1 is still being merged out of the other one (on the compute stream)
-  void* recv[2] = {nullptr, nullptr};
-  size_t recv_cap = 0;
+  hipStream_t out = nullptr;  // downloads of finished batches (ffx_sharded_fetch_async), created on first use
+  hipEvent_t x_begin = nullptr, x_end = nullptr, m_begin = nullptr, m_end = nullptr;  // timing of the last step's exchange and merge
+  hipEvent_t r_begin = nullptr, r_end = nullptr;                                      // ... and of the last batch's routing
+  struct Slot {
+    // scores arriving for the owned queries: one buffer per slot, because the exchange of batch i runs (on the
+    // communicator's stream) while batch i-1 is still being merged out of another one (on the compute stream)
+    void* recv = nullptr;
+    size_t recv_cap = 0;
+    std::vector<int64_t> send_counts, recv_counts;  // of the score exchange
+    int64_t own[4] = {0, 0, 0, 0};                  // first owned query, one past the last, first owned pair, owned pairs
+    int64_t local_pairs = 0;
+    bool have_sparse = false;
+    float* send_dev = nullptr;
+    int merge = 0;  // the merge that holds this batch's owner-side state
+    // ordering between the streams (no timing): the batch is routed / scored / its scores have left / it is merged
+    hipEvent_t routed = nullptr, scored = nullptr, sent = nullptr, merged = nullptr;
+    bool routed_valid = false, scored_valid = false, sent_valid = false, merged_valid = false;
+  } slot[kSlots];
+  hipEvent_t out_done[kSlots] = {nullptr, nullptr, nullptr};  // per MERGE: its results have been copied out
+  bool out_valid[kSlots] = {false, false, false};
   // the batch whose exchange has been issued but whose owner-side merge has not (-1: none), with its arguments
   int pending = -1;
   double pending_alpha = 0.0;
   uint32_t pending_flags = 0;
+  int last_merged = -1;  // slot whose merge was queued last: what ffx_sharded_fetch[_async] hands out
+  bool fresh = false;    // the current batch came through ffx_sharded_stage_owned
+  int cur = 0;           // ... into this slot
+  uint64_t staged = 0;
+  // what the set-once form fills (then published to slots 0 and 1)
   std::vector<int64_t> send_counts, recv_counts;
-  // device-side routing (document-range shards): the batch's ids are uploaded once and everything else is derived
+  // device-side routing: the batch's ids are uploaded once and everything else is derived
   // in HBM; buffers grow as needed and are kept
   struct DevArr {
     void* p = nullptr;
@@ -885,32 +1059,56 @@ struct ffx_sharded {
     T* as() const { return static_cast<T*>(p); }
   };
   DevArr d_ids, d_off, d_who, d_cnt, d_local_off, d_local_ids, d_pos, d_keys, d_arrival, d_slot, d_small, d_tmp;
+  DevArr d_held, d_start, d_sendids, d_qcnt, d_verdict;  // owner-side routing (ffx_sharded_stage_owned)
+  void* host_small = nullptr;                            // page-locked read-back block of the staging
+  size_t host_small_cap = 0;
   // routing outputs, kept between calls (a fresh 140 MB array costs more in page faults than the routing itself)
   std::vector<int64_t> local_off;
-  std::vector<int32_t> local_ids, slot;
+  std::vector<int32_t> local_ids, slot_host;
   int64_t own[4] = {0, 0, 0, 0};
   int64_t local_pairs = 0;
   bool have_pairs = false, have_sparse = false;
   uint64_t runs = 0;
   int last = 0;
+  // per-batch intake of the owner-routed form, for the stats
+  int64_t stage_h2d_bytes = 0, stage_route_send_bytes = 0, stage_route_recv_bytes = 0;
+  double stage_host_ms = 0.0;
 };
 
 namespace {
 
-// what both routes end with: room for the scores the owned queries receive
+// room in a slot for the scores its owned queries receive
+int slot_recv_room(ffx_sharded* s, int i, int64_t own_pairs) {
+  ffx_sharded::Slot& sl = s->slot[i];
+  const size_t need = (size_t)std::max<int64_t>(own_pairs, 1) * sizeof(float);
+  if (need <= sl.recv_cap) return FFX_OK;
+  C_HIP(hipSetDevice(s->device));
+  if (sl.recv) C_HIP(hipFree(sl.recv));
+  sl.recv = nullptr;
+  sl.recv_cap = 0;
+  C_HIP(hipMalloc(&sl.recv, need + need / 8));
+  sl.recv_cap = need + need / 8;
+  return FFX_OK;
+}
+
+// what both routes of the set-once form end with: the batch sits in slots 0 and 1 (two plans alternating as send
+// buffers, one merge), with room for the scores the owned queries receive
 int sharded_finish_set(ffx_sharded* s, bool have_sparse) {
   s->have_sparse = have_sparse;
-  const size_t need = (size_t)std::max<int64_t>(s->own[3], 1) * sizeof(float);
-  if (need > s->recv_cap) {
-    C_HIP(hipSetDevice(s->device));
-    for (void*& r : s->recv) {
-      if (r) C_HIP(hipFree(r));
-      r = nullptr;
-    }
-    s->recv_cap = 0;
-    for (void*& r : s->recv) C_HIP(hipMalloc(&r, need + need / 8));
-    s->recv_cap = need + need / 8;
+  for (int i = 0; i < 2; ++i) {
+    ffx_sharded::Slot& sl = s->slot[i];
+    C_TRY(slot_recv_room(s, i, s->own[3]));
+    sl.send_counts = s->send_counts;
+    sl.recv_counts = s->recv_counts;
+    for (int k = 0; k < 4; ++k) sl.own[k] = s->own[k];
+    sl.local_pairs = s->local_pairs;
+    sl.have_sparse = have_sparse;
+    sl.merge = 0;
+    sl.routed_valid = sl.scored_valid = sl.sent_valid = sl.merged_valid = false;  // (sharded_set drained the streams)
   }
+  for (bool& v : s->out_valid) v = false;
+  s->fresh = false;
+  s->last_merged = -1;
   s->have_pairs = true;
   return FFX_OK;
 }
@@ -1112,11 +1310,11 @@ int sharded_route_on_device(ffx_sharded* s, const int64_t* pair_off, int64_t n_q
   for (int i = 0; i < 2; ++i) {
     void* p = nullptr;
     C_TRY(ffx_plan_device_ptr(s->plans[i], FFX_BUF_FF, &p, nullptr));
-    s->send_dev[i] = static_cast<float*>(p);
+    s->slot[i].send_dev = static_cast<float*>(p);
   }
   std::vector<int64_t> own_off((size_t)(q_hi - q_lo) + 1);
   for (int64_t q = q_lo; q <= q_hi; ++q) own_off[(size_t)(q - q_lo)] = pair_off[q] - lo;
-  C_TRY(ffx_merge_set_device(s->merge, own_off.data(), q_hi - q_lo, s->d_slot.as<int32_t>(), sparse ? sparse + lo : nullptr));
+  C_TRY(ffx_merge_set_device(s->merges[0], own_off.data(), q_hi - q_lo, s->d_slot.as<int32_t>(), sparse ? sparse + lo : nullptr));
   return FFX_OK;
 }
 
@@ -1147,7 +1345,7 @@ int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, cons
   ffx_query_partition(n_queries, world, qb.data());
   std::vector<int64_t>& local_off = s->local_off;
   std::vector<int32_t>& local_ids = s->local_ids;
-  std::vector<int32_t>& slot = s->slot;
+  std::vector<int32_t>& slot = s->slot_host;
   try {
     if (local_off.size() < (size_t)n_queries + 1) local_off.resize((size_t)n_queries + 1);
     if (local_ids.size() < (size_t)std::max<int64_t>(P, 1)) local_ids.resize((size_t)std::max<int64_t>(P, 1));
@@ -1178,13 +1376,395 @@ int sharded_set(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, cons
     C_TRY(rc);
     void* p = nullptr;
     C_TRY(ffx_plan_device_ptr(s->plans[i], FFX_BUF_FF, &p, nullptr));
-    s->send_dev[i] = static_cast<float*>(p);
+    s->slot[i].send_dev = static_cast<float*>(p);
   }
   const int64_t q_lo = s->own[0], q_hi = s->own[1], lo = s->own[2];
   std::vector<int64_t> own_off((size_t)(q_hi - q_lo) + 1);
   for (int64_t q = q_lo; q <= q_hi; ++q) own_off[(size_t)(q - q_lo)] = pair_off[q] - lo;
-  C_TRY(ffx_merge_set(s->merge, own_off.data(), q_hi - q_lo, slot.data(), sparse ? sparse + lo : nullptr));
+  C_TRY(ffx_merge_set(s->merges[0], own_off.data(), q_hi - q_lo, slot.data(), sparse ? sparse + lo : nullptr));
   return sharded_finish_set(s, sparse != nullptr);
+}
+
+// ---- owner-side routing: a FRESH batch taken in at 1/world of the cost per rank ------------------------------------------
+// The reference scores a new set of queries on every call (index/base.py:418-429, 445-459).  With one process per GPU
+// nobody holds "the batch": rank r is handed only the block of queries it OWNS (their candidate lists and first-stage
+// scores: ~P/world pairs), finds the holder of each of its candidates on the device, and the ids travel to the holders in
+// a first all-to-all on the communicator's routing lane; the holders score them and the scores come back as before.
+//   count    (a workgroup per owned query) how many of the query's candidates each rank holds: cnt[h][q]
+//   scan     cnt (holder-major) -> start[h][q]: where the (h, q) run begins in the holder-grouped list = the ARRIVAL
+//            ORDER of the scores (sources in rank order, queries ascending, first-stage order inside)
+//   place    (a workgroup per owned query) stable multi-way partition of the query's candidates by holder:
+//            slot[p] = arrival position of candidate p (what the owner-side merge reads), send_ids[slot[p]] = its
+//            ordinal on the holder
+//   exchange A  cnt[h][*] -> holder h: every rank learns how many candidates of EVERY query it holds (its local CSR offsets)
+//   exchange B  send_ids runs -> the holders, received straight into the scoring plan's candidate list: the messages of
+//            the owners in rank order ARE the local CSR (queries are owned in blocks, in rank order)
+//   exchange C  two words per peer: what went wrong, so that every rank leaves the call with the same verdict
+__device__ inline int route_holder_of(int64_t id, const RouteBounds& bounds, int world) {
+  if (id < bounds.b[0] || id >= bounds.b[world]) return -1;
+  int lo = 0, hi = world;  // the h with b[h] <= id < b[h+1] (empty ranges are skipped by construction)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (bounds.b[mid] <= id) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+own_count_kernel(const int64_t* __restrict__ own_off, const int32_t* __restrict__ ids, const int32_t* __restrict__ held, RouteBounds bounds, int world,
+                 int n_q, int32_t* __restrict__ cnt, unsigned long long* __restrict__ bad) {
+  __shared__ unsigned int hist[kMaxWorld];
+  const int q = blockIdx.x;
+  if (threadIdx.x < kMaxWorld) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t p = own_off[q] + threadIdx.x; p < own_off[q + 1]; p += blockDim.x) {
+    const int h = held ? held[p] : route_holder_of(ids[p], bounds, world);
+    if (h < 0 || h >= world)
+      atomicMin(bad, (unsigned long long)p);
+    else
+      atomicAdd(&hist[h], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < world) cnt[(size_t)threadIdx.x * n_q + q] = (int32_t)hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256)
+own_place_kernel(const int64_t* __restrict__ own_off, const int32_t* __restrict__ ids, const int32_t* __restrict__ held, RouteBounds bounds, int world,
+                 int n_q, const int32_t* __restrict__ start, int32_t* __restrict__ slot, int32_t* __restrict__ send_ids) {
+  __shared__ int run[kMaxWorld];
+  __shared__ int wave_cnt[4][kMaxWorld];
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < world) run[threadIdx.x] = start[(size_t)threadIdx.x * n_q + q];
+  const int64_t lo = own_off[q], hi = own_off[q + 1];
+  for (int64_t p0 = lo; p0 < hi; p0 += blockDim.x) {
+    for (int i = lane; i < world; i += 64) wave_cnt[wave][i] = 0;
+    const int64_t p = p0 + threadIdx.x;
+    int h = -1;
+    if (p < hi) h = held ? held[p] : route_holder_of(ids[p], bounds, world);
+    const bool valid = h >= 0 && h < world;  // (an id no rank holds was reported by the count pass and gets no slot)
+    // the distinct holders of this wave's 64 candidates, one at a time: rank of every candidate among its holder's
+    int before = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int hh = __shfl(h, leader, 64);
+      const unsigned long long same = __ballot(valid && h == hh);
+      if (valid && h == hh) before = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wave_cnt[wave][hh] = __popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (valid) {
+      int at = run[h] + before;
+      for (int w = 0; w < wave; ++w) at += wave_cnt[w][h];
+      slot[p] = at;
+      send_ids[at] = held ? ids[p] : (int32_t)((int64_t)ids[p] - bounds.b[h]);
+    } else if (p < hi) {
+      slot[p] = 0;  // never read: the call fails
+    }
+    __syncthreads();
+    if (threadIdx.x < world) run[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// small[1 + h] = how many of the owned candidates rank h holds (h < world)
+__global__ void own_totals_kernel(const int32_t* __restrict__ start, int world, int n_q, long long* __restrict__ small) {
+  const int h = threadIdx.x;
+  if (h < world) small[1 + h] = (long long)start[(size_t)(h + 1) * n_q] - (long long)start[(size_t)h * n_q];
+}
+
+struct WidenI32 {
+  __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
+};
+
+// One batch staged into slot (staged % kSlots): see above.  Collective; every rank leaves with the same status.
+int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_off, const int32_t* own_ids,
+                        const int32_t* own_holder, const float* own_sparse, int mode, int32_t order_base, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!s || !q_bounds || !own_off) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return ffx_fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  int rank = 0, world = 1;
+  ffx_comm_rank(s->comm, &rank, &world);
+  if (!own_holder && s->doc_bounds.empty()) return ffx_fail(FFX_BAD_ARG, "created without doc_bounds: the candidates need explicit holders");
+  if (q_bounds[0] != 0) return ffx_fail(FFX_BAD_ARG, "q_bounds[0] must be 0");
+  for (int r = 0; r < world; ++r)
+    if (q_bounds[r + 1] < q_bounds[r]) return ffx_fail(FFX_BAD_ARG, "q_bounds not monotone at rank %d", r);
+  const int64_t Q = q_bounds[world], q_lo = q_bounds[rank], Qo = q_bounds[rank + 1] - q_lo;
+  if (Q > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many queries");
+  if (own_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "own_pair_off[0] must be 0");
+  int64_t longest = 0;
+  for (int64_t q = 0; q < Qo; ++q) {
+    if (own_off[q + 1] < own_off[q]) return ffx_fail(FFX_BAD_ARG, "own_pair_off not monotone at query %lld", (long long)q);
+    longest = std::max(longest, own_off[q + 1] - own_off[q]);
+  }
+  const int64_t Po = own_off[Qo];
+  if (Po > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  if (Po > 0 && !own_ids) return ffx_fail(FFX_BAD_ARG, "own_pair_ids is NULL");
+  if ((int64_t)world * Qo > INT32_MAX - 2) return ffx_fail(FFX_BAD_ARG, "too many owned queries for %d ranks", world);
+  const auto t_begin = std::chrono::steady_clock::now();
+  C_TRY(comm_route_lane(s->comm));  // collective on first use
+  C_HIP(hipSetDevice(s->device));
+  hipStream_t rs = s->comm->route_stream;
+  if (!s->fresh) {  // coming from the set-once form: nothing of it may still be in flight
+    C_TRY(ffx_sharded_sync(s));
+    for (auto& sl : s->slot) sl.routed_valid = sl.scored_valid = sl.sent_valid = sl.merged_valid = false;
+    for (bool& v : s->out_valid) v = false;
+    s->last_merged = -1;
+  }
+  s->have_pairs = false;
+  const int t = (int)(s->staged % kSlots);
+  ffx_sharded::Slot& sl = s->slot[t];
+  // the batch that used this slot three stages ago: scored, its scores sent, merged, its results copied out
+  if (sl.scored_valid) C_HIP(hipStreamWaitEvent(rs, sl.scored, 0));
+  if (sl.sent_valid) C_HIP(hipStreamWaitEvent(rs, sl.sent, 0));
+  if (sl.merged_valid) C_HIP(hipStreamWaitEvent(rs, sl.merged, 0));
+  if (s->out_valid[t]) C_HIP(hipStreamWaitEvent(rs, s->out_done[t], 0));
+  if (s->pending == t) return ffx_fail(FFX_BAD_ARG, "three batches staged without a run in between");
+  const int qdim = [&] {
+    int32_t d = 0;
+    ffx_index_query_dim(s->shard, &d);
+    return (int)d;
+  }();
+  // room: the owner-side state goes straight into the slot's merge, the local lists straight into its plan
+  int64_t* m_off = nullptr;
+  int32_t* m_slot = nullptr;
+  float* m_sparse = nullptr;
+  C_TRY(ffx_merge_adopt_begin(s->merges[t], Qo, Po, own_sparse != nullptr, &m_off, &m_slot, &m_sparse));
+  float* d_q = nullptr;
+  if (own_queries) C_TRY(ffx_plan_queries_room(s->plans[t], Q, &d_q));
+  const size_t pb = (size_t)std::max<int64_t>(Po, 1), n_cnt = (size_t)world * (size_t)Qo + 1;
+  C_TRY(s->d_ids.ensure(pb * 4));
+  if (own_holder) C_TRY(s->d_held.ensure(pb * 4));
+  C_TRY(s->d_cnt.ensure(n_cnt * 4));
+  C_TRY(s->d_start.ensure(n_cnt * 4));
+  C_TRY(s->d_sendids.ensure(pb * 4));
+  C_TRY(s->d_qcnt.ensure(((size_t)Q + 1) * 4));
+  C_TRY(s->d_local_off.ensure(((size_t)Q + 1) * 8));
+  const size_t small_words = 1 + (size_t)kMaxWorld;
+  C_TRY(s->d_small.ensure(small_words * 8));
+  C_TRY(s->d_verdict.ensure(4 * (size_t)kMaxWorld * 4));
+  const size_t back_bytes = small_words * 8 + ((size_t)Q + 1) * 8 + 4 * (size_t)kMaxWorld * 4;
+  if (back_bytes > s->host_small_cap) {
+    if (s->host_small) (void)hipHostFree(s->host_small);
+    s->host_small = nullptr;
+    s->host_small_cap = 0;
+    C_HIP(hipHostMalloc(&s->host_small, back_bytes + back_bytes / 4, hipHostMallocDefault));
+    s->host_small_cap = back_bytes + back_bytes / 4;
+  }
+  long long* h_small = static_cast<long long*>(s->host_small);
+  int64_t* h_local_off = reinterpret_cast<int64_t*>(h_small + small_words);
+  int32_t* h_verdict = reinterpret_cast<int32_t*>(h_local_off + Q + 1);
+  unsigned long long* d_bad = s->d_small.as<unsigned long long>();
+  // uploads: this rank's block only
+  C_HIP(hipEventRecord(s->r_begin, rs));
+  C_HIP(hipMemcpyAsync(m_off, own_off, ((size_t)Qo + 1) * 8, hipMemcpyHostToDevice, rs));
+  int64_t h2d = (Qo + 1) * 8;
+  if (Po > 0) {
+    C_HIP(hipMemcpyAsync(s->d_ids.p, own_ids, (size_t)Po * 4, hipMemcpyHostToDevice, rs));
+    h2d += Po * 4;
+    if (own_holder) {
+      C_HIP(hipMemcpyAsync(s->d_held.p, own_holder, (size_t)Po * 4, hipMemcpyHostToDevice, rs));
+      h2d += Po * 4;
+    }
+    if (own_sparse) {
+      C_HIP(hipMemcpyAsync(m_sparse, own_sparse, (size_t)Po * 4, hipMemcpyHostToDevice, rs));
+      h2d += Po * 4;
+    }
+  }
+  if (own_queries && Qo > 0) {
+    C_HIP(hipMemcpyAsync(d_q + (size_t)q_lo * qdim, own_queries, (size_t)Qo * qdim * 4, hipMemcpyHostToDevice, rs));
+    h2d += Qo * (int64_t)qdim * 4;
+  }
+  C_HIP(hipMemsetAsync(d_bad, 0xFF, 8, rs));
+  C_HIP(hipMemsetAsync(s->d_cnt.as<int32_t>() + (n_cnt - 1), 0, 4, rs));
+  C_HIP(hipMemsetAsync(s->d_qcnt.as<int32_t>() + Q, 0, 4, rs));
+  RouteBounds bounds;
+  for (int r = 0; r <= world; ++r) bounds.b[r] = own_holder ? 0 : s->doc_bounds[(size_t)r];
+  const int32_t* d_held = own_holder ? s->d_held.as<int32_t>() : nullptr;
+  if (Qo > 0) {
+    own_count_kernel<<<(unsigned)Qo, 256, 0, rs>>>(m_off, s->d_ids.as<int32_t>(), d_held, bounds, world, (int)Qo, s->d_cnt.as<int32_t>(), d_bad);
+    C_HIP(hipGetLastError());
+  }
+  {
+    size_t tmp = 0;
+    C_HIP(rocprim::exclusive_scan(nullptr, tmp, s->d_cnt.as<int32_t>(), s->d_start.as<int32_t>(), (int32_t)0, n_cnt, rocprim::plus<int32_t>(), rs));
+    C_TRY(s->d_tmp.ensure(std::max<size_t>(tmp, 16)));
+    C_HIP(rocprim::exclusive_scan(s->d_tmp.p, tmp, s->d_cnt.as<int32_t>(), s->d_start.as<int32_t>(), (int32_t)0, n_cnt, rocprim::plus<int32_t>(), rs));
+  }
+  if (Qo > 0) {
+    own_place_kernel<<<(unsigned)Qo, 256, 0, rs>>>(m_off, s->d_ids.as<int32_t>(), d_held, bounds, world, (int)Qo, s->d_start.as<int32_t>(), m_slot,
+                                                    s->d_sendids.as<int32_t>());
+    C_HIP(hipGetLastError());
+  }
+  own_totals_kernel<<<1, kMaxWorld, 0, rs>>>(s->d_start.as<int32_t>(), world, (int)Qo, reinterpret_cast<long long*>(d_bad));
+  C_HIP(hipGetLastError());
+  Piece pc[kMaxWorld];
+  // exchange A: per-query counts to the holders
+  for (int r = 0; r < world; ++r) {
+    pc[r].send = s->d_cnt.as<int32_t>() + (size_t)r * Qo;
+    pc[r].n_send = Qo;
+    pc[r].recv = s->d_qcnt.as<int32_t>() + q_bounds[r];
+    pc[r].n_recv = q_bounds[r + 1] - q_bounds[r];
+  }
+  int64_t route_send = 0, route_recv = 0;
+  for (int r = 0; r < world; ++r)
+    if (r != rank) {
+      route_send += pc[r].n_send * 4;
+      route_recv += pc[r].n_recv * 4;
+    }
+  C_TRY(comm_alltoallv(s->comm, 1, pc, rs));
+  {
+    auto wide = rocprim::make_transform_iterator(s->d_qcnt.as<int32_t>(), WidenI32());
+    size_t tmp = 0;
+    C_HIP(rocprim::exclusive_scan(nullptr, tmp, wide, s->d_local_off.as<int64_t>(), (int64_t)0, (size_t)Q + 1, rocprim::plus<int64_t>(), rs));
+    C_TRY(s->d_tmp.ensure(std::max<size_t>(tmp, 16)));
+    C_HIP(rocprim::exclusive_scan(s->d_tmp.p, tmp, wide, s->d_local_off.as<int64_t>(), (int64_t)0, (size_t)Q + 1, rocprim::plus<int64_t>(), rs));
+  }
+  C_HIP(hipMemcpyAsync(h_small, s->d_small.p, small_words * 8, hipMemcpyDeviceToHost, rs));
+  C_HIP(hipMemcpyAsync(h_local_off, s->d_local_off.p, ((size_t)Q + 1) * 8, hipMemcpyDeviceToHost, rs));
+  // the query vectors of the whole batch, every rank contributing its block (nothing below depends on them)
+  if (own_queries && world > 1) {
+    Piece qp[kMaxWorld];
+    for (int r = 0; r < world; ++r) {
+      qp[r].send = d_q + (size_t)q_lo * qdim;
+      qp[r].n_send = Qo * qdim;
+      qp[r].recv = d_q + (size_t)q_bounds[r] * qdim;
+      qp[r].n_recv = (q_bounds[r + 1] - q_bounds[r]) * qdim;
+      if (r != rank) {
+        route_send += qp[r].n_send * 4;
+        route_recv += qp[r].n_recv * 4;
+      }
+    }
+    C_TRY(comm_alltoallv(s->comm, 1, qp, rs));
+  }
+  C_HIP(hipStreamSynchronize(rs));
+  const unsigned long long bad_own = (unsigned long long)h_small[0];
+  sl.send_counts.assign((size_t)world, 0);
+  sl.recv_counts.assign((size_t)world, 0);
+  for (int r = 0; r < world; ++r) {
+    sl.recv_counts[(size_t)r] = h_small[1 + r];                                         // scores coming back from holder r
+    sl.send_counts[(size_t)r] = h_local_off[q_bounds[r + 1]] - h_local_off[q_bounds[r]];  // scores going to owner r
+  }
+  sl.local_pairs = h_local_off[Q];
+  int status = FFX_OK;  // this rank's own trouble, told to the others in exchange C
+  int64_t bad_local = -1;
+  if (sl.local_pairs > INT32_MAX - 1) status = ffx_fail(FFX_BAD_ARG, "more than 2^31-2 candidates on one rank: split the queries");
+  // exchange B: the ordinals, received straight into the plan
+  int64_t* p_off = nullptr;
+  int32_t* p_ids = nullptr;
+  if (status == FFX_OK) status = ffx_plan_adopt_begin(s->plans[t], Q, sl.local_pairs, mode, &p_off, &p_ids);
+  if (status != FFX_OK) {  // still take part: the peers are sending
+    C_TRY(s->d_local_ids.ensure((size_t)std::max<int64_t>(std::min<int64_t>(sl.local_pairs, INT32_MAX), 1) * 4));
+    p_ids = s->d_local_ids.as<int32_t>();
+  } else {
+    C_HIP(hipMemcpyAsync(p_off, s->d_local_off.p, ((size_t)Q + 1) * 8, hipMemcpyDeviceToDevice, rs));
+  }
+  {
+    int64_t s_at = 0;
+    for (int r = 0; r < world; ++r) {
+      pc[r].send = s->d_sendids.as<int32_t>() + s_at;
+      pc[r].n_send = sl.recv_counts[(size_t)r];
+      pc[r].recv = p_ids + h_local_off[q_bounds[r]];
+      pc[r].n_recv = sl.send_counts[(size_t)r];
+      s_at += sl.recv_counts[(size_t)r];
+      if (r != rank) {
+        route_send += pc[r].n_send * 4;
+        route_recv += pc[r].n_recv * 4;
+      }
+    }
+    C_TRY(comm_alltoallv(s->comm, 1, pc, rs));
+  }
+  if (status == FFX_OK) status = ffx_plan_adopt_finish(s->plans[t], h_local_off, rs, &bad_local);  // validates on rs, waits for it
+  // exchange C, two words per peer, so that EVERY rank leaves with the same verdict:
+  //   [0] to owner r: the first of ITS ordinals that names no row here (position in its message; -1: none)
+  //   [1] to everybody: this rank's status -- 0 ok, 1 one of MY candidates is held by no rank, 3 somebody's ordinal names
+  //       no row here (the owner concerned finds its position in word 0), 2 anything else
+  std::string own_error;
+  if (status != FFX_OK) own_error = ffx_last_error();
+  int bad_owner = -1;
+  if (status == FFX_NOT_FOUND && bad_local >= 0)
+    for (int r = 0; r < world; ++r)
+      if (bad_local >= h_local_off[q_bounds[r]] && bad_local < h_local_off[q_bounds[r + 1]]) bad_owner = r;
+  const int my_status = bad_own != ~0ull ? 1 : status == FFX_OK ? 0 : bad_owner >= 0 ? 3 : 2;
+  for (int r = 0; r < world; ++r) {
+    h_verdict[2 * r] = r == bad_owner ? (int32_t)(bad_local - h_local_off[q_bounds[r]]) : -1;
+    h_verdict[2 * r + 1] = my_status;
+  }
+  int32_t* h_got = h_verdict + 2 * kMaxWorld;
+  if (world > 1) {
+    int32_t* d_v = s->d_verdict.as<int32_t>();
+    C_HIP(hipMemcpyAsync(d_v, h_verdict, (size_t)world * 8, hipMemcpyHostToDevice, rs));
+    for (int r = 0; r < world; ++r) {
+      pc[r].send = d_v + 2 * r;
+      pc[r].n_send = 2;
+      pc[r].recv = d_v + 2 * kMaxWorld + 2 * r;
+      pc[r].n_recv = 2;
+    }
+    C_TRY(comm_alltoallv(s->comm, 1, pc, rs));
+    C_HIP(hipMemcpyAsync(h_got, d_v + 2 * kMaxWorld, (size_t)world * 8, hipMemcpyDeviceToHost, rs));
+    C_HIP(hipStreamSynchronize(rs));
+    if (s->comm->transport == FFX_COMM_REHEARSAL)  // the words moved; the peers that would have written them do not exist
+      for (int r = 0; r < world; ++r)
+        if (r != rank) {
+          h_got[2 * r] = -1;
+          h_got[2 * r + 1] = 0;
+        }
+  } else {
+    h_got[0] = h_verdict[0];
+    h_got[1] = h_verdict[1];
+  }
+  s->stage_h2d_bytes = h2d;
+  s->stage_route_send_bytes = route_send;
+  s->stage_route_recv_bytes = route_recv;
+  if (bad_own != ~0ull) {
+    if (bad_pair) *bad_pair = (int64_t)bad_own;
+    return ffx_fail(FFX_NOT_FOUND, "pair %llu names a document no rank of the sharded index holds", bad_own);
+  }
+  for (int r = 0; r < world; ++r)
+    if (h_got[2 * r] >= 0) {  // holder r could not place one of THIS rank's candidates: which one?
+      int64_t at = h_got[2 * r];
+      for (int i = 0; i < r; ++i) at += sl.recv_counts[(size_t)i];
+      std::vector<int32_t> slots((size_t)Po);
+      C_HIP(hipMemcpy(slots.data(), m_slot, (size_t)Po * 4, hipMemcpyDeviceToHost));
+      int64_t found = -1;
+      for (int64_t p = 0; p < Po && found < 0; ++p)
+        if (slots[(size_t)p] == at) found = p;
+      if (bad_pair) *bad_pair = found;
+      return ffx_fail(FFX_NOT_FOUND, "pair %lld names an ordinal with no rows in the index (rank %d holds it)", (long long)found, r);
+    }
+  if (my_status == 2) return ffx_fail(status, "%s", own_error.c_str());
+  for (int r = 0; r < world; ++r) {
+    const int st = r == rank ? my_status : h_got[2 * r + 1];
+    if (st == 1 || st == 3) return ffx_fail(FFX_NOT_FOUND, "a candidate owned by another rank names an ordinal without rows (reported by rank %d)", r);
+    if (st != 0) return ffx_fail(FFX_RCCL_ERROR, "rank %d could not take the batch in", r);
+  }
+  C_TRY(ffx_merge_adopt_finish(s->merges[t], longest, order_base));
+  C_TRY(slot_recv_room(s, t, Po));
+  void* ffp = nullptr;
+  C_TRY(ffx_plan_device_ptr(s->plans[t], FFX_BUF_FF, &ffp, nullptr));
+  sl.send_dev = static_cast<float*>(ffp);
+  sl.own[0] = q_lo;
+  sl.own[1] = q_lo + Qo;
+  sl.own[2] = 0;
+  sl.own[3] = Po;
+  sl.have_sparse = own_sparse != nullptr;
+  sl.merge = t;
+  C_HIP(hipEventRecord(s->r_end, rs));
+  C_HIP(hipEventRecord(sl.routed, rs));
+  sl.routed_valid = true;
+  sl.scored_valid = sl.sent_valid = sl.merged_valid = false;
+  s->out_valid[t] = false;
+  for (int k = 0; k < 4; ++k) s->own[k] = sl.own[k];
+  s->local_pairs = sl.local_pairs;
+  s->have_sparse = sl.have_sparse;
+  s->fresh = true;
+  s->cur = t;
+  ++s->staged;
+  s->have_pairs = true;
+  s->stage_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return FFX_OK;
 }
 
 }  // namespace
@@ -1211,20 +1791,19 @@ int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_boun
   int rc = FFX_OK;
   hipError_t e = hipSetDevice(s->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking);
-  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-    e = hipEventCreateWithFlags(&s->scored[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->sent[i], hipEventDisableTiming);
+  for (int i = 0; i < kSlots && e == hipSuccess; ++i) {
+    for (hipEvent_t* ev : {&s->slot[i].routed, &s->slot[i].scored, &s->slot[i].sent, &s->slot[i].merged, &s->out_done[i]})
+      if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
   }
-  if (e == hipSuccess) e = hipEventCreate(&s->merged);
-  if (e == hipSuccess) e = hipEventCreate(&s->x_begin);
-  if (e == hipSuccess) e = hipEventCreate(&s->x_end);
-  if (e == hipSuccess) e = hipEventCreate(&s->m_begin);
+  for (hipEvent_t* ev : {&s->x_begin, &s->x_end, &s->m_begin, &s->m_end, &s->r_begin, &s->r_end})
+    if (e == hipSuccess) e = hipEventCreate(ev);
   if (e != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
-  for (int i = 0; i < 2 && rc == FFX_OK; ++i) {
-    rc = ffx_plan_create(shard, &s->plans[i]);
-    if (rc == FFX_OK) rc = ffx_plan_set_stream(s->plans[i], s->compute);
+  // the plans issue their work on the compute stream and own none (a process has few hardware queues: every stream
+  // that is created and never used still takes part in their assignment)
+  for (int i = 0; i < kSlots && rc == FFX_OK; ++i) {
+    rc = ffx_plan_create_on(shard, s->compute, &s->plans[i]);
+    if (rc == FFX_OK) rc = ffx_merge_create(s->device, &s->merges[i]);
   }
-  if (rc == FFX_OK) rc = ffx_merge_create(s->device, &s->merge);
   if (rc != FFX_OK) {
     ffx_sharded_destroy(s);
     return rc;
@@ -1238,22 +1817,24 @@ int ffx_sharded_destroy(ffx_sharded* s) {
   (void)hipSetDevice(s->device);
   if (s->compute) (void)hipStreamSynchronize(s->compute);
   if (s->comm && s->comm->stream) (void)hipStreamSynchronize(s->comm->stream);
+  if (s->comm && s->comm->route_stream) (void)hipStreamSynchronize(s->comm->route_stream);
+  if (s->out) (void)hipStreamSynchronize(s->out);
   for (auto* p : s->plans)
     if (p) ffx_plan_destroy(p);
-  if (s->merge) ffx_merge_destroy(s->merge);
+  for (auto* m : s->merges)
+    if (m) ffx_merge_destroy(m);
   for (auto* a : {&s->d_ids, &s->d_off, &s->d_who, &s->d_cnt, &s->d_local_off, &s->d_local_ids, &s->d_pos, &s->d_keys, &s->d_arrival, &s->d_slot,
-                  &s->d_small, &s->d_tmp})
+                  &s->d_small, &s->d_tmp, &s->d_held, &s->d_start, &s->d_sendids, &s->d_qcnt, &s->d_verdict})
     a->release();
-  for (int i = 0; i < 2; ++i) {
-    if (s->scored[i]) (void)hipEventDestroy(s->scored[i]);
-    if (s->sent[i]) (void)hipEventDestroy(s->sent[i]);
+  if (s->host_small) (void)hipHostFree(s->host_small);
+  for (int i = 0; i < kSlots; ++i) {
+    for (hipEvent_t ev : {s->slot[i].routed, s->slot[i].scored, s->slot[i].sent, s->slot[i].merged, s->out_done[i]})
+      if (ev) (void)hipEventDestroy(ev);
+    if (s->slot[i].recv) (void)hipFree(s->slot[i].recv);
   }
-  if (s->merged) (void)hipEventDestroy(s->merged);
-  if (s->x_begin) (void)hipEventDestroy(s->x_begin);
-  if (s->x_end) (void)hipEventDestroy(s->x_end);
-  if (s->m_begin) (void)hipEventDestroy(s->m_begin);
-  for (void* r : s->recv)
-    if (r) (void)hipFree(r);
+  for (hipEvent_t ev : {s->x_begin, s->x_end, s->m_begin, s->m_end, s->r_begin, s->r_end})
+    if (ev) (void)hipEventDestroy(ev);
+  if (s->out) (void)hipStreamDestroy(s->out);
   if (s->compute) (void)hipStreamDestroy(s->compute);
   delete s;
   return FFX_OK;
@@ -1278,45 +1859,60 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
   return sharded_set(s, pair_off, n_queries, local_ids, holder, sparse, mode, bad_pair);
 }
 
+int ffx_sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
+                            const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, int64_t* bad_pair) {
+  return sharded_stage_owned(s, q_bounds, own_queries, own_pair_off, own_pair_ids, own_holder, own_sparse, mode, 0, bad_pair);
+}
+
 // The owner-side half of batch `s->pending` (scatter to first-stage order, interpolation, per-query order) on the
 // COMPUTE stream, behind whatever has been queued there, once that batch's scores have arrived.
 static int sharded_merge_pending(ffx_sharded* s) {
   if (s->pending < 0) return FFX_OK;
   const int i = s->pending;
   s->pending = -1;
-  C_HIP(hipStreamWaitEvent(s->compute, s->sent[i], 0));
+  ffx_sharded::Slot& sl = s->slot[i];
+  C_HIP(hipStreamWaitEvent(s->compute, sl.sent, 0));
+  if (s->out_valid[sl.merge]) C_HIP(hipStreamWaitEvent(s->compute, s->out_done[sl.merge], 0));  // the results this merge held before have left
   C_HIP(hipEventRecord(s->m_begin, s->compute));
-  C_TRY(ffx_merge_run(s->merge, static_cast<const float*>(s->recv[i]), s->pending_alpha, s->pending_flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), s->compute));
-  C_HIP(hipEventRecord(s->merged, s->compute));
+  C_TRY(ffx_merge_run(s->merges[sl.merge], static_cast<const float*>(sl.recv), s->pending_alpha, s->pending_flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), s->compute));
+  C_HIP(hipEventRecord(s->m_end, s->compute));
+  C_HIP(hipEventRecord(sl.merged, s->compute));
+  sl.merged_valid = true;
+  s->last_merged = i;
   return FFX_OK;
 }
 
 int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags) {
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
-  if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_set_pairs has not succeeded on this handle");
+  if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "no batch has been set on this handle (ffx_sharded_set_pairs / ffx_sharded_stage_owned)");
   C_HIP(hipSetDevice(s->device));
-  const int i = (int)(s->runs & 1);
+  const int i = s->fresh ? s->cur : (int)(s->runs & 1);
   ++s->runs;
   s->last = i;
+  ffx_sharded::Slot& sl = s->slot[i];
   hipStream_t cs = s->comm->stream;
   // Everything that needs the CUs runs in order on the compute stream; only the exchange -- link-bound, a handful of
-  // workgroups -- runs beside it on the communicator's stream:
+  // workgroups -- runs beside it on the communicator's stream (and the routing of the NEXT batch on the routing lane):
   //   compute:  expand, gather_dot (batch i)   | merge + order (batch i-1) | expand, gather_dot (batch i+1) | ...
   //   comm:                                      exchange (batch i)                                          ...
+  //   route:    ids of batch i+1 -> holders                                  ids of batch i+2 -> holders      ...
   // so the exchange of batch i is hidden behind the merge of batch i-1 and the scoring of batch i+1, and the merge
   // of batch i-1 never shares the CUs with a gather_dot.  (Round 2 ran merge + order on the communicator's stream
   // NEXT TO the following gather_dot: beside a kernel that fills every CU the LDS-heavy ordering got no slots and
   // stretched from 0.07 ms to the gather's whole 2.0 ms at an eighth of the batch, and the next exchange queued
-  // behind it: profiles/r03/rehearsal_trace_n8_before.csv.)  Two plans and two receive buffers alternate.
-  if (s->sent_valid[i]) C_HIP(hipStreamWaitEvent(s->compute, s->sent[i], 0));  // the exchange of two runs ago has read this plan's scores
+  // behind it: profiles/r03/rehearsal_trace_n8_before.csv.)
+  if (sl.routed_valid) C_HIP(hipStreamWaitEvent(s->compute, sl.routed, 0));  // the lists, the queries and the owner-side state are in place
+  if (sl.sent_valid) C_HIP(hipStreamWaitEvent(s->compute, sl.sent, 0));      // the exchange that read this plan's scores last has finished
+  if (s->pending == i) C_TRY(sharded_merge_pending(s));                      // (the same slot run twice in a row: its merge first)
   C_TRY(ffx_plan_run(s->plans[i], 0.0, flags & FFX_FLAG_EXACT_SUM));
-  C_HIP(hipEventRecord(s->scored[i], s->compute));
-  C_HIP(hipStreamWaitEvent(cs, s->scored[i], 0));
+  C_HIP(hipEventRecord(sl.scored, s->compute));
+  sl.scored_valid = true;
+  C_HIP(hipStreamWaitEvent(cs, sl.scored, 0));
   C_HIP(hipEventRecord(s->x_begin, cs));
-  C_TRY(ffx_comm_exchange(s->comm, s->send_dev[i], s->send_counts.data(), static_cast<float*>(s->recv[i]), s->recv_counts.data(), cs));
+  C_TRY(ffx_comm_exchange(s->comm, sl.send_dev, sl.send_counts.data(), static_cast<float*>(sl.recv), sl.recv_counts.data(), cs));
   C_HIP(hipEventRecord(s->x_end, cs));
-  C_HIP(hipEventRecord(s->sent[i], cs));
-  s->sent_valid[i] = true;
+  C_HIP(hipEventRecord(sl.sent, cs));
+  sl.sent_valid = true;
   C_TRY(sharded_merge_pending(s));  // batch i-1, behind batch i's gather_dot
   s->pending = i;
   s->pending_alpha = alpha;
@@ -1330,18 +1926,37 @@ int ffx_sharded_sync(ffx_sharded* s) {
   C_TRY(sharded_merge_pending(s));  // the last batch has nothing behind it to hide its merge
   C_HIP(hipStreamSynchronize(s->comm->stream));
   C_HIP(hipStreamSynchronize(s->compute));
+  if (s->out) C_HIP(hipStreamSynchronize(s->out));
   return FFX_OK;
 }
 
 int ffx_sharded_fetch(ffx_sharded* s, float* out_ff, float* out_interp, int32_t* out_order) {
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
   C_TRY(ffx_sharded_sync(s));
-  return ffx_merge_fetch(s->merge, out_ff, out_interp, out_order);
+  if (s->last_merged < 0) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_run has not been called since the batch was set");
+  return ffx_merge_fetch(s->merges[s->slot[s->last_merged].merge], out_ff, out_interp, out_order);
+}
+
+int ffx_sharded_fetch_async(ffx_sharded* s, float* out_ff, float* out_interp, int32_t* out_order) {
+  if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
+  if (s->last_merged < 0) return ffx_fail(FFX_BAD_ARG, "no batch has been merged yet: ffx_sharded_run queues the merge of the batch BEFORE the one it runs");
+  C_HIP(hipSetDevice(s->device));
+  if (!s->out) {
+    int least = 0, greatest = 0;
+    C_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    C_HIP(hipStreamCreateWithPriority(&s->out, hipStreamNonBlocking, greatest));  // (as ffx_score's result stream: not behind the next batch's kernels)
+  }
+  ffx_sharded::Slot& sl = s->slot[s->last_merged];
+  C_HIP(hipStreamWaitEvent(s->out, sl.merged, 0));
+  C_TRY(ffx_merge_fetch_async(s->merges[sl.merge], out_ff, out_interp, out_order, s->out));
+  C_HIP(hipEventRecord(s->out_done[sl.merge], s->out));
+  s->out_valid[sl.merge] = true;
+  return FFX_OK;
 }
 
 int ffx_sharded_owned(const ffx_sharded* s, int64_t* q_lo, int64_t* q_hi, int64_t* first_pair, int64_t* n_pairs) {
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
-  if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_set_pairs has not succeeded on this handle");
+  if (!s->have_pairs) return ffx_fail(FFX_BAD_ARG, "no batch has been set on this handle");
   if (q_lo) *q_lo = s->own[0];
   if (q_hi) *q_hi = s->own[1];
   if (first_pair) *first_pair = s->own[2];
@@ -1349,29 +1964,104 @@ int ffx_sharded_owned(const ffx_sharded* s, int64_t* q_lo, int64_t* q_hi, int64_
   return FFX_OK;
 }
 
+// One batch from host buffers to host buffers, every rank handing over the queries it owns: the block is cut into
+// n_slices slices of whole queries (the same number on every rank; slice j of every rank together is sub-batch j) and the
+// sub-batches go through the three slots -- while sub-batch j is scored, j+1 is routed and the results of j-1 leave.
+int ffx_sharded_score(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off, const int32_t* own_pair_ids,
+                      const int32_t* own_holder, const float* own_sparse, int mode, double alpha, uint32_t flags, int32_t n_slices, float* out_ff,
+                      float* out_interp, int32_t* out_order, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!s || !q_bounds || !own_pair_off) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (out_interp && !own_sparse) return ffx_fail(FFX_BAD_ARG, "no sparse scores were given: nothing to interpolate");
+  if (out_order && !(flags & FFX_FLAG_SORT)) return ffx_fail(FFX_BAD_ARG, "out_order needs FFX_FLAG_SORT");
+  int rank = 0, world = 1;
+  ffx_comm_rank(s->comm, &rank, &world);
+  const int64_t Qo = q_bounds[rank + 1] - q_bounds[rank];
+  if (Qo < 0) return ffx_fail(FFX_BAD_ARG, "q_bounds not monotone");
+  if (n_slices <= 0) {  // by size: ~4 M pairs per slice on the rank that has most (every rank must cut alike)
+    double most = (double)own_pair_off[Qo];
+    C_TRY(ffx_comm_allreduce_f64(s->comm, &most, 1, FFX_OP_MAX));
+    n_slices = (int32_t)std::min<double>(64.0, std::max(1.0, std::ceil(most / (double)(4 << 20))));
+  }
+  int32_t qdim = 0;
+  C_TRY(ffx_index_query_dim(s->shard, &qdim));
+  std::vector<int64_t> qb((size_t)world + 1), off;
+  auto cut = [&](int r, int j) { return (q_bounds[r + 1] - q_bounds[r]) * (int64_t)j / n_slices; };  // first query of rank r's slice j, in its block
+  int rc = FFX_OK;
+  int64_t first_pair[2] = {0, 0};  // of the slice whose results leave next
+  for (int j = 0; j <= n_slices && rc == FFX_OK; ++j) {
+    if (j < n_slices) {
+      qb[0] = 0;
+      for (int r = 0; r < world; ++r) qb[(size_t)r + 1] = qb[(size_t)r] + cut(r, j + 1) - cut(r, j);
+      const int64_t q0 = cut(rank, j), q1 = cut(rank, j + 1), p0 = own_pair_off[q0];
+      off.resize((size_t)(q1 - q0) + 1);
+      for (int64_t q = q0; q <= q1; ++q) off[(size_t)(q - q0)] = own_pair_off[q] - p0;
+      int64_t bad = -1;
+      rc = sharded_stage_owned(s, qb.data(), own_queries ? own_queries + (size_t)q0 * qdim : nullptr, off.data(), own_pair_ids ? own_pair_ids + p0 : nullptr,
+                               own_holder ? own_holder + p0 : nullptr, own_sparse ? own_sparse + p0 : nullptr, mode, (int32_t)p0, &bad);
+      if (rc != FFX_OK) {
+        if (bad_pair && bad >= 0) *bad_pair = p0 + bad;
+        break;
+      }
+      rc = ffx_sharded_run(s, alpha, flags);  // queues the merge of slice j-1 behind slice j's gather_dot
+      first_pair[j & 1] = p0;
+    } else {
+      rc = sharded_merge_pending(s);  // the last slice has nothing behind it
+    }
+    if (rc == FFX_OK && j >= 1) {
+      const int64_t p0 = first_pair[(j - 1) & 1];
+      rc = ffx_sharded_fetch_async(s, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr, out_order ? out_order + p0 : nullptr);
+    }
+  }
+  if (rc != FFX_OK) {  // nothing may still be writing when the caller gets its buffers back
+    const std::string keep = ffx_last_error();
+    s->pending = -1;
+    (void)hipStreamSynchronize(s->comm->stream);
+    (void)hipStreamSynchronize(s->compute);
+    if (s->out) (void)hipStreamSynchronize(s->out);
+    ffx_fail(rc, "%s", keep.c_str());
+    return rc;
+  }
+  return ffx_sharded_sync(s);
+}
+
 int ffx_sharded_stats(ffx_sharded* s, ffx_shard_stats* out) {
   if (!s || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
   if (s->runs == 0) return ffx_fail(FFX_BAD_ARG, "ffx_sharded_run has not been called");
   C_TRY(ffx_sharded_sync(s));
   memset(out, 0, sizeof *out);
+  const ffx_sharded::Slot& sl = s->slot[s->last];
   C_TRY(ffx_plan_stats(s->plans[s->last], &out->local));
   ffx_comm_rank(s->comm, &out->rank, &out->world);
-  out->own_queries = s->own[1] - s->own[0];
-  out->own_pairs = s->own[3];
+  out->own_queries = sl.own[1] - sl.own[0];
+  out->own_pairs = sl.own[3];
   for (int r = 0; r < out->world; ++r) {
     if (r == out->rank) continue;
-    out->send_bytes += s->send_counts[r] * 4;
-    out->recv_bytes += s->recv_counts[r] * 4;
+    out->send_bytes += sl.send_counts[(size_t)r] * 4;
+    out->recv_bytes += sl.recv_counts[(size_t)r] * 4;
   }
   out->transport = s->comm->transport;
   C_HIP(hipEventElapsedTime(&out->ms_exchange, s->x_begin, s->x_end));
-  C_HIP(hipEventElapsedTime(&out->ms_merge, s->m_begin, s->merged));
+  C_HIP(hipEventElapsedTime(&out->ms_merge, s->m_begin, s->m_end));
+  if (s->fresh) {
+    out->stage_h2d_bytes = s->stage_h2d_bytes;
+    out->stage_route_send_bytes = s->stage_route_send_bytes;
+    out->stage_route_recv_bytes = s->stage_route_recv_bytes;
+    out->ms_stage_host = (float)s->stage_host_ms;
+    if (s->comm->route_stream) {
+      C_HIP(hipStreamSynchronize(s->comm->route_stream));
+      C_HIP(hipEventElapsedTime(&out->ms_stage_device, s->r_begin, s->r_end));
+    }
+  }
   return FFX_OK;
 }
 
 int ffx_sharded_device_ptr(ffx_sharded* s, int which, void** ptr, int64_t* n_elems) {
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
-  return ffx_merge_device_ptr(s->merge, which, ptr, n_elems);
+  // what ffx_sharded_fetch would copy out: the batch merged last.  (The merge of the batch run last is still pending
+  // until ffx_sharded_sync: a caller that wants ITS results syncs first.)
+  const int m = s->last_merged >= 0 ? s->slot[s->last_merged].merge : 0;
+  return ffx_merge_device_ptr(s->merges[m], which, ptr, n_elems);
 }
 
 }  // extern "C"

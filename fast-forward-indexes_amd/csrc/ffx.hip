@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/ffx.h"
+#include "ffx_internal.h"
 #include "aux_kernels.hip.h"
 #include "gather_dot.hip.h"
 
@@ -1290,6 +1291,67 @@ int ffx_plan_set_pairs_lazy(ffx_plan* pl, const int64_t* pair_off, int64_t n_que
 
 }  // extern "C" (templates need C++ linkage)
 
+// ---- ffx_internal.h: candidate lists written in place by the sharded scorer (comm.hip) ------------------------------
+int ffx_plan_create_on(ffx_index* idx, hipStream_t stream, ffx_plan** out) {
+  FFX_TRY(plan_create(idx, out, false));
+  (*out)->stream = stream;
+  return FFX_OK;
+}
+
+int ffx_plan_adopt_begin(ffx_plan* pl, int64_t n_queries, int64_t n_pairs, int mode, int64_t** d_pair_off, int32_t** d_pair_ids) {
+  if (!pl || n_queries < 0 || n_pairs < 0 || !d_pair_off || !d_pair_ids) return fail(FFX_BAD_ARG, "bad argument");
+  if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
+  if (n_queries > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many queries");
+  if (n_pairs > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
+  FFX_HIP(hipSetDevice(pl->device));
+  pl->have_pairs = false;
+  pl->lazy_pairs = false;
+  pl->ran = false;
+  pl->n_queries = n_queries;
+  pl->n_pairs = n_pairs;
+  pl->mode = mode;
+  pl->have_sparse = false;
+  pl->order_base = 0;
+  const size_t pb = std::max<size_t>((size_t)n_pairs, 1);
+  FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(pl->cnt.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(pl->seg_off.ensure((pb + 1) * sizeof(int32_t)));
+  FFX_TRY(pl->ff.ensure(pb * sizeof(float)));
+  *d_pair_off = pl->pair_off.as<int64_t>();
+  *d_pair_ids = pl->pair_ids.as<int32_t>();
+  return FFX_OK;
+}
+
+int ffx_plan_adopt_finish(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t stream, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!pl || !host_pair_off) return fail(FFX_BAD_ARG, "bad argument");
+  if (host_pair_off[0] != 0 || host_pair_off[pl->n_queries] != pl->n_pairs) return fail(FFX_BAD_ARG, "the offsets do not describe the adopted lists");
+  ffx_index* ix = pl->idx;
+  if ((pl->mode == FFX_MODE_PASSAGE ? ix->n_psgs == 0 : ix->n_docs == 0) && pl->n_pairs > 0) {
+    if (bad_pair) *bad_pair = 0;
+    return fail(FFX_NOT_FOUND, "the index holds no %s ids", pl->mode == FFX_MODE_PASSAGE ? "passage" : "document");
+  }
+  FFX_HIP(hipSetDevice(pl->device));
+  pl->host_pair_off.assign(host_pair_off, host_pair_off + pl->n_queries + 1);
+  pl->hstage_used = 0;
+  hipStream_t keep = pl->stream;
+  pl->stream = stream;  // the validation (and its one wait) belong to the caller's stream, not to the one the plan scores on
+  const int rc = finish_set_pairs(pl, bad_pair);
+  pl->stream = keep;
+  return rc;
+}
+
+int ffx_plan_queries_room(ffx_plan* pl, int64_t n_queries, float** d_queries) {
+  if (!pl || n_queries < 0 || !d_queries) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_queries > INT32_MAX) return fail(FFX_BAD_ARG, "too many queries");
+  FFX_HIP(hipSetDevice(pl->device));
+  FFX_TRY(pl->queries.ensure(std::max<size_t>((size_t)n_queries * pl->idx->qdim * sizeof(float), 16)));
+  pl->n_queries_set = (int)n_queries;
+  *d_queries = pl->queries.as<float>();
+  return FFX_OK;
+}
+
 // pick and launch the gather_dot instantiation for rows of type T (float / _Float16); the
 // variant id lands in ffx_stats.kernel_variant (+1000 for half rows)
 template <typename T>
@@ -2086,6 +2148,7 @@ struct ffx_merge {
   hipStream_t own_stream = nullptr, last_stream = nullptr;
   DevBuf pair_off, slot, sparse, ff, interp, order, iota, sorted_keys, sort_tmp;
   int64_t n_queries = 0, n_pairs = 0, max_len = 0;
+  int32_t order_base = 0;  // added to the positions of the per-query order (the owned block as a slice of a larger list)
   bool have_sparse = false, ready = false, ran = false, ran_sort = false;
 };
 
@@ -2151,6 +2214,7 @@ int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, cons
   m->n_queries = n_queries;
   m->n_pairs = P;
   m->max_len = longest_segment(pair_off, n_queries);
+  m->order_base = 0;
   m->ready = true;
   return FFX_OK;
 }
@@ -2195,6 +2259,7 @@ int ffx_merge_set_device(ffx_merge* m, const int64_t* pair_off, int64_t n_querie
   m->n_queries = n_queries;
   m->n_pairs = P;
   m->max_len = longest_segment(pair_off, n_queries);
+  m->order_base = 0;
   m->ready = true;
   return FFX_OK;
 }
@@ -2216,7 +2281,7 @@ int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t fl
     if (do_sort) {
       const float* keys = (m->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? m->interp.as<float>() : m->ff.as<float>();
       FFX_TRY(launch_segmented_sort(keys, P, m->pair_off.as<int64_t>(), m->n_queries, m->order, m->iota, m->sorted_keys,
-                                    m->sort_tmp, st, m->max_len));
+                                    m->sort_tmp, st, m->max_len, m->order_base));
     }
   }
   m->ran = true;
@@ -2261,6 +2326,59 @@ int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems) 
   if (n_elems) *n_elems = b->p ? m->n_pairs : 0;
   return FFX_OK;
 }
+
+}  // extern "C"
+
+// ---- ffx_internal.h: the owner-side state written in place by the sharded scorer (comm.hip) -------------------------
+int ffx_merge_adopt_begin(ffx_merge* m, int64_t n_queries, int64_t n_pairs, bool have_sparse, int64_t** d_pair_off, int32_t** d_slot,
+                          float** d_sparse) {
+  if (!m || n_queries < 0 || n_pairs < 0 || !d_pair_off || !d_slot || !d_sparse) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_pairs > INT32_MAX - 1) return fail(FFX_BAD_ARG, "too many pairs");
+  FFX_HIP(hipSetDevice(m->device));
+  m->ready = m->ran = false;
+  const size_t pb = std::max<size_t>((size_t)n_pairs, 1);
+  FFX_TRY(m->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(m->slot.ensure(pb * sizeof(int32_t)));
+  FFX_TRY(m->ff.ensure(pb * sizeof(float)));
+  m->have_sparse = have_sparse;
+  if (have_sparse) {
+    FFX_TRY(m->sparse.ensure(pb * sizeof(float)));
+    FFX_TRY(m->interp.ensure(pb * sizeof(float)));
+  }
+  m->n_queries = n_queries;
+  m->n_pairs = n_pairs;
+  *d_pair_off = m->pair_off.as<int64_t>();
+  *d_slot = m->slot.as<int32_t>();
+  *d_sparse = have_sparse ? m->sparse.as<float>() : nullptr;
+  return FFX_OK;
+}
+
+int ffx_merge_adopt_finish(ffx_merge* m, int64_t longest_query, int32_t order_base) {
+  if (!m || longest_query < 0) return fail(FFX_BAD_ARG, "bad argument");
+  m->max_len = longest_query;
+  m->order_base = order_base;
+  m->ready = true;
+  return FFX_OK;
+}
+
+int ffx_merge_fetch_async(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order, hipStream_t stream) {
+  if (!m) return fail(FFX_BAD_ARG, "NULL merge");
+  if (!m->ran) return fail(FFX_BAD_ARG, "ffx_merge_run has not been issued on this handle");
+  if (out_interp && !m->have_sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
+  if (out_order && !m->ran_sort) return fail(FFX_BAD_ARG, "the last run did not request FFX_FLAG_SORT");
+  FFX_HIP(hipSetDevice(m->device));
+  const size_t P = (size_t)m->n_pairs;
+  if (P > 0) {
+    if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff, m->ff.p, P * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp, m->interp.p, P * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (out_order) FFX_HIP(hipMemcpyAsync(out_order, m->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  }
+  return FFX_OK;
+}
+
+int64_t ffx_merge_pairs(const ffx_merge* m) { return m ? m->n_pairs : 0; }
+
+extern "C" {
 
 // ---- stand-alone epilogue ---------------------------------------------------------------------------
 int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, int64_t n_pairs, int mode,
@@ -2705,15 +2823,26 @@ int ffx_host_free(void* p) {
   return FFX_OK;
 }
 
+// A refusal (RLIMIT_MEMLOCK in a container, a mapping that cannot be read) is an answer, not a fault: callers fall back
+// to ordinary copies on the same thread, so the runtime's thread-local last error is cleared before returning -- the next
+// launch check (FFX_HIP(hipGetLastError())) must not report this stale failure as its own.
 int ffx_host_pin(void* p, size_t bytes) {
   if (!p || bytes == 0) return fail(FFX_BAD_ARG, "bad argument");
-  FFX_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e == hipErrorOutOfMemory ? FFX_OOM : FFX_HIP_ERROR, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
+  }
   return FFX_OK;
 }
 
 int ffx_host_unpin(void* p) {
   if (!p) return fail(FFX_BAD_ARG, "bad argument");
-  FFX_HIP(hipHostUnregister(p));
+  const hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FFX_HIP_ERROR, "hipHostUnregister: %s", hipGetErrorString(e));
+  }
   return FFX_OK;
 }
 

@@ -1,0 +1,38 @@
+// ffx_internal.h -- what the translation units of libffx share beyond the public ABI (include/ffx.h).
+// C++ linkage, no stability promise, not installed: comm.hip (the multi-GPU half) fills a plan's candidate lists and a
+// merge's owner-side state IN PLACE, on its own routing stream, when a batch is routed by the ranks that own its
+// queries (ffx_sharded_stage_owned): the lists arrive from the other ranks straight into the buffers the kernels read.
+#ifndef FFX_INTERNAL_H_
+#define FFX_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/ffx.h"
+
+int ffx_fail(int code, const char* fmt, ...);
+bool ffx_debug_variant(const char* name, long long* value);  // the FFX_DEBUG_VARIANT list of A/B switches (ffx.hip)
+
+// Room in the plan for n_queries + 1 offsets and n_pairs ordinals; the caller fills both device buffers on any stream.
+// (Buffers may be re-allocated here: call it while nothing of the plan is in flight.)
+int ffx_plan_adopt_begin(ffx_plan* pl, int64_t n_queries, int64_t n_pairs, int mode, int64_t** d_pair_off, int32_t** d_pair_ids);
+// The lists are in place once `stream` reaches this point; host_pair_off holds the same offsets on the host.  The
+// ordinals are validated ON `stream` (get_indices, index/util.py:29-41; the call waits for that stream only).
+int ffx_plan_adopt_finish(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t stream, int64_t* bad_pair);
+// Device room for n_queries query vectors, which the caller fills before the plan runs.
+int ffx_plan_queries_room(ffx_plan* pl, int64_t n_queries, float** d_queries);
+// A plan that owns no stream of its own and issues its work on `stream`.
+int ffx_plan_create_on(ffx_index* idx, hipStream_t stream, ffx_plan** out);
+
+// The owner-side state of a merge written in place: offsets of the owned queries, arrival slot and first-stage score
+// of every owned candidate (d_sparse is NULL without first-stage scores).
+int ffx_merge_adopt_begin(ffx_merge* m, int64_t n_queries, int64_t n_pairs, bool have_sparse, int64_t** d_pair_off, int32_t** d_slot,
+                          float** d_sparse);
+// order_base: added to the positions the per-query order is made of (a slice of a larger list)
+int ffx_merge_adopt_finish(ffx_merge* m, int64_t longest_query, int32_t order_base);
+// results of the last ffx_merge_run copied out on `stream` (asynchronously for page-locked destinations)
+int ffx_merge_fetch_async(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order, hipStream_t stream);
+int64_t ffx_merge_pairs(const ffx_merge* m);
+
+#endif  // FFX_INTERNAL_H_

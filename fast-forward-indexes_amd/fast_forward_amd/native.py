@@ -36,10 +36,11 @@ SYMBOLS = (
     "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets", "ffx_host_segment_rows_unique",
     "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
-    "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
+    "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host", "ffx_comm_rehearsal_inbox",
     "ffx_query_partition", "ffx_route",
     "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs", "ffx_sharded_set_pairs_held",
     "ffx_sharded_run", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
+    "ffx_sharded_stage_owned", "ffx_sharded_fetch_async", "ffx_sharded_score",
 )
 COMM_RCCL, COMM_HOST, COMM_REHEARSAL, COMM_ID_BYTES = 0, 1, 2, 128
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
@@ -63,6 +64,8 @@ class ShardStats(C.Structure):
         ("local", Stats), ("own_queries", C.c_int64), ("own_pairs", C.c_int64), ("send_bytes", C.c_int64), ("recv_bytes", C.c_int64),
         ("rank", C.c_int32), ("world", C.c_int32), ("transport", C.c_int32), ("reserved", C.c_int32),
         ("ms_exchange", C.c_float), ("ms_merge", C.c_float),
+        ("stage_h2d_bytes", C.c_int64), ("stage_route_send_bytes", C.c_int64), ("stage_route_recv_bytes", C.c_int64),
+        ("ms_stage_host", C.c_float), ("ms_stage_device", C.c_float),
     ]
 
     def as_dict(self) -> dict:
@@ -218,6 +221,7 @@ def lib() -> C.CDLL:
         "ffx_comm_allgather": ([vp, vp, i64, vp], C.c_int),
         "ffx_comm_exchange": ([vp, vp, vp, vp, vp, vp], C.c_int),
         "ffx_comm_exchange_host": ([vp, vp, vp, vp, vp], C.c_int),
+        "ffx_comm_rehearsal_inbox": ([vp, vp, i64], C.c_int),
         "ffx_query_partition": ([i64, C.c_int, vp], C.c_int),
         "ffx_route": ([vp, i64, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, P(i64)], C.c_int),
         "ffx_sharded_create": ([vp, vp, vp, P(vp)], C.c_int),
@@ -231,13 +235,16 @@ def lib() -> C.CDLL:
         "ffx_sharded_owned": ([vp, P(i64), P(i64), P(i64), P(i64)], C.c_int),
         "ffx_sharded_stats": ([vp, P(ShardStats)], C.c_int),
         "ffx_sharded_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
+        "ffx_sharded_stage_owned": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, P(i64)], C.c_int),
+        "ffx_sharded_fetch_async": ([vp, vp, vp, vp], C.c_int),
+        "ffx_sharded_score": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, i32, vp, vp, vp, P(i64)], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = restype
-    if L.ffx_abi_version() != 2:
-        raise ImportError(f"libffx ABI {L.ffx_abi_version()} does not match this binding (2)")
+    if L.ffx_abi_version() != 3:
+        raise ImportError(f"libffx ABI {L.ffx_abi_version()} does not match this binding (3)")
     _lib = L
     return L
 
@@ -1268,6 +1275,10 @@ class Comm:
         _check(lib().ffx_comm_allgather(self._h, _ptr(a), a.nbytes, _ptr(out)))
         return out
 
+    def rehearsal_inbox(self, dev_ptr: "int | None", n_words: int = 0) -> None:
+        """Rehearsal transport only: the device words the peers WOULD send on the routing lane from now on."""
+        _check(lib().ffx_comm_rehearsal_inbox(self._h, C.c_void_p(dev_ptr) if dev_ptr else None, int(n_words)))
+
     def exchange_host(self, send: np.ndarray, send_counts, recv_counts) -> np.ndarray:
         """All-to-all-v of float32 HOST arrays (host transport)."""
         send = _arr(send, np.float32)
@@ -1358,6 +1369,62 @@ class Sharded:
         _check(rc, bad.value)
         self.has_sparse = sp is not None
         self._owned()
+
+    def _owned_args(self, q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, own_holder):
+        qb = _arr(q_bounds, np.int64)
+        if qb.shape[0] != self._comm.world + 1:
+            raise ValueError("q_bounds must have world + 1 entries")
+        n_own = int(qb[self._comm.rank + 1] - qb[self._comm.rank])
+        off, ids = _arr(own_pair_off, np.int64), _arr(own_pair_ids, np.int32)
+        if off.shape[0] != n_own + 1 or ids.shape[0] != int(off[-1]):
+            raise ValueError("own_pair_off / own_pair_ids do not describe this rank's block of the batch")
+        qv = None
+        if own_queries is not None:
+            qv = _arr(own_queries, np.float32)
+            if qv.shape != (n_own, self._shard.query_dim):
+                raise ValueError("own_queries must hold one vector per owned query")
+        sp = None if own_sparse is None else _arr(own_sparse, np.float32)
+        ho = None if own_holder is None else _arr(own_holder, np.int32)
+        if (sp is not None and sp.shape[0] != ids.shape[0]) or (ho is not None and ho.shape[0] != ids.shape[0]):
+            raise ValueError("own_sparse / own_holder must have one entry per owned pair")
+        return qb, n_own, qv, off, ids, sp, ho
+
+    def stage_owned(self, q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, mode: int, own_holder=None) -> None:
+        """``ffx_sharded_stage_owned``: a FRESH batch of which this rank hands over only the queries it owns
+        (``q_bounds[rank] .. q_bounds[rank + 1]``): their vectors, candidate lists (offsets from 0) and first-stage
+        scores.  Collective; may be called while the previous batch runs.  ``run`` then runs the batch staged last."""
+        qb, n_own, qv, off, ids, sp, ho = self._owned_args(q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, own_holder)
+        bad = C.c_int64(-1)
+        rc = lib().ffx_sharded_stage_owned(self._h, _ptr(qb), _ptr(qv), _ptr(off), _ptr(ids), _ptr(ho), _ptr(sp), int(mode), C.byref(bad))
+        _check(rc, bad.value)
+        self.has_sparse = sp is not None
+        self.q_lo, self.q_hi, self.own_first_pair, self.own_pairs = int(qb[self._comm.rank]), int(qb[self._comm.rank + 1]), 0, int(off[-1])
+
+    def fetch_async(self, out, ff: bool = True, interp: bool = False, order: bool = False) -> None:
+        """``ffx_sharded_fetch_async``: the batch merged last (after ``run``: the one BEFORE the batch it ran) copied into
+        ``out = (ff, interp, order)`` arrays (page-locked ones for a truly asynchronous copy); complete after ``sync``."""
+        a, b, c = (out[0] if ff else None), (out[1] if interp else None), (out[2] if order else None)
+        _check(lib().ffx_sharded_fetch_async(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
+    def score_owned(self, q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, mode: int, alpha: float = 0.0, exact_sum: bool = True,
+                    sort: bool = False, n_slices: int = 0, own_holder=None, out=None):
+        """``ffx_sharded_score``: this rank's block of a fresh batch from host arrays to host arrays, cut into ``n_slices``
+        slices (0: by size; the same on every rank) that are routed, scored, exchanged, merged and fetched back to back.
+        Returns (dense, interpolated|None, order|None) of the owned queries."""
+        qb, n_own, qv, off, ids, sp, ho = self._owned_args(q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, own_holder)
+        n = ids.shape[0]
+        o = out if out is not None else (None, None, None)
+        ff = o[0][:n] if o[0] is not None else np.empty(n, dtype=np.float32)
+        interp = None if sp is None else (o[1][:n] if o[1] is not None else np.empty(n, dtype=np.float32))
+        order = None if not sort else (o[2][:n] if o[2] is not None else np.empty(n, dtype=np.int32))
+        flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0)
+        bad = C.c_int64(-1)
+        rc = lib().ffx_sharded_score(self._h, _ptr(qb), _ptr(qv), _ptr(off), _ptr(ids), _ptr(ho), _ptr(sp), int(mode), float(alpha), flags, int(n_slices),
+                                     _ptr(ff), _ptr(interp), _ptr(order), C.byref(bad))
+        _check(rc, bad.value)
+        self.has_sparse = sp is not None
+        self.q_lo, self.q_hi, self.own_first_pair, self.own_pairs = int(qb[self._comm.rank]), int(qb[self._comm.rank + 1]), 0, n
+        return ff, interp, order
 
     def run(self, alpha: float = 0.0, exact_sum: bool = True, sort: bool = False, sort_ff: bool = False) -> None:
         flags = (FLAG_EXACT_SUM if exact_sum else 0) | (FLAG_SORT if sort else 0) | (FLAG_SORT_FF if sort_ff else 0)

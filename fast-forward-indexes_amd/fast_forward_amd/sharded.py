@@ -96,6 +96,58 @@ def route(pair_off, pair_ids, doc_bounds, rank: int, world: int, sparse=None) ->
     )
 
 
+# ---- owner-side routing: every rank is handed only the queries it owns ---------------------------------------------
+@dataclass
+class OwnedRoute:
+    """What rank ``rank`` derives from ITS block of a batch (the NumPy statement of ``ffx_sharded_stage_owned``'s device
+    kernels): two messages per holder and the owner-side arrival slots."""
+
+    rank: int
+    world: int
+    counts: np.ndarray    # int32[world, Qo]: counts[h, q] = candidates of owned query q that rank h holds (message A to h: counts[h])
+    starts: np.ndarray    # int64[world + 1]: the run of ordinals for holder h is send_ids[starts[h]:starts[h + 1]] (message B)
+    send_ids: np.ndarray  # int32[Po]: holder-local ordinals grouped by holder, queries ascending, first-stage order inside
+    slot: np.ndarray      # int32[Po]: where the score of owned candidate p arrives (what the owner-side merge reads)
+
+
+def route_owned(own_pair_off, own_pair_ids, rank: int, world: int, doc_bounds=None, holder=None) -> OwnedRoute:
+    """Owner side of a fresh batch.  ``own_pair_ids``: global document ordinals (holders by ``doc_bounds``) or, with
+    ``holder``, the ordinal on rank ``holder[p]``."""
+    off = np.asarray(own_pair_off, dtype=np.int64)
+    ids = np.asarray(own_pair_ids, dtype=np.int64)
+    n_q = off.shape[0] - 1
+    if holder is None:
+        bounds = np.asarray(doc_bounds, dtype=np.int64)
+        if ids.size and (ids.min() < bounds[0] or ids.max() >= bounds[-1]):
+            bad = int(np.flatnonzero((ids < bounds[0]) | (ids >= bounds[-1]))[0])
+            raise IndexError(f"pair {bad} names document ordinal {int(ids[bad])}, outside the sharded index")
+        who = (np.searchsorted(bounds, ids, side="right") - 1).astype(np.int64)
+        local = ids - bounds[who]
+    else:
+        who = np.asarray(holder, dtype=np.int64)
+        local = ids
+    pair_q = np.repeat(np.arange(n_q, dtype=np.int64), np.diff(off))
+    counts = np.zeros((world, n_q), dtype=np.int32)
+    np.add.at(counts, (who, pair_q), 1)
+    arrival = np.lexsort((np.arange(ids.shape[0]), pair_q, who))  # by holder, then query, then first-stage position
+    slot = np.empty(ids.shape[0], dtype=np.int32)
+    slot[arrival] = np.arange(ids.shape[0], dtype=np.int32)
+    starts = np.concatenate([[0], np.cumsum(counts.sum(axis=1, dtype=np.int64))]).astype(np.int64)
+    return OwnedRoute(rank=rank, world=world, counts=counts, starts=starts, send_ids=local[arrival].astype(np.int32), slot=slot)
+
+
+def assemble_local(q_bounds, counts_from, ids_from):
+    """Holder side: the messages of the owners, in rank order, ARE this rank's local CSR.  ``counts_from[o]``: int32[Q_o]
+    per-query counts from owner o, ``ids_from[o]``: its ordinals.  Returns (local_pair_off, local_pair_ids, send_counts:
+    how many local scores go back to each owner)."""
+    q_bounds = np.asarray(q_bounds, dtype=np.int64)
+    per_q = np.concatenate([np.asarray(c, dtype=np.int64) for c in counts_from]) if len(counts_from) else np.zeros(0, dtype=np.int64)
+    assert per_q.shape[0] == int(q_bounds[-1])
+    local_off = np.concatenate([[0], np.cumsum(per_q)]).astype(np.int64)
+    local_ids = np.concatenate([np.asarray(i, dtype=np.int32) for i in ids_from]) if len(ids_from) else np.zeros(0, dtype=np.int32)
+    return local_off, local_ids.astype(np.int32), np.diff(local_off[q_bounds])
+
+
 # ---- process bootstrap -------------------------------------------------------------------------------
 def _rendezvous_key() -> str:
     """Names this job: the same string in every rank of one launch, different between launches.
@@ -238,6 +290,37 @@ class ShardedScorer:
             if isinstance(e, native.NotFound):
                 raise IndexError(f"pair {e.pair} names an ordinal outside the sharded index") from None
             raise
+
+    def stage_owned(self, q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, mode: int, own_holder=None) -> None:
+        """A FRESH batch of which this rank hands over only the queries it owns (``ffx_sharded_stage_owned``): ~P/world
+        candidates per rank go to its GPU, the ordinals travel to the holders in a first all-to-all.  May be called while
+        the previous batch runs; ``run`` then runs the batch staged last."""
+        try:
+            self._s.stage_owned(q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, mode, own_holder=own_holder)
+        except Exception as e:
+            from fast_forward_amd import native
+
+            if isinstance(e, native.NotFound):
+                raise IndexError(f"pair {e.pair} of this rank's block names an ordinal outside the sharded index" if e.pair >= 0
+                                 else "a candidate owned by another rank names an ordinal outside the sharded index") from None
+            raise
+
+    def score_owned(self, q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, mode: int, alpha: float = 0.0, exact_sum: bool = True,
+                    sort: bool = False, n_slices: int = 0, own_holder=None, out=None):
+        """Host arrays in, host arrays out (``ffx_sharded_score``): this rank's block, sliced and pipelined."""
+        try:
+            return self._s.score_owned(q_bounds, own_queries, own_pair_off, own_pair_ids, own_sparse, mode, alpha, exact_sum=exact_sum, sort=sort,
+                                       n_slices=n_slices, own_holder=own_holder, out=out)
+        except Exception as e:
+            from fast_forward_amd import native
+
+            if isinstance(e, native.NotFound):
+                raise IndexError(f"pair {e.pair} of this rank's block names an ordinal outside the sharded index" if e.pair >= 0
+                                 else "a candidate owned by another rank names an ordinal outside the sharded index") from None
+            raise
+
+    def fetch_async(self, out, ff: bool = True, interp: bool = False, order: bool = False) -> None:
+        self._s.fetch_async(out, ff=ff, interp=interp, order=order)
 
     def run(self, alpha: float, exact_sum: bool = True, sort: bool = False) -> None:
         self._s.run(alpha, exact_sum=exact_sum, sort=sort)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 2  /* 2: ffx_shard_stats grew (ms_exchange, ms_merge); everything else added since 1 is additive */
+#define FFX_ABI_VERSION 3  /* 3: ffx_shard_stats grew (the stage_* fields of the owner-routed form); 2: (ms_exchange, ms_merge); everything else is additive */
 
 /* status codes */
 #define FFX_OK 0
@@ -277,6 +277,10 @@ int ffx_comm_exchange(ffx_comm* comm, const float* send_dev, const int64_t* send
  * scratch -- for scores a streamed index produced on the host) */
 int ffx_comm_exchange_host(ffx_comm* comm, const float* send, const int64_t* send_counts, float* recv,
                            const int64_t* recv_counts);
+/* FFX_COMM_REHEARSAL only: what the peers WOULD send on the routing lane (ffx_sharded_stage_owned) from now on -- n_words
+ * 4-byte words of DEVICE memory made by the caller, who knows the whole synthetic batch: per-query counts, candidate
+ * ordinals, query vectors, in the order the lane receives them.  NULL: zeros again. */
+int ffx_comm_rehearsal_inbox(ffx_comm* comm, const void* dev_words, int64_t n_words);
 
 /* routing, host only: from the CSR of ALL queries (pair_ids = GLOBAL document ordinals) what rank
  * `rank` scores and what it finalises.  Shards are the document ranges doc_bounds[r]..doc_bounds[r+1];
@@ -295,9 +299,22 @@ int ffx_route(const int64_t* pair_off, int64_t n_queries, const int32_t* pair_id
               int64_t* send_counts, int64_t* recv_counts, int32_t* recv_slot, int64_t* own, int64_t* bad_pair);
 
 /* ffx_sharded: one rank of the row-sharded index = local plans + exchange + owner merge.  All ranks
- * make the same calls with the same arguments (SPMD).  Two plans alternate as send buffers, scoring
- * runs on a compute stream and exchange + merge on the communicator's stream, so back-to-back
- * ffx_sharded_run calls overlap: a step costs max(scoring, exchange + merge). */
+ * make the same calls with the same arguments (SPMD).  Scoring runs on a compute stream, the exchange of scores on the
+ * communicator's stream, and the owner-side merge of batch i is queued on the compute stream BEHIND the scoring of batch
+ * i+1 -- by the NEXT ffx_sharded_run, or by ffx_sharded_sync / _fetch for the last batch -- so back-to-back runs hide
+ * the exchange and a step costs about the local scoring.  Results are therefore valid only after ffx_sharded_sync or
+ * ffx_sharded_fetch (ffx_sharded_fetch_async hands out the batch BEFORE the one run last); synchronising
+ * ffx_comm_stream is not enough, and ffx_sharded_device_ptr names the buffers of the batch merged last.
+ *
+ * Two ways to hand a batch over:
+ *   ffx_sharded_set_pairs[_held]   every rank passes the CSR of ALL queries (set once, run many times: another alpha, a
+ *                                  timing loop); each rank uploads and routes all P candidates
+ *   ffx_sharded_stage_owned        every rank passes only the block of queries it OWNS (~P/world candidates): the owners
+ *                                  find the holders on the device and the candidate ordinals travel to them in a first
+ *                                  all-to-all (4 bytes per pair, same mesh as the scores) on a routing lane of the
+ *                                  communicator, WHILE the previous batch is being scored.  What the reference does on
+ *                                  every call -- score a new set of queries (index/base.py:418-429, 445-459) -- at 1/world
+ *                                  of the intake cost per rank.  ffx_sharded_score is the host-to-host call built on it. */
 typedef struct ffx_sharded ffx_sharded;
 typedef struct ffx_shard_stats {
   ffx_stats local;      /* the local ffx_plan_run of the last step (kernel times, gathered rows) */
@@ -308,6 +325,12 @@ typedef struct ffx_shard_stats {
   int32_t rank, world, transport, reserved;
   float ms_exchange;    /* last step, HIP events on the communicator's stream: the all-to-all of scores */
   float ms_merge;       /* ... and the owner-side scatter + interpolation + per-query order            */
+  /* the last ffx_sharded_stage_owned (0 for a batch set with ffx_sharded_set_pairs) */
+  int64_t stage_h2d_bytes;        /* host -> device: this rank's block only (offsets, ordinals, first-stage scores, query vectors) */
+  int64_t stage_route_send_bytes; /* routing lane, to / from OTHER ranks: per-query counts, ordinals, query vectors               */
+  int64_t stage_route_recv_bytes;
+  float ms_stage_host;            /* wall-clock of the call (it waits for its own routing stream three times)                     */
+  float ms_stage_device;          /* first upload to last routing kernel, HIP events on the routing stream                        */
 } ffx_shard_stats;
 /* shard: this rank's rows (document ordinals relative to the shard); doc_bounds[world+1]: first
  * global document ordinal of every shard (NULL: pairs come with explicit holders, below) */
@@ -320,7 +343,27 @@ int ffx_sharded_set_pairs(ffx_sharded* s, const int64_t* pair_off, int64_t n_que
 /* pair p is held by rank holder[p]; local_ids[p] = its ordinal on that rank (read where holder[p] == rank) */
 int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t n_queries, const int32_t* holder,
                                const int32_t* local_ids, const float* sparse, int mode, int64_t* bad_pair);
+/* A FRESH batch, routed by the ranks that own its queries.  q_bounds[world + 1]: rank r owns queries q_bounds[r] ..
+ * q_bounds[r+1] of the batch (the same array on every rank; any block sizes).  The rest describes THIS rank's block only:
+ * own_queries [Qo, dim] (NULL: the replicated vectors of ffx_sharded_set_queries stay), own_pair_off[Qo + 1] starting at
+ * 0, own_pair_ids = global document ordinals (shards = the doc_bounds ranges) or, with own_holder != NULL, the ordinal
+ * on rank own_holder[p]; own_sparse may be NULL.  Collective, and may be called while the previous batch runs (three
+ * batches rotate: staged, running, merging); ffx_sharded_run then runs the batch staged last.  Every rank returns the
+ * same status: FFX_NOT_FOUND when any rank's candidate names an ordinal without rows (*bad_pair is set on the rank that
+ * owns it: a position in ITS list).  Per-rank host->device bytes are proportional to the block, not to the batch. */
+int ffx_sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
+                            const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, int64_t* bad_pair);
 int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags); /* asynchronous */
+/* the results of the batch merged last -- after ffx_sharded_run that is the batch BEFORE the one it ran -- copied out on a
+ * stream of their own (truly asynchronous into page-locked buffers); complete after ffx_sharded_sync */
+int ffx_sharded_fetch_async(ffx_sharded* s, float* out_ff, float* out_interp, int32_t* out_order);
+/* One batch from host buffers to host buffers (arguments as ffx_sharded_stage_owned; results of the OWNED queries,
+ * first-stage order, out_order = positions in the rank's own list): the block is cut into n_slices slices of whole queries
+ * (0: by size; the same on every rank) that go through stage / run / fetch_async back to back, so uploads, routing,
+ * scoring, exchange, merge and downloads of successive slices overlap.  The multi-GPU form of ffx_score. */
+int ffx_sharded_score(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
+                      const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, double alpha,
+                      uint32_t flags, int32_t n_slices, float* out_ff, float* out_interp, int32_t* out_order, int64_t* bad_pair);
 int ffx_sharded_sync(ffx_sharded* s);
 /* results of the OWNED queries, first-stage order (ffx_sharded_owned tells which) */
 int ffx_sharded_fetch(ffx_sharded* s, float* out_ff, float* out_interp, int32_t* out_order);

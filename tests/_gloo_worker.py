@@ -19,7 +19,7 @@ for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
 
 import ffx_oracle as fo  # noqa: E402
 from _cases import MODE_NO, load_scoring_case  # noqa: E402
-from fast_forward_amd.sharded import doc_partition, query_partition, route  # noqa: E402
+from fast_forward_amd.sharded import assemble_local, doc_partition, query_partition, route, route_owned  # noqa: E402
 
 
 def exchange(send, send_counts, recv_counts):
@@ -68,6 +68,22 @@ def main():
             assert np.array_equal(dense.view(np.uint32), want_ff[lo:hi].view(np.uint32)), (name, mode, rank)
             assert np.array_equal(interp.view(np.uint32), want_i[lo:hi].view(np.uint32)), (name, mode, rank)
             checked += hi - lo
+            # the same batch handed over the way a serving loop would: every rank sees ONLY the queries it owns
+            # (ffx_sharded_stage_owned).  Message A: per-query counts to the holders; message B: the ordinals.
+            qb = query_partition(len(pair_off2) - 1, world)
+            own = route_owned(pair_off2[qb[rank]:qb[rank + 1] + 1] - lo, pair_ids2[lo:hi], rank, world, doc_bounds=doc_bounds)
+            n_own_q = int(qb[rank + 1] - qb[rank])
+            cnt = exchange(torch.from_numpy(own.counts.reshape(-1)), [n_own_q] * world, np.diff(qb)).numpy()
+            ids_in = exchange(torch.from_numpy(own.send_ids), np.diff(own.starts), np.add.reduceat(cnt, qb[:-1]) if cnt.size else np.zeros(world, dtype=np.int64)).numpy() \
+                if all(qb[i + 1] > qb[i] for i in range(world)) else None
+            if ids_in is not None:
+                got_by = np.add.reduceat(cnt, qb[:-1])
+                bounds_in = np.concatenate([[0], np.cumsum(got_by)])
+                l_off, l_ids, send_back = assemble_local(qb, [cnt[qb[o]:qb[o + 1]] for o in range(world)], [ids_in[bounds_in[o]:bounds_in[o + 1]] for o in range(world)])
+                assert np.array_equal(l_off, r.local_pair_off) and np.array_equal(l_ids, r.local_pair_ids) and np.array_equal(send_back, r.send_counts)
+                assert np.array_equal(own.slot, r.recv_slot) and np.array_equal(np.diff(own.starts), r.recv_counts)
+                recv2 = exchange(torch.from_numpy(local_ff), send_back, np.diff(own.starts)).numpy()
+                assert np.array_equal(recv2[own.slot].view(np.uint32), want_ff[lo:hi].view(np.uint32)), (name, mode, rank, "owner-routed")
         # every query is owned exactly once
         qb = query_partition(len(case.q_names), world)
         assert qb[0] == 0 and qb[-1] == len(case.q_names)

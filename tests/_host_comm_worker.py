@@ -19,7 +19,7 @@ for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
 import ffx_oracle as fo  # noqa: E402
 from _cases import MODE_NO, load_scoring_case  # noqa: E402
 from fast_forward_amd import native  # noqa: E402
-from fast_forward_amd.sharded import connect, doc_partition  # noqa: E402
+from fast_forward_amd.sharded import assemble_local, connect, doc_partition, query_partition, route_owned  # noqa: E402
 
 
 def main():
@@ -65,6 +65,20 @@ def main():
             assert np.array_equal(dense.view(np.uint32), want_ff[lo:hi].view(np.uint32)), (name, mode, rank)
             assert np.array_equal(interp.view(np.uint32), want_i[lo:hi].view(np.uint32)), (name, mode, rank)
             checked += hi - lo
+            # the same batch with every rank handed ONLY the queries it owns (the protocol of ffx_sharded_stage_owned over the
+            # native all-to-all-v: words travel as bit patterns): counts to the holders, ordinals to the holders, scores back
+            qb = query_partition(len(pair_off2) - 1, world)
+            own = route_owned(pair_off2[qb[rank]:qb[rank + 1] + 1] - lo, pair_ids2[lo:hi], rank, world, doc_bounds=doc_bounds)
+            n_own_q = int(qb[rank + 1] - qb[rank])
+            cnt = comm.exchange_host(own.counts.reshape(-1).view(np.float32), [n_own_q] * world, np.diff(qb)).view(np.int32)
+            got_by = np.array([int(cnt[qb[o]:qb[o + 1]].sum()) for o in range(world)], dtype=np.int64)
+            ids_in = comm.exchange_host(own.send_ids.view(np.float32), np.diff(own.starts), got_by).view(np.int32)
+            at = np.concatenate([[0], np.cumsum(got_by)])
+            l_off, l_ids, send_back = assemble_local(qb, [cnt[qb[o]:qb[o + 1]] for o in range(world)], [ids_in[at[o]:at[o + 1]] for o in range(world)])
+            assert np.array_equal(l_off, r["local_pair_off"]) and np.array_equal(l_ids, r["local_pair_ids"]) and np.array_equal(send_back, r["send_counts"])
+            assert np.array_equal(own.slot, r["recv_slot"])
+            recv2 = comm.exchange_host(local_ff, send_back, np.diff(own.starts))
+            assert np.array_equal(recv2[own.slot].view(np.uint32), want_ff[lo:hi].view(np.uint32)), (name, mode, rank, "owner-routed")
     total = int(comm.allreduce([checked])[0])
     # a growing payload re-creates the data segments (new generation): peers must re-map
     for n in (10, 300_000, 5, 2_000_000):

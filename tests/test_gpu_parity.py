@@ -594,6 +594,10 @@ def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding, spelling)
     assert result["n_gpus"] == world and result["parity_on_cpu_sample"] == "bit-exact"
     assert sum(result["roofline"]["gathered_rows_per_rank"]) == 90 * 700
     if sharding == "rows":
+        # every rank takes in ITS block of a fresh batch: offsets + (ordinal, first-stage score) per pair + its query vectors
+        assert sum(result["stage_h2d_bytes_per_rank"]) == (90 + world) * 8 + 90 * 700 * 8 + 90 * 768 * 4
+        assert max(result["stage_h2d_bytes_per_rank"]) < 1.2 * sum(result["stage_h2d_bytes_per_rank"]) / world
+        assert result["fresh_batch_step_ms"] > 0 and result["host_to_host_batch_ms"] > 0
         assert result["transport"] == "host" and len(result["exchange_bytes_per_rank"]["sent"]) == world
         assert sum(result["owned_pairs_per_rank"]) == 90 * 700
         assert sum(result["exchange_bytes_per_rank"]["sent"]) == sum(result["exchange_bytes_per_rank"]["received"])
@@ -653,6 +657,9 @@ def test_rehearsal_of_one_rank_of_eight_on_one_gpu():
     assert (reh["as_rank"], reh["of"]) == (5, 8) and reh["owned_queries"] == 20 and reh["owned_pairs"] == 20 * 900
     assert abs(reh["local_pairs"] - 160 * 900 / 8) < 0.1 * 160 * 900 / 8
     assert result["parity_on_cpu_sample"].startswith("bit-exact on the ")
+    # the fresh-batch loop of the rehearsed rank: its own block goes up (1/8 of the batch), the peers' messages come out of the inbox
+    assert result["stage_h2d_bytes_per_rank"][5] == 21 * 8 + 20 * 900 * 8 + 20 * 768 * 4
+    assert reh["fresh_batch_step_ms"] > 0
 
 
 def test_device_routing_equals_host_routing(monkeypatch):
@@ -715,6 +722,21 @@ def test_device_routing_equals_host_routing(monkeypatch):
                     assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     comm.close()
     shard.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_owner_routed_fresh_batches_with_ranks_sharing_the_gpu(world):
+    """ffx_sharded_stage_owned / ffx_sharded_score: every rank is handed only the queries it owns, finds the holders on the
+    device and sends them the ordinals in a first all-to-all; results equal the single-GPU scorer over the whole index bit for
+    bit -- sliced and unsliced, document ranges and explicit holders, every mode, several different batches in flight, and
+    an ordinal without rows is the same IndexError on every rank (tests/_sharded_owned_worker.py)."""
+    from pathlib import Path
+
+    from test_sharded_native import run_ranks
+
+    codes, outs = run_ranks(world, Path(__file__).resolve().parent / "_sharded_owned_worker.py", timeout=600)
+    assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    assert f"owner-routed world={world}:" in outs[0][0] and "checked bit-exact" in outs[0][0]
 
 
 def test_sharded_bench_leg_also_runs_under_torchrun():

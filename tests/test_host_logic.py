@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = native.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ffx_abi_version() == 2
+    assert lib.ffx_abi_version() == 3
 
 
 def test_no_cpu_fallback(have_gpu):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from fast_forward_amd import native
-from fast_forward_amd.sharded import doc_partition, query_partition, route
+from fast_forward_amd.sharded import assemble_local, doc_partition, query_partition, route, route_owned
 
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -85,6 +85,42 @@ def test_native_route_equals_numpy_route(seed):
             held = native.route(pair_off, local, rank, world, holder=holder)
             for key in ("local_pair_off", "local_pair_ids", "send_counts", "recv_counts", "recv_slot"):
                 assert np.array_equal(held[key], got[key]), key
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_owner_side_routing_delivers_what_full_routing_derives(seed):
+    """ffx_sharded_stage_owned's protocol (its NumPy statement): every rank is handed only the block of queries it OWNS,
+    groups its candidates by holder (message A: per-query counts, message B: holder-local ordinals) and the messages of
+    the owners in rank order ARE each holder's local CSR; the owner-side arrival slots are the ones the full routing
+    derives from the whole batch.  Document ranges and explicit holders, ragged and empty queries, empty blocks."""
+    rng = np.random.default_rng(100 + seed)
+    n_docs, n_q = int(rng.integers(50, 3000)), int(rng.integers(1, 40))
+    per_doc = rng.integers(1, 6, size=n_docs)
+    doc_off = np.concatenate([[0], np.cumsum(per_doc)])
+    lens = rng.integers(0, min(n_docs, 200), size=n_q)
+    lens[rng.integers(0, n_q)] = 0
+    pair_off = np.concatenate([[0], np.cumsum(lens)])
+    pair_ids = np.concatenate([rng.choice(n_docs, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+    for world in (1, 2, 3, 5, 8):
+        bounds = doc_partition(doc_off, world)
+        qb = query_partition(n_q, world)
+        who = (np.searchsorted(bounds, pair_ids, side="right") - 1).astype(np.int32)
+        for explicit in (False, True):
+            owned = []
+            for r in range(world):
+                lo, hi = pair_off[qb[r]], pair_off[qb[r + 1]]
+                if explicit:
+                    owned.append(route_owned(pair_off[qb[r]:qb[r + 1] + 1] - lo, (pair_ids - bounds[who])[lo:hi], r, world, holder=who[lo:hi]))
+                else:
+                    owned.append(route_owned(pair_off[qb[r]:qb[r + 1] + 1] - lo, pair_ids[lo:hi], r, world, doc_bounds=bounds))
+            for h in range(world):
+                want = route(pair_off, pair_ids, bounds, h, world)
+                l_off, l_ids, back = assemble_local(qb, [owned[o].counts[h] for o in range(world)],
+                                                    [owned[o].send_ids[owned[o].starts[h]:owned[o].starts[h + 1]] for o in range(world)])
+                assert np.array_equal(l_off, want.local_pair_off) and np.array_equal(l_ids, want.local_pair_ids) and np.array_equal(back, want.send_counts)
+                assert np.array_equal(np.diff(owned[h].starts), want.recv_counts) and np.array_equal(owned[h].slot, want.recv_slot)
+    with pytest.raises(IndexError):
+        route_owned(np.array([0, 1]), np.array([10]), 0, 2, doc_bounds=np.array([0, 5, 10]))
 
 
 def test_native_route_large_batch_uses_threads_and_stays_exact():
