@@ -84,6 +84,9 @@ def parse_args():
                     help="rccl (default): RCCL over xGMI, one GPU per rank; host: the exchange staged through shared "
                          "memory, so N ranks can rehearse on ONE GPU (RCCL refuses ranks that share a device)")
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"], help="older spelling of --transport (gloo = host)")
+    ap.add_argument("--fresh-queries", default="allgather", choices=["allgather", "replicate"],
+                    help="fresh batches of the sharded leg: every rank uploads the vectors of the queries it OWNS and the ranks all-gather them on the "
+                         "routing lane (intake per rank ~ 1/N), or every rank uploads ALL query vectors over its own PCIe link (no exchange)")
     ap.add_argument("--require-rccl", action="store_true",
                     help="N > 1: exit non-zero if RCCL cannot be brought up on every rank instead of falling back to the shared-memory "
                          "transport (a fallback line is marked `\"scaling\": \"invalid: host transport\"` and `\"value_is_rccl\": false`)")
@@ -546,6 +549,11 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
     own_off = np.arange(n_own_q + 1, dtype=np.int64) * args.k
     own_q = native.pinned_empty((max(n_own_q, 1), args.dim), np.float32)[:n_own_q]
     own_q[...] = queries[q_lo:q_hi]
+    replicate = args.fresh_queries == "replicate"
+    all_q = None
+    if replicate:
+        all_q = native.pinned_empty(queries.shape, np.float32)
+        all_q[...] = queries
     batches, inboxes, keep_alive = [], [], []
     for b in range(n_distinct):
         seed = args.seed + 1000 * (b + 1)
@@ -555,7 +563,7 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
         batches.append((seed, p_ids, p_sp))
         if rehearsal and world > 1:
             # what the ranks that do not exist would send this one on the routing lane, in the order the lane receives it:
-            # per-query counts, their query vectors, the ordinals of the candidates this rank holds
+            # their query vectors, per-query counts, the ordinals of the candidates this rank holds
             parts_cnt, parts_q, parts_ids = [], [], []
             for o in range(world):
                 if o == rank:
@@ -565,7 +573,7 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
                 parts_cnt.append(mine.reshape(-1, args.k).sum(axis=1).astype(np.int32))
                 parts_q.append(queries[int(qb[o]):int(qb[o + 1])].reshape(-1).view(np.int32))
                 parts_ids.append((o_ids[mine] - doc_bounds[rank]).astype(np.int32))
-            words = np.concatenate(parts_cnt + parts_q + parts_ids)
+            words = np.concatenate(([] if replicate else parts_q) + parts_cnt + parts_ids)
             box = native.DeviceIndex(max(1, -(-words.shape[0] // 256)), 256, device=comm.device, dtype=np.float32)
             padded = np.zeros(box.capacity * 256, dtype=np.int32)
             padded[:words.shape[0]] = words
@@ -577,7 +585,9 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
         seed, p_ids, p_sp = batches[b % n_distinct]
         if inboxes:
             comm.rehearsal_inbox(*inboxes[b % n_distinct])
-        scorer.stage_owned(qb, own_q, own_off, p_ids, p_sp, mode)
+        if replicate:
+            scorer.stage_queries(all_q)
+        scorer.stage_owned(qb, None if replicate else own_q, own_off, p_ids, p_sp, mode)
         return seed
 
     seed = stage(0)
@@ -602,7 +612,7 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
     rows = comm.allgather_array(np.array([float(st[k]) for k in keys], dtype=np.float64))
     line = {
         "fresh_batch_step_ms": elapsed * 1e3 / args.steps,
-        "fresh_batch_queries_per_s": args.queries / (elapsed / args.steps),
+        "fresh_batch_queries_per_s": args.queries / (elapsed / args.steps), "fresh_batch_query_vectors": args.fresh_queries,
         "fresh_batch_note": f"{args.steps} DIFFERENT batches back to back ({n_distinct} distinct candidate sets in page-locked host memory, cycled), every rank handed only "
                             "the queries it owns: upload of the rank's block, holders found on the device, ordinals to the holders in a first all-to-all on the routing "
                             "lane while the previous batch is scored; then local gather_dot, all-to-all of scores, owner-side merge + order.  Results stay in HBM",
@@ -620,7 +630,7 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
             sd, p_ids, p_sp = batches[b % n_distinct]
             comm.barrier()
             tb = time.perf_counter()
-            scorer.score_owned(qb, own_q, own_off, p_ids, p_sp, mode, args.alpha, exact_sum=exact, sort=args.sort, out=outs)
+            scorer.score_owned(qb, own_q, own_off, p_ids, p_sp, mode, args.alpha, exact_sum=exact, sort=args.sort, out=outs)  # (vectors: all-gathered)
             times.append(float(comm.allreduce([time.perf_counter() - tb], native.OP_MAX)[0]))
             seed = sd
         line.update({"host_to_host_batch_ms": min(times[1:]) * 1e3, "host_to_host_queries_per_s": args.queries / min(times[1:]),

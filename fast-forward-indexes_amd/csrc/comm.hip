@@ -176,10 +176,9 @@ struct ffx_comm {
   // communicator execute in issue order).  Created on first use (collective).
   ncclComm_t nccl_route = nullptr;
   hipStream_t route_stream = nullptr;
-  // rehearsal: what stands in for the peers' memory -- a zeroed source the "received" slices come out of and a sink
-  // the "sent" slices go into (floats each, grown as needed)
+  // rehearsal: what stands in for the peers' memory -- a zeroed source the "received" pieces come out of (grown as needed);
+  // the "sent" pieces are read and stored nowhere (the peer's memory is not on this GPU)
   float* reh_src = nullptr;
-  float* reh_sink = nullptr;
   size_t reh_cap = 0;
   // rehearsal of the routing lane: what the peers WOULD have sent (made by the caller, who knows the whole batch),
   // consumed piece by piece by the exchanges of that lane; zeros once it is used up (ffx_comm_rehearsal_inbox)
@@ -323,7 +322,6 @@ void destroy_comm(ffx_comm* c) {
   if (c->ctl_host) (void)hipHostFree(c->ctl_host);
   if (c->stage_dev) (void)hipFree(c->stage_dev);
   if (c->reh_src) (void)hipFree(c->reh_src);
-  if (c->reh_sink) (void)hipFree(c->reh_sink);
   if (c->hdr) {
     if (c->seg[c->rank].p) shm_unlink(seg_name(c, c->rank, c->seg[c->rank].gen).c_str());
     for (int r = 0; r < c->world; ++r) c->seg[r].unmap();
@@ -625,16 +623,65 @@ struct RehearsalPieces {
   const uint32_t* flag;
 };
 
-// ONE kernel on a handful of workgroups (RCCL groups its sends and receives into one kernel on a handful of workgroups too)
-__global__ void __launch_bounds__(256) rehearsal_exchange_kernel(RehearsalPieces pc) {
-  for (int i = 0; i < pc.count; ++i) {
-    const uint32_t* __restrict__ s = pc.src[i];
-    uint32_t* __restrict__ d = pc.dst[i];
-    const long n = pc.n[i];
-    // pieces start at arbitrary word offsets: scalar head up to 16-byte alignment of the destination is not worth it
-    // for a stand-in; 4-byte accesses, fully coalesced
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) d[e] = s[e];
+// n words from s to d by `nthreads` threads: 16-byte stores, 16-byte loads where the source allows, four of them in flight
+// per thread (a copy loop that keeps about as many bytes in flight per workgroup as a collective library's does; with
+// 4-byte accesses the stand-in is latency-bound beside an HBM-saturating kernel and says more about itself than about
+// the step it rehearses)
+__device__ inline void copy_words(const uint32_t* __restrict__ s, uint32_t* __restrict__ d, long n, long tid, long nthreads) {
+  if (!d) {  // a piece that leaves this GPU: it is read here and written elsewhere
+    uint32_t acc = 0;
+    long head = (long)(((16 - ((uintptr_t)s & 15)) & 15) >> 2);
+    if (head > n) head = n;
+    for (long e = tid; e < head; e += nthreads) acc ^= s[e];
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(s + head);
+    const long n4 = (n - head) >> 2;
+    long e = tid;
+    for (; e + 3 * nthreads < n4; e += 4 * nthreads) {
+      const uint4 a = s4[e], b = s4[e + nthreads], c = s4[e + 2 * nthreads], f = s4[e + 3 * nthreads];
+      acc ^= a.x ^ a.w ^ b.x ^ b.w ^ c.x ^ c.w ^ f.x ^ f.w;
+    }
+    for (; e < n4; e += nthreads) acc ^= s4[e].x ^ s4[e].w;
+    for (long e2 = head + (n4 << 2) + tid; e2 < n; e2 += nthreads) acc ^= s[e2];
+    if (acc == 0x9E3779B9u && n < 0) const_cast<uint32_t*>(s)[0] = acc;  // (never: keeps the loads)
+    return;
   }
+  long head = (long)(((16 - ((uintptr_t)d & 15)) & 15) >> 2);
+  if (head > n) head = n;
+  for (long e = tid; e < head; e += nthreads) d[e] = s[e];
+  s += head;
+  d += head;
+  n -= head;
+  const long n4 = n >> 2;
+  uint4* __restrict__ d4 = reinterpret_cast<uint4*>(d);
+  if (((uintptr_t)s & 15) == 0) {
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(s);
+    long e = tid;
+    for (; e + 3 * nthreads < n4; e += 4 * nthreads) {
+      const uint4 a = s4[e], b = s4[e + nthreads], c = s4[e + 2 * nthreads], f = s4[e + 3 * nthreads];
+      d4[e] = a;
+      d4[e + nthreads] = b;
+      d4[e + 2 * nthreads] = c;
+      d4[e + 3 * nthreads] = f;
+    }
+    for (; e < n4; e += nthreads) d4[e] = s4[e];
+  } else {
+    for (long e = tid; e < n4; e += nthreads) {
+      uint4 v;
+      v.x = s[4 * e];
+      v.y = s[4 * e + 1];
+      v.z = s[4 * e + 2];
+      v.w = s[4 * e + 3];
+      d4[e] = v;
+    }
+  }
+  for (long e = (n4 << 2) + tid; e < n; e += nthreads) d[e] = s[e];
+}
+
+// ONE kernel on a handful of workgroups (RCCL groups its sends and receives into one kernel on a handful of workgroups too)
+// (32 registers per lane: next to gather_dot's six waves per SIMD that is what is left -- a kernel that needs more is not
+// scheduled until gather_dot has drained, and a stand-in that waits for the kernel it is meant to run beside rehearses nothing)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) rehearsal_exchange_kernel(RehearsalPieces pc) {
+  for (int i = 0; i < pc.count; ++i) copy_words(pc.src[i], pc.dst[i], pc.n[i], (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // The harsher stand-in (FFX_DEBUG_VARIANT=rehearsal_paced[=GB/s per link]): what RCCL's send/recv kernel looks like to
@@ -642,7 +689,7 @@ __global__ void __launch_bounds__(256) rehearsal_exchange_kernel(RehearsalPieces
 // its piece in 64 KiB chunks and, between chunks, SPINNING on a flag in memory until the chunk "would have arrived" over
 // a link of the given rate (default 50 GB/s, a third of an xGMI link's peak).  The workgroups therefore hold their CU
 // slots and keep issuing polls for as long as the fabric would take, next to whatever the compute stream runs.
-__global__ void __launch_bounds__(256) rehearsal_exchange_paced_kernel(RehearsalPieces pc) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) rehearsal_exchange_paced_kernel(RehearsalPieces pc) {
   const int i = blockIdx.x;
   if (i >= pc.count) return;
   const uint32_t* __restrict__ s = pc.src[i];
@@ -653,12 +700,12 @@ __global__ void __launch_bounds__(256) rehearsal_exchange_paced_kernel(Rehearsal
   long done = 0;
   while (done < n) {
     const long m = n - done < kChunk ? n - done : kChunk;
-    for (long e = threadIdx.x; e < m; e += blockDim.x) d[done + e] = s[done + e];
+    copy_words(s + done, d ? d + done : nullptr, m, threadIdx.x, blockDim.x);
     done += m;
     const long long due = t0 + (long long)((float)(done >> 8) * pc.ns_per_kib * 0.1f);  // ticks of 10 ns
     unsigned int seen = 0;
     while (wall_clock64() < due) seen += __builtin_nontemporal_load(pc.flag);  // poll memory, as a receiver waiting for its peer does
-    if (seen == 0xFFFFFFFFu && threadIdx.x == 0) d[0] = s[0];  // (never: keeps the polls alive)
+    if (seen == 0xFFFFFFFFu && threadIdx.x == 0 && d) d[0] = s[0];  // (never: keeps the polls alive)
   }
 }
 
@@ -669,18 +716,16 @@ static int rehearsal_exchange(ffx_comm* c, int lane, const Piece* pc, hipStream_
   if (need > c->reh_cap) {
     C_HIP(hipStreamSynchronize(st));
     if (c->reh_src) (void)hipFree(c->reh_src);
-    if (c->reh_sink) (void)hipFree(c->reh_sink);
-    c->reh_src = c->reh_sink = nullptr;
+    c->reh_src = nullptr;
     c->reh_cap = 0;
     const size_t want = need + need / 8;
     C_HIP(hipMalloc(reinterpret_cast<void**>(&c->reh_src), want * sizeof(float)));
-    C_HIP(hipMalloc(reinterpret_cast<void**>(&c->reh_sink), want * sizeof(float)));
     C_HIP(hipMemset(c->reh_src, 0, want * sizeof(float)));
     c->reh_cap = want;
   }
   RehearsalPieces k;
   k.count = 0;
-  int64_t s_at = 0, r_at = 0;
+  int64_t r_at = 0;
   for (int p = 0; p < c->world; ++p) {
     if (p == c->rank) {  // exactly what the RCCL path does with the piece a rank keeps
       if (pc[p].n_send > 0 && pc[p].recv != pc[p].send)
@@ -689,9 +734,8 @@ static int rehearsal_exchange(ffx_comm* c, int lane, const Piece* pc, hipStream_
     }
     if (pc[p].n_send > 0) {  // what peer p would read out of this GPU
       k.src[k.count] = static_cast<const uint32_t*>(pc[p].send);
-      k.dst[k.count] = reinterpret_cast<uint32_t*>(c->reh_sink) + s_at;
+      k.dst[k.count] = nullptr;  // read, not stored: the peer's memory is not on this GPU
       k.n[k.count++] = (long)pc[p].n_send;
-      s_at += pc[p].n_send;
     }
     if (pc[p].n_recv > 0) {  // what peer p would write into this GPU: out of the inbox (routing lane), else zeros
       const uint32_t* from = reinterpret_cast<const uint32_t*>(c->reh_src) + r_at;
@@ -1002,6 +1046,8 @@ struct ffx_sharded {
   ffx_merge* merges[kSlots] = {nullptr, nullptr, nullptr};
   hipStream_t compute = nullptr;
   hipStream_t out = nullptr;  // downloads of finished batches (ffx_sharded_fetch_async), created on first use
+  hipStream_t up = nullptr;   // uploads of a fresh batch's first-stage scores and query vectors, created on first use
+  hipEvent_t ids_up = nullptr;  // the ordinals of the batch being staged have gone up (the link is free for the rest)
   hipEvent_t x_begin = nullptr, x_end = nullptr, m_begin = nullptr, m_end = nullptr;  // timing of the last step's exchange and merge
   hipEvent_t r_begin = nullptr, r_end = nullptr;                                      // ... and of the last batch's routing
   struct Slot {
@@ -1017,6 +1063,7 @@ struct ffx_sharded {
     int merge = 0;  // the merge that holds this batch's owner-side state
     // ordering between the streams (no timing): the batch is routed / scored / its scores have left / it is merged
     hipEvent_t routed = nullptr, scored = nullptr, sent = nullptr, merged = nullptr;
+    hipEvent_t queries_up = nullptr, sparse_up = nullptr;  // this rank's own query vectors / first-stage scores have been uploaded
     bool routed_valid = false, scored_valid = false, sent_valid = false, merged_valid = false;
   } slot[kSlots];
   hipEvent_t out_done[kSlots] = {nullptr, nullptr, nullptr};  // per MERGE: its results have been copied out
@@ -1059,7 +1106,9 @@ struct ffx_sharded {
     T* as() const { return static_cast<T*>(p); }
   };
   DevArr d_ids, d_off, d_who, d_cnt, d_local_off, d_local_ids, d_pos, d_keys, d_arrival, d_slot, d_small, d_tmp;
-  DevArr d_held, d_start, d_sendids, d_qcnt, d_verdict;  // owner-side routing (ffx_sharded_stage_owned)
+  DevArr d_held, d_start, d_sendids, d_qcnt, d_verdict, d_cntq, d_tiles;  // owner-side routing (ffx_sharded_stage_owned)
+  std::vector<int32_t> tile_first;
+  std::vector<int64_t> tile_p0, tile_hi;
   void* host_small = nullptr;                            // page-locked read-back block of the staging
   size_t host_small_cap = 0;
   // routing outputs, kept between calls (a fresh 140 MB array costs more in page faults than the routing itself)
@@ -1072,6 +1121,7 @@ struct ffx_sharded {
   int last = 0;
   // per-batch intake of the owner-routed form, for the stats
   int64_t stage_h2d_bytes = 0, stage_route_send_bytes = 0, stage_route_recv_bytes = 0;
+  int64_t staged_query_bytes = 0;  // of ffx_sharded_stage_queries for the batch being staged
   double stage_host_ms = 0.0;
 };
 
@@ -1410,69 +1460,143 @@ __device__ inline int route_holder_of(int64_t id, const RouteBounds& bounds, int
   return lo;
 }
 
-__global__ void __launch_bounds__(256)
-own_count_kernel(const int64_t* __restrict__ own_off, const int32_t* __restrict__ ids, const int32_t* __restrict__ held, RouteBounds bounds, int world,
-                 int n_q, int32_t* __restrict__ cnt, unsigned long long* __restrict__ bad) {
-  __shared__ unsigned int hist[kMaxWorld];
-  const int q = blockIdx.x;
-  if (threadIdx.x < kMaxWorld) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int64_t p = own_off[q] + threadIdx.x; p < own_off[q + 1]; p += blockDim.x) {
-    const int h = held ? held[p] : route_holder_of(ids[p], bounds, world);
-    if (h < 0 || h >= world)
-      atomicMin(bad, (unsigned long long)p);
-    else
-      atomicAdd(&hist[h], 1u);
+// A TILE is up to kTile = 1024 consecutive candidates of one owned query (tile_p0 / tile_hi: its first candidate and the
+// end of its query, made on the host from the offsets): a workgroup per tile, four passes of 256 candidates whose loads are
+// all issued before anything is ranked, one barrier -- thousands of independent workgroups with short dependency chains
+// instead of one workgroup per query walking it in twenty dependent steps next to a kernel that fills every CU.
+// The distinct holders among a wave's 64 candidates are taken one at a time (ballots): `before` = how many of the lanes
+// below hold the same holder's candidate; the wave's count per holder lands in its own row of LDS.
+constexpr int kTile = 1024, kTilePasses = kTile / 256;
+
+__device__ inline int wave_rank_by_holder(int h, bool valid, int lane, int* wave_row) {
+  int before = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int hh = __shfl(h, leader, 64);
+    const unsigned long long same = __ballot(valid && h == hh);
+    if (valid && h == hh) before = __popcll(same & ((1ull << lane) - 1ull));
+    if (lane == leader) wave_row[hh] = __popcll(same);
+    todo &= ~same;
   }
-  __syncthreads();
-  if (threadIdx.x < world) cnt[(size_t)threadIdx.x * n_q + q] = (int32_t)hist[threadIdx.x];
+  return before;
 }
 
 __global__ void __launch_bounds__(256)
-own_place_kernel(const int64_t* __restrict__ own_off, const int32_t* __restrict__ ids, const int32_t* __restrict__ held, RouteBounds bounds, int world,
-                 int n_q, const int32_t* __restrict__ start, int32_t* __restrict__ slot, int32_t* __restrict__ send_ids) {
-  __shared__ int run[kMaxWorld];
-  __shared__ int wave_cnt[4][kMaxWorld];
-  const int q = blockIdx.x;
+own_count_kernel(const int64_t* __restrict__ tile_p0, const int64_t* __restrict__ tile_hi, const int32_t* __restrict__ ids, const int32_t* __restrict__ held,
+                 RouteBounds bounds, int world, int n_tiles, int32_t* __restrict__ cnt, unsigned long long* __restrict__ bad) {
+  __shared__ int wave_cnt[kTilePasses * 4][kMaxWorld];
+  const int t = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < world) run[threadIdx.x] = start[(size_t)threadIdx.x * n_q + q];
-  const int64_t lo = own_off[q], hi = own_off[q + 1];
-  for (int64_t p0 = lo; p0 < hi; p0 += blockDim.x) {
-    for (int i = lane; i < world; i += 64) wave_cnt[wave][i] = 0;
-    const int64_t p = p0 + threadIdx.x;
-    int h = -1;
-    if (p < hi) h = held ? held[p] : route_holder_of(ids[p], bounds, world);
-    const bool valid = h >= 0 && h < world;  // (an id no rank holds was reported by the count pass and gets no slot)
-    // the distinct holders of this wave's 64 candidates, one at a time: rank of every candidate among its holder's
-    int before = 0;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int hh = __shfl(h, leader, 64);
-      const unsigned long long same = __ballot(valid && h == hh);
-      if (valid && h == hh) before = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) wave_cnt[wave][hh] = __popcll(same);
-      todo &= ~same;
+  for (int j = 0; j < kTilePasses; ++j)
+    for (int i = lane; i < world; i += 64) wave_cnt[j * 4 + wave][i] = 0;
+  const int64_t p0 = tile_p0[t] + threadIdx.x, hi = tile_hi[t];
+  int h[kTilePasses];
+#pragma unroll
+  for (int j = 0; j < kTilePasses; ++j) {
+    const int64_t p = p0 + j * 256;
+    h[j] = p < hi ? (held ? held[p] : ids[p]) : -1;  // (an ordinal for now: every load is in flight before the first is used)
+  }
+#pragma unroll
+  for (int j = 0; j < kTilePasses; ++j) {
+    const int64_t p = p0 + j * 256;
+    if (p < hi) {
+      if (!held) h[j] = route_holder_of(h[j], bounds, world);
+      if (h[j] < 0 || h[j] >= world) atomicMin(bad, (unsigned long long)p);
     }
-    __syncthreads();
-    if (valid) {
-      int at = run[h] + before;
-      for (int w = 0; w < wave; ++w) at += wave_cnt[w][h];
+    (void)wave_rank_by_holder(h[j], p < hi && h[j] >= 0 && h[j] < world, lane, wave_cnt[j * 4 + wave]);
+  }
+  __syncthreads();
+  if (threadIdx.x < world) {
+    int total = 0;
+    for (int r = 0; r < kTilePasses * 4; ++r) total += wave_cnt[r][threadIdx.x];
+    cnt[(size_t)threadIdx.x * n_tiles + t] = total;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+own_place_kernel(const int64_t* __restrict__ tile_p0, const int64_t* __restrict__ tile_hi, const int32_t* __restrict__ ids, const int32_t* __restrict__ held,
+                 RouteBounds bounds, int world, int n_tiles, const int32_t* __restrict__ start, int32_t* __restrict__ slot, int32_t* __restrict__ send_ids) {
+  __shared__ int wave_cnt[kTilePasses * 4][kMaxWorld];
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = 0; j < kTilePasses; ++j)
+    for (int i = lane; i < world; i += 64) wave_cnt[j * 4 + wave][i] = 0;
+  const int64_t p0 = tile_p0[t] + threadIdx.x, hi = tile_hi[t];
+  int32_t id[kTilePasses];
+  int h[kTilePasses], before[kTilePasses];
+#pragma unroll
+  for (int j = 0; j < kTilePasses; ++j) {
+    const int64_t p = p0 + j * 256;
+    id[j] = p < hi ? ids[p] : 0;
+    h[j] = p < hi && held ? held[p] : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < kTilePasses; ++j) {
+    const int64_t p = p0 + j * 256;
+    if (p < hi && !held) h[j] = route_holder_of(id[j], bounds, world);
+    if (h[j] >= world) h[j] = -1;  // (an id no rank holds was reported by the count pass and gets no slot)
+    before[j] = wave_rank_by_holder(h[j], p < hi && h[j] >= 0, lane, wave_cnt[j * 4 + wave]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kTilePasses; ++j) {
+    const int64_t p = p0 + j * 256;
+    if (p >= hi) continue;
+    if (h[j] >= 0) {
+      int at = start[(size_t)h[j] * n_tiles + t] + before[j];
+      for (int r = 0; r < j * 4 + wave; ++r) at += wave_cnt[r][h[j]];
       slot[p] = at;
-      send_ids[at] = held ? ids[p] : (int32_t)((int64_t)ids[p] - bounds.b[h]);
-    } else if (p < hi) {
+      send_ids[at] = held ? id[j] : (int32_t)((int64_t)id[j] - bounds.b[h[j]]);
+    } else {
       slot[p] = 0;  // never read: the call fails
     }
-    __syncthreads();
-    if (threadIdx.x < world) run[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
-    __syncthreads();
   }
 }
 
-// small[1 + h] = how many of the owned candidates rank h holds (h < world)
-__global__ void own_totals_kernel(const int32_t* __restrict__ start, int world, int n_q, long long* __restrict__ small) {
-  const int h = threadIdx.x;
-  if (h < world) small[1 + h] = (long long)start[(size_t)(h + 1) * n_q] - (long long)start[(size_t)h * n_q];
+// per-query counts out of the tile scan: cnt_q[h][q] = start[h][first tile of q + 1] - start[h][first tile of q] (message A);
+// small[1 + h] = how many of the owned candidates rank h holds
+__global__ void __launch_bounds__(256)
+own_qcount_kernel(const int32_t* __restrict__ start, const int32_t* __restrict__ tile_first, int world, int n_q, int n_tiles, int32_t* __restrict__ cnt_q,
+                  long long* __restrict__ small) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)world * n_q) {
+    const int h = (int)(i / n_q), q = (int)(i % n_q);
+    cnt_q[i] = start[(size_t)h * n_tiles + tile_first[q + 1]] - start[(size_t)h * n_tiles + tile_first[q]];
+  }
+  if (i < world) small[1 + i] = (long long)start[(size_t)(i + 1) * n_tiles] - (long long)start[(size_t)i * n_tiles];
+}
+
+// exchange C's words, made on the device: own_bad = the smallest position of one of MY candidates that no rank holds,
+// plan_bad = the smallest LOCAL position of an ordinal that names no row here (either ~0: none)
+__global__ void stage_verdict_kernel(const unsigned long long* __restrict__ own_bad, const unsigned long long* __restrict__ plan_bad, const int64_t* __restrict__ local_off,
+                                     RouteBounds qb, int world, int host_status, int32_t* __restrict__ out) {
+  const int r = threadIdx.x;
+  if (r >= world) return;
+  const unsigned long long ob = *own_bad, pb = plan_bad ? *plan_bad : ~0ull;
+  int32_t report = -1;
+  if (pb != ~0ull) {
+    const long long lo = local_off[qb.b[r]], hi = local_off[qb.b[r + 1]];
+    if ((long long)pb >= lo && (long long)pb < hi) report = (int32_t)((long long)pb - lo);
+  }
+  out[2 * r] = report;
+  out[2 * r + 1] = ob != ~0ull ? 1 : host_status ? 2 : pb != ~0ull ? 3 : 0;
+}
+
+// The streams beside the three that carry kernels (compute, the communicator's two lanes), created on first use: `out`, on
+// which results leave, and `up`, on which a fresh batch's first-stage scores and query vectors arrive (DMA both ways, beside
+// the kernels).  A HIP stream is assigned one of FOUR hardware queues per priority class, and two streams on one queue
+// execute in issue order: compute, the two lanes and the default stream fill the normal class, so these two live in the
+// high (results: not behind the next batch's kernels, as ffx_score's result stream) and the low class.
+int sharded_io_streams(ffx_sharded* s) {
+  if (s->out && s->up) return FFX_OK;
+  C_HIP(hipSetDevice(s->device));
+  int least = 0, greatest = 0;
+  C_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  if (!s->out) C_HIP(hipStreamCreateWithPriority(&s->out, hipStreamNonBlocking, greatest));
+  if (!s->up) C_HIP(hipStreamCreateWithPriority(&s->up, hipStreamNonBlocking, least));
+  if (!s->ids_up) C_HIP(hipEventCreateWithFlags(&s->ids_up, hipEventDisableTiming));
+  return FFX_OK;
 }
 
 struct WidenI32 {
@@ -1527,6 +1651,23 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
     ffx_index_query_dim(s->shard, &d);
     return (int)d;
   }();
+  // tiles: up to kTile consecutive candidates of one query (what a workgroup of the count / place kernels takes)
+  std::vector<int64_t>& tile_hi = s->tile_hi;
+  std::vector<int64_t>& tile_p0 = s->tile_p0;
+  std::vector<int32_t>& tile_first = s->tile_first;
+  tile_hi.clear();
+  tile_p0.clear();
+  tile_first.resize((size_t)Qo + 1);
+  for (int64_t q = 0; q < Qo; ++q) {
+    tile_first[(size_t)q] = (int32_t)tile_p0.size();
+    for (int64_t p = own_off[q]; p < own_off[q + 1]; p += kTile) {
+      tile_p0.push_back(p);
+      tile_hi.push_back(own_off[q + 1]);
+    }
+  }
+  tile_first[(size_t)Qo] = (int32_t)tile_p0.size();
+  const int64_t n_tiles = (int64_t)tile_p0.size();
+  if ((int64_t)world * n_tiles > INT32_MAX - 2) return ffx_fail(FFX_BAD_ARG, "too many candidates for %d ranks in one batch: split the queries", world);
   // room: the owner-side state goes straight into the slot's merge, the local lists straight into its plan
   int64_t* m_off = nullptr;
   int32_t* m_slot = nullptr;
@@ -1534,11 +1675,13 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
   C_TRY(ffx_merge_adopt_begin(s->merges[t], Qo, Po, own_sparse != nullptr, &m_off, &m_slot, &m_sparse));
   float* d_q = nullptr;
   if (own_queries) C_TRY(ffx_plan_queries_room(s->plans[t], Q, &d_q));
-  const size_t pb = (size_t)std::max<int64_t>(Po, 1), n_cnt = (size_t)world * (size_t)Qo + 1;
+  const size_t pb = (size_t)std::max<int64_t>(Po, 1), n_cnt = (size_t)world * (size_t)n_tiles + 1, tb = (size_t)std::max<int64_t>(n_tiles, 1);
   C_TRY(s->d_ids.ensure(pb * 4));
   if (own_holder) C_TRY(s->d_held.ensure(pb * 4));
   C_TRY(s->d_cnt.ensure(n_cnt * 4));
   C_TRY(s->d_start.ensure(n_cnt * 4));
+  C_TRY(s->d_cntq.ensure(((size_t)world * (size_t)Qo + 1) * 4));
+  C_TRY(s->d_tiles.ensure(tb * 16 + ((size_t)Qo + 1) * 4 + 64));
   C_TRY(s->d_sendids.ensure(pb * 4));
   C_TRY(s->d_qcnt.ensure(((size_t)Q + 1) * 4));
   C_TRY(s->d_local_off.ensure(((size_t)Q + 1) * 8));
@@ -1557,34 +1700,71 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
   int64_t* h_local_off = reinterpret_cast<int64_t*>(h_small + small_words);
   int32_t* h_verdict = reinterpret_cast<int32_t*>(h_local_off + Q + 1);
   unsigned long long* d_bad = s->d_small.as<unsigned long long>();
-  // uploads: this rank's block only
+  int64_t* d_tile_p0 = s->d_tiles.as<int64_t>();
+  int64_t* d_tile_hi = d_tile_p0 + tb;
+  int32_t* d_tile_first = reinterpret_cast<int32_t*>(d_tile_hi + tb);
+  // uploads: this rank's block only, one after the other on a stream of their own (the link is the shared resource) in the
+  // order the routing stream needs them: the query vectors (their all-gather starts at once and runs while the ordinals are
+  // still on their way), the ordinals (the routing kernels), the first-stage scores (nobody before the owner-side merge).
+  C_TRY(sharded_io_streams(s));
+  hipStream_t io = s->up;
+  if (sl.scored_valid) C_HIP(hipStreamWaitEvent(io, sl.scored, 0));
+  if (sl.merged_valid) C_HIP(hipStreamWaitEvent(io, sl.merged, 0));
+  if (s->out_valid[t]) C_HIP(hipStreamWaitEvent(io, s->out_done[t], 0));
   C_HIP(hipEventRecord(s->r_begin, rs));
-  C_HIP(hipMemcpyAsync(m_off, own_off, ((size_t)Qo + 1) * 8, hipMemcpyHostToDevice, rs));
-  int64_t h2d = (Qo + 1) * 8;
-  if (Po > 0) {
-    C_HIP(hipMemcpyAsync(s->d_ids.p, own_ids, (size_t)Po * 4, hipMemcpyHostToDevice, rs));
-    h2d += Po * 4;
-    if (own_holder) {
-      C_HIP(hipMemcpyAsync(s->d_held.p, own_holder, (size_t)Po * 4, hipMemcpyHostToDevice, rs));
-      h2d += Po * 4;
-    }
-    if (own_sparse) {
-      C_HIP(hipMemcpyAsync(m_sparse, own_sparse, (size_t)Po * 4, hipMemcpyHostToDevice, rs));
-      h2d += Po * 4;
-    }
-  }
+  int64_t h2d = (Qo + 1) * 8 + s->staged_query_bytes;
+  s->staged_query_bytes = 0;
   if (own_queries && Qo > 0) {
-    C_HIP(hipMemcpyAsync(d_q + (size_t)q_lo * qdim, own_queries, (size_t)Qo * qdim * 4, hipMemcpyHostToDevice, rs));
+    C_HIP(hipMemcpyAsync(d_q + (size_t)q_lo * qdim, own_queries, (size_t)Qo * qdim * 4, hipMemcpyHostToDevice, io));
     h2d += Qo * (int64_t)qdim * 4;
   }
+  C_HIP(hipEventRecord(sl.queries_up, io));
+  if (Po > 0) {
+    C_HIP(hipMemcpyAsync(s->d_ids.p, own_ids, (size_t)Po * 4, hipMemcpyHostToDevice, io));
+    h2d += Po * 4;
+    if (own_holder) {
+      C_HIP(hipMemcpyAsync(s->d_held.p, own_holder, (size_t)Po * 4, hipMemcpyHostToDevice, io));
+      h2d += Po * 4;
+    }
+  }
+  C_HIP(hipEventRecord(s->ids_up, io));
+  if (own_sparse && Po > 0) {
+    C_HIP(hipMemcpyAsync(m_sparse, own_sparse, (size_t)Po * 4, hipMemcpyHostToDevice, io));
+    h2d += Po * 4;
+  }
+  C_HIP(hipEventRecord(sl.sparse_up, io));
+  C_HIP(hipMemcpyAsync(m_off, own_off, ((size_t)Qo + 1) * 8, hipMemcpyHostToDevice, rs));
+  if (n_tiles > 0) {
+    C_HIP(hipMemcpyAsync(d_tile_p0, tile_p0.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, rs));
+    C_HIP(hipMemcpyAsync(d_tile_hi, tile_hi.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, rs));
+  }
+  C_HIP(hipMemcpyAsync(d_tile_first, tile_first.data(), ((size_t)Qo + 1) * 4, hipMemcpyHostToDevice, rs));
+  int64_t route_send = 0, route_recv = 0;
+  // the query vectors of the whole batch, every rank contributing its block
+  if (own_queries && world > 1) {
+    Piece qp[kMaxWorld];
+    for (int r = 0; r < world; ++r) {
+      qp[r].send = d_q + (size_t)q_lo * qdim;
+      qp[r].n_send = Qo * qdim;
+      qp[r].recv = d_q + (size_t)q_bounds[r] * qdim;
+      qp[r].n_recv = (q_bounds[r + 1] - q_bounds[r]) * qdim;
+      if (r != rank) {
+        route_send += qp[r].n_send * 4;
+        route_recv += qp[r].n_recv * 4;
+      }
+    }
+    C_HIP(hipStreamWaitEvent(rs, sl.queries_up, 0));  // this rank's own vectors are in place
+    C_TRY(comm_alltoallv(s->comm, 1, qp, rs));
+  }
+  C_HIP(hipStreamWaitEvent(rs, s->ids_up, 0));
   C_HIP(hipMemsetAsync(d_bad, 0xFF, 8, rs));
   C_HIP(hipMemsetAsync(s->d_cnt.as<int32_t>() + (n_cnt - 1), 0, 4, rs));
   C_HIP(hipMemsetAsync(s->d_qcnt.as<int32_t>() + Q, 0, 4, rs));
   RouteBounds bounds;
   for (int r = 0; r <= world; ++r) bounds.b[r] = own_holder ? 0 : s->doc_bounds[(size_t)r];
   const int32_t* d_held = own_holder ? s->d_held.as<int32_t>() : nullptr;
-  if (Qo > 0) {
-    own_count_kernel<<<(unsigned)Qo, 256, 0, rs>>>(m_off, s->d_ids.as<int32_t>(), d_held, bounds, world, (int)Qo, s->d_cnt.as<int32_t>(), d_bad);
+  if (n_tiles > 0) {
+    own_count_kernel<<<(unsigned)n_tiles, 256, 0, rs>>>(d_tile_p0, d_tile_hi, s->d_ids.as<int32_t>(), d_held, bounds, world, (int)n_tiles, s->d_cnt.as<int32_t>(), d_bad);
     C_HIP(hipGetLastError());
   }
   {
@@ -1593,22 +1773,22 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
     C_TRY(s->d_tmp.ensure(std::max<size_t>(tmp, 16)));
     C_HIP(rocprim::exclusive_scan(s->d_tmp.p, tmp, s->d_cnt.as<int32_t>(), s->d_start.as<int32_t>(), (int32_t)0, n_cnt, rocprim::plus<int32_t>(), rs));
   }
-  if (Qo > 0) {
-    own_place_kernel<<<(unsigned)Qo, 256, 0, rs>>>(m_off, s->d_ids.as<int32_t>(), d_held, bounds, world, (int)Qo, s->d_start.as<int32_t>(), m_slot,
-                                                    s->d_sendids.as<int32_t>());
+  if (n_tiles > 0) {
+    own_place_kernel<<<(unsigned)n_tiles, 256, 0, rs>>>(d_tile_p0, d_tile_hi, s->d_ids.as<int32_t>(), d_held, bounds, world, (int)n_tiles, s->d_start.as<int32_t>(), m_slot,
+                                                         s->d_sendids.as<int32_t>());
     C_HIP(hipGetLastError());
   }
-  own_totals_kernel<<<1, kMaxWorld, 0, rs>>>(s->d_start.as<int32_t>(), world, (int)Qo, reinterpret_cast<long long*>(d_bad));
+  own_qcount_kernel<<<(unsigned)(((int64_t)world * Qo + kMaxWorld + 255) / 256), 256, 0, rs>>>(s->d_start.as<int32_t>(), d_tile_first, world, (int)Qo, (int)n_tiles,
+                                                                                            s->d_cntq.as<int32_t>(), reinterpret_cast<long long*>(d_bad));
   C_HIP(hipGetLastError());
   Piece pc[kMaxWorld];
   // exchange A: per-query counts to the holders
   for (int r = 0; r < world; ++r) {
-    pc[r].send = s->d_cnt.as<int32_t>() + (size_t)r * Qo;
+    pc[r].send = s->d_cntq.as<int32_t>() + (size_t)r * Qo;
     pc[r].n_send = Qo;
     pc[r].recv = s->d_qcnt.as<int32_t>() + q_bounds[r];
     pc[r].n_recv = q_bounds[r + 1] - q_bounds[r];
   }
-  int64_t route_send = 0, route_recv = 0;
   for (int r = 0; r < world; ++r)
     if (r != rank) {
       route_send += pc[r].n_send * 4;
@@ -1624,21 +1804,6 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
   }
   C_HIP(hipMemcpyAsync(h_small, s->d_small.p, small_words * 8, hipMemcpyDeviceToHost, rs));
   C_HIP(hipMemcpyAsync(h_local_off, s->d_local_off.p, ((size_t)Q + 1) * 8, hipMemcpyDeviceToHost, rs));
-  // the query vectors of the whole batch, every rank contributing its block (nothing below depends on them)
-  if (own_queries && world > 1) {
-    Piece qp[kMaxWorld];
-    for (int r = 0; r < world; ++r) {
-      qp[r].send = d_q + (size_t)q_lo * qdim;
-      qp[r].n_send = Qo * qdim;
-      qp[r].recv = d_q + (size_t)q_bounds[r] * qdim;
-      qp[r].n_recv = (q_bounds[r + 1] - q_bounds[r]) * qdim;
-      if (r != rank) {
-        route_send += qp[r].n_send * 4;
-        route_recv += qp[r].n_recv * 4;
-      }
-    }
-    C_TRY(comm_alltoallv(s->comm, 1, qp, rs));
-  }
   C_HIP(hipStreamSynchronize(rs));
   const unsigned long long bad_own = (unsigned long long)h_small[0];
   sl.send_counts.assign((size_t)world, 0);
@@ -1676,26 +1841,23 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
     }
     C_TRY(comm_alltoallv(s->comm, 1, pc, rs));
   }
-  if (status == FFX_OK) status = ffx_plan_adopt_finish(s->plans[t], h_local_off, rs, &bad_local);  // validates on rs, waits for it
-  // exchange C, two words per peer, so that EVERY rank leaves with the same verdict:
+  const unsigned long long* d_plan_bad = nullptr;
+  if (status == FFX_OK) status = ffx_plan_adopt_check(s->plans[t], h_local_off, rs, &d_plan_bad);  // validates on rs, asynchronously
+  // exchange C, two words per peer (made on the device: nothing to wait for), so that EVERY rank leaves with the same verdict:
   //   [0] to owner r: the first of ITS ordinals that names no row here (position in its message; -1: none)
   //   [1] to everybody: this rank's status -- 0 ok, 1 one of MY candidates is held by no rank, 3 somebody's ordinal names
   //       no row here (the owner concerned finds its position in word 0), 2 anything else
   std::string own_error;
   if (status != FFX_OK) own_error = ffx_last_error();
-  int bad_owner = -1;
-  if (status == FFX_NOT_FOUND && bad_local >= 0)
-    for (int r = 0; r < world; ++r)
-      if (bad_local >= h_local_off[q_bounds[r]] && bad_local < h_local_off[q_bounds[r + 1]]) bad_owner = r;
-  const int my_status = bad_own != ~0ull ? 1 : status == FFX_OK ? 0 : bad_owner >= 0 ? 3 : 2;
-  for (int r = 0; r < world; ++r) {
-    h_verdict[2 * r] = r == bad_owner ? (int32_t)(bad_local - h_local_off[q_bounds[r]]) : -1;
-    h_verdict[2 * r + 1] = my_status;
+  int32_t* d_v = s->d_verdict.as<int32_t>();
+  {
+    RouteBounds qbk;
+    for (int r = 0; r <= world; ++r) qbk.b[r] = q_bounds[r];
+    stage_verdict_kernel<<<1, kMaxWorld, 0, rs>>>(d_bad, status == FFX_OK ? d_plan_bad : nullptr, s->d_local_off.as<int64_t>(), qbk, world, status != FFX_OK ? 1 : 0, d_v);
+    C_HIP(hipGetLastError());
   }
   int32_t* h_got = h_verdict + 2 * kMaxWorld;
   if (world > 1) {
-    int32_t* d_v = s->d_verdict.as<int32_t>();
-    C_HIP(hipMemcpyAsync(d_v, h_verdict, (size_t)world * 8, hipMemcpyHostToDevice, rs));
     for (int r = 0; r < world; ++r) {
       pc[r].send = d_v + 2 * r;
       pc[r].n_send = 2;
@@ -1704,17 +1866,20 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
     }
     C_TRY(comm_alltoallv(s->comm, 1, pc, rs));
     C_HIP(hipMemcpyAsync(h_got, d_v + 2 * kMaxWorld, (size_t)world * 8, hipMemcpyDeviceToHost, rs));
-    C_HIP(hipStreamSynchronize(rs));
-    if (s->comm->transport == FFX_COMM_REHEARSAL)  // the words moved; the peers that would have written them do not exist
-      for (int r = 0; r < world; ++r)
-        if (r != rank) {
-          h_got[2 * r] = -1;
-          h_got[2 * r + 1] = 0;
-        }
   } else {
-    h_got[0] = h_verdict[0];
-    h_got[1] = h_verdict[1];
+    C_HIP(hipMemcpyAsync(h_got, d_v, 8, hipMemcpyDeviceToHost, rs));
   }
+  C_HIP(hipStreamSynchronize(rs));  // the second and last wait of the call
+  if (s->comm->transport == FFX_COMM_REHEARSAL)  // the words moved; the peers that would have written them do not exist
+    for (int r = 0; r < world; ++r)
+      if (r != rank) {
+        h_got[2 * r] = -1;
+        h_got[2 * r + 1] = 0;
+      }
+  if (status == FFX_OK) status = ffx_plan_adopt_finish(s->plans[t], rs, &bad_local);
+  if (status != FFX_OK && own_error.empty()) own_error = ffx_last_error();
+  const bool holder_complaint = status == FFX_NOT_FOUND && bad_local >= 0;
+  const int my_status = bad_own != ~0ull ? 1 : status == FFX_OK ? 0 : holder_complaint ? 3 : 2;
   s->stage_h2d_bytes = h2d;
   s->stage_route_send_bytes = route_send;
   s->stage_route_recv_bytes = route_recv;
@@ -1752,6 +1917,8 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
   sl.have_sparse = own_sparse != nullptr;
   sl.merge = t;
   C_HIP(hipEventRecord(s->r_end, rs));
+  C_HIP(hipStreamWaitEvent(rs, sl.queries_up, 0));
+  C_HIP(hipStreamWaitEvent(rs, sl.sparse_up, 0));
   C_HIP(hipEventRecord(sl.routed, rs));
   sl.routed_valid = true;
   sl.scored_valid = sl.sent_valid = sl.merged_valid = false;
@@ -1792,7 +1959,7 @@ int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_boun
   hipError_t e = hipSetDevice(s->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking);
   for (int i = 0; i < kSlots && e == hipSuccess; ++i) {
-    for (hipEvent_t* ev : {&s->slot[i].routed, &s->slot[i].scored, &s->slot[i].sent, &s->slot[i].merged, &s->out_done[i]})
+    for (hipEvent_t* ev : {&s->slot[i].routed, &s->slot[i].scored, &s->slot[i].sent, &s->slot[i].merged, &s->slot[i].queries_up, &s->slot[i].sparse_up, &s->out_done[i]})
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
   }
   for (hipEvent_t* ev : {&s->x_begin, &s->x_end, &s->m_begin, &s->m_end, &s->r_begin, &s->r_end})
@@ -1802,7 +1969,7 @@ int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_boun
   // that is created and never used still takes part in their assignment)
   for (int i = 0; i < kSlots && rc == FFX_OK; ++i) {
     rc = ffx_plan_create_on(shard, s->compute, &s->plans[i]);
-    if (rc == FFX_OK) rc = ffx_merge_create(s->device, &s->merges[i]);
+    if (rc == FFX_OK) rc = ffx_merge_create_on(s->device, &s->merges[i]);
   }
   if (rc != FFX_OK) {
     ffx_sharded_destroy(s);
@@ -1819,22 +1986,25 @@ int ffx_sharded_destroy(ffx_sharded* s) {
   if (s->comm && s->comm->stream) (void)hipStreamSynchronize(s->comm->stream);
   if (s->comm && s->comm->route_stream) (void)hipStreamSynchronize(s->comm->route_stream);
   if (s->out) (void)hipStreamSynchronize(s->out);
+  if (s->up) (void)hipStreamSynchronize(s->up);
   for (auto* p : s->plans)
     if (p) ffx_plan_destroy(p);
   for (auto* m : s->merges)
     if (m) ffx_merge_destroy(m);
   for (auto* a : {&s->d_ids, &s->d_off, &s->d_who, &s->d_cnt, &s->d_local_off, &s->d_local_ids, &s->d_pos, &s->d_keys, &s->d_arrival, &s->d_slot,
-                  &s->d_small, &s->d_tmp, &s->d_held, &s->d_start, &s->d_sendids, &s->d_qcnt, &s->d_verdict})
+                  &s->d_small, &s->d_tmp, &s->d_held, &s->d_start, &s->d_sendids, &s->d_qcnt, &s->d_verdict, &s->d_cntq, &s->d_tiles})
     a->release();
   if (s->host_small) (void)hipHostFree(s->host_small);
   for (int i = 0; i < kSlots; ++i) {
-    for (hipEvent_t ev : {s->slot[i].routed, s->slot[i].scored, s->slot[i].sent, s->slot[i].merged, s->out_done[i]})
+    for (hipEvent_t ev : {s->slot[i].routed, s->slot[i].scored, s->slot[i].sent, s->slot[i].merged, s->slot[i].queries_up, s->slot[i].sparse_up, s->out_done[i]})
       if (ev) (void)hipEventDestroy(ev);
     if (s->slot[i].recv) (void)hipFree(s->slot[i].recv);
   }
   for (hipEvent_t ev : {s->x_begin, s->x_end, s->m_begin, s->m_end, s->r_begin, s->r_end})
     if (ev) (void)hipEventDestroy(ev);
+  if (s->ids_up) (void)hipEventDestroy(s->ids_up);
   if (s->out) (void)hipStreamDestroy(s->out);
+  if (s->up) (void)hipStreamDestroy(s->up);
   if (s->compute) (void)hipStreamDestroy(s->compute);
   delete s;
   return FFX_OK;
@@ -1859,24 +2029,60 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
   return sharded_set(s, pair_off, n_queries, local_ids, holder, sparse, mode, bad_pair);
 }
 
+int ffx_sharded_stage_queries(ffx_sharded* s, const float* all_queries, int64_t n_queries) {
+  if (!s || n_queries < 0 || (n_queries > 0 && !all_queries)) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  C_HIP(hipSetDevice(s->device));
+  if (!s->fresh) {  // coming from the set-once form: nothing of it may still be in flight
+    C_TRY(ffx_sharded_sync(s));
+    for (auto& sl : s->slot) sl.routed_valid = sl.scored_valid = sl.sent_valid = sl.merged_valid = false;
+    for (bool& v : s->out_valid) v = false;
+    s->last_merged = -1;
+    s->fresh = true;
+    s->have_pairs = false;
+  }
+  const int t = (int)(s->staged % kSlots);
+  ffx_sharded::Slot& sl = s->slot[t];
+  C_TRY(sharded_io_streams(s));
+  if (sl.scored_valid) C_HIP(hipStreamWaitEvent(s->up, sl.scored, 0));  // the batch that read this slot's vectors last has been scored
+  float* d_q = nullptr;
+  C_TRY(ffx_plan_queries_room(s->plans[t], n_queries, &d_q));
+  int32_t qdim = 0;
+  C_TRY(ffx_index_query_dim(s->shard, &qdim));
+  if (n_queries > 0) C_HIP(hipMemcpyAsync(d_q, all_queries, (size_t)n_queries * qdim * 4, hipMemcpyHostToDevice, s->up));
+  s->staged_query_bytes = n_queries * (int64_t)qdim * 4;
+  return FFX_OK;
+}
+
 int ffx_sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
                             const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, int64_t* bad_pair) {
   return sharded_stage_owned(s, q_bounds, own_queries, own_pair_off, own_pair_ids, own_holder, own_sparse, mode, 0, bad_pair);
 }
 
-// The owner-side half of batch `s->pending` (scatter to first-stage order, interpolation, per-query order) on the
-// COMPUTE stream, behind whatever has been queued there, once that batch's scores have arrived.
+// The owner-side half of batch `s->pending` (scatter to first-stage order, interpolation, per-query order), once that
+// batch's scores have arrived.  Two placements (by size; FFX_DEBUG_VARIANT=merge_on_compute / merge_on_results force one):
+//   compute stream  behind whatever has been queued there: never beside a gather_dot, but every step then pays for it
+//                   (merge 0.03 + order 0.07 ms + two launch gaps between one gather_dot and the next at an eighth of the batch)
+//   result stream   (high priority, where the results leave anyway): its waves take the slots gather_dot's retiring waves
+//                   free, so it runs INSIDE the next batch's gather_dot instead of between two of them
 static int sharded_merge_pending(ffx_sharded* s) {
   if (s->pending < 0) return FFX_OK;
   const int i = s->pending;
   s->pending = -1;
   ffx_sharded::Slot& sl = s->slot[i];
-  C_HIP(hipStreamWaitEvent(s->compute, sl.sent, 0));
-  if (s->out_valid[sl.merge]) C_HIP(hipStreamWaitEvent(s->compute, s->out_done[sl.merge], 0));  // the results this merge held before have left
-  C_HIP(hipEventRecord(s->m_begin, s->compute));
-  C_TRY(ffx_merge_run(s->merges[sl.merge], static_cast<const float*>(sl.recv), s->pending_alpha, s->pending_flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), s->compute));
-  C_HIP(hipEventRecord(s->m_end, s->compute));
-  C_HIP(hipEventRecord(sl.merged, s->compute));
+  hipStream_t ms = s->compute;
+  // a small merge hides inside the next gather_dot; a large one (tens of millions of candidates: one or two ranks) takes
+  // slots from it for its whole length and is better paid for once, in line (measured: DESIGN.md section 7)
+  const bool small = sl.own[3] <= (int64_t)(10 << 20);
+  if (ffx_debug_variant("merge_on_results", nullptr) || (small && !ffx_debug_variant("merge_on_compute", nullptr))) {
+    C_TRY(sharded_io_streams(s));
+    ms = s->out;
+  }
+  C_HIP(hipStreamWaitEvent(ms, sl.sent, 0));
+  if (ms != s->out && s->out_valid[sl.merge]) C_HIP(hipStreamWaitEvent(ms, s->out_done[sl.merge], 0));  // the results this merge held before have left
+  C_HIP(hipEventRecord(s->m_begin, ms));
+  C_TRY(ffx_merge_run(s->merges[sl.merge], static_cast<const float*>(sl.recv), s->pending_alpha, s->pending_flags & (FFX_FLAG_SORT | FFX_FLAG_SORT_FF), ms));
+  C_HIP(hipEventRecord(s->m_end, ms));
+  C_HIP(hipEventRecord(sl.merged, ms));
   sl.merged_valid = true;
   s->last_merged = i;
   return FFX_OK;
@@ -1908,6 +2114,7 @@ int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags) {
   C_HIP(hipEventRecord(sl.scored, s->compute));
   sl.scored_valid = true;
   C_HIP(hipStreamWaitEvent(cs, sl.scored, 0));
+  if (sl.merged_valid) C_HIP(hipStreamWaitEvent(cs, sl.merged, 0));  // the merge that read this slot's receive buffer last has finished
   C_HIP(hipEventRecord(s->x_begin, cs));
   C_TRY(ffx_comm_exchange(s->comm, sl.send_dev, sl.send_counts.data(), static_cast<float*>(sl.recv), sl.recv_counts.data(), cs));
   C_HIP(hipEventRecord(s->x_end, cs));
@@ -1941,11 +2148,7 @@ int ffx_sharded_fetch_async(ffx_sharded* s, float* out_ff, float* out_interp, in
   if (!s) return ffx_fail(FFX_BAD_ARG, "NULL handle");
   if (s->last_merged < 0) return ffx_fail(FFX_BAD_ARG, "no batch has been merged yet: ffx_sharded_run queues the merge of the batch BEFORE the one it runs");
   C_HIP(hipSetDevice(s->device));
-  if (!s->out) {
-    int least = 0, greatest = 0;
-    C_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    C_HIP(hipStreamCreateWithPriority(&s->out, hipStreamNonBlocking, greatest));  // (as ffx_score's result stream: not behind the next batch's kernels)
-  }
+  C_TRY(sharded_io_streams(s));
   ffx_sharded::Slot& sl = s->slot[s->last_merged];
   C_HIP(hipStreamWaitEvent(s->out, sl.merged, 0));
   C_TRY(ffx_merge_fetch_async(s->merges[sl.merge], out_ff, out_interp, out_order, s->out));
@@ -1978,15 +2181,29 @@ int ffx_sharded_score(ffx_sharded* s, const int64_t* q_bounds, const float* own_
   ffx_comm_rank(s->comm, &rank, &world);
   const int64_t Qo = q_bounds[rank + 1] - q_bounds[rank];
   if (Qo < 0) return ffx_fail(FFX_BAD_ARG, "q_bounds not monotone");
-  if (n_slices <= 0) {  // by size: ~4 M pairs per slice on the rank that has most (every rank must cut alike)
+  if (n_slices <= 0) {  // by size: ~4 M pairs per full slice on the rank that has most (every rank must cut alike)
     double most = (double)own_pair_off[Qo];
     C_TRY(ffx_comm_allreduce_f64(s->comm, &most, 1, FFX_OP_MAX));
-    n_slices = (int32_t)std::min<double>(64.0, std::max(1.0, std::ceil(most / (double)(4 << 20))));
+    const int full = (int)std::min<double>(64.0, std::max(1.0, std::ceil(most / (double)(4 << 20))));
+    n_slices = full >= 3 ? full + 4 : full;  // room for the ramp below
+  }
+  // The first slices are small (1/8, 1/4, 1/2 of a full one: the device idles while the first one is taken in) and so are
+  // the last (the caller idles while the last one's results come back), as in ffx_score.  Weights by slice NUMBER only:
+  // every rank cuts its own block at the same fractions.
+  std::vector<int64_t> weight_before((size_t)n_slices + 1, 0);
+  for (int j = 0; j < n_slices; ++j) {
+    int w = 8;
+    if (n_slices >= 7) {
+      const int from_end = n_slices - 1 - j;
+      w = std::min(8, std::min(1 << std::min(j, 3), 1 << std::min(from_end, 3)));
+    }
+    weight_before[(size_t)j + 1] = weight_before[(size_t)j] + w;
   }
   int32_t qdim = 0;
   C_TRY(ffx_index_query_dim(s->shard, &qdim));
   std::vector<int64_t> qb((size_t)world + 1), off;
-  auto cut = [&](int r, int j) { return (q_bounds[r + 1] - q_bounds[r]) * (int64_t)j / n_slices; };  // first query of rank r's slice j, in its block
+  // first query of rank r's slice j, in its block
+  auto cut = [&](int r, int j) { return (int64_t)(((__int128)(q_bounds[r + 1] - q_bounds[r]) * weight_before[(size_t)j]) / weight_before[(size_t)n_slices]); };
   int rc = FFX_OK;
   int64_t first_pair[2] = {0, 0};  // of the slice whose results leave next
   for (int j = 0; j <= n_slices && rc == FFX_OK; ++j) {

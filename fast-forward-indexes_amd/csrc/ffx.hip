@@ -283,6 +283,11 @@ struct ffx_plan {
   DevBuf es_active, es_cnt, es_pos, es_scan_tmp;
   DevBuf small_flag;  // ffx_score's single-submission path: smallest bad pair position, ~0 between calls
   bool lazy_pairs = false;
+  // the ordinal check of set_pairs between its launch and its completion: where the verdict lands on the host
+  bool check_one_each = false;
+  char* check_back = nullptr;
+  char check_host[16] = {};
+  bool adopt_empty_index = false;
   // Small batches (a service scoring one query at a time) are latency-bound on the copies: a
   // copy between pageable memory and the device blocks the caller each time, so inputs and
   // outputs of up to kStageBytes travel through this page-locked block and only one wait remains.
@@ -1080,8 +1085,11 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
 }
 
 // the second half of ffx_plan_set_pairs: the lists are in the plan's device buffers; validate the ordinals and
-// size the row list on the device (get_indices, index/util.py:29-41)
-static int finish_set_pairs(ffx_plan* pl, int64_t* bad_pair) {
+// size the row list on the device (get_indices, index/util.py:29-41).  In two steps, so that a caller with more to queue
+// on the stream (the sharded scorer's staging) waits once for everything: launch (asynchronous; the verdict and, where
+// candidates may contribute several rows, the row count travel into page-locked memory) and complete (after the stream
+// has been synchronised).
+static int set_pairs_check_launch(ffx_plan* pl) {
   ffx_index* ix = pl->idx;
   const int64_t P = pl->n_pairs;
   const int mode = pl->mode;
@@ -1090,50 +1098,44 @@ static int finish_set_pairs(ffx_plan* pl, int64_t* bad_pair) {
   // each, when no document is empty) there is nothing to count or scan: the ordinals are range-checked and the row
   // list has one entry per candidate.  (The count + scan of a 4 M-pair slice took 0.12 ms beside the scoring kernels of
   // the slice before: a tenth of ffx_score's device time went there.)
-  const bool one_each = (mode == FFX_MODE_PASSAGE ? ix->psgs_identity : ix->docs_nonempty && (mode == FFX_MODE_FIRSTP || ix->max_doc_rows <= 1)) &&
-                        !ffx_debug_variant("count_always", nullptr);
-  if (one_each) {
+  pl->check_one_each = (mode == FFX_MODE_PASSAGE ? ix->psgs_identity : ix->docs_nonempty && (mode == FFX_MODE_FIRSTP || ix->max_doc_rows <= 1)) &&
+                       !ffx_debug_variant("count_always", nullptr);
+  if (pl->check_one_each) {
     if (P > 0) {
       ffx::check_range_kernel<<<blocks_for(P, 256), 256, 0, pl->stream>>>(pl->pair_ids.as<int32_t>(), P, (int32_t)(mode == FFX_MODE_PASSAGE ? ix->n_psgs : ix->n_docs),
                                                                           pl->flags.as<unsigned long long>());
       FFX_HIP(hipGetLastError());
     }
-    unsigned long long bad1 = ~0ull;
-    if (char* back = pl->stage(8)) {
-      FFX_HIP(hipMemcpyAsync(back, pl->flags.p, sizeof bad1, hipMemcpyDeviceToHost, pl->stream));
-      FFX_HIP(hipStreamSynchronize(pl->stream));
-      memcpy(&bad1, back, sizeof bad1);
-    } else {
-      FFX_HIP(hipMemcpyAsync(&bad1, pl->flags.p, sizeof bad1, hipMemcpyDeviceToHost, pl->stream));
-      FFX_HIP(hipStreamSynchronize(pl->stream));
-    }
-    if (bad1 != ~0ull) {
-      if (bad_pair) *bad_pair = (int64_t)bad1;
-      return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad1);
-    }
+  } else {
+    FFX_TRY(launch_count_scan(pl));
+  }
+  char* back = pl->stage(16);  // both read-backs land in page-locked memory: one wait, no blocking copies
+  pl->check_back = back ? back : pl->check_host;
+  memset(pl->check_back, 0xFF, 8);
+  memset(pl->check_back + 8, 0, 8);
+  FFX_HIP(hipMemcpyAsync(pl->check_back, pl->flags.p, 8, hipMemcpyDeviceToHost, pl->stream));
+  if (!pl->check_one_each) FFX_HIP(hipMemcpyAsync(pl->check_back + 8, pl->seg_off.as<int32_t>() + P, sizeof(int32_t), hipMemcpyDeviceToHost, pl->stream));
+  return FFX_OK;
+}
+
+static int set_pairs_check_complete(ffx_plan* pl, int64_t* bad_pair) {
+  ffx_index* ix = pl->idx;
+  const int64_t P = pl->n_pairs;
+  const int mode = pl->mode;
+  unsigned long long bad = ~0ull;
+  int32_t total = 0;
+  memcpy(&bad, pl->check_back, sizeof bad);
+  memcpy(&total, pl->check_back + 8, sizeof total);
+  if (bad != ~0ull) {
+    if (bad_pair) *bad_pair = (int64_t)bad;
+    return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad);
+  }
+  if (pl->check_one_each) {
     pl->n_rows = P;
     FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)P, 1) * sizeof(int2)));
     pl->have_pairs = true;
     pl->lazy_pairs = false;
     return FFX_OK;
-  }
-  FFX_TRY(launch_count_scan(pl));
-  unsigned long long bad = ~0ull;
-  int32_t total = 0;
-  if (char* back = pl->stage(16)) {  // both read-backs land in page-locked memory: one wait, no blocking copies
-    FFX_HIP(hipMemcpyAsync(back, pl->flags.p, sizeof bad, hipMemcpyDeviceToHost, pl->stream));
-    FFX_HIP(hipMemcpyAsync(back + 8, pl->seg_off.as<int32_t>() + P, sizeof total, hipMemcpyDeviceToHost, pl->stream));
-    FFX_HIP(hipStreamSynchronize(pl->stream));
-    memcpy(&bad, back, sizeof bad);
-    memcpy(&total, back + 8, sizeof total);
-  } else {
-    FFX_HIP(hipMemcpyAsync(&bad, pl->flags.p, sizeof bad, hipMemcpyDeviceToHost, pl->stream));
-    FFX_HIP(hipMemcpyAsync(&total, pl->seg_off.as<int32_t>() + P, sizeof total, hipMemcpyDeviceToHost, pl->stream));
-    FFX_HIP(hipStreamSynchronize(pl->stream));
-  }
-  if (bad != ~0ull) {
-    if (bad_pair) *bad_pair = (int64_t)bad;
-    return fail(FFX_NOT_FOUND, "pair %llu names an ordinal with no rows in the index", bad);
   }
   // the row list is addressed with int32 and the counts were scanned in int32: where that scan could have
   // wrapped (a candidate contributes at most the rows of the longest document) the total is re-derived in int64
@@ -1159,6 +1161,12 @@ static int finish_set_pairs(ffx_plan* pl, int64_t* bad_pair) {
   pl->have_pairs = true;
   pl->lazy_pairs = false;
   return FFX_OK;
+}
+
+static int finish_set_pairs(ffx_plan* pl, int64_t* bad_pair) {
+  FFX_TRY(set_pairs_check_launch(pl));
+  FFX_HIP(hipStreamSynchronize(pl->stream));
+  return set_pairs_check_complete(pl, bad_pair);
 }
 
 // ffx_plan_set_pairs for candidate lists that already are in device memory (the sharded scorer routes a batch on the
@@ -1323,21 +1331,41 @@ int ffx_plan_adopt_begin(ffx_plan* pl, int64_t n_queries, int64_t n_pairs, int m
   return FFX_OK;
 }
 
-int ffx_plan_adopt_finish(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t stream, int64_t* bad_pair) {
-  if (bad_pair) *bad_pair = -1;
-  if (!pl || !host_pair_off) return fail(FFX_BAD_ARG, "bad argument");
+int ffx_plan_adopt_check(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t stream, const unsigned long long** d_verdict) {
+  if (!pl || !host_pair_off || !d_verdict) return fail(FFX_BAD_ARG, "bad argument");
   if (host_pair_off[0] != 0 || host_pair_off[pl->n_queries] != pl->n_pairs) return fail(FFX_BAD_ARG, "the offsets do not describe the adopted lists");
   ffx_index* ix = pl->idx;
-  if ((pl->mode == FFX_MODE_PASSAGE ? ix->n_psgs == 0 : ix->n_docs == 0) && pl->n_pairs > 0) {
-    if (bad_pair) *bad_pair = 0;
-    return fail(FFX_NOT_FOUND, "the index holds no %s ids", pl->mode == FFX_MODE_PASSAGE ? "passage" : "document");
-  }
+  pl->adopt_empty_index = (pl->mode == FFX_MODE_PASSAGE ? ix->n_psgs == 0 : ix->n_docs == 0) && pl->n_pairs > 0;
   FFX_HIP(hipSetDevice(pl->device));
   pl->host_pair_off.assign(host_pair_off, host_pair_off + pl->n_queries + 1);
   pl->hstage_used = 0;
   hipStream_t keep = pl->stream;
-  pl->stream = stream;  // the validation (and its one wait) belong to the caller's stream, not to the one the plan scores on
-  const int rc = finish_set_pairs(pl, bad_pair);
+  pl->stream = stream;  // the validation belongs to the caller's stream, not to the one the plan scores on
+  int rc = FFX_OK;
+  if (pl->adopt_empty_index) {  // every candidate is unknown: the verdict is position 0
+    const unsigned long long zero = 0;
+    memcpy(pl->check_host, &zero, 8);
+    pl->check_back = pl->check_host;
+    if (hipMemsetAsync(pl->flags.p, 0, sizeof(unsigned long long), stream) != hipSuccess) rc = fail(FFX_HIP_ERROR, "memset failed");
+  } else {
+    rc = set_pairs_check_launch(pl);
+  }
+  pl->stream = keep;
+  *d_verdict = pl->flags.as<unsigned long long>();
+  return rc;
+}
+
+int ffx_plan_adopt_finish(ffx_plan* pl, hipStream_t stream, int64_t* bad_pair) {
+  if (bad_pair) *bad_pair = -1;
+  if (!pl) return fail(FFX_BAD_ARG, "bad argument");
+  if (pl->adopt_empty_index) {
+    if (bad_pair) *bad_pair = 0;
+    return fail(FFX_NOT_FOUND, "the index holds no %s ids", pl->mode == FFX_MODE_PASSAGE ? "passage" : "document");
+  }
+  FFX_HIP(hipSetDevice(pl->device));
+  hipStream_t keep = pl->stream;
+  pl->stream = stream;
+  const int rc = set_pairs_check_complete(pl, bad_pair);
   pl->stream = keep;
   return rc;
 }
@@ -2330,6 +2358,17 @@ int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems) 
 }  // extern "C"
 
 // ---- ffx_internal.h: the owner-side state written in place by the sharded scorer (comm.hip) -------------------------
+int ffx_merge_create_on(int device, ffx_merge** out) {
+  if (!out) return fail(FFX_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  FFX_HIP(hipSetDevice(device));
+  ffx_merge* m = new (std::nothrow) ffx_merge();
+  if (!m) return fail(FFX_OOM, "host allocation failed");
+  m->device = device;
+  *out = m;
+  return FFX_OK;
+}
+
 int ffx_merge_adopt_begin(ffx_merge* m, int64_t n_queries, int64_t n_pairs, bool have_sparse, int64_t** d_pair_off, int32_t** d_slot,
                           float** d_sparse) {
   if (!m || n_queries < 0 || n_pairs < 0 || !d_pair_off || !d_slot || !d_sparse) return fail(FFX_BAD_ARG, "bad argument");

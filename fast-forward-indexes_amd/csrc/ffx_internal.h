@@ -18,13 +18,18 @@ bool ffx_debug_variant(const char* name, long long* value);  // the FFX_DEBUG_VA
 // (Buffers may be re-allocated here: call it while nothing of the plan is in flight.)
 int ffx_plan_adopt_begin(ffx_plan* pl, int64_t n_queries, int64_t n_pairs, int mode, int64_t** d_pair_off, int32_t** d_pair_ids);
 // The lists are in place once `stream` reaches this point; host_pair_off holds the same offsets on the host.  The
-// ordinals are validated ON `stream` (get_indices, index/util.py:29-41; the call waits for that stream only).
-int ffx_plan_adopt_finish(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t stream, int64_t* bad_pair);
+// ordinals are validated ON `stream` (get_indices, index/util.py:29-41), asynchronously: *d_verdict is the device word
+// that will hold the smallest position of an ordinal without rows (~0: none) ...
+int ffx_plan_adopt_check(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t stream, const unsigned long long** d_verdict);
+// ... and once the caller has SYNCHRONISED `stream`, the plan is sized and ready (or FFX_NOT_FOUND + *bad_pair).
+int ffx_plan_adopt_finish(ffx_plan* pl, hipStream_t stream, int64_t* bad_pair);
 // Device room for n_queries query vectors, which the caller fills before the plan runs.
 int ffx_plan_queries_room(ffx_plan* pl, int64_t n_queries, float** d_queries);
 // A plan that owns no stream of its own and issues its work on `stream`.
 int ffx_plan_create_on(ffx_index* idx, hipStream_t stream, ffx_plan** out);
 
+// A merge that owns no stream (ffx_merge_run is given one; the set forms use the default stream).
+int ffx_merge_create_on(int device, ffx_merge** out);
 // The owner-side state of a merge written in place: offsets of the owned queries, arrival slot and first-stage score
 // of every owned candidate (d_sparse is NULL without first-stage scores).
 int ffx_merge_adopt_begin(ffx_merge* m, int64_t n_queries, int64_t n_pairs, bool have_sparse, int64_t** d_pair_off, int32_t** d_slot,

@@ -40,7 +40,7 @@ SYMBOLS = (
     "ffx_query_partition", "ffx_route",
     "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs", "ffx_sharded_set_pairs_held",
     "ffx_sharded_run", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
-    "ffx_sharded_stage_owned", "ffx_sharded_fetch_async", "ffx_sharded_score",
+    "ffx_sharded_stage_owned", "ffx_sharded_stage_queries", "ffx_sharded_fetch_async", "ffx_sharded_score",
 )
 COMM_RCCL, COMM_HOST, COMM_REHEARSAL, COMM_ID_BYTES = 0, 1, 2, 128
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
@@ -236,6 +236,7 @@ def lib() -> C.CDLL:
         "ffx_sharded_stats": ([vp, P(ShardStats)], C.c_int),
         "ffx_sharded_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
         "ffx_sharded_stage_owned": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, P(i64)], C.c_int),
+        "ffx_sharded_stage_queries": ([vp, vp, i64], C.c_int),
         "ffx_sharded_fetch_async": ([vp, vp, vp, vp], C.c_int),
         "ffx_sharded_score": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, i32, vp, vp, vp, P(i64)], C.c_int),
     }
@@ -1399,6 +1400,14 @@ class Sharded:
         _check(rc, bad.value)
         self.has_sparse = sp is not None
         self.q_lo, self.q_hi, self.own_first_pair, self.own_pairs = int(qb[self._comm.rank]), int(qb[self._comm.rank + 1]), 0, int(off[-1])
+
+    def stage_queries(self, all_queries: np.ndarray) -> None:
+        """``ffx_sharded_stage_queries``: ALL query vectors of the batch about to be staged, replicated on every rank (then
+        ``stage_owned(..., own_queries=None, ...)``).  The array must stay alive until that call returns."""
+        q = _arr(all_queries, np.float32)
+        assert q.ndim == 2 and q.shape[1] == self._shard.query_dim, "query dimensionality does not match the index"
+        self._staged_queries = q
+        _check(lib().ffx_sharded_stage_queries(self._h, _ptr(q), q.shape[0]))
 
     def fetch_async(self, out, ff: bool = True, interp: bool = False, order: bool = False) -> None:
         """``ffx_sharded_fetch_async``: the batch merged last (after ``run``: the one BEFORE the batch it ran) copied into

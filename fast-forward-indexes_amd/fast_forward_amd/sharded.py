@@ -319,6 +319,10 @@ class ShardedScorer:
                                  else "a candidate owned by another rank names an ordinal outside the sharded index") from None
             raise
 
+    def stage_queries(self, all_queries) -> None:
+        """ALL query vectors of the batch about to be staged, replicated on every rank (``ffx_sharded_stage_queries``)."""
+        self._s.stage_queries(all_queries)
+
     def fetch_async(self, out, ff: bool = True, interp: bool = False, order: bool = False) -> None:
         self._s.fetch_async(out, ff=ff, interp=interp, order=order)
 

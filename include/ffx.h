@@ -353,6 +353,12 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
  * owns it: a position in ITS list).  Per-rank host->device bytes are proportional to the block, not to the batch. */
 int ffx_sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
                             const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, int64_t* bad_pair);
+/* The other way to hand over the query vectors of the batch about to be staged: ALL n_queries of them, on every rank (each
+ * rank uploads Q * dim * 4 bytes over its own link; nothing is exchanged), then ffx_sharded_stage_owned with own_queries =
+ * NULL.  Asynchronous (the vectors must stay put until the stage call returns).  Which of the two is cheaper depends on the
+ * node: the all-gather keeps the intake per rank proportional to its block but runs as a copy kernel beside gather_dot,
+ * the replicated upload costs PCIe time only (DESIGN.md section 7 has both measured). */
+int ffx_sharded_stage_queries(ffx_sharded* s, const float* all_queries, int64_t n_queries);
 int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags); /* asynchronous */
 /* the results of the batch merged last -- after ffx_sharded_run that is the batch BEFORE the one it ran -- copied out on a
  * stream of their own (truly asynchronous into page-locked buffers); complete after ffx_sharded_sync */

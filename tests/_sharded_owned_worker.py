@@ -95,8 +95,13 @@ def main():
             results.append((order_of[i - 1], keep))
         if i + 1 < len(order_of):
             own_off, own_ids, own_sp, _, _ = block(order_of[i + 1])
-            scorer.stage_owned(qb, queries[q_lo:q_hi], own_off, own_ids, own_sp, mode)
-            st_h2d = (q_hi - q_lo + 1) * 8 + own_ids.shape[0] * 8 + (q_hi - q_lo) * d * 4
+            if i % 2:  # the other way to hand the vectors over: all of them on every rank, nothing exchanged
+                scorer.stage_queries(queries)
+                scorer.stage_owned(qb, None, own_off, own_ids, own_sp, mode)
+                st_h2d = (q_hi - q_lo + 1) * 8 + own_ids.shape[0] * 8 + n_q * d * 4
+            else:
+                scorer.stage_owned(qb, queries[q_lo:q_hi], own_off, own_ids, own_sp, mode)
+                st_h2d = (q_hi - q_lo + 1) * 8 + own_ids.shape[0] * 8 + (q_hi - q_lo) * d * 4
     scorer.sync()
     last = scorer.fetch(order=True)
     results.append((order_of[-1], last))
@@ -113,9 +118,6 @@ def main():
     # an ordinal without rows, in ONE rank's block: the same IndexError on every rank, the position on the rank that owns it
     own_off, own_ids, own_sp, lo, hi = block(0)
     bad_ids = own_ids.copy()
-    culprit = 0 if hi > lo and rank == 0 else -1
-    if world > 1 and rank == world - 1 and hi > lo:
-        culprit = -1
     if rank == 0 and hi > lo:
         bad_ids[min(40, hi - lo - 1)] = int(np.flatnonzero(per_doc == 0)[0])
     try:
