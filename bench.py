@@ -87,6 +87,13 @@ def parse_args():
     ap.add_argument("--fresh-queries", default="allgather", choices=["allgather", "replicate"],
                     help="fresh batches of the sharded leg: every rank uploads the vectors of the queries it OWNS and the ranks all-gather them on the "
                          "routing lane (intake per rank ~ 1/N), or every rank uploads ALL query vectors over its own PCIe link (no exchange)")
+    ap.add_argument("--nccl-channels", default=None, metavar="MIN:MAX",
+                    help="N > 1 over RCCL: export NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS before the communicator comes up (how many workgroups RCCL's "
+                         "send/recv kernel may take beside gather_dot: the first knob if a measured scaling point falls short of the rehearsal); echoed in the line")
+    ap.add_argument("--rehearsal-exchange", default="copy", metavar="copy|paced[:GB/s]",
+                    help="--as-rank-of N: what stands in for the peers' traffic -- `copy`: one kernel of 16 workgroups moving the bytes through this GPU's memory; "
+                         "`paced[:R]`: one PERSISTENT workgroup per peer and direction that moves its piece in 64 KiB chunks and spins on a flag between chunks "
+                         "until a link of R GB/s (default 50) would have delivered them")
     ap.add_argument("--require-rccl", action="store_true",
                     help="N > 1: exit non-zero if RCCL cannot be brought up on every rank instead of falling back to the shared-memory "
                          "transport (a fallback line is marked `\"scaling\": \"invalid: host transport\"` and `\"value_is_rccl\": false`)")
@@ -262,12 +269,29 @@ def gather_stats(comm, st: dict) -> list[dict]:
     return [dict(zip(keys, row.tolist())) for row in comm.allgather_array(mine)]
 
 
+def apply_comm_knobs(args) -> dict:
+    """Environment the communicator reads when it comes up; returns what was set (echoed in the line)."""
+    knobs = {}
+    if args.nccl_channels:
+        lo, _, hi = args.nccl_channels.partition(":")
+        os.environ["NCCL_MIN_NCHANNELS"], os.environ["NCCL_MAX_NCHANNELS"] = lo, (hi or lo)
+    for name in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "NCCL_P2P_NET_CHUNKSIZE", "NCCL_PROTO", "GPU_MAX_HW_QUEUES"):
+        if name in os.environ:
+            knobs[name] = os.environ[name]
+    if args.as_rank_of and args.rehearsal_exchange.startswith("paced"):
+        _, _, rate = args.rehearsal_exchange.partition(":")
+        word = "rehearsal_paced" + (f"={int(float(rate))}" if rate else "")
+        os.environ["FFX_DEBUG_VARIANT"] = ",".join(w for w in (os.environ.get("FFX_DEBUG_VARIANT"), word) if w)
+    return knobs
+
+
 def bench_sharded(args, rank: int, world: int):
     """bench.py --gpus N>1: the SAME workload as N=1 (fixed index, queries and k: strong
     scaling), index row-sharded by document, one rank per GPU, scores exchanged through libffx's
     communicator (RCCL, or shared memory with --transport host)."""
     from fast_forward_amd.sharded import ShardedScorer, connect, doc_partition, query_partition
 
+    args.comm_knobs = apply_comm_knobs(args)
     if args.as_rank_of:  # one process standing in for one rank: no peers, no rendezvous
         native.require_device()
         comm = connect("rehearsal", rank=args.as_rank, world=args.as_rank_of, device=0)
@@ -416,9 +440,15 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
         host_batch.append(float(comm.allreduce([time.perf_counter() - tb], native.OP_MAX)[0]))
     t_host_batch = min(host_batch[1:])
 
-    for _ in range(args.warmup):
+    # one step alone, twice: nothing hides its exchange and its merge, and the FIRST one also pays for what the transport sets
+    # up lazily (RCCL connects a send/recv channel pair the first time two ranks talk)
+    alone = []
+    for _ in range(2 + args.warmup):
+        comm.barrier()
+        ta = time.perf_counter()
         scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
-    scorer.sync()
+        scorer.sync()
+        alone.append(float(comm.allreduce([time.perf_counter() - ta], native.OP_MAX)[0]) * 1e3)
     comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -493,6 +523,11 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                 "kernel_ms_per_rank": [t["ms_gather_dot"] for t in per_rank], "gathered_rows_per_rank": rows_per_rank,
             },
             "transport": args.transport, "rccl_ranks": world if args.transport == "rccl" else 0,
+            "comm_env": getattr(args, "comm_knobs", {}),
+            "first_step_alone_ms": alone[0], "step_alone_ms": min(alone[1:]),
+            "step_alone_note": "one step run by itself, wall clock, max over ranks: local scoring + exchange + owner merge with nothing to hide behind (what the LAST "
+                               "batch of a run costs); first_step_alone_ms is the very first one, connection set-up of the transport included",
+            **({"rehearsal_exchange": args.rehearsal_exchange} if rehearsal else {}),
             "load_balance": {"gathered_rows_max": max(rows_per_rank), "gathered_rows_mean": float(np.mean(rows_per_rank)),
                              "max_over_mean": max(rows_per_rank) / max(1.0, float(np.mean(rows_per_rank)))},
             "exchange_bytes_per_rank": {"sent": [int(t["send_bytes"]) for t in per_rank], "received": [int(t["recv_bytes"]) for t in per_rank]},
@@ -590,7 +625,10 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
         scorer.stage_owned(qb, None if replicate else own_q, own_off, p_ids, p_sp, mode)
         return seed
 
-    seed = stage(0)
+    comm.barrier()
+    t_first = time.perf_counter()
+    seed = stage(0)  # brings the routing lane up (over RCCL: a second communicator) and allocates the staging buffers
+    t_first = float(comm.allreduce([time.perf_counter() - t_first], native.OP_MAX)[0])
     for b in range(args.warmup):
         scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
         seed = stage(b + 1)
@@ -613,6 +651,7 @@ def fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exac
     line = {
         "fresh_batch_step_ms": elapsed * 1e3 / args.steps,
         "fresh_batch_queries_per_s": args.queries / (elapsed / args.steps), "fresh_batch_query_vectors": args.fresh_queries,
+        "fresh_first_stage_ms": t_first * 1e3,
         "fresh_batch_note": f"{args.steps} DIFFERENT batches back to back ({n_distinct} distinct candidate sets in page-locked host memory, cycled), every rank handed only "
                             "the queries it owns: upload of the rank's block, holders found on the device, ordinals to the holders in a first all-to-all on the routing "
                             "lane while the previous batch is scored; then local gather_dot, all-to-all of scores, owner-side merge + order.  Results stay in HBM",

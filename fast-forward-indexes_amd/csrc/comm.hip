@@ -1963,7 +1963,7 @@ int ffx_sharded_create(ffx_index* shard, ffx_comm* comm, const int64_t* doc_boun
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
   }
   for (hipEvent_t* ev : {&s->x_begin, &s->x_end, &s->m_begin, &s->m_end, &s->r_begin, &s->r_end})
-    if (e == hipSuccess) e = hipEventCreate(ev);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableSystemFence);  // timing only: no cache write-back when recorded
   if (e != hipSuccess) rc = ffx_fail(FFX_HIP_ERROR, "stream/event creation failed: %s", hipGetErrorString(e));
   // the plans issue their work on the compute stream and own none (a process has few hardware queues: every stream
   // that is created and never used still takes part in their assignment)
