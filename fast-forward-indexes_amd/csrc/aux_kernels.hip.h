@@ -106,6 +106,19 @@ small_out_kernel(const uint32_t* __restrict__ ff, const uint32_t* __restrict__ i
 }
 
 // out[i] = src[index[i]]
+// The run in FINAL order (ranking.py:115-117 applied, not just described): position i of the per-query order holds candidate
+// order[i] - base of the slice; its key (the score the order was made by) and its carried word (whatever the caller numbered
+// the candidates with: id codes of a Ranking) land at i.  Reads of a query's block come out of the cache; writes are coalesced.
+__global__ void __launch_bounds__(256)
+rank_take_kernel(const float* __restrict__ keys, const int32_t* __restrict__ carry, const int32_t* __restrict__ order, int32_t base, int64_t n,
+                 float* __restrict__ out_keys, int32_t* __restrict__ out_carry) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t j = order[i] - base;
+  out_keys[i] = keys[j];
+  if (carry) out_carry[i] = carry[j];
+}
+
 __global__ void __launch_bounds__(256)
 take_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ index, int64_t n, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

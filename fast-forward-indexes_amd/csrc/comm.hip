@@ -38,6 +38,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/ffx.h"
+#include "../../include/ffx_private.h"
 #include "ffx_internal.h"  // ffx_fail, ffx_debug_variant, in-place hooks of plans and merges (ffx.hip)
 
 namespace {

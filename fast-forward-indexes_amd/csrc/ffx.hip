@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/ffx.h"
+#include "../../include/ffx_private.h"
 #include "ffx_internal.h"
 #include "aux_kernels.hip.h"
 #include "gather_dot.hip.h"
@@ -258,6 +259,9 @@ struct ffx_plan {
   int ov_dim = 0, ov_rows = 0;
   // outputs
   DevBuf ff, interp, order;
+  // the run in final order (ffx_score_ranked): the sort key and a carried word per candidate, permuted by `order`
+  DevBuf carry, ranked, carry_ranked;
+  bool want_ranked = false, have_carry = false;
   int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
   int n_queries_set = 0;
   int mode = 0;
@@ -976,7 +980,7 @@ int ffx_plan_destroy(ffx_plan* pl) {
   for (DevBuf* b : {&pl->es_active, &pl->es_cnt, &pl->es_pos, &pl->es_scan_tmp, &pl->small_flag}) b->release();
   for (DevBuf* b : {&pl->queries, &pl->pair_off, &pl->pair_ids, &pl->sparse, &pl->cnt, &pl->seg_off, &pl->desc,
                     &pl->rs, &pl->scan_tmp, &pl->sort_tmp, &pl->iota, &pl->sorted_keys, &pl->leaf_start, &pl->lut, &pl->vdesc, &pl->rs_v, &pl->combine_steps, &pl->seg_tables,
-                    &pl->flags, &pl->ff, &pl->interp, &pl->order})
+                    &pl->flags, &pl->ff, &pl->interp, &pl->order, &pl->carry, &pl->ranked, &pl->carry_ranked})
     b->release();
   for (auto& e : pl->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1902,6 +1906,12 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
                                   pl->sorted_keys, pl->sort_tmp, st, longest_segment(pl->host_pair_off.data(), pl->n_queries),
                                   pl->order_base));
   }
+  if (pl->want_ranked && do_sort && P > 0) {
+    const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
+    ffx::rank_take_kernel<<<blocks_for(P, 256), 256, 0, st>>>(keys, pl->have_carry ? pl->carry.as<int32_t>() : nullptr, pl->order.as<int32_t>(), pl->order_base, P,
+                                                           pl->ranked.as<float>(), pl->carry_ranked.as<int32_t>());
+    FFX_HIP(hipGetLastError());
+  }
   FFX_HIP(hipEventRecord(pl->ev[4], st));
   pl->ran = true;
   pl->ran_sort = do_sort;
@@ -2605,11 +2615,14 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
   return FFX_OK;
 }
 
-int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
-              const int32_t* pair_ids, const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff,
-              float* out_interp, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
+static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
+                      const int32_t* pair_ids, const float* sparse, const int32_t* carry, int mode, double alpha, uint32_t flags, float* out_ff,
+                      float* out_interp, int32_t* out_order, float* out_ranked, int32_t* out_carry, int64_t* bad_pair, ffx_stats* stats) {
   if (bad_pair) *bad_pair = -1;
   if (!idx || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
+  const bool ranked = out_ranked != nullptr || out_carry != nullptr;
+  if (ranked && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "the run in final order needs FFX_FLAG_SORT");
+  if (out_carry && !carry) return fail(FFX_BAD_ARG, "out_carry without carry");
   if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
   for (int64_t q = 0; q < n_queries; ++q)
     if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
@@ -2618,7 +2631,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
   if (out_order && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "out_order needs FFX_FLAG_SORT");
   if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
-  if (n_queries <= INT32_MAX - 1) {  // small batches of single-row candidates: one submission, one wait
+  if (n_queries <= INT32_MAX - 1 && !ranked) {  // small batches of single-row candidates: one submission, one wait
     bool handled = false;
     const int rc_small = score_small(idx, host_queries, n_queries, pair_off, pair_ids, sparse, mode, alpha, flags, out_ff, out_interp, out_order,
                                      bad_pair, stats, &handled);
@@ -2664,7 +2677,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   // instead of 18.4 ms for the headline batch, depending on which other streams the process had created).
   bool async_out = false;
   if (n_slices > 1 && !ffx_debug_variant("score_no_out_stream", nullptr)) {
-    const void* any = out_ff ? (const void*)out_ff : out_interp ? (const void*)out_interp : (const void*)out_order;
+    const void* any = out_ff ? (const void*)out_ff : out_interp ? (const void*)out_interp : out_order ? (const void*)out_order : out_ranked ? (const void*)out_ranked : (const void*)out_carry;
     hipPointerAttribute_t attr;
     if (any && hipPointerGetAttributes(&attr, any) == hipSuccess && attr.type == hipMemoryTypeHost)
       async_out = true;
@@ -2677,7 +2690,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
     for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order) && !ffx_debug_variant("score_blocking_out", nullptr);
+  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order || ranked) && !ffx_debug_variant("score_blocking_out", nullptr);
   const int n_plans = n_slices > 1 ? (async_out || threaded_out ? 3 : 2) : 1;
   for (int i = 0; i < n_plans; ++i)
     if (!idx->score_plans[i]) FFX_TRY(plan_create(idx, &idx->score_plans[i], i == 0));
@@ -2716,6 +2729,10 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
     const int64_t p0 = pair_off[cut[c]];
     FFX_TRY(ffx_plan_fetch(pl, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr,
                            out_order ? out_order + p0 : nullptr));
+    if (pl->n_pairs > 0) {
+      if (out_ranked) FFX_HIP(hipMemcpy(out_ranked + p0, pl->ranked.p, (size_t)pl->n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+      if (out_carry) FFX_HIP(hipMemcpy(out_carry + p0, pl->carry_ranked.p, (size_t)pl->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return add_stats(pl);
   };
   // FFX_SCORE_TRACE=1: host-side timeline of the slices on stderr (us since the call began)
@@ -2732,6 +2749,8 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
       if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff + p0, pl->ff.p, bytes, hipMemcpyDeviceToHost, os));
       if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp + p0, pl->interp.p, bytes, hipMemcpyDeviceToHost, os));
       if (out_order) FFX_HIP(hipMemcpyAsync(out_order + p0, pl->order.p, bytes, hipMemcpyDeviceToHost, os));
+      if (out_ranked) FFX_HIP(hipMemcpyAsync(out_ranked + p0, pl->ranked.p, bytes, hipMemcpyDeviceToHost, os));
+      if (out_carry) FFX_HIP(hipMemcpyAsync(out_carry + p0, pl->carry_ranked.p, bytes, hipMemcpyDeviceToHost, os));
     }
     FFX_HIP(hipEventRecord(idx->out_done[c % n_plans], os));
     return FFX_OK;
@@ -2759,6 +2778,8 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
         if (out_ff) FFX_HIP(hipMemcpy(out_ff + p0, pl->ff.p, bytes, hipMemcpyDeviceToHost));
         if (out_interp) FFX_HIP(hipMemcpy(out_interp + p0, pl->interp.p, bytes, hipMemcpyDeviceToHost));
         if (out_order) FFX_HIP(hipMemcpy(out_order + p0, pl->order.p, bytes, hipMemcpyDeviceToHost));
+        if (out_ranked) FFX_HIP(hipMemcpy(out_ranked + p0, pl->ranked.p, bytes, hipMemcpyDeviceToHost));
+        if (out_carry) FFX_HIP(hipMemcpy(out_carry + p0, pl->carry_ranked.p, bytes, hipMemcpyDeviceToHost));
       }
       return FFX_OK;
     };
@@ -2790,6 +2811,17 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
       off.resize((size_t)(q1 - q0 + 1));
       for (int64_t q = q0; q <= q1; ++q) off[(size_t)(q - q0)] = pair_off[q] - p0;
       pl->order_base = (int32_t)p0;
+      if (ranked) {  // room for the slice in final order; its carried words go up ahead of the lists (set_pairs waits for the stream)
+        const size_t sb = std::max<size_t>((size_t)(pair_off[q1] - p0), 1) * 4;
+        FFX_TRY(pl->ranked.ensure(sb));
+        FFX_TRY(pl->carry_ranked.ensure(sb));
+        if (carry) {
+          FFX_TRY(pl->carry.ensure(sb));
+          if (pair_off[q1] > p0) FFX_HIP(hipMemcpyAsync(pl->carry.p, carry + p0, (size_t)(pair_off[q1] - p0) * 4, hipMemcpyHostToDevice, pl->stream));
+        }
+      }
+      pl->want_ranked = ranked;
+      pl->have_carry = carry != nullptr;
       int64_t bad = -1;
       const int rc = ffx_plan_set_pairs(pl, off.data(), q1 - q0, pair_ids ? pair_ids + p0 : nullptr,
                                         sparse ? sparse + p0 : nullptr, mode, &bad);
@@ -2800,6 +2832,7 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
       const double t2 = us();
       if (async_out || threaded_out) pl->stream = idx->score_stream;
       const int rc_run = ffx_plan_run(pl, alpha, flags);
+      pl->want_ranked = false;
       pl->stream = home[c % n_plans];
       if (rc_run != FFX_OK) return rc_run;
       const double t3 = us();
@@ -2847,6 +2880,21 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, cons
   }
   if (stats) *stats = acc;
   return FFX_OK;
+}
+
+int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
+              const int32_t* pair_ids, const float* sparse, int mode, double alpha, uint32_t flags, float* out_ff,
+              float* out_interp, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
+  return score_impl(idx, host_queries, n_queries, pair_off, pair_ids, sparse, nullptr, mode, alpha, flags, out_ff, out_interp, out_order, nullptr, nullptr,
+                    bad_pair, stats);
+}
+
+int ffx_score_ranked(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off, const int32_t* pair_ids,
+                     const float* sparse, const int32_t* carry, int mode, double alpha, uint32_t flags, float* out_scores, int32_t* out_carry,
+                     int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
+  if (!out_scores) return fail(FFX_BAD_ARG, "out_scores is NULL");
+  return score_impl(idx, host_queries, n_queries, pair_off, pair_ids, sparse, carry, mode, alpha, flags | FFX_FLAG_SORT, nullptr, nullptr, out_order, out_scores,
+                    out_carry, bad_pair, stats);
 }
 
 // ---- page-locked host memory ------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <cstdint>
 
 #include "../../include/ffx.h"
+#include "../../include/ffx_private.h"
 
 int ffx_fail(int code, const char* fmt, ...);
 bool ffx_debug_variant(const char* name, long long* value);  // the FFX_DEBUG_VARIANT list of A/B switches (ffx.hip)

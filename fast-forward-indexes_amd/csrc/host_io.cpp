@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/ffx.h"
+#include "../../include/ffx_private.h"
 
 int ffx_fail(int code, const char* fmt, ...);  // ffx.hip: records the thread's last error
 

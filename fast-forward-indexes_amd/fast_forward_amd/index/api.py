@@ -88,33 +88,37 @@ class _Run:
         step = self.n_q if (batch_size is None or batch_size >= self.n_q) else max(1, int(batch_size))
         return [(qa, min(self.n_q, qa + step)) for qa in range(0, self.n_q, max(1, step))]
 
-    def result(self, name, kept: np.ndarray, scores: np.ndarray, off: np.ndarray, q_range: "tuple[int, int] | None" = None) -> Ranking:
+    def result(self, name, kept: "np.ndarray | None", scores: np.ndarray, off: np.ndarray, q_range: "tuple[int, int] | None" = None,
+               codes: "np.ndarray | None" = None) -> Ranking:
         """The ``Ranking`` of the rows ``kept`` (positions in the grouped layout; query after query in query-number
         order, ``off[q]`` .. ``off[q+1]`` those of query q of ``q_range``, inside a query in their final order) with
         ``scores``.  Queries without a kept row disappear; the queries are put in descending id order if they do not
-        stand so already (ranking.py:115-117)."""
+        stand so already (ranking.py:115-117).  ``codes``: the id codes of the kept rows when the device has permuted
+        them along already (``kept`` may then be None: nothing is gathered here)."""
         from fast_forward_amd import native
 
         q_lo, q_hi = q_range if q_range is not None else (0, self.n_q)
         counts = np.diff(off)
         present = np.flatnonzero(counts)
         q_order = [self.q_order[q_lo + i] for i in present]
-        src = kept if self.perm is None else self.perm[kept]  # rows of the ranking
+        src = None if kept is None else (kept if self.perm is None else self.perm[kept])  # rows of the ranking
         if not _in_final_order(q_order):  # lay the queries' blocks out in descending id order
             by_name = sorted(range(len(present)), key=lambda i: q_order[i], reverse=True)
             blocks = present[by_name]
             pick = np.concatenate([np.arange(off[q], off[q + 1]) for q in blocks]) if len(blocks) else np.zeros(0, dtype=np.int64)
-            src, scores, present, q_order = src[pick], scores[pick], blocks, [q_order[i] for i in by_name]
+            src, scores, present, q_order = (None if src is None else src[pick]), scores[pick], blocks, [q_order[i] for i in by_name]
+            codes = None if codes is None else codes[pick]
             counts_out, moved = counts[blocks], True
         else:
             counts_out, moved = counts[present], False
-        if q_range is None and self.perm is None and not moved and len(present) == self.n_q and len(src) == len(self.q_no) \
+        if q_range is None and self.perm is None and not moved and len(present) == self.n_q and len(scores) == len(self.q_no) \
                 and np.array_equal(off, self.pair_off):
             q_no = self.q_no  # every row kept, the queries' blocks where they were: the ranking's own numbering (35 M int64 not written again)
         else:
             q_no = np.repeat(np.arange(len(present), dtype=np.int64), counts_out)
         texts = None if self.texts is None else [self.texts[q_lo + i] for i in present]
-        codes = native.take32(self.codes, src) if src.dtype == np.int32 else self.codes[src]
+        if codes is None:
+            codes = native.take32(self.codes, src) if src.dtype == np.int32 else self.codes[src]
         out = Ranking._assemble_coded(name, q_no, q_order, codes, self.names, scores.astype(self.ranking._score_dtype(), copy=False), texts,
                                       self.ranking._id_blob(self.names))
         return out, src
@@ -393,6 +397,15 @@ class Index(abc.ABC):
         if early_stopping is None:
             ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
             whole = len(run.batches(batch_size)) == 1
+            if whole and hasattr(self, "_score_ranked") and len(ordinals) >= self._RANKED_FROM:
+                # the device lays the run out in its final order, the ranking's id codes permuted along: nothing is gathered here
+                scores, codes, kept = self._score_ranked(run.query_vectors, off, ordinals, self.mode, None, None, run.grouped(run.codes), want_order=True)
+                out, _ = run.result("fast-forward", kept, scores, off, codes=codes)
+                LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
+                src = kept if run.perm is None else run.perm[kept]
+                out._source_rows = (weakref.ref(ranking), src)
+                out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None))
+                return out
             for qa, qb in run.batches(batch_size):
                 pa, pb = int(off[qa]), int(off[qb])
                 dense, _, order = self._score_pairs(run.query_vectors[qa:qb], off[qa:qb + 1] - pa, ordinals[pa:pb], self.mode, sort=True,
@@ -427,7 +440,10 @@ class Index(abc.ABC):
             out._source_rows = (weakref.ref(ranking), src if (borrowed or src.base is None) else np.array(src, dtype=np.int32))
             if borrowed:
                 self._order_borrower = weakref.ref(out)
+            out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None))
         return out
+
+    _RANKED_FROM = 1 << 18  # candidates from which the device applies the ordering itself (ffx_score_ranked)
 
     def _ordinals_of_codes(self, ranking: Ranking, codes: np.ndarray, names: np.ndarray, missing_ok: bool = False) -> np.ndarray:
         """Index ordinals of a ranking's rows through its id codes: the DISTINCT id strings are looked
@@ -483,19 +499,33 @@ class Index(abc.ABC):
         ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
         t.append(perf_counter())
         sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
-        _, interp, order = self._score_pairs(run.query_vectors, run.pair_off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False,
-                                             **self._reuse_kw())
-        t.append(perf_counter())
         off = run.pair_off
-        if cutoff is not None:  # (the device order is a permutation inside every query)
-            keep = np.arange(len(order)) - np.repeat(off[:-1], np.diff(off)) < cutoff
-            order = order[keep]
-            off = np.concatenate([[0], np.cumsum(np.minimum(np.diff(off), cutoff))]).astype(np.int64)
-        out, _ = run.result(ranking.name, order, native.take32(interp, order), off)
-        t.append(perf_counter())
+        if hasattr(self, "_score_ranked") and len(ordinals) >= self._RANKED_FROM:
+            # the device applies the ordering: interpolated scores and the ranking's id codes come back in final order, in
+            # page-locked blocks of the result pool that the result keeps -- no gather, no copy, no fresh pages on the host
+            carry = run.grouped(run.codes)
+            t.append(perf_counter())
+            scores, codes, _ = self._score_ranked(run.query_vectors, off, ordinals, self.mode, sparse, alpha, carry)
+            t.append(perf_counter())
+            if cutoff is not None:  # (a query's block stands in final order: its first `cutoff` rows are its best)
+                keep = np.arange(len(scores)) - np.repeat(off[:-1], np.diff(off)) < cutoff
+                scores, codes = scores[keep], codes[keep]
+                off = np.concatenate([[0], np.cumsum(np.minimum(np.diff(off), cutoff))]).astype(np.int64)
+            out, _ = run.result(ranking.name, None, scores, off, codes=codes)
+            t.append(perf_counter())
+            names = ("queries_numbered_and_encoded_s", "ids_to_ordinals_s", "first_stage_scores_and_codes_grouped_s", "upload_device_download_s", "result_assembled_s")
+        else:
+            _, interp, order = self._score_pairs(run.query_vectors, off, ordinals, self.mode, sparse, alpha, sort=True, want_dense=False, **self._reuse_kw())
+            t.append(perf_counter())
+            if cutoff is not None:  # (the device order is a permutation inside every query)
+                keep = np.arange(len(order)) - np.repeat(off[:-1], np.diff(off)) < cutoff
+                order = order[keep]
+                off = np.concatenate([[0], np.cumsum(np.minimum(np.diff(off), cutoff))]).astype(np.int64)
+            out, _ = run.result(ranking.name, order, native.take32(interp, order), off)
+            t.append(perf_counter())
+            names = ("queries_numbered_and_encoded_s", "ids_to_ordinals_s", "upload_device_download_s", "result_gathers_s")
         # where a call's time went (seconds): a first call on a ranking pays for the distinct-id look-up, later ones do not
-        self.last_timings = dict(zip(("queries_numbered_and_encoded_s", "ids_to_ordinals_s", "upload_device_download_s", "result_gathers_s"),
-                                     np.diff(t).tolist()), **getattr(self, "_last_lookup_timings", {}))
+        self.last_timings = dict(zip(names, np.diff(t).tolist()), total_s=t[-1] - t[0], **getattr(self, "_last_lookup_timings", {}))
         return out
 
     def rerank_file(self, run_in, run_out, alpha: float, queries, cutoff: int | None = None, name: str | None = None) -> dict:

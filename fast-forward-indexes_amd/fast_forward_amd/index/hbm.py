@@ -258,6 +258,21 @@ class InMemoryIndex(Index):
         self.last_stats = plan.stats()
         return ff, interp, order
 
+    def _score_ranked(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse, alpha, carry, want_order: bool = False):
+        """The run in final order straight off the device (``ffx_score_ranked``): (scores, carried codes, order | None).
+        Scores are the interpolated ones when ``sparse`` is given, else the dense ones."""
+        if self._store is None:
+            raise IndexError("the index is empty")
+        q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self._store.query_dim:
+            raise ValueError(f"Query vector dimensionality ({q.shape[-1]}) does not match index dimensionality ({self._store.query_dim}).")
+        if self._rotation is not None:
+            q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
+        self._sync_ids()
+        scores, codes, order, self.last_stats = native.score_ranked(self._store, q, pair_off, pair_ids, mode.value, sparse, 0.0 if alpha is None else alpha,
+                                                                    carry=carry, exact_sum=self.exact_sum, want_order=want_order)
+        return scores, codes, order
+
     _PIPELINED_FROM = 6 << 20  # pairs: below this ffx_score would run a single slice anyway
 
     def _early_stopping_kept(self, id_at, sparse, pair_off, query_vectors, cutoff: int, alpha: float, depths, ordinals):

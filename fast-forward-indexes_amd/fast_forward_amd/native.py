@@ -20,27 +20,31 @@ TOKEN_INT, TOKEN_NUMBER, TOKEN_NA, TOKEN_TEXT = 1, 2, 4, 8
 RUN_SHORT_LINE, RUN_LONG_LINE, RUN_QUOTES = 1, 2, 4
 BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 3, 4, 5
 
-# every symbol include/ffx.h declares (tests check the library exports all of them)
+# every symbol include/ffx.h declares: the stable contract (tests check the library exports all of them) ...
 SYMBOLS = (
-    "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info",
-    "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype", "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
-    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_after", "ffx_index_upload_wait", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_fill_synthetic",
-    "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
-    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device",
-    "ffx_plan_run", "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_recent_gather_ms", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats", "ffx_plan_device_ptr",
-    "ffx_plan_stream", "ffx_plan_set_stream", "ffx_score",
-    "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set", "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync",
-    "ffx_merge_fetch", "ffx_merge_device_ptr",
-    "ffx_aggregate",
-    "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_ids_get", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_host_code_u64", "ffx_host_owner_crc32", "ffx_buffer_free",
-    "ffx_run_open", "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_run_save", "ffx_run_save_coded", "ffx_run_flags", "ffx_run_ids_blob",
-    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin", "ffx_host_order", "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_outer_join", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets", "ffx_host_segment_rows_unique",
-    "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank", "ffx_comm_stream", "ffx_comm_barrier",
-    "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host", "ffx_comm_rehearsal_inbox",
-    "ffx_query_partition", "ffx_route",
-    "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs", "ffx_sharded_set_pairs_held",
-    "ffx_sharded_run", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
-    "ffx_sharded_stage_owned", "ffx_sharded_stage_queries", "ffx_sharded_fetch_async", "ffx_sharded_score",
+    "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info", "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype",
+    "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
+    "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
+    "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_run",
+    "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats",
+    "ffx_plan_device_ptr", "ffx_plan_stream", "ffx_plan_set_stream", "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank",
+    "ffx_comm_stream", "ffx_comm_barrier", "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
+    "ffx_query_partition", "ffx_route", "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs",
+    "ffx_sharded_set_pairs_held", "ffx_sharded_stage_owned", "ffx_sharded_stage_queries", "ffx_sharded_run", "ffx_sharded_fetch_async",
+    "ffx_sharded_score", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
+    "ffx_aggregate", "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get", "ffx_run_open",
+    "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_score", "ffx_score_ranked",
+    "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
+)
+# ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
+PRIVATE_SYMBOLS = (
+    "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
+    "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
+    "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
+    "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_buffer_free",
+    "ffx_host_owner_crc32", "ffx_host_code_u64", "ffx_run_flags", "ffx_run_ids_blob", "ffx_run_save", "ffx_run_save_coded", "ffx_host_order",
+    "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets",
+    "ffx_host_segment_rows_unique", "ffx_host_outer_join",
 )
 COMM_RCCL, COMM_HOST, COMM_REHEARSAL, COMM_ID_BYTES = 0, 1, 2, 128
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
@@ -198,6 +202,7 @@ def lib() -> C.CDLL:
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
+        "ffx_score_ranked": ([vp, vp, i64, vp, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
         "ffx_host_alloc": ([C.c_size_t, P(vp)], C.c_int),
         "ffx_host_free": ([vp], C.c_int),
         "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
@@ -622,6 +627,79 @@ def pinned_empty(shape, dtype) -> np.ndarray:
     return np.frombuffer(owner, dtype=dtype, count=n).reshape(shape)
 
 
+# ---- a pool of page-locked result blocks --------------------------------------------------------------------
+# The arrays a large result is handed out in.  A fresh 140 MB NumPy array costs a page fault per 4 KB when it is first
+# written (~10 ms) and an munmap when it dies (~5 ms), and the device cannot copy into it at link rate; a page-locked block
+# costs ~40 ms to make.  So result blocks are page-locked ONCE and go back to this pool when the last view of them dies: the
+# next call's results land straight in them (no gather, no copy, no fault).  Bounded: at most FFX_RESULT_POOL_BYTES (default
+# 4 GiB) of idle blocks are kept; beyond that a dying block is released.
+_POOL: dict = {}
+_POOL_IDLE = [0]
+
+
+def _pool_limit() -> int:
+    import os
+
+    try:
+        return int(os.environ.get("FFX_RESULT_POOL_BYTES", str(4 << 30)))
+    except ValueError:
+        return 4 << 30
+
+
+def _pool_class(nbytes: int) -> int:
+    """Block size a request is served from: the next of 1, 1.25, 1.5, 1.75 x 2^k (at most 25 % over)."""
+    nbytes = max(nbytes, 1 << 16)
+    k = nbytes.bit_length() - 1
+    for q in (4, 5, 6, 7, 8):
+        if (q << k) >> 2 >= nbytes:
+            return (q << k) >> 2
+    return 2 << k
+
+
+def _return_pooled(self) -> None:
+    addr = C.addressof(self)
+    if not addr or _lib is None:
+        return
+    cap = C.sizeof(self)
+    try:
+        if _POOL_IDLE[0] + cap <= _pool_limit():
+            _POOL.setdefault(cap, []).append(addr)
+            _POOL_IDLE[0] += cap
+            return
+    except Exception:  # interpreter shutdown: the module's globals may be gone
+        pass
+    _lib.ffx_host_free(C.c_void_p(addr))
+
+
+def pooled_empty(n: int, dtype) -> np.ndarray:
+    """``np.empty(n, dtype)`` in a page-locked block of the result pool (see above): released back to the pool, not to
+    the system, when its last view dies."""
+    dtype = np.dtype(dtype)
+    n = int(n)
+    cap = _pool_class(max(1, n * dtype.itemsize))
+    free = _POOL.get(cap)
+    if free:
+        addr = free.pop()
+        _POOL_IDLE[0] -= cap
+    else:
+        p = C.c_void_p()
+        _check(lib().ffx_host_alloc(cap, C.byref(p)))
+        addr = p.value
+    owner = type("PooledBytes", (C.c_char * cap,), {"__del__": _return_pooled}).from_address(addr)
+    return np.frombuffer(owner, dtype=dtype, count=n)
+
+
+def drain_result_pool() -> int:
+    """Release every idle block of the result pool; returns the bytes freed."""
+    freed = 0
+    for cap, blocks in list(_POOL.items()):
+        while blocks:
+            lib().ffx_host_free(C.c_void_p(blocks.pop()))
+            freed += cap
+    _POOL_IDLE[0] = 0
+    return freed
+
+
 class pinned:
     """Context manager: page-lock existing arrays for the duration (``ffx_host_pin``)."""
 
@@ -710,6 +788,28 @@ def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=Non
                          float(alpha), flags, _ptr(ff), _ptr(interp), _ptr(order), C.byref(bad), C.byref(st))
     _check(rc, bad.value)
     return ff, interp, order, st.as_dict()
+
+
+def score_ranked(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0, carry=None,
+                 exact_sum: bool = True, want_order: bool = False, sort_ff: bool = False):
+    """``ffx_score_ranked``: the run in FINAL order -- (scores, carried words | None, order | None, stats), the scores
+    being the interpolated ones when ``sparse`` is given, else the dense ones; ``carry``: one int32 per candidate that is
+    permuted along (a ranking's id codes).  Large results land in blocks of the page-locked result pool."""
+    queries = _arr(queries, np.float32)
+    pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
+    sp = None if sparse is None else _arr(sparse, np.float32)
+    ca = None if carry is None else _arr(carry, np.int32)
+    n = int(pair_off[-1])
+    make = pooled_empty if n >= (1 << 18) else (lambda m, dt: np.empty(m, dtype=dt))
+    scores = make(n, np.float32)
+    out_carry = None if ca is None else make(n, np.int32)
+    order = make(n, np.int32) if want_order else None
+    bad, st = C.c_int64(-1), Stats()
+    flags = (FLAG_EXACT_SUM if exact_sum else 0) | FLAG_SORT | (FLAG_SORT_FF if sort_ff else 0)
+    rc = lib().ffx_score_ranked(index._h, _ptr(queries), queries.shape[0], _ptr(pair_off), _ptr(pair_ids), _ptr(sp), _ptr(ca), int(mode), float(alpha), flags,
+                                _ptr(scores), _ptr(out_carry), _ptr(order), C.byref(bad), C.byref(st))
+    _check(rc, bad.value)
+    return scores, out_carry, order, st.as_dict()
 
 
 def host_order(scores, pair_off, threads: int = 0, dst_off=None) -> np.ndarray:

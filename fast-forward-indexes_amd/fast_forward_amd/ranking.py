@@ -597,6 +597,14 @@ class Ranking:
             native.lib()
         except (ImportError, OSError):
             return None
+        # A large run whose dense scores came from an index that is still there, unchanged: the device does the whole of it
+        # again -- gather, interpolation with THIS alpha, ordering, final layout -- faster than the host orders 35 M scores
+        # (Index.rerank; same bits, pinned by test_rerank_equals_call_then_interpolate).
+        origin = getattr(other, "_origin", None)
+        index = origin[0]() if origin is not None else None
+        if (index is not None and isinstance(alpha, (int, float)) and len(mine) >= (1 << 20) and self.has_queries and origin[1] == index.mode
+                and origin[2] == getattr(getattr(index, "_ids", None), "version", None) and hasattr(index, "_score_ranked")):
+            return index.rerank(self, alpha)
         if isinstance(alpha, (int, float)) and len(mine) >= (1 << 18) and link[1].dtype == np.int32:
             # one threaded pass: scatter back + `alpha * mine + (1 - alpha) * dense` in float32, as below
             score, any_nan = native.host_interpolate(mine, other._scores(), link[1], alpha)

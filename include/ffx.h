@@ -19,6 +19,11 @@
  *   - ids are integers here: a *document ordinal* names the rows of one document (in
  *     insertion order), a *passage ordinal* names one row.  String ids stay in the host
  *     language (reference: the dicts at src/fast_forward/index/memory.py:46-47).
+ *
+ * This header is the STABLE contract: what INTEGRATION.md binds and tests/c_abi/ uses from plain C.  The helpers the
+ * Python layer of this repository uses on top of it (threaded host gathers / joins / orderings over NumPy arrays, string
+ * numbering, the building blocks ffx_sharded and the streamed index are made of, test-data generators) live in
+ * ffx_private.h: exported by the same library, no stability promise.
  */
 #ifndef FFX_H_
 #define FFX_H_
@@ -124,27 +129,10 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
  * (n_threads; 0 = half the cores) fill page-locked staging while the previous block is copied. */
 int ffx_index_upload_rows(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
                           const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads);
-/* the same, returning once every row is gathered and its copy queued (not landed): the caller's next gather overlaps the
- * tail of the copies; ffx_index_upload_wait before the rows are used (it also finishes the code check of PQ rows) */
-int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
-                                const int64_t* rows, int64_t n_rows, int64_t dst_row, int32_t n_threads);
-/* the same rows pulled by the DEVICE itself: every chunk map is page-locked host memory (ffx_host_pin each map once; a
- * memory-mapped file may be page-locked), a kernel on the index's copy stream reads the rows over PCIe.  No staging
- * block and no host thread touches the rows.  Asynchronous; ffx_index_upload_wait before the rows are used. */
-int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t n_chunks, int64_t chunk_rows,
-                              const int64_t* rows, int64_t n_rows, int64_t dst_row);
-int ffx_index_upload_wait(ffx_index* idx);
-/* whatever is queued on idx's copy stream from now on runs after what `before`'s copy stream holds so far (the windows
- * of a streamed index arrive one after the other instead of sharing the link) */
-int ffx_index_upload_after(ffx_index* idx, ffx_index* before);
 /* device copy between two indexes on the same device (growing an index) */
 int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows);
 /* read rows back: InMemoryIndex._get_vectors, memory.py:139-140 / index/util.py:97-98 */
 int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, void* host_out); /* in the index dtype */
-/* fill rows with the counter-based synthetic generator shared with the oracle
- * (value of element e of global row g: see fast_forward_amd/synth.py); bench/test data only */
-int ffx_index_fill_synthetic(ffx_index* idx, uint64_t seed, float scale, int64_t row_offset,
-                             int64_t n_rows, int64_t first_global_row);
 /* id structure: the two dicts of memory.py:46-47 as arrays.
  *   doc ordinal o -> rows doc_rows[doc_off[o] .. doc_off[o+1])   (insertion order)
  *   psg ordinal o -> row psg_row[o]                               (-1: no such passage) */
@@ -171,17 +159,7 @@ int ffx_plan_set_queries_device(ffx_plan* plan, const float* dev_queries, int64_
  * the first-stage score (may be NULL).  get_indices, index/util.py:12-42, runs here. */
 int ffx_plan_set_pairs(ffx_plan* plan, const int64_t* pair_off, int64_t n_queries,
                        const int32_t* pair_ids, const float* sparse, int mode, int64_t* bad_pair);
-/* dst is to score the same candidate lists as src (two plans of ONE index, e.g. alternating send buffers): the
- * validated lists are taken over device to device instead of being uploaded and validated again. */
-int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src);
-/* ffx_plan_set_pairs for lists that already are in DEVICE memory (copied device to device); host_pair_off holds the
- * same offsets on the host.  No first-stage scores.  Used by the sharded scorer, which routes a batch on the device. */
-int ffx_plan_set_pairs_device(ffx_plan* plan, const int64_t* dev_pair_off, const int64_t* host_pair_off, int64_t n_queries,
-                              const int32_t* dev_pair_ids, int mode, int64_t* bad_pair);
 int ffx_plan_run(ffx_plan* plan, double alpha, uint32_t flags);
-/* gather_dot's duration (HIP events on the plan's stream) of the last n runs, oldest first, for a caller that queues
- * runs back to back without waiting in between (n <= 256 and <= the runs so far); waits for the stream */
-int ffx_plan_recent_gather_ms(ffx_plan* plan, int32_t n, float* out_ms);
 /* ---- early stopping: replaces Index._early_stopping, index/base.py:316-387 ------------------
  * Candidates of a query stand in first-stage rank order.  set_pairs_lazy uploads the lists without
  * validating ordinals (use -1 for an id the host could not resolve): as in the reference, an unknown
@@ -213,27 +191,6 @@ int ffx_plan_stream(ffx_plan* plan, void** stream);
 /* run the plan on a caller-owned HIP stream (hipStream_t; e.g. the stream a collective library
  * orders its work on) instead of the plan's own; NULL restores the plan's own stream */
 int ffx_plan_set_stream(ffx_plan* plan, void* stream);
-
-/* ---- merge: the owner-side half of a row-sharded index --------------------------------------
- * With the index row-sharded by document over several GPUs (one process each), every rank scores
- * the candidates whose documents it holds, and the dense scores of one query arrive at the
- * query's owner rank from all ranks (ffx_comm_exchange below).  The owner then scatters them back
- * into first-stage order, interpolates (ranking.py:319) and orders (ranking.py:115-117) -- the same
- * arithmetic as ffx_plan_run's epilogue, on a device buffer. */
-typedef struct ffx_merge ffx_merge;
-int ffx_merge_create(int device, ffx_merge** out);
-int ffx_merge_destroy(ffx_merge* m);
-/* pair_off: CSR of the owned queries' candidates in first-stage order; recv_slot[p]: where the
- * dense score of candidate p sits in the received buffer; sparse may be NULL */
-int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* recv_slot,
-                  const float* sparse);
-/* the same with the arrival slots in DEVICE memory (offsets and first-stage scores still come from the host) */
-int ffx_merge_set_device(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, const int32_t* dev_recv_slot, const float* sparse);
-/* recv_dev: DEVICE pointer to n_pairs floats.  stream: hipStream_t to run on (NULL: own stream) */
-int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t flags, void* stream);
-int ffx_merge_sync(ffx_merge* m);
-int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out_order);
-int ffx_merge_device_ptr(ffx_merge* m, int which, void** ptr, int64_t* n_elems);
 
 /* ---- multi-GPU: one process per GPU, row-sharded index ------------------------------------------
  * The reference is single-process; this is the sharded form of the same path
@@ -277,10 +234,6 @@ int ffx_comm_exchange(ffx_comm* comm, const float* send_dev, const int64_t* send
  * scratch -- for scores a streamed index produced on the host) */
 int ffx_comm_exchange_host(ffx_comm* comm, const float* send, const int64_t* send_counts, float* recv,
                            const int64_t* recv_counts);
-/* FFX_COMM_REHEARSAL only: what the peers WOULD send on the routing lane (ffx_sharded_stage_owned) from now on -- n_words
- * 4-byte words of DEVICE memory made by the caller, who knows the whole synthetic batch: per-query counts, candidate
- * ordinals, query vectors, in the order the lane receives them.  NULL: zeros again. */
-int ffx_comm_rehearsal_inbox(ffx_comm* comm, const void* dev_words, int64_t n_words);
 
 /* routing, host only: from the CSR of ALL queries (pair_ids = GLOBAL document ordinals) what rank
  * `rank` scores and what it finalises.  Shards are the document ranges doc_bounds[r]..doc_bounds[r+1];
@@ -398,37 +351,7 @@ int ffx_ids_intern(ffx_ids* table, const char* strs, int32_t width, int64_t n, i
 /* FFX_NOT_FOUND (+ position of the first unknown string) if any is absent; absent -> -1 */
 int ffx_ids_lookup(const ffx_ids* table, const char* strs, int32_t width, int64_t n, int32_t* out_ordinals,
                    int64_t* first_missing);
-/* ffx_ids_lookup for n strings handed over as one buffer with the byte `sep` between them */
-int ffx_ids_lookup_packed(const ffx_ids* ids, const char* data, int64_t n_bytes, char sep, int64_t n,
-                          int32_t* out_ordinals, int64_t* first_missing);
-/* ffx_ids_intern for n strings handed over as one buffer with `sep` between them */
-int ffx_ids_intern_packed(ffx_ids* table, const char* data, int64_t n_bytes, char sep, int64_t n, int32_t* out_ordinals);
-/* all strings in ordinal order joined by `sep`; *needed = bytes required, copied when cap suffices */
-int ffx_ids_blob(const ffx_ids* table, char sep, char* buf, int64_t cap, int64_t* needed);
 int ffx_ids_get(const ffx_ids* table, int32_t ordinal, const char** str, int32_t* len);
-
-/* Numbering the n strings of one joined buffer without keeping a table (the factorisation of a run's id column,
- * ranking.py:95-98): codes[i] = number of string i, equal strings get equal numbers, numbers are dense; *names_blob
- * receives the distinct strings in number order, joined by `sep` (*names_bytes bytes, *n_names strings; release it
- * with ffx_buffer_free).  By host threads (n_threads <= 0: every core this process may use); the numbering does not
- * depend on the thread count. */
-int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int32_t n_threads, int32_t* codes, char** names_blob,
-                     int64_t* names_bytes, int64_t* n_names);
-/* ffx_strings_code for strings lying back to back in `data`, string i = data[offsets[i] .. offsets[i+1]) (the layout of
- * an Arrow string array: nothing to join, nothing to scan for separators); `sep` only joins *names_blob */
-int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes,
-                             char** names_blob, int64_t* names_bytes, int64_t* n_names);
-int ffx_buffer_free(void* p);
-/* owner[i] = crc32 (zlib's) of row i's document id -- its passage id if it has no document id -- modulo world: the rank of a
- * sharded index that holds the row (255: the row has neither id).  Ids as NUL-padded fixed-width fields (the id columns of
- * an index file, index/disk.py:145-165); either column may be NULL.  Each rank keeps and interns only its own rows' ids. */
-int ffx_host_owner_crc32(const char* doc_ids, int32_t doc_width, const char* psg_ids, int32_t psg_width, int64_t n, int32_t world,
-                         int32_t n_threads, uint8_t* owner);
-/* Numbering n 8-byte values (the key is the value itself): codes[i] = number of values[i], dense, ascending with the
- * values; first_row[c] = a row that holds number c (first_row must hold n entries at most).  A column of a pandas frame is an
- * array of pointers to string objects shared by many rows: numbering the pointers leaves only the distinct objects to
- * be read as strings (the Ranking constructor, ranking.py:95-116, at tens of millions of rows). */
-int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int32_t* codes, int64_t* first_row, int64_t* n_distinct);
 
 /* ffx_run: a TREC run file (q_id Q0 id rank score name) parsed straight into the CSR of
  * ffx_plan_set_pairs, and written back; replaces Ranking.from_file / cut / save
@@ -447,8 +370,6 @@ typedef struct ffx_run ffx_run;
 #define FFX_RUN_LONG_LINE 2  /* a line with more than 6 fields                                   */
 #define FFX_RUN_QUOTES 4     /* a double quote somewhere in the file                             */
 int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* bad_line);
-int ffx_run_flags(const ffx_run* run, int32_t* q_flags, int32_t* id_flags, int32_t* misc_flags);
-int ffx_run_ids_blob(const ffx_run* run, char* buf, int64_t cap, int64_t* needed);
 int ffx_run_close(ffx_run* run);
 int ffx_run_counts(const ffx_run* run, int64_t* n_queries, int64_t* n_pairs);
 int ffx_run_query_id(const ffx_run* run, int64_t q, const char** str, int32_t* len);
@@ -457,18 +378,6 @@ int ffx_run_tag(const ffx_run* run, const char** str, int32_t* len);
 int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pair_ids, float* sparse, int64_t* n_pairs);
 int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
                   const char* tag);
-
-/* Ranking.save (ranking.py:348-366) of a frame grouped by query, without a parsed run: q_blob holds
- * the n_queries query ids and id_blob the n_pairs candidate ids (frame order), each joined by '\n';
- * pair_off[q] .. pair_off[q+1] are the rows of query q.  Scores are printed like pandas prints
- * float32. */
-int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
-                 const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag);
-/* the same for rows that hold id CODES (what Index.__call__ / Index.rerank / Ranking.from_file keep for a large
- * run): row p is written with string number id_codes[p] of name_blob (n_names strings joined by '\n') */
-int ffx_run_save_coded(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
-                       const char* name_blob, int64_t name_bytes, int64_t n_names, const int32_t* id_codes, int64_t n_pairs,
-                       const float* scores, const char* tag);
 
 /* one-shot, host buffers in, host buffers out.  A small batch of single-row candidates is submitted in one go
  * and waited for once.  A large batch is cut into slices of whole queries that rotate through three plans kept
@@ -482,57 +391,14 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
               double alpha, uint32_t flags, float* out_ff, float* out_interp, int32_t* out_order,
               int64_t* bad_pair, ffx_stats* stats);
 
-/* per-query order computed on the HOST (threads over queries): scores descending, exact ties by position,
- * -0.0 == +0.0 -- the same order FFX_FLAG_SORT gives on the device (ranking.py:115-117), for scores that were
- * combined on the host (Ranking.interpolate, ranking.py:293-326).  out_order[p]: position in the whole array. */
-int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queries, int32_t n_threads, int32_t* out_order);
-/* the same with the queries' blocks laid out anew: query q's order is written from out_order[dst_off[q]] on (every query
- * ordered and the queries put into the constructor's "q_id descending" sequence in one pass); dst_off NULL = in place */
-int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries, int32_t n_threads,
-                          int32_t* out_order);
-
-/* out[i] = src[index[i]] for 4-byte elements (float32 scores, int32 id codes), by host threads (n_threads <= 0:
- * every core this process may use): reorders a run's columns by the per-query order of ffx_plan_fetch /
- * ffx_score / ffx_host_order (the other half of ranking.py:115-117's sort).  FFX_BAD_ARG for an index
- * outside [0, n_src). */
-int ffx_host_take32(const void* src, int64_t n_src, const int32_t* index, int64_t n, int32_t n_threads, void* out);
-
-/* Ranking.interpolate (ranking.py:319) on the host when the dense ranking's rows are a known permutation of the
- * first-stage ranking's (row i of the dense one is row source_row[i] of the sparse one):
- *   out[source_row[i]] = f32(a * sparse[source_row[i]]) + f32(b * dense_of[i])      (no FMA)
- * by host threads.  source_row must be a permutation of 0..n-1 (FFX_BAD_ARG otherwise); *any_nan (may be NULL)
- * is set when a result is NaN. */
-int ffx_host_interpolate(const float* sparse, const float* dense_of, const int32_t* source_row, int64_t n, float a, float b,
-                         int32_t n_threads, float* out, int32_t* any_nan);
-
-/* numpy.unique(rows, return_inverse=True) for row numbers in 0 .. n_index_rows-1 without a sort (a bitmap over the
- * index's rows, marked and ranked by host threads): the distinct rows a streamed batch reads from the index file, ascending,
- * and every gathered row's position among them.  uniq must hold min(n, n_index_rows) entries. */
-int ffx_host_unique_rows(const int64_t* rows, int64_t n, int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse);
-
-/* get_indices (index/util.py:29-41) for candidates that contribute one row each, fused with the above:
- * row(i) = table2 ? table2[table1[ids[i]]] : table1[ids[i]] (PASSAGE: table1 = rows of the passages; FIRSTP / one-row
- * documents: table1 = first entry of each document, table2 = rows of the entries), then the distinct rows ascending and
- * every candidate's slot among them.  An id or entry outside its table, or a row outside the index, is refused. */
-int ffx_host_rows_unique(const int32_t* ids, int64_t n, const int32_t* table1, int64_t n1, const int32_t* table2, int64_t n2,
-                         int64_t n_index_rows, int32_t n_threads, int64_t* uniq, int64_t* n_uniq, int32_t* inverse);
-
-/* the same for candidates that contribute ALL rows of their document (MaxP / AveP over multi-passage documents):
- * entry_off[id] .. entry_off[id + 1] (n_docs + 1 offsets) are the document's entries, entry_row[] (n_entries) their rows.
- * ffx_host_segment_offsets: seg_off[0 .. n], seg_off[n] = R gathered rows; ffx_host_segment_rows_unique (seg_off as
- * returned): the distinct rows ascending and, in inverse[0 .. R), the slot of every gathered row among them. */
-int ffx_host_segment_offsets(const int32_t* ids, int64_t n, const int32_t* entry_off, int64_t n_docs, int32_t n_threads, int64_t* seg_off);
-int ffx_host_segment_rows_unique(const int32_t* ids, int64_t n, const int32_t* entry_off, int64_t n_docs, const int32_t* entry_row,
-                                 int64_t n_entries, const int64_t* seg_off, int64_t n_index_rows, int32_t n_threads, int64_t* uniq,
-                                 int64_t* n_uniq, int32_t* inverse);
-
-/* The outer join of Ranking.interpolate / + (ranking.py:293-326) on integer keys, for two rankings whose rows stand
- * grouped by query: rows off_a[g] .. off_a[g+1] of A and off_b[g] .. off_b[g+1] of B belong to query g, code_a / code_b
- * number the ids in one common table, a pair occurs at most once per side (FFX_BAD_ARG otherwise).  Per query the union
- * of the id sets in ascending code: u_code, the row of A / of B holding the pair (u_a / u_b, -1 where missing); union
- * rows of query g are u_off[g] .. u_off[g+1].  u_code / u_a / u_b must hold off_a[n] + off_b[n] entries. */
-int ffx_host_outer_join(const int64_t* off_a, const int32_t* code_a, const int64_t* off_b, const int32_t* code_b, int64_t n_queries,
-                        int32_t n_threads, int64_t* u_off, int32_t* u_code, int32_t* u_a, int32_t* u_b);
+/* ffx_score with the ordering APPLIED on the device: out_scores[i] / out_carry[i] = the ranking score (interpolated when
+ * sparse is given, else dense) and the carried word of the candidate at position i of the per-query order -- the run as
+ * Ranking.__init__ lays it out (ranking.py:115-117), with whatever the caller numbers its candidates with (the id codes of
+ * a run) permuted along, so the host gathers nothing afterwards.  carry / out_carry may be NULL; out_order (positions in
+ * the caller's list, as ffx_score) may be NULL.  FFX_FLAG_SORT is implied. */
+int ffx_score_ranked(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
+                     const int32_t* pair_ids, const float* sparse, const int32_t* carry, int mode, double alpha, uint32_t flags,
+                     float* out_scores, int32_t* out_carry, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats);
 
 /* ---- page-locked host memory ------------------------------------------------------------
  * Host buffers handed to the calls above may live anywhere; when they are page-locked the

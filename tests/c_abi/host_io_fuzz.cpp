@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/ffx.h"
+#include "../../include/ffx_private.h"
 
 // host_io.cpp reports errors through ffx.hip's ffx_fail; the sanitizer build has no HIP side
 static std::string g_err;

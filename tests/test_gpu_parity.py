@@ -965,6 +965,107 @@ def test_baseline_config_full_size_properties():
     idx.close()
 
 
+def _bench_module():
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _full_size_properties(idx, n_docs, nq, k, seed, scale, d, rows_of, store_label):
+    """The size-independent checks of test_baseline_config_full_size_properties on an index of any store:
+    order = per-query permutation with non-increasing scores, reversal invariance, MAXP == FIRSTP == PASSAGE on
+    one-passage documents, 4096 sampled pairs against the oracle on rows re-derived on the host (``rows_of(ids)``)."""
+    bench = _bench_module()
+    ids, sparse = bench.candidates(n_docs, nq, k, seed)
+    pair_off = np.arange(nq + 1, dtype=np.int64) * k
+    queries = synth.rows(seed + 3, scale, 0, nq, d)
+    plan = native.Plan(idx)
+    plan.set_queries(queries)
+    plan.set_pairs(pair_off, ids, sparse, 2)
+    plan.run(0.1, exact_sum=True, sort=True)
+    ff, interp, order = plan.fetch(interp=True, order=True)
+    assert plan.stats()["n_rows"] == nq * k
+    o2 = order.reshape(nq, k).astype(np.int64)
+    assert np.array_equal(np.sort(o2, axis=1), pair_off[:-1, None] + np.arange(k)[None, :])
+    along = interp[o2]
+    assert (np.diff(along, axis=1) <= 0).all(), store_label
+    ties = np.diff(along, axis=1) == 0
+    assert (np.diff(o2, axis=1)[ties] > 0).all()
+    rev = ids.reshape(nq, k)[:, ::-1].reshape(-1).copy()
+    plan.set_pairs(pair_off, rev, sparse.reshape(nq, k)[:, ::-1].reshape(-1).copy(), 2)
+    plan.run(0.1, exact_sum=True)
+    ff_r, interp_r, _ = plan.fetch(interp=True)
+    assert np.array_equal(bits(ff_r.reshape(nq, k)[:, ::-1]), bits(ff.reshape(nq, k))), store_label
+    assert np.array_equal(bits(interp_r.reshape(nq, k)[:, ::-1]), bits(interp.reshape(nq, k)))
+    for mode in (1, 3):
+        plan.set_pairs(pair_off, ids, None, mode)
+        plan.run(0.0, exact_sum=True)
+        assert np.array_equal(bits(plan.fetch()[0]), bits(ff)), (store_label, mode)
+    sel = np.random.default_rng(1).choice(nq * k, size=4096, replace=False)
+    want = fo.row_scores(queries, rows_of(ids[sel]), (sel // k).astype(np.int32), np.arange(sel.shape[0], dtype=np.int32))
+    assert np.array_equal(bits(ff[sel]), bits(want)), store_label
+    assert np.array_equal(bits(interp[sel]), bits(fo.interpolate(sparse[sel], want, 0.1)))
+    # the one-shot host-to-host call (sliced, pipelined) gives the same bits and the same order
+    ff2, interp2, order2, _ = native.score(idx, queries, pair_off, ids, 2, sparse, 0.1, exact_sum=True, sort=True)
+    assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp)) and np.array_equal(order2, order)
+    plan.close()
+
+
+def test_config2_full_size_at_k_1000():
+    """BASELINE config 2 as written: 8 841 823 x 768 fp32 on one GPU, 6980 queries, k = 1000, Mode.MAXP (6.98 M pairs)."""
+    n, d, seed = 8_841_823, 768, 2024
+    scale = float(1 / np.sqrt(d))
+    idx = native.DeviceIndex(n, d)
+    idx.fill_synthetic(seed, scale, 0, n)
+    idx.set_doc_rows(np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32))
+    idx.set_psg_rows(np.arange(n, dtype=np.int32))
+    _full_size_properties(idx, n, 6980, 1000, seed, scale, d, lambda ids: fo.synth_row_list(seed, scale, ids, d), "fp32 k=1000")
+    idx.close()
+
+
+def test_config4_float16_rows_50m_full_size():
+    """BASELINE config 4, first half: 50 M x 768 float16 rows = 76.8 GB resident on the one GPU (filled on the device), 6980
+    queries x k = 5000.  The reference keeps the dtype it is given (index/memory.py:80-83) and NumPy multiplies float32
+    queries by float16 rows in float32 (index/base.py:292-303): the oracle scores the rows rounded to float16 once."""
+    n, d, seed = 50_000_000, 768, 2024
+    scale = float(1 / np.sqrt(d))
+    if native.device_info(0)["free_bytes"] < 90e9:
+        pytest.skip("needs ~80 GB of free HBM")
+    idx = native.DeviceIndex(n, d, dtype=np.float16)
+    idx.fill_synthetic(seed, scale, 0, n)
+    idx.set_doc_rows(np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32))
+    idx.set_psg_rows(np.arange(n, dtype=np.int32))
+    _full_size_properties(idx, n, 6980, 5000, seed, scale, d,
+                          lambda ids: fo.synth_row_list(seed, scale, ids, d).astype(np.float16).astype(np.float32), "fp16 50M")
+    idx.close()
+
+
+def test_config4_product_quantized_rows_50m_full_size():
+    """BASELINE config 4, second half: 50 M rows of M = 8 product-quantizer codes (Ks = 256, Ds = 96), 6980 queries x
+    k = 5000: the exact ADC path (fused pairs kernel) against decode + np.sum(q * d) (index/base.py:292-303,
+    quantizer/nanopq.py:43-44) on 4096 sampled pairs whose codes are re-derived on the host."""
+    n, d, m, ks, seed = 50_000_000, 768, 8, 256, 2024
+    scale = float(1 / np.sqrt(d))
+    book = synth.rows(seed + 9, scale, 0, m * ks, d // m).reshape(m, ks, d // m)
+    idx = native.DeviceIndex(n, m, dtype=np.uint8)
+    idx.set_codebook(book)
+    idx.fill_synthetic(seed, scale, 0, n)
+    idx.set_doc_rows(np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.int32))
+    idx.set_psg_rows(np.arange(n, dtype=np.int32))
+
+    def decoded(ids):
+        elem = (ids.astype(np.int64)[:, None] * m + np.arange(m)[None, :]).astype(np.uint64)
+        codes = ((synth.mix64(elem.reshape(-1), seed) >> np.uint64(32)) % np.uint64(ks)).astype(np.int64).reshape(-1, m)
+        return np.concatenate([book[j][codes[:, j]] for j in range(m)], axis=1)
+
+    _full_size_properties(idx, n, 6980, 5000, seed, scale, d, decoded, "PQ 50M")
+    idx.close()
+
+
 @pytest.mark.parametrize("d,m,ks", [(768, 8, 256), (1024, 8, 64), (384, 4, 32), (2048, 16, 16), (96, 1, 8), (256, 2, 200)])
 def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
     """Tabulated leaf sums + balanced pairwise combination == np.sum(q * decode(codes)), bit for bit."""

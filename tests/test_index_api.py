@@ -688,10 +688,13 @@ def test_adopting_rows_that_are_already_on_the_device():
     plain.close()
 
 
-def test_a_result_keeps_its_row_link_when_the_index_reuses_its_result_block():
-    """Index.__call__ on a large run leaves the device's order in the index's re-used page-locked block and lends it to
-    the result (for the interpolate that usually follows at once).  A later large call on the same index must not
-    disturb an earlier result: it gets its own copy first.  1.2 M pairs per call (the block is used from 1 M)."""
+def test_a_result_keeps_its_arrays_when_later_calls_reuse_the_result_pool():
+    """Index.__call__ / rerank on a large run return arrays that live in page-locked blocks of the result pool (the device
+    writes the run there in its final order).  A block goes back to the pool only when the LAST view of it dies: a later
+    large call on the same index must not disturb an earlier result, and a dropped result's block is what the next call
+    gets.  1.2 M pairs per call (the device applies the ordering from 256 K)."""
+    from fast_forward_amd import native
+
     rng = np.random.default_rng(5)
     n, d, n_q, k = 60_000, 32, 300, 4000
     rows = rng.standard_normal((n, d)).astype(np.float32)
@@ -708,14 +711,25 @@ def test_a_result_keeps_its_row_link_when_the_index_reuses_its_result_block():
 
     first, second = run(1), run(2)
     dense_first = index(first)
-    borrowed = dense_first._source_rows[1]
-    assert borrowed.base is not None  # a view of the index's block
-    keep = borrowed.copy()
-    dense_second = index(second)       # re-uses the block
-    assert dense_first._source_rows[1].base is None and np.array_equal(dense_first._source_rows[1], keep)  # its own copy now, same content
+    link = dense_first._source_rows[1]
+    keep_link, keep_scores, keep_codes = link.copy(), dense_first._coded["score"].copy(), dense_first._coded["id_codes"].copy()
+    dense_second = index(second)       # more blocks of the pool, not these
+    for _ in range(3):
+        index.rerank(second, 0.3)      # ... and results that die at once: their blocks go round
+    assert np.array_equal(dense_first._source_rows[1], keep_link)
+    assert np.array_equal(dense_first._coded["score"].view(np.uint32), keep_scores.view(np.uint32)) and np.array_equal(dense_first._coded["id_codes"], keep_codes)
     assert first.interpolate(dense_first, 0.2) == index.rerank(first, 0.2)
     assert second.interpolate(dense_second, 0.2) == index.rerank(second, 0.2)
+    # a dropped result hands its block back: the next result of that size is served from the pool
+    idle_before = native._POOL_IDLE[0]
+    gone = index.rerank(second, 0.5)
+    addr = gone._coded["score"].ctypes.data
+    del gone
+    assert native._POOL_IDLE[0] > idle_before - 1  # (nothing was lost on the way)
+    again = index.rerank(second, 0.5)
+    assert again._coded["score"].ctypes.data == addr or again._coded["id_codes"].ctypes.data == addr
     index.close()
+    assert native.drain_result_pool() > 0
 
 
 def test_early_stopping_on_a_large_run_edge_cases():

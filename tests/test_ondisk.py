@@ -1,7 +1,9 @@
 """``OnDiskIndex``: file behaviour on the CPU (reference tests/test_index.py:513-654: load, stored
 quantizer, id length limit, reads across chunks) and streamed scoring on the GPU."""
 
+import os
 import shutil
+from pathlib import Path
 
 import numpy as np
 import pandas as pd
@@ -516,3 +518,57 @@ def test_export_hdf5_round_trip_scores_identically(tmp_path):
     plain = InMemoryIndex(enc)
     plain.add(rows, doc_ids=docs, psg_ids=psgs)
     assert again(first) == plain(first)
+
+
+@pytest.mark.gpu
+def test_streamed_index_of_8_gb_through_windows_equals_the_same_rows_resident():
+    """BASELINE config 5 scaled to what one box holds in /dev/shm: an index FILE of 2.8 M x 768 fp32 rows (8.6 GB) scored
+    through 1 GiB windows -- the device pulls each window's rows out of the page-locked file maps while the window before is
+    scored (reference: index/disk.py:309-336 reads every batch's vectors from the file) -- against the same rows resident in
+    HBM (``to_memory``, disk.py:177-205): the same Ranking, bit for bit, for the fused and the two-call form."""
+    import shutil
+    import tempfile
+
+    from fast_forward_amd.index.ondisk import _available_host_bytes
+
+    free_shm = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") else 0
+    avail = _available_host_bytes()
+    if free_shm < 14e9 or (avail is not None and avail < 40e9):
+        pytest.skip("needs 14 GB of /dev/shm and 40 GB of host memory")
+    n, d, n_q, k = 2_800_000, 768, 400, 5000
+    rng = np.random.default_rng(11)
+    tmp = tempfile.mkdtemp(dir="/dev/shm", prefix="ffx_big_")
+    try:
+        qv = (rng.random((n_q, d), dtype=np.float32) - np.float32(0.5)) * np.float32(0.07)
+        enc = LambdaEncoder(lambda t: qv[int(t)])
+        disk = OnDiskIndex(Path(tmp) / "index.ffx", enc, mode=Mode.MAXP, chunk_size=2**16, max_id_length=12, window_bytes=1 << 30)
+        step = 2**18
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            disk.add((rng.random((hi - lo, d), dtype=np.float32) - np.float32(0.5)) * np.float32(0.07), doc_ids=[f"D{i}" for i in range(lo, hi)])
+        assert (Path(tmp) / "index.ffx").stat().st_size > 8.5e9
+        picks = rng.integers(0, n, size=(n_q, k), dtype=np.int64)
+        for q in range(n_q):  # k distinct documents per query
+            u = np.unique(picks[q])
+            while u.shape[0] < k:
+                u = np.unique(np.concatenate([u, rng.integers(0, n, size=k - u.shape[0])]))
+            picks[q] = rng.permutation(u)
+        names = np.array([f"D{i}" for i in range(n)], dtype=object)
+        frame = pd.DataFrame({"q_id": np.repeat([f"q{i:04d}" for i in range(n_q)], k), "id": names[picks.reshape(-1)],
+                              "score": (rng.random(n_q * k) * 20).astype(np.float32)})
+        first = Ranking(frame, queries={f"q{i:04d}": str(i) for i in range(n_q)})
+        streamed = disk.rerank(first, 0.2)
+        st = disk.last_stats
+        assert st["row_source"].startswith("device pull"), st["row_source"]
+        assert st["windows"] >= 4, st
+        dense_streamed = disk(first)
+        resident = disk.to_memory()
+        assert resident.rerank(first, 0.2) == streamed
+        assert resident(first) == dense_streamed
+        assert first.interpolate(dense_streamed, 0.2) == streamed
+        resident.close()
+        disk._release_windows()
+        disk._unlock_maps()
+        del disk
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
