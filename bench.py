@@ -1043,10 +1043,14 @@ def bench_single(args):
         },
         "roofline": {
             "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']})",
-            **({"note": "PQ rows: 12 algorithmic bytes per row, but a random gather moves a whole 128-B line per row "
-                        "(exact ADC: 34.9 M lines = 4.5 GB in 0.68 ms = 6.6 TB/s, plus 0.19 ms of table build); decode-then-dot is "
-                        "bound by L2->CU codeword traffic.  The fraction of algorithmic bytes is not the figure of merit here"} if args.store == "pq" else {}),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # product-quantized rows: what limits the kernel is the REQUEST rate of a random gather, not bytes -- every 8-byte row
+            # costs one 128-byte read request (rocprofv3 --pmc TCC_EA0_RDREQ_sum: 1.03 per row, none of them 32-byte ones,
+            # the same request the fp32 kernel issues 24 of per 3072-byte row: profiles/r04/pmc_pq_requests.json)
+            **({"bound": "hbm, as 128-byte read requests: a random gather of 8-byte rows moves one line per row (10.7 x the algorithmic bytes)",
+                "achieved": st["n_rows"] * 128 / (kern_avg_ms * 1e-3) / 1e9, "frac": st["n_rows"] * 128 / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "achieved_is": "gathered rows x 128 B (one read request each) / kernel time, table build of the exact ADC included",
+                "algorithmic_achieved": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBS} if args.store == "pq" else {}),
             # HBM bytes per launch from the PMC counters: measured by child rocprofv3 passes of this workload (measure_traffic)
             **pmc,
             **({"traffic_over_algorithmic": pmc["traffic"] / (st["n_rows"] * row_bytes)} if pmc.get("traffic") else {}),

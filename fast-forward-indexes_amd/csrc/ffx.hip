@@ -66,7 +66,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 // A comma-separated list of words, `name` or `name=N`:
 //   no_small_path          ffx_score never takes the single-submission path of small batches
 //   route_host             the sharded scorer routes a batch on the host even for document-range shards
-//   pq_no_fuse, pq_no_adc  product-quantized rows: unfused exact ADC / decode-then-dot instead of exact ADC
+//   pq_no_fuse, pq_no_adc, pq_sort_apart  product-quantized rows: unfused exact ADC / decode-then-dot instead of exact ADC / the ordering as a launch of its own
 //   generic_staged, generic_plain   the round-1 generic exact kernels instead of the any-d / segment kernels
 //   anyd_u=N               loads in flight per wave of the any-d kernel (2, 4, 8)
 //   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
@@ -1638,8 +1638,12 @@ static bool pq_exact_adc_applies(const ffx_plan* pl) {
   return aligned;
 }
 
-// single-row candidates on exact-ADC rows: expand + look-ups + interpolation fused (pq_adc_exact_pairs_kernel)
-static int launch_pq_fused(ffx_plan* pl, float a, float b) {
+static int64_t longest_segment(const int64_t* off, int64_t n);
+
+// single-row candidates on exact-ADC rows: expand + look-ups + interpolation fused (pq_adc_exact_pairs_kernel); with
+// *sorted != NULL and queries of 129 .. 8192 candidates also the per-query ordering (pq_adc_exact_pairs_sort_kernel: a
+// workgroup per query), and *sorted says whether that happened
+static int launch_pq_fused(ffx_plan* pl, float a, float b, uint32_t flags = 0, bool* sorted = nullptr) {
   const ffx_index* ix = pl->idx;
   const int M = ix->dim, Ks = ix->pq_ks, Ds = ix->pq_ds;
   const int64_t P = pl->n_pairs;
@@ -1655,6 +1659,33 @@ static int launch_pq_fused(ffx_plan* pl, float a, float b) {
                                                        : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
   const size_t lds = (size_t)M * Ks * sizeof(float);
   const double qpp = (double)pl->n_queries / (double)P;
+  if (sorted) *sorted = false;
+  if (sorted && (M == 8 || M == 16) && lds <= (32u << 10) && !ffx_debug_variant("pq_sort_apart", nullptr)) {
+    const int64_t longest = longest_segment(pl->host_pair_off.data(), pl->n_queries);
+    if (longest >= 129 && longest <= 8192) {
+      FFX_TRY(pl->order.ensure((size_t)P * sizeof(int32_t)));
+      const unsigned nq = (unsigned)pl->n_queries;
+      const int sort_ff = (flags & FFX_FLAG_SORT_FF) ? 1 : 0;
+#define FFX_ADCS(MM, BS, IPT)                                                                                                                     \
+  ffx::pq_adc_exact_pairs_sort_kernel<MM, BS, IPT><<<nq, BS, lds, st>>>(static_cast<const uint8_t*>(ix->vectors), Ks, pl->lut.as<float>(),        \
+      pl->pair_ids.as<int32_t>(), pl->pair_off.as<int64_t>(), row_of, pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b, sort_ff,          \
+      pl->ff.as<float>(), pl->interp.as<float>(), pl->order_base, pl->order.as<int32_t>(), (long)ix->capacity)
+#define FFX_ADCS_M(MM)                               \
+  do {                                               \
+    if (longest <= 1024) FFX_ADCS(MM, 256, 4);       \
+    else if (longest <= 4096) FFX_ADCS(MM, 512, 8);  \
+    else if (longest <= 5120) FFX_ADCS(MM, 512, 10); \
+    else FFX_ADCS(MM, 1024, 8);                      \
+  } while (0)
+      if (M == 8) FFX_ADCS_M(8); else FFX_ADCS_M(16);
+#undef FFX_ADCS_M
+#undef FFX_ADCS
+      FFX_HIP(hipGetLastError());
+      pl->variant = 2500 + M;
+      *sorted = true;
+      return FFX_OK;
+    }
+  }
 #define FFX_ADCP(MM)                                                                                                               \
   ffx::pq_adc_exact_pairs_kernel<MM><<<blocks_for(P, 256), 256, lds, st>>>(static_cast<const uint8_t*>(ix->vectors), Ks, pl->lut.as<float>(), \
       pl->pair_ids.as<int32_t>(), pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of,                                    \
@@ -1842,6 +1873,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   FFX_HIP(hipEventRecord(pl->ev[0], st));
   // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
   const bool pq_fused = single && P > 0 && !ffx_debug_variant("pq_no_fuse", nullptr) && pq_exact_adc_applies(pl);
+  bool pq_sorted = false;  // the fused kernel ordered the queries as well
   if (pq_fused) {
     hipEvent_t* recent_pq = pl->recent[pl->n_runs % ffx_plan::kRecent];
     if (!recent_pq[0]) {
@@ -1850,7 +1882,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
     }
     FFX_HIP(hipEventRecord(pl->ev[1], st));
     FFX_HIP(hipEventRecord(recent_pq[0], st));
-    FFX_TRY(launch_pq_fused(pl, (float)alpha, (float)(1.0 - alpha)));
+    FFX_TRY(launch_pq_fused(pl, (float)alpha, (float)(1.0 - alpha), flags, do_sort ? &pq_sorted : nullptr));
     FFX_HIP(hipEventRecord(pl->ev[2], st));
     FFX_HIP(hipEventRecord(recent_pq[1], st));
   }
@@ -1900,7 +1932,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   pl->last_interp = pl->have_sparse;
   FFX_HIP(hipEventRecord(pl->ev[3], st));
   // 4. per-query order: score descending, ties by position (stable radix sort)
-  if (do_sort && P > 0) {
+  if (do_sort && P > 0 && !pq_sorted) {
     const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
     FFX_TRY(launch_segmented_sort(keys, P, pl->pair_off.as<int64_t>(), pl->n_queries, pl->order, pl->iota,
                                   pl->sorted_keys, pl->sort_tmp, st, longest_segment(pl->host_pair_off.data(), pl->n_queries),

@@ -986,6 +986,100 @@ pq_adc_exact_pairs_kernel(const uint8_t* __restrict__ codes, int Ks, const float
   if (sparse != nullptr) interp[p] = __fadd_rn(__fmul_rn(a, sparse[p]), __fmul_rn(b, leaf[0]));
 }
 
+// ... and the per-query ordering folded in as well (ranking.py:115-117): ONE workgroup per query stages the query's table,
+// scores its candidates (each thread IPT of them: the ordinals first, then the code words, then the look-ups, so that the
+// dependent loads of all of them are in flight together), keeps the order-preserving images of the keys in LDS and orders
+// them there with the block-level radix sort block_sort_desc_kernel uses -- candidate -> row -> codes -> look-ups -> dense
+// score -> interpolation -> order in one launch, nothing written that is read back.  Stable, descending, ties by position,
+// -0.0 counted as +0.0: bit for bit the order of the separate sort (test_pq_* and test_per_query_order).
+template <int M, unsigned BS, unsigned IPT>
+__global__ void __launch_bounds__(BS)
+pq_adc_exact_pairs_sort_kernel(const uint8_t* __restrict__ codes, int Ks, const float* __restrict__ lut, const int32_t* __restrict__ pair_ids,
+                               const int64_t* __restrict__ pair_off, const int32_t* __restrict__ row_of, const float* __restrict__ sparse, float a, float b,
+                               int sort_ff, float* __restrict__ ff, float* __restrict__ interp, int32_t base, int32_t* __restrict__ order, long n_index_rows) {
+  using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, int32_t>;
+  __shared__ typename Sort::storage_type storage;
+  __shared__ uint32_t stage[BS * IPT];
+  extern __shared__ float table[];
+  const int q = blockIdx.x;
+  const int64_t lo = pair_off[q];
+  const int n = (int)(pair_off[q + 1] - lo);
+  if (n == 0) return;  // block-uniform
+  {
+    const float* __restrict__ src = lut + (size_t)q * M * Ks;
+    for (int i = threadIdx.x; i < M * Ks; i += BS) table[i] = src[i];
+  }
+  __syncthreads();
+  int32_t row[IPT];
+#pragma unroll
+  for (unsigned j = 0; j < IPT; ++j) {
+    const int i = (int)(threadIdx.x + j * BS);
+    int32_t r = 0;
+    if (i < n) {
+      const int32_t o = pair_ids[lo + i];
+      r = row_of ? row_of[o] : o;
+      r = (uint32_t)r < (unsigned long)n_index_rows ? r : 0;  // see expand_single_kernel
+    }
+    row[j] = r;
+  }
+  static_assert(M % 8 == 0, "the code words are fetched eight at a time");
+  uint2 word[IPT][M / 8];
+#pragma unroll
+  for (unsigned j = 0; j < IPT; ++j) {
+    const uint2* __restrict__ c = reinterpret_cast<const uint2*>(codes + (size_t)row[j] * M);
+#pragma unroll
+    for (int w = 0; w < M / 8; ++w) word[j][w] = c[w];
+  }
+#pragma unroll
+  for (unsigned j = 0; j < IPT; ++j) {
+    const int i = (int)(threadIdx.x + j * BS);
+    uint32_t image = 0u;
+    if (i < n) {
+      float leaf[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const uint32_t half = (m & 4) ? word[j][m / 8].y : word[j][m / 8].x;
+        int code = (int)((half >> (8 * (m & 3))) & 0xFFu);
+        code = code < Ks ? code : Ks - 1;
+        leaf[m] = table[m * Ks + code];
+      }
+#pragma unroll
+      for (int s = 1; s < M; s *= 2) {
+#pragma unroll
+        for (int t = 0; t + s < M; t += 2 * s) leaf[t] = __fadd_rn(leaf[t], leaf[t + s]);
+      }
+      float key = leaf[0];
+      ff[lo + i] = key;
+      if (sparse != nullptr) {
+        const float mixed = __fadd_rn(__fmul_rn(a, sparse[lo + i]), __fmul_rn(b, key));
+        interp[lo + i] = mixed;
+        if (!sort_ff) key = mixed;
+      }
+      uint32_t bits = __float_as_uint(key);
+      if (bits == 0x80000000u) bits = 0u;
+      image = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    }
+    stage[i] = image;
+  }
+  __syncthreads();
+  uint32_t k[IPT];
+  int32_t v[IPT];
+#pragma unroll
+  for (unsigned j = 0; j < IPT; ++j) {
+    const int at = (int)(threadIdx.x * IPT + j);
+    k[j] = stage[at];
+    v[j] = at;
+  }
+  __syncthreads();
+  Sort().sort_desc(k, v, storage);
+  __syncthreads();
+#pragma unroll
+  for (unsigned j = 0; j < IPT; ++j) stage[threadIdx.x * IPT + j] = (uint32_t)v[j];
+  __syncthreads();
+  const int32_t first = base + (int32_t)lo;
+  for (int i = threadIdx.x; i < n; i += BS) order[lo + i] = first + (int32_t)stage[i];
+}
+
 // One thread per row.  Rows of a query are contiguous, so almost every block works for a single
 // query: its M*Ks-float table is staged in LDS once and the M look-ups per row hit LDS.
 __global__ void __launch_bounds__(256)

@@ -1066,6 +1066,59 @@ def test_config4_product_quantized_rows_50m_full_size():
     idx.close()
 
 
+@pytest.mark.parametrize("m,ks,longest", [(8, 256, 700), (8, 256, 3000), (8, 256, 5000), (8, 64, 8000), (16, 256, 4500), (8, 256, 100), (8, 256, 9000)])
+def test_pq_fused_ordering_equals_the_separate_sort(monkeypatch, m, ks, longest):
+    """Exact-ADC rows, one row per candidate: the per-query ordering is folded into the scoring kernel (a workgroup per
+    query: candidate -> row -> codes -> look-ups -> dense -> interpolated -> order) for queries of 129 .. 8192 candidates.
+    Scores, interpolated scores and the order equal the separate launches (FFX_DEBUG_VARIANT=pq_sort_apart) bit for bit, on
+    ragged batches (an empty query, one candidate, exact ties, -0.0), ordered by the interpolated or by the dense score."""
+    d = m * 96
+    rng = np.random.default_rng(m * 1000 + longest)
+    n, nq = 40_000, 9
+    codewords = synth.rows(70 + m, 1.0, 0, m * ks, d // m).reshape(m, ks, d // m)
+    codes = rng.integers(0, ks, size=(n, m)).astype(np.uint8)
+    codes[:50] = codes[0]  # rows with identical codes: exact ties
+    queries = synth.rows(71 + m, 1.0, 0, nq, d)
+    queries[3] = 0.0       # every score of this query is +-0.0
+    idx = native.DeviceIndex(n, m, dtype=np.uint8)
+    idx.set_codebook(codewords)
+    idx.upload(codes, 0)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    lens = [longest, 0, 1, longest // 2, 130, longest - 1, 77, longest, 300]
+    pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pair_ids = np.concatenate([rng.permutation(n)[:k] for k in lens]).astype(np.int32)
+    pair_ids[pair_off[0]:pair_off[0] + 40] = np.arange(40)  # the tied rows, in a known first-stage order
+    sparse = (rng.random(pair_ids.shape[0]) * 4).astype(np.float32)
+    sparse[pair_off[3]:pair_off[4]] = 0.0  # ... and so is every interpolated score of the all-zero query
+    plan = native.Plan(idx)
+    plan.set_queries(queries)
+    got = {}
+    for variant in ("", "pq_sort_apart"):
+        if variant:
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", variant)
+        else:
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+        for sp in (sparse, None):
+            for sort_ff in (False, True):
+                plan.set_pairs(pair_off, pair_ids, sp, 1)
+                plan.run(0.3, exact_sum=True, sort=True, sort_ff=sort_ff)
+                got[(variant, sp is None, sort_ff)] = plan.fetch(ff=True, interp=sp is not None, order=True) + (plan.stats()["kernel_variant"],)
+    monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+    folded = 129 <= max(lens) <= 8192
+    for key, (ff, interp, order, variant_no) in got.items():
+        if key[0] == "":
+            assert variant_no == (2500 + m if folded else 2400 + m), (key, variant_no)
+            ff2, interp2, order2, v2 = got[("pq_sort_apart",) + key[1:]]
+            assert v2 == 2400 + m
+            assert np.array_equal(bits(ff), bits(ff2)) and np.array_equal(order, order2), key
+            assert interp is None or np.array_equal(bits(interp), bits(interp2))
+            keys = ff if (key[1] or key[2]) else interp
+            assert np.array_equal(order.astype(np.int64), fo.order(keys, pair_off)), key
+    plan.close()
+    idx.close()
+
+
 @pytest.mark.parametrize("d,m,ks", [(768, 8, 256), (1024, 8, 64), (384, 4, 32), (2048, 16, 16), (96, 1, 8), (256, 2, 200)])
 def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
     """Tabulated leaf sums + balanced pairwise combination == np.sum(q * decode(codes)), bit for bit."""
