@@ -571,9 +571,34 @@ iota_kernel(int32_t* __restrict__ dst, int64_t n, int32_t base) {
 // order-preserving unsigned images of the scores (-0.0 counted as +0.0), values the positions, so
 // "descending, exact ties by position" is the plain stable descending sort -- and stored once.
 // Padding items carry image 0 behind every real item (stability), so they never reach the output.
+// Where a candidate's sort key comes from: an array of keys, or -- the launch before the ordering folded into it -- made here:
+// the dense score of candidate p (dense[p], or dense[slot[p]] at the owner of a sharded query, whose scores arrive grouped by
+// the rank that sent them), interpolated with its first-stage score (ranking.py:319, two multiplications and one addition,
+// each rounded), both stored on the way.
+struct SortKeys {
+  const float* keys = nullptr;    // plain form
+  const float* dense = nullptr;   // made-here form ...
+  const int32_t* slot = nullptr;  // ... read through the arrival slots
+  const float* sparse = nullptr;  // NULL: the key is the dense score
+  float a = 0.f, b = 0.f;
+  int key_is_dense = 0;           // order by the dense score although first-stage scores are given (FFX_FLAG_SORT_FF)
+  float* ff_out = nullptr;        // dense scores in first-stage order (the slot form)
+  float* interp_out = nullptr;
+};
+
+__device__ inline float sort_key_of(const SortKeys& sk, int64_t p) {
+  if (sk.keys) return sk.keys[p];
+  const float d = sk.dense[sk.slot ? sk.slot[p] : p];
+  if (sk.ff_out) sk.ff_out[p] = d;
+  if (!sk.sparse) return d;
+  const float mixed = __fadd_rn(__fmul_rn(sk.a, sk.sparse[p]), __fmul_rn(sk.b, d));
+  sk.interp_out[p] = mixed;
+  return sk.key_is_dense ? d : mixed;
+}
+
 template <unsigned BS, unsigned IPT>
 __global__ void __launch_bounds__(BS)
-block_sort_desc_kernel(const float* __restrict__ keys, const int64_t* __restrict__ pair_off, int32_t base,
+block_sort_desc_kernel(SortKeys sk, const int64_t* __restrict__ pair_off, int32_t base,
                        int32_t* __restrict__ order) {
   using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, int32_t>;
   __shared__ typename Sort::storage_type storage;
@@ -585,7 +610,7 @@ block_sort_desc_kernel(const float* __restrict__ keys, const int64_t* __restrict
   for (int i = threadIdx.x; i < (int)(BS * IPT); i += BS) {
     uint32_t image = 0u;
     if (i < n) {
-      uint32_t b = __float_as_uint(keys[lo + i]);
+      uint32_t b = __float_as_uint(sort_key_of(sk, lo + i));
       if (b == 0x80000000u) b = 0u;
       image = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     }

@@ -753,8 +753,26 @@ static int rehearsal_exchange(ffx_comm* c, int lane, const Piece* pc, hipStream_
   if (k.count > 0) {
     long long gbs = 50;
     if (ffx_debug_variant("rehearsal_paced", &gbs)) {
-      k.ns_per_kib = 1024.0f / (float)std::max<long long>(gbs, 1);  // 1 KiB at g GB/s = 1024 / g ns
-      k.flag = reinterpret_cast<const uint32_t*>(c->reh_src);
+      // a large piece travels over several channels of its link: sub-pieces of <= 4 MiB, a persistent workgroup each, the
+      // link's rate shared between them
+      RehearsalPieces cut;
+      cut.count = 0;
+      constexpr long kSub = 1 << 20;  // words
+      int most = 1;
+      for (int i = 0; i < k.count; ++i) most = std::max<int>(most, (int)((k.n[i] + kSub - 1) / kSub));
+      most = std::min(most, std::max(1, (2 * kMaxWorld) / k.count));
+      for (int i = 0; i < k.count; ++i) {
+        const int parts = (int)std::min<long>(most, std::max<long>(1, (k.n[i] + kSub - 1) / kSub));
+        for (int j = 0; j < parts; ++j) {
+          const long lo = k.n[i] * j / parts, hi = k.n[i] * (j + 1) / parts;
+          cut.src[cut.count] = k.src[i] + lo;
+          cut.dst[cut.count] = k.dst[i] ? k.dst[i] + lo : nullptr;
+          cut.n[cut.count++] = hi - lo;
+        }
+      }
+      cut.ns_per_kib = 1024.0f / (float)std::max<long long>(gbs, 1) * (float)most;  // 1 KiB at g GB/s = 1024 / g ns; `most` channels share the link
+      cut.flag = reinterpret_cast<const uint32_t*>(c->reh_src);
+      k = cut;
       rehearsal_exchange_paced_kernel<<<k.count, 256, 0, st>>>(k);
     } else {
       k.ns_per_kib = 0.0f;
@@ -2073,7 +2091,7 @@ static int sharded_merge_pending(ffx_sharded* s) {
   hipStream_t ms = s->compute;
   // a small merge hides inside the next gather_dot; a large one (tens of millions of candidates: one or two ranks) takes
   // slots from it for its whole length and is better paid for once, in line (measured: DESIGN.md section 7)
-  const bool small = sl.own[3] <= (int64_t)(10 << 20);
+  const bool small = sl.own[3] <= (int64_t)(6 << 20);  // (4.4 M owned candidates: hidden, 2.26 -> 2.12 ms; 8.7 M: the fresh step loses 5 %; 34.9 M: 7 %)
   if (ffx_debug_variant("merge_on_results", nullptr) || (small && !ffx_debug_variant("merge_on_compute", nullptr))) {
     C_TRY(sharded_io_streams(s));
     ms = s->out;

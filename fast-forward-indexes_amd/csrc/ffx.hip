@@ -37,6 +37,32 @@
 
 thread_local std::string g_last_error;
 
+// FFX_ABORT_BACKTRACE=1 (a diagnostic, off by default): when something below this library -- the HIP runtime, the driver's
+// user-mode part -- ends the process with abort(), the native call stack of the aborting thread goes to stderr first (Python's
+// faulthandler shows the Python frames only).  For the rare SIGABRT inside hipMemcpy of DESIGN.md section 10 / tools/abort_hunt.sh.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void ffx_abort_backtrace(int) {
+  static const char head[] = "\nlibffx: SIGABRT -- native call stack of the aborting thread:\n";
+  (void)!write(2, head, sizeof head - 1);
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(SIGABRT, SIG_DFL);
+  raise(SIGABRT);
+}
+__attribute__((constructor)) void ffx_install_abort_backtrace() {
+  const char* e = getenv("FFX_ABORT_BACKTRACE");
+  if (e && *e && *e != '0') {
+    void* warm[2];
+    (void)backtrace(warm, 2);  // (loads libgcc now: not inside the handler)
+    signal(SIGABRT, ffx_abort_backtrace);
+  }
+}
+}  // namespace
+
 namespace {
 
 int fail(int code, const char* fmt, ...) {
@@ -71,6 +97,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 //   anyd_u=N               loads in flight per wave of the any-d kernel (2, 4, 8)
 //   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
 //   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N   where the per-query sort switches form
+//   sort_interp_apart      the interpolation (and the owner-side scatter) as launches of their own instead of inside the block sort
 //   score_slice_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N, count_always
 //                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py)
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
@@ -554,8 +581,11 @@ int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64
   size_t want = (size_t)64 << 20;
   if (long long v = 0; ffx_debug_variant("stage_bytes", &v)) want = std::max<size_t>(rb, (size_t)v);
   want = std::max(want, rb);
+  if (idx->pending_rows > 0) FFX_TRY(ffx_index_upload_wait(idx));  // (an earlier asynchronous upload nobody waited for: its copies may still read the staging blocks)
   if (idx->stage_bytes < want) {
+    if (idx->copy_stream) FFX_HIP(hipStreamSynchronize(idx->copy_stream));  // nothing may be in flight out of a block that is released
     for (int i = 0; i < 2; ++i) {
+      idx->stage_busy[i] = false;
       if (idx->stage[i]) (void)hipHostFree(idx->stage[i]);
       idx->stage[i] = nullptr;
     }
@@ -574,7 +604,6 @@ int ffx_index_upload_rows_async(ffx_index* idx, const void* const* chunks, int64
     if (!idx->stage_ev[i]) FFX_HIP(hipEventCreateWithFlags(&idx->stage_ev[i], hipEventDisableTiming));
   const int64_t per = (int64_t)(idx->stage_bytes / rb);
   const int T = std::max(1, std::min<int>(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency() / 2, 64));
-  if (idx->pending_rows > 0) FFX_TRY(ffx_index_upload_wait(idx));  // (an earlier asynchronous upload nobody waited for)
   // Helper threads live for the whole call (starting a set of threads per 64 MiB block cost about as much as copying the
   // block): block k is gathered by all of them, slice by slice, once the main thread has seen the copy out of its
   // staging block finish (go >= k); the main thread takes slice 0, queues the block's copy when every slice is in
@@ -1800,9 +1829,19 @@ static int64_t longest_segment(const int64_t* off, int64_t n) {
 // cost does not depend on the query lengths (0.085 ms per million pairs; the segmented sort needs
 // 0.10 / 0.15 / 0.28 ms per million at 15K / 30K / 60K candidates and 112 ms for one query of 5 M:
 // tools/shapes.py).
+// which form the ordering of a batch takes: one workgroup per query, in LDS (the form that can make its keys itself)?
+static bool sort_in_blocks(int64_t max_len, int64_t n_queries) {
+  int64_t device_wide_from = 16 << 10, block_from = 129, block_to = 8192;
+  if (long long v = 0; ffx_debug_variant("sort_device_wide_from", &v)) device_wide_from = (int64_t)v;
+  if (long long v = 0; ffx_debug_variant("sort_block_from", &v)) block_from = (int64_t)v;
+  if (long long v = 0; ffx_debug_variant("sort_block_to", &v)) block_to = (int64_t)v;
+  return max_len <= device_wide_from && max_len >= block_from && max_len <= std::min<int64_t>(block_to, 8192) && n_queries > 0;
+}
+
+// `made_here` (only where sort_in_blocks says so): the keys are made by the sort kernel itself (ffx::SortKeys), `keys` is unused
 static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* offs_dev, int64_t n_queries, DevBuf& order,
                                  DevBuf& iota, DevBuf& sorted_keys, DevBuf& sort_tmp, hipStream_t st, int64_t max_len,
-                                 int32_t base = 0) {
+                                 int32_t base = 0, const ffx::SortKeys* made_here = nullptr) {
   const size_t pb = (size_t)P;
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
@@ -1834,13 +1873,15 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
   if (long long v = 0; ffx_debug_variant("sort_block_to", &v)) block_to = (int64_t)v;
   if (max_len >= block_from && max_len <= std::min<int64_t>(block_to, 8192) && n_queries > 0) {
     const unsigned nq = (unsigned)n_queries;
-    if (max_len <= 256) ffx::block_sort_desc_kernel<64, 4><<<nq, 64, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
-    else if (max_len <= 512) ffx::block_sort_desc_kernel<128, 4><<<nq, 128, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
-    else if (max_len <= 1024) ffx::block_sort_desc_kernel<256, 4><<<nq, 256, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
-    else if (max_len <= 2048) ffx::block_sort_desc_kernel<256, 8><<<nq, 256, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
-    else if (max_len <= 4096) ffx::block_sort_desc_kernel<512, 8><<<nq, 512, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
-    else if (max_len <= 5120) ffx::block_sort_desc_kernel<512, 10><<<nq, 512, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
-    else ffx::block_sort_desc_kernel<1024, 8><<<nq, 1024, 0, st>>>(keys, offs_dev, base, order.as<int32_t>());
+    ffx::SortKeys sk;
+    if (made_here) sk = *made_here; else sk.keys = keys;
+    if (max_len <= 256) ffx::block_sort_desc_kernel<64, 4><<<nq, 64, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 512) ffx::block_sort_desc_kernel<128, 4><<<nq, 128, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 1024) ffx::block_sort_desc_kernel<256, 4><<<nq, 256, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 2048) ffx::block_sort_desc_kernel<256, 8><<<nq, 256, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 4096) ffx::block_sort_desc_kernel<512, 8><<<nq, 512, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
+    else if (max_len <= 5120) ffx::block_sort_desc_kernel<512, 10><<<nq, 512, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
+    else ffx::block_sort_desc_kernel<1024, 8><<<nq, 1024, 0, st>>>(sk, offs_dev, base, order.as<int32_t>());
     FFX_HIP(hipGetLastError());
     return FFX_OK;
   }
@@ -1915,15 +1956,20 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (R > 0 && !pq_fused) FFX_TRY(launch_gather_dot(pl, exact, rs));
   if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[2], st));
   if (!pq_fused) FFX_HIP(hipEventRecord(recent[1], st));
-  // 3. segment aggregation + interpolation
+  // 3. segment aggregation + interpolation.  One row per candidate, first-stage scores, queries that are ordered a workgroup
+  // each: the interpolation is made by the sort kernel while it loads its keys (one launch and its gap less per run; what
+  // ffx_score pays fourteen times for a batch cut into fourteen slices)
   const float a = (float)alpha;
   const float b = (float)(1.0 - alpha);
+  const int64_t longest_query = (do_sort && P > 0) ? longest_segment(pl->host_pair_off.data(), pl->n_queries) : 0;
+  const bool interp_in_sort = single && pl->have_sparse && do_sort && P > 0 && !pq_fused && sort_in_blocks(longest_query, pl->n_queries) &&
+                              !ffx_debug_variant("sort_interp_apart", nullptr);
   if (P > 0 && !pq_fused) {
     if (!single) {
       ffx::reduce_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
           rs, pl->seg_off.as<int32_t>(), P, pl->mode, pl->have_sparse ? pl->sparse.as<float>() : nullptr, a, b,
           pl->ff.as<float>(), pl->interp.as<float>());
-    } else if (pl->have_sparse) {
+    } else if (pl->have_sparse && !interp_in_sort) {
       ffx::interp_kernel<<<blocks_for((P + 3) / 4, 256), 256, 0, st>>>(pl->ff.as<float>(), pl->sparse.as<float>(), P, a, b,
                                                             pl->interp.as<float>());
     }
@@ -1934,9 +1980,17 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   // 4. per-query order: score descending, ties by position (stable radix sort)
   if (do_sort && P > 0 && !pq_sorted) {
     const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
+    ffx::SortKeys made;
+    if (interp_in_sort) {
+      made.dense = pl->ff.as<float>();
+      made.sparse = pl->sparse.as<float>();
+      made.a = a;
+      made.b = b;
+      made.key_is_dense = (flags & FFX_FLAG_SORT_FF) ? 1 : 0;
+      made.interp_out = pl->interp.as<float>();
+    }
     FFX_TRY(launch_segmented_sort(keys, P, pl->pair_off.as<int64_t>(), pl->n_queries, pl->order, pl->iota,
-                                  pl->sorted_keys, pl->sort_tmp, st, longest_segment(pl->host_pair_off.data(), pl->n_queries),
-                                  pl->order_base));
+                                  pl->sorted_keys, pl->sort_tmp, st, longest_query, pl->order_base, interp_in_sort ? &made : nullptr));
   }
   if (pl->want_ranked && do_sort && P > 0) {
     const float* keys = (pl->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? pl->interp.as<float>() : pl->ff.as<float>();
@@ -2348,14 +2402,30 @@ int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t fl
   const int64_t P = m->n_pairs;
   const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
   if (P > 0) {
-    ffx::merge_kernel<<<blocks_for(P, 256), 256, 0, st>>>(recv_dev, m->slot.as<int32_t>(),
-                                                         m->have_sparse ? m->sparse.as<float>() : nullptr, P, (float)alpha,
-                                                         (float)(1.0 - alpha), m->ff.as<float>(), m->interp.as<float>());
-    FFX_HIP(hipGetLastError());
+    // queries that are ordered a workgroup each: the scatter out of the receive buffer and the interpolation are made by the
+    // sort kernel while it loads its keys -- the owner-side half of a step is ONE launch
+    const bool in_sort = do_sort && sort_in_blocks(m->max_len, m->n_queries) && !ffx_debug_variant("sort_interp_apart", nullptr);
+    if (!in_sort) {
+      ffx::merge_kernel<<<blocks_for(P, 256), 256, 0, st>>>(recv_dev, m->slot.as<int32_t>(),
+                                                           m->have_sparse ? m->sparse.as<float>() : nullptr, P, (float)alpha,
+                                                           (float)(1.0 - alpha), m->ff.as<float>(), m->interp.as<float>());
+      FFX_HIP(hipGetLastError());
+    }
     if (do_sort) {
       const float* keys = (m->have_sparse && !(flags & FFX_FLAG_SORT_FF)) ? m->interp.as<float>() : m->ff.as<float>();
+      ffx::SortKeys made;
+      if (in_sort) {
+        made.dense = recv_dev;
+        made.slot = m->slot.as<int32_t>();
+        made.sparse = m->have_sparse ? m->sparse.as<float>() : nullptr;
+        made.a = (float)alpha;
+        made.b = (float)(1.0 - alpha);
+        made.key_is_dense = (flags & FFX_FLAG_SORT_FF) ? 1 : 0;
+        made.ff_out = m->ff.as<float>();
+        made.interp_out = m->interp.as<float>();
+      }
       FFX_TRY(launch_segmented_sort(keys, P, m->pair_off.as<int64_t>(), m->n_queries, m->order, m->iota, m->sorted_keys,
-                                    m->sort_tmp, st, m->max_len, m->order_base));
+                                    m->sort_tmp, st, m->max_len, m->order_base, in_sort ? &made : nullptr));
     }
   }
   m->ran = true;

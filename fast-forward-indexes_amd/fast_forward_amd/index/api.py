@@ -494,13 +494,19 @@ class Index(abc.ABC):
         from fast_forward_amd import native
 
         t = [perf_counter()]
+        n_rows = len(ranking._q_no)
+        ranked = hasattr(self, "_score_ranked") and n_rows >= self._RANKED_FROM
+        # the blocks the result will live in are page-locked (once) while the queries are encoded and the ids looked up
+        warm = native.reserve_pooled([(n_rows, np.float32), (n_rows, np.int32)]) if ranked else None
         run = _Run(self, ranking)
         t.append(perf_counter())
         ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
+        if warm is not None:
+            warm.join()
         t.append(perf_counter())
         sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
         off = run.pair_off
-        if hasattr(self, "_score_ranked") and len(ordinals) >= self._RANKED_FROM:
+        if ranked:
             # the device applies the ordering: interpolated scores and the ranking's id codes come back in final order, in
             # page-locked blocks of the result pool that the result keeps -- no gather, no copy, no fresh pages on the host
             carry = run.grouped(run.codes)

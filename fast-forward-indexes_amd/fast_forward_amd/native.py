@@ -689,6 +689,31 @@ def pooled_empty(n: int, dtype) -> np.ndarray:
     return np.frombuffer(owner, dtype=dtype, count=n)
 
 
+def reserve_pooled(requests) -> "object":
+    """Make sure the pool can serve ``requests`` (``[(n, dtype), ...]``) without page-locking anything, on a helper thread:
+    page-locking 2 x 140 MB takes ~0.1 s of driver time that a first call can spend looking its ids up instead.  Returns the
+    thread (``join`` it before the blocks are needed); blocks that exist already are left alone."""
+    import threading
+
+    lib()
+    need: dict = {}
+    for n, dtype in requests:
+        cap = _pool_class(max(1, int(n) * np.dtype(dtype).itemsize))
+        need[cap] = need.get(cap, 0) + 1
+    todo = [cap for cap, k in need.items() for _ in range(max(0, k - len(_POOL.get(cap, ()))))]
+
+    def work():
+        for cap in todo:
+            p = C.c_void_p()
+            if _lib.ffx_host_alloc(cap, C.byref(p)) == OK:
+                _POOL.setdefault(cap, []).append(p.value)
+                _POOL_IDLE[0] += cap
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    return t
+
+
 def drain_result_pool() -> int:
     """Release every idle block of the result pool; returns the bytes freed."""
     freed = 0

@@ -407,14 +407,23 @@ class _ShardedIndex:
         return self.local.encode_queries(queries)
 
     def _all_ids(self, mine: set) -> set:
-        """The union of every rank's id strings (collective; the ids travel once, as one joined buffer per rank)."""
-        blob = "\n".join(sorted(mine)).encode()
-        sizes = self.comm.allgather_array(np.array([len(blob), len(mine)], dtype=np.int64))
-        room = max(1, int(sizes[:, 0].max()))
+        """The union of every rank's id strings (collective; the ids travel once per rank: one buffer of the UTF-8 bytes laid
+        back to back plus their lengths -- an id may hold any character, a newline included)."""
+        ordered = sorted(mine)
+        parts = [x.encode() for x in ordered]
+        blob = b"".join(parts)
+        lengths = np.array([len(p) for p in parts], dtype=np.int64)
+        sizes = self.comm.allgather_array(np.array([len(blob), len(parts)], dtype=np.int64))
+        room_b, room_n = max(1, int(sizes[:, 0].max())), max(1, int(sizes[:, 1].max()))
+        pad = np.zeros(room_n, dtype=np.int64)
+        pad[:len(parts)] = lengths
+        all_len = self.comm.allgather_array(pad)
         out: set = set()
-        for r, part in enumerate(self.comm.allgather_bytes(blob.ljust(room, b"\0"))):
-            if sizes[r, 1]:
-                out.update(part[:int(sizes[r, 0])].decode().split("\n"))
+        for r, part in enumerate(self.comm.allgather_bytes(blob.ljust(room_b, b"\0"))):
+            at = 0
+            for n in all_len[r, :int(sizes[r, 1])].tolist():
+                out.add(part[at:at + n].decode())
+                at += n
         return out
 
     @property
@@ -486,6 +495,9 @@ class _ShardedIndex:
         mode = self.local.mode.value
         streamed = self._local_scores(run.query_vectors, pair_off, holder, local_ids, mode)
         if streamed is None:
+            # (hash-placed shards: every rank knows the ordinals of ITS OWN rows only, so every rank is handed the whole
+            # candidate list and picks what it holds -- ffx_sharded_set_pairs_held.  The owner-routed form, in which a rank
+            # uploads only the queries it owns, needs ordinals the OWNER can name: document-range shards, ShardedScorer.score_owned)
             scorer = self._sharded()
             scorer.set_queries(self._scorer_queries(run.query_vectors))
             scorer.set_pairs(pair_off, local_ids, sparse if alpha is not None else None, mode, holder=holder)
@@ -657,10 +669,17 @@ class ShardedInMemoryIndex(_ShardedIndex):
         if self._scorer is not None:
             return self._scorer
         store = self.local._store if len(self.local) else None
-        mine = np.array([len(self.local), 0 if store is None else store.dim, -1 if store is None else native._DTYPE_CODE[np.dtype(store.dtype)]], dtype=np.int64)
+        has_book = self.local._quantizer is not None and self.local._quantizer.device_codebook() is not None
+        mine = np.array([len(self.local), 0 if store is None else store.dim, -1 if store is None else native._DTYPE_CODE[np.dtype(store.dtype)],
+                         1 if has_book else 0], dtype=np.int64)
         everyone = self.comm.allgather_array(mine)
         if int(everyone[:, 0].max()) == 0:
             raise RuntimeError("the sharded index is empty on every rank")  # every rank raises: nobody is left waiting
+        # a rank without rows takes part with a placeholder store of the others' kind; for product-quantized rows it needs the
+        # codebook for that.  Whether every such rank has one is known to all (the gathered vector): all raise, or none
+        quantized = bool((everyone[:, 2] == native._DTYPE_CODE[np.dtype(np.uint8)]).any())
+        if quantized and bool(((everyone[:, 0] == 0) & (everyone[:, 3] == 0)).any()):
+            raise RuntimeError("a rank without rows needs the index's quantizer to take part in a quantized sharded index")
         if store is None:
             donor = everyone[int(np.argmax(everyone[:, 0] > 0))]
             dtype = next(dt for dt, code in native._DTYPE_CODE.items() if code == int(donor[2]))

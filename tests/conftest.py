@@ -12,6 +12,9 @@ for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests", RO
         sys.path.insert(0, str(p))
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# if anything below libffx ends the process with abort() (one full-suite run in ~12 of round 4 did, inside hipMemcpy), the log
+# should show the NATIVE call stack of the aborting thread, not only Python's (libffx installs the handler when it is loaded)
+os.environ.setdefault("FFX_ABORT_BACKTRACE", "1")
 
 
 def pytest_configure(config):
@@ -68,7 +71,7 @@ def _release_device_objects_between_tests(request):
     predecessors.  (One run of the suite ended in a SIGABRT inside hipMemcpy of a test whose predecessor had left two
     indexes unclosed; with nothing piling up it has not come back.)"""
     yield
-    if "gpu" in request.keywords:
+    if "gpu" in request.keywords and not os.environ.get("FFX_TEST_KEEP_GARBAGE"):  # (tools/abort_hunt.sh runs the suite without this)
         import gc
 
         gc.collect()

@@ -729,7 +729,11 @@ def test_a_result_keeps_its_arrays_when_later_calls_reuse_the_result_pool():
     again = index.rerank(second, 0.5)
     assert again._coded["score"].ctypes.data == addr or again._coded["id_codes"].ctypes.data == addr
     index.close()
-    assert native.drain_result_pool() > 0
+    del again, dense_first, dense_second
+    import gc
+
+    gc.collect()
+    assert native.drain_result_pool() > 0 and native._POOL_IDLE[0] == 0
 
 
 def test_early_stopping_on_a_large_run_edge_cases():

@@ -572,3 +572,58 @@ def test_streamed_index_of_8_gb_through_windows_equals_the_same_rows_resident():
         del disk
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_a_refused_page_lock_falls_back_to_host_threads_and_leaves_no_stale_error(tmp_path, monkeypatch):
+    """The driver may refuse to page-lock a mapping (RLIMIT_MEMLOCK in a container, a mapping that cannot be read).  With the
+    automatic policy (``page_lock=None``) that is an answer, not a fault: the call goes on with the host gather threads ON THE
+    SAME THREAD -- so ffx_host_pin must not leave the runtime's sticky last error behind for the next launch check to report
+    as its own.  Forced here by handing the real ffx_host_pin an address range that is not mapped."""
+    import ctypes
+    import mmap
+
+    from fast_forward_amd import native
+
+    # (1) the C entry point itself: a refusal, then a scoring call on the same thread.  (The driver of this image page-locks
+    # a PROT_NONE mapping, the same range twice and even a range that was unmapped a moment ago without complaint; a range
+    # that can never be mapped -- below mmap_min_addr, or in the kernel's half of the address space -- is what is left to try.)
+    size = 1 << 20
+    hole, refused = None, False
+    for candidate in (4096, 0xFFFF800000000000):
+        if native.lib().ffx_host_pin(ctypes.c_void_p(candidate), size) != native.OK:
+            hole, refused = candidate, True
+            break
+        native.lib().ffx_host_unpin(ctypes.c_void_p(candidate))
+    rng = np.random.default_rng(3)
+    n, d = 3000, 64
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(rows, 0)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    q = rng.standard_normal((2, d)).astype(np.float32)
+    ff, _, _, _ = native.score(idx, q, np.array([0, 100, 200]), rng.permutation(n)[:200].astype(np.int32), 1)  # launches + their checks
+    assert np.isfinite(ff).all()
+    idx.close()
+    # (2) the streamed index under the automatic policy: the refusal is recorded, the rows come through the host threads
+    qv = rng.standard_normal((4, d)).astype(np.float32)
+    enc = LambdaEncoder(lambda t: qv[int(t)])
+    disk = OnDiskIndex(tmp_path / "refused.ffx", enc, mode=Mode.MAXP, chunk_size=512, window_bytes=1 << 16)
+    disk.add(rows, doc_ids=[f"D{i}" for i in range(n)])
+    run = {f"q{j}": {f"D{x}": float(rng.random()) for x in rng.choice(n, size=300, replace=False)} for j in range(4)}
+    first = Ranking.from_run(run, queries={f"q{j}": str(j) for j in range(4)})
+    want = disk.to_memory().rerank(first, 0.2)
+    real_pin = native.lib().ffx_host_pin
+
+    class Refusing(native.PinnedMaps):
+        def __init__(self, arrays):
+            if refused:
+                native._check(real_pin(ctypes.c_void_p(hole), size))  # the REAL refusal, with whatever it leaves behind in the runtime
+            raise native.FFXError(native.HIP_ERROR, "hipHostRegister: refused (simulated: this driver page-locks anything it is handed)")
+
+    monkeypatch.setattr(native, "PinnedMaps", Refusing)
+    auto = OnDiskIndex.load(tmp_path / "refused.ffx", enc, window_bytes=1 << 16)  # page_lock=None
+    monkeypatch.setattr("fast_forward_amd.index.ondisk._resident_fraction", lambda maps, samples=1024: 1.0)
+    assert auto.rerank(first, 0.2) == want
+    assert auto.last_stats["row_source"].startswith("host gather threads (page-locking the vector maps failed"), auto.last_stats["row_source"]

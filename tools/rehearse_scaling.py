@@ -44,18 +44,28 @@ def main():
                          "local_pairs": reh["local_pairs"], "owned_pairs": reh["owned_pairs"],
                          "exchange_ms": line["exchange_ms_per_rank"][r], "merge_ms": line["merge_ms_per_rank"][r],
                          "local_step_ms": line["local_step_ms_per_rank"][r], "parity": line.get("parity_on_cpu_sample"),
-                         "route_and_upload_next_batch_s": line["route_and_upload_next_batch_s"], "host_issue_ms_per_step": line.get("host_issue_ms_per_step"), "host_to_host_batch_ms": line["host_to_host_batch_ms"],
+                         "set_once_route_and_upload_s": line["route_and_upload_next_batch_s"], "host_issue_ms_per_step": line.get("host_issue_ms_per_step"),
+                         "set_once_host_to_host_batch_ms": line.get("set_once_host_to_host_batch_ms"),
+                         # a FRESH batch per step, every rank handed only the queries it owns (ffx_sharded_stage_owned)
+                         "fresh_batch_step_ms": line["fresh_batch_step_ms"], "fresh_over_ideal": line["fresh_batch_step_ms"] / reh["ideal_ms"],
+                         "fresh_query_vectors": line.get("fresh_batch_query_vectors"), "stage_h2d_bytes": line["stage_h2d_bytes_per_rank"][r],
+                         "stage_route_sent_bytes": line["stage_route_sent_bytes_per_rank"][r], "stage_device_ms": line["stage_device_ms_per_rank"][r],
+                         "fresh_gather_dot_ms": line["fresh_batch_gather_dot_ms_per_rank"][r], "rehearsal_exchange": line.get("rehearsal_exchange"),
                          "queries": line["config"]["queries"]})
             print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
     base = next((x["step_ms"] for x in rows if x["N"] == 1), None)
+    base_fresh = next((x["fresh_batch_step_ms"] for x in rows if x["N"] == 1), None)
     for x in rows:
         x["predicted_queries_per_s"] = x["queries"] / (x["step_ms"] * 1e-3)
         x["predicted_efficiency"] = None if base is None else base / (x["N"] * x["step_ms"])
-    print(f"{'N':>3} {'rank':>4} {'step ms':>9} {'ideal ms':>9} {'step/ideal':>10} {'exch ms':>8} {'merge ms':>8} {'pred q/s':>11} {'pred eff':>8}")
+        x["fresh_predicted_queries_per_s"] = x["queries"] / (x["fresh_batch_step_ms"] * 1e-3)
+        x["fresh_predicted_efficiency"] = None if base_fresh is None else base_fresh / (x["N"] * x["fresh_batch_step_ms"])
+    print(f"{'N':>3} {'rank':>4} {'step ms':>9} {'ideal ms':>9} {'step/ideal':>10} {'fresh ms':>9} {'fresh/ideal':>11} {'stage ms':>9} {'H2D MB':>8} {'pred eff':>8} {'fresh eff':>9}")
     for x in rows:
         eff = "-" if x["predicted_efficiency"] is None else f"{x['predicted_efficiency']:.3f}"
-        print(f"{x['N']:>3} {x['rank']:>4} {x['step_ms']:>9.3f} {x['ideal_ms']:>9.3f} {x['step_over_ideal']:>10.3f} {x['exchange_ms']:>8.3f} "
-              f"{x['merge_ms']:>8.3f} {x['predicted_queries_per_s']:>11.0f} {eff:>8}")
+        feff = "-" if x["fresh_predicted_efficiency"] is None else f"{x['fresh_predicted_efficiency']:.3f}"
+        print(f"{x['N']:>3} {x['rank']:>4} {x['step_ms']:>9.3f} {x['ideal_ms']:>9.3f} {x['step_over_ideal']:>10.3f} {x['fresh_batch_step_ms']:>9.3f} "
+              f"{x['fresh_over_ideal']:>11.3f} {x['stage_device_ms']:>9.3f} {x['stage_h2d_bytes'] / 1e6:>8.1f} {eff:>8} {feff:>9}")
     if args.out:
         Path(args.out).parent.mkdir(parents=True, exist_ok=True)
         Path(args.out).write_text(json.dumps({"what": "single-GPU rehearsal of one rank of N (bench.py --as-rank-of N): predicted scaling, not measured",
