@@ -24,7 +24,7 @@ import bench as B  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=8_841_823)
-ap.add_argument("--order", default="first", choices=["first", "sorted", "in_order"])
+ap.add_argument("--order", default="first", help="first | sorted | in_order | bucket:SHIFT (stable sort by row >> SHIFT inside every query)")
 ap.add_argument("--steps", type=int, default=8)
 args = ap.parse_args()
 n, d, nq, k = args.rows, 768, 6980, 5000
@@ -44,6 +44,11 @@ else:
     ids, sparse = B.candidates(n, nq, k, 2024)
     if args.order == "sorted":
         ids = np.sort(ids.reshape(nq, k), axis=1).reshape(-1)
+    elif args.order.startswith("bucket:"):
+        shift = int(args.order.split(":")[1])
+        m = ids.reshape(nq, k)
+        o = np.argsort(m >> shift, axis=1, kind="stable")
+        ids = np.take_along_axis(m, o, axis=1).reshape(-1).copy()
     plan.set_queries(synth.rows(2027, 0.036, 0, nq, d))
     plan.set_pairs(np.arange(nq + 1, dtype=np.int64) * k, ids, sparse, 1)
     pairs = nq * k

@@ -8,7 +8,7 @@ BIG=${2:-85000000}
 ROOT=$(pwd)
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
-COUNTERS=$( (rocprofv3 --list-avail 2>/dev/null || rocprofv3 -L 2>/dev/null) | grep -o -E "Counter_Name +:[[:space:]]+(TCP_UTCL1_[A-Z_]+_sum|TCP_UTCL1_[A-Z_]+|TCC_HIT_sum|TCC_MISS_sum)" | awk '{print $NF}' | sort -u | grep -E "_sum$" | tr '\n' ' ')
+COUNTERS=$( (rocprofv3 --list-avail 2>/dev/null || rocprofv3 -L 2>/dev/null) | grep -o -E "Counter_Name +:[[:space:]]+(TCP_UTCL1_[A-Z_]+_sum|TCP_UTCL1_[A-Z_]+|TCC_HIT_sum|TCC_MISS_sum)" | awk '{print $NF}' | sort -u | grep -E "_sum$" | grep -E "TRANSLATION_MISS|TRANSLATION_HIT|UTCL1_REQUEST|PERMISSION_MISS|TCC_MISS" | head -5 | tr '\n' ' ')
 echo "counters: $COUNTERS" | tee "$OUT/counters.txt"
 for rows in 8841823 $BIG; do
   for order in first sorted in_order; do
