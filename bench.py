@@ -94,6 +94,7 @@ def parse_args():
                     help="--as-rank-of N: what stands in for the peers' traffic -- `copy`: one kernel of 16 workgroups moving the bytes through this GPU's memory; "
                          "`paced[:R]`: one PERSISTENT workgroup per peer and direction that moves its piece in 64 KiB chunks and spins on a flag between chunks "
                          "until a link of R GB/s (default 50) would have delivered them")
+    ap.add_argument("--fresh-timeout", type=float, default=300.0, help="seconds the fresh-batch section of the sharded leg may take before the line is printed without it")
     ap.add_argument("--require-rccl", action="store_true",
                     help="N > 1: exit non-zero if RCCL cannot be brought up on every rank instead of falling back to the shared-memory "
                          "transport (a fallback line is marked `\"scaling\": \"invalid: host transport\"` and `\"value_is_rccl\": false`)")
@@ -464,31 +465,54 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
     scorer.run(args.alpha, exact_sum=exact, sort=args.sort)
     per_rank = gather_stats(comm, scorer.stats())
     row_bytes = args.dim * np.dtype(store).itemsize + 4
-    fresh = fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exact, rank, world, query_partition)
 
-    # parity: owned queries' interpolated scores vs the oracle on a small sample (the rank that prints the line)
+    # parity: owned queries' interpolated scores vs the oracle on a small sample (the rank that prints the line) -- of the batch
+    # that was replayed above, and once more of the last FRESH batch below
     rehearsal = bool(args.as_rank_of)
     lead = rank == 0 or rehearsal
-    parity = base = None
-    if lead and args.cpu_sample_queries > 0 and scorer.q_hi > scorer.q_lo:
+    base = None
+
+    def check(interp, q_lo, batch_seed):
+        nonlocal base
         # the CPU baseline proper is a figure of the N = 1 line; here the oracle only checks a few owned queries
         args.cpu_sample_queries = min(args.cpu_sample_queries, scorer.q_hi - scorer.q_lo, 16 if world > 1 else args.cpu_sample_queries)
         if world > 1:
             args.cpu_seconds = min(args.cpu_seconds, 0.5)
-        base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale, q_first=scorer.q_lo, batch_seed=fresh["last_batch_seed"])
-        interp = fresh.get("interp")  # of the last fresh batch: out of ffx_sharded_score's host buffers, or (rehearsal) out of the device
-        if interp is None:
-            _, interp, _ = scorer.fetch()
+        base, (s_ids, s_sparse, s_interp) = cpu_baseline(args, doc_off, n_docs, scale, q_first=q_lo, batch_seed=batch_seed)
         n_s = s_ids.shape[0]
         got, want = interp[:n_s], s_interp
+        held = None
         if rehearsal:  # only the candidates this rank holds were scored: the peers' scores arrive as zeros
             held = (s_ids >= doc_bounds[rank]) & (s_ids < doc_bounds[rank + 1])
             got, want = got[held], want[held]
         ok = np.array_equal(got.view(np.uint32), want.view(np.uint32)) if exact else bool(np.abs(got - want).max() <= 1e-4)
-        parity = ("bit-exact" if exact else "within 1e-4") if ok else "MISMATCH"
+        verdict = ("bit-exact" if exact else "within 1e-4") if ok else "MISMATCH"
         if rehearsal and ok:
-            parity += f" on the {int(held.sum())} of {n_s} sampled pairs this rank holds"
-    failed = parity == "MISMATCH"
+            verdict += f" on the {int(held.sum())} of {n_s} sampled pairs this rank holds"
+        return verdict
+
+    parity = None
+    checking = lead and args.cpu_sample_queries > 0 and scorer.q_hi > scorer.q_lo
+    if checking:
+        parity = check(scorer.fetch()[1], scorer.q_lo, None)
+    # Fresh batches: new code paths over the fabric (a second communicator, exchanges on two lanes).  Whatever happens in there
+    # -- an error, a collective that never completes -- the line with the replayed batch's figures still comes out.
+    fresh_failed = None
+    try:
+        fresh = _guarded(lambda: fresh_batches(args, comm, scorer, doc_off, n_docs, doc_bounds, queries, exact, rank, world, query_partition),
+                         args.fresh_timeout, "the fresh-batch section")
+    except (TimeoutError, native.FFXError, RuntimeError, MemoryError, IndexError, OSError, AssertionError) as e:
+        fresh_failed = f"{type(e).__name__}: {e}"
+        print(f"rank {rank}: fresh-batch section failed ({fresh_failed}); the line carries the replayed batch only", file=sys.stderr, flush=True)
+        fresh = {"line": {"fresh_batch_step_ms": None, "fresh_batch_error": fresh_failed[:300]}, "last_batch_seed": None, "interp": None}
+    fresh_parity = None
+    if checking and fresh_failed is None:
+        interp = fresh.get("interp")  # of the last fresh batch: out of ffx_sharded_score's host buffers, or (rehearsal) out of the device
+        if interp is None:
+            _, interp, _ = scorer.fetch()
+        fresh_parity = check(interp, scorer.q_lo, fresh["last_batch_seed"])
+        fresh["line"]["fresh_batch_parity_on_cpu_sample"] = fresh_parity
+    failed = parity == "MISMATCH" or fresh_parity == "MISMATCH"
     if lead:
         slowest = max(per_rank, key=lambda t: t["ms_gather_dot"])
         achieved = slowest["n_rows"] * row_bytes / (slowest["ms_gather_dot"] * 1e-3) / 1e9
@@ -553,7 +577,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                 "step_ms": ms_per_step, "ideal_ms": me["ms_gather_dot"], "step_over_ideal": ms_per_step / max(me["ms_gather_dot"], 1e-9),
                 "local_pairs": int(me["n_pairs"]), "owned_pairs": int(me["own_pairs"]), "owned_queries": int(me["own_queries"]),
                 "fresh_batch_step_ms": fresh["line"]["fresh_batch_step_ms"],
-                "fresh_batch_step_over_ideal": fresh["line"]["fresh_batch_step_ms"] / max(me["ms_gather_dot"], 1e-9),
+                "fresh_batch_step_over_ideal": None if fresh["line"]["fresh_batch_step_ms"] is None else fresh["line"]["fresh_batch_step_ms"] / max(me["ms_gather_dot"], 1e-9),
                 "note": "step_ms: K back-to-back steps of this one rank (batch i's exchange + merge overlap batch i+1's scoring); ideal_ms: this "
                         "rank's gather_dot alone (HIP events of a step run by itself).  `value` = queries / step_ms is what N such ranks would "
                         "deliver if the fabric added nothing: a prediction, not a measurement of N GPUs",
@@ -563,6 +587,11 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                 result["cpu_baseline"] = base
             result["parity_on_cpu_sample"] = parity
         print(json.dumps(result), flush=True)
+    if fresh_failed is not None:
+        # a call of that section may still be inside the library on its thread: no further collective, no teardown that waits for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(4 if failed else 0)
     failed = bool(comm.allreduce([1.0 if failed else 0.0], native.OP_MAX)[0])
     scorer.close()
     comm.close()
