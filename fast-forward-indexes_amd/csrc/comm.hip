@@ -1126,6 +1126,8 @@ struct ffx_sharded {
   };
   DevArr d_ids, d_off, d_who, d_cnt, d_local_off, d_local_ids, d_pos, d_keys, d_arrival, d_slot, d_small, d_tmp;
   DevArr d_held, d_start, d_sendids, d_qcnt, d_verdict, d_cntq, d_tiles;  // owner-side routing (ffx_sharded_stage_owned)
+  DevArr d_code_table;     // ffx_sharded_set_code_table: this rank's ordinal of every code (-1: not held here)
+  int64_t n_codes = -1;    // -1: candidates come as ordinals
   std::vector<int32_t> tile_first;
   std::vector<int64_t> tile_p0, tile_hi;
   void* host_small = nullptr;                            // page-locked read-back block of the staging
@@ -1586,6 +1588,14 @@ own_qcount_kernel(const int32_t* __restrict__ start, const int32_t* __restrict__
   if (i < world) small[1 + i] = (long long)start[(size_t)(i + 1) * n_tiles] - (long long)start[(size_t)i * n_tiles];
 }
 
+// candidates that travelled as CODES (a numbering every rank agrees on: a ranking's id codes) become this rank's ordinals
+__global__ void __launch_bounds__(256) codes_to_ordinals_kernel(int32_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ table, int64_t n_codes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = ids[i];
+  ids[i] = (uint32_t)c < (uint64_t)n_codes ? table[c] : -1;  // -1: the ordinal check that follows reports it
+}
+
 // exchange C's words, made on the device: own_bad = the smallest position of one of MY candidates that no rank holds,
 // plan_bad = the smallest LOCAL position of an ordinal that names no row here (either ~0: none)
 __global__ void stage_verdict_kernel(const unsigned long long* __restrict__ own_bad, const unsigned long long* __restrict__ plan_bad, const int64_t* __restrict__ local_off,
@@ -1860,6 +1870,10 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
     }
     C_TRY(comm_alltoallv(s->comm, 1, pc, rs));
   }
+  if (status == FFX_OK && own_holder && s->n_codes >= 0 && sl.local_pairs > 0) {
+    codes_to_ordinals_kernel<<<(unsigned)((sl.local_pairs + 255) / 256), 256, 0, rs>>>(p_ids, sl.local_pairs, s->d_code_table.as<int32_t>(), s->n_codes);
+    C_HIP(hipGetLastError());
+  }
   const unsigned long long* d_plan_bad = nullptr;
   if (status == FFX_OK) status = ffx_plan_adopt_check(s->plans[t], h_local_off, rs, &d_plan_bad);  // validates on rs, asynchronously
   // exchange C, two words per peer (made on the device: nothing to wait for), so that EVERY rank leaves with the same verdict:
@@ -2011,7 +2025,7 @@ int ffx_sharded_destroy(ffx_sharded* s) {
   for (auto* m : s->merges)
     if (m) ffx_merge_destroy(m);
   for (auto* a : {&s->d_ids, &s->d_off, &s->d_who, &s->d_cnt, &s->d_local_off, &s->d_local_ids, &s->d_pos, &s->d_keys, &s->d_arrival, &s->d_slot,
-                  &s->d_small, &s->d_tmp, &s->d_held, &s->d_start, &s->d_sendids, &s->d_qcnt, &s->d_verdict, &s->d_cntq, &s->d_tiles})
+                  &s->d_small, &s->d_tmp, &s->d_held, &s->d_start, &s->d_sendids, &s->d_qcnt, &s->d_verdict, &s->d_cntq, &s->d_tiles, &s->d_code_table})
     a->release();
   if (s->host_small) (void)hipHostFree(s->host_small);
   for (int i = 0; i < kSlots; ++i) {
@@ -2046,6 +2060,21 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
                                const int32_t* local_ids, const float* sparse, int mode, int64_t* bad_pair) {
   if (!holder) return ffx_fail(FFX_BAD_ARG, "holder is NULL");
   return sharded_set(s, pair_off, n_queries, local_ids, holder, sparse, mode, bad_pair);
+}
+
+int ffx_sharded_set_code_table(ffx_sharded* s, const int32_t* ordinal_of_code, int64_t n_codes) {
+  if (!s || n_codes < 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  C_HIP(hipSetDevice(s->device));
+  C_TRY(ffx_sharded_sync(s));
+  if (s->comm->route_stream) C_HIP(hipStreamSynchronize(s->comm->route_stream));
+  if (!ordinal_of_code) {
+    s->n_codes = -1;
+    return FFX_OK;
+  }
+  C_TRY(s->d_code_table.ensure((size_t)std::max<int64_t>(n_codes, 1) * 4));
+  if (n_codes > 0) C_HIP(hipMemcpy(s->d_code_table.p, ordinal_of_code, (size_t)n_codes * 4, hipMemcpyHostToDevice));
+  s->n_codes = n_codes;
+  return FFX_OK;
 }
 
 int ffx_sharded_stage_queries(ffx_sharded* s, const float* all_queries, int64_t n_queries) {

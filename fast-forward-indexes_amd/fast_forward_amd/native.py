@@ -30,7 +30,7 @@ SYMBOLS = (
     "ffx_plan_device_ptr", "ffx_plan_stream", "ffx_plan_set_stream", "ffx_comm_unique_id", "ffx_comm_init", "ffx_comm_destroy", "ffx_comm_rank",
     "ffx_comm_stream", "ffx_comm_barrier", "ffx_comm_allreduce_f64", "ffx_comm_allgather", "ffx_comm_exchange", "ffx_comm_exchange_host",
     "ffx_query_partition", "ffx_route", "ffx_sharded_create", "ffx_sharded_destroy", "ffx_sharded_set_queries", "ffx_sharded_set_pairs",
-    "ffx_sharded_set_pairs_held", "ffx_sharded_stage_owned", "ffx_sharded_stage_queries", "ffx_sharded_run", "ffx_sharded_fetch_async",
+    "ffx_sharded_set_pairs_held", "ffx_sharded_stage_owned", "ffx_sharded_set_code_table", "ffx_sharded_stage_queries", "ffx_sharded_run", "ffx_sharded_fetch_async",
     "ffx_sharded_score", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
     "ffx_aggregate", "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get", "ffx_run_open",
     "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_score", "ffx_score_ranked",
@@ -242,6 +242,7 @@ def lib() -> C.CDLL:
         "ffx_sharded_device_ptr": ([vp, C.c_int, P(vp), P(i64)], C.c_int),
         "ffx_sharded_stage_owned": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, P(i64)], C.c_int),
         "ffx_sharded_stage_queries": ([vp, vp, i64], C.c_int),
+        "ffx_sharded_set_code_table": ([vp, vp, i64], C.c_int),
         "ffx_sharded_fetch_async": ([vp, vp, vp, vp], C.c_int),
         "ffx_sharded_score": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, i32, vp, vp, vp, P(i64)], C.c_int),
     }
@@ -1525,6 +1526,12 @@ class Sharded:
         _check(rc, bad.value)
         self.has_sparse = sp is not None
         self.q_lo, self.q_hi, self.own_first_pair, self.own_pairs = int(qb[self._comm.rank]), int(qb[self._comm.rank + 1]), 0, int(off[-1])
+
+    def set_code_table(self, ordinal_of_code: "np.ndarray | None") -> None:
+        """``ffx_sharded_set_code_table``: with explicit holders, candidates travel as codes and the holder translates them
+        (``ordinal_of_code[c]``: this rank's ordinal of code c, -1 where it does not hold it); None: ordinals again."""
+        t = None if ordinal_of_code is None else _arr(ordinal_of_code, np.int32)
+        _check(lib().ffx_sharded_set_code_table(self._h, _ptr(t), 0 if t is None else t.shape[0]))
 
     def stage_queries(self, all_queries: np.ndarray) -> None:
         """``ffx_sharded_stage_queries``: ALL query vectors of the batch about to be staged, replicated on every rank (then

@@ -448,25 +448,51 @@ class _ShardedIndex:
         holder = held.argmax(axis=0).astype(np.int32) if len(names) else np.zeros(0, dtype=np.int32)
         return holder, np.maximum(ord_u, 0), ~held.any(axis=0)
 
-    def _holders(self, ranking, perm, missing_ok: bool = False) -> tuple[np.ndarray, np.ndarray]:
-        """(holder rank, ordinal on that rank) of every candidate, rows grouped by query.  The distinct ids are
-        looked up once per (ranking, index, mode) and remembered with the ranking; ``IndexError`` on EVERY rank
-        for an id no rank holds (the reference's util.py:38-39), naming the first one in row order -- or, with
-        ``missing_ok`` (early stopping: an unknown id only matters if it is reached), holder -1 for such rows."""
+    def _code_routing(self, ranking) -> dict:
+        """What routing needs of a ranking's DISTINCT ids, looked up once per (ranking, index, mode) and remembered with
+        the ranking (collective on a miss): ``holder_c[c]`` = rank holding the id with code c (-1: nobody) and
+        ``ordinal_c[c]`` = its ordinal on THIS rank (0 where another rank holds it)."""
         codes, names = ranking._id_coding()
         key = (id(self), self.local.mode, getattr(self, "_n_global", None), getattr(self.local._ids, "version", None))
         cached = getattr(ranking, "_holder_cache", None)
-        if cached is None or cached[0] != key or cached[1] is not names or cached[2] is not codes:
+        if cached is None or cached["key"] != key or cached["names"] is not names or cached["codes"] is not codes:
             holder_c, local_c, missing_c = self._holders_by_code(names, ranking._id_blob(names))
-            holder_c = np.where(missing_c, -1, holder_c).astype(np.int32)
-            cached = (key, names, codes, holder_c[codes], local_c.astype(np.int32)[codes])
+            cached = {"key": key, "names": names, "codes": codes, "holder_c": np.where(missing_c, -1, holder_c).astype(np.int32),
+                      "ordinal_c": local_c.astype(np.int32), "missing": bool(missing_c.any())}
             ranking._holder_cache = cached
-        holder, local_ids = cached[3], cached[4]
-        if not missing_ok:
-            bad = np.flatnonzero(holder < 0)
-            if bad.size:
-                raise IndexError(f"ID {names[codes[int(bad[0])]]} not found in the index.")
+        return cached
+
+    @staticmethod
+    def _raise_first_missing(routing: dict) -> None:
+        """``IndexError`` naming the first id in ROW order that no rank holds (the reference's util.py:38-39)."""
+        codes, names = routing["codes"], routing["names"]
+        bad = np.flatnonzero(routing["holder_c"][codes] < 0)
+        raise IndexError(f"ID {names[codes[int(bad[0])]]} not found in the index.")
+
+    def _holders(self, ranking, perm, missing_ok: bool = False) -> tuple[np.ndarray, np.ndarray]:
+        """(holder rank, ordinal on that rank) of every candidate, rows grouped by query.  ``IndexError`` on EVERY rank
+        for an id no rank holds, naming the first one in row order -- or, with ``missing_ok`` (early stopping: an unknown
+        id only matters if it is reached), holder -1 for such rows."""
+        routing = self._code_routing(ranking)
+        if "rows" not in routing:
+            routing["rows"] = (routing["holder_c"][routing["codes"]], routing["ordinal_c"][routing["codes"]])
+        holder, local_ids = routing["rows"]
+        if not missing_ok and routing["missing"]:
+            self._raise_first_missing(routing)
         return (holder, local_ids) if perm is None else (holder[perm], local_ids[perm])
+
+    def _streams_rows(self) -> bool:
+        """True when this rank's rows are not resident and every call streams them from the file (``ShardedOnDiskIndex``)."""
+        return False
+
+    def _install_code_table(self, scorer: ShardedScorer, routing: dict) -> None:
+        """This rank's ordinal of every code of the ranking (-1: held elsewhere) into the scorer's HBM, once per
+        (ranking, index state): 4 bytes per DISTINCT id, where the candidate lists are 4 bytes per row."""
+        if getattr(scorer, "_code_table_of", None) is routing:
+            return
+        table = np.where(routing["holder_c"] == self.comm.rank, routing["ordinal_c"], np.int32(-1)).astype(np.int32)
+        scorer._s.set_code_table(table)
+        scorer._code_table_of = routing  # (keeps the routing alive: `is` cannot be fooled by a recycled id)
 
     def _sharded(self) -> ShardedScorer:
         raise NotImplementedError
@@ -490,23 +516,32 @@ class _ShardedIndex:
             raise ValueError("Input ranking has no queries attached.")
         run = _Run(self.local, ranking)
         pair_off = run.pair_off
-        sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
-        holder, local_ids = self._holders(ranking, run.perm)
         mode = self.local.mode.value
-        streamed = self._local_scores(run.query_vectors, pair_off, holder, local_ids, mode)
-        if streamed is None:
-            # (hash-placed shards: every rank knows the ordinals of ITS OWN rows only, so every rank is handed the whole
-            # candidate list and picks what it holds -- ffx_sharded_set_pairs_held.  The owner-routed form, in which a rank
-            # uploads only the queries it owns, needs ordinals the OWNER can name: document-range shards, ShardedScorer.score_owned)
+        if not self._streams_rows():
+            # Owner-side routing: this rank hands its GPU only the queries it OWNS (~P/world candidates).  Rows are placed
+            # by a hash of the document id and every rank knows the ordinals of its own rows only, so the candidates travel
+            # as the ranking's id CODES (every rank numbers a ranking's ids alike) beside their holder, and the holder
+            # translates what arrives through a table in its HBM (ffx_sharded_set_code_table, set once per ranking).
+            routing = self._code_routing(ranking)
+            if routing["missing"]:
+                self._raise_first_missing(routing)
             scorer = self._sharded()
-            scorer.set_queries(self._scorer_queries(run.query_vectors))
-            scorer.set_pairs(pair_off, local_ids, sparse if alpha is not None else None, mode, holder=holder)
-            scorer.run(0.0 if alpha is None else alpha, exact_sum=self.exact_sum, sort=True)
-            ff, interp, order = scorer.fetch(order=True)
-            q_lo, q_hi = scorer.q_lo, scorer.q_hi
-            lo, hi = scorer.own_first_pair, scorer.own_first_pair + scorer.own_pairs
+            self._install_code_table(scorer, routing)
+            qb = native.query_partition(run.n_q, self.comm.world)
+            q_lo, q_hi = int(qb[self.comm.rank]), int(qb[self.comm.rank + 1])
+            lo, hi = int(pair_off[q_lo]), int(pair_off[q_hi])
+            rows = slice(lo, hi) if run.perm is None else run.perm[lo:hi]  # this block's rows of the ranking
+            own_codes = np.ascontiguousarray(run.codes[rows], dtype=np.int32)
+            own_sparse = np.ascontiguousarray(ranking._scores()[rows], dtype=np.float32) if alpha is not None else None
+            own_q = self._scorer_queries(run.query_vectors[q_lo:q_hi]) if q_hi > q_lo else np.zeros((0, scorer.shard.query_dim), dtype=np.float32)
+            ff, interp, order = scorer.score_owned(qb, own_q, pair_off[q_lo:q_hi + 1] - lo, own_codes, own_sparse, mode, 0.0 if alpha is None else alpha,
+                                                   exact_sum=self.exact_sum, sort=True, own_holder=routing["holder_c"][own_codes])
         else:
-            # the same exchange on host buffers, then the owner-side epilogue (ffx_aggregate, 1-row segments)
+            # the shard is streamed from its file: local scores by the 1-GPU streaming path, the same exchange on host
+            # buffers, then the owner-side epilogue (ffx_aggregate, 1-row segments)
+            sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
+            holder, local_ids = self._holders(ranking, run.perm)
+            streamed = self._local_scores(run.query_vectors, pair_off, holder, local_ids, mode)
             r = native.route(pair_off, local_ids, self.comm.rank, self.comm.world, holder=holder)
             recv = self.comm.exchange_host(streamed, r["send_counts"], r["recv_counts"])
             dense = recv[r["recv_slot"]]
@@ -802,6 +837,9 @@ class ShardedOnDiskIndex(_ShardedIndex):
         # OPQ decodes to c @ R.T, and <q, c R^T> = <q R, c>: the queries are rotated once (as InMemoryIndex does)
         rotation = getattr(self, "_rotation", None)
         return query_vectors if rotation is None else np.ascontiguousarray(np.asarray(query_vectors, dtype=np.float32) @ rotation, dtype=np.float32)
+
+    def _streams_rows(self) -> bool:
+        return not self.resident
 
     def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode):
         if self.resident:

@@ -306,6 +306,13 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
  * owns it: a position in ITS list).  Per-rank host->device bytes are proportional to the block, not to the batch. */
 int ffx_sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
                             const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, int64_t* bad_pair);
+/* Shards whose rows only their holder can name (rows placed by a hash of the document id: every rank interns the ids of its own
+ * rows and no others): the candidates of ffx_sharded_stage_owned / _score then travel as CODES -- any numbering of the distinct
+ * ids that every rank agrees on, e.g. a ranking's id codes -- with explicit holders, and the holder translates them after they
+ * have arrived: ordinal_of_code[c] = this rank's ordinal of code c (-1: not held here).  The table stays in device memory
+ * until it is replaced; NULL: candidates are ordinals again.  (The reference has one id table per process:
+ * index/memory.py:46-47; here every rank has its own.) */
+int ffx_sharded_set_code_table(ffx_sharded* s, const int32_t* ordinal_of_code, int64_t n_codes);
 /* The other way to hand over the query vectors of the batch about to be staged: ALL n_queries of them, on every rank (each
  * rank uploads Q * dim * 4 bytes over its own link; nothing is exchanged), then ffx_sharded_stage_owned with own_queries =
  * NULL.  Asynchronous (the vectors must stay put until the stage call returns).  Which of the two is cheaper depends on the

@@ -44,6 +44,12 @@ for mode in ("MAXP", "PASSAGE", "AVEP"):
     own = idx.rerank(first, 0.1)  # only the queries this rank owns
     exp_i = case.expected_order(f"{mode}_int0.1")
     assert 0 < len(own.q_ids) < len(case.q_names)
+    # what this rank's GPU took in is ITS block of the batch (offsets, id codes + holders + first-stage scores, the owned
+    # queries' vectors), not the batch: rows are hash-placed, so the candidates travelled as the ranking's id codes
+    st = idx._sharded().stats()
+    n_own_q, n_own_p = st["own_queries"], st["own_pairs"]
+    assert n_own_q == len(own.q_ids) and 0 < n_own_p < len(names)
+    assert st["stage_h2d_bytes"] == (n_own_q + 1) * 8 + n_own_p * 12 + n_own_q * idx.dim * 4, st
     for qn in own.q_ids:
         rows = own._df[own._df["q_id"] == qn]
         assert_same_order_modulo_ties(rows["id"].tolist(), rows["score"].to_numpy(), exp_i[qn])

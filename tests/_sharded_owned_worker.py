@@ -80,6 +80,26 @@ def main():
             who = (np.searchsorted(bounds, own_ids, side="right") - 1).astype(np.int32)
             ff, interp, _ = scorer.score_owned(qb, queries[q_lo:q_hi], own_off, (own_ids - bounds[who]).astype(np.int32), own_sp, mode, 0.3, n_slices=2, own_holder=who)
             assert np.array_equal(bits(ff), bits(want_ff[lo:hi])) and np.array_equal(bits(interp), bits(want_in[lo:hi]))
+            # ... and the candidates as CODES (a numbering all ranks share, here a shuffle of the documents) that only the
+            # holder can turn into ordinals: ffx_sharded_set_code_table
+            code_of_doc = np.random.default_rng(5).permutation(n_docs).astype(np.int32)
+            table = np.full(n_docs + 3, -1, dtype=np.int32)  # (codes nobody uses stay -1)
+            table[code_of_doc[d_lo:d_hi]] = np.arange(d_hi - d_lo, dtype=np.int32)
+            scorer._s.set_code_table(table)
+            ff, interp, order = scorer.score_owned(qb, queries[q_lo:q_hi], own_off, code_of_doc[own_ids], own_sp, mode, 0.3, sort=True, n_slices=3, own_holder=who)
+            assert np.array_equal(bits(ff), bits(want_ff[lo:hi])) and np.array_equal(bits(interp), bits(want_in[lo:hi]))
+            assert np.array_equal(order + lo, want_or[lo:hi])
+            if b == 0 and mode == 2:  # a code the named holder does not hold: the owner is told which pair, everybody raises
+                wrong = code_of_doc[own_ids].copy()
+                if rank == world - 1 and hi > lo:
+                    wrong[hi - lo - 1] = n_docs + 1
+                try:
+                    scorer.score_owned(qb, queries[q_lo:q_hi], own_off, wrong, own_sp, mode, 0.3, n_slices=1, own_holder=who)
+                    raise SystemExit("a code its holder cannot translate was accepted")
+                except IndexError as e:
+                    assert (f"pair {hi - lo - 1} " in str(e)) if (rank == world - 1 and hi > lo) else ("another rank" in str(e)), str(e)
+            scorer._s.set_code_table(None)  # ordinals again
+            checked += hi - lo
     # several DIFFERENT batches in flight: stage (i+1) while (i) runs, results of (i-1) leaving
     mode = 2
     outs = [tuple(native.pinned_empty(2000, dt) for dt in (np.float32, np.float32, np.int32)) for _ in range(len(batches))]
