@@ -923,6 +923,8 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
     t1 = time.perf_counter()
     final2 = first.interpolate(dense, args.alpha)
     out["iii_call_s"], out["iii_interpolate_s"] = t1 - t0, time.perf_counter() - t1
+    # (which route the interpolate took: "queries_numbered_s" = from the dense scores index(first) left in HBM, no second gather)
+    out["iii_interpolate_breakdown"] = dict(getattr(api, "last_timings", None) or {})
     again = []
     for _ in range(3):  # the blocks of the result pool exist after the first calls (how many results are alive at once decides when)
         t1 = time.perf_counter()

@@ -264,6 +264,12 @@ struct ffx_index {
   hipStream_t out_stream = nullptr;
   hipStream_t score_stream = nullptr;  // ... and every slice's kernels run on this one, in order (see ffx_score)
   hipEvent_t out_done[3] = {nullptr, nullptr, nullptr};
+  // FFX_FLAG_KEEP_DENSE: the dense scores (first-stage order) and the carried words of the last such ffx_score_ranked call,
+  // for ffx_rank_kept (Ranking.interpolate on an Index.__call__ result: the interpolation and the ordering, no gather)
+  DevBuf kept_dense, kept_carry;
+  int64_t kept_pairs = -1, kept_queries = -1;
+  bool kept_has_carry = false;
+  uint64_t kept_token = 0, kept_off_hash = 0;
 };
 
 struct ffx_plan {
@@ -289,6 +295,7 @@ struct ffx_plan {
   // the run in final order (ffx_score_ranked): the sort key and a carried word per candidate, permuted by `order`
   DevBuf carry, ranked, carry_ranked;
   bool want_ranked = false, have_carry = false;
+  bool dense_given = false;  // the next run starts from dense scores already in `ff` (ffx_rank_kept): no expand, no gather
   int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
   int n_queries_set = 0;
   int mode = 0;
@@ -477,6 +484,8 @@ int ffx_index_destroy(ffx_index* idx) {
   if (idx->order_ev) (void)hipEventDestroy(idx->order_ev);
   idx->pull_list.release();
   idx->pull_chunks.release();
+  idx->kept_dense.release();
+  idx->kept_carry.release();
   if (idx->out_stream) (void)hipStreamDestroy(idx->out_stream);
   if (idx->score_stream) (void)hipStreamDestroy(idx->score_stream);
   for (auto& e : idx->out_done)
@@ -1096,6 +1105,7 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   }
   FFX_HIP(hipSetDevice(ix->device));
   pl->have_pairs = false;
+  pl->dense_given = false;
   pl->ran = false;
   pl->n_queries = n_queries;
   pl->n_pairs = P;
@@ -1228,6 +1238,7 @@ int ffx_plan_set_pairs_device(ffx_plan* pl, const int64_t* dev_pair_off, const i
   }
   FFX_HIP(hipSetDevice(ix->device));
   pl->have_pairs = false;
+  pl->dense_given = false;
   pl->lazy_pairs = false;
   pl->ran = false;
   pl->n_queries = n_queries;
@@ -1309,6 +1320,7 @@ int ffx_plan_set_pairs_lazy(ffx_plan* pl, const int64_t* pair_off, int64_t n_que
   if (P > 0 && (!pair_ids || !sparse)) return fail(FFX_BAD_ARG, "early stopping needs candidate ordinals and first-stage scores");
   FFX_HIP(hipSetDevice(pl->device));
   pl->have_pairs = false;
+  pl->dense_given = false;
   pl->lazy_pairs = false;
   pl->ran = false;
   pl->n_queries = n_queries;
@@ -1350,6 +1362,7 @@ int ffx_plan_adopt_begin(ffx_plan* pl, int64_t n_queries, int64_t n_pairs, int m
   if (n_pairs > INT32_MAX - 1) return fail(FFX_BAD_ARG, "more than 2^31-2 pairs in one batch: split the queries");
   FFX_HIP(hipSetDevice(pl->device));
   pl->have_pairs = false;
+  pl->dense_given = false;
   pl->lazy_pairs = false;
   pl->ran = false;
   pl->n_queries = n_queries;
@@ -1907,13 +1920,15 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   FFX_HIP(hipSetDevice(ix->device));
   const int64_t P = pl->n_pairs, R = pl->n_rows;
   hipStream_t st = pl->stream;
-  const bool single = (R == P);
+  // dense scores given (plan_set_given): stages 1 and 2 have happened in an earlier call; one dense score per candidate
+  const bool given = pl->dense_given;
+  const bool single = given || (R == P);
   const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
   const bool exact = (flags & FFX_FLAG_EXACT_SUM) != 0;
   pl->ran = false;
   FFX_HIP(hipEventRecord(pl->ev[0], st));
   // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
-  const bool pq_fused = single && P > 0 && !ffx_debug_variant("pq_no_fuse", nullptr) && pq_exact_adc_applies(pl);
+  const bool pq_fused = !given && single && P > 0 && !ffx_debug_variant("pq_no_fuse", nullptr) && pq_exact_adc_applies(pl);
   bool pq_sorted = false;  // the fused kernel ordered the queries as well
   if (pq_fused) {
     hipEvent_t* recent_pq = pl->recent[pl->n_runs % ffx_plan::kRecent];
@@ -1927,7 +1942,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
     FFX_HIP(hipEventRecord(pl->ev[2], st));
     FFX_HIP(hipEventRecord(recent_pq[1], st));
   }
-  if (P > 0 && !pq_fused) {
+  if (P > 0 && !pq_fused && !given) {
     // 1. candidates -> row list
     const double qpp = (double)pl->n_queries / (double)P;
     if (single) {
@@ -1953,7 +1968,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (!pq_fused) FFX_HIP(hipEventRecord(recent[0], st));
   // 2. gather + inner product (the hot kernel)
   float* rs = single ? pl->ff.as<float>() : pl->rs.as<float>();
-  if (R > 0 && !pq_fused) FFX_TRY(launch_gather_dot(pl, exact, rs));
+  if (R > 0 && !pq_fused && !given) FFX_TRY(launch_gather_dot(pl, exact, rs));
   if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[2], st));
   if (!pq_fused) FFX_HIP(hipEventRecord(recent[1], st));
   // 3. segment aggregation + interpolation.  One row per candidate, first-stage scores, queries that are ordered a workgroup
@@ -2002,6 +2017,10 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   pl->ran = true;
   pl->ran_sort = do_sort;
   ++pl->n_runs;
+  if (given) {  // one shot: the plan holds no row list a second run could start from
+    pl->dense_given = false;
+    pl->have_pairs = false;
+  }
   return FFX_OK;
 }
 
@@ -2660,6 +2679,7 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
   memcpy(s_ids, pair_ids, p_bytes);
   if (sparse) memcpy(s_sp, sparse, p_bytes);
   pl->have_pairs = false;
+  pl->dense_given = false;
   pl->lazy_pairs = false;
   pl->ran = false;
   pl->n_queries = n_queries;
@@ -2717,14 +2737,64 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
   return FFX_OK;
 }
 
+// ffx_rank_kept's form of set_queries + set_pairs for one slice: offsets and first-stage scores go up, the dense scores (and the
+// carried words) of the slice are copied from where the FFX_FLAG_KEEP_DENSE call left them; the next run starts behind gather_dot
+static int plan_set_given(ffx_plan* pl, const int64_t* off, int64_t n_queries, const float* sparse, const float* dev_dense, const int32_t* dev_carry) {
+  ffx_index* ix = pl->idx;
+  const int64_t P = off[n_queries];
+  FFX_HIP(hipSetDevice(ix->device));
+  pl->have_pairs = false;
+  pl->dense_given = false;
+  pl->lazy_pairs = false;
+  pl->ran = false;
+  pl->n_queries = n_queries;
+  pl->n_queries_set = (int)n_queries;  // (no query vector is read)
+  pl->n_pairs = pl->n_rows = P;
+  pl->have_sparse = sparse != nullptr;
+  pl->host_pair_off.assign(off, off + n_queries + 1);
+  const size_t pb = std::max<size_t>((size_t)P, 1) * 4;
+  FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
+  FFX_TRY(pl->ff.ensure(pb));
+  if (sparse) {
+    FFX_TRY(pl->sparse.ensure(pb));
+    FFX_TRY(pl->interp.ensure(pb));
+  }
+  if (dev_carry) FFX_TRY(pl->carry.ensure(pb));
+  pl->hstage_used = 0;
+  FFX_TRY(plan_h2d(pl, pl->pair_off.p, off, (size_t)(n_queries + 1) * sizeof(int64_t)));
+  if (P > 0) {
+    if (sparse) FFX_TRY(plan_h2d(pl, pl->sparse.p, sparse, (size_t)P * 4));
+    FFX_HIP(hipMemcpyAsync(pl->ff.p, dev_dense, (size_t)P * 4, hipMemcpyDeviceToDevice, pl->stream));
+    if (dev_carry) FFX_HIP(hipMemcpyAsync(pl->carry.p, dev_carry, (size_t)P * 4, hipMemcpyDeviceToDevice, pl->stream));
+  }
+  FFX_HIP(hipStreamSynchronize(pl->stream));  // (as ffx_plan_set_pairs: the run goes to another stream)
+  pl->have_pairs = true;
+  pl->dense_given = true;
+  return FFX_OK;
+}
+
+static uint64_t offsets_hash(const int64_t* off, int64_t n) {  // FNV-1a over the CSR offsets: "the same candidate lists"
+  uint64_t h = 1469598103934665603ull;
+  for (int64_t i = 0; i <= n; ++i) {
+    h ^= (uint64_t)off[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+static std::atomic<uint64_t> g_kept_tokens{0};
+
+// keep: 0 = ffx_score / ffx_score_ranked; 1 = ... and the dense scores + carried words stay in HBM (FFX_FLAG_KEEP_DENSE);
+// 2 = ffx_rank_kept: no candidates, no queries -- every slice starts from the kept dense scores
 static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
                       const int32_t* pair_ids, const float* sparse, const int32_t* carry, int mode, double alpha, uint32_t flags, float* out_ff,
-                      float* out_interp, int32_t* out_order, float* out_ranked, int32_t* out_carry, int64_t* bad_pair, ffx_stats* stats) {
+                      float* out_interp, int32_t* out_order, float* out_ranked, int32_t* out_carry, int64_t* bad_pair, ffx_stats* stats, int keep = 0) {
   if (bad_pair) *bad_pair = -1;
   if (!idx || !pair_off || n_queries < 0) return fail(FFX_BAD_ARG, "bad argument");
   const bool ranked = out_ranked != nullptr || out_carry != nullptr;
+  const bool given = keep == 2;
   if (ranked && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "the run in final order needs FFX_FLAG_SORT");
-  if (out_carry && !carry) return fail(FFX_BAD_ARG, "out_carry without carry");
+  if (out_carry && !carry && !(given && idx->kept_has_carry)) return fail(FFX_BAD_ARG, "out_carry without carry");
   if (pair_off[0] != 0) return fail(FFX_BAD_ARG, "pair_off[0] must be 0");
   for (int64_t q = 0; q < n_queries; ++q)
     if (pair_off[q + 1] < pair_off[q]) return fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
@@ -2733,7 +2803,16 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   if (out_interp && !sparse) return fail(FFX_BAD_ARG, "no sparse scores were set: nothing to interpolate");
   if (out_order && !(flags & FFX_FLAG_SORT)) return fail(FFX_BAD_ARG, "out_order needs FFX_FLAG_SORT");
   if (mode < FFX_MODE_PASSAGE || mode > FFX_MODE_AVEP) return fail(FFX_BAD_ARG, "unknown mode %d", mode);
-  if (n_queries <= INT32_MAX - 1 && !ranked) {  // small batches of single-row candidates: one submission, one wait
+  if (given && (idx->kept_pairs != P || idx->kept_queries != n_queries || idx->kept_off_hash != offsets_hash(pair_off, n_queries)))
+    return fail(FFX_BAD_ARG, "these are not the candidate lists whose dense scores were kept");
+  if (keep == 1) {
+    FFX_HIP(hipSetDevice(idx->device));
+    idx->kept_pairs = idx->kept_queries = -1;  // nothing valid until this call has succeeded
+    idx->kept_token = 0;
+    FFX_TRY(idx->kept_dense.ensure(std::max<size_t>((size_t)P, 1) * 4));
+    if (carry) FFX_TRY(idx->kept_carry.ensure(std::max<size_t>((size_t)P, 1) * 4));
+  }
+  if (n_queries <= INT32_MAX - 1 && !ranked && keep == 0) {  // small batches of single-row candidates: one submission, one wait
     bool handled = false;
     const int rc_small = score_small(idx, host_queries, n_queries, pair_off, pair_ids, sparse, mode, alpha, flags, out_ff, out_interp, out_order,
                                      bad_pair, stats, &handled);
@@ -2744,7 +2823,8 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   int64_t per_slice = 6 << 20;
   {
     hipPointerAttribute_t attr;
-    if (pair_ids && hipPointerGetAttributes(&attr, pair_ids) == hipSuccess && attr.type == hipMemoryTypeHost)
+    const void* in = given ? (const void*)sparse : (const void*)pair_ids;
+    if (in && hipPointerGetAttributes(&attr, in) == hipSuccess && attr.type == hipMemoryTypeHost)
       per_slice = 4 << 20;
     else
       (void)hipGetLastError();  // an ordinary pointer is "invalid value" to the runtime: not an error here
@@ -2908,7 +2988,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
       if (threaded_out && c >= n_plans) FFX_TRY(join_fetch(c - n_plans));
       const double t0b = us();
       pl->stream = home[c % n_plans];
-      FFX_TRY(ffx_plan_set_queries(pl, host_queries ? host_queries + (size_t)q0 * idx->qdim : nullptr, q1 - q0));
+      if (!given) FFX_TRY(ffx_plan_set_queries(pl, host_queries ? host_queries + (size_t)q0 * idx->qdim : nullptr, q1 - q0));
       const double t1 = us();
       off.resize((size_t)(q1 - q0 + 1));
       for (int64_t q = q0; q <= q1; ++q) off[(size_t)(q - q0)] = pair_off[q] - p0;
@@ -2923,10 +3003,11 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
         }
       }
       pl->want_ranked = ranked;
-      pl->have_carry = carry != nullptr;
+      pl->have_carry = carry != nullptr || (given && idx->kept_has_carry);
       int64_t bad = -1;
-      const int rc = ffx_plan_set_pairs(pl, off.data(), q1 - q0, pair_ids ? pair_ids + p0 : nullptr,
-                                        sparse ? sparse + p0 : nullptr, mode, &bad);
+      const int rc = given ? plan_set_given(pl, off.data(), q1 - q0, sparse ? sparse + p0 : nullptr, idx->kept_dense.as<float>() + p0,
+                                            idx->kept_has_carry ? idx->kept_carry.as<int32_t>() + p0 : nullptr)
+                           : ffx_plan_set_pairs(pl, off.data(), q1 - q0, pair_ids ? pair_ids + p0 : nullptr, sparse ? sparse + p0 : nullptr, mode, &bad);
       if (rc != FFX_OK) {
         if (bad_pair && bad >= 0) *bad_pair = p0 + bad;
         return rc;
@@ -2935,6 +3016,11 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
       if (async_out || threaded_out) pl->stream = idx->score_stream;
       const int rc_run = ffx_plan_run(pl, alpha, flags);
       pl->want_ranked = false;
+      if (rc_run == FFX_OK && keep == 1 && pl->n_pairs > 0) {  // behind the slice's kernels, on their stream
+        FFX_HIP(hipMemcpyAsync(idx->kept_dense.as<float>() + p0, pl->ff.p, (size_t)pl->n_pairs * 4, hipMemcpyDeviceToDevice, pl->stream));
+        if (carry) FFX_HIP(hipMemcpyAsync(idx->kept_carry.as<int32_t>() + p0, pl->carry.p, (size_t)pl->n_pairs * 4, hipMemcpyDeviceToDevice, pl->stream));
+        FFX_HIP(hipEventRecord(pl->ev[4], pl->stream));  // "the slice is done" now includes these copies: the plan is not re-used under them
+      }
       pl->stream = home[c % n_plans];
       if (rc_run != FFX_OK) return rc_run;
       const double t3 = us();
@@ -2980,6 +3066,15 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
     g_last_error = keep;
     return rc;
   }
+  if (keep == 1) {  // the copies into the kept blocks ran behind the slices' kernels: done before anybody reads them
+    for (int i = 0; i < n_plans; ++i) FFX_HIP(hipStreamSynchronize(home[i]));
+    if (idx->score_stream) FFX_HIP(hipStreamSynchronize(idx->score_stream));
+    idx->kept_pairs = P;
+    idx->kept_queries = n_queries;
+    idx->kept_has_carry = carry != nullptr;
+    idx->kept_off_hash = offsets_hash(pair_off, n_queries);
+    idx->kept_token = ++g_kept_tokens;
+  }
   if (stats) *stats = acc;
   return FFX_OK;
 }
@@ -2995,8 +3090,80 @@ int ffx_score_ranked(ffx_index* idx, const float* host_queries, int64_t n_querie
                      const float* sparse, const int32_t* carry, int mode, double alpha, uint32_t flags, float* out_scores, int32_t* out_carry,
                      int32_t* out_order, int64_t* bad_pair, ffx_stats* stats) {
   if (!out_scores) return fail(FFX_BAD_ARG, "out_scores is NULL");
-  return score_impl(idx, host_queries, n_queries, pair_off, pair_ids, sparse, carry, mode, alpha, flags | FFX_FLAG_SORT, nullptr, nullptr, out_order, out_scores,
-                    out_carry, bad_pair, stats);
+  return score_impl(idx, host_queries, n_queries, pair_off, pair_ids, sparse, carry, mode, alpha, (flags & ~FFX_FLAG_KEEP_DENSE) | FFX_FLAG_SORT, nullptr, nullptr,
+                    out_order, out_scores, out_carry, bad_pair, stats, (flags & FFX_FLAG_KEEP_DENSE) ? 1 : 0);
+}
+
+// What the first ffx_score / ffx_score_ranked call of an index would allocate on the way -- the three plans with their
+// page-locked staging blocks, the kernel and result streams, every device buffer of a full slice -- made now, so that a
+// caller with something else to do first (Index.rerank looks the ranking's ids up: host work) has it done beside that, on
+// another thread.  Sizes follow ffx_score's slicing (uniform candidate lists assumed; anything that turns out too small
+// simply grows in the call).  Not to be called while another thread uses the index.
+int ffx_index_prepare_score(ffx_index* idx, int64_t n_queries, int64_t n_pairs, int32_t has_sparse, int32_t ranked, int32_t page_locked_buffers) {
+  if (!idx || n_queries < 0 || n_pairs < 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (n_pairs == 0 || n_queries == 0) return FFX_OK;
+  FFX_HIP(hipSetDevice(idx->device));
+  const int64_t per_slice = page_locked_buffers ? (4 << 20) : (6 << 20);
+  const int64_t per_query = (n_pairs + n_queries - 1) / n_queries;
+  const bool sliced = n_pairs > per_slice + per_query;
+  const int64_t Ps = sliced ? per_slice + 2 * per_query : n_pairs;
+  const int64_t Qs = std::min<int64_t>(n_queries, Ps / std::max<int64_t>(per_query, 1) + 2);
+  const int n_plans = sliced ? 3 : 1;
+  if (sliced && page_locked_buffers && !idx->out_stream) {
+    int least = 0, greatest = 0;
+    FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
+    for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  for (int i = 0; i < n_plans; ++i)
+    if (!idx->score_plans[i]) FFX_TRY(plan_create(idx, &idx->score_plans[i], i == 0));
+  if (sliced && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
+  const size_t pb = (size_t)Ps * 4;
+  for (int i = 0; i < n_plans; ++i) {
+    ffx_plan* pl = idx->score_plans[i];
+    pl->hstage_used = 0;
+    (void)pl->stage(16);  // the page-locked staging block of the plan
+    pl->hstage_used = 0;
+    FFX_TRY(pl->queries.ensure((size_t)Qs * idx->qdim * sizeof(float)));
+    FFX_TRY(pl->pair_off.ensure((size_t)(Qs + 1) * sizeof(int64_t)));
+    for (DevBuf* b : {&pl->pair_ids, &pl->ff, &pl->order, &pl->iota}) FFX_TRY(b->ensure(pb));
+    FFX_TRY(pl->cnt.ensure(pb + 4));
+    FFX_TRY(pl->seg_off.ensure(pb + 4));
+    FFX_TRY(pl->desc.ensure(2 * pb));
+    if (has_sparse) {
+      FFX_TRY(pl->sparse.ensure(pb));
+      FFX_TRY(pl->interp.ensure(pb));
+    }
+    if (ranked)
+      for (DevBuf* b : {&pl->carry, &pl->ranked, &pl->carry_ranked}) FFX_TRY(b->ensure(pb));
+  }
+  return FFX_OK;
+}
+
+int ffx_index_kept(ffx_index* idx, uint64_t* token, int64_t* n_queries, int64_t* n_pairs) {
+  if (!idx) return fail(FFX_BAD_ARG, "NULL index");
+  if (token) *token = idx->kept_pairs >= 0 ? idx->kept_token : 0;
+  if (n_queries) *n_queries = idx->kept_queries;
+  if (n_pairs) *n_pairs = idx->kept_pairs;
+  return FFX_OK;
+}
+
+int ffx_index_drop_kept(ffx_index* idx) {
+  if (!idx) return fail(FFX_BAD_ARG, "NULL index");
+  FFX_HIP(hipSetDevice(idx->device));
+  idx->kept_pairs = idx->kept_queries = -1;
+  idx->kept_token = 0;
+  idx->kept_dense.release();
+  idx->kept_carry.release();
+  return FFX_OK;
+}
+
+int ffx_rank_kept(ffx_index* idx, uint64_t token, int64_t n_queries, const int64_t* pair_off, const float* sparse, double alpha, uint32_t flags,
+                  float* out_scores, int32_t* out_carry, int32_t* out_order, ffx_stats* stats) {
+  if (!idx || !out_scores) return fail(FFX_BAD_ARG, "bad argument");
+  if (token == 0 || idx->kept_pairs < 0 || token != idx->kept_token) return fail(FFX_BAD_ARG, "no dense scores are kept under this token");
+  return score_impl(idx, nullptr, n_queries, pair_off, nullptr, sparse, nullptr, FFX_MODE_PASSAGE, alpha, (flags & ~FFX_FLAG_KEEP_DENSE) | FFX_FLAG_SORT, nullptr,
+                    nullptr, out_order, out_scores, out_carry, nullptr, stats, 2);
 }
 
 // ---- page-locked host memory ------------------------------------------------------------------

@@ -66,11 +66,14 @@ class _Run:
     routes see, and ``result`` is the one way back: a coded ``Ranking`` (its frame of strings is built if and when
     somebody asks for it)."""
 
-    def __init__(self, index: "Index", ranking: Ranking):
+    def __init__(self, index: "Index", ranking: Ranking, encode: bool = True):
         self.ranking = ranking
         self.q_no, self.q_order, self.texts = index._numbered_queries(ranking)
         self.n_q = len(self.q_order)
-        self.query_vectors = np.ascontiguousarray(index.encode_queries(self.texts)) if self.n_q else np.zeros((0, index.dim or 0), dtype=np.float32)
+        if not encode:  # (a route that reads no query vector: Index._interpolate_kept)
+            self.query_vectors = None
+        else:
+            self.query_vectors = np.ascontiguousarray(index.encode_queries(self.texts)) if self.n_q else np.zeros((0, index.dim or 0), dtype=np.float32)
         self.perm, self.pair_off = ranking._csr() if len(self.q_no) else (None, np.zeros(self.n_q + 1, dtype=np.int64))
         self.codes, self.names = ranking._id_coding()
 
@@ -395,16 +398,25 @@ class Index(abc.ABC):
         off = run.pair_off
         kept_parts, score_parts = [], []
         if early_stopping is None:
-            ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
             whole = len(run.batches(batch_size)) == 1
-            if whole and hasattr(self, "_score_ranked") and len(ordinals) >= self._RANKED_FROM:
+            n_rows = len(run.q_no)
+            ranked = whole and hasattr(self, "_score_ranked") and n_rows >= self._RANKED_FROM
+            warm = self._warm_up(run.n_q, n_rows, False, [(n_rows, np.float32), (n_rows, np.int32), (n_rows, np.int32)]) if ranked else None
+            ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
+            if warm is not None:
+                warm.join()
+            if ranked:
                 # the device lays the run out in its final order, the ranking's id codes permuted along: nothing is gathered here
-                scores, codes, kept = self._score_ranked(run.query_vectors, off, ordinals, self.mode, None, None, run.grouped(run.codes), want_order=True)
+                # ... and the dense scores stay in HBM beside the codes (8 bytes per candidate): the `ranking.interpolate(result,
+                # alpha)` that usually follows is then the interpolation and the ordering alone (_interpolate_kept)
+                keeps = hasattr(self, "_rank_kept")
+                scores, codes, kept = self._score_ranked(run.query_vectors, off, ordinals, self.mode, None, None, run.grouped(run.codes), want_order=True,
+                                                         **({"keep": True} if keeps else {}))
                 out, _ = run.result("fast-forward", kept, scores, off, codes=codes)
                 LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
                 src = kept if run.perm is None else run.perm[kept]
                 out._source_rows = (weakref.ref(ranking), src)
-                out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None))
+                out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None), self._kept_token() if keeps else 0)
                 return out
             for qa, qb in run.batches(batch_size):
                 pa, pb = int(off[qa]), int(off[qb])
@@ -444,6 +456,14 @@ class Index(abc.ABC):
         return out
 
     _RANKED_FROM = 1 << 18  # candidates from which the device applies the ordering itself (ffx_score_ranked)
+
+    def _warm_up(self, n_queries: int, n_rows: int, has_sparse: bool, result_blocks: list):
+        """A helper thread that gets ready what a large device call will need while this thread resolves the ranking's ids
+        (host work): the page-locked blocks of the result pool the result will live in; a resident index adds its own
+        device-side preparation.  ``join`` it before the device call."""
+        from fast_forward_amd import native
+
+        return native.reserve_pooled(result_blocks)
 
     def _ordinals_of_codes(self, ranking: Ranking, codes: np.ndarray, names: np.ndarray, missing_ok: bool = False) -> np.ndarray:
         """Index ordinals of a ranking's rows through its id codes: the DISTINCT id strings are looked
@@ -497,7 +517,7 @@ class Index(abc.ABC):
         n_rows = len(ranking._q_no)
         ranked = hasattr(self, "_score_ranked") and n_rows >= self._RANKED_FROM
         # the blocks the result will live in are page-locked (once) while the queries are encoded and the ids looked up
-        warm = native.reserve_pooled([(n_rows, np.float32), (n_rows, np.int32)]) if ranked else None
+        warm = self._warm_up(len(ranking._q_order), n_rows, True, [(n_rows, np.float32), (n_rows, np.int32)]) if ranked else None
         run = _Run(self, ranking)
         t.append(perf_counter())
         ordinals = run.grouped(self._ordinals_of_codes(ranking, run.codes, run.names))
@@ -532,6 +552,23 @@ class Index(abc.ABC):
             names = ("queries_numbered_and_encoded_s", "ids_to_ordinals_s", "upload_device_download_s", "result_gathers_s")
         # where a call's time went (seconds): a first call on a ranking pays for the distinct-id look-up, later ones do not
         self.last_timings = dict(zip(names, np.diff(t).tolist()), total_s=t[-1] - t[0], **getattr(self, "_last_lookup_timings", {}))
+        return out
+
+    def _interpolate_kept(self, ranking, token: int, alpha: float):
+        """``ranking.interpolate(self(ranking), alpha)`` when the device still keeps the dense scores of that
+        ``self(ranking)`` under ``token`` (and the ranking's id codes beside them): the first-stage scores go up, the
+        interpolation (ranking.py:319) and the per-query ordering (ranking.py:115-117) run on the device, interpolated
+        scores and codes come back in final order.  No query is encoded, no row of the index is read; the bits are
+        ``rerank``'s.  The ranking's rows must stand grouped by query (they do: the caller checked)."""
+        t = [perf_counter()]
+        run = _Run(self, ranking, encode=False)
+        sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
+        t.append(perf_counter())
+        scores, codes = self._rank_kept(token, run.pair_off, sparse, alpha)
+        t.append(perf_counter())
+        out, _ = run.result(ranking.name, None, scores, run.pair_off, codes=codes)
+        t.append(perf_counter())
+        self.last_timings = dict(zip(("queries_numbered_s", "upload_device_download_s", "result_assembled_s"), np.diff(t).tolist()), total_s=t[-1] - t[0])
         return out
 
     def rerank_file(self, run_in, run_out, alpha: float, queries, cutoff: int | None = None, name: str | None = None) -> dict:

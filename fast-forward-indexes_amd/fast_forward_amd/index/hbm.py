@@ -258,9 +258,10 @@ class InMemoryIndex(Index):
         self.last_stats = plan.stats()
         return ff, interp, order
 
-    def _score_ranked(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse, alpha, carry, want_order: bool = False):
+    def _score_ranked(self, query_vectors, pair_off, pair_ids, mode: Mode, sparse, alpha, carry, want_order: bool = False, keep: bool = False):
         """The run in final order straight off the device (``ffx_score_ranked``): (scores, carried codes, order | None).
-        Scores are the interpolated ones when ``sparse`` is given, else the dense ones."""
+        Scores are the interpolated ones when ``sparse`` is given, else the dense ones.  ``keep``: the dense scores and the
+        carried codes stay in HBM (8 bytes per candidate) for a ``Ranking.interpolate`` that follows (``_rank_kept``)."""
         if self._store is None:
             raise IndexError("the index is empty")
         q = np.ascontiguousarray(query_vectors, dtype=np.float32)
@@ -270,10 +271,30 @@ class InMemoryIndex(Index):
             q = np.ascontiguousarray(q @ self._rotation, dtype=np.float32)
         self._sync_ids()
         scores, codes, order, self.last_stats = native.score_ranked(self._store, q, pair_off, pair_ids, mode.value, sparse, 0.0 if alpha is None else alpha,
-                                                                    carry=carry, exact_sum=self.exact_sum, want_order=want_order)
+                                                                    carry=carry, exact_sum=self.exact_sum, want_order=want_order, keep=keep)
         return scores, codes, order
 
+    def _kept_token(self) -> int:
+        """Token of the dense scores the device keeps from the last ``__call__`` (0: none)."""
+        return 0 if self._store is None else native.kept_token(self._store)
+
+    def _rank_kept(self, token: int, pair_off, sparse, alpha: float):
+        """``ffx_rank_kept``: (interpolated scores, id codes) in final order from the dense scores kept under ``token``."""
+        scores, codes, _, self.last_stats = native.rank_kept(self._store, token, pair_off, sparse, alpha)
+        return scores, codes
+
     _PIPELINED_FROM = 6 << 20  # pairs: below this ffx_score would run a single slice anyway
+
+    def _warm_up(self, n_queries: int, n_rows: int, has_sparse: bool, result_blocks: list):
+        """Beside the id look-up of a first call, on the helper thread: the id structure goes to the device if it is not
+        there yet (``_sync_ids``: 0.1 s for 8.8 M documents), the plans / streams / device buffers ``ffx_score_ranked`` would
+        otherwise allocate on its way are made (``ffx_index_prepare_score``), then the result blocks are page-locked."""
+        def device_side():
+            if self._store is not None:
+                self._sync_ids()
+                self._store.prepare_score(n_queries, n_rows, has_sparse, True, False)
+
+        return native.reserve_pooled(result_blocks, first=device_side)
 
     def _early_stopping_kept(self, id_at, sparse, pair_off, query_vectors, cutoff: int, alpha: float, depths, ordinals):
         """Early stopping (base.py:316-387) resident on the device (``ffx_plan_early_stopping``): the active mask, the

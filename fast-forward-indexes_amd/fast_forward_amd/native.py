@@ -15,7 +15,7 @@ import numpy as np
 LIB_PATH = Path(__file__).resolve().parent / "libffx.so"
 
 OK, BAD_ARG, OOM, HIP_ERROR, RCCL_ERROR, NOT_FOUND, NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
-FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF, FLAG_ES_BOUND_F32 = 1, 2, 4, 8
+FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF, FLAG_ES_BOUND_F32, FLAG_KEEP_DENSE = 1, 2, 4, 8, 16
 TOKEN_INT, TOKEN_NUMBER, TOKEN_NA, TOKEN_TEXT = 1, 2, 4, 8
 RUN_SHORT_LINE, RUN_LONG_LINE, RUN_QUOTES = 1, 2, 4
 BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 3, 4, 5
@@ -33,12 +33,13 @@ SYMBOLS = (
     "ffx_sharded_set_pairs_held", "ffx_sharded_stage_owned", "ffx_sharded_set_code_table", "ffx_sharded_stage_queries", "ffx_sharded_run", "ffx_sharded_fetch_async",
     "ffx_sharded_score", "ffx_sharded_sync", "ffx_sharded_fetch", "ffx_sharded_owned", "ffx_sharded_stats", "ffx_sharded_device_ptr",
     "ffx_aggregate", "ffx_ids_create", "ffx_ids_destroy", "ffx_ids_count", "ffx_ids_intern", "ffx_ids_lookup", "ffx_ids_get", "ffx_run_open",
-    "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_score", "ffx_score_ranked",
+    "ffx_run_close", "ffx_run_counts", "ffx_run_query_id", "ffx_run_tag", "ffx_run_export", "ffx_run_write", "ffx_score", "ffx_score_ranked", "ffx_index_kept", "ffx_index_drop_kept", "ffx_rank_kept",
     "ffx_host_alloc", "ffx_host_free", "ffx_host_pin", "ffx_host_unpin",
 )
 # ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
 PRIVATE_SYMBOLS = (
     "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
+    "ffx_index_prepare_score",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_buffer_free",
@@ -142,6 +143,7 @@ def lib() -> C.CDLL:
         "ffx_index_upload_rows": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_upload_rows_async": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_pull_rows_async": ([vp, vp, i64, i64, vp, i64, i64], C.c_int),
+        "ffx_index_prepare_score": ([vp, i64, i64, C.c_int32, C.c_int32, C.c_int32], C.c_int),
         "ffx_index_upload_after": ([vp, vp], C.c_int),
         "ffx_index_upload_wait": ([vp], C.c_int),
         "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
@@ -203,6 +205,9 @@ def lib() -> C.CDLL:
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
         "ffx_score_ranked": ([vp, vp, i64, vp, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
+        "ffx_index_kept": ([vp, P(C.c_uint64), P(i64), P(i64)], C.c_int),
+        "ffx_index_drop_kept": ([vp], C.c_int),
+        "ffx_rank_kept": ([vp, C.c_uint64, i64, vp, vp, C.c_double, C.c_uint32, vp, vp, vp, P(Stats)], C.c_int),
         "ffx_host_alloc": ([C.c_size_t, P(vp)], C.c_int),
         "ffx_host_free": ([vp], C.c_int),
         "ffx_host_pin": ([vp, C.c_size_t], C.c_int),
@@ -424,6 +429,10 @@ class DeviceIndex:
     def set_doc_rows(self, doc_off, doc_rows) -> None:
         doc_off, doc_rows = _arr(doc_off, np.int64), _arr(doc_rows, np.int32)
         _check(lib().ffx_index_set_doc_rows(self._h, _ptr(doc_off), doc_off.shape[0] - 1, _ptr(doc_rows), doc_rows.shape[0]))
+
+    def prepare_score(self, n_queries: int, n_pairs: int, has_sparse: bool, ranked: bool, page_locked_buffers: bool) -> None:
+        """``ffx_index_prepare_score``: the first ``score`` / ``score_ranked`` call's allocations, made now."""
+        _check(lib().ffx_index_prepare_score(self._h, int(n_queries), int(n_pairs), int(bool(has_sparse)), int(bool(ranked)), int(bool(page_locked_buffers))))
 
     def set_psg_rows(self, psg_row) -> None:
         psg_row = _arr(psg_row, np.int32)
@@ -690,10 +699,12 @@ def pooled_empty(n: int, dtype) -> np.ndarray:
     return np.frombuffer(owner, dtype=dtype, count=n)
 
 
-def reserve_pooled(requests) -> "object":
+def reserve_pooled(requests, first=None) -> "object":
     """Make sure the pool can serve ``requests`` (``[(n, dtype), ...]``) without page-locking anything, on a helper thread:
     page-locking 2 x 140 MB takes ~0.1 s of driver time that a first call can spend looking its ids up instead.  Returns the
-    thread (``join`` it before the blocks are needed); blocks that exist already are left alone."""
+    thread (``join`` it before the blocks are needed); blocks that exist already are left alone.  ``first``: something else
+    for that thread to do before (an index brings its device-side state up to date: ``InMemoryIndex._warm_up``); whatever
+    it raises is dropped -- the caller's own thread does the same work again where it needs it, and reports."""
     import threading
 
     lib()
@@ -704,6 +715,11 @@ def reserve_pooled(requests) -> "object":
     todo = [cap for cap, k in need.items() for _ in range(max(0, k - len(_POOL.get(cap, ()))))]
 
     def work():
+        if first is not None:
+            try:
+                first()
+            except Exception:  # noqa: BLE001
+                pass
         for cap in todo:
             p = C.c_void_p()
             if _lib.ffx_host_alloc(cap, C.byref(p)) == OK:
@@ -817,24 +833,48 @@ def score(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=Non
 
 
 def score_ranked(index: DeviceIndex, queries, pair_off, pair_ids, mode: int, sparse=None, alpha: float = 0.0, carry=None,
-                 exact_sum: bool = True, want_order: bool = False, sort_ff: bool = False):
+                 exact_sum: bool = True, want_order: bool = False, sort_ff: bool = False, keep: bool = False, pool: bool = True):
     """``ffx_score_ranked``: the run in FINAL order -- (scores, carried words | None, order | None, stats), the scores
     being the interpolated ones when ``sparse`` is given, else the dense ones; ``carry``: one int32 per candidate that is
-    permuted along (a ranking's id codes).  Large results land in blocks of the page-locked result pool."""
+    permuted along (a ranking's id codes).  Large results land in blocks of the page-locked result pool.  ``keep``: the
+    dense scores and the carried words stay in HBM with the index (``FFX_FLAG_KEEP_DENSE``; ``kept_token`` / ``rank_kept``)."""
     queries = _arr(queries, np.float32)
     pair_off, pair_ids = _arr(pair_off, np.int64), _arr(pair_ids, np.int32)
     sp = None if sparse is None else _arr(sparse, np.float32)
     ca = None if carry is None else _arr(carry, np.int32)
     n = int(pair_off[-1])
-    make = pooled_empty if n >= (1 << 18) else (lambda m, dt: np.empty(m, dtype=dt))
+    make = pooled_empty if (pool and n >= (1 << 18)) else (lambda m, dt: np.empty(m, dtype=dt))
     scores = make(n, np.float32)
     out_carry = None if ca is None else make(n, np.int32)
     order = make(n, np.int32) if want_order else None
     bad, st = C.c_int64(-1), Stats()
-    flags = (FLAG_EXACT_SUM if exact_sum else 0) | FLAG_SORT | (FLAG_SORT_FF if sort_ff else 0)
+    flags = (FLAG_EXACT_SUM if exact_sum else 0) | FLAG_SORT | (FLAG_SORT_FF if sort_ff else 0) | (FLAG_KEEP_DENSE if keep else 0)
     rc = lib().ffx_score_ranked(index._h, _ptr(queries), queries.shape[0], _ptr(pair_off), _ptr(pair_ids), _ptr(sp), _ptr(ca), int(mode), float(alpha), flags,
                                 _ptr(scores), _ptr(out_carry), _ptr(order), C.byref(bad), C.byref(st))
     _check(rc, bad.value)
+    return scores, out_carry, order, st.as_dict()
+
+
+def kept_token(index: DeviceIndex) -> int:
+    """``ffx_index_kept``: the token of the dense scores the index keeps (0: none)."""
+    tok = C.c_uint64(0)
+    _check(lib().ffx_index_kept(index._h, C.byref(tok), None, None))
+    return int(tok.value)
+
+
+def rank_kept(index: DeviceIndex, token: int, pair_off, sparse, alpha: float, want_carry: bool = True, want_order: bool = False):
+    """``ffx_rank_kept``: (scores, carried words | None, order | None, stats) as ``score_ranked`` would return them for the
+    candidate lists whose dense scores the index keeps under ``token`` -- interpolation and ordering only."""
+    pair_off = _arr(pair_off, np.int64)
+    sp = None if sparse is None else _arr(sparse, np.float32)
+    n = int(pair_off[-1])
+    make = pooled_empty if n >= (1 << 18) else (lambda m, dt: np.empty(m, dtype=dt))
+    scores = make(n, np.float32)
+    out_carry = make(n, np.int32) if want_carry else None
+    order = make(n, np.int32) if want_order else None
+    st = Stats()
+    _check(lib().ffx_rank_kept(index._h, int(token), pair_off.shape[0] - 1, _ptr(pair_off), _ptr(sp), float(alpha), FLAG_SORT, _ptr(scores), _ptr(out_carry),
+                               _ptr(order), C.byref(st)))
     return scores, out_carry, order, st.as_dict()
 
 

@@ -333,8 +333,10 @@ class Ranking:
         starts = np.concatenate([[0], np.flatnonzero(codes[1:] != codes[:-1]) + 1]) if len(codes) else np.zeros(0, dtype=np.int64)
         if len(codes) and np.unique(codes[starts]).shape[0] == starts.shape[0]:
             firsts = codes[starts]  # rows of a query adjacent: the numbers follow the blocks
-            q_no = np.repeat(np.arange(len(starts), dtype=np.int64), np.diff(np.concatenate([starts, [len(codes)]])))
+            block_off = np.concatenate([starts, [len(codes)]]).astype(np.int64)
+            q_no = np.repeat(np.arange(len(starts), dtype=np.int64), np.diff(block_off))
         else:
+            block_off = None
             q_no, firsts = pd.factorize(codes)
             q_no = q_no.astype(np.int64, copy=False)
         q_order = [q_names[i] for i in firsts]
@@ -350,6 +352,8 @@ class Ranking:
                        "score": score, "q_texts": q_texts, "id_blob": id_blob}
         self._q_no, self._q_order = q_no, q_order
         self._q_ids = set(q_order)
+        if block_off is not None:  # the CSR by query an index asks for (_csr) is known already: no pass over the rows later
+            self._csr_cache = (q_no, None, block_off)
         return True
 
     @classmethod
@@ -597,13 +601,17 @@ class Ranking:
             native.lib()
         except (ImportError, OSError):
             return None
-        # A large run whose dense scores came from an index that is still there, unchanged: the device does the whole of it
-        # again -- gather, interpolation with THIS alpha, ordering, final layout -- faster than the host orders 35 M scores
-        # (Index.rerank; same bits, pinned by test_rerank_equals_call_then_interpolate).
+        # A large run whose dense scores came from an index that is still there, unchanged: the device interpolates with THIS
+        # alpha and orders -- from the dense scores it kept in HBM when it made them (Index._interpolate_kept), or, once
+        # another call has displaced those, by doing the whole of it again (Index.rerank) -- faster than the host orders
+        # 35 M scores; same bits either way, pinned by test_rerank_equals_call_then_interpolate.
         origin = getattr(other, "_origin", None)
         index = origin[0]() if origin is not None else None
         if (index is not None and isinstance(alpha, (int, float)) and len(mine) >= (1 << 20) and self.has_queries and origin[1] == index.mode
                 and origin[2] == getattr(getattr(index, "_ids", None), "version", None) and hasattr(index, "_score_ranked")):
+            token = origin[3] if len(origin) > 3 else 0
+            if token and index._kept_token() == token:  # the dense scores of that very call are still in HBM: no second gather
+                return index._interpolate_kept(self, token, alpha)
             return index.rerank(self, alpha)
         if isinstance(alpha, (int, float)) and len(mine) >= (1 << 18) and link[1].dtype == np.int32:
             # one threaded pass: scatter back + `alpha * mine + (1 - alpha) * dense` in float32, as below

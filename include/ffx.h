@@ -73,6 +73,9 @@ extern "C" {
  * computes under its pinned numpy>=1.24,<2 (pyproject.toml:16).  The two differ when a decision sits within float32
  * rounding of the bound (always, e.g., at cut-off 1 after a first depth of 1). */
 #define FFX_FLAG_ES_BOUND_F32 8u
+/* ffx_score_ranked only: the dense scores of the call (in the caller's candidate order) and the carried words stay in HBM with
+ * the index (8 bytes per candidate) until the next such call, ffx_index_drop_kept or ffx_index_destroy: ffx_rank_kept. */
+#define FFX_FLAG_KEEP_DENSE 16u
 
 /* ffx_plan_device_ptr selectors */
 #define FFX_BUF_FF 0       /* float[P]   aggregated dense scores                         */
@@ -406,6 +409,18 @@ int ffx_score(ffx_index* idx, const float* host_queries, int64_t n_queries,
 int ffx_score_ranked(ffx_index* idx, const float* host_queries, int64_t n_queries, const int64_t* pair_off,
                      const int32_t* pair_ids, const float* sparse, const int32_t* carry, int mode, double alpha, uint32_t flags,
                      float* out_scores, int32_t* out_carry, int32_t* out_order, int64_t* bad_pair, ffx_stats* stats);
+
+/* Ranking.interpolate on the result of Index.__call__ (ranking.py:293-326 after index/base.py:389-469) without scoring twice:
+ * a call of ffx_score_ranked with FFX_FLAG_KEEP_DENSE leaves its dense scores in HBM; ffx_index_kept says under which token
+ * (0: nothing is kept) and for how many queries / candidates; ffx_rank_kept then produces, for the SAME candidate lists
+ * (pair_off must be the one of the keeping call: checked) and any first-stage scores and alpha, what ffx_score_ranked with those
+ * arguments would -- interpolated scores and carried words in final order, out_order optional -- by the interpolation and the
+ * ordering alone: no row of the index is read.  sparse may be NULL (the dense scores, ordered).  A token dies with the next
+ * keeping call on the index; rows uploaded in between do not change what is kept (the caller decides whether it still wants it). */
+int ffx_index_kept(ffx_index* idx, uint64_t* token, int64_t* n_queries, int64_t* n_pairs);
+int ffx_index_drop_kept(ffx_index* idx);
+int ffx_rank_kept(ffx_index* idx, uint64_t token, int64_t n_queries, const int64_t* pair_off, const float* sparse, double alpha,
+                  uint32_t flags, float* out_scores, int32_t* out_carry, int32_t* out_order, ffx_stats* stats);
 
 /* ---- page-locked host memory ------------------------------------------------------------
  * Host buffers handed to the calls above may live anywhere; when they are page-locked the

@@ -166,6 +166,13 @@ int ffx_host_segment_rows_unique(const int32_t* ids, int64_t n, const int32_t* e
 int ffx_host_outer_join(const int64_t* off_a, const int32_t* code_a, const int64_t* off_b, const int32_t* code_b, int64_t n_queries,
                         int32_t n_threads, int64_t* u_off, int32_t* u_code, int32_t* u_a, int32_t* u_b);
 
+/* The allocations the first ffx_score / ffx_score_ranked call of an index would make on the way (its three plans and their
+ * page-locked staging blocks, the kernel and result streams, the device buffers of a full slice), made now: a caller with
+ * host work to do before its first call (Index.rerank resolves the ranking's ids) runs this beside it on another thread.
+ * Sizes follow ffx_score's slicing for n_pairs candidates of n_queries queries; what turns out too small grows in the
+ * call.  Not while another thread uses the index. */
+int ffx_index_prepare_score(ffx_index* idx, int64_t n_queries, int64_t n_pairs, int32_t has_sparse, int32_t ranked, int32_t page_locked_buffers);
+
 #ifdef __cplusplus
 }
 #endif

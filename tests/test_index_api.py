@@ -736,6 +736,59 @@ def test_a_result_keeps_its_arrays_when_later_calls_reuse_the_result_pool():
     assert native.drain_result_pool() > 0 and native._POOL_IDLE[0] == 0
 
 
+def test_interpolate_after_call_starts_from_the_dense_scores_the_device_kept():
+    """``first.interpolate(index(first), alpha)`` -- the reference's documented pipeline (README; ranking.py:293-326 after
+    index/base.py:389-469) -- does not score twice: ``index(first)`` leaves its dense scores (and the ranking's id codes)
+    in HBM (FFX_FLAG_KEEP_DENSE) and the interpolate is the interpolation + ordering on the device alone (ffx_rank_kept).
+    Same Ranking as ``index.rerank`` for every alpha; MaxP over documents of 1 - 3 passages (the kept scores are the
+    aggregated ones); once another call has displaced the kept scores the interpolate scores again -- same result."""
+    from fast_forward_amd import native
+
+    rng = np.random.default_rng(11)
+    n_docs, d, n_q, k = 50_000, 48, 280, 4000
+    per_doc = rng.integers(1, 4, size=n_docs)
+    doc_of_row = np.repeat(np.arange(n_docs), per_doc)
+    rows = rng.standard_normal((len(doc_of_row), d)).astype(np.float32)
+    qv = rng.standard_normal((n_q, d)).astype(np.float32)
+    index = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=Mode.MAXP)
+    index.add(rows, doc_ids=[f"D{x}" for x in doc_of_row])
+
+    def run(seed):
+        r = np.random.default_rng(seed)
+        ids = np.concatenate([r.choice(n_docs, size=k, replace=False) for _ in range(n_q)])
+        frame = pd.DataFrame({"q_id": np.repeat([f"q{i:03d}" for i in range(n_q)], k), "id": [f"D{x}" for x in ids],
+                              "score": (r.random(n_q * k) * 20).astype(np.float32)})
+        return Ranking(frame, queries={f"q{i:03d}": str(i) for i in range(n_q)})
+
+    first, second = run(1), run(2)
+    dense = index(first)
+    token = index._kept_token()
+    assert token != 0 and dense._origin[3] == token
+    for alpha in (0.0, 0.2, 0.75, 1.0):
+        index.last_timings = None
+        got = first.interpolate(dense, alpha)
+        assert "queries_numbered_s" in index.last_timings  # the kept route (no query encoded, no row read)
+        assert index._kept_token() == token                 # ... which leaves the kept scores where they are
+        want = index.rerank(first, alpha)
+        assert got == want and np.array_equal(bits(got._coded["score"]), bits(want._coded["score"]))
+        assert np.array_equal(got._coded["id_codes"], want._coded["id_codes"])
+    # C ABI: the token is bound to the candidate lists, and goes with the next keeping call
+    off = np.arange(n_q + 1, dtype=np.int64) * k
+    with pytest.raises(native.FFXError):
+        native.rank_kept(index._store, token, off[:-1], None, 0.0)
+    dense_order, codes, order, _ = native.rank_kept(index._store, token, off, None, 0.0, want_order=True)  # no first-stage scores: dense, ordered
+    assert np.array_equal(bits(dense_order), bits(dense._coded["score"])) and np.array_equal(codes, dense._coded["id_codes"])
+    assert np.array_equal(order, dense._source_rows[1])
+    dense_second = index(second)
+    assert index._kept_token() not in (0, token)
+    with pytest.raises(native.FFXError):
+        native.rank_kept(index._store, token, off, None, 0.0)
+    index.last_timings = None
+    assert first.interpolate(dense, 0.2) == index.rerank(first, 0.2) and "ids_to_ordinals_s" in index.last_timings  # scored again
+    assert second.interpolate(dense_second, 0.2) == index.rerank(second, 0.2)
+    index.close()
+
+
 def test_early_stopping_on_a_large_run_edge_cases():
     """The coded early-stopping route (>= 4096 rows: id codes in, only the scored candidates back, a coded Ranking out)
     on the edges: depths all below the cutoff (nothing is scored: an empty ranking), an unknown id that IS reached
