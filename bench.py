@@ -1121,6 +1121,15 @@ def bench_single(args):
         # SURVEY 8(d)'s headline region, next to `value`: CSR in host memory -> scores + order in host memory (page-locked buffers)
         result["value_host_to_host"] = args.queries / (regions["ii_pinned_ms"] * 1e-3)
         result["value_host_to_host_over_value"] = result["value_host_to_host"] / result["value"]
+        # the public API against region (ii), warm: Index.rerank; Index.__call__ followed by Ranking.interpolate (the reference's
+        # two-call form) with the result pool warm (`again`) and as first measured (`first`: new result blocks are page-locked)
+        if "iii_rerank_again_s" in regions and int(regions.get("iii_pairs", 0)) == int(pair_off[-1]):
+            ii_s = regions["ii_pinned_ms"] * 1e-3
+            result["api_over_host_to_host"] = {
+                "rerank_warm": regions["iii_rerank_again_s"] / ii_s,
+                "call_then_interpolate_warm": (regions["iii_call_s"] + regions["iii_interpolate_again_s"]) / ii_s,
+                "call_then_interpolate_first": (regions["iii_call_s"] + regions["iii_interpolate_s"]) / ii_s,
+                "rerank_first_call_s": regions["iii_rerank_first_call_s"]}
     result["value_hbm_resident"] = result["value"]
     print(json.dumps(result), flush=True)
     if not ok:

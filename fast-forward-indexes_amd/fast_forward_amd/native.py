@@ -862,6 +862,11 @@ def kept_token(index: DeviceIndex) -> int:
     return int(tok.value)
 
 
+def drop_kept(index: DeviceIndex) -> None:
+    """``ffx_index_drop_kept``: release the dense scores the index keeps."""
+    _check(lib().ffx_index_drop_kept(index._h))
+
+
 def rank_kept(index: DeviceIndex, token: int, pair_off, sparse, alpha: float, want_carry: bool = True, want_order: bool = False):
     """``ffx_rank_kept``: (scores, carried words | None, order | None, stats) as ``score_ranked`` would return them for the
     candidate lists whose dense scores the index keeps under ``token`` -- interpolation and ordering only."""

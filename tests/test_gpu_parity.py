@@ -1161,6 +1161,104 @@ def test_pq_exact_adc_when_subspaces_are_numpy_leaves(d, m, ks):
     idx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("slice_pairs", [0, 1, 70, 400])
+def test_rank_kept_equals_score_ranked_against_the_oracle(monkeypatch, slice_pairs):
+    """FFX_FLAG_KEEP_DENSE + ffx_rank_kept (Ranking.interpolate on an Index.__call__ result, ranking.py:293-326 after
+    index/base.py:389-469): the keeping call returns what it returns without the flag; ffx_rank_kept then gives, for any
+    first-stage scores and alpha, the bits of a full ffx_score_ranked -- and of the oracle: interpolated scores in final
+    order, the carried words permuted along, the order itself.  Ragged batch with empty queries, every mode over
+    multi-passage documents, one slice and many, ordinary and page-locked result buffers; the token is bound to the
+    candidate lists and dies with the next keeping call or ffx_index_drop_kept."""
+    d, n = 768, 900
+    vectors = synth.rows(21, 0.05, 0, n, d)
+    queries = synth.rows(22, 0.05, 0, 9, d)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    rng = np.random.default_rng(5)
+    per_doc = rng.integers(1, 4, size=300)
+    doc_off = np.concatenate([[0], np.cumsum(per_doc)])
+    doc_rows = rng.permutation(n)[: doc_off[-1]]
+    idx.set_doc_rows(doc_off, doc_rows)
+    idx.set_psg_rows(np.arange(n))
+    lens = [120, 0, 1, 77, 300, 0, 0, 250, 33]
+    pair_off = np.concatenate([[0], np.cumsum(lens)])
+    pair_ids = np.concatenate([rng.choice(300, size=k, replace=False) for k in lens]).astype(np.int32)
+    carry = rng.integers(0, 1 << 30, size=len(pair_ids)).astype(np.int32)
+    if slice_pairs:
+        monkeypatch.setenv("FFX_DEBUG_VARIANT", f"score_slice_pairs={slice_pairs},no_small_path")
+    assert native.kept_token(idx) == 0
+    with pytest.raises(native.FFXError):
+        native.rank_kept(idx, 1, pair_off, None, 0.0)
+    last = 0
+    for mode in (1, 2, 3, 4):
+        ids = pair_ids if mode != 1 else rng.integers(0, n, size=len(pair_ids)).astype(np.int32)
+        want_ff, _ = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, ids, mode)
+        dense_order = fo.order(want_ff, pair_off)
+        plain = native.score_ranked(idx, queries, pair_off, ids, mode, None, 0.0, carry=carry, want_order=True)
+        kept = native.score_ranked(idx, queries, pair_off, ids, mode, None, 0.0, carry=carry, want_order=True, keep=True)
+        for a, b in zip(plain[:3], kept[:3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(bits(kept[0]), bits(want_ff[dense_order])) and np.array_equal(kept[2].astype(np.int64), dense_order)
+        token = native.kept_token(idx)
+        assert token not in (0, last)
+        last = token
+        for alpha in (0.0, 0.3, 1.0):
+            sparse = rng.random(len(ids), dtype=np.float32) * 20
+            want_in = fo.interpolate(sparse, want_ff, alpha)
+            want_or = fo.order(want_in, pair_off)
+            for pool in (True, False):
+                scores, codes, order, _ = native.rank_kept(idx, token, pair_off, sparse, alpha, want_order=True) if pool else \
+                    _rank_kept_into(idx, token, pair_off, sparse, alpha)
+                assert np.array_equal(bits(scores), bits(want_in[want_or])), (mode, alpha, pool)
+                assert np.array_equal(codes, carry[want_or]) and np.array_equal(order.astype(np.int64), want_or)
+            full = native.score_ranked(idx, queries, pair_off, ids, mode, sparse, alpha, carry=carry, want_order=True)
+            assert np.array_equal(bits(full[0]), bits(want_in[want_or])) and np.array_equal(full[1], carry[want_or])
+            assert native.kept_token(idx) == token  # a call that does not keep leaves the kept scores alone
+        # no first-stage scores: the dense scores, ordered; other candidate lists are refused
+        scores, codes, order, _ = native.rank_kept(idx, token, pair_off, None, 0.0, want_order=True)
+        assert np.array_equal(bits(scores), bits(want_ff[dense_order])) and np.array_equal(codes, carry[dense_order])
+        other = pair_off.copy()
+        other[4] -= 1  # the same totals, another cut
+        with pytest.raises(native.FFXError, match="not the candidate lists"):
+            native.rank_kept(idx, token, other, None, 0.0)
+        with pytest.raises(native.FFXError, match="not the candidate lists"):
+            native.rank_kept(idx, token, pair_off[:-1], None, 0.0)
+    # kept without carried words: asking for them is refused, the scores come
+    ids = pair_ids
+    native.score_ranked(idx, queries, pair_off, ids, 2, None, 0.0, keep=True)
+    token = native.kept_token(idx)
+    with pytest.raises(native.FFXError, match="out_carry"):
+        native.rank_kept(idx, token, pair_off, None, 0.0, want_carry=True)
+    want_ff, _ = fo.score(vectors, doc_off, doc_rows, np.arange(n), queries, pair_off, ids, 2)
+    scores, _, _, _ = native.rank_kept(idx, token, pair_off, None, 0.0, want_carry=False)
+    assert np.array_equal(bits(scores), bits(want_ff[fo.order(want_ff, pair_off)]))
+    with pytest.raises(native.FFXError, match="token"):
+        native.rank_kept(idx, last, pair_off, None, 0.0, want_carry=False)  # the earlier keeping call's token is dead
+    # an empty batch, and dropping what is kept
+    empty_off = np.zeros(4, dtype=np.int64)
+    native.score_ranked(idx, queries[:3], empty_off, np.zeros(0, dtype=np.int32), 2, None, 0.0, keep=True)
+    scores, _, _, _ = native.rank_kept(idx, native.kept_token(idx), empty_off, None, 0.0, want_carry=False)
+    assert scores.shape == (0,)
+    native.drop_kept(idx)
+    assert native.kept_token(idx) == 0
+    idx.close()
+
+
+def _rank_kept_into(idx, token, pair_off, sparse, alpha):
+    """ffx_rank_kept into page-locked buffers of the caller (the asynchronous result stream)."""
+    import ctypes as C
+
+    n = int(pair_off[-1])
+    scores, codes, order = native.pinned_empty(max(n, 1), np.float32), native.pinned_empty(max(n, 1), np.int32), native.pinned_empty(max(n, 1), np.int32)
+    off = np.ascontiguousarray(pair_off, dtype=np.int64)
+    sp = np.ascontiguousarray(sparse, dtype=np.float32)
+    st = native.Stats()
+    native._check(native.lib().ffx_rank_kept(idx._h, int(token), off.shape[0] - 1, native._ptr(off), native._ptr(sp), float(alpha), native.FLAG_SORT,
+                                             native._ptr(scores), native._ptr(codes), native._ptr(order), C.byref(st)))
+    return scores[:n], codes[:n], order[:n], st.as_dict()
+
+
 @pytest.mark.parametrize("slice_pairs", [1, 50, 400])
 def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
     """ffx_score pipelines slices of whole queries through two plans: scores, interpolation, the
