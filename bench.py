@@ -892,16 +892,23 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
     out["iii_rerank_first_call_s"] = time.perf_counter() - t0
     out["iii_first_call_breakdown"] = dict(getattr(api, "last_timings", {}))
     out["iii_queries_per_s_cold"] = nq / (out["iii_ranking_constructor_s"] + out["iii_rerank_first_call_s"])
-    # WARM: the same ranking again (another alpha on the same run): the resolved candidate list is kept with the ranking
+    # SECOND call on the same ranking: the resolved candidate list is kept with the ranking, but the first result is still
+    # alive, so this result needs two MORE page-locked blocks of the result pool (~60 ms to make, once per number of results
+    # alive at a time)
     t0 = time.perf_counter()
     final = api.rerank(first, args.alpha)
-    out["iii_rerank_s"] = time.perf_counter() - t0
-    out["iii_warm_call_breakdown"] = dict(getattr(api, "last_timings", {}))
+    out["iii_rerank_second_call_s"] = time.perf_counter() - t0
+    out["iii_second_call_breakdown"] = dict(getattr(api, "last_timings", {}))
+    # WARM: the same ranking again (another alpha on the same run), steady state: the best of three further calls
+    warm = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        final = api.rerank(first, args.alpha)
+        warm.append((time.perf_counter() - t0, dict(getattr(api, "last_timings", {}))))
+    out["iii_rerank_s"], out["iii_warm_call_breakdown"] = min(warm, key=lambda w: w[0])
+    out["iii_rerank_again_s"] = out["iii_rerank_s"]  # (the name round 4's first lines used)
     # what the breakdown does not see: binding the result (the previous one is released: its blocks go back to the result pool)
     out["iii_rerank_outside_the_breakdown_s"] = out["iii_rerank_s"] - out["iii_warm_call_breakdown"].get("total_s", 0.0)
-    t0 = time.perf_counter()
-    final = api.rerank(first, args.alpha)
-    out["iii_rerank_again_s"] = time.perf_counter() - t0
     out["iii_pairs"] = int(nq * args.k)
     out["iii_queries_per_s_rerank"] = nq / out["iii_rerank_s"]
     t0 = time.perf_counter()
@@ -945,7 +952,8 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
     out["iii_general_join_equals_rerank"] = bool(joined == api.rerank(sub, args.alpha))
     out["iii_note"] = (f"{nq} queries x k={args.k} from a pandas frame of string ids: the Ranking constructor (iii_ranking_constructor_s), then "
                        f"Index.rerank COLD (iii_rerank_first_call_s: first call on that ranking, distinct-id look-up and allocations included) and "
-                       f"WARM (iii_rerank_s: the same ranking again); Index.__call__ followed by Ranking.interpolate (warm); the general host join on {nq2} queries")
+                       f"WARM (iii_rerank_s: the same ranking again, best of three calls after the second, which is iii_rerank_second_call_s); Index.__call__ followed by "
+                       f"Ranking.interpolate (iii_interpolate_s: first time, new result blocks; iii_interpolate_again_s: steady state); the general host join on {nq2} queries")
     api.release()
     return out
 

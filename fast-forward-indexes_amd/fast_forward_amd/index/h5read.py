@@ -71,6 +71,37 @@ class Dataset:
                 out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
         return out
 
+    def read_rows(self, path: Path, lo: int, hi: int) -> np.ndarray:
+        """Elements ``lo .. hi`` of a ONE-dimensional dataset (the id columns of an index file) without reading the rest:
+        the extent of a contiguous dataset, the chunks that overlap the range of a chunked one (fill value 0 elsewhere)."""
+        if len(self.shape) != 1:
+            raise ValueError("read_rows is for one-dimensional datasets")
+        lo, hi = max(0, int(lo)), min(int(hi), self.shape[0])
+        if hi <= lo:
+            return np.zeros(0, dtype=self.dtype)
+        if self.inline is not None:
+            return np.frombuffer(self.inline, dtype=self.dtype)[lo:hi].copy()
+        item = self.dtype.itemsize
+        out = np.zeros(hi - lo, dtype=self.dtype)
+        with open(path, "rb") as f:
+            if self.chunk_shape is None:
+                if self.address is not None:
+                    f.seek(self.address + lo * item)
+                    out = np.frombuffer(f.read((hi - lo) * item), dtype=self.dtype).copy()
+                return out
+            per = int(self.chunk_shape[0])
+            for c in range(lo // per, (hi - 1) // per + 1):
+                where = self.chunks.get((c * per,))
+                if where is None:
+                    continue
+                addr, size = where
+                if size != per * item:
+                    raise NotImplementedError("HDF5: filtered (compressed) chunks")
+                a, b = max(lo, c * per), min(hi, (c + 1) * per)
+                f.seek(addr + (a - c * per) * item)
+                out[a - lo:b - lo] = np.frombuffer(f.read((b - a) * item), dtype=self.dtype)
+        return out
+
 
 @dataclass
 class Group:

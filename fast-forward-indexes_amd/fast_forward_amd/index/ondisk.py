@@ -463,9 +463,11 @@ class OnDiskIndex(Index):
             where = vec.chunks.get((c * cs, 0))
             rows = empty if where is None else np.memmap(self._index_file, mode="r", dtype=vec.dtype, offset=where[0], shape=(cs, dim))
             self._maps.append((rows, None, None))
-        docs = root.datasets["doc_ids"].read(self._index_file)[:n]
-        psgs = root.datasets["psg_ids"].read(self._index_file)[:n]
-        kept = [self._register_ids(docs[lo:lo + (1 << 20)], psgs[lo:lo + (1 << 20)], lo, shard) for lo in range(0, n, 1 << 20)]
+        # the id columns block by block (a shard view keeps ~1 / world of every block: its host memory never holds the columns
+        # of the whole file, as the container format's loader above)
+        d_ids, p_ids = root.datasets["doc_ids"], root.datasets["psg_ids"]
+        kept = [self._register_ids(d_ids.read_rows(self._index_file, lo, min(n, lo + (1 << 20))), p_ids.read_rows(self._index_file, lo, min(n, lo + (1 << 20))),
+                                   lo, shard) for lo in range(0, n, 1 << 20)]
         if shard is not None:
             self._row_map = np.concatenate(kept) if kept else np.zeros(0, dtype=np.int64)
 

@@ -699,12 +699,20 @@ def pooled_empty(n: int, dtype) -> np.ndarray:
     return np.frombuffer(owner, dtype=dtype, count=n)
 
 
+_RESERVING: list = []  # helper threads of reserve_pooled that may still be page-locking
+
+
 def reserve_pooled(requests, first=None) -> "object":
     """Make sure the pool can serve ``requests`` (``[(n, dtype), ...]``) without page-locking anything, on a helper thread:
-    page-locking 2 x 140 MB takes ~0.1 s of driver time that a first call can spend looking its ids up instead.  Returns the
-    thread (``join`` it before the blocks are needed); blocks that exist already are left alone.  ``first``: something else
-    for that thread to do before (an index brings its device-side state up to date: ``InMemoryIndex._warm_up``); whatever
-    it raises is dropped -- the caller's own thread does the same work again where it needs it, and reports."""
+    page-locking 2 x 140 MB takes ~0.1 s of driver time that a first call can spend looking its ids up instead.  Blocks that
+    exist already are left alone.  ``first``: something else for that thread to do before (an index brings its device-side
+    state up to date: ``InMemoryIndex._warm_up``); whatever it raises is dropped -- the caller's own thread does the same
+    work again where it needs it, and reports.  Returns the thread (``join`` it before the blocks are needed).
+
+    Tried and dropped (tools/cold_api_probe.py): not waiting for the page-locking -- results in ordinary arrays when the
+    blocks are not ready, the thread carrying on beside the device call.  A call whose results land in fresh ordinary
+    memory takes 25 - 43 ms instead of 19 by itself, but 100 ms with the page-locking thread beside it (the driver serialises
+    the two): worse than waiting the ~60 ms a new pair of blocks costs, once per number of results alive at a time."""
     import threading
 
     lib()
@@ -715,11 +723,11 @@ def reserve_pooled(requests, first=None) -> "object":
     todo = [cap for cap, k in need.items() for _ in range(max(0, k - len(_POOL.get(cap, ()))))]
 
     def work():
-        if first is not None:
-            try:
+        try:
+            if first is not None:
                 first()
-            except Exception:  # noqa: BLE001
-                pass
+        except Exception:  # noqa: BLE001
+            pass
         for cap in todo:
             p = C.c_void_p()
             if _lib.ffx_host_alloc(cap, C.byref(p)) == OK:
@@ -727,12 +735,16 @@ def reserve_pooled(requests, first=None) -> "object":
                 _POOL_IDLE[0] += cap
 
     t = threading.Thread(target=work, daemon=True)
+    _RESERVING[:] = [x for x in _RESERVING if x.is_alive()] + [t]
     t.start()
     return t
 
 
 def drain_result_pool() -> int:
     """Release every idle block of the result pool; returns the bytes freed."""
+    for t in list(_RESERVING):  # nobody adds a block behind this call's back
+        t.join()
+    _RESERVING.clear()
     freed = 0
     for cap, blocks in list(_POOL.items()):
         while blocks:

@@ -285,6 +285,20 @@ def test_hdf5_reader_on_real_hdf5_files():
     assert q.groups["attributes"].attrs == {"M": 4, "Ks": 8, "Ds": 6, "metric": "dot", "verbose": 0}
     assert np.array_equal(q.groups["data"].datasets["codewords"].read(H5 / "quantized.h5"), np.array(e["codewords"], dtype=np.float32))
     assert not h5read.is_hdf5(Path(__file__))
+    # a range of a one-dimensional dataset without the rest (what a shard view reads of the id columns): every cut of
+    # every id column of the files real HDF5 wrote, and of one this build's writer lays out contiguously
+    for name in ("plain.h5", "big_f64.h5", "quantized.h5"):
+        root = h5read.read(H5 / name)
+        for col in ("doc_ids", "psg_ids"):
+            ds = root.datasets[col]
+            whole = ds.read(H5 / name)
+            n = whole.shape[0]
+            per = ds.chunk_shape[0] if ds.chunk_shape else max(1, n // 3)
+            for lo, hi in {(0, n), (0, 1), (n - 1, n), (1, n - 1), (per - 1, per + 1), (per, 2 * per), (n // 2, n + 5), (n, n + 3), (5, 5)}:
+                got = ds.read_rows(H5 / name, lo, hi)
+                assert got.dtype == whole.dtype and np.array_equal(got, whole[max(0, lo):max(lo, min(hi, n))]), (name, col, lo, hi)
+    with pytest.raises(ValueError):
+        h5read.read(H5 / "plain.h5").datasets["vectors"].read_rows(H5 / "plain.h5", 0, 1)
 
 
 def test_load_reference_hdf5_index_files(tmp_path):
