@@ -37,6 +37,17 @@
 
 thread_local std::string g_last_error;
 
+// FFX_TRACE_HOST=1 (a diagnostic, off by default): one line on stderr per operation that hands host addresses to the runtime
+// outside the scoring paths -- page-locked allocations, device pulls, row gathers -- so that the address of a device fault
+// ("Memory access fault by GPU node ... on address ...", the runtime's last words) can be matched with who owned it.
+static bool ffx_trace_host() {
+  static const bool on = [] {
+    const char* e = getenv("FFX_TRACE_HOST");
+    return e && *e && *e != '0';
+  }();
+  return on;
+}
+
 // FFX_ABORT_BACKTRACE=1 (a diagnostic, off by default): when something below this library -- the HIP runtime, the driver's
 // user-mode part -- ends the process with abort(), the native call stack of the aborting thread goes to stderr first (Python's
 // faulthandler shows the Python frames only).  For the rare SIGABRT inside hipMemcpy of DESIGN.md section 10 / tools/abort_hunt.sh.
@@ -52,6 +63,21 @@ void ffx_abort_backtrace(int) {
   backtrace_symbols_fd(frames, n, 2);
   signal(SIGABRT, SIG_DFL);
   raise(SIGABRT);
+}
+// Transfers between ORDINARY host memory and the device of more than 1 MiB make the HIP runtime page-lock the caller's pages on
+// the fly (its default; the knob is GPU_PINNED_MIN_XFER_SIZE, in MiB).  On this stack (ROCm 7.2, gfx950) that path now and then
+// leaves the device with a bad mapping of HEAP memory: in 7 of 28 full runs of this repository's GPU suite the runtime ended the
+// process with "Memory access fault by GPU node-N on address A" -- A inside the NumPy array a blocking hipMemcpy was writing at
+// that moment ("Write access to a read-only page", 1 - 5 pages past the end of a heap range that had been hipHostRegister'ed and
+// released earlier), or inside another heap array ("Reason: Unknown"); profiles/r04/abort_hunt.  malloc never serves more than
+// 32 MiB from the heap (glibc's cap on its mmap threshold), so with the threshold at 32 MiB heap memory is never page-locked
+// behind the caller's back -- such transfers go through the runtime's own staging blocks (30 GB/s in, 17 GB/s out instead of
+// 40 - 55: tools/probes/pinned_xfer_knob.py) -- while large arrays, which are mappings of their own, keep the fast path.  The
+// runtime reads the variable when it starts: this runs when the library is loaded, sets it only if the process has not, and
+// FFX_KEEP_RUNTIME_PINNING=1 leaves the runtime's default alone.
+__attribute__((constructor)) void ffx_keep_the_runtime_from_pinning_heap_memory() {
+  const char* keep = getenv("FFX_KEEP_RUNTIME_PINNING");
+  if (!(keep && *keep && *keep != '0')) setenv("GPU_PINNED_MIN_XFER_SIZE", "32", 0);
 }
 __attribute__((constructor)) void ffx_install_abort_backtrace() {
   const char* e = getenv("FFX_ABORT_BACKTRACE");
@@ -98,7 +124,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 //   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
 //   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N   where the per-query sort switches form
 //   sort_interp_apart      the interpolation (and the owner-side scatter) as launches of their own instead of inside the block sort
-//   score_slice_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N, count_always
+//   score_slice_pairs=N, score_ramp_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N, count_always
 //                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py)
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
 // (FFX_SCORE_TRACE=1 -- a timeline on stderr -- and the operational settings FFX_COMM_TIMEOUT_S, FFX_RDZV_DIR,
@@ -266,6 +292,8 @@ struct ffx_index {
   hipEvent_t out_done[3] = {nullptr, nullptr, nullptr};
   // FFX_FLAG_KEEP_DENSE: the dense scores (first-stage order) and the carried words of the last such ffx_score_ranked call,
   // for ffx_rank_kept (Ranking.interpolate on an Index.__call__ result: the interpolation and the ordering, no gather)
+  void* gather_stage = nullptr;  // ffx_index_gather's page-locked block (rows never go straight into the caller's memory)
+  size_t gather_stage_bytes = 0;
   DevBuf kept_dense, kept_carry;
   int64_t kept_pairs = -1, kept_queries = -1;
   bool kept_has_carry = false;
@@ -486,6 +514,7 @@ int ffx_index_destroy(ffx_index* idx) {
   idx->pull_chunks.release();
   idx->kept_dense.release();
   idx->kept_carry.release();
+  if (idx->gather_stage) (void)hipHostFree(idx->gather_stage);
   if (idx->out_stream) (void)hipStreamDestroy(idx->out_stream);
   if (idx->score_stream) (void)hipStreamDestroy(idx->score_stream);
   for (auto& e : idx->out_done)
@@ -745,6 +774,7 @@ int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid_cap, (waves + 3) / 4));
   const char* const* table = idx->pull_chunks.as<const char*>();
   char* dst = static_cast<char*>(idx->row_ptr(dst_row));
+  if (ffx_trace_host()) fprintf(stderr, "\nffx trace: pull %lld rows, chunks[0]=%p (%lld x %lld rows of %zu bytes), list_host=%p list_dev=%p table_dev=%p dst=%p..%p\n", (long long)n_rows, chunks[0], (long long)n_chunks, (long long)chunk_rows, rb, (void*)idx->pull_list_host, idx->pull_list.p, (const void*)table, (void*)dst, (void*)(dst + (size_t)n_rows * rb));
   if (align == 16)
     ffx::pull_rows_kernel<uint4><<<grid, 256, 0, idx->copy_stream>>>(table, chunk_rows, idx->pull_list.as<int64_t>(), n_rows, units, G, dst);
   else if (align == 8)  // (where an HDF5 file's allocator usually puts a chunk)
@@ -799,31 +829,57 @@ int ffx_index_copy_rows(ffx_index* dst, const ffx_index* src, int64_t n_rows) {
   return FFX_OK;
 }
 
+// Rows back to the host, THROUGH A PAGE-LOCKED BLOCK OF THE INDEX'S OWN (8 MiB, a chunk of rows at a time) and a host memcpy.
+// Handing the caller's ordinary memory to hipMemcpy makes the runtime page-lock those pages on the fly for transfers of more
+// than 1 MiB, and that is where the one abort this library has seen comes from: in 6 of 21 full runs of the GPU suite of round
+// 4 the runtime ended the process from its own thread with "Memory access fault by GPU node-N on address A. Reason: Write
+// access to a read-only page" -- every time with A inside the 1.32 MB NumPy array (heap memory, part of it never written before)
+// that this function was copying into at that moment (FFX_TRACE_HOST=1; profiles/r04/abort_hunt).  Nothing of the sort when
+// the device writes into page-locked memory and the CPU writes the caller's.
 int ffx_index_gather(ffx_index* idx, const int32_t* rows, int64_t n_rows, void* host_out) {
   if (!idx || (n_rows > 0 && (!rows || !host_out))) return fail(FFX_BAD_ARG, "NULL argument");
   if (n_rows == 0) return FFX_OK;
   for (int64_t i = 0; i < n_rows; ++i)
     if (rows[i] < 0 || rows[i] >= idx->capacity) return fail(FFX_BAD_ARG, "row %d outside the index", rows[i]);
   FFX_HIP(hipSetDevice(idx->device));
+  const size_t row_bytes = (size_t)idx->dim * idx->elem;
+  const int64_t per_chunk = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t)((size_t(8) << 20) / std::max<size_t>(row_bytes, 1))));
+  const size_t list_bytes = ((size_t)per_chunk * sizeof(int32_t) + 255) & ~size_t(255);
+  const size_t stage_need = list_bytes + (size_t)per_chunk * row_bytes;
+  if (idx->gather_stage_bytes < stage_need) {
+    if (idx->gather_stage) (void)hipHostFree(idx->gather_stage);
+    idx->gather_stage = nullptr;
+    idx->gather_stage_bytes = 0;
+    const hipError_t e = hipHostMalloc(&idx->gather_stage, stage_need, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      idx->gather_stage = nullptr;
+      (void)hipGetLastError();
+      return fail(FFX_OOM, "hipHostMalloc(%zu bytes) failed: %s", stage_need, hipGetErrorString(e));
+    }
+    idx->gather_stage_bytes = stage_need;
+  }
+  char* s_rows = static_cast<char*>(idx->gather_stage);
+  char* s_out = s_rows + list_bytes;
+  if (ffx_trace_host()) fprintf(stderr, "\nffx trace: gather %lld rows of %zu bytes -> %p through the page-locked block %p\n", (long long)n_rows, row_bytes, host_out, idx->gather_stage);
   DevBuf drows, dout;
-  int rc = drows.ensure((size_t)n_rows * sizeof(int32_t));
-  const size_t out_bytes = (size_t)n_rows * idx->dim * idx->elem;
-  if (rc == FFX_OK) rc = dout.ensure(out_bytes);
-  if (rc == FFX_OK) {
-    hipError_t e = hipMemcpy(drows.p, rows, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice);
+  int rc = drows.ensure((size_t)per_chunk * sizeof(int32_t));
+  if (rc == FFX_OK) rc = dout.ensure((size_t)per_chunk * row_bytes);
+  for (int64_t c0 = 0; c0 < n_rows && rc == FFX_OK; c0 += per_chunk) {
+    const int64_t m = std::min(per_chunk, n_rows - c0);
+    memcpy(s_rows, rows + c0, (size_t)m * sizeof(int32_t));
+    hipError_t e = hipMemcpy(drows.p, s_rows, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
       // rows are copied as raw bytes, so one kernel serves every storage type
-      const int row_bytes = (int)(idx->dim * idx->elem);
       if (row_bytes % 2 == 0)
-        ffx::gather_rows_kernel<uint16_t><<<blocks_for(n_rows, 4), 256>>>(static_cast<const uint16_t*>(idx->vectors), row_bytes / 2,
-                                                                         drows.as<int32_t>(), n_rows, dout.as<uint16_t>());
+        ffx::gather_rows_kernel<uint16_t><<<blocks_for(m, 4), 256>>>(static_cast<const uint16_t*>(idx->vectors), (int)(row_bytes / 2), drows.as<int32_t>(), m,
+                                                                     dout.as<uint16_t>());
       else
-        ffx::gather_rows_kernel<uint8_t><<<blocks_for(n_rows, 4), 256>>>(static_cast<const uint8_t*>(idx->vectors), row_bytes,
-                                                                        drows.as<int32_t>(), n_rows, dout.as<uint8_t>());
+        ffx::gather_rows_kernel<uint8_t><<<blocks_for(m, 4), 256>>>(static_cast<const uint8_t*>(idx->vectors), (int)row_bytes, drows.as<int32_t>(), m, dout.as<uint8_t>());
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(host_out, dout.p, out_bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(s_out, dout.p, (size_t)m * row_bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(FFX_HIP_ERROR, "gather failed: %s", hipGetErrorString(e));
+    if (rc == FFX_OK) memcpy(static_cast<char*>(host_out) + (size_t)c0 * row_bytes, s_out, (size_t)m * row_bytes);
   }
   drows.release();
   dout.release();
@@ -2832,7 +2888,8 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   if (long long v = 0; ffx_debug_variant("score_slice_pairs", &v)) per_slice = std::max<int64_t>(1, (int64_t)v);
   // ... and the first and last slices are smaller (an eighth of a slice, doubling / halving): the device idles
   // while the first slice is uploaded and the caller idles while the last one's results come back
-  const int64_t ramp_base = ffx_debug_variant("score_no_ramp", nullptr) ? per_slice : std::max<int64_t>(per_slice / 8, 1);
+  int64_t ramp_base = ffx_debug_variant("score_no_ramp", nullptr) ? per_slice : std::max<int64_t>(per_slice / 8, 1);
+  if (long long v = 0; ffx_debug_variant("score_ramp_pairs", &v)) ramp_base = std::max<int64_t>(1, std::min<int64_t>((int64_t)v, per_slice));  // A/B hook: tools/slice_sweep.py
   auto slice_target = [&](size_t i, int64_t first_pair) {
     const int64_t up = i < 8 ? ramp_base << i : per_slice;
     const int64_t down = std::max<int64_t>(ramp_base, (P - first_pair) / 2);
@@ -3169,6 +3226,13 @@ int ffx_rank_kept(ffx_index* idx, uint64_t token, int64_t n_queries, const int64
 // ---- page-locked host memory ------------------------------------------------------------------
 int ffx_host_alloc(size_t bytes, void** out) {
   if (!out) return fail(FFX_BAD_ARG, "out is NULL");
+  struct Say {
+    size_t bytes;
+    void** out;
+    ~Say() {
+      if (ffx_trace_host()) fprintf(stderr, "\nffx trace: host_alloc %zu bytes -> %p\n", bytes, *out);
+    }
+  } say{bytes, out};
   *out = nullptr;
   hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -3179,6 +3243,7 @@ int ffx_host_alloc(size_t bytes, void** out) {
 }
 
 int ffx_host_free(void* p) {
+  if (p && ffx_trace_host()) fprintf(stderr, "\nffx trace: host_free %p\n", p);
   if (p) FFX_HIP(hipHostFree(p));
   return FFX_OK;
 }
@@ -3188,6 +3253,7 @@ int ffx_host_free(void* p) {
 // launch check (FFX_HIP(hipGetLastError())) must not report this stale failure as its own.
 int ffx_host_pin(void* p, size_t bytes) {
   if (!p || bytes == 0) return fail(FFX_BAD_ARG, "bad argument");
+  if (ffx_trace_host()) fprintf(stderr, "\nffx trace: host_pin %p..%p\n", p, (char*)p + bytes);
   const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -3198,6 +3264,7 @@ int ffx_host_pin(void* p, size_t bytes) {
 
 int ffx_host_unpin(void* p) {
   if (!p) return fail(FFX_BAD_ARG, "bad argument");
+  if (ffx_trace_host()) fprintf(stderr, "\nffx trace: host_unpin %p\n", p);
   const hipError_t e = hipHostUnregister(p);
   if (e != hipSuccess) {
     (void)hipGetLastError();

@@ -112,6 +112,12 @@ def lib() -> C.CDLL:
     import sys
 
     TORCH_LOADED_FIRST = "torch" in sys.modules
+    # (libffx's constructor does the same for C callers; here too, so that os.environ -- what child processes inherit -- says
+    # so: the HIP runtime must not page-lock HEAP memory behind the caller's back, see csrc/ffx.hip)
+    import os
+
+    if os.environ.get("FFX_KEEP_RUNTIME_PINNING", "0") in ("", "0"):
+        os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "32")
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
