@@ -916,13 +916,48 @@ def host_order(scores, pair_off, threads: int = 0, dst_off=None) -> np.ndarray:
     return out
 
 
-def take32(src: np.ndarray, index: np.ndarray, threads: int = 0) -> np.ndarray:
+_HAVE_DEVICE: list = [None]
+INPUT_BLOCKS_FROM = 32 << 20  # bytes from which a ranking's own arrays are kept in page-locked blocks (page_locked_copy)
+
+
+def page_locked_or_empty(n: int, dtype) -> np.ndarray:
+    """``np.empty(n, dtype)``, in a page-locked block of the result pool when the array is large and a device is there.
+    For the arrays a large ranking hands to the device on EVERY call (its first-stage scores, its id codes, the candidates'
+    ordinals): out of page-locked memory they go up by DMA at link rate while the caller carries on; out of ordinary memory
+    the runtime stages them through its own blocks on the calling thread (30 GB/s, and libffx keeps the runtime from
+    page-locking ordinary memory itself: csrc/ffx.hip).  ~35 ms per 140 MB to make, once; back to the pool with the array."""
+    dtype = np.dtype(dtype)
+    if int(n) * dtype.itemsize >= INPUT_BLOCKS_FROM:
+        try:
+            if _HAVE_DEVICE[0] is None:
+                _HAVE_DEVICE[0] = device_count() > 0
+            if _HAVE_DEVICE[0]:
+                return pooled_empty(n, dtype)
+        except Exception:  # noqa: BLE001  (no library, no device, no page-locked memory to be had: ordinary memory does)
+            _HAVE_DEVICE[0] = False
+    return np.empty(int(n), dtype=dtype)
+
+
+def page_locked_copy(a: np.ndarray) -> np.ndarray:
+    """``a`` itself, or -- a large contiguous 1-d array of 4-byte elements with a device present -- its copy in a page-locked
+    block (``page_locked_or_empty``)."""
+    if a.ndim != 1 or a.dtype.itemsize != 4 or a.nbytes < INPUT_BLOCKS_FROM or not a.flags["C_CONTIGUOUS"]:
+        return a
+    out = page_locked_or_empty(a.shape[0], a.dtype)
+    if out.base is None:  # (an ordinary array came back: nothing gained by copying)
+        return a
+    np.copyto(out, a)
+    return out
+
+
+def take32(src: np.ndarray, index: np.ndarray, threads: int = 0, page_locked: bool = False) -> np.ndarray:
     """``src[index]`` for a contiguous 1-d array of 4-byte elements and an int32 index, by host threads
-    (``ffx_host_take32``); small or otherwise shaped inputs take NumPy's route."""
+    (``ffx_host_take32``); small or otherwise shaped inputs take NumPy's route.  ``page_locked``: a large result lands in a
+    page-locked block (``page_locked_or_empty``)."""
     if (src.ndim != 1 or src.dtype.itemsize != 4 or not src.flags["C_CONTIGUOUS"] or index.dtype != np.int32 or index.ndim != 1
             or not index.flags["C_CONTIGUOUS"] or index.shape[0] < (1 << 18)):
         return src[index]
-    out = np.empty(index.shape[0], dtype=src.dtype)
+    out = page_locked_or_empty(index.shape[0], src.dtype) if page_locked else np.empty(index.shape[0], dtype=src.dtype)
     _check(lib().ffx_host_take32(_ptr(src), src.shape[0], _ptr(index), index.shape[0], int(threads), _ptr(out)))
     return out
 

@@ -348,7 +348,12 @@ class Ranking:
             q_texts = None if text_of_q is None else [t_names[text_of_q[i]] for i in firsts]
         self._frame = None
         self._id_cache = None
-        self._coded = {"q_no": q_no, "q_order": q_order, "id_codes": np.ascontiguousarray(id_codes, dtype=np.int32), "id_names": id_names,
+        # what an index uploads on every call on this ranking -- first-stage scores and id codes -- lives in page-locked blocks
+        # when it is large and a device is there (native.page_locked_copy: DMA at link rate instead of a staged copy per call)
+        id_codes = native.page_locked_copy(np.ascontiguousarray(id_codes, dtype=np.int32))
+        if score.dtype == np.float32:
+            score = native.page_locked_copy(np.ascontiguousarray(score))
+        self._coded = {"q_no": q_no, "q_order": q_order, "id_codes": id_codes, "id_names": id_names,
                        "score": score, "q_texts": q_texts, "id_blob": id_blob}
         self._q_no, self._q_order = q_no, q_order
         self._q_ids = set(q_order)
