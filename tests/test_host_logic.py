@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol of
 include/ffx.h, id tables, CSR grouping, argument checks that must fire before device work."""
 
+import os
 import re
 from pathlib import Path
 
@@ -148,3 +149,27 @@ def test_header_is_plain_c(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_loading_the_library_keeps_the_runtime_from_page_locking_heap_memory():
+    """libffx sets GPU_PINNED_MIN_XFER_SIZE=32 (MiB) when it is loaded -- the HIP runtime then stages transfers from or into
+    ordinary memory of up to 32 MiB (all that malloc ever serves from the heap) instead of page-locking the caller's pages on
+    the fly, the path the rare device fault of DESIGN.md section 10 came from -- unless the process has set the variable
+    itself or asks for the runtime's default (FFX_KEEP_RUNTIME_PINNING=1).  Checked in child processes (the variable is
+    decided when the library is loaded): through the Python binding, and through the C constructor alone (ctypes.CDLL)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "fast-forward-indexes_amd" / "fast_forward_amd" / "libffx.so"
+    via_binding = ("import os, sys; sys.path.insert(0, %r); from fast_forward_amd import native; native.lib(); "
+                   "print(os.environ.get('GPU_PINNED_MIN_XFER_SIZE'))" % str(root / "fast-forward-indexes_amd"))
+    via_constructor = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL('libc.so.6'); libc.getenv.restype = ctypes.c_char_p; "
+                       "print((libc.getenv(b'GPU_PINNED_MIN_XFER_SIZE') or b'None').decode())" % str(lib))
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_PINNED_MIN_XFER_SIZE", "FFX_KEEP_RUNTIME_PINNING")}
+    for code in (via_binding, via_constructor):
+        for extra, want in (({}, "32"), ({"GPU_PINNED_MIN_XFER_SIZE": "7"}, "7"), ({"FFX_KEEP_RUNTIME_PINNING": "1"}, "None")):
+            out = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr[-2000:]
+            assert out.stdout.strip().splitlines()[-1] == want, (code[:40], extra, out.stdout)
