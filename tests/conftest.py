@@ -12,15 +12,16 @@ for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests", RO
         sys.path.insert(0, str(p))
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# if anything below libffx ends the process with abort() (one full-suite run in ~12 of round 4 did, inside hipMemcpy), the log
-# should show the NATIVE call stack of the aborting thread, not only Python's (libffx installs the handler when it is loaded)
+# if anything below libffx ends the process with abort(), the log should show the NATIVE call stack of the aborting thread, not
+# only Python's (libffx installs the handler when it is loaded).  That -- with pytest.ini's Python-level capture, which lets the
+# runtime's own last words through -- is how the rare abort of rounds 3 - 4 was traced to the HIP runtime's on-the-fly
+# page-locking of heap memory; libffx keeps heap memory off that path since, and the handler stays armed
 os.environ.setdefault("FFX_ABORT_BACKTRACE", "1")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # if the runtime ever aborts the process (one run in ~25 of round 3 ended in a SIGABRT inside hipMemcpy), the log
-    # should say which test and which Python line it was in
+    # if the runtime ever aborts the process, the log should say which test and which Python line the main thread was in
     import faulthandler
 
     if not faulthandler.is_enabled():
@@ -68,8 +69,8 @@ def _release_device_objects_between_tests(request):
     """Indexes, plans and communicators a GPU test did not close are released right after it (a collection pass), not
     whenever the interpreter gets to it in the middle of a later test: the device-side resources of ~200 tests (streams,
     events, page-locked blocks) then never pile up, and what a test sees does not depend on the garbage of its
-    predecessors.  (One run of the suite ended in a SIGABRT inside hipMemcpy of a test whose predecessor had left two
-    indexes unclosed; with nothing piling up it has not come back.)"""
+    predecessors.  (Not what the rare SIGABRT of rounds 3 - 4 was about -- that was the runtime page-locking heap memory on the
+    fly, DESIGN.md section 10 -- but a suite whose tests do not see each other's leftovers is worth having anyway.)"""
     yield
     if "gpu" in request.keywords and not os.environ.get("FFX_TEST_KEEP_GARBAGE"):  # (tools/abort_hunt.sh runs the suite without this)
         import gc
