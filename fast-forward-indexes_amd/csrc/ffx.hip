@@ -2817,7 +2817,11 @@ static int staged_d2h(ffx_plan* pl, int lane, void* dst, const void* src_dev, si
   if (bytes == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(pl->device));
   if (!pl->out_stage_stream[lane]) {
-    FFX_HIP(hipStreamCreateWithFlags(&pl->out_stage_stream[lane], hipStreamNonBlocking));
+    // (highest priority, as the result stream of the page-locked form: a copy that queues behind the next slices' scoring
+    // kernels leaves when they are done -- measured: 24.6 ms for the headline batch with ordinary result buffers at normal priority)
+    int least = 0, greatest = 0;
+    FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    FFX_HIP(hipStreamCreateWithPriority(&pl->out_stage_stream[lane], hipStreamNonBlocking, greatest));
     for (int i = 0; i < 2; ++i) {
       FFX_HIP(hipHostMalloc(reinterpret_cast<void**>(&pl->out_stage[lane][i]), ffx_plan::kOutStageBytes, hipHostMallocDefault));
       FFX_HIP(hipEventCreateWithFlags(&pl->out_stage_ev[lane][i], hipEventDisableTiming));

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""ffx_score at the headline size with ORDINARY (not page-locked) buffers both ways, written before: best of 5 calls and the
+host-side timeline of one (FFX_SCORE_TRACE=1).  argv[1]: 'in' = only the inputs ordinary, 'out' = only the outputs, default both."""
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
+sys.path.insert(0, str(ROOT))
+from fast_forward_amd import native, synth  # noqa: E402
+import bench as B  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "both"
+rows, d, nq, k = 8_841_823, 768, 6980, 5000
+scale = float(1 / np.sqrt(d))
+idx = native.DeviceIndex(rows, d)
+idx.fill_synthetic(2024, scale, 0, rows)
+idx.set_doc_rows(np.arange(rows + 1, dtype=np.int64), np.arange(rows, dtype=np.int32))
+idx.set_psg_rows(np.arange(rows, dtype=np.int32))
+ids, sparse = B.candidates(rows, nq, k, 2024)
+pair_off = np.arange(nq + 1, dtype=np.int64) * k
+queries = synth.rows(2027, scale, 0, nq, d)
+n = int(pair_off[-1])
+if which == "out":
+    pq = native.pinned_empty(queries.shape, np.float32)
+    pi, ps = native.pinned_empty(n, np.int32), native.pinned_empty(n, np.float32)
+    pq[...], pi[...], ps[...] = queries, ids, sparse
+    queries, ids, sparse = pq, pi, ps
+outs = tuple(native.pinned_empty(n, t) for t in (np.float32, np.float32, np.int32)) if which == "in" else \
+    (np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.int32))
+run = lambda: native.score(idx, queries, pair_off, ids, 2, sparse, 0.1, exact_sum=True, sort=True, out=outs)  # noqa: E731
+run()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    run()
+    ts.append(time.perf_counter() - t0)
+print(json.dumps({"ordinary": which, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}))
+os.environ["FFX_SCORE_TRACE"] = "1"
+run()
