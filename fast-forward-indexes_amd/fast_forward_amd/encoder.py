@@ -37,13 +37,27 @@ class LambdaEncoder(Encoder):
 
 
 class ArrayEncoder(Encoder):
-    """Pre-computed query vectors keyed by query text (a ``dict`` or a callable batch function).
+    """Pre-computed query vectors keyed by query text (a ``dict``).
 
-    Not in the reference; the cheapest way to feed an externally encoded ``(Q, d)`` matrix."""
+    Not in the reference; the cheapest way to feed an externally encoded ``(Q, d)`` matrix.  The vectors are laid out as
+    one matrix on first use, and a batch is one gather of its rows; ``Index.encode_queries`` hands it all texts at once
+    (``encode_all``: there is no model behind it whose batch size would matter) -- 6980 queries: ~1 ms instead of 5 - 8
+    for 219 batches of 32."""
 
     def __init__(self, vectors_by_text: dict[str, np.ndarray]) -> None:
         super().__init__()
         self._table = vectors_by_text
+        self._rows: dict[str, int] | None = None
+        self._matrix: np.ndarray | None = None
+
+    def _laid_out(self) -> None:
+        if self._rows is None or len(self._rows) != len(self._table):
+            self._rows = {t: i for i, t in enumerate(self._table)}
+            self._matrix = np.stack(list(self._table.values())) if self._table else np.zeros((0, 0), dtype=np.float32)
 
     def _encode(self, texts: Sequence[str]) -> np.ndarray:
-        return np.stack([self._table[t] for t in texts])
+        self._laid_out()
+        rows = self._rows
+        return self._matrix[np.fromiter((rows[t] for t in texts), dtype=np.int64, count=len(texts))]
+
+    encode_all = _encode

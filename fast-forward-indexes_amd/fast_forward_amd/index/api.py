@@ -197,6 +197,9 @@ class Index(abc.ABC):
         """Encode query texts in batches of ``encoder_batch_size`` (base.py:58-72)."""
         if self.query_encoder is None:
             raise RuntimeError("Index does not have a query encoder.")
+        whole = getattr(self.query_encoder, "encode_all", None)
+        if whole is not None and len(queries):  # (an encoder that is a table, not a model: one gather, see ArrayEncoder)
+            return whole(queries)
         step = self._encoder_batch_size
         return np.concatenate([self.query_encoder(queries[i:i + step]) for i in range(0, len(queries), step)])
 

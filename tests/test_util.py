@@ -182,3 +182,29 @@ def test_indexer_on_the_hbm_index():
 @pytest.mark.gpu
 def test_coalesced_hbm_index_equals_the_reference():
     _check_coalesce(_hbm, lambda index, docs: index._get_vectors(docs))
+
+
+def test_array_encoder_is_a_table_and_encodes_all_queries_in_one_gather():
+    """``ArrayEncoder`` (this build's cheapest way to feed pre-computed query vectors): a batch is one gather of the table's
+    rows, ``Index.encode_queries`` hands it all texts at once, and the result is what batches of ``encoder_batch_size``
+    through an ordinary encoder give (base.py:58-72); the table may grow between calls; an unknown text is a ``KeyError``."""
+    import pytest
+
+    from fast_forward_amd.encoder import ArrayEncoder, LambdaEncoder
+    from fast_forward_amd.index import InMemoryIndex
+
+    rng = np.random.default_rng(3)
+    table = {f"text {i}": rng.standard_normal(24).astype(np.float32) for i in range(100)}
+    enc = ArrayEncoder(table)
+    asked = [f"text {i}" for i in (5, 99, 0, 5, 42)]
+    assert np.array_equal(enc(asked), np.stack([table[t] for t in asked]))
+    assert enc([]).shape[0] == 0
+    index = InMemoryIndex(enc, encoder_batch_size=7)
+    every = [f"text {i}" for i in rng.permutation(100)]
+    batched = InMemoryIndex(LambdaEncoder(lambda t: table[t]), encoder_batch_size=7).encode_queries(every)
+    got = index.encode_queries(every)
+    assert got.dtype == np.float32 and np.array_equal(got, batched)
+    table["one more"] = np.ones(24, dtype=np.float32)
+    assert np.array_equal(index.encode_queries(["one more", "text 3"]), np.stack([table["one more"], table["text 3"]]))
+    with pytest.raises(KeyError):
+        enc(["never seen"])
