@@ -173,3 +173,30 @@ def test_loading_the_library_keeps_the_runtime_from_page_locking_heap_memory():
             out = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=120)
             assert out.returncode == 0, out.stderr[-2000:]
             assert out.stdout.strip().splitlines()[-1] == want, (code[:40], extra, out.stdout)
+
+
+def test_helpers_around_page_locked_memory_degrade_quietly_without_a_device():
+    """Without a device (this container) nothing can be page-locked: a large ranking's arrays stay ordinary memory
+    (``page_locked_copy`` hands the array itself back), and the helper thread of a first call (``reserve_pooled``) runs what
+    it is given first, drops whatever that raises -- the caller's own thread does the work again and reports -- and adds no
+    block to the pool."""
+    from fast_forward_amd import native
+
+    if native.device_count() > 0:
+        pytest.skip("a device is present: covered by the GPU tests")
+    big = np.arange(native.INPUT_BLOCKS_FROM // 4 + 5, dtype=np.int32)
+    assert native.page_locked_copy(big) is big
+    assert native.page_locked_or_empty(big.shape[0], np.float32).base is None
+    two_d = np.zeros((4, 4), dtype=np.float32)
+    assert native.page_locked_copy(two_d) is two_d
+    ran = []
+
+    def first():
+        ran.append(1)
+        raise RuntimeError("the helper thread must not take the process down")
+
+    idle = native._POOL_IDLE[0]
+    t = native.reserve_pooled([(1 << 20, np.float32)], first=first)
+    t.join(30)
+    assert not t.is_alive() and ran == [1] and native._POOL_IDLE[0] == idle
+    assert native.drain_result_pool() == 0
