@@ -1,7 +1,8 @@
 /* rerank_sharded.c (test infrastructure: it links the oracle) -- the multi-GPU half of the C ABI from
  * plain C99, no Python and no PyTorch anywhere: N processes (fork), one communicator (ffx_comm_*),
  * an index row-sharded by document (ffx_sharded_*), one all-to-all of scores per batch, and every
- * owner checks its queries against the CPU oracle bit for bit.
+ * owner checks its queries against the CPU oracle bit for bit -- once with the batch set on every rank (ffx_sharded_set_pairs)
+ * and once as a fresh batch of which every rank hands over only the queries it owns (ffx_sharded_score).
  *
  *   rerank_sharded rccl        1 rank over RCCL on device 0 (the same calls an 8-GPU node makes)
  *   rerank_sharded host N      N ranks sharing device 0, scores exchanged through shared memory
@@ -107,6 +108,29 @@ static int run_rank(int transport, int rank, int world, const unsigned char* id)
         return 1;
       }
     }
+  /* The same batch as a FRESH one, the way the reference meets a batch (a new set of queries on every call, index/base.py:418-429):
+   * every rank hands over ONLY the block of queries it owns -- their vectors, candidate lists (offsets from 0), first-stage
+   * scores -- and ffx_sharded_score routes the candidates to their holders, scores, exchanges, merges, orders and returns this
+   * rank's block, host buffers to host buffers.  Same bits as above. */
+  {
+    int64_t q_bounds[65];
+    CHECK(ffx_query_partition(N_Q, world, q_bounds));
+    if (q_bounds[rank] != q_lo || q_bounds[rank + 1] != q_hi) {
+      fprintf(stderr, "rank %d: ffx_query_partition disagrees with ffx_sharded_owned\n", rank);
+      return 1;
+    }
+    static int64_t own_off[N_Q + 1];
+    for (int64_t q = q_lo; q <= q_hi; ++q) own_off[q - q_lo] = pair_off[q] - first;
+    static float ff2[N_Q * K], interp2[N_Q * K];
+    static int32_t order2[N_Q * K];
+    CHECK(ffx_sharded_score(s, q_bounds, queries + (size_t)q_lo * DIM, own_off, pair_ids + first, NULL, sparse + first, FFX_MODE_MAXP, alpha,
+                            FFX_FLAG_EXACT_SUM | FFX_FLAG_SORT, 2, ff2, interp2, order2, &bad));
+    if (memcmp(ff2, want_ff + first, sizeof(float) * (size_t)n_own) != 0 || memcmp(interp2, want_interp + first, sizeof(float) * (size_t)n_own) != 0 ||
+        memcmp(order2, order, sizeof(int32_t) * (size_t)n_own) != 0) {
+      fprintf(stderr, "rank %d: the fresh-batch form (ffx_sharded_score) differs from the set-once form\n", rank);
+      return 1;
+    }
+  }
   ffx_shard_stats st;
   CHECK(ffx_sharded_stats(s, &st));
   double checked = (double)n_own;
