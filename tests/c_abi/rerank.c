@@ -89,6 +89,41 @@ int main(void) {
       }
     }
 
+  /* The reference's documented two-call pipeline -- dense = index(first), then first.interpolate(dense, alpha)
+   * (index/base.py:389-469, ranking.py:293-326) -- without scoring twice: the first call returns the dense scores in final
+   * order and leaves them in HBM (FFX_FLAG_KEEP_DENSE) with the carried words (here: the candidate ordinals themselves); the
+   * second hands over first-stage scores and alpha for the SAME candidate lists and gets interpolated scores + carried words in
+   * final order -- the interpolation and the ordering alone.  Checked against the oracle's scores in the order found above. */
+  {
+    static float dense_ranked[N_Q * K], ranked[N_Q * K];
+    static int32_t dense_carry[N_Q * K], carry[N_Q * K];
+    CHECK(ffx_score_ranked(index, queries, N_Q, pair_off, pair_ids, NULL, pair_ids, FFX_MODE_MAXP, 0.0, FFX_FLAG_EXACT_SUM | FFX_FLAG_KEEP_DENSE,
+                           dense_ranked, dense_carry, NULL, &bad, NULL));
+    uint64_t token = 0;
+    int64_t kept_q = 0, kept_p = 0;
+    CHECK(ffx_index_kept(index, &token, &kept_q, &kept_p));
+    if (token == 0 || kept_q != N_Q || kept_p != pair_off[N_Q]) {
+      fprintf(stderr, "nothing kept after FFX_FLAG_KEEP_DENSE\n");
+      return 1;
+    }
+    for (int q = 0; q < N_Q; ++q)
+      for (int i = 1; i < K; ++i)
+        if (dense_ranked[q * K + i - 1] < dense_ranked[q * K + i]) {
+          fprintf(stderr, "dense scores of query %d are not in order\n", q);
+          return 1;
+        }
+    CHECK(ffx_rank_kept(index, token, N_Q, pair_off, sparse, alpha, FFX_FLAG_EXACT_SUM, ranked, carry, NULL, NULL));
+    for (int64_t p = 0; p < pair_off[N_Q]; ++p)
+      if (memcmp(&ranked[p], &want_interp[order[p]], sizeof(float)) != 0 || carry[p] != pair_ids[order[p]]) {
+        fprintf(stderr, "ffx_rank_kept differs from the oracle at rank %lld\n", (long long)p);
+        return 1;
+      }
+    if (ffx_rank_kept(index, token + 1, N_Q, pair_off, sparse, alpha, 0, ranked, carry, NULL, NULL) == FFX_OK) {
+      fprintf(stderr, "a stale token was accepted\n");
+      return 1;
+    }
+  }
+
   /* an id the index does not hold is reported with its position */
   pair_ids[321] = N_DOCS + 5;
   int rc = ffx_score(index, queries, N_Q, pair_off, pair_ids, sparse, FFX_MODE_MAXP, alpha, FFX_FLAG_EXACT_SUM, ff, interp,
