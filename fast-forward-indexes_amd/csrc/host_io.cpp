@@ -732,6 +732,57 @@ int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int3
   if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many values for int32 codes");
   int T = n_threads > 0 ? n_threads : usable_cores();
   T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 16) + 1}));
+  // A column of long RUNS -- the query-id and query-text columns of a run name each query through one object, k rows in a row --
+  // is numbered through its run heads: one streaming pass finds them, the few heads are numbered by the general scheme below
+  // (the numbers depend on the set of values only, so they are the numbers the whole column would get), and every row takes its
+  // head's number.  (Two of the three text columns of a 34.9 M-row run: ~0.2 s each by the general scheme.)
+  if (n >= (1 << 16)) {
+    try {
+      std::vector<std::vector<int64_t>> heads_of((size_t)T);
+      run_threads(T, [&](int t) {
+        auto& mine = heads_of[(size_t)t];
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (int64_t i = lo; i < hi; ++i)
+          if (i == 0 || values[i] != values[i - 1]) {
+            if ((int64_t)mine.size() > (hi - lo) / 64 + 16) return;  // no long runs here: give up early
+            mine.push_back(i);
+          }
+      });
+      int64_t H = 0;
+      bool long_runs = true;
+      for (int t = 0; t < T; ++t) {
+        const int64_t span = n * (t + 1) / T - n * t / T;
+        long_runs = long_runs && (int64_t)heads_of[(size_t)t].size() <= span / 64 + 16;
+        H += (int64_t)heads_of[(size_t)t].size();
+      }
+      if (long_runs && H <= n / 64) {
+        std::vector<int64_t> head((size_t)H + 1);
+        {
+          int64_t w = 0;
+          for (int t = 0; t < T; ++t)
+            for (const int64_t i : heads_of[(size_t)t]) head[(size_t)w++] = i;
+          head[(size_t)H] = n;
+        }
+        std::vector<uint64_t> head_value((size_t)H);
+        for (int64_t h = 0; h < H; ++h) head_value[(size_t)h] = values[head[(size_t)h]];
+        std::vector<int32_t> head_code((size_t)H);
+        std::vector<int64_t> head_first((size_t)H);
+        int64_t nd = 0;
+        const int rc = ffx_host_code_u64(head_value.data(), H, 1, head_code.data(), head_first.data(), &nd);  // (H < 2^16 or no runs: the general scheme)
+        if (rc != FFX_OK) return rc;
+        run_threads(T, [&](int t) {
+          for (int64_t h = H * t / T; h < H * (t + 1) / T; ++h) std::fill(codes + head[(size_t)h], codes + head[(size_t)h + 1], head_code[(size_t)h]);
+        });
+        for (int64_t c = 0; c < nd; ++c) first_row[c] = head[(size_t)head_first[(size_t)c]];
+        *n_distinct = nd;
+        return FFX_OK;
+      }
+    } catch (const std::bad_alloc&) {
+      return ffx_fail(FFX_OOM, "host allocation failed");
+    } catch (const std::system_error&) {
+      return ffx_fail(FFX_OOM, "could not start host threads");
+    }
+  }
   constexpr int S = 256;
   auto mix = [](uint64_t v) {
     v ^= v >> 33;

@@ -79,3 +79,20 @@ def test_code_u64_property(values, threads):
     assert first.shape[0] == uniq.shape[0]
     if v.shape[0]:
         assert np.array_equal(uniq[codes], v) and np.array_equal(v[first], uniq)
+
+
+@small
+@given(st.lists(st.tuples(st.integers(0, 40), st.integers(1, 9000)), min_size=1, max_size=60), st.integers(1, 4), st.booleans())
+def test_code_u64_on_columns_of_long_runs_and_mixed_columns(runs, threads, sprinkle):
+    """The run-head shortcut of ffx_host_code_u64 (a run's query-id column: thousands of rows in a row name one object) gives what
+    the general scheme gives -- dense numbers ascending with the values, first_row naming a row of each -- for columns of long
+    runs, columns where only a part is runs (a thread's range without long runs sends the whole column down the general path)
+    and values that come back in later runs."""
+    parts = [np.full(length, value, dtype=np.uint64) for value, length in runs]
+    if sprinkle:  # a stretch without runs in the middle
+        parts.insert(len(parts) // 2, np.arange(5000, dtype=np.uint64) % np.uint64(37) + np.uint64(100))
+    v = np.concatenate(parts) * np.uint64(48) + np.uint64(0x7F0000000000)
+    v = np.concatenate([v] * (1 + (1 << 16) // max(1, v.shape[0])))  # (the shortcut looks at columns of 65 536 rows and more)
+    codes, first = native.code_u64(v.ctypes.data, v.shape[0], threads)
+    uniq = np.unique(v)
+    assert first.shape[0] == uniq.shape[0] and np.array_equal(uniq[codes], v) and np.array_equal(v[first], uniq)
