@@ -908,6 +908,36 @@ int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int3
   }
 }
 
+// out[off[r] .. off[r+1]) = r for r = 0 .. n_runs-1 (numpy.repeat(arange(n_runs), diff(off)) as int64), by host threads: the
+// per-row query numbers of a run whose rows stand grouped by query -- 280 MB of fresh memory at 34.9 M rows, whose page faults
+// one thread takes a second over and sixteen do not.
+int ffx_host_fill_runs(const int64_t* off, int64_t n_runs, int32_t n_threads, int64_t* out) {
+  if (n_runs < 0 || (n_runs > 0 && (!off || !out))) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n_runs == 0) return FFX_OK;
+  if (off[0] != 0) return ffx_fail(FFX_BAD_ARG, "off[0] must be 0");
+  for (int64_t r = 0; r < n_runs; ++r)
+    if (off[r + 1] < off[r]) return ffx_fail(FFX_BAD_ARG, "off not monotone at %lld", (long long)r);
+  const int64_t n = off[n_runs];
+  int T = n_threads > 0 ? n_threads : usable_cores();
+  T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)T, (int64_t)64, n / (1 << 18) + 1}));
+  try {
+    run_threads(T, [&](int t) {  // threads take ranges of ROWS (runs differ in length); the first run of a range by binary search
+      const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+      if (lo >= hi) return;
+      int64_t r = std::upper_bound(off, off + n_runs + 1, lo) - off - 1;
+      for (int64_t i = lo; i < hi;) {
+        while (off[r + 1] <= i) ++r;
+        const int64_t end = std::min(hi, off[r + 1]);
+        std::fill(out + i, out + end, r);
+        i = end;
+      }
+    });
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+  return FFX_OK;
+}
+
 // Which rank of a sharded index holds row i: crc32 (the zlib / IEEE one, so that Python's zlib.crc32 names the same
 // rank) of its document id -- or, for a row without one, of its passage id -- modulo `world`.  Ids arrive as the
 // NUL-padded fixed-width fields an index file stores them in (numpy 'S<width>'; an empty field = no id).  Every rank

@@ -118,7 +118,7 @@ class _Run:
                 and np.array_equal(off, self.pair_off):
             q_no = self.q_no  # every row kept, the queries' blocks where they were: the ranking's own numbering (35 M int64 not written again)
         else:
-            q_no = np.repeat(np.arange(len(present), dtype=np.int64), counts_out)
+            q_no = native.run_numbers(np.concatenate([[0], np.cumsum(counts_out)]))
         texts = None if self.texts is None else [self.texts[q_lo + i] for i in present]
         if codes is None:
             codes = native.take32(self.codes, src) if src.dtype == np.int32 else self.codes[src]

@@ -39,7 +39,7 @@ SYMBOLS = (
 # ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
 PRIVATE_SYMBOLS = (
     "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
-    "ffx_index_prepare_score",
+    "ffx_index_prepare_score", "ffx_host_fill_runs",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_buffer_free",
@@ -150,6 +150,7 @@ def lib() -> C.CDLL:
         "ffx_index_upload_rows_async": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_pull_rows_async": ([vp, vp, i64, i64, vp, i64, i64], C.c_int),
         "ffx_index_prepare_score": ([vp, i64, i64, C.c_int32, C.c_int32, C.c_int32], C.c_int),
+        "ffx_host_fill_runs": ([vp, i64, C.c_int32, vp], C.c_int),
         "ffx_index_upload_after": ([vp, vp], C.c_int),
         "ffx_index_upload_wait": ([vp], C.c_int),
         "ffx_index_copy_rows": ([vp, vp, i64], C.c_int),
@@ -947,6 +948,20 @@ def page_locked_copy(a: np.ndarray) -> np.ndarray:
     if out.base is None:  # (an ordinary array came back: nothing gained by copying)
         return a
     np.copyto(out, a)
+    return out
+
+
+def run_numbers(off: np.ndarray, threads: int = 0) -> np.ndarray:
+    """``np.repeat(np.arange(len(off) - 1), np.diff(off))`` as int64 (``ffx_host_fill_runs``: host threads share the page
+    faults of the fresh array); small inputs take NumPy's route."""
+    off = _arr(off, np.int64)
+    n_runs = off.shape[0] - 1
+    if n_runs <= 0:
+        return np.zeros(0, dtype=np.int64)
+    if int(off[-1]) < (1 << 20):
+        return np.repeat(np.arange(n_runs, dtype=np.int64), np.diff(off))
+    out = np.empty(int(off[-1]), dtype=np.int64)
+    _check(lib().ffx_host_fill_runs(_ptr(off), n_runs, int(threads), _ptr(out)))
     return out
 
 

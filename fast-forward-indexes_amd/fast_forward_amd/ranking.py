@@ -334,7 +334,7 @@ class Ranking:
         if len(codes) and np.unique(codes[starts]).shape[0] == starts.shape[0]:
             firsts = codes[starts]  # rows of a query adjacent: the numbers follow the blocks
             block_off = np.concatenate([starts, [len(codes)]]).astype(np.int64)
-            q_no = np.repeat(np.arange(len(starts), dtype=np.int64), np.diff(block_off))
+            q_no = native.run_numbers(block_off)
         else:
             block_off = None
             q_no, firsts = pd.factorize(codes)

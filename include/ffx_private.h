@@ -166,6 +166,9 @@ int ffx_host_segment_rows_unique(const int32_t* ids, int64_t n, const int32_t* e
 int ffx_host_outer_join(const int64_t* off_a, const int32_t* code_a, const int64_t* off_b, const int32_t* code_b, int64_t n_queries,
                         int32_t n_threads, int64_t* u_off, int32_t* u_code, int32_t* u_a, int32_t* u_b);
 
+/* numpy.repeat(arange(n_runs), diff(off)) as int64 by host threads: out[off[r] .. off[r+1]) = r (the per-row query numbers of a run
+ * whose rows stand grouped by query; index/base.py:418-421 numbers queries in order of first appearance). */
+int ffx_host_fill_runs(const int64_t* off, int64_t n_runs, int32_t n_threads, int64_t* out);
 /* The allocations the first ffx_score / ffx_score_ranked call of an index would make on the way (its three plans and their
  * page-locked staging blocks, the kernel and result streams, the device buffers of a full slice), made now: a caller with
  * host work to do before its first call (Index.rerank resolves the ranking's ids) runs this beside it on another thread.
