@@ -507,6 +507,35 @@ int main(int argc, char** argv) {
     if (ffx_host_code_u64(vals.data(), n, 1, o1.data(), f1.data(), &c1) != FFX_OK || ffx_host_code_u64(vals.data(), n, 4, o4.data(), f4.data(), &c4) != FFX_OK || c1 != c4 || o1 != o4) return 1;
     for (int64_t c = 0; c < c1; ++c)
       if (vals[(size_t)f4[(size_t)c]] != vals[(size_t)f1[(size_t)c]] || (c > 0 && vals[(size_t)f4[(size_t)c]] <= vals[(size_t)f4[(size_t)c - 1]])) return 1;
+    // ... and a column of long RUNS (the run-head shortcut): the numbers the general scheme gives, by 1 and by 4 threads; the
+    // per-row run numbers (ffx_host_fill_runs) against a plain loop
+    {
+      std::vector<int64_t> run_off{0};
+      std::vector<uint64_t> runs;
+      while (run_off.back() < n) {
+        const int64_t len = std::min<int64_t>(n - run_off.back(), 1 + (int64_t)(rnd() % 9000));
+        runs.insert(runs.end(), (size_t)len, 0x7f0000000000ull + 48 * (uint64_t)(rnd() % 300));
+        run_off.push_back(run_off.back() + len);
+      }
+      std::vector<int32_t> r1((size_t)n), r4((size_t)n);
+      std::vector<int64_t> g1((size_t)n), g4((size_t)n);
+      int64_t d1 = 0, d4 = 0;
+      if (ffx_host_code_u64(runs.data(), n, 1, r1.data(), g1.data(), &d1) != FFX_OK || ffx_host_code_u64(runs.data(), n, 4, r4.data(), g4.data(), &d4) != FFX_OK ||
+          d1 != d4 || r1 != r4)
+        return 1;
+      for (int64_t i = 0; i < n; ++i)
+        if (r4[(size_t)i] < 0 || r4[(size_t)i] >= d4 || runs[(size_t)g4[(size_t)r4[(size_t)i]]] != runs[(size_t)i]) return 1;
+      for (int64_t c = 1; c < d4; ++c)
+        if (runs[(size_t)g4[(size_t)c]] <= runs[(size_t)g4[(size_t)c - 1]]) return 1;
+      const int64_t n_runs = (int64_t)run_off.size() - 1;
+      std::vector<int64_t> numbers((size_t)n, -1);
+      if (ffx_host_fill_runs(run_off.data(), n_runs, 4, numbers.data()) != FFX_OK) return 1;
+      for (int64_t r = 0; r < n_runs; ++r)
+        for (int64_t i = run_off[(size_t)r]; i < run_off[(size_t)r + 1]; ++i)
+          if (numbers[(size_t)i] != r) return 1;
+      run_off[1] = run_off[2] + 1;  // not monotone: refused
+      if (n_runs > 2 && ffx_host_fill_runs(run_off.data(), n_runs, 2, numbers.data()) != FFX_BAD_ARG) return 1;
+    }
     // strings: joined by a separator and back to back with offsets; the numbering depends on the set of strings only
     std::string blob, packed;
     std::vector<int64_t> soff{0};
