@@ -1588,6 +1588,11 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       FFX_EXP_LDS(919, 8, 8, true);
       FFX_EXP_LDS(920, 16, 16, true);
 #undef FFX_EXP_LDS
+      // the shipping kernel as a persistent grid (experiment, see gather_dot.hip.h): strided tiles / contiguous shares, 6 or 12 workgroups per CU
+      case 921: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, false><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 922: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 923: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, false><<<256 * 12, 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 924: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 16, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 951: ffx::gather_dot_fast_kernel<T, 3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 953: ffx::gather_dot_fast_kernel<T, 3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;

@@ -277,6 +277,93 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   }
 }
 
+// ---- experiment (FFX_DEBUG_VARIANT=gather=921 / 922 / 923, tools/kernel_ab.py): the same kernel as a PERSISTENT grid --------
+// gridDim.x workgroups stay for the whole launch and every wave walks tiles of the row list: CHUNKED = false: tile w, w + W,
+// w + 2 W ... (W waves in all); CHUNKED = true: a contiguous share of the tiles (consecutive rows: the query vector stays in
+// registers for ~k / TILE tiles).  Same arithmetic, same bits.  Question put to it: does the turnover of a million short-lived
+// workgroups (a workgroup's LDS and wave slots come free only when its last wave is done) cost bandwidth?
+template <typename T, int NCH, int U, int TILE, bool NT, bool CHUNKED>
+__global__ void __launch_bounds__(256)
+gather_dot_exact_lds_persistent_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
+                                       const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+  constexpr int D = 256 * NCH;
+  constexpr int LL = D / 8;
+  constexpr int NPER = LL / 8;
+  constexpr int LPAD = LL + 8;
+  static_assert(LL % 32 == 0 && LL <= 128, "8 leaves of at most 128 elements");
+  static_assert(TILE % U == 0 && TILE <= 64, "bad tile");
+  __shared__ __attribute__((aligned(16))) float tile[4][8 * LPAD];
+
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+  const long n_waves = (long)gridDim.x * (blockDim.x >> 6);
+  const long n_tiles = ((long)n_rows + TILE - 1) / TILE;
+  const long per_wave = (n_tiles + n_waves - 1) / n_waves;
+  long t_first = CHUNKED ? wave * per_wave : wave;
+  const long t_end = CHUNKED ? (t_first + per_wave < n_tiles ? t_first + per_wave : n_tiles) : n_tiles;
+  const long t_step = CHUNKED ? 1 : n_waves;
+
+  float* buf = tile[wave_in_block];
+  int woff[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = 4 * lane + 256 * c;
+    woff[c] = (e / LL) * LPAD + (e % LL);
+  }
+  const float* rbuf = buf + (lane >> 3) * LPAD + (lane & 7);
+  float4 q[NCH];
+  int cur_q = -1;
+#pragma unroll 1
+  for (long t = t_first; t < t_end; t += t_step) {
+    const long base = t * TILE;
+    const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
+    const int my_t = lane < n_here ? lane : n_here - 1;
+    const int2 my = desc[base + my_t];
+#pragma unroll 1
+    for (int b = 0; b < TILE; b += U) {
+      if (b >= n_here) break;
+      typename raw4<T>::type v[U][NCH];
+      int qn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int tt = (b + u) < n_here ? (b + u) : n_here - 1;
+        const int rid = __builtin_amdgcn_readlane(my.x, tt);
+        qn[u] = __builtin_amdgcn_readlane(my.y, tt);
+        const T* rowp = vectors + (size_t)rid * D + 4 * lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[u][c] = load4raw<T, NT>(rowp + 256 * c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (qn[u] != cur_q) {
+          cur_q = qn[u];
+          const float4* qp = reinterpret_cast<const float4*>(queries + (size_t)cur_q * D) + lane;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) q[c] = qp[64 * c];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const float4 w = widen4(v[u][c]);
+          float4 p;
+          p.x = __fmul_rn(q[c].x, w.x);
+          p.y = __fmul_rn(q[c].y, w.y);
+          p.z = __fmul_rn(q[c].z, w.z);
+          p.w = __fmul_rn(q[c].w, w.w);
+          *reinterpret_cast<float4*>(buf + woff[c]) = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float acc = rbuf[0];
+#pragma unroll
+        for (int i = 1; i < NPER; ++i) acc = __fadd_rn(acc, rbuf[8 * i]);
+        __builtin_amdgcn_wave_barrier();
+        acc = butterfly<8>(acc);
+        if (lane == 0 && (b + u) < n_here) rs[base + b + u] = acc;
+      }
+    }
+  }
+}
+
 // ---- the same for smaller rows: d = 8*LEAVES*NPER with LEAVES in {1,2,4}, NPER % 4 == 0 ----------
 // (d = 512, 384, 256, 128, 64, ...).  NumPy's tree for such a row has 8*LEAVES partial sums, so
 // RPP = 8/LEAVES rows fill a wave.  A pass takes RPP consecutive work rows and treats them as ONE
