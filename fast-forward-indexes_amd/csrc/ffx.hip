@@ -1593,6 +1593,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       case 922: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 923: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, false><<<256 * 12, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 924: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 16, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 925: ffx::gather_dot_exact_lds_kernel<T, 3, 4, 8, true><<<blocks_for(waves, 2 * 8), 128, 0, st>>>(V, Q, desc, rs, R); break;  // workgroups of two waves
       case 951: ffx::gather_dot_fast_kernel<T, 3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 953: ffx::gather_dot_fast_kernel<T, 3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
