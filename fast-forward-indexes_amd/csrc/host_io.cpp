@@ -7,63 +7,25 @@
 //   ffx_ids_*  an insertion-ordered string -> ordinal table (open addressing, FNV-1a)
 //   ffx_run_*  a TREC run parsed straight into the CSR the kernels take, and written back
 // No device code here; plain C++17.
-#include <sched.h>
-
-#include <algorithm>
 #include <atomic>
 #include <cctype>
-#include <charconv>
 #include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <new>
 #include <numeric>
-#include <string>
-#include <string_view>
 #include <system_error>
-#include <thread>
-#include <vector>
 
-#include "../../include/ffx.h"
-#include "../../include/ffx_private.h"
+#include "host_util.h"
+#include "string_code.h"
 
-int ffx_fail(int code, const char* fmt, ...);  // ffx.hip: records the thread's last error
+using namespace ffx_host;
+
+namespace ffx_host {
+std::string& stage_report() {
+  static thread_local std::string report;
+  return report;
+}
+}  // namespace ffx_host
 
 namespace {
-
-// cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container on a
-// 256-core host is often allowed 16; 128 threads on that quota crawl)
-inline int usable_cores() {
-  int n = (int)std::max(1u, std::thread::hardware_concurrency());
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    char quota[32];
-    long period = 0;
-    if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
-      n = std::min(n, std::max(1, (int)((atol(quota) + period / 2) / period)));
-    fclose(f);
-  }
-  return n;
-}
-
-// body(t) for t in 0..T-1, t = 0 on the calling thread.  If a thread cannot be started, the ones already running are
-// joined before the std::system_error goes on to the caller (a std::thread destroyed while joinable ends the process).
-template <class Body>
-void run_threads(int T, Body&& body) {
-  std::vector<std::thread> pool;
-  pool.reserve(T > 1 ? (size_t)(T - 1) : 0);
-  try {
-    for (int t = 1; t < T; ++t) pool.emplace_back([&body, t] { body(t); });
-  } catch (...) {
-    for (auto& th : pool) th.join();
-    throw;
-  }
-  body(0);
-  for (auto& th : pool) th.join();
-}
 
 // bits[r / 64] |= 1 << (r % 64) for every row number in rows[0 .. n) (all valid): threads take blocks of the list, the
 // updates are atomic.  (Tried: no atomics, every thread reading the whole list and setting the bits of its own share of the
@@ -76,146 +38,6 @@ void mark_rows(uint64_t* bits, const Int* rows, int64_t n, int T) {
   });
 }
 
-inline uint64_t fnv1a(const char* p, size_t n) {
-  uint64_t h = 1469598103934665603ull;
-  for (size_t i = 0; i < n; ++i) {
-    h ^= (unsigned char)p[i];
-    h *= 1099511628211ull;
-  }
-  return h ^ (h >> 29);
-}
-
-}  // namespace
-
-// insertion-ordered interning table: ordinal = order of first insertion
-struct ffx_ids {
-  std::vector<char> arena;
-  std::vector<uint64_t> off;   // off[i]..off[i+1] = bytes of string i
-  std::vector<int32_t> slots;  // open addressing, -1 = empty
-  size_t mask = 0;
-
-  ffx_ids() { off.push_back(0); rehash(1024); }
-  int64_t size() const { return (int64_t)off.size() - 1; }
-  std::string_view get(int32_t i) const { return {arena.data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i])}; }
-  void rehash(size_t cap) {
-    slots.assign(cap, -1);
-    mask = cap - 1;
-    for (int32_t i = 0; i < (int32_t)size(); ++i) {
-      const std::string_view s = get(i);
-      size_t h = fnv1a(s.data(), s.size()) & mask;
-      while (slots[h] >= 0) h = (h + 1) & mask;
-      slots[h] = i;
-    }
-  }
-  int32_t find(std::string_view s) const {
-    size_t h = fnv1a(s.data(), s.size()) & mask;
-    while (true) {
-      const int32_t i = slots[h];
-      if (i < 0) return -1;
-      if (get(i) == s) return i;
-      h = (h + 1) & mask;
-    }
-  }
-  int32_t intern(std::string_view s) {
-    size_t h = fnv1a(s.data(), s.size()) & mask;
-    while (true) {
-      const int32_t i = slots[h];
-      if (i < 0) break;
-      if (get(i) == s) return i;
-      h = (h + 1) & mask;
-    }
-    const int32_t id = (int32_t)size();
-    arena.insert(arena.end(), s.begin(), s.end());
-    off.push_back(arena.size());
-    slots[h] = id;
-    if ((size_t)size() * 10 > slots.size() * 6) rehash(slots.size() * 2);
-    return id;
-  }
-};
-
-// one parsed TREC run: rows grouped by query (order of first appearance), rows of a query in file order
-struct ffx_run {
-  ffx_ids qids;                     // query ids in order of first appearance
-  std::vector<int64_t> pair_off;    // [Q+1]
-  std::vector<int32_t> pair_ids;    // ordinal in the id table given to ffx_run_open
-  std::vector<float> score;
-  std::string tag;                  // last column of the first line (Ranking.name, ranking.py:409)
-  const ffx_ids* ids = nullptr;     // borrowed: candidate id strings for writing
-  // opened without an id table (Ranking.from_file): the candidate ids stay views into the file text
-  std::string text;
-  std::vector<std::string_view> pair_view;
-  int32_t q_flags = 0, id_flags = 0, misc_flags = 0;
-};
-
-namespace {
-
-// What pandas.read_csv would make of a column holding this token (it decides per column, so the
-// caller ORs the classes of all tokens): an integer it prints back unchanged, another number or
-// boolean (printed back differently, or only when the whole column is like that), one of its NA
-// words, or plain text.
-inline int token_class(std::string_view t) {
-  static const char* const na_words[] = {"#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN",
-                                         "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
-  if (t.empty()) return FFX_TOKEN_TEXT;
-  // (called once per row of a run file: the common cases -- "D1234", "1234" -- are decided on their first byte)
-  const char c0 = t[0];
-  if (c0 == '#' || c0 == '-' || c0 == '1' || c0 == '<' || c0 == 'N' || c0 == 'n')
-    for (const char* w : na_words)
-      if (t == w) return FFX_TOKEN_NA;
-  size_t i = 0;
-  if (i < t.size() && t[i] == '-') ++i;
-  const size_t digits_from = i;
-  while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i;
-  if (i == t.size() && i > digits_from && i - digits_from <= 18 && (t[digits_from] != '0' || (i - digits_from == 1 && digits_from == 0)))
-    return FFX_TOKEN_INT;
-  {
-    // a number or boolean starts (after a sign) with a digit, a point, or the first letter of inf / nan / true / false
-    const char c1 = (c0 == '-' || c0 == '+') ? (t.size() > 1 ? t[1] : '\0') : c0;
-    const bool maybe = (c1 >= '0' && c1 <= '9') || c1 == '.' || c1 == 'i' || c1 == 'I' || c1 == 'n' || c1 == 'N' || c1 == 't' || c1 == 'T' ||
-                       c1 == 'f' || c1 == 'F';
-    if (!maybe) return FFX_TOKEN_TEXT;
-  }
-  std::string tmp(t);
-  for (char& c : tmp) c = (char)tolower((unsigned char)c);
-  if (tmp == "true" || tmp == "false") return FFX_TOKEN_NUMBER;
-  char* endp = nullptr;
-  (void)strtod(tmp.c_str(), &endp);
-  if (endp == tmp.c_str() + tmp.size() && !tmp.empty()) return FFX_TOKEN_NUMBER;
-  return FFX_TOKEN_TEXT;
-}
-
-// A score field as pandas.read_csv would take it: 0 = a plain decimal number or an infinity (strtod
-// and pandas agree on those), 1 = one of pandas' NA words (the row is dropped, ranking.py:103),
-// 2 = anything else -- hexadecimal floats, "nan(123)", "NAN", ... -- which strtod would accept but
-// pandas would not read as a number: the caller rejects the file so that the pandas route decides.
-inline int score_token_kind(std::string_view t) {
-  size_t i = 0;
-  if (i < t.size() && (t[i] == '-' || t[i] == '+')) ++i;
-  const bool digit_first = i < t.size() && ((t[i] >= '0' && t[i] <= '9') || t[i] == '.');
-  if (!digit_first) {  // words: pandas' NA spellings, infinities, anything else
-    if (token_class(t) == FFX_TOKEN_NA) return 1;
-    std::string low(t.substr(i));
-    for (char& c : low) c = (char)tolower((unsigned char)c);
-    return (low == "inf" || low == "infinity") ? 0 : 2;
-  }
-  size_t digits = 0;
-  while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++digits;
-  if (i < t.size() && t[i] == '.') {
-    ++i;
-    while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++digits;
-  }
-  if (digits == 0) return 2;
-  if (i < t.size() && (t[i] == 'e' || t[i] == 'E')) {
-    ++i;
-    if (i < t.size() && (t[i] == '-' || t[i] == '+')) ++i;
-    size_t exp_digits = 0;
-    while (i < t.size() && t[i] >= '0' && t[i] <= '9') ++i, ++exp_digits;
-    if (exp_digits == 0) return 2;
-  }
-  if (i == t.size()) return 0;
-  return token_class(t) == FFX_TOKEN_NA ? 1 : 2;  // "1.#IND", "-1.#QNAN", ... start like numbers
-}
-
 inline std::string_view fixed_width(const char* base, int32_t width, int64_t i) {
   const char* p = base + (size_t)i * width;
   size_t n = 0;
@@ -223,258 +45,7 @@ inline std::string_view fixed_width(const char* base, int32_t width, int64_t i) 
   return {p, n};
 }
 
-// shortest round-trip decimal of a float, laid out like numpy's str(np.float32), which is
-// what pandas.to_csv writes for a float32 column (ranking.py:360-366)
-void append_float_repr(std::string& out, float v) {
-  if (std::isnan(v)) { out += "nan"; return; }
-  if (std::isinf(v)) { out += v < 0 ? "-inf" : "inf"; return; }
-  char buf[48];
-  auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
-  std::string_view s(buf, (size_t)(r.ptr - buf));  // d[.ddd]e[+-]XX
-  bool neg = false;
-  if (!s.empty() && s[0] == '-') { neg = true; s.remove_prefix(1); }
-  const size_t e = s.find('e');
-  std::string digits;
-  for (char c : s.substr(0, e)) if (c != '.') digits.push_back(c);
-  int exp10 = 0;
-  std::from_chars(s.data() + e + 1 + (s[e + 1] == '+' ? 1 : 0), s.data() + s.size(), exp10);
-  if (neg) out.push_back('-');
-  // numpy switches to scientific on the VALUE (|v| < 1e-4 or >= 1e16), not on the decimal exponent
-  // of the shortest digits: float32(1e-4) = 9.99999975e-05 prints as 1e-04
-  const double mag = std::fabs((double)v);
-  if ((mag != 0 && mag < 1e-4) || mag >= 1e16) {
-    out.push_back(digits[0]);
-    if (digits.size() > 1) { out.push_back('.'); out.append(digits, 1, std::string::npos); }
-    char eb[8];
-    snprintf(eb, sizeof eb, "e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10) % 1000);  // a float's decimal exponent has two digits
-    out += eb;
-  } else if (exp10 < 0) {
-    out += "0.";
-    out.append((size_t)(-exp10 - 1), '0');
-    out += digits;
-  } else {
-    const size_t int_len = (size_t)exp10 + 1;
-    if (digits.size() <= int_len) {
-      out += digits;
-      out.append(int_len - digits.size(), '0');
-      out += ".0";
-    } else {
-      out.append(digits, 0, int_len);
-      out.push_back('.');
-      out.append(digits, int_len, std::string::npos);
-    }
-  }
-}
-
-// The run writers format lines by threads and write them in order: queries are handed out in batches of about
-// 64K lines per thread; while one round of buffers is written to the file the next round is being formatted.
-// format(q_lo, q_hi, out) appends the lines of queries q_lo .. q_hi-1 to `out`.
-template <class Format>
-int write_formatted(FILE* f, const char* path, int64_t n_queries, int64_t n_rows, Format format) {
-  const int T = (int)std::min<int64_t>(std::max(1, std::min(32, usable_cores())), std::max<int64_t>(1, n_rows >> 15));
-  std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)T), std::vector<std::string>((size_t)T)};
-  int used[2] = {0, 0};
-  bool ok = true;
-  std::atomic<bool> oom(false);
-  try {
-    const int64_t avg = std::max<int64_t>(1, n_rows / std::max<int64_t>(1, n_queries));
-    const int64_t q_per_thread = std::max<int64_t>(1, (64 << 10) / avg);
-    int round = 0;
-    for (int64_t q0 = 0; (q0 < n_queries || used[(round + 1) & 1] > 0) && ok; q0 += q_per_thread * T, ++round) {
-      std::vector<std::string>& mine = bufs[round & 1];
-      std::vector<std::thread> pool;
-      pool.reserve((size_t)T);
-      used[round & 1] = 0;
-      try {
-        for (int t = 0; t < T; ++t) {
-          const int64_t lo = q0 + t * q_per_thread, hi = std::min(n_queries, lo + q_per_thread);
-          if (lo >= hi) break;
-          pool.emplace_back([&format, &oom, lo, hi, buf = &mine[(size_t)t]] {
-            try {
-              format(lo, hi, *buf);
-            } catch (const std::bad_alloc&) {  // (an exception leaving a thread would end the process)
-              oom.store(true);
-            }
-          });
-          ++used[round & 1];
-        }
-      } catch (...) {  // join what was started before the error goes on
-        for (auto& th : pool) th.join();
-        throw;
-      }
-      // meanwhile: the previous round's buffers go to the file
-      std::vector<std::string>& prev = bufs[(round + 1) & 1];
-      for (int t = 0; t < used[(round + 1) & 1] && ok; ++t)
-        ok = prev[(size_t)t].empty() || fwrite(prev[(size_t)t].data(), 1, prev[(size_t)t].size(), f) == prev[(size_t)t].size();
-      used[(round + 1) & 1] = 0;
-      for (auto& th : pool) th.join();
-      if (oom.load()) throw std::bad_alloc();
-    }
-  } catch (const std::bad_alloc&) {
-    fclose(f);
-    return ffx_fail(FFX_OOM, "host allocation failed while writing %s", path);
-  } catch (const std::system_error&) {
-    fclose(f);
-    return ffx_fail(FFX_OOM, "could not start host threads while writing %s", path);
-  }
-  if (!ok) {
-    fclose(f);
-    return ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
-  }
-  return fclose(f) == 0 ? FFX_OK : ffx_fail(FFX_BAD_ARG, "write to %s failed", path);
-}
-
 }  // namespace
-
-// steps 2 - 5 of ffx_strings_code for n strings given as view(i) -> std::string_view (hashes, shards, per-shard
-// numbering, global numbers + the distinct strings joined by sep)
-template <class View>
-static int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, char** names_blob, int64_t* names_bytes, int64_t* n_names) {
-  constexpr int S = 256;
-  auto in_threads = [&](auto&& body) { run_threads(T, body); };
-  {
-    // 2. hashes, and how many rows of every row range fall into every shard
-    std::vector<uint64_t> hash((size_t)n);
-    std::vector<int64_t> count((size_t)T * S, 0);
-    auto row_range = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
-    in_threads([&](int t) {
-      const auto [lo, hi] = row_range(t);
-      int64_t* c = count.data() + (size_t)t * S;
-      for (int64_t i = lo; i < hi; ++i) {
-        const std::string_view v = view(i);
-        uint64_t h = fnv1a(v.data(), v.size());
-        h ^= h >> 29;
-        h *= 0xbf58476d1ce4e5b9ull;  // fnv's high bits are weak on short numeric strings: mix before taking the shard from them
-        h ^= h >> 32;
-        hash[(size_t)i] = h;
-        ++c[h >> 56];
-      }
-    });
-    // 3. rows dealt into shards, row order kept inside a shard
-    std::vector<int64_t> shard_off((size_t)S + 1, 0);
-    {
-      int64_t at = 0;
-      for (int s = 0; s < S; ++s) {
-        shard_off[(size_t)s] = at;
-        for (int t = 0; t < T; ++t) {
-          const int64_t c = count[(size_t)t * S + s];
-          count[(size_t)t * S + s] = at;  // becomes: where range t writes its rows of shard s
-          at += c;
-        }
-      }
-      shard_off[(size_t)S] = at;
-    }
-    std::vector<int32_t> rows((size_t)n);
-    in_threads([&](int t) {
-      const auto [lo, hi] = row_range(t);
-      int64_t* at = count.data() + (size_t)t * S;
-      for (int64_t i = lo; i < hi; ++i) rows[(size_t)at[hash[(size_t)i] >> 56]++] = (int32_t)i;
-    });
-    // 4. every shard numbered on its own; codes[] holds shard-local numbers for now
-    std::vector<std::vector<int32_t>> firsts((size_t)S);  // first row of every distinct string of the shard, in number order
-    std::vector<int64_t> shard_bytes((size_t)S, 0);
-    std::atomic<int> next_shard(0);
-    std::atomic<bool> oom(false);
-    in_threads([&](int) {
-      try {
-        std::vector<int32_t> slot;
-        for (;;) {
-          const int s = next_shard.fetch_add(1);
-          if (s >= S) return;
-          const int64_t lo = shard_off[(size_t)s], hi = shard_off[(size_t)s + 1];
-          size_t cap = 16;
-          while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
-          slot.assign(cap, -1);  // slot -> shard-local number
-          auto& first = firsts[(size_t)s];
-          int64_t bytes = 0;
-          for (int64_t k = lo; k < hi; ++k) {
-            const int32_t i = rows[(size_t)k];
-            const uint64_t h = hash[(size_t)i];
-            const std::string_view v = view(i);
-            size_t at = (size_t)(h >> 8) & (cap - 1);
-            for (;;) {
-              const int32_t have = slot[at];
-              if (have < 0) {
-                slot[at] = (int32_t)first.size();
-                codes[i] = (int32_t)first.size();
-                first.push_back(i);
-                bytes += (int64_t)v.size();
-                break;
-              }
-              const int32_t j = first[(size_t)have];
-              if (hash[(size_t)j] == h && view(j) == v) {
-                codes[i] = have;
-                break;
-              }
-              at = (at + 1) & (cap - 1);
-            }
-          }
-          shard_bytes[(size_t)s] = bytes;
-        }
-      } catch (const std::bad_alloc&) {
-        oom.store(true);
-      }
-    });
-    if (oom.load()) return ffx_fail(FFX_OOM, "host allocation failed");
-    // 5. shard-local numbers -> global numbers; the names written shard by shard
-    std::vector<int64_t> base((size_t)S + 1, 0), at_byte((size_t)S + 1, 0);
-    for (int s = 0; s < S; ++s) {
-      base[(size_t)s + 1] = base[(size_t)s] + (int64_t)firsts[(size_t)s].size();
-      at_byte[(size_t)s + 1] = at_byte[(size_t)s] + shard_bytes[(size_t)s] + (int64_t)firsts[(size_t)s].size();  // + one separator each
-    }
-    const int64_t total = at_byte[(size_t)S];  // one separator too many (after the last name)
-    char* blob = static_cast<char*>(malloc((size_t)std::max<int64_t>(total, 1)));
-    if (!blob) return ffx_fail(FFX_OOM, "host allocation failed");
-    next_shard.store(0);
-    in_threads([&](int) {
-      try {
-      for (;;) {
-        const int s = next_shard.fetch_add(1);
-        if (s >= S) return;
-        const int32_t b = (int32_t)base[(size_t)s];
-        // Inside the shard the strings are numbered by (hash, bytes), not by first appearance: the numbering then
-        // depends on the SET of strings only -- not on the order of the rows, the thread count or (for strings that
-        // were gathered through their object addresses first) the process.  Ranks of a sharded index number the same
-        // ids alike and can talk about them by number.
-        auto& first = firsts[(size_t)s];
-        std::vector<int32_t> by_content(first.size()), renumber(first.size());
-        for (size_t j = 0; j < first.size(); ++j) by_content[j] = (int32_t)j;
-        std::sort(by_content.begin(), by_content.end(), [&](int32_t x, int32_t y) {
-          const uint64_t hx = hash[(size_t)first[(size_t)x]], hy = hash[(size_t)first[(size_t)y]];
-          return hx != hy ? hx < hy : view(first[(size_t)x]) < view(first[(size_t)y]);
-        });
-        for (size_t j = 0; j < first.size(); ++j) renumber[(size_t)by_content[j]] = (int32_t)j;
-        {
-          std::vector<int32_t> sorted(first.size());
-          for (size_t j = 0; j < first.size(); ++j) sorted[j] = first[(size_t)by_content[j]];
-          first.swap(sorted);
-        }
-        for (int64_t k = shard_off[(size_t)s]; k < shard_off[(size_t)s + 1]; ++k) {
-          int32_t& c = codes[rows[(size_t)k]];
-          c = renumber[(size_t)c] + b;
-        }
-        char* w = blob + at_byte[(size_t)s];
-        for (const int32_t i : firsts[(size_t)s]) {
-          const std::string_view v = view(i);
-          memcpy(w, v.data(), v.size());
-          w += v.size();
-          *w++ = sep;
-        }
-      }
-      } catch (const std::bad_alloc&) {  // (an exception leaving a thread would end the process)
-        oom.store(true);
-      }
-    });
-    if (oom.load()) {
-      free(blob);
-      return ffx_fail(FFX_OOM, "host allocation failed");
-    }
-    *names_blob = blob;
-    *names_bytes = total - 1;
-    *n_names = base[(size_t)S];
-    return FFX_OK;
-  }
-}
 
 extern "C" {
 
@@ -561,36 +132,27 @@ int ffx_ids_lookup_packed(const ffx_ids* t, const char* data, int64_t n_bytes, c
     int64_t mine = INT64_MAX;
     constexpr int B = 8;
     std::string_view sv[B];
-    size_t h[B];
-    int32_t cand[B];
+    uint64_t h[B];
     for (int64_t done = 0; done < owned;) {
       const int nb = (int)std::min<int64_t>(B, owned - done);
       for (int b2 = 0; b2 < nb; ++b2) {
         const char* q = static_cast<const char*>(memchr(p, sep, (size_t)(buf_end - p)));
         const char* e = q ? q : buf_end;
         sv[b2] = std::string_view(p, (size_t)(e - p));
-        h[b2] = fnv1a(p, (size_t)(e - p)) & t->mask;
-        __builtin_prefetch(&t->slots[h[b2]]);
+        h[b2] = fnv1a(p, (size_t)(e - p));
+        __builtin_prefetch(&t->slots[h[b2] & t->mask]);
         p = e + 1;
       }
-      for (int b2 = 0; b2 < nb; ++b2) {
-        cand[b2] = t->slots[h[b2]];
-        if (cand[b2] >= 0) __builtin_prefetch(&t->off[(size_t)cand[b2]]);
+      for (int b2 = 0; b2 < nb; ++b2) {  // (a slot says whose string it holds: the right one, almost always)
+        const uint64_t v = t->slots[h[b2] & t->mask];
+        if (v != 0) __builtin_prefetch(&t->off[(size_t)((uint32_t)v - 1)]);
       }
-      for (int b2 = 0; b2 < nb; ++b2)
-        if (cand[b2] >= 0) __builtin_prefetch(t->arena.data() + t->off[(size_t)cand[b2]]);
       for (int b2 = 0; b2 < nb; ++b2) {
-        size_t hh = h[b2];
-        int32_t o = -1;
-        while (true) {
-          const int32_t c = t->slots[hh];
-          if (c < 0) break;
-          if (t->get(c) == sv[b2]) {
-            o = c;
-            break;
-          }
-          hh = (hh + 1) & t->mask;
-        }
+        const uint64_t v = t->slots[h[b2] & t->mask];
+        if (v != 0) __builtin_prefetch(t->arena.data() + t->off[(size_t)((uint32_t)v - 1)]);
+      }
+      for (int b2 = 0; b2 < nb; ++b2) {
+        const int32_t o = t->find_hashed(sv[b2], h[b2]);
         out_ordinals[first + done + b2] = o;
         if (o < 0 && mine == INT64_MAX) mine = first + done + b2;
       }
@@ -1470,6 +1032,15 @@ int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queri
 // caller sees to it that the destination blocks do not overlap.
 int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries, int32_t n_threads,
                           int32_t* out_order) {
+  return ffx_host_rank_blocks(scores, nullptr, pair_off, dst_off, n_queries, n_threads, out_order, nullptr, nullptr);
+}
+
+// ffx_host_order_blocks with the columns moved along in the same pass: out_scores / out_carry receive the scores and a
+// second 4-byte column (the id codes) of every query in its final order at the query's destination block -- while the
+// query's 5000 words are in the core's cache, instead of two gathers over the whole run afterwards.  The constructor's sort
+// (ranking.py:115-117) of a run that stands grouped by query, in one pass.  Any output may be NULL.
+int ffx_host_rank_blocks(const float* scores, const int32_t* carry, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries,
+                         int32_t n_threads, int32_t* out_order, float* out_scores, int32_t* out_carry) {
   if (!pair_off || n_queries < 0 || pair_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "bad argument");
   if (dst_off)
     for (int64_t q = 0; q < n_queries; ++q)
@@ -1478,7 +1049,7 @@ int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const in
     if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
   const int64_t P = pair_off[n_queries];
   if (P > INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many pairs");
-  if (P > 0 && (!scores || !out_order)) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  if (P > 0 && (!scores || (out_carry && !carry))) return ffx_fail(FFX_BAD_ARG, "NULL argument");
   auto image = [](float x) -> uint32_t {  // larger score <=> larger image
     uint32_t b;
     memcpy(&b, &x, sizeof b);
@@ -1534,8 +1105,13 @@ int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const in
             }
             if (from != keys.data()) keys.swap(other);
           }
-          int32_t* dst = out_order + (dst_off ? dst_off[q] : lo);
-          for (int64_t i = 0; i < n; ++i) dst[i] = (int32_t)(lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu));
+          const int64_t at = dst_off ? dst_off[q] : lo;
+          if (out_order)
+            for (int64_t i = 0; i < n; ++i) out_order[at + i] = (int32_t)(lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu));
+          if (out_scores)
+            for (int64_t i = 0; i < n; ++i) out_scores[at + i] = scores[lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu)];
+          if (out_carry)
+            for (int64_t i = 0; i < n; ++i) out_carry[at + i] = carry[lo + (int64_t)(keys[(size_t)i] & 0xFFFFFFFFu)];
         }
       }
     } catch (const std::bad_alloc&) {
@@ -1559,473 +1135,12 @@ int ffx_ids_get(const ffx_ids* t, int32_t ordinal, const char** str, int32_t* le
   return FFX_OK;
 }
 
-// ---- TREC run files ---------------------------------------------------------------------------------
-// Line format (Ranking.from_file, ranking.py:400-409): q_id Q0 id rank score name, any whitespace.
-// Candidate ids are resolved against `ids` while parsing; the first unknown id is FFX_NOT_FOUND with
-// its 1-based line number in *bad_line (the reference's IndexError, index/util.py:38-39).
-// A (query, id) pair that appears twice is FFX_BAD_ARG (ValueError, ranking.py:95-98).
-int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* bad_line) {
-  if (bad_line) *bad_line = -1;
-  if (!path || !out) return ffx_fail(FFX_BAD_ARG, "NULL argument");
-  *out = nullptr;
-  const bool standalone = ids == nullptr;  // keep the id strings instead of resolving them
-  FILE* f = fopen(path, "rb");
-  if (!f) return ffx_fail(FFX_BAD_ARG, "cannot open %s", path);
-  std::string data;
-  try {
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    data.resize(sz > 0 ? (size_t)sz : 0);
-    if (sz > 0 && fread(data.data(), 1, (size_t)sz, f) != (size_t)sz) {
-      fclose(f);
-      return ffx_fail(FFX_BAD_ARG, "short read on %s", path);
-    }
-  } catch (const std::bad_alloc&) {
-    fclose(f);
-    return ffx_fail(FFX_OOM, "run file does not fit in memory");
-  }
-  fclose(f);
-
-  ffx_run* run = new (std::nothrow) ffx_run();
-  if (!run) return ffx_fail(FFX_OOM, "host allocation failed");
-  run->ids = ids;
-  std::vector<int32_t> row_q, row_id;
-  std::vector<std::string_view> row_view;
-  std::vector<float> row_s;
-  int rc = FFX_OK;
-  // The file is cut into pieces at line ends and the pieces are tokenised, resolved against the
-  // (read-only) id table and converted in parallel; query ids are run-length encoded per piece
-  // and interned afterwards in file order, so numbering and errors are those of a serial pass.
-  struct Piece {
-    const char *begin = nullptr, *end = nullptr;
-    std::vector<int32_t> id;
-    std::vector<std::string_view> id_view;  // standalone mode
-    int32_t q_flags = 0, id_flags = 0, misc_flags = 0;
-    std::vector<float> score;
-    std::vector<std::pair<std::string_view, int64_t>> q_runs;  // (query id, consecutive rows)
-    std::string_view tag;
-    int64_t lines = 0;
-    int err = FFX_OK;  // first problem of the piece
-    int64_t err_line = 0;
-    std::string err_text;
-    bool oom = false;
-  };
-  if (standalone) {
-    run->text = std::move(data);  // the id views point into it
-    if (memchr(run->text.data(), '"', run->text.size())) run->misc_flags |= FFX_RUN_QUOTES;
-  }
-  const std::string& text = standalone ? run->text : data;
-  const char* const base = text.data();
-  const char* const end = base + text.size();
-  const int T = (int)std::min<size_t>((size_t)std::max(1, std::min(32, usable_cores())), std::max<size_t>(1, text.size() >> 20));
-  std::vector<Piece> pieces((size_t)T);
-  {
-    const char* cut = base;
-    for (int t = 0; t < T; ++t) {
-      pieces[(size_t)t].begin = cut;
-      const char* want = t + 1 == T ? end : base + text.size() * (size_t)(t + 1) / (size_t)T;
-      if (want < cut) want = cut;
-      if (want < end) {
-        const char* nl = (const char*)memchr(want, '\n', (size_t)(end - want));
-        want = nl ? nl + 1 : end;
-      }
-      pieces[(size_t)t].end = cut = want;
-    }
-  }
-  auto parse = [&](Piece& pc) {
-    auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r'; };
-    try {
-      const char* p = pc.begin;
-      while (p < pc.end) {
-        const char* eol = (const char*)memchr(p, '\n', (size_t)(pc.end - p));
-        if (!eol) eol = pc.end;
-        ++pc.lines;
-        std::string_view field[6];
-        int nf = 0;
-        const char* c = p;
-        while (c < eol && nf < 6) {
-          while (c < eol && is_space(*c)) ++c;
-          if (c >= eol) break;
-          const char* s0 = c;
-          while (c < eol && !is_space(*c)) ++c;
-          field[nf++] = {s0, (size_t)(c - s0)};
-        }
-        p = eol + 1;
-        if (nf == 0) continue;  // blank line
-        if (nf < 5) {
-          pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "expected 'q_id Q0 id rank score [name]'";
-          return;
-        }
-        const int score_kind = score_token_kind(field[4]);
-        if (score_kind == 2) {
-          pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
-          return;
-        }
-        if (score_kind == 1) continue;  // a missing score: the reference drops the row (ranking.py:103)
-        int32_t o = 0;
-        if (standalone) {
-          pc.id_flags |= token_class(field[2]);
-          if (pc.q_runs.empty() || pc.q_runs.back().first != field[0]) pc.q_flags |= token_class(field[0]);
-          if (nf < 6) pc.misc_flags |= FFX_RUN_SHORT_LINE;
-          for (const char* x = c; x < eol; ++x)
-            if (!is_space(*x)) pc.misc_flags |= FFX_RUN_LONG_LINE;
-        } else {
-          o = ids->find(field[2]);
-          if (o < 0) {
-            pc.err = FFX_NOT_FOUND, pc.err_line = pc.lines, pc.err_text.assign(field[2]);
-            return;
-          }
-        }
-        // correctly rounded double, then float32 (what read_csv + the constructor's cast give); from_chars is
-        // several times faster than strtod and needs no terminator; it takes no leading '+'
-        double sc = 0.0;
-        {
-          const char* s0 = field[4].data();
-          const char* s1 = s0 + field[4].size();
-          if (s0 < s1 && *s0 == '+') ++s0;
-          const auto res = std::from_chars(s0, s1, sc);
-          if (res.ec == std::errc::result_out_of_range) {  // strtod's answer for these: +-inf / +-0
-            char* endp = nullptr;
-            sc = strtod(field[4].data(), &endp);  // (the buffer ends in NUL and a field ends at white space)
-            if (endp != s1) {
-              pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
-              return;
-            }
-          } else if (res.ec != std::errc() || res.ptr != s1) {
-            pc.err = FFX_BAD_ARG, pc.err_line = pc.lines, pc.err_text = "bad score '" + std::string(field[4]) + "'";
-            return;
-          }
-        }
-        if (pc.tag.data() == nullptr && nf >= 6) pc.tag = field[5];
-        if (pc.q_runs.empty() || pc.q_runs.back().first != field[0]) pc.q_runs.emplace_back(field[0], 0);
-        ++pc.q_runs.back().second;
-        if (standalone)
-          pc.id_view.push_back(field[2]);
-        else
-          pc.id.push_back(o);
-        pc.score.push_back((float)sc);  // scores become float32 (Ranking dtype, ranking.py:72)
-      }
-    } catch (const std::bad_alloc&) {
-      pc.oom = true;
-    }
-  };
-  try {
-    run_threads(T, [&](int t) { parse(pieces[(size_t)t]); });
-    int64_t lines_before = 0;
-    for (Piece& pc : pieces) {
-      if (pc.oom) throw std::bad_alloc();
-      if (pc.err != FFX_OK) {
-        const int64_t line_no = lines_before + pc.err_line;
-        if (bad_line) *bad_line = line_no;
-        rc = pc.err == FFX_NOT_FOUND ? ffx_fail(FFX_NOT_FOUND, "ID %s not found in the index.", pc.err_text.c_str())
-                                     : ffx_fail(FFX_BAD_ARG, "%s:%lld: %s", path, (long long)line_no, pc.err_text.c_str());
-        break;
-      }
-      lines_before += pc.lines;
-      if (run->tag.empty() && pc.tag.data() != nullptr) run->tag.assign(pc.tag);
-      row_id.insert(row_id.end(), pc.id.begin(), pc.id.end());
-      row_view.insert(row_view.end(), pc.id_view.begin(), pc.id_view.end());
-      run->q_flags |= pc.q_flags;
-      run->id_flags |= pc.id_flags;
-      run->misc_flags |= pc.misc_flags;
-      row_s.insert(row_s.end(), pc.score.begin(), pc.score.end());
-      for (const auto& qr : pc.q_runs) row_q.insert(row_q.end(), (size_t)qr.second, run->qids.intern(qr.first));
-    }
-    if (rc == FFX_OK) {
-      const int64_t nq = run->qids.size(), n = (int64_t)row_q.size();
-      run->pair_off.assign((size_t)nq + 1, 0);
-      for (int32_t q : row_q) ++run->pair_off[(size_t)q + 1];
-      for (int64_t q = 0; q < nq; ++q) run->pair_off[(size_t)q + 1] += run->pair_off[(size_t)q];
-      run->pair_ids.resize(standalone ? 0 : (size_t)n);
-      run->pair_view.resize(standalone ? (size_t)n : 0);
-      run->score.resize((size_t)n);
-      std::vector<int64_t> cursor(run->pair_off.begin(), run->pair_off.end() - 1);
-      for (int64_t i = 0; i < n; ++i) {  // stable: rows of a query keep file order
-        const int64_t dst = cursor[(size_t)row_q[(size_t)i]]++;
-        if (standalone)
-          run->pair_view[(size_t)dst] = row_view[(size_t)i];
-        else
-          run->pair_ids[(size_t)dst] = row_id[(size_t)i];
-        run->score[(size_t)dst] = row_s[(size_t)i];
-      }
-      // duplicate (query, id) pairs: one mark per ordinal, set and cleared query by query
-      std::atomic<bool> dup{false}, scan_oom{false};
-      auto scan = [&](int64_t q_lo, int64_t q_hi) {
-        if (standalone) {  // no ordinals: order each query's id strings and look at neighbours
-          std::vector<std::string_view> tmp;
-          try {
-            for (int64_t q = q_lo; q < q_hi && !dup.load(std::memory_order_relaxed); ++q) {
-              tmp.assign(run->pair_view.begin() + run->pair_off[(size_t)q], run->pair_view.begin() + run->pair_off[(size_t)q + 1]);
-              std::sort(tmp.begin(), tmp.end());
-              if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) dup.store(true);
-            }
-          } catch (const std::bad_alloc&) {
-            scan_oom.store(true);
-          }
-          return;
-        }
-        std::vector<uint8_t> seen;
-        try {
-          seen.assign((size_t)ids->size(), 0);
-        } catch (const std::bad_alloc&) {
-          scan_oom.store(true);
-          return;
-        }
-        for (int64_t q = q_lo; q < q_hi && !dup.load(std::memory_order_relaxed); ++q) {
-          const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
-          for (int64_t i = lo; i < hi; ++i) {
-            uint8_t& m = seen[(size_t)run->pair_ids[(size_t)i]];
-            if (m) dup.store(true);
-            m = 1;
-          }
-          for (int64_t i = lo; i < hi; ++i) seen[(size_t)run->pair_ids[(size_t)i]] = 0;
-        }
-      };
-      const int TD = (int)std::min<int64_t>(T, std::max<int64_t>(1, n >> 16));
-      run_threads(TD, [&](int t) { scan(nq * t / TD, nq * (t + 1) / TD); });
-      if (scan_oom.load()) throw std::bad_alloc();
-      if (dup.load()) rc = ffx_fail(FFX_BAD_ARG, "Only one score per query-document/passage pair is allowed.");
-    }
-  } catch (const std::bad_alloc&) {
-    rc = ffx_fail(FFX_OOM, "host allocation failed while parsing %s", path);
-  } catch (const std::system_error&) {
-    rc = ffx_fail(FFX_OOM, "could not start host threads while parsing %s", path);
-  }
-  if (rc != FFX_OK) {
-    delete run;
-    return rc;
-  }
-  *out = run;
-  return FFX_OK;
-}
-
-int ffx_run_close(ffx_run* run) {
-  delete run;
-  return FFX_OK;
-}
-
-int ffx_run_counts(const ffx_run* run, int64_t* n_queries, int64_t* n_pairs) {
-  if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
-  if (n_queries) *n_queries = run->qids.size();
-  if (n_pairs) *n_pairs = (int64_t)run->score.size();
-  return FFX_OK;
-}
-
-int ffx_run_query_id(const ffx_run* run, int64_t q, const char** str, int32_t* len) {
-  if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
-  return ffx_ids_get(&run->qids, (int32_t)q, str, len);
-}
-
-int ffx_run_tag(const ffx_run* run, const char** str, int32_t* len) {
-  if (!run || !str || !len) return ffx_fail(FFX_BAD_ARG, "NULL argument");
-  *str = run->tag.data();
-  *len = (int32_t)run->tag.size();
-  return FFX_OK;
-}
-
-// copy out the CSR; with cutoff > 0 only each query's `cutoff` best-scoring candidates are kept
-// (Ranking.cut, ranking.py:279-291: order by score descending, ties in file order)
-int ffx_run_export(ffx_run* run, int64_t cutoff, int64_t* pair_off, int32_t* pair_ids, float* sparse, int64_t* n_pairs_out) {
-  if (!run || !pair_off) return ffx_fail(FFX_BAD_ARG, "NULL argument");
-  const int64_t nq = run->qids.size();
-  if (!run->ids && (cutoff > 0 || pair_ids)) return ffx_fail(FFX_BAD_ARG, "a run opened without an id table has no ordinals to export or cut");
-  if (cutoff > 0) {  // trim in place, once
-    std::vector<int64_t> new_off((size_t)nq + 1, 0);
-    std::vector<int32_t> ids2;
-    std::vector<float> sc2;
-    std::vector<int64_t> idx;
-    for (int64_t q = 0; q < nq; ++q) {
-      const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
-      idx.resize((size_t)(hi - lo));
-      std::iota(idx.begin(), idx.end(), lo);
-      if ((int64_t)idx.size() > cutoff) {
-        std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return run->score[(size_t)a] > run->score[(size_t)b]; });
-        idx.resize((size_t)cutoff);
-        std::sort(idx.begin(), idx.end());  // survivors back in file order
-      }
-      for (int64_t i : idx) {
-        ids2.push_back(run->pair_ids[(size_t)i]);
-        sc2.push_back(run->score[(size_t)i]);
-      }
-      new_off[(size_t)q + 1] = (int64_t)ids2.size();
-    }
-    run->pair_off.swap(new_off);
-    run->pair_ids.swap(ids2);
-    run->score.swap(sc2);
-  }
-  const int64_t n = (int64_t)run->score.size();
-  if (n_pairs_out) *n_pairs_out = n;
-  memcpy(pair_off, run->pair_off.data(), (size_t)(nq + 1) * sizeof(int64_t));
-  if (pair_ids && n > 0) memcpy(pair_ids, run->pair_ids.data(), (size_t)n * sizeof(int32_t));  // (an empty vector's data() may be NULL)
-  if (sparse && n > 0) memcpy(sparse, run->score.data(), (size_t)n * sizeof(float));
-  return FFX_OK;
-}
-
-// write `q_id Q0 id rank score tag` (tab separated; Ranking.save, ranking.py:348-366): queries in
-// descending q_id order, candidates of a query in the order given by `order` (positions into the
-// CSR, e.g. the device sort of ffx_plan_run); keep > 0 writes only the first `keep` of each query.
-// standalone runs (opened without an id table): what pandas would make of the q_id / id columns
-// (FFX_TOKEN_* classes OR-ed over the column) and of the file's shape (FFX_RUN_* bits)
-int ffx_run_flags(const ffx_run* run, int32_t* q_flags, int32_t* id_flags, int32_t* misc_flags) {
-  if (!run) return ffx_fail(FFX_BAD_ARG, "NULL run");
-  if (q_flags) *q_flags = run->q_flags;
-  if (id_flags) *id_flags = run->id_flags;
-  if (misc_flags) *misc_flags = run->misc_flags;
-  return FFX_OK;
-}
-
-// standalone runs: the candidate ids in CSR order (grouped by query, file order inside), joined by
-// '\n'.  Call with buf == NULL to learn the size.
-int ffx_run_ids_blob(const ffx_run* run, char* buf, int64_t cap, int64_t* needed) {
-  if (!run || !needed) return ffx_fail(FFX_BAD_ARG, "NULL argument");
-  if (run->ids) return ffx_fail(FFX_BAD_ARG, "this run was resolved against an id table: it holds ordinals, not strings");
-  int64_t total = 0;
-  for (const std::string_view& v : run->pair_view) total += (int64_t)v.size() + 1;
-  if (total > 0) --total;  // no separator after the last one
-  *needed = total;
-  if (!buf) return FFX_OK;
-  if (cap < total) return ffx_fail(FFX_BAD_ARG, "buffer too small");
-  char* w = buf;
-  for (size_t i = 0; i < run->pair_view.size(); ++i) {
-    if (i) *w++ = '\n';
-    memcpy(w, run->pair_view[i].data(), run->pair_view[i].size());
-    w += run->pair_view[i].size();
-  }
-  return FFX_OK;
-}
-
-int ffx_run_write(const ffx_run* run, const char* path, const float* scores, const int32_t* order, int64_t keep,
-                  const char* tag) {
-  if (!run || !path || !scores || !order) return ffx_fail(FFX_BAD_ARG, "NULL argument");
-  if (!run->ids) return ffx_fail(FFX_BAD_ARG, "this run was opened without an id table");
-  FILE* f = fopen(path, "wb");
-  if (!f) return ffx_fail(FFX_BAD_ARG, "cannot create %s", path);
-  const int64_t nq = run->qids.size();
-  std::vector<int64_t> qorder((size_t)nq);
-  std::iota(qorder.begin(), qorder.end(), 0);
-  std::sort(qorder.begin(), qorder.end(), [&](int64_t a, int64_t b) { return run->qids.get((int32_t)a) > run->qids.get((int32_t)b); });
-  const std::string name = tag ? tag : run->tag;
-  // formatting is the cost here (a shortest-round-trip float per line): queries are handed to a
-  // few threads in batches, each fills its own buffer, and the buffers are written in order
-  auto format = [&](int64_t q_lo, int64_t q_hi, std::string& out) {
-    out.clear();
-    for (int64_t qi = q_lo; qi < q_hi; ++qi) {
-      const int64_t q = qorder[(size_t)qi];
-      const std::string_view qid = run->qids.get((int32_t)q);
-      const int64_t lo = run->pair_off[(size_t)q], hi = run->pair_off[(size_t)q + 1];
-      const int64_t n = (keep > 0 && hi - lo > keep) ? keep : hi - lo;
-      for (int64_t r = 0; r < n; ++r) {
-        const int64_t p = order[lo + r];
-        const std::string_view id = run->ids->get(run->pair_ids[(size_t)p]);
-        out.append(qid).append("\tQ0\t").append(id).push_back('\t');
-        out += std::to_string(r + 1);
-        out.push_back('\t');
-        append_float_repr(out, scores[p]);
-        out.push_back('\t');
-        out += name;
-        out.push_back('\n');
-      }
-    }
-  };
-  const int64_t n_rows = run->pair_off.empty() ? 0 : run->pair_off.back();
-  return write_formatted(f, path, nq, n_rows, format);
-}
-
-// Ranking.save (ranking.py:348-366) for a frame that is already grouped by query: the q_id and id
-// columns arrive as two '\n'-joined buffers (n_queries names; n_pairs ids in frame order), pair_off
-// gives every query's rows.  Lines "q_id\tQ0\tid\trank\tscore\tname", rank = 1-based position inside
-// the query, score formatted like pandas' to_csv of a float32 column.  Formatted by threads.
-}  // extern "C" (the writers below share helpers in an unnamed namespace)
-
-namespace {
-// n strings out of a buffer where the byte '\n' stands between them
-bool split_lines(const char* blob, int64_t bytes, int64_t n, std::vector<std::string_view>& out) {
-  out.clear();
-  if (n == 0) return bytes == 0;
-  out.reserve((size_t)n);
-  const char* p = blob;
-  const char* end = blob + bytes;
-  while ((int64_t)out.size() < n) {
-    const char* q = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-    if (!q) {
-      out.emplace_back(p, (size_t)(end - p));
-      p = end + 1;
-      break;
-    }
-    out.emplace_back(p, (size_t)(q - p));
-    p = q + 1;
-  }
-  return (int64_t)out.size() == n && p == end + 1;
-}
-
-// Ranking.save (ranking.py:348-366): rows grouped by query, rank = position inside the query; formatted by
-// threads, written in order.  id_at(p) is the candidate id of row p.
-template <class IdAt>
-int save_rows(const char* path, const std::vector<std::string_view>& q_names, int64_t n_queries, const int64_t* pair_off, int64_t n_pairs,
-              IdAt id_at, const float* scores, const char* tag) {
-  FILE* f = fopen(path, "wb");
-  if (!f) return ffx_fail(FFX_BAD_ARG, "cannot create %s", path);
-  const std::string name = tag;
-  auto format = [&](int64_t q_lo, int64_t q_hi, std::string& out) {
-    out.clear();
-    for (int64_t q = q_lo; q < q_hi; ++q) {
-      for (int64_t p = pair_off[q]; p < pair_off[q + 1]; ++p) {
-        out.append(q_names[(size_t)q]).append("\tQ0\t").append(id_at(p)).push_back('\t');
-        out += std::to_string(p - pair_off[q] + 1);
-        out.push_back('\t');
-        append_float_repr(out, scores[p]);
-        out.push_back('\t');
-        out += name;
-        out.push_back('\n');
-      }
-    }
-  };
-  return write_formatted(f, path, n_queries, n_pairs, format);
-}
-
-int check_save_args(const char* path, const int64_t* pair_off, int64_t n_queries, int64_t n_pairs, const char* tag) {
-  if (!path || !pair_off || n_queries < 0 || n_pairs < 0 || !tag) return ffx_fail(FFX_BAD_ARG, "bad argument");
-  if (pair_off[0] != 0 || pair_off[n_queries] != n_pairs) return ffx_fail(FFX_BAD_ARG, "pair_off does not cover the rows");
-  for (int64_t q = 0; q < n_queries; ++q)
-    if (pair_off[q + 1] < pair_off[q]) return ffx_fail(FFX_BAD_ARG, "pair_off not monotone at query %lld", (long long)q);
-  return FFX_OK;
-}
-}  // namespace
-
-extern "C" {
-
-int ffx_run_save(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
-                 const char* id_blob, int64_t id_bytes, int64_t n_pairs, const float* scores, const char* tag) {
-  if (int rc = check_save_args(path, pair_off, n_queries, n_pairs, tag)) return rc;
-  if (n_pairs > 0 && (!id_blob || !scores || !q_blob)) return ffx_fail(FFX_BAD_ARG, "bad argument");
-  std::vector<std::string_view> q_names, ids;
-  try {
-    if (!split_lines(q_blob, q_bytes, n_queries, q_names) || !split_lines(id_blob, id_bytes, n_pairs, ids))
-      return ffx_fail(FFX_BAD_ARG, "a buffer does not hold the announced number of strings");
-  } catch (const std::bad_alloc&) {
-    return ffx_fail(FFX_OOM, "host allocation failed");
-  }
-  return save_rows(path, q_names, n_queries, pair_off, n_pairs, [&](int64_t p) { return ids[(size_t)p]; }, scores, tag);
-}
-
-// The same for rows whose candidate ids are CODES into a table of names (a run as the device hands it back:
-// Ranking._assemble_coded): row p is written with name_blob's string number id_codes[p].
-int ffx_run_save_coded(const char* path, const char* q_blob, int64_t q_bytes, int64_t n_queries, const int64_t* pair_off,
-                       const char* name_blob, int64_t name_bytes, int64_t n_names, const int32_t* id_codes, int64_t n_pairs,
-                       const float* scores, const char* tag) {
-  if (int rc = check_save_args(path, pair_off, n_queries, n_pairs, tag)) return rc;
-  if (n_names < 0 || (n_pairs > 0 && (!name_blob || !id_codes || !scores || !q_blob))) return ffx_fail(FFX_BAD_ARG, "bad argument");
-  std::vector<std::string_view> q_names, names;
-  try {
-    if (!split_lines(q_blob, q_bytes, n_queries, q_names) || !split_lines(name_blob, name_bytes, n_names, names))
-      return ffx_fail(FFX_BAD_ARG, "a buffer does not hold the announced number of strings");
-  } catch (const std::bad_alloc&) {
-    return ffx_fail(FFX_OOM, "host allocation failed");
-  }
-  for (int64_t p = 0; p < n_pairs; ++p)
-    if ((uint32_t)id_codes[p] >= (uint64_t)n_names) return ffx_fail(FFX_BAD_ARG, "row %lld holds id code %d, outside the %lld names", (long long)p, id_codes[p], (long long)n_names);
-  return save_rows(path, q_names, n_queries, pair_off, n_pairs, [&](int64_t p) { return names[(size_t)id_codes[p]]; }, scores, tag);
-}
-
 }  // extern "C"
+
+extern "C" int ffx_host_stage_report(char* buf, int64_t cap, int64_t* needed) {
+  if (!needed) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  const std::string& r = stage_report();
+  *needed = (int64_t)r.size() + 1;
+  if (buf && cap >= *needed) memcpy(buf, r.c_str(), r.size() + 1);
+  return FFX_OK;
+}

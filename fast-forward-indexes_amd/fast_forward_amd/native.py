@@ -43,8 +43,8 @@ PRIVATE_SYMBOLS = (
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_buffer_free",
-    "ffx_host_owner_crc32", "ffx_host_code_u64", "ffx_run_flags", "ffx_run_ids_blob", "ffx_run_save", "ffx_run_save_coded", "ffx_host_order",
-    "ffx_host_order_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets",
+    "ffx_host_owner_crc32", "ffx_host_code_u64", "ffx_run_flags", "ffx_run_ids_blob", "ffx_run_names", "ffx_host_stage_report", "ffx_run_save", "ffx_run_save_coded", "ffx_host_order",
+    "ffx_host_order_blocks", "ffx_host_rank_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets",
     "ffx_host_segment_rows_unique", "ffx_host_outer_join",
 )
 COMM_RCCL, COMM_HOST, COMM_REHEARSAL, COMM_ID_BYTES = 0, 1, 2, 128
@@ -208,6 +208,8 @@ def lib() -> C.CDLL:
         "ffx_run_write": ([vp, C.c_char_p, vp, vp, i64, C.c_char_p], C.c_int),
         "ffx_run_flags": ([vp, P(i32), P(i32), P(i32)], C.c_int),
         "ffx_run_ids_blob": ([vp, vp, i64, P(i64)], C.c_int),
+        "ffx_run_names": ([vp, P(vp), P(i64), P(i64)], C.c_int),
+        "ffx_host_stage_report": ([vp, i64, P(i64)], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
@@ -221,6 +223,7 @@ def lib() -> C.CDLL:
         "ffx_host_unpin": ([vp], C.c_int),
         "ffx_host_order": ([vp, vp, i64, i32, vp], C.c_int),
         "ffx_host_order_blocks": ([vp, vp, vp, i64, i32, vp], C.c_int),
+        "ffx_host_rank_blocks": ([vp, vp, vp, vp, i64, i32, vp, vp, vp], C.c_int),
         "ffx_host_take32": ([vp, i64, vp, i64, i32, vp], C.c_int),
         "ffx_host_interpolate": ([vp, vp, vp, i64, C.c_float, C.c_float, i32, vp, P(i32)], C.c_int),
         "ffx_host_outer_join": ([vp, vp, vp, vp, i64, i32, vp, vp, vp, vp], C.c_int),
@@ -266,6 +269,15 @@ def lib() -> C.CDLL:
         raise ImportError(f"libffx ABI {L.ffx_abi_version()} does not match this binding (3)")
     _lib = L
     return L
+
+
+def stage_report() -> dict:
+    """Where the time of this thread's last ``ffx_run_open`` / ``ffx_run_write`` / ``ffx_run_save*`` call went: {stage: seconds}."""
+    need = C.c_int64(0)
+    _check(lib().ffx_host_stage_report(None, 0, C.byref(need)))
+    buf = C.create_string_buffer(max(1, need.value))
+    _check(lib().ffx_host_stage_report(buf, need.value, C.byref(need)))
+    return {k: float(v) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
 
 
 def usable_cores() -> int:
@@ -917,6 +929,21 @@ def host_order(scores, pair_off, threads: int = 0, dst_off=None) -> np.ndarray:
     return out
 
 
+def rank_blocks(scores, carry, pair_off, dst_off=None, threads: int = 0, want_order: bool = False):
+    """``ffx_host_rank_blocks``: every query ordered (scores descending, exact ties by position) and its scores and a
+    second int32 column (id codes) written in that order at the query's block (``dst_off``; None: where it stands):
+    ``(scores, carry[, order])`` of the whole run in final layout, one threaded pass."""
+    scores, carry, pair_off = _arr(scores, np.float32), _arr(carry, np.int32), _arr(pair_off, np.int64)
+    assert scores.shape[0] == carry.shape[0]
+    dst = None if dst_off is None else _arr(dst_off, np.int64)
+    assert dst is None or dst.shape[0] >= pair_off.shape[0] - 1
+    out_s, out_c = page_locked_or_empty(scores.shape[0], np.float32), page_locked_or_empty(scores.shape[0], np.int32)
+    order = np.empty(scores.shape[0], dtype=np.int32) if want_order else None
+    _check(lib().ffx_host_rank_blocks(_ptr(scores), _ptr(carry), _ptr(pair_off), _ptr(dst), pair_off.shape[0] - 1, int(threads), _ptr(order),
+                                      _ptr(out_s), _ptr(out_c)))
+    return (out_s, out_c, order) if want_order else (out_s, out_c)
+
+
 _HAVE_DEVICE: list = [None]
 INPUT_BLOCKS_FROM = 32 << 20  # bytes from which a ranking's own arrays are kept in page-locked blocks (page_locked_copy)
 
@@ -1417,6 +1444,13 @@ class RunFile:
     def id_strings(self) -> list[str]:
         """... as Python strings."""
         return self.ids_blob().decode("utf-8").split("\n") if self.n_pairs else []
+
+    def names(self) -> tuple[bytes, int]:
+        """A run opened without an id table numbers its candidate ids while it is parsed: (the DISTINCT ids in code order
+        joined by ``'\\n'``, how many); :meth:`export` hands out every row's code."""
+        p, n_bytes, n_names = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        _check(lib().ffx_run_names(self._h, C.byref(p), C.byref(n_bytes), C.byref(n_names)))
+        return (C.string_at(p.value, n_bytes.value) if p.value and n_bytes.value > 0 else b""), int(n_names.value)
 
     def scores(self) -> tuple[np.ndarray, np.ndarray]:
         """(pair_off, first-stage scores) without touching ordinals (any run)."""

@@ -23,6 +23,8 @@ from pathlib import Path
 import numpy as np
 import pandas as pd
 
+from fast_forward_amd.names import Names
+
 LOGGER = logging.getLogger(__name__)
 
 Run = Mapping[str, Mapping[str, float]]
@@ -187,6 +189,8 @@ class Ranking:
         """The id strings of ``_id_coding`` once more as (one ``'\n'``-joined UTF-8 buffer, their number), if this
         ranking was built from such a buffer (the native constructors number ids out of one): an index resolves
         the distinct ids from it without touching a Python string."""
+        if isinstance(names, Names):  # (a table that IS one buffer: Ranking.from_file, the native constructors)
+            return names.packed
         c = self._coded
         if c is not None and c.get("id_blob") is not None and names is c["id_names"]:
             return c["id_blob"]
@@ -300,6 +304,8 @@ class Ranking:
             if coded[c] is None:
                 return False
         (q_code, q_names, _), (id_code, id_names, id_blob) = coded["q_id"], coded["id"]
+        if id_blob is not None:  # the distinct names are one buffer already: the table an index resolves and a writer prints from
+            id_names, id_blob = Names(id_blob[0], id_blob[1], objects=id_names), None
         n_q = len(q_names)
         text_of_q = None
         if "query" in coded:
@@ -462,14 +468,15 @@ class Ranking:
         else:  # merge the two tables of DISTINCT ids (not the rows)
             merged = None
             if native is not None:  # numbered by threads from one joined buffer (no hash insert per string in Python)
-                packed = native._packed(np.concatenate([ids_a, ids_b]))
+                if isinstance(ids_a, Names) and isinstance(ids_b, Names):
+                    packed = Names.joined(ids_a, ids_b).packed
+                else:
+                    packed = native._packed(np.concatenate([np.asarray(ids_a), np.asarray(ids_b)]))
                 if packed is not None:
-                    codes, names_blob, n_names = native.code_strings(*packed)
-                    id_names = np.empty(n_names, dtype=object)
-                    id_names[:] = names_blob.decode("utf-8").split("\n")
-                    merged = codes
+                    merged, names_blob, n_names = native.code_strings(*packed)
+                    id_names = Names(names_blob, n_names)
             if merged is None:
-                merged, uniques = pd.factorize(np.concatenate([ids_a, ids_b]))
+                merged, uniques = pd.factorize(np.concatenate([np.asarray(ids_a), np.asarray(ids_b)]))
                 id_names = np.asarray(uniques, dtype=object)
             code_a, code_b = merged[:len(ids_a)][ca], merged[len(ids_a):][cb]
         n_all = len(names)
@@ -673,8 +680,12 @@ class Ranking:
             raise ValueError("Queries are incomplete.")
         if self._coded is not None:  # stays coded: only the texts are new
             c = self._coded
-            return Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"].copy(), c["id_names"], c["score"].copy(),
-                                           [queries[q] for q in self._q_order], c.get("id_blob"))
+            out = Ranking._assemble_coded(self.name, c["q_no"], c["q_order"], c["id_codes"], c["id_names"], c["score"],  # (shared: a Ranking never changes its arrays)
+                                          [queries[q] for q in self._q_order], c.get("id_blob"))
+            cached = getattr(self, "_csr_cache", None)
+            if cached is not None and cached[0] is self._q_no:
+                out._csr_cache = cached
+            return out
         # rows, order and pairs are this ranking's own: nothing to re-check, the texts follow the
         # per-row query numbers
         cols = {c: self._df[c].to_numpy().copy() for c in (*_KEY, "score")}
@@ -755,10 +766,12 @@ class Ranking:
                 return None
             if not _is_plain_text(name):
                 return None
-            pair_off, scores = run.scores()
             q_names = np.array(run.query_ids(), dtype=object)
-            if run.n_pairs >= _CODED_FROM_FILE_ROWS and not np.isnan(scores).any():
-                return cls._from_parsed_run_coded(run, native, name, pair_off, scores, q_names, queries)
+            if run.n_pairs >= _CODED_FROM_FILE_ROWS:
+                pair_off, codes, scores = run.export()
+                if not np.isnan(scores).any():
+                    return cls._from_parsed_run_coded(run, native, name, pair_off, codes, scores, q_names, queries)
+            pair_off, scores = run.scores()
             ids = np.array(run.id_strings(), dtype=object)
         finally:
             run.close()
@@ -785,32 +798,31 @@ class Ranking:
         return out
 
     @classmethod
-    def _from_parsed_run_coded(cls, run, native, name: str, pair_off: np.ndarray, scores: np.ndarray, q_names: np.ndarray, queries) -> "Ranking":
-        """A large run file straight into the coded form: the parser's candidate ids are numbered natively (one
-        joined buffer into ``ffx_strings_code``, by threads: a Python string per DISTINCT id, none per row), every query
-        is ordered by host threads (score descending, exact ties in file order: what the constructor's stable
-        sort gives) and the queries are put in descending id order.  Same rows, order and values as the frame
-        route (``test_from_file_coded_equals_the_frame_route``)."""
-        codes, names_blob, n_names = native.code_strings(run.ids_blob(), run.n_pairs)
-        id_names = np.empty(n_names, dtype=object)
-        id_names[:] = names_blob.decode("utf-8").split("\n") if n_names else []
-        inside = native.host_order(scores, pair_off)               # positions, queries in the parser's (first-appearance) order
+    def _from_parsed_run_coded(cls, run, native, name: str, pair_off: np.ndarray, codes: np.ndarray, scores: np.ndarray, q_names: np.ndarray,
+                               queries) -> "Ranking":
+        """A large run file straight into the coded form: the parser has numbered the candidate ids already (no string per
+        row ever exists, the DISTINCT names stay one buffer: ``Names``), every query is ordered by host threads (score
+        descending, exact ties in file order: what the constructor's stable sort gives) and its block written where the
+        query stands in descending id order, codes and scores moved along in the same pass.  Same rows, order and values as
+        the frame route (``test_from_file_coded_equals_the_frame_route``)."""
+        from fast_forward_amd.names import Names
+
+        id_names = Names(*run.names())
         counts = np.diff(pair_off)
         by_name = np.argsort(q_names)[::-1]                         # q_id descending (ranking.py:115-117)
         by_name = by_name[counts[by_name] > 0]
-        new_counts = counts[by_name]
         new_off = np.zeros(len(by_name) + 1, dtype=np.int64)
-        np.cumsum(new_counts, out=new_off[1:])
-        # row i of the result is row inside[src[i]]: the blocks of `inside`, re-arranged query by query
-        src = np.arange(int(new_off[-1]), dtype=np.int64) + np.repeat(pair_off[by_name] - new_off[:-1], new_counts)
-        order = inside[src] if len(src) else np.zeros(0, dtype=np.int32)
+        np.cumsum(counts[by_name], out=new_off[1:])
+        dst = np.zeros(len(q_names), dtype=np.int64)                # where the block of (parser) query q starts; empty queries: anywhere
+        dst[by_name] = new_off[:-1]
+        score_o, code_o = native.rank_blocks(scores, codes, pair_off, dst)
         q_order = q_names[by_name].tolist()
         if queries is not None and any(q not in queries for q in q_order):
             raise ValueError("Queries are incomplete.")
         texts = None if queries is None else [queries[q] for q in q_order]
-        q_no = np.repeat(np.arange(len(by_name), dtype=np.int64), new_counts)
-        blob = (names_blob, n_names) if n_names else None  # (the parser's ids cannot hold a newline)
-        return cls._assemble_coded(name, q_no, q_order, native.take32(codes, order), id_names, native.take32(scores, order), texts, blob)
+        out = cls._assemble_coded(name, native.run_numbers(new_off), q_order, code_o, id_names, score_o, texts)
+        out._csr_cache = (out._q_no, None, new_off)
+        return out
 
     def _save_native_coded(self, target: Path) -> bool:
         """``save`` of a coded ranking without growing its frame: codes and the name table go to libffx's
@@ -822,13 +834,18 @@ class Ranking:
         except (ImportError, OSError):
             return False
         c = self._coded
-        q_no = np.asarray(c["q_no"])
-        if len(q_no) < 4096 or (np.diff(q_no) < 0).any():
+        if len(c["q_no"]) < 4096:
             return False
-        pair_off = np.zeros(len(c["q_order"]) + 1, dtype=np.int64)
-        np.cumsum(np.bincount(q_no, minlength=len(c["q_order"])), out=pair_off[1:])
+        perm, pair_off = self._csr()  # (known from the constructor for every ranking it made: no pass over the rows here)
+        if perm is not None:
+            return False
         target.parent.mkdir(parents=True, exist_ok=True)
-        return native.save_run_coded(target, c["q_order"], pair_off, c["id_codes"], c["id_names"], c["score"], str(self.name))
+        names = c["id_names"]
+        if isinstance(names, Names):
+            if not names.plain_for_csv():
+                return False
+            names = names.packed or (b"", 0)
+        return native.save_run_coded(target, c["q_order"], pair_off, c["id_codes"], names, c["score"], str(self.name))
 
     def _save_native(self, target: Path) -> bool:
         """The same bytes through libffx's threaded formatter (pandas' to_csv spends seconds on a

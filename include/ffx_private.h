@@ -107,6 +107,13 @@ int ffx_host_owner_crc32(const char* doc_ids, int32_t doc_width, const char* psg
 int ffx_host_code_u64(const uint64_t* values, int64_t n, int32_t n_threads, int32_t* codes, int64_t* first_row, int64_t* n_distinct);
 int ffx_run_flags(const ffx_run* run, int32_t* q_flags, int32_t* id_flags, int32_t* misc_flags);
 int ffx_run_ids_blob(const ffx_run* run, char* buf, int64_t cap, int64_t* needed);
+/* A run opened WITHOUT an id table numbers its candidate ids while it is parsed (as ffx_strings_code would): ffx_run_export
+ * hands out the code of every row, and this the distinct ids in code order joined by '\n' -- a view into the run, valid until
+ * ffx_run_close (Ranking.from_file on a large run: no string per row ever exists, ranking.py:388-409). */
+int ffx_run_names(const ffx_run* run, const char** blob, int64_t* bytes, int64_t* n_names);
+/* Where the time of the calling thread's last ffx_run_open / ffx_run_write / ffx_run_save* / ffx_strings_code* call went:
+ * "stage=seconds;stage=seconds;..." (*needed = bytes required incl. the NUL; copied when cap suffices). */
+int ffx_host_stage_report(char* buf, int64_t cap, int64_t* needed);
 /* Ranking.save (ranking.py:348-366) of a frame grouped by query, without a parsed run: q_blob holds
  * the n_queries query ids and id_blob the n_pairs candidate ids (frame order), each joined by '\n';
  * pair_off[q] .. pair_off[q+1] are the rows of query q.  Scores are printed like pandas prints
@@ -128,6 +135,10 @@ int ffx_host_order(const float* scores, const int64_t* pair_off, int64_t n_queri
  * ordered and the queries put into the constructor's "q_id descending" sequence in one pass); dst_off NULL = in place */
 int ffx_host_order_blocks(const float* scores, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries, int32_t n_threads,
                           int32_t* out_order);
+/* the same pass with the columns moved along: out_scores / out_carry (a second 4-byte column: the id codes) receive every
+ * query's rows in final order at the query's destination block; any output may be NULL */
+int ffx_host_rank_blocks(const float* scores, const int32_t* carry, const int64_t* pair_off, const int64_t* dst_off, int64_t n_queries,
+                         int32_t n_threads, int32_t* out_order, float* out_scores, int32_t* out_carry);
 /* out[i] = src[index[i]] for 4-byte elements (float32 scores, int32 id codes), by host threads (n_threads <= 0:
  * every core this process may use): reorders a run's columns by the per-query order of ffx_plan_fetch /
  * ffx_score / ffx_host_order (the other half of ranking.py:115-117's sort).  FFX_BAD_ARG for an index
