@@ -851,32 +851,39 @@ def side_regions(args, index, plan, queries, pair_off, ids, sparse, exact: bool)
     return out
 
 
-def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
+def api_context(args, index, doc_off, scale: float, exact: bool) -> "dict | None":
+    """What regions (iii) share: the bench's index adopted by an ``InMemoryIndex`` under string document ids, the query
+    encoder (a table of vectors), the candidate lists of the workload."""
+    from fast_forward_amd.encoder import ArrayEncoder
+    from fast_forward_amd.index import InMemoryIndex, Mode
+
+    if not hasattr(InMemoryIndex, "adopt"):
+        return None
+    nq = min(args.api_queries, args.queries)
+    n_docs = doc_off.shape[0] - 1
+    t0 = time.perf_counter()
+    # names as Python strings, one object per document / query -- what a frame read from a run file holds (pandas'
+    # readers keep one object per distinct value of a column), and what a frame built from arrays of names holds
+    doc_names = np.array([f"D{i}" for i in range(n_docs)], dtype=object)
+    api = InMemoryIndex.adopt(index, doc_ids=doc_names, doc_off=doc_off, mode=Mode[args.mode], exact_sum=exact)
+    adopt_s = time.perf_counter() - t0
+    ids, sparse = candidates(n_docs, nq, args.k, args.seed)
+    qvecs = synth.rows(args.seed + 3, scale, 0, nq, args.dim)
+    q_names = np.array([f"q{i:06d}" for i in range(nq)], dtype=object)
+    api.query_encoder = ArrayEncoder(dict(zip(q_names.tolist(), qvecs)))
+    return {"api": api, "nq": nq, "n_docs": n_docs, "doc_names": doc_names, "q_names": q_names, "ids": ids, "sparse": sparse, "adopt_s": adopt_s}
+
+
+def api_region(args, ctx: dict) -> dict:
     """Region (iii): the public API on the same index -- a first-stage ``Ranking`` of STRING ids in,
     ``InMemoryIndex.rerank`` (= ``ranking.interpolate(index(ranking), alpha)`` with the epilogue on
     the device) out, id resolution and frame construction included."""
     import pandas as pd
 
     from fast_forward_amd import Ranking
-    from fast_forward_amd.encoder import ArrayEncoder
-    from fast_forward_amd.index import InMemoryIndex, Mode
 
-    nq = min(args.api_queries, args.queries)
-    n_docs = doc_off.shape[0] - 1
-    out = {}
-    if not hasattr(InMemoryIndex, "adopt"):
-        return out
-    t0 = time.perf_counter()
-    # names as Python strings, one object per document / query -- what a frame read from a run file holds (pandas'
-    # readers keep one object per distinct value of a column), and what a frame built from arrays of names holds
-    doc_names = np.array([f"D{i}" for i in range(n_docs)], dtype=object)
-    api = InMemoryIndex.adopt(index, doc_ids=doc_names, doc_off=doc_off, mode=Mode[args.mode], exact_sum=exact)
-    out["iii_adopt_ids_s"] = time.perf_counter() - t0
-    out["iii_ids"] = n_docs
-    ids, sparse = candidates(n_docs, nq, args.k, args.seed)
-    qvecs = synth.rows(args.seed + 3, scale, 0, nq, args.dim)
-    q_names = np.array([f"q{i:06d}" for i in range(nq)], dtype=object)
-    api.query_encoder = ArrayEncoder(dict(zip(q_names.tolist(), qvecs)))
+    api, nq, n_docs, doc_names, q_names, ids, sparse = (ctx[k] for k in ("api", "nq", "n_docs", "doc_names", "q_names", "ids", "sparse"))
+    out = {"iii_adopt_ids_s": ctx["adopt_s"], "iii_ids": n_docs}
     t0 = time.perf_counter()
     frame = pd.DataFrame({"q_id": np.repeat(q_names, args.k), "id": doc_names[ids], "score": sparse,
                           "query": np.repeat(q_names, args.k)})
@@ -954,7 +961,137 @@ def api_region(args, index, doc_off, scale: float, exact: bool) -> dict:
                        f"Index.rerank COLD (iii_rerank_first_call_s: first call on that ranking, distinct-id look-up and allocations included) and "
                        f"WARM (iii_rerank_s: the same ranking again, best of three calls after the second, which is iii_rerank_second_call_s); Index.__call__ followed by "
                        f"Ranking.interpolate (iii_interpolate_s: first time, new result blocks; iii_interpolate_again_s: steady state); the general host join on {nq2} queries")
-    api.release()
+    ctx["frame"] = frame  # (region iii_fresh starts from the same frame)
+    return out
+
+
+def fresh_region(args, ctx: dict) -> dict:
+    """Region (iii) for a run the index has NEVER seen -- what every real call is (the reference scores a new ranking on each
+    call, index/base.py:418-429; README.md:34-52): nothing of the ranking is cached, every route below builds its own
+    ``Ranking`` and pays for the id look-up.  6980 x k rows each:
+      a_*        columns in -> ``Ranking`` -> ``Index.rerank`` -> ``Ranking.columns()`` (arrays out; no frame of strings)
+                 from a pandas frame of Python strings, Arrow string arrays, fixed-width bytes, pre-coded integers
+      b_file     ``Ranking.from_file`` -> ``attach_queries`` -> ``index()`` -> ``interpolate`` -> ``save`` (ranking.py:388-409, :348-366)
+      c_rerank_file  ``Index.rerank_file``: the same, file to file, no Ranking in between
+    Every stage is timed; the stages of a route sum to its total.  All routes must give the same rows, scores and order."""
+    import shutil
+    import tempfile
+
+    import pandas as pd
+
+    from fast_forward_amd import Ranking
+    from fast_forward_amd import ranking as ranking_module
+
+    api, nq, n_docs, doc_names, q_names, ids = (ctx[k] for k in ("api", "nq", "n_docs", "doc_names", "q_names", "ids"))
+    k, alpha = args.k, args.alpha
+    # a first-stage run lists every query's candidates best first
+    sparse = np.ascontiguousarray(-np.sort(-ctx["sparse"].reshape(nq, k), axis=1).reshape(-1))
+    queries = dict(zip(q_names.tolist(), q_names.tolist()))
+    out = {"rows": int(nq * k), "queries": int(nq), "distinct_ids": int(np.unique(ids).shape[0])}
+
+    def stages(route: dict) -> dict:
+        route["total_s"] = float(sum(v for key, v in route.items() if key.endswith("_s") and isinstance(v, float)))
+        return route
+
+    reference = {}  # the first route's result (copies: the result itself goes back to the pool like a served one would)
+    same = {"arrays": True}
+
+    def rerank_and_hand_out(first, route: dict):
+        t0 = time.perf_counter()
+        final = api.rerank(first, alpha)
+        route["rerank_first_call_s"] = time.perf_counter() - t0
+        route["rerank_breakdown"] = dict(getattr(api, "last_timings", {}))
+        t0 = time.perf_counter()
+        cols = final.columns()
+        route["result_columns_s"] = time.perf_counter() - t0
+        compare(cols)
+
+    def compare(cols: dict) -> None:
+        """Every route must hand out the rows, scores and order of the first one (untimed)."""
+        if not reference:
+            reference.update(score=np.array(cols["score"]), id_codes=np.array(cols["id_codes"]), packed=cols["id_names"].packed, q_names=list(cols["q_names"]),
+                             names=cols["id_names"])
+            return
+        ok = np.array_equal(cols["score"].view(np.uint32), reference["score"].view(np.uint32)) and cols["q_names"] == reference["q_names"]
+        if cols["id_names"].packed == reference["packed"]:  # (one numbering rule: equal tables, so the codes must agree)
+            ok = ok and np.array_equal(cols["id_codes"], reference["id_codes"])
+        else:
+            rows = np.random.default_rng(0).integers(0, len(cols["id_codes"]), size=4096)
+            ok = ok and all(cols["id_names"][int(cols["id_codes"][r])] == reference["names"][int(reference["id_codes"][r])] for r in rows)
+        same["arrays"] = same["arrays"] and bool(ok)
+
+    # ---- (a) from columns -------------------------------------------------------------------------------
+    frame = ctx.pop("frame", None)
+    if frame is None or not np.array_equal(frame["score"].to_numpy(), sparse):
+        frame = pd.DataFrame({"q_id": np.repeat(q_names, k), "id": doc_names[ids], "score": sparse, "query": np.repeat(q_names, k)})
+    route = {}
+    t0 = time.perf_counter()
+    first = Ranking(frame, name="first-stage", copy=False)
+    route["ranking_constructor_s"] = time.perf_counter() - t0
+    route["constructor_breakdown"] = dict(ranking_module.BUILD_TIMINGS)
+    rerank_and_hand_out(first, route)
+    out["a_frame_of_python_strings"] = stages(route)
+    del first
+    forms = {}
+    try:
+        import pyarrow as pa
+
+        forms["a_arrow_strings"] = (pa.array(frame["q_id"].to_numpy(), type=pa.string()), pa.array(frame["id"].to_numpy(), type=pa.string()))
+    except ImportError:
+        pass
+    forms["a_fixed_width_bytes"] = (np.repeat(q_names.astype("S"), k), doc_names.astype("S")[ids])
+    forms["a_pre_coded_integers"] = ((np.repeat(np.arange(nq, dtype=np.int32), k), q_names), (ids, doc_names.astype("S")))
+    del frame
+    for label, (q_form, id_form) in forms.items():
+        route = {}
+        t0 = time.perf_counter()
+        first = Ranking.from_columns(q_form, id_form, sparse, name="first-stage", queries=queries)
+        route["from_columns_s"] = time.perf_counter() - t0
+        route["constructor_breakdown"] = dict(ranking_module.BUILD_TIMINGS)
+        rerank_and_hand_out(first, route)
+        out[label] = stages(route)
+        del first
+    forms.clear()
+
+    # ---- (b), (c) file to file --------------------------------------------------------------------------
+    work = Path(tempfile.mkdtemp(prefix="ffx_fresh_"))
+    try:
+        run_in = work / "first_stage.tsv"
+        pair_off = np.arange(nq + 1, dtype=np.int64) * k
+        assert native.save_run_coded(run_in, q_names.tolist(), pair_off, ids, doc_names, sparse, "bm25")
+        out["run_file_MB"] = run_in.stat().st_size / 1e6
+        route = {}
+        t = [time.perf_counter()]
+        first = Ranking.from_file(run_in)
+        t.append(time.perf_counter())
+        route["from_file_stages"] = native.stage_report()
+        first = first.attach_queries(queries)
+        t.append(time.perf_counter())
+        dense = api(first)
+        t.append(time.perf_counter())
+        final_b = first.interpolate(dense, alpha)
+        t.append(time.perf_counter())
+        final_b.save(work / "out_b.tsv")
+        t.append(time.perf_counter())
+        route["save_stages"] = native.stage_report()
+        route.update(dict(zip(("from_file_s", "attach_queries_s", "call_s", "interpolate_s", "save_s"), np.diff(t).tolist())))
+        out["b_file"] = stages(route)
+        out["b_file"]["GB_per_s"] = {"from_file": out["run_file_MB"] / 1e3 / route["from_file_s"], "save": (work / "out_b.tsv").stat().st_size / 1e9 / route["save_s"]}
+        route = {}
+        t0 = time.perf_counter()
+        api.rerank_file(run_in, work / "out_c.tsv", alpha, queries)
+        route["rerank_file_s"] = time.perf_counter() - t0
+        route["stages"] = dict(getattr(api, "last_file_timings", {}))
+        out["c_rerank_file"] = stages(route)
+        # ---- all routes give the same run -----------------------------------------------------------------
+        import filecmp
+
+        same_files = filecmp.cmp(work / "out_b.tsv", work / "out_c.tsv", shallow=False)
+        compare(final_b.columns())
+        out["outputs_identical"] = {"file_route_equals_rerank_file_bytes": bool(same_files), "every_column_route_equals_the_file_route": same["arrays"]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out["queries_per_s"] = {key: nq / val["total_s"] for key, val in out.items() if isinstance(val, dict) and "total_s" in val}
     return out
 
 
@@ -1124,7 +1261,11 @@ def bench_single(args):
         regions = {"i_device_sorted_ms" if args.sort else "i_device_ms": ms_per_step}
         regions.update(side_regions(args, index, plan, queries, pair_off, ids, sparse, exact))
         if args.api_queries > 0 and args.store == "f32" and args.layout == "single":
-            regions.update(api_region(args, index, doc_off, scale, exact))
+            ctx = api_context(args, index, doc_off, scale, exact)
+            if ctx is not None:
+                regions.update(api_region(args, ctx))
+                regions["iii_fresh"] = fresh_region(args, ctx)
+                ctx["api"].release()
         result["regions"] = regions
         # SURVEY 8(d)'s headline region, next to `value`: CSR in host memory -> scores + order in host memory (page-locked buffers)
         result["value_host_to_host"] = args.queries / (regions["ii_pinned_ms"] * 1e-3)

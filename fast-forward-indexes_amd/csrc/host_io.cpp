@@ -272,7 +272,91 @@ int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n
     });
     if (bad.load()) return ffx_fail(FFX_BAD_ARG, "offsets are not monotone");
     auto view = [&](int64_t i) { return std::string_view(data + offsets[i], (size_t)(offsets[i + 1] - offsets[i])); };
+    StageClock clock;
+    return strings_code_views(n, T, view, sep, codes, names_blob, names_bytes, n_names, &clock);
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+}
+
+// ffx_strings_code_offsets for 32-bit offsets (an Arrow `string` array; `large_string` has 64-bit ones)
+int ffx_strings_code_offsets32(const char* data, const int32_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes, char** names_blob,
+                               int64_t* names_bytes, int64_t* n_names) {
+  if (names_blob) *names_blob = nullptr;
+  if (names_bytes) *names_bytes = 0;
+  if (n_names) *n_names = 0;
+  if (n < 0 || (n > 0 && (!offsets || !codes)) || !names_blob || !names_bytes || !n_names) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return FFX_OK;
+  if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many strings for int32 codes");
+  if (offsets[0] < 0 || (offsets[n] > offsets[0] && !data)) return ffx_fail(FFX_BAD_ARG, "bad offsets");
+  const int T = threads_for(n, 1 << 16, n_threads);
+  try {
+    std::atomic<bool> bad(false);
+    run_threads(T, [&](int t) {
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i)
+        if (offsets[i + 1] < offsets[i]) bad.store(true);
+    });
+    if (bad.load()) return ffx_fail(FFX_BAD_ARG, "offsets are not monotone");
+    auto view = [&](int64_t i) { return std::string_view(data + offsets[i], (size_t)(offsets[i + 1] - offsets[i])); };
+    StageClock clock;
+    return strings_code_views(n, T, view, sep, codes, names_blob, names_bytes, n_names, &clock);
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+}
+
+// ffx_strings_code for n NUL-padded fields of `width` bytes each (numpy 'S<width>': the id columns of an index file,
+// a column of fixed-width ids); a field ends at its first NUL byte
+int ffx_strings_code_fixed(const char* data, int32_t width, int64_t n, char sep, int32_t n_threads, int32_t* codes, char** names_blob,
+                           int64_t* names_bytes, int64_t* n_names) {
+  if (names_blob) *names_blob = nullptr;
+  if (names_bytes) *names_bytes = 0;
+  if (n_names) *n_names = 0;
+  if (n < 0 || width <= 0 || (n > 0 && (!data || !codes)) || !names_blob || !names_bytes || !n_names) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n == 0) return FFX_OK;
+  if (n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many strings for int32 codes");
+  const int T = threads_for(n, 1 << 16, n_threads);
+  try {
+    auto view = [&](int64_t i) { return fixed_width(data, width, i); };
     return strings_code_views(n, T, view, sep, codes, names_blob, names_bytes, n_names);
+  } catch (const std::bad_alloc&) {
+    return ffx_fail(FFX_OOM, "host allocation failed");
+  } catch (const std::system_error&) {
+    return ffx_fail(FFX_OOM, "could not start host threads");
+  }
+}
+
+// The first group of rows (group_off[g] .. group_off[g+1]) that holds one code twice, -1 in *group if there is none: the
+// repeated (query, id) pair of ranking.py:95-98 for rows that stand grouped by query and hold id codes in [0, n_codes).
+int ffx_host_repeated_in_groups(const int32_t* codes, const int64_t* group_off, int64_t n_groups, int64_t n_codes, int32_t n_threads, int64_t* group) {
+  if (!group) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  *group = -1;
+  if (n_groups < 0 || n_codes < 0 || (n_groups > 0 && !group_off)) return ffx_fail(FFX_BAD_ARG, "bad argument");
+  if (n_groups == 0) return FFX_OK;
+  if (group_off[0] != 0) return ffx_fail(FFX_BAD_ARG, "group_off[0] must be 0");
+  for (int64_t g = 0; g < n_groups; ++g)
+    if (group_off[g + 1] < group_off[g]) return ffx_fail(FFX_BAD_ARG, "group_off not monotone at %lld", (long long)g);
+  const int64_t n = group_off[n_groups];
+  if (n > 0 && !codes) return ffx_fail(FFX_BAD_ARG, "NULL argument");
+  const int T = threads_for(n, 1 << 18, n_threads);
+  try {
+    std::atomic<int64_t> bad(INT64_MAX);
+    run_threads(T, [&](int t) {
+      for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i)
+        if ((uint32_t)codes[i] >= (uint64_t)n_codes) {
+          int64_t cur = bad.load();
+          while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+          }
+          return;
+        }
+    });
+    if (bad.load() != INT64_MAX) return ffx_fail(FFX_BAD_ARG, "row %lld holds code %d, outside the %lld codes", (long long)bad.load(), codes[bad.load()], (long long)n_codes);
+    *group = first_group_with_repeated_code(codes, group_off, n_groups, n_codes, T);
+    return FFX_OK;
   } catch (const std::bad_alloc&) {
     return ffx_fail(FFX_OOM, "host allocation failed");
   } catch (const std::system_error&) {

@@ -630,7 +630,7 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
         Piece& pc = pieces[(size_t)k];
         int64_t c = 0;
         for (const char* p = pc.begin; p < pc.end && (p = static_cast<const char*>(memchr(p, '\n', (size_t)(pc.end - p)))) != nullptr; ++p) ++c;
-        pc.room = c + 1;  // (the last line of the file need not end in a line break)
+        pc.room = c + ((pc.end > pc.begin && pc.end[-1] != '\n') ? 1 : 0);  // (the last line of the file need not end in a line break)
       }
     });
     int64_t room = 0;
@@ -707,6 +707,7 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
           n += qr.rows;
         }
       }
+      clock.lap("group.queries_numbered");
       const int64_t nq = run->qids.size();
       run->pair_off.assign((size_t)nq + 1, 0);
       for (int64_t q = 0; q < nq; ++q) run->pair_off[(size_t)q + 1] = run->pair_off[(size_t)q] + rows_of[(size_t)q];
@@ -752,15 +753,13 @@ int ffx_run_open(const char* path, const ffx_ids* ids, ffx_run** out, int64_t* b
         run->pair_ids = std::move(ids2);
         if (standalone) ref = std::move(ref2);
       }
-      clock.lap("group");
+      clock.lap("group.rows_moved");
       int64_t n_codes = ids ? ids->size() : 0;
       if (standalone) {
         const int TC = threads_for(n, 1 << 16);
         auto view = [&](int64_t i) { return std::string_view(base + (ref[(size_t)i] >> 16), (size_t)(ref[(size_t)i] & 0xFFFFu)); };
-        rc = strings_code_views(n, TC, view, '\n', run->pair_ids.data(), &run->names, &run->names_bytes, &run->n_names);
-        if (rc == FFX_OK && !line_starts(run->names, run->names_bytes, run->n_names, run->name_start)) rc = ffx_fail(FFX_BAD_ARG, "%s: an id holds a line break", path);
+        rc = strings_code_views(n, TC, view, '\n', run->pair_ids.data(), &run->names, &run->names_bytes, &run->n_names, &clock, &run->name_start);
         n_codes = run->n_names;
-        clock.lap("number_ids");
       }
       // duplicate (query, id) pairs
       if (rc == FFX_OK && n > 0 && first_group_with_repeated_code(run->pair_ids.data(), run->pair_off.data(), nq, n_codes, threads_for(n, 1 << 16)) >= 0)
@@ -934,17 +933,41 @@ int ffx_run_write(const ffx_run* run, const char* path, const float* scores, con
     const int64_t n_pairs = run->n_pairs;
     std::atomic<bool> bad_order(false);
     const std::string name = tag ? tag : run->tag;
+    auto id_of = [&](int64_t p) { return run->pair_ids[(size_t)p]; };
     auto format = [&](int64_t qi, int64_t r_lo, int64_t r_hi, Out& out) {
       const int64_t q = qorder[(size_t)qi];
       const std::string_view qid = run->qids.get((int32_t)q);
       const int64_t lo = run->pair_off[(size_t)q];
+      auto in_run = [&](int64_t p) { return p >= 0 && p < n_pairs; };
       for (int64_t r = r_lo; r < r_hi; ++r) {
         const int64_t p = order[lo + r];
-        if (p < 0 || p >= n_pairs) {
+        if (!in_run(p)) {
           bad_order.store(true);
           return;
         }
-        const int32_t c = run->pair_ids[(size_t)p];
+        // a row's line is a chain of dependent cache misses (its position in the run -> its ordinal and score -> where the
+        // id's bytes start -> the bytes): each link is asked for a few rows ahead of the row being printed
+        if (r + 24 < r_hi && in_run(order[lo + r + 24])) {
+          __builtin_prefetch(&run->pair_ids[(size_t)order[lo + r + 24]]);
+          __builtin_prefetch(&scores[order[lo + r + 24]]);
+        }
+        if (r + 16 < r_hi && in_run(order[lo + r + 16])) {
+          const int32_t c = id_of(order[lo + r + 16]);
+          if (run->ids) {
+            if (c >= 0 && c < run->ids->size()) __builtin_prefetch(&run->ids->off[(size_t)c]);
+          } else if (c >= 0 && c < run->n_names) {
+            __builtin_prefetch(&run->name_start[(size_t)c]);
+          }
+        }
+        if (r + 8 < r_hi && in_run(order[lo + r + 8])) {
+          const int32_t c = id_of(order[lo + r + 8]);
+          if (run->ids) {
+            if (c >= 0 && c < run->ids->size()) __builtin_prefetch(run->ids->arena.data() + run->ids->off[(size_t)c]);
+          } else if (c >= 0 && c < run->n_names) {
+            __builtin_prefetch(run->names + run->name_start[(size_t)c]);
+          }
+        }
+        const int32_t c = id_of(p);
         write_line(out, qid, run->ids ? run->ids->get(c) : run->name(c), r + 1, scores[p], name);
       }
     };

@@ -33,12 +33,19 @@ constexpr int kCodeShardShift = 54;  // shard = hash >> 54
 // view(i) -> std::string_view of string i, valid until this returns.  *names_blob is malloc'ed (ffx_buffer_free) and holds
 // the distinct strings in number order joined by sep, *names_bytes without a trailing separator.
 template <class View>
-int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, char** names_blob, int64_t* names_bytes, int64_t* n_names) {
+int strings_code_all(int64_t n, int T, View&& view, char sep, int32_t* codes, char** names_blob, int64_t* names_bytes, int64_t* n_names,
+                     StageClock* clock = nullptr, Buf<int64_t>* name_start = nullptr) {
   constexpr int S = kCodeShards;
   *names_blob = nullptr;
   *names_bytes = 0;
   *n_names = 0;
-  if (n == 0) return FFX_OK;
+  if (n == 0) {
+    if (name_start) {
+      name_start->alloc(1);
+      (*name_start)[0] = 1;
+    }
+    return FFX_OK;
+  }
   auto row_range = [&](int t) { return std::pair<int64_t, int64_t>(n * t / T, n * (t + 1) / T); };
   // 1. how many rows of every row range fall into every shard
   std::vector<int64_t> count((size_t)T * S, 0);
@@ -56,6 +63,7 @@ int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, 
     }
   });
   if (too_long.load()) return ffx_fail(FFX_BAD_ARG, "a string of more than 2 GiB cannot be numbered");
+  if (clock) clock->lap("number_ids.count");
   // 2. the records dealt into shards, row order kept inside a shard
   std::vector<int64_t> shard_off((size_t)S + 1, 0);
   {
@@ -80,6 +88,7 @@ int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, 
       recs[(size_t)at[h >> kCodeShardShift]++] = CodeRec{h, (uint32_t)i, (uint32_t)v.size()};
     }
   });
+  if (clock) clock->lap("number_ids.deal");
   // 3. every shard numbered on its own, in (hash, bytes) order; afterwards rec.len holds the shard-local number
   auto same = [&](const CodeRec& a, const CodeRec& b) {
     if (a.hash != b.hash || a.len != b.len) return false;
@@ -155,6 +164,7 @@ int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, 
     }
   });
   if (oom.load()) return ffx_fail(FFX_OOM, "host allocation failed");
+  if (clock) clock->lap("number_ids.shards");
   // 4. shard-local numbers -> global numbers; the names written shard by shard
   std::vector<int64_t> base((size_t)S + 1, 0), at_byte((size_t)S + 1, 0);
   for (int s = 0; s < S; ++s) {
@@ -164,6 +174,15 @@ int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, 
   const int64_t total = at_byte[(size_t)S];  // one separator too many (after the last name)
   char* blob = static_cast<char*>(malloc((size_t)std::max<int64_t>(total, 1)));
   if (!blob) return ffx_fail(FFX_OOM, "host allocation failed");
+  if (name_start) {  // name c is blob[start[c] .. start[c+1] - 1)
+    try {
+      name_start->alloc((size_t)base[(size_t)S] + 1);
+    } catch (const std::bad_alloc&) {
+      free(blob);
+      return ffx_fail(FFX_OOM, "host allocation failed");
+    }
+    (*name_start)[(size_t)base[(size_t)S]] = total;
+  }
   next_shard.store(0);
   run_threads(T, [&](int) {
     for (;;) {
@@ -174,8 +193,10 @@ int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, 
       const int32_t b = (int32_t)base[(size_t)s];
       for (int64_t k = 0; k < hi - lo; ++k) codes[rec[k].row] = (int32_t)rec[k].len + b;
       char* w = blob + at_byte[(size_t)s];
+      int64_t number = base[(size_t)s];
       for (const int32_t row : firsts[(size_t)s]) {
         const std::string_view v = view(row);
+        if (name_start) (*name_start)[(size_t)number++] = w - blob;
         memcpy(w, v.data(), v.size());
         w += v.size();
         *w++ = sep;
@@ -185,7 +206,61 @@ int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, 
   *names_blob = blob;
   *names_bytes = total - 1;
   *n_names = base[(size_t)S];
+  if (clock) clock->lap("number_ids.codes_and_names");
   return FFX_OK;
+}
+
+// The entry point.  A column of long RUNS of one string -- the query-id column of a run names each query k rows in a row -- is
+// numbered through its run heads: one streaming pass compares neighbours, the few heads are numbered by the general scheme
+// (the numbers depend on the set of strings only, so they are the numbers the whole column would get) and every row takes its
+// head's number.  Anything else: the general scheme over all rows.
+template <class View>
+int strings_code_views(int64_t n, int T, View&& view, char sep, int32_t* codes, char** names_blob, int64_t* names_bytes, int64_t* n_names,
+                       StageClock* clock = nullptr, Buf<int64_t>* name_start = nullptr) {
+  if (n >= (1 << 16)) {
+    std::vector<std::vector<int64_t>> heads_of((size_t)T);
+    std::atomic<bool> oom(false);
+    run_threads(T, [&](int t) {
+      try {
+        auto& mine = heads_of[(size_t)t];
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (int64_t i = lo; i < hi; ++i)
+          if (i == 0 || view(i) != view(i - 1)) {
+            if ((int64_t)mine.size() > (hi - lo) / 64 + 16) return;  // no long runs here: give up early
+            mine.push_back(i);
+          }
+      } catch (const std::bad_alloc&) {
+        oom.store(true);
+      }
+    });
+    if (oom.load()) return ffx_fail(FFX_OOM, "host allocation failed");
+    int64_t H = 0;
+    bool long_runs = true;
+    for (int t = 0; t < T; ++t) {
+      const int64_t span = n * (t + 1) / T - n * t / T;
+      long_runs = long_runs && (int64_t)heads_of[(size_t)t].size() <= span / 64 + 16;
+      H += (int64_t)heads_of[(size_t)t].size();
+    }
+    if (long_runs && H <= n / 64) {
+      std::vector<int64_t> head((size_t)H + 1);
+      {
+        int64_t w = 0;
+        for (int t = 0; t < T; ++t)
+          for (const int64_t i : heads_of[(size_t)t]) head[(size_t)w++] = i;
+        head[(size_t)H] = n;
+      }
+      std::vector<int32_t> head_code((size_t)H);
+      const int rc = strings_code_all(H, threads_for(H, 1 << 16, T), [&](int64_t j) { return view(head[(size_t)j]); }, sep, head_code.data(), names_blob,
+                                      names_bytes, n_names, nullptr, name_start);
+      if (rc != FFX_OK) return rc;
+      run_threads(T, [&](int t) {
+        for (int64_t h = H * t / T; h < H * (t + 1) / T; ++h) std::fill(codes + head[(size_t)h], codes + head[(size_t)h + 1], head_code[(size_t)h]);
+      });
+      return FFX_OK;
+    }
+    if (clock) clock->lap("number_ids.look_for_runs");
+  }
+  return strings_code_all(n, T, view, sep, codes, names_blob, names_bytes, n_names, clock, name_start);
 }
 
 // The first group of rows (group_off[g] .. group_off[g+1]) in which one code occurs twice, -1 if there is none: the repeated

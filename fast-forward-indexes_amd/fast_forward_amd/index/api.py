@@ -589,18 +589,28 @@ class Index(abc.ABC):
         Returns the device stage times.  Same scores and ordering as the step-by-step API."""
         from fast_forward_amd import native
 
+        t = [perf_counter()]
         run = native.RunFile(run_in, self._native_id_table(self.mode))
+        t.append(perf_counter())
+        parse_stages = native.stage_report()
         try:
             q_ids = run.query_ids()
             missing = [q for q in q_ids if q not in queries]
             if missing:
                 raise ValueError("Queries are incomplete.")
             pair_off, ordinals, sparse = run.export(cutoff or 0)
+            t.append(perf_counter())
             query_vectors = np.ascontiguousarray(self.encode_queries([queries[q] for q in q_ids]))
+            t.append(perf_counter())
             _, interp, order = self._score_pairs(query_vectors, pair_off, ordinals, self.mode, sparse, alpha, sort=True)
+            t.append(perf_counter())
             if name is None and run.tag in _PANDAS_NA_STRINGS:
                 name = "nan"  # Ranking.from_file reads such a method name as NaN and save() prints "nan"
             run.write(run_out, interp, order, tag=name)
+            t.append(perf_counter())
+            # where the call's time went (seconds), the parser's and the writer's own stages beside it
+            self.last_file_timings = dict(zip(("parse_and_resolve_s", "export_s", "encode_queries_s", "upload_device_download_s", "write_s"), np.diff(t).tolist()),
+                                          parse_stages=parse_stages, write_stages=native.stage_report())
             return dict(getattr(self, "last_stats", None) or {}, n_queries=len(q_ids), n_pairs=int(pair_off[-1]))
         finally:
             run.close()

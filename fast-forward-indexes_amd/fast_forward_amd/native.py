@@ -42,7 +42,7 @@ PRIVATE_SYMBOLS = (
     "ffx_index_prepare_score", "ffx_host_fill_runs",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
-    "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_buffer_free",
+    "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_strings_code_offsets32", "ffx_strings_code_fixed", "ffx_host_repeated_in_groups", "ffx_buffer_free",
     "ffx_host_owner_crc32", "ffx_host_code_u64", "ffx_run_flags", "ffx_run_ids_blob", "ffx_run_names", "ffx_host_stage_report", "ffx_run_save", "ffx_run_save_coded", "ffx_host_order",
     "ffx_host_order_blocks", "ffx_host_rank_blocks", "ffx_host_take32", "ffx_host_interpolate", "ffx_host_unique_rows", "ffx_host_rows_unique", "ffx_host_segment_offsets",
     "ffx_host_segment_rows_unique", "ffx_host_outer_join",
@@ -195,6 +195,9 @@ def lib() -> C.CDLL:
         "ffx_ids_blob": ([vp, C.c_char, vp, i64, P(i64)], C.c_int),
         "ffx_strings_code": ([C.c_char_p, i64, C.c_char, i64, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
         "ffx_strings_code_offsets": ([vp, vp, i64, C.c_char, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
+        "ffx_strings_code_offsets32": ([vp, vp, i64, C.c_char, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
+        "ffx_strings_code_fixed": ([vp, i32, i64, C.c_char, i32, vp, P(vp), P(i64), P(i64)], C.c_int),
+        "ffx_host_repeated_in_groups": ([vp, vp, i64, i64, i32, P(i64)], C.c_int),
         "ffx_buffer_free": ([vp], C.c_int),
         "ffx_host_code_u64": ([vp, i64, i32, vp, vp, P(i64)], C.c_int),
         "ffx_host_owner_crc32": ([vp, i32, vp, i32, i64, i32, i32, vp], C.c_int),
@@ -1030,6 +1033,78 @@ def code_strings(blob: bytes, n: int, threads: int = 0) -> tuple[np.ndarray, byt
         if names.value:
             lib().ffx_buffer_free(names)
     return codes, joined, int(n_names.value)
+
+
+def _coded_call(fn, n: int, *args, threads: int = 0):
+    """One of the ``ffx_strings_code*`` calls: (int32 codes, the distinct strings as :class:`Names`)."""
+    from fast_forward_amd.names import Names
+
+    codes = np.empty(int(n), dtype=np.int32)
+    names, n_bytes, n_names = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+    _check(fn(*args, int(n), b"\n", int(threads), _ptr(codes), C.byref(names), C.byref(n_bytes), C.byref(n_names)))
+    try:
+        joined = C.string_at(names.value, n_bytes.value) if names.value and n_bytes.value > 0 else b""
+    finally:
+        if names.value:
+            lib().ffx_buffer_free(names)
+    return codes, Names(joined, int(n_names.value))
+
+
+def code_arrow_strings(arr, threads: int = 0):
+    """(int32 code of every element, the distinct strings as :class:`Names`) of a pyarrow ``string`` / ``large_string`` array
+    (or chunked array), numbered straight from its offsets and data buffers -- no Python object per row, no copy of the
+    text.  None when that does not apply (another type, nulls, a string holding a line break)."""
+    import pyarrow as pa
+
+    if isinstance(arr, pa.ChunkedArray):
+        arr = arr.chunk(0) if arr.num_chunks == 1 else arr.combine_chunks()
+        if isinstance(arr, pa.ChunkedArray):  # (no chunk at all)
+            arr = pa.array([], type=arr.type)
+    large = pa.types.is_large_string(arr.type)
+    if not (large or pa.types.is_string(arr.type)) or arr.null_count:
+        return None
+    n = len(arr)
+    if n == 0:
+        from fast_forward_amd.names import Names
+
+        return np.zeros(0, dtype=np.int32), Names(b"", 0)
+    bufs = arr.buffers()  # [validity, offsets, data]
+    width = 8 if large else 4
+    offsets = C.c_void_p(bufs[1].address + arr.offset * width)
+    data = C.c_void_p(bufs[2].address if bufs[2] is not None else 0)
+    fn = lib().ffx_strings_code_offsets if large else lib().ffx_strings_code_offsets32
+    codes, names = _coded_call(fn, n, data, offsets, threads=threads)
+    if names.blob.count(b"\n") != max(0, names.n - 1):
+        return None
+    return codes, names
+
+
+def code_fixed_strings(a: np.ndarray, threads: int = 0):
+    """The same for a NumPy array of fixed-width bytes (``S<w>``); ``U<w>`` arrays are converted when they are ASCII."""
+    if a.dtype.kind == "U":
+        try:
+            a = a.astype("S")
+        except UnicodeEncodeError:
+            return None
+    if a.dtype.kind != "S" or a.ndim != 1:
+        return None
+    a = np.ascontiguousarray(a)
+    if a.shape[0] == 0 or a.dtype.itemsize == 0:
+        from fast_forward_amd.names import Names
+
+        return np.zeros(a.shape[0], dtype=np.int32), Names(b"", 1 if a.shape[0] else 0)
+    codes, names = _coded_call(lib().ffx_strings_code_fixed, a.shape[0], _ptr(a), int(a.dtype.itemsize), threads=threads)
+    if names.blob.count(b"\n") != max(0, names.n - 1):
+        return None
+    return codes, names
+
+
+def repeated_in_groups(codes: np.ndarray, group_off: np.ndarray, n_codes: int, threads: int = 0) -> int:
+    """``ffx_host_repeated_in_groups``: the first group of rows holding one code twice, -1 if none."""
+    codes, group_off = _arr(codes, np.int32), _arr(group_off, np.int64)
+    group = C.c_int64(-1)
+    _check(lib().ffx_host_repeated_in_groups(_ptr(codes), _ptr(group_off), group_off.shape[0] - 1, int(n_codes), int(threads), C.byref(group)))
+    return int(group.value)
 
 
 def owner_of_rows(doc_ids: "np.ndarray | None", psg_ids: "np.ndarray | None", world: int, threads: int = 0) -> np.ndarray:

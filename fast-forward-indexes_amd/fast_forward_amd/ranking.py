@@ -19,6 +19,7 @@ from __future__ import annotations
 import logging
 from collections.abc import Iterator, Mapping
 from pathlib import Path
+from time import perf_counter
 
 import numpy as np
 import pandas as pd
@@ -30,6 +31,7 @@ LOGGER = logging.getLogger(__name__)
 Run = Mapping[str, Mapping[str, float]]
 _KEY = ["q_id", "id"]
 _CODED_FROM_FILE_ROWS = 1 << 16  # run files with at least this many rows are read into the coded form
+BUILD_TIMINGS: dict = {}  # where the time of the last large Ranking(...) / Ranking.from_columns went (seconds per stage)
 
 
 def _with_queries(df: pd.DataFrame, queries: Mapping[str, str]) -> pd.DataFrame:
@@ -126,6 +128,70 @@ def _order_by_query_then_score(q_rank: np.ndarray, score: np.ndarray) -> np.ndar
             grouped = np.argsort(q_rank, kind="stable")
             return grouped[native.host_order(score[grouped], off)]
     return np.lexsort((-score.astype(np.float64), q_rank))
+
+
+def _coded_text_column(native, col) -> "tuple[np.ndarray, object] | None":
+    """(int32 code of every row, the distinct strings by code) of a column of strings in any columnar form -- a
+    ``(codes, names)`` pair or pandas ``Categorical`` (pre-coded), a pyarrow string array or a pandas Series backed by one,
+    a NumPy ``S`` / ``U`` array, an object array of ``str`` -- or None when the column is something else or holds a missing
+    value.  No Python object per row is made for any of them (the object array HAS one per row already: its cells are
+    numbered through their addresses, ``native.code_object_column``)."""
+    if isinstance(col, tuple) and len(col) == 2:
+        codes, names = col
+        codes = np.asarray(codes)
+        if codes.ndim != 1 or codes.dtype.kind not in "iu":
+            return None
+        if isinstance(names, Names):
+            table, of_name = names, None
+        else:  # the names in any column form; numbered like a column (a table may name one string twice)
+            got = _coded_text_column(native, names)
+            if got is None:
+                return None
+            of_name, table = got
+        n_given = len(of_name) if of_name is not None else len(table)
+        if len(codes) and (int(codes.min()) < 0 or int(codes.max()) >= n_given):
+            return None  # (-1: pandas' code for a missing value)
+        codes = np.ascontiguousarray(codes, dtype=np.int32)
+        if of_name is not None and not (len(of_name) == len(table) and np.array_equal(of_name, np.arange(len(table), dtype=np.int32))):
+            codes = native.take32(np.ascontiguousarray(of_name, dtype=np.int32), codes)
+        return codes, table
+    if isinstance(col, pd.Series):
+        if isinstance(col.dtype, pd.CategoricalDtype):
+            col = col.array
+        elif col.dtype == object:
+            col = col.to_numpy()
+        elif hasattr(col.array, "__arrow_array__"):
+            col = col.array
+        else:
+            return None
+    if isinstance(col, pd.Categorical):
+        return _coded_text_column(native, (col.codes, col.categories.to_numpy(dtype=object)))
+    if isinstance(col, (list, tuple)):
+        arr = np.empty(len(col), dtype=object)
+        arr[:] = col
+        col = arr
+    if isinstance(col, np.ndarray):
+        if col.dtype == object:
+            if col.ndim != 1:
+                return None
+            got = native.code_object_column(np.ascontiguousarray(col))
+            if got is None:
+                return None
+            codes, names, packed = got
+            return codes, (names if packed is None else Names(packed[0], packed[1], objects=names))
+        return native.code_fixed_strings(col) if col.dtype.kind in "SU" else None
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return None
+    if hasattr(col, "__arrow_array__") and not isinstance(col, (pa.Array, pa.ChunkedArray)):
+        try:
+            col = pa.array(col) if not hasattr(col, "_pa_array") else col._pa_array
+        except (pa.ArrowInvalid, pa.ArrowTypeError, TypeError, ValueError):
+            return None
+    if isinstance(col, (pa.Array, pa.ChunkedArray)):
+        return native.code_arrow_strings(col)
+    return None
 
 
 class Ranking:
@@ -279,12 +345,12 @@ class Ranking:
     def _init_from_columns(self, df: pd.DataFrame, queries, dtype: np.dtype, copy: bool, is_sorted: bool) -> bool:
         """The constructor for the ordinary large frame -- string ids, numeric scores, nothing missing but possibly
         some scores -- without a pandas hash of a Python string per row: every text column is numbered natively
-        (``native.code_object_column``: the column's object POINTERS first, then only the distinct strings), and the
-        duplicate check, the NaN drop, the sort and the per-row query numbers all work on those integers.  The
-        result is kept in the coded form (query number, id code, score per row + the two string tables); the frame
-        of strings is built if and when somebody asks for it.  34.9 M rows: seconds where three ``pd.factorize``
-        passes and three object-column gathers took ~20.  Returns False (nothing done) for anything else -- a
-        non-string cell, a query id with two different texts, no native library -- and the general code decides."""
+        (``_coded_text_column``: Arrow-backed and categorical columns from their buffers, object columns through the
+        column's object POINTERS first, then only the distinct strings), and the duplicate check, the NaN drop, the sort
+        and the per-row query numbers all work on those integers (``_build_coded``).  The result is kept in the coded
+        form (query number, id code, score per row + the two string tables); the frame of strings is built if and when
+        somebody asks for it.  Returns False (nothing done) for anything else -- a non-string cell, a query id with two
+        different texts, no native library -- and the general code decides."""
         from pandas.api.types import is_bool_dtype, is_numeric_dtype
 
         if len(df) < 2048 or any(c not in df.columns for c in (*_KEY, "score")):
@@ -295,56 +361,101 @@ class Ranking:
         native = _native_or_none()
         if native is None:
             return False
-        text_cols = [*_KEY] + (["query"] if "query" in df.columns else [])
-        if any(df[c].dtype != object for c in text_cols):
-            return False
         coded = {}
-        for c in text_cols:  # (None: some cell is not a str -- missing values, numbers: the general path knows what to do)
-            coded[c] = native.code_object_column(np.ascontiguousarray(df[c].to_numpy()))
+        laps = BUILD_TIMINGS
+        laps.clear()
+        for c in [*_KEY] + (["query"] if "query" in df.columns else []):
+            t0 = perf_counter()
+            coded[c] = _coded_text_column(native, df[c])  # (None: missing values, numbers, ...: the general path knows what to do)
+            laps[f"column_{c}_numbered_s"] = perf_counter() - t0
             if coded[c] is None:
                 return False
-        (q_code, q_names, _), (id_code, id_names, id_blob) = coded["q_id"], coded["id"]
-        if id_blob is not None:  # the distinct names are one buffer already: the table an index resolves and a writer prints from
-            id_names, id_blob = Names(id_blob[0], id_blob[1], objects=id_names), None
+        return self._build_coded(native, coded["q_id"], coded["id"], s_col.to_numpy(), queries, coded.get("query"), dtype, is_sorted,
+                                 getattr(df, "_ffx_pairs_unique", False))
+
+    def _build_coded(self, native, q_col, id_col, score: np.ndarray, queries, text_col, dtype: np.dtype, is_sorted: bool, pairs_unique: bool) -> bool:
+        """The coded form from numbered columns: ``q_col`` / ``id_col`` / ``text_col`` = (int32 code of every row, the
+        distinct strings by code).  What the reference's constructor does with strings (ranking.py:95-117) -- repeated
+        pairs refused, rows without a score dropped, rows ordered by query id descending and score descending, queries
+        numbered in order of first appearance -- on integers.  A run that stands grouped by query (any run file, any frame
+        made from one) is ordered query by query by host threads, scores and id codes moved along in the same pass
+        (``ffx_host_rank_blocks``), and looked through for repeated pairs block by block.  False: one query id with two
+        different texts (nothing done; the frame path decides)."""
+        laps, t0 = BUILD_TIMINGS, perf_counter()
+        q_code, q_names = q_col
+        id_code, id_names = id_col
         n_q = len(q_names)
-        text_of_q = None
-        if "query" in coded:
-            t_code, t_names, _ = coded["query"]
+        q_names = np.asarray(q_names)
+        text_of_q = t_names = None
+        if text_col is not None:
+            t_code, t_names = text_col
             text_of_q = np.full(n_q, -1, dtype=np.int32)
             text_of_q[q_code] = t_code
             if not np.array_equal(text_of_q[q_code], t_code):
                 return False  # one query id with two different texts: leave it to the frame path
-        score = s_col.to_numpy()
-        if not getattr(df, "_ffx_pairs_unique", False):
-            key = q_code.astype(np.int64) * max(1, len(id_names)) + id_code
-            key.sort()
-            if (key[1:] == key[:-1]).any():
-                raise ValueError("Only one score per query-document/passage pair is allowed.")
-            del key
-        rows = None  # None: every row, in frame order
         if score.dtype.kind == "f":
             missing = np.isnan(score)
-            if missing.any():
-                rows = np.flatnonzero(~missing).astype(np.int32)
-        score = score.astype(dtype, copy=True) if rows is None else score[rows].astype(dtype)
-        codes = q_code if rows is None else q_code[rows]
-        if not is_sorted:
-            rank_of = np.empty(n_q, dtype=np.int64)
-            rank_of[np.argsort(q_names)[::-1]] = np.arange(n_q)
-            order = np.ascontiguousarray(_order_by_query_then_score(rank_of[codes], score), dtype=np.int32)
-            rows = order if rows is None else rows[order]
-            score, codes = native.take32(score, order) if score.dtype.itemsize == 4 else score[order], native.take32(codes, order)
-        id_codes = id_code if rows is None else native.take32(id_code, rows)
-        # query numbers: order of first appearance in the final row order (base.py:418-421)
-        starts = np.concatenate([[0], np.flatnonzero(codes[1:] != codes[:-1]) + 1]) if len(codes) else np.zeros(0, dtype=np.int64)
-        if len(codes) and np.unique(codes[starts]).shape[0] == starts.shape[0]:
-            firsts = codes[starts]  # rows of a query adjacent: the numbers follow the blocks
-            block_off = np.concatenate([starts, [len(codes)]]).astype(np.int64)
+            if missing.any():  # rows without a score are dropped (ranking.py:103)
+                rows = np.flatnonzero(~missing)
+                q_code, id_code, score = q_code[rows], id_code[rows], score[rows]
+        score = np.ascontiguousarray(score.astype(dtype, copy=False))
+        n = len(q_code)
+        starts = np.concatenate([[0], np.flatnonzero(q_code[1:] != q_code[:-1]) + 1]) if n else np.zeros(0, dtype=np.int64)
+        run_q = q_code[starts]
+        laps["texts_checked_scores_cast_blocks_found_s"] = perf_counter() - t0
+        t0 = perf_counter()
+        rank_of = np.empty(n_q, dtype=np.int64)  # position of every query id in descending order (ranking.py:115-117)
+        rank_of[np.argsort(q_names)[::-1]] = np.arange(n_q)
+        block_off = None
+        if n and np.unique(run_q).shape[0] == run_q.shape[0] and score.dtype == np.float32:
+            # one block per query: ordered inside by threads, the blocks laid out by rank, repeated pairs looked for block by block
+            off = np.concatenate([starts, [n]]).astype(np.int64)
+            id_code = np.ascontiguousarray(id_code, dtype=np.int32)
+            if is_sorted:
+                block_off, firsts = off, run_q
+                score, id_codes = native.page_locked_copy(score), native.page_locked_copy(id_code)
+            else:
+                by_rank = np.argsort(rank_of[run_q], kind="stable")
+                block_off = np.zeros(len(by_rank) + 1, dtype=np.int64)
+                np.cumsum(np.diff(off)[by_rank], out=block_off[1:])
+                dst = np.empty(len(by_rank), dtype=np.int64)
+                dst[by_rank] = block_off[:-1]  # where block q lands
+                score, id_codes = native.rank_blocks(score, id_code, off, dst)
+                firsts = run_q[by_rank]
+            laps["queries_ordered_columns_moved_s"] = perf_counter() - t0
+            t0 = perf_counter()
+            if not pairs_unique and native.repeated_in_groups(id_codes, block_off, len(id_names)) >= 0:
+                raise ValueError("Only one score per query-document/passage pair is allowed.")
+            laps["repeated_pairs_looked_for_s"] = perf_counter() - t0
+            t0 = perf_counter()
             q_no = native.run_numbers(block_off)
+            laps["rows_numbered_by_query_s"] = perf_counter() - t0
         else:
-            block_off = None
-            q_no, firsts = pd.factorize(codes)
-            q_no = q_no.astype(np.int64, copy=False)
+            if not pairs_unique:
+                key = q_code.astype(np.int64) * max(1, len(id_names)) + id_code
+                key.sort()
+                if (key[1:] == key[:-1]).any():
+                    raise ValueError("Only one score per query-document/passage pair is allowed.")
+                del key
+            codes = q_code
+            if not is_sorted:
+                order = np.ascontiguousarray(_order_by_query_then_score(rank_of[q_code], score), dtype=np.int32)
+                score = native.take32(score, order) if score.dtype.itemsize == 4 else score[order]
+                codes, id_code = native.take32(q_code, order), native.take32(np.ascontiguousarray(id_code, dtype=np.int32), order)
+            # query numbers: order of first appearance in the final row order (base.py:418-421)
+            starts = np.concatenate([[0], np.flatnonzero(codes[1:] != codes[:-1]) + 1]) if n else np.zeros(0, dtype=np.int64)
+            if n and np.unique(codes[starts]).shape[0] == starts.shape[0]:
+                firsts = codes[starts]  # rows of a query adjacent: the numbers follow the blocks
+                block_off = np.concatenate([starts, [n]]).astype(np.int64)
+                q_no = native.run_numbers(block_off)
+            else:
+                q_no, firsts = pd.factorize(codes)
+                q_no = q_no.astype(np.int64, copy=False)
+            # what an index uploads on every call on this ranking -- first-stage scores and id codes -- lives in page-locked blocks
+            # when it is large and a device is there (native.page_locked_copy: DMA at link rate instead of a staged copy per call)
+            id_codes = native.page_locked_copy(np.ascontiguousarray(id_code, dtype=np.int32))
+            if score.dtype == np.float32:
+                score = native.page_locked_copy(score)
         q_order = [q_names[i] for i in firsts]
         if queries is not None:
             if any(q not in queries for q in q_order):
@@ -354,18 +465,78 @@ class Ranking:
             q_texts = None if text_of_q is None else [t_names[text_of_q[i]] for i in firsts]
         self._frame = None
         self._id_cache = None
-        # what an index uploads on every call on this ranking -- first-stage scores and id codes -- lives in page-locked blocks
-        # when it is large and a device is there (native.page_locked_copy: DMA at link rate instead of a staged copy per call)
-        id_codes = native.page_locked_copy(np.ascontiguousarray(id_codes, dtype=np.int32))
-        if score.dtype == np.float32:
-            score = native.page_locked_copy(np.ascontiguousarray(score))
         self._coded = {"q_no": q_no, "q_order": q_order, "id_codes": id_codes, "id_names": id_names,
-                       "score": score, "q_texts": q_texts, "id_blob": id_blob}
+                       "score": score, "q_texts": q_texts, "id_blob": None}
         self._q_no, self._q_order = q_no, q_order
         self._q_ids = set(q_order)
         if block_off is not None:  # the CSR by query an index asks for (_csr) is known already: no pass over the rows later
             self._csr_cache = (q_no, None, block_off)
         return True
+
+    @classmethod
+    def from_columns(cls, q_ids, ids, scores, name: "str | None" = None, queries: "Mapping[str, str] | None" = None,
+                     dtype: np.dtype = np.dtype(np.float32), is_sorted: bool = False) -> "Ranking":
+        """A ranking from COLUMNS -- one entry per (query, candidate) row -- without a Python object per row: what
+        ``Ranking(pd.DataFrame({"q_id": q_ids, "id": ids, "score": scores}), ...)`` gives (same checks, same order,
+        same values; ranking.py:67-121), for runs of tens of millions of rows.  ``q_ids`` / ``ids`` may each be
+
+        * a pyarrow ``string`` / ``large_string`` array or chunked array, or a pandas Series backed by one
+          (``dtype="string[pyarrow]"``, ``pd.ArrowDtype(pa.string())``): numbered from its offsets and data buffers;
+        * a NumPy array of fixed-width bytes (``S``) or ASCII text (``U``);
+        * pre-coded: a ``(codes, names)`` pair -- integer code of every row, distinct strings by code -- or a pandas
+          ``Categorical``;
+        * an object array / list of ``str`` (numbered through the objects' addresses first).
+
+        ``scores``: a numeric array; rows whose score is NaN are dropped.  Raises ``ValueError`` for a repeated (query, id)
+        pair and for incomplete ``queries``; ``TypeError`` for a column that is none of the above or holds missing values."""
+        native = _native_or_none()
+        if native is None:
+            raise ImportError("Ranking.from_columns needs libffx (build it: python -c 'import __graft_entry__ as g; g.build()')")
+        scores = np.asarray(scores)
+        if scores.ndim != 1 or scores.dtype.kind not in "fiu":
+            raise TypeError("scores must be a one-dimensional numeric array")
+        cols = []
+        BUILD_TIMINGS.clear()
+        for label, col in (("q_ids", q_ids), ("ids", ids)):
+            t0 = perf_counter()
+            got = _coded_text_column(native, col)
+            BUILD_TIMINGS[f"column_{label}_numbered_s"] = perf_counter() - t0
+            if got is None:
+                raise TypeError(f"{label}: not a column of strings without missing values (see Ranking.from_columns)")
+            if len(got[0]) != scores.shape[0]:
+                raise ValueError("q_ids, ids and scores must have one entry per row each")
+            cols.append(got)
+        out = cls.__new__(cls)
+        out.name = name
+        if scores.shape[0] == 0:
+            out._df = pd.DataFrame({"q_id": np.empty(0, dtype=object), "id": np.empty(0, dtype=object), "score": np.empty(0, dtype=np.dtype(dtype))})
+            out._q_no, out._q_order, out._q_ids = np.zeros(0, dtype=np.int64), [], set()
+            return out
+        built = out._build_coded(native, cols[0], cols[1], scores, queries, None, np.dtype(dtype), is_sorted, False)
+        assert built
+        return out
+
+    def columns(self) -> dict:
+        """This ranking as columns, without a Python object per row: ``{"q_codes", "q_names", "id_codes", "id_names",
+        "score", "pair_off"}`` -- the query of row i is ``q_names[q_codes[i]]``, its candidate ``id_names[id_codes[i]]``
+        (``id_names``: a :class:`~fast_forward_amd.names.Names`, the distinct ids as one buffer; ``np.asarray`` makes
+        strings of it); ``pair_off``: the rows of query number q are ``pair_off[q] .. pair_off[q+1]`` when the rows stand
+        grouped by query (they do for every ranking a constructor or an index made), else None.  Rows in this ranking's
+        order (query id descending, score descending).  The arrays are the ranking's own: do not write to them."""
+        if self._coded is None:
+            codes, names = self._id_coding()
+            packed = native_packed = None
+            native = _native_or_none()
+            if native is not None:
+                native_packed = native._packed(names)
+            id_names = Names(native_packed[0], native_packed[1], objects=names) if native_packed is not None else names
+            del packed
+            score = self._frame["score"].to_numpy()
+        else:
+            codes, id_names, score = self._coded["id_codes"], self._coded["id_names"], self._coded["score"]
+        perm, pair_off = self._csr() if len(self._q_no) else (None, np.zeros(len(self._q_order) + 1, dtype=np.int64))
+        return {"q_codes": self._q_no, "q_names": list(self._q_order), "id_codes": codes, "id_names": id_names, "score": score,
+                "pair_off": pair_off if perm is None else None}
 
     @classmethod
     def _assemble(cls, columns: Mapping[str, np.ndarray], name: str | None, q_no: np.ndarray, q_order: list[str]) -> "Ranking":

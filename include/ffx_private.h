@@ -94,6 +94,15 @@ int ffx_strings_code(const char* data, int64_t n_bytes, char sep, int64_t n, int
  * an Arrow string array: nothing to join, nothing to scan for separators); `sep` only joins *names_blob */
 int ffx_strings_code_offsets(const char* data, const int64_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes,
                              char** names_blob, int64_t* names_bytes, int64_t* n_names);
+/* ... with 32-bit offsets (an Arrow `string` array), and for n NUL-padded fields of `width` bytes (numpy 'S<width>') */
+int ffx_strings_code_offsets32(const char* data, const int32_t* offsets, int64_t n, char sep, int32_t n_threads, int32_t* codes,
+                               char** names_blob, int64_t* names_bytes, int64_t* n_names);
+int ffx_strings_code_fixed(const char* data, int32_t width, int64_t n, char sep, int32_t n_threads, int32_t* codes, char** names_blob,
+                           int64_t* names_bytes, int64_t* n_names);
+/* *group = the first group of rows (group_off[g] .. group_off[g+1]) that holds one code twice, -1 if none: the repeated
+ * (query, id) pair of ranking.py:95-98 for rows grouped by query that hold id codes in [0, n_codes) */
+int ffx_host_repeated_in_groups(const int32_t* codes, const int64_t* group_off, int64_t n_groups, int64_t n_codes, int32_t n_threads,
+                                int64_t* group);
 int ffx_buffer_free(void* p);
 /* owner[i] = crc32 (zlib's) of row i's document id -- its passage id if it has no document id -- modulo world: the rank of a
  * sharded index that holds the row (255: the row has neither id).  Ids as NUL-padded fixed-width fields (the id columns of
