@@ -39,6 +39,7 @@
 
 #include "../../include/ffx.h"
 #include "../../include/ffx_private.h"
+#include "host_xfer.h"
 #include "ffx_internal.h"  // ffx_fail, ffx_debug_variant, in-place hooks of plans and merges (ffx.hip)
 
 namespace {
@@ -573,7 +574,7 @@ static int shm_exchange_body(ffx_comm* c, const Piece* pc, bool device, hipStrea
     if (pc[r].n_send > 0) {
       char* dst = static_cast<char*>(c->seg[c->rank].p) + (size_t)at * 4;
       if (device)
-        C_HIP(hipMemcpyAsync(dst, pc[r].send, (size_t)pc[r].n_send * 4, hipMemcpyDeviceToHost, st));
+        C_TRY(ffx_d2h(c->device, dst, pc[r].send, (size_t)pc[r].n_send * 4, st));
       else
         memcpy(dst, pc[r].send, (size_t)pc[r].n_send * 4);
     }
@@ -598,7 +599,7 @@ static int shm_exchange_body(ffx_comm* c, const Piece* pc, bool device, hipStrea
       const char* src = static_cast<const char*>(c->seg[r].p) + (size_t)off * 4;
       const size_t bytes = (size_t)pc[r].n_recv * 4;
       if (device)
-        C_HIP(hipMemcpyAsync(pc[r].recv, src, bytes, hipMemcpyHostToDevice, st));
+        C_TRY(ffx_h2d(c->device, pc[r].recv, src, bytes, st));
       else
         memcpy(pc[r].recv, src, bytes);
     }
@@ -882,10 +883,10 @@ int ffx_comm_exchange_host(ffx_comm* c, const float* send, const int64_t* send_c
   }
   float* dev = c->stage_dev;
   int rc = FFX_OK;
-  if (n_send > 0 && hipMemcpyAsync(dev, send, (size_t)n_send * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+  if (n_send > 0 && ffx_h2d(c->device, dev, send, (size_t)n_send * sizeof(float), c->stream) != FFX_OK)
     rc = ffx_fail(FFX_HIP_ERROR, "upload of the local scores failed");
   if (rc == FFX_OK) rc = ffx_comm_exchange(c, dev, send_counts, dev + n_send, recv_counts, c->stream);
-  if (rc == FFX_OK && n_recv > 0 && hipMemcpyAsync(recv, dev + n_send, (size_t)n_recv * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+  if (rc == FFX_OK && n_recv > 0 && ffx_d2h(c->device, recv, dev + n_send, (size_t)n_recv * sizeof(float), c->stream) != FFX_OK)
     rc = ffx_fail(FFX_HIP_ERROR, "download of the received scores failed");
   if (hipStreamSynchronize(c->stream) != hipSuccess && rc == FFX_OK) rc = ffx_fail(FFX_HIP_ERROR, "stream synchronisation failed");
   return rc;
@@ -1306,9 +1307,9 @@ int sharded_route_on_device(ffx_sharded* s, const int64_t* pair_off, int64_t n_q
   unsigned long long* d_recv = d_bad + 1;
   int64_t* d_qb = reinterpret_cast<int64_t*>(d_bad) + 1 + kMaxWorld;
   int64_t* d_pick = d_qb + kMaxWorld + 1;
-  C_HIP(hipMemcpyAsync(s->d_off.p, pair_off, ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice, st));
-  if (P > 0) C_HIP(hipMemcpyAsync(s->d_ids.p, pair_ids, (size_t)P * 4, hipMemcpyHostToDevice, st));
-  C_HIP(hipMemcpyAsync(d_qb, qb.data(), ((size_t)world + 1) * 8, hipMemcpyHostToDevice, st));
+  C_TRY(ffx_h2d(s->device, s->d_off.p, pair_off, ((size_t)n_queries + 1) * 8, st));
+  if (P > 0) C_TRY(ffx_h2d(s->device, s->d_ids.p, pair_ids, (size_t)P * 4, st));
+  C_TRY(ffx_h2d(s->device, d_qb, qb.data(), ((size_t)world + 1) * 8, st));
   C_HIP(hipMemsetAsync(d_bad, 0xFF, 8, st));
   C_HIP(hipMemsetAsync(d_recv, 0, (size_t)kMaxWorld * 8, st));
   C_HIP(hipMemsetAsync(s->d_cnt.p, 0, ((size_t)n_queries + 1) * 8, st));
@@ -1350,8 +1351,8 @@ int sharded_route_on_device(ffx_sharded* s, const int64_t* pair_off, int64_t n_q
   // what the host needs: the verdict, the counts, the local CSR offsets (the plans size their row lists from them)
   std::vector<int64_t> small(small_words);
   if (s->local_off.size() < (size_t)n_queries + 1) s->local_off.resize((size_t)n_queries + 1);
-  C_HIP(hipMemcpyAsync(small.data(), s->d_small.p, small_words * 8, hipMemcpyDeviceToHost, st));
-  C_HIP(hipMemcpyAsync(s->local_off.data(), s->d_local_off.p, ((size_t)n_queries + 1) * 8, hipMemcpyDeviceToHost, st));
+  C_TRY(ffx_d2h(s->device, small.data(), s->d_small.p, small_words * 8, st));
+  C_TRY(ffx_d2h(s->device, s->local_off.data(), s->d_local_off.p, ((size_t)n_queries + 1) * 8, st));
   C_HIP(hipStreamSynchronize(st));
   const unsigned long long bad = (unsigned long long)small[0];
   if (bad != ~0ull) {
@@ -1744,30 +1745,30 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
   int64_t h2d = (Qo + 1) * 8 + s->staged_query_bytes;
   s->staged_query_bytes = 0;
   if (own_queries && Qo > 0) {
-    C_HIP(hipMemcpyAsync(d_q + (size_t)q_lo * qdim, own_queries, (size_t)Qo * qdim * 4, hipMemcpyHostToDevice, io));
+    C_TRY(ffx_h2d(s->device, d_q + (size_t)q_lo * qdim, own_queries, (size_t)Qo * qdim * 4, io));
     h2d += Qo * (int64_t)qdim * 4;
   }
   C_HIP(hipEventRecord(sl.queries_up, io));
   if (Po > 0) {
-    C_HIP(hipMemcpyAsync(s->d_ids.p, own_ids, (size_t)Po * 4, hipMemcpyHostToDevice, io));
+    C_TRY(ffx_h2d(s->device, s->d_ids.p, own_ids, (size_t)Po * 4, io));
     h2d += Po * 4;
     if (own_holder) {
-      C_HIP(hipMemcpyAsync(s->d_held.p, own_holder, (size_t)Po * 4, hipMemcpyHostToDevice, io));
+      C_TRY(ffx_h2d(s->device, s->d_held.p, own_holder, (size_t)Po * 4, io));
       h2d += Po * 4;
     }
   }
   C_HIP(hipEventRecord(s->ids_up, io));
   if (own_sparse && Po > 0) {
-    C_HIP(hipMemcpyAsync(m_sparse, own_sparse, (size_t)Po * 4, hipMemcpyHostToDevice, io));
+    C_TRY(ffx_h2d(s->device, m_sparse, own_sparse, (size_t)Po * 4, io));
     h2d += Po * 4;
   }
   C_HIP(hipEventRecord(sl.sparse_up, io));
-  C_HIP(hipMemcpyAsync(m_off, own_off, ((size_t)Qo + 1) * 8, hipMemcpyHostToDevice, rs));
+  C_TRY(ffx_h2d(s->device, m_off, own_off, ((size_t)Qo + 1) * 8, rs));
   if (n_tiles > 0) {
-    C_HIP(hipMemcpyAsync(d_tile_p0, tile_p0.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, rs));
-    C_HIP(hipMemcpyAsync(d_tile_hi, tile_hi.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, rs));
+    C_TRY(ffx_h2d(s->device, d_tile_p0, tile_p0.data(), (size_t)n_tiles * 8, rs));
+    C_TRY(ffx_h2d(s->device, d_tile_hi, tile_hi.data(), (size_t)n_tiles * 8, rs));
   }
-  C_HIP(hipMemcpyAsync(d_tile_first, tile_first.data(), ((size_t)Qo + 1) * 4, hipMemcpyHostToDevice, rs));
+  C_TRY(ffx_h2d(s->device, d_tile_first, tile_first.data(), ((size_t)Qo + 1) * 4, rs));
   int64_t route_send = 0, route_recv = 0;
   // the query vectors of the whole batch, every rank contributing its block
   if (own_queries && world > 1) {
@@ -1925,7 +1926,7 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
       int64_t at = h_got[2 * r];
       for (int i = 0; i < r; ++i) at += sl.recv_counts[(size_t)i];
       std::vector<int32_t> slots((size_t)Po);
-      C_HIP(hipMemcpy(slots.data(), m_slot, (size_t)Po * 4, hipMemcpyDeviceToHost));
+      C_TRY(ffx_d2h_now(s->device, slots.data(), m_slot, (size_t)Po * 4));
       int64_t found = -1;
       for (int64_t p = 0; p < Po && found < 0; ++p)
         if (slots[(size_t)p] == at) found = p;
@@ -1963,6 +1964,10 @@ int sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* ow
   s->cur = t;
   ++s->staged;
   s->have_pairs = true;
+  // the caller's own_* arrays are free again on return (ffx.h): ordinary memory has been consumed by ffx_h2d, page-locked
+  // memory is read by copies on the upload stream, of which the first-stage scores are the last (normally long done:
+  // the two waits for the routing stream above came after the ordinals, which precede them on the same stream)
+  C_HIP(hipEventSynchronize(sl.sparse_up));
   s->stage_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return FFX_OK;
 }
@@ -2072,7 +2077,7 @@ int ffx_sharded_set_code_table(ffx_sharded* s, const int32_t* ordinal_of_code, i
     return FFX_OK;
   }
   C_TRY(s->d_code_table.ensure((size_t)std::max<int64_t>(n_codes, 1) * 4));
-  if (n_codes > 0) C_HIP(hipMemcpy(s->d_code_table.p, ordinal_of_code, (size_t)n_codes * 4, hipMemcpyHostToDevice));
+  if (n_codes > 0) C_TRY(ffx_h2d_now(s->device, s->d_code_table.p, ordinal_of_code, (size_t)n_codes * 4));
   s->n_codes = n_codes;
   return FFX_OK;
 }
@@ -2096,7 +2101,7 @@ int ffx_sharded_stage_queries(ffx_sharded* s, const float* all_queries, int64_t 
   C_TRY(ffx_plan_queries_room(s->plans[t], n_queries, &d_q));
   int32_t qdim = 0;
   C_TRY(ffx_index_query_dim(s->shard, &qdim));
-  if (n_queries > 0) C_HIP(hipMemcpyAsync(d_q, all_queries, (size_t)n_queries * qdim * 4, hipMemcpyHostToDevice, s->up));
+  if (n_queries > 0) C_TRY(ffx_h2d(s->device, d_q, all_queries, (size_t)n_queries * qdim * 4, s->up));
   s->staged_query_bytes = n_queries * (int64_t)qdim * 4;
   return FFX_OK;
 }

@@ -32,6 +32,7 @@
 #include "../../include/ffx.h"
 #include "../../include/ffx_private.h"
 #include "ffx_internal.h"
+#include "host_xfer.h"
 #include "aux_kernels.hip.h"
 #include "gather_dot.hip.h"
 
@@ -64,21 +65,10 @@ void ffx_abort_backtrace(int) {
   signal(SIGABRT, SIG_DFL);
   raise(SIGABRT);
 }
-// Transfers between ORDINARY host memory and the device of more than 1 MiB make the HIP runtime page-lock the caller's pages on
-// the fly (its default; the knob is GPU_PINNED_MIN_XFER_SIZE, in MiB).  On this stack (ROCm 7.2, gfx950) that path now and then
-// leaves the device with a bad mapping of HEAP memory: in 7 of 28 full runs of this repository's GPU suite the runtime ended the
-// process with "Memory access fault by GPU node-N on address A" -- A inside the NumPy array a blocking hipMemcpy was writing at
-// that moment ("Write access to a read-only page", 1 - 5 pages past the end of a heap range that had been hipHostRegister'ed and
-// released earlier), or inside another heap array ("Reason: Unknown"); profiles/r04/abort_hunt.  malloc never serves more than
-// 32 MiB from the heap (glibc's cap on its mmap threshold), so with the threshold at 32 MiB heap memory is never page-locked
-// behind the caller's back -- such transfers go through the runtime's own staging blocks (30 GB/s in, 17 GB/s out instead of
-// 40 - 55: tools/probes/pinned_xfer_knob.py) -- while large arrays, which are mappings of their own, keep the fast path.  The
-// runtime reads the variable when it starts: this runs when the library is loaded, sets it only if the process has not, and
-// FFX_KEEP_RUNTIME_PINNING=1 leaves the runtime's default alone.
-__attribute__((constructor)) void ffx_keep_the_runtime_from_pinning_heap_memory() {
-  const char* keep = getenv("FFX_KEEP_RUNTIME_PINNING");
-  if (!(keep && *keep && *keep != '0')) setenv("GPU_PINNED_MIN_XFER_SIZE", "32", 0);
-}
+// (Rounds 3 - 4 lowered the runtime's on-the-fly page-locking threshold from a constructor here, GPU_PINNED_MIN_XFER_SIZE=32: a
+// process-wide setting changed behind the host program's back.  Gone: every transfer between caller memory and the device now
+// goes through host_xfer.h, which stages ordinary memory through page-locked blocks of the library's own, so the runtime is
+// never handed pages it would lock -- whatever its threshold, and whether or not HIP was initialised before this library loaded.)
 __attribute__((constructor)) void ffx_install_abort_backtrace() {
   const char* e = getenv("FFX_ABORT_BACKTRACE");
   if (e && *e && *e != '0') {
@@ -394,7 +384,7 @@ int plan_h2d(ffx_plan* pl, void* dst, const void* src, size_t bytes) {
     memcpy(st, src, bytes);
     src = st;
   }
-  FFX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pl->stream));
+  FFX_TRY(ffx_h2d(pl->device, dst, src, bytes, pl->stream));
   return FFX_OK;
 }
 }  // namespace
@@ -414,7 +404,7 @@ int check_pq_codes(ffx_index* idx, int64_t row, int64_t n_rows) {
     ffx::pq_check_codes_kernel<<<blocks_for(n_bytes, 256), 256>>>(reinterpret_cast<const uint8_t*>(idx->row_ptr(row)), n_bytes, idx->pq_ks, flag);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(&bad, flag, sizeof bad, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&bad, flag, sizeof bad, hipMemcpyDeviceToHost);  // (8 bytes: the runtime's own staging)
   (void)hipFree(flag);
   if (e != hipSuccess) return fail(FFX_HIP_ERROR, "code check failed: %s", hipGetErrorString(e));
   if (bad != ~0ull)
@@ -562,13 +552,13 @@ int ffx_index_set_codebook(ffx_index* idx, const float* codewords, int32_t m, in
   }
   const size_t bytes = (size_t)m * ks * ds * sizeof(float);
   FFX_TRY(idx->codebook.ensure(bytes));
-  FFX_HIP(hipMemcpy(idx->codebook.p, codewords, bytes, hipMemcpyHostToDevice));
+  FFX_TRY(ffx_h2d_now(idx->device, idx->codebook.p, codewords, bytes));
   std::vector<float> tr((size_t)m * ks * ds);
   for (int a = 0; a < m; ++a)
     for (int b = 0; b < ks; ++b)
       for (int c = 0; c < ds; ++c) tr[((size_t)a * ds + c) * ks + b] = codewords[((size_t)a * ks + b) * ds + c];
   FFX_TRY(idx->codebook_t.ensure(bytes));
-  FFX_HIP(hipMemcpy(idx->codebook_t.p, tr.data(), bytes, hipMemcpyHostToDevice));
+  FFX_TRY(ffx_h2d_now(idx->device, idx->codebook_t.p, tr.data(), bytes));
   idx->pq_ks = ks;
   idx->pq_ds = ds;
   idx->qdim = m * ds;
@@ -594,7 +584,7 @@ int ffx_index_upload(ffx_index* idx, const void* host_rows, int64_t row_offset, 
                 (long long)(row_offset + n_rows), (long long)idx->capacity);
   if (n_rows == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(idx->device));
-  FFX_HIP(hipMemcpy(idx->row_ptr(row_offset), host_rows, (size_t)n_rows * idx->dim * idx->elem, hipMemcpyHostToDevice));
+  FFX_TRY(ffx_h2d_now(idx->device, idx->row_ptr(row_offset), host_rows, (size_t)n_rows * idx->dim * idx->elem));
   return check_pq_codes(idx, row_offset, n_rows);
 }
 
@@ -748,7 +738,7 @@ int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t
     idx->pull_chunk_hosts.clear();
     FFX_TRY(idx->pull_chunks.ensure((size_t)n_chunks * sizeof(void*)));
     FFX_HIP(hipStreamSynchronize(idx->copy_stream));  // (a kernel of an earlier call may still read the old table)
-    FFX_HIP(hipMemcpy(idx->pull_chunks.p, dev.data(), (size_t)n_chunks * sizeof(void*), hipMemcpyHostToDevice));
+    FFX_TRY(ffx_h2d_now(idx->device, idx->pull_chunks.p, dev.data(), (size_t)n_chunks * sizeof(void*)));
     idx->pull_chunk_hosts.assign(chunks, chunks + n_chunks);
   }
   for (int64_t c = 0; c < n_chunks; ++c)  // the widest unit every row starts on
@@ -942,10 +932,10 @@ int ffx_index_set_doc_rows(ffx_index* idx, const int64_t* doc_off, int64_t n_doc
   FFX_TRY(idx->doc_off.ensure(off32.size() * sizeof(int32_t)));
   FFX_TRY(idx->doc_rows.ensure(std::max<size_t>((size_t)n_doc_rows, 1) * sizeof(int32_t)));
   FFX_TRY(idx->doc_first.ensure(first.size() * sizeof(int32_t)));
-  FFX_HIP(hipMemcpy(idx->doc_off.p, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  FFX_HIP(hipMemcpy(idx->doc_first.p, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  FFX_TRY(ffx_h2d_now(idx->device, idx->doc_off.p, off32.data(), off32.size() * sizeof(int32_t)));
+  FFX_TRY(ffx_h2d_now(idx->device, idx->doc_first.p, first.data(), first.size() * sizeof(int32_t)));
   if (n_doc_rows > 0)
-    FFX_HIP(hipMemcpy(idx->doc_rows.p, doc_rows, (size_t)n_doc_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    FFX_TRY(ffx_h2d_now(idx->device, idx->doc_rows.p, doc_rows, (size_t)n_doc_rows * sizeof(int32_t)));
   idx->n_docs = n_docs;
   idx->n_doc_rows = n_doc_rows;
   idx->max_doc_rows = 1;
@@ -961,7 +951,7 @@ int ffx_index_set_psg_rows(ffx_index* idx, const int32_t* psg_row, int64_t n_psg
   if (n_psgs > INT32_MAX) return fail(FFX_BAD_ARG, "too many passages for int32 ids");
   FFX_HIP(hipSetDevice(idx->device));
   FFX_TRY(idx->psg_row.ensure(std::max<size_t>((size_t)n_psgs, 1) * sizeof(int32_t)));
-  if (n_psgs > 0) FFX_HIP(hipMemcpy(idx->psg_row.p, psg_row, (size_t)n_psgs * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n_psgs > 0) FFX_TRY(ffx_h2d_now(idx->device, idx->psg_row.p, psg_row, (size_t)n_psgs * sizeof(int32_t)));
   idx->n_psgs = n_psgs;
   bool identity = n_psgs > 0 && n_psgs <= idx->capacity;
   for (int64_t i = 0; i < n_psgs && identity; ++i) identity = psg_row[i] == i;
@@ -1006,7 +996,7 @@ static int plan_create(ffx_index* idx, ffx_plan** out, bool with_stream) {
     pl->anyd_tails = pl->anyd_tails || (len % 8) != 0;
   }
   int rc = pl->leaf_start.ensure(bounds.size() * sizeof(int));
-  if (rc == FFX_OK && hipMemcpy(pl->leaf_start.p, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+  if (rc == FFX_OK && ffx_h2d_now(pl->device, pl->leaf_start.p, bounds.data(), bounds.size() * sizeof(int)) != FFX_OK)
     rc = fail(FFX_HIP_ERROR, "leaf plan upload failed");
   if (rc == FFX_OK) {
     std::vector<int> steps;
@@ -1014,7 +1004,7 @@ static int plan_create(ffx_index* idx, ffx_plan** out, bool with_stream) {
     numpy_combine_plan(idx->qdim, next_leaf, steps);
     steps.push_back(0);  // never empty
     rc = pl->combine_steps.ensure(steps.size() * sizeof(int));
-    if (rc == FFX_OK && hipMemcpy(pl->combine_steps.p, steps.data(), steps.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    if (rc == FFX_OK && ffx_h2d_now(pl->device, pl->combine_steps.p, steps.data(), steps.size() * sizeof(int)) != FFX_OK)
       rc = fail(FFX_HIP_ERROR, "combine plan upload failed");
   }
   if (rc == FFX_OK && pl->n_leaves > 8 && idx->dtype != FFX_DTYPE_PQ8) {
@@ -1054,7 +1044,7 @@ static int plan_create(ffx_index* idx, ffx_plan** out, bool with_stream) {
       pl->segments.clear();  // (rows beyond ~64 K elements: the staged generic kernel)
     } else {
       rc = pl->seg_tables.ensure(tables.size() * sizeof(int));
-      if (rc == FFX_OK && hipMemcpy(pl->seg_tables.p, tables.data(), tables.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+      if (rc == FFX_OK && ffx_h2d_now(pl->device, pl->seg_tables.p, tables.data(), tables.size() * sizeof(int)) != FFX_OK)
         rc = fail(FFX_HIP_ERROR, "segment plan upload failed");
     }
   }
@@ -1230,8 +1220,8 @@ static int set_pairs_check_launch(ffx_plan* pl) {
   pl->check_back = back ? back : pl->check_host;
   memset(pl->check_back, 0xFF, 8);
   memset(pl->check_back + 8, 0, 8);
-  FFX_HIP(hipMemcpyAsync(pl->check_back, pl->flags.p, 8, hipMemcpyDeviceToHost, pl->stream));
-  if (!pl->check_one_each) FFX_HIP(hipMemcpyAsync(pl->check_back + 8, pl->seg_off.as<int32_t>() + P, sizeof(int32_t), hipMemcpyDeviceToHost, pl->stream));
+  FFX_TRY(ffx_d2h(pl->device, pl->check_back, pl->flags.p, 8, pl->stream));
+  if (!pl->check_one_each) FFX_TRY(ffx_d2h(pl->device, pl->check_back + 8, pl->seg_off.as<int32_t>() + P, sizeof(int32_t), pl->stream));
   return FFX_OK;
 }
 
@@ -1265,7 +1255,7 @@ static int set_pairs_check_complete(ffx_plan* pl, int64_t* bad_pair) {
     FFX_TRY(pl->scan_tmp.ensure(std::max<size_t>(tmp, 16)));
     FFX_HIP(rocprim::reduce(pl->scan_tmp.p, tmp, wide, out64, (long long)0, (size_t)P, rocprim::plus<long long>(), pl->stream));
     long long exact = 0;
-    FFX_HIP(hipMemcpyAsync(&exact, out64, sizeof exact, hipMemcpyDeviceToHost, pl->stream));
+    FFX_TRY(ffx_d2h(pl->device, &exact, out64, sizeof exact, pl->stream));
     FFX_HIP(hipStreamSynchronize(pl->stream));
     if (exact > (long long)INT32_MAX)
       return fail(FFX_BAD_ARG, "%lld gathered rows in one batch (more than 2^31-1): split the queries", exact);
@@ -2186,7 +2176,7 @@ int ffx_plan_early_stopping(ffx_plan* pl, int32_t cutoff, double alpha, const in
     FFX_HIP(rocprim::exclusive_scan(pl->es_scan_tmp.p, tmp, pl->es_cnt.as<int64_t>(), ch->pair_off.as<int64_t>(), (int64_t)0, (size_t)(Q + 1),
                                     rocprim::plus<int64_t>(), st));
     int64_t n_sub = 0;  // counter 1 of 2: candidates of this interval
-    FFX_HIP(hipMemcpyAsync(&n_sub, ch->pair_off.as<int64_t>() + Q, sizeof n_sub, hipMemcpyDeviceToHost, st));
+    FFX_TRY(ffx_d2h(pl->device, &n_sub, ch->pair_off.as<int64_t>() + Q, sizeof n_sub, st));
     FFX_HIP(hipStreamSynchronize(st));
     if (n_sub == 0) break;  // no pairs are left (base.py:368-369)
     ffx::es_fill_kernel<<<(unsigned)Q, 256, 0, st>>>(pl->pair_off.as<int64_t>(), pl->pair_ids.as<int32_t>(), pl->sparse.as<float>(),
@@ -2203,12 +2193,12 @@ int ffx_plan_early_stopping(ffx_plan* pl, int32_t cutoff, double alpha, const in
     FFX_TRY(launch_count_scan(ch));
     unsigned long long bad = ~0ull;
     int32_t rows = 0;  // counter 2 of 2: index rows the interval gathers
-    FFX_HIP(hipMemcpyAsync(&bad, ch->flags.p, sizeof bad, hipMemcpyDeviceToHost, st));
-    FFX_HIP(hipMemcpyAsync(&rows, ch->seg_off.as<int32_t>() + n_sub, sizeof rows, hipMemcpyDeviceToHost, st));
+    FFX_TRY(ffx_d2h(pl->device, &bad, ch->flags.p, sizeof bad, st));
+    FFX_TRY(ffx_d2h(pl->device, &rows, ch->seg_off.as<int32_t>() + n_sub, sizeof rows, st));
     FFX_HIP(hipStreamSynchronize(st));
     if (bad != ~0ull) {
       int32_t at = -1;
-      FFX_HIP(hipMemcpy(&at, pl->es_pos.as<int32_t>() + bad, sizeof at, hipMemcpyDeviceToHost));
+      FFX_TRY(ffx_d2h_now(pl->device, &at, pl->es_pos.as<int32_t>() + bad, sizeof at));
       if (bad_pair) *bad_pair = at;
       return fail(FFX_NOT_FOUND, "pair %d names an ordinal with no rows in the index", at);
     }
@@ -2271,9 +2261,9 @@ int ffx_plan_fetch(ffx_plan* pl, float* out_ff, float* out_interp, int32_t* out_
       if (out_order) memcpy(out_order, b_or, each);
       return FFX_OK;
     }
-    if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff, pl->ff.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));
-    if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp, pl->interp.p, P * sizeof(float), hipMemcpyDeviceToHost, pl->stream));
-    if (out_order) FFX_HIP(hipMemcpyAsync(out_order, pl->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, pl->stream));
+    if (out_ff) FFX_TRY(ffx_d2h(pl->device, out_ff, pl->ff.p, P * sizeof(float), pl->stream));
+    if (out_interp) FFX_TRY(ffx_d2h(pl->device, out_interp, pl->interp.p, P * sizeof(float), pl->stream));
+    if (out_order) FFX_TRY(ffx_d2h(pl->device, out_order, pl->order.p, P * sizeof(int32_t), pl->stream));
   }
   FFX_HIP(hipStreamSynchronize(pl->stream));
   return FFX_OK;
@@ -2304,7 +2294,7 @@ int ffx_plan_fetch_scored(ffx_plan* pl, int64_t cap, int32_t* out_pos, float* ou
   FFX_TRY(pl->es_scan_tmp.ensure(std::max<size_t>(tmp, 16)));
   FFX_HIP(rocprim::select(pl->es_scan_tmp.p, tmp, positions, scored, pl->es_pos.as<int32_t>(), d_count, pb, st));
   unsigned long long count = 0;
-  FFX_HIP(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, st));
+  FFX_TRY(ffx_d2h(pl->device, &count, d_count, sizeof count, st));
   FFX_HIP(hipStreamSynchronize(st));
   *n_scored = (int64_t)count;
   const int64_t n = std::min<int64_t>((int64_t)count, cap);
@@ -2312,8 +2302,8 @@ int ffx_plan_fetch_scored(ffx_plan* pl, int64_t cap, int32_t* out_pos, float* ou
   float* packed = pl->iota.as<float>();
   ffx::take_f32_kernel<<<blocks_for(n, 256), 256, 0, st>>>(pl->ff.as<float>(), pl->es_pos.as<int32_t>(), n, packed);
   FFX_HIP(hipGetLastError());
-  FFX_HIP(hipMemcpyAsync(out_pos, pl->es_pos.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  FFX_HIP(hipMemcpyAsync(out_ff, packed, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  FFX_TRY(ffx_d2h(pl->device, out_pos, pl->es_pos.p, (size_t)n * sizeof(int32_t), st));
+  FFX_TRY(ffx_d2h(pl->device, out_ff, packed, (size_t)n * sizeof(float), st));
   FFX_HIP(hipStreamSynchronize(st));
   return FFX_OK;
 }
@@ -2426,13 +2416,13 @@ int ffx_merge_set(ffx_merge* m, const int64_t* pair_off, int64_t n_queries, cons
   FFX_TRY(m->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
   FFX_TRY(m->slot.ensure(pb * sizeof(int32_t)));
   FFX_TRY(m->ff.ensure(pb * sizeof(float)));
-  FFX_HIP(hipMemcpy(m->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-  if (P > 0) FFX_HIP(hipMemcpy(m->slot.p, recv_slot, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice));
+  FFX_TRY(ffx_h2d_now(m->device, m->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t)));
+  if (P > 0) FFX_TRY(ffx_h2d_now(m->device, m->slot.p, recv_slot, (size_t)P * sizeof(int32_t)));
   m->have_sparse = sparse != nullptr;
   if (sparse) {
     FFX_TRY(m->sparse.ensure(pb * sizeof(float)));
     FFX_TRY(m->interp.ensure(pb * sizeof(float)));
-    if (P > 0) FFX_HIP(hipMemcpy(m->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice));
+    if (P > 0) FFX_TRY(ffx_h2d_now(m->device, m->sparse.p, sparse, (size_t)P * sizeof(float)));
   }
   m->n_queries = n_queries;
   m->n_pairs = P;
@@ -2461,7 +2451,7 @@ int ffx_merge_set_device(ffx_merge* m, const int64_t* pair_off, int64_t n_querie
   FFX_TRY(m->ff.ensure(pb * sizeof(float)));
   FFX_TRY(m->sort_tmp.ensure(64));
   hipStream_t st = m->own_stream;
-  FFX_HIP(hipMemcpyAsync(m->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  FFX_TRY(ffx_h2d(m->device, m->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), st));
   unsigned long long bad = ~0ull;
   if (P > 0) {
     FFX_HIP(hipMemcpyAsync(m->slot.p, dev_recv_slot, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -2469,13 +2459,13 @@ int ffx_merge_set_device(ffx_merge* m, const int64_t* pair_off, int64_t n_querie
     FFX_HIP(hipMemsetAsync(flag, 0xFF, sizeof *flag, st));
     ffx::check_range_kernel<<<blocks_for(P, 256), 256, 0, st>>>(m->slot.as<int32_t>(), P, (int32_t)P, flag);
     FFX_HIP(hipGetLastError());
-    FFX_HIP(hipMemcpyAsync(&bad, flag, sizeof bad, hipMemcpyDeviceToHost, st));
+    FFX_TRY(ffx_d2h(m->device, &bad, flag, sizeof bad, st));
   }
   m->have_sparse = sparse != nullptr;
   if (sparse) {
     FFX_TRY(m->sparse.ensure(pb * sizeof(float)));
     FFX_TRY(m->interp.ensure(pb * sizeof(float)));
-    if (P > 0) FFX_HIP(hipMemcpyAsync(m->sparse.p, sparse, (size_t)P * sizeof(float), hipMemcpyHostToDevice, st));
+    if (P > 0) FFX_TRY(ffx_h2d(m->device, m->sparse.p, sparse, (size_t)P * sizeof(float), st));
   }
   FFX_HIP(hipStreamSynchronize(st));
   if (bad != ~0ull) return fail(FFX_BAD_ARG, "recv_slot[%llu] out of range", bad);
@@ -2544,9 +2534,9 @@ int ffx_merge_fetch(ffx_merge* m, float* out_ff, float* out_interp, int32_t* out
   FFX_HIP(hipStreamSynchronize(m->last_stream));
   const size_t P = (size_t)m->n_pairs;
   if (P > 0) {
-    if (out_ff) FFX_HIP(hipMemcpy(out_ff, m->ff.p, P * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_interp) FFX_HIP(hipMemcpy(out_interp, m->interp.p, P * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_order) FFX_HIP(hipMemcpy(out_order, m->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_ff) FFX_TRY(ffx_d2h_now(m->device, out_ff, m->ff.p, P * sizeof(float)));
+    if (out_interp) FFX_TRY(ffx_d2h_now(m->device, out_interp, m->interp.p, P * sizeof(float)));
+    if (out_order) FFX_TRY(ffx_d2h_now(m->device, out_order, m->order.p, P * sizeof(int32_t)));
   }
   return FFX_OK;
 }
@@ -2619,9 +2609,9 @@ int ffx_merge_fetch_async(ffx_merge* m, float* out_ff, float* out_interp, int32_
   FFX_HIP(hipSetDevice(m->device));
   const size_t P = (size_t)m->n_pairs;
   if (P > 0) {
-    if (out_ff) FFX_HIP(hipMemcpyAsync(out_ff, m->ff.p, P * sizeof(float), hipMemcpyDeviceToHost, stream));
-    if (out_interp) FFX_HIP(hipMemcpyAsync(out_interp, m->interp.p, P * sizeof(float), hipMemcpyDeviceToHost, stream));
-    if (out_order) FFX_HIP(hipMemcpyAsync(out_order, m->order.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (out_ff) FFX_TRY(ffx_d2h(m->device, out_ff, m->ff.p, P * sizeof(float), stream));
+    if (out_interp) FFX_TRY(ffx_d2h(m->device, out_interp, m->interp.p, P * sizeof(float), stream));
+    if (out_order) FFX_TRY(ffx_d2h(m->device, out_order, m->order.p, P * sizeof(int32_t), stream));
   }
   return FFX_OK;
 }
@@ -2681,20 +2671,20 @@ int ffx_aggregate(int device, const float* row_scores, const int64_t* seg_off, i
       at += 2 * b_p;
     }
     int64_t* d_po = (int64_t*)at;
-    FFX_HIP(hipMemcpy(d_rs, row_scores, (size_t)R * sizeof(float), hipMemcpyHostToDevice));
-    if (seg_off) FFX_HIP(hipMemcpy(d_so, off32.data(), off32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (sparse) FFX_HIP(hipMemcpy(d_sp, sparse, (size_t)n_pairs * sizeof(float), hipMemcpyHostToDevice));
+    FFX_TRY(ffx_h2d_now(device, d_rs, row_scores, (size_t)R * sizeof(float)));
+    if (seg_off) FFX_TRY(ffx_h2d_now(device, d_so, off32.data(), off32.size() * sizeof(int32_t)));
+    if (sparse) FFX_TRY(ffx_h2d_now(device, d_sp, sparse, (size_t)n_pairs * sizeof(float)));
     ffx::reduce_kernel<<<blocks_for(n_pairs, 256), 256>>>(d_rs, d_so, n_pairs, mode, d_sp, (float)alpha, (float)(1.0 - alpha), d_ff, d_in);
     FFX_HIP(hipGetLastError());
     if (do_sort) {
-      FFX_HIP(hipMemcpy(d_po, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+      FFX_TRY(ffx_h2d_now(device, d_po, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t)));
       const float* k = (sparse && !(flags & FFX_FLAG_SORT_FF)) ? d_in : d_ff;
       FFX_TRY(launch_segmented_sort(k, n_pairs, d_po, n_queries, order, iota, keys, tmp, nullptr, longest_segment(pair_off, n_queries)));
     }
     FFX_HIP(hipDeviceSynchronize());
-    FFX_HIP(hipMemcpy(out_ff, d_ff, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_interp) FFX_HIP(hipMemcpy(out_interp, d_in, (size_t)n_pairs * sizeof(float), hipMemcpyDeviceToHost));
-    if (do_sort) FFX_HIP(hipMemcpy(out_order, order.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FFX_TRY(ffx_d2h_now(device, out_ff, d_ff, (size_t)n_pairs * sizeof(float)));
+    if (out_interp) FFX_TRY(ffx_d2h_now(device, out_interp, d_in, (size_t)n_pairs * sizeof(float)));
+    if (do_sort) FFX_TRY(ffx_d2h_now(device, out_order, order.p, (size_t)n_pairs * sizeof(int32_t)));
     return FFX_OK;
   };
   rc = run();
@@ -3028,8 +3018,8 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
     FFX_TRY(ffx_plan_fetch(pl, out_ff ? out_ff + p0 : nullptr, out_interp ? out_interp + p0 : nullptr,
                            out_order ? out_order + p0 : nullptr));
     if (pl->n_pairs > 0) {
-      if (out_ranked) FFX_HIP(hipMemcpy(out_ranked + p0, pl->ranked.p, (size_t)pl->n_pairs * sizeof(float), hipMemcpyDeviceToHost));
-      if (out_carry) FFX_HIP(hipMemcpy(out_carry + p0, pl->carry_ranked.p, (size_t)pl->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (out_ranked) FFX_TRY(ffx_d2h_now(idx->device, out_ranked + p0, pl->ranked.p, (size_t)pl->n_pairs * sizeof(float)));
+      if (out_carry) FFX_TRY(ffx_d2h_now(idx->device, out_carry + p0, pl->carry_ranked.p, (size_t)pl->n_pairs * sizeof(int32_t)));
     }
     return add_stats(pl);
   };
@@ -3155,7 +3145,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
         FFX_TRY(pl->carry_ranked.ensure(sb));
         if (carry) {
           FFX_TRY(pl->carry.ensure(sb));
-          if (pair_off[q1] > p0) FFX_HIP(hipMemcpyAsync(pl->carry.p, carry + p0, (size_t)(pair_off[q1] - p0) * 4, hipMemcpyHostToDevice, pl->stream));
+          if (pair_off[q1] > p0) FFX_TRY(ffx_h2d(idx->device, pl->carry.p, carry + p0, (size_t)(pair_off[q1] - p0) * 4, pl->stream));
         }
       }
       pl->want_ranked = ranked;

@@ -1,0 +1,286 @@
+// host_xfer.cpp -- see host_xfer.h: the caller's ordinary memory never reaches the runtime in pieces it would page-lock.
+#include "host_xfer.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <system_error>
+#include <thread>
+#include <vector>
+
+#include "../../include/ffx.h"
+#include "../../include/ffx_private.h"
+
+int ffx_fail(int code, const char* fmt, ...);  // ffx.hip
+extern thread_local std::string g_last_error;
+
+namespace {
+
+constexpr size_t kDirectBytes = size_t(1) << 20;  // at or below: the runtime copies through its own staging, it pins nothing
+constexpr size_t kPiece = size_t(4) << 20;
+constexpr int kLanes = 4;       // host threads (and copy streams) a large transfer is spread over
+constexpr int kMaxDevices = 64;
+
+#define X_HIP(expr)                                                                                              \
+  do {                                                                                                           \
+    hipError_t e_ = (expr);                                                                                      \
+    if (e_ != hipSuccess)                                                                                        \
+      return ffx_fail(e_ == hipErrorOutOfMemory ? FFX_OOM : FFX_HIP_ERROR, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                      __FILE__, __LINE__);                                                                       \
+  } while (0)
+
+struct Lane {
+  char* block[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};  // block b's last copy (in: out of it, out: into it) is done
+  bool busy[2] = {false, false};
+  hipStream_t st = nullptr;
+  hipEvent_t done = nullptr;  // everything this lane queued for the current transfer
+  int make(bool high_priority) {
+    if (st) return FFX_OK;
+    int least = 0, greatest = 0;
+    X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // results leave at the highest priority (a copy queued behind the next slices' kernels leaves when they are done);
+    // uploads at normal priority
+    X_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high_priority ? greatest : 0));
+    X_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) {
+      X_HIP(hipHostMalloc(reinterpret_cast<void**>(&block[b]), kPiece, hipHostMallocDefault));
+      X_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    }
+    return FFX_OK;
+  }
+  void release() {
+    if (st) (void)hipStreamSynchronize(st);
+    for (int b = 0; b < 2; ++b) {
+      if (block[b]) (void)hipHostFree(block[b]);
+      if (ev[b]) (void)hipEventDestroy(ev[b]);
+      block[b] = nullptr;
+      ev[b] = nullptr;
+      busy[b] = false;
+    }
+    if (done) (void)hipEventDestroy(done);
+    if (st) (void)hipStreamDestroy(st);
+    done = nullptr;
+    st = nullptr;
+  }
+};
+
+// one direction of one device: a transfer holds the mutex from its first piece to its last
+struct Way {
+  std::mutex mu;
+  Lane lanes[kLanes];
+  hipEvent_t fence = nullptr;  // what the stream held when the transfer began
+};
+
+struct DeviceWays {
+  Way in, out;
+};
+
+DeviceWays* g_ways[kMaxDevices] = {};
+std::mutex g_ways_mu;
+
+DeviceWays* ways_of(int device) {
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ways_mu);
+  if (!g_ways[device]) g_ways[device] = new (std::nothrow) DeviceWays();
+  return g_ways[device];
+}
+
+std::atomic<unsigned long long> g_staged_transfers{0}, g_staged_bytes{0};
+
+int lanes_for(size_t bytes) {
+  const size_t pieces = (bytes + kPiece - 1) / kPiece;
+  // a thread per 8 MiB at least: starting one costs what copying ~0.5 MiB does
+  return (int)std::max<size_t>(1, std::min<size_t>(kLanes, pieces / 2));
+}
+
+template <class Body>
+int on_threads(int T, Body&& body) {
+  std::vector<int> rc((size_t)T, FFX_OK);
+  std::vector<std::string> err((size_t)T);
+  std::vector<std::thread> pool;
+  auto run = [&](int t) {
+    rc[(size_t)t] = body(t);
+    if (rc[(size_t)t] != FFX_OK) err[(size_t)t] = g_last_error;  // thread-local: carried to the caller's thread
+  };
+  int started = 1;
+  for (int t = 1; t < T; ++t) {
+    try {
+      pool.emplace_back(run, t);
+      ++started;
+    } catch (const std::system_error&) {
+      break;  // no thread to be had: the calling thread takes the rest
+    }
+  }
+  run(0);
+  for (int t = started; t < T; ++t) run(t);
+  for (auto& th : pool) th.join();
+  for (int t = 0; t < T; ++t)
+    if (rc[(size_t)t] != FFX_OK) {
+      g_last_error = err[(size_t)t];
+      return rc[(size_t)t];
+    }
+  return FFX_OK;
+}
+
+}  // namespace
+
+bool ffx_runtime_owns(const void* p) {
+  hipPointerAttribute_t attr;
+  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess)
+    return attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  (void)hipGetLastError();  // an ordinary pointer is "invalid value" to the runtime: not an error here
+  return false;
+}
+
+int ffx_h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return FFX_OK;
+  if (!dst || !src) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: null pointer");
+  if (bytes <= kDirectBytes || ffx_runtime_owns(src)) {
+    X_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    return FFX_OK;
+  }
+  DeviceWays* dw = ways_of(device);
+  if (!dw) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: device %d", device);
+  Way& w = dw->in;
+  std::lock_guard<std::mutex> lock(w.mu);
+  X_HIP(hipSetDevice(device));
+  const int T = lanes_for(bytes);
+  if (!w.fence) X_HIP(hipEventCreateWithFlags(&w.fence, hipEventDisableTiming));
+  for (int t = 0; t < T; ++t) {
+    const int rc = w.lanes[t].make(false);
+    if (rc != FFX_OK) return rc;
+  }
+  // the destination may still be read by what the stream holds (the previous batch's kernels): the lanes start behind it
+  X_HIP(hipEventRecord(w.fence, stream));
+  const size_t n = (bytes + kPiece - 1) / kPiece;
+  const int rc = on_threads(T, [&](int t) -> int {
+    Lane& ln = w.lanes[t];
+    if (t > 0) X_HIP(hipSetDevice(device));
+    X_HIP(hipStreamWaitEvent(ln.st, w.fence, 0));
+    int b = 0;
+    for (size_t k = (size_t)t; k < n; k += (size_t)T, b ^= 1) {
+      const size_t at = k * kPiece, len = std::min(kPiece, bytes - at);
+      if (ln.busy[b]) X_HIP(hipEventSynchronize(ln.ev[b]));
+      memcpy(ln.block[b], static_cast<const char*>(src) + at, len);
+      X_HIP(hipMemcpyAsync(static_cast<char*>(dst) + at, ln.block[b], len, hipMemcpyHostToDevice, ln.st));
+      X_HIP(hipEventRecord(ln.ev[b], ln.st));
+      ln.busy[b] = true;
+    }
+    X_HIP(hipEventRecord(ln.done, ln.st));
+    return FFX_OK;
+  });
+  if (rc != FFX_OK) return rc;
+  for (int t = 0; t < T; ++t) X_HIP(hipStreamWaitEvent(stream, w.lanes[t].done, 0));
+  g_staged_transfers.fetch_add(1, std::memory_order_relaxed);
+  g_staged_bytes.fetch_add(bytes, std::memory_order_relaxed);
+  return FFX_OK;
+}
+
+int ffx_d2h(int device, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return FFX_OK;
+  if (!dst || !src) return ffx_fail(FFX_BAD_ARG, "ffx_d2h: null pointer");
+  if (bytes <= kDirectBytes || ffx_runtime_owns(dst)) {
+    X_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    return FFX_OK;
+  }
+  DeviceWays* dw = ways_of(device);
+  if (!dw) return ffx_fail(FFX_BAD_ARG, "ffx_d2h: device %d", device);
+  Way& w = dw->out;
+  std::lock_guard<std::mutex> lock(w.mu);
+  X_HIP(hipSetDevice(device));
+  const int T = lanes_for(bytes);
+  if (!w.fence) X_HIP(hipEventCreateWithFlags(&w.fence, hipEventDisableTiming));
+  for (int t = 0; t < T; ++t) {
+    const int rc = w.lanes[t].make(true);
+    if (rc != FFX_OK) return rc;
+  }
+  X_HIP(hipEventRecord(w.fence, stream));
+  const size_t n = (bytes + kPiece - 1) / kPiece;
+  const int rc = on_threads(T, [&](int t) -> int {
+    Lane& ln = w.lanes[t];
+    if (t > 0) X_HIP(hipSetDevice(device));
+    X_HIP(hipStreamWaitEvent(ln.st, w.fence, 0));
+    auto issue = [&](size_t k, int b) -> int {
+      const size_t at = k * kPiece, len = std::min(kPiece, bytes - at);
+      X_HIP(hipMemcpyAsync(ln.block[b], static_cast<const char*>(src) + at, len, hipMemcpyDeviceToHost, ln.st));
+      X_HIP(hipEventRecord(ln.ev[b], ln.st));
+      return FFX_OK;
+    };
+    // (the blocks of an out-lane are empty between transfers: every piece is copied out before the transfer returns)
+    if ((size_t)t < n) {
+      const int rc0 = issue((size_t)t, 0);
+      if (rc0 != FFX_OK) return rc0;
+    }
+    int b = 0;
+    for (size_t k = (size_t)t; k < n; k += (size_t)T, b ^= 1) {
+      if (k + (size_t)T < n) {
+        const int rc1 = issue(k + (size_t)T, b ^ 1);
+        if (rc1 != FFX_OK) return rc1;
+      }
+      X_HIP(hipEventSynchronize(ln.ev[b]));
+      const size_t at = k * kPiece, len = std::min(kPiece, bytes - at);
+      memcpy(static_cast<char*>(dst) + at, ln.block[b], len);
+    }
+    return FFX_OK;
+  });
+  if (rc != FFX_OK) {
+    for (int t = 0; t < T; ++t) (void)hipStreamSynchronize(w.lanes[t].st);  // nothing may still be landing in the blocks
+    return rc;
+  }
+  g_staged_transfers.fetch_add(1, std::memory_order_relaxed);
+  g_staged_bytes.fetch_add(bytes, std::memory_order_relaxed);
+  return FFX_OK;
+}
+
+int ffx_h2d_now(int device, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return FFX_OK;
+  X_HIP(hipSetDevice(device));
+  const int rc = ffx_h2d(device, dst, src, bytes, nullptr);
+  if (rc != FFX_OK) return rc;
+  X_HIP(hipStreamSynchronize(nullptr));
+  return FFX_OK;
+}
+
+int ffx_d2h_now(int device, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return FFX_OK;
+  X_HIP(hipSetDevice(device));
+  const int rc = ffx_d2h(device, dst, src, bytes, nullptr);
+  if (rc != FFX_OK) return rc;
+  X_HIP(hipStreamSynchronize(nullptr));
+  return FFX_OK;
+}
+
+void ffx_xfer_release() {
+  std::lock_guard<std::mutex> lock(g_ways_mu);
+  for (int d = 0; d < kMaxDevices; ++d) {
+    DeviceWays* dw = g_ways[d];
+    if (!dw) continue;
+    if (hipSetDevice(d) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    for (Way* w : {&dw->in, &dw->out}) {
+      std::lock_guard<std::mutex> held(w->mu);
+      for (auto& ln : w->lanes) ln.release();
+      if (w->fence) (void)hipEventDestroy(w->fence);
+      w->fence = nullptr;
+    }
+  }
+}
+
+void ffx_xfer_counters(unsigned long long* staged_transfers, unsigned long long* staged_bytes) {
+  if (staged_transfers) *staged_transfers = g_staged_transfers.load();
+  if (staged_bytes) *staged_bytes = g_staged_bytes.load();
+}
+
+extern "C" int ffx_host_xfer_stats(uint64_t* staged_transfers, uint64_t* staged_bytes) {
+  unsigned long long t = 0, b = 0;
+  ffx_xfer_counters(&t, &b);
+  if (staged_transfers) *staged_transfers = t;
+  if (staged_bytes) *staged_bytes = b;
+  return FFX_OK;
+}

@@ -39,7 +39,7 @@ SYMBOLS = (
 # ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
 PRIVATE_SYMBOLS = (
     "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
-    "ffx_index_prepare_score", "ffx_host_fill_runs",
+    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_strings_code_offsets32", "ffx_strings_code_fixed", "ffx_host_repeated_in_groups", "ffx_buffer_free",
@@ -104,20 +104,17 @@ def lib() -> C.CDLL:
 
     One process can hold only one HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own
     ``libamdhip64.so.7`` (same soname as /opt/rocm's), so whichever of torch and libffx is loaded
-    first decides which runtime both use.  The single-GPU path never imports torch; the
-    multi-GPU path (``fast_forward_amd.sharded``) imports torch BEFORE the first call in here."""
+    first decides which runtime both use.  Nothing in this package imports torch (the multi-GPU
+    path has its own communicator, csrc/comm.hip); a host program that does (a transformer query
+    encoder) may load either first -- ``TORCH_LOADED_FIRST`` records which it was.  Loading the
+    library changes no setting of the HIP runtime: transfers from or into ordinary memory are
+    staged by the library itself (csrc/host_xfer.h)."""
     global _lib, TORCH_LOADED_FIRST
     if _lib is not None:
         return _lib
     import sys
 
     TORCH_LOADED_FIRST = "torch" in sys.modules
-    # (libffx's constructor does the same for C callers; here too, so that os.environ -- what child processes inherit -- says
-    # so: the HIP runtime must not page-lock HEAP memory behind the caller's back, see csrc/ffx.hip)
-    import os
-
-    if os.environ.get("FFX_KEEP_RUNTIME_PINNING", "0") in ("", "0"):
-        os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "32")
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -213,6 +210,7 @@ def lib() -> C.CDLL:
         "ffx_run_ids_blob": ([vp, vp, i64, P(i64)], C.c_int),
         "ffx_run_names": ([vp, P(vp), P(i64), P(i64)], C.c_int),
         "ffx_host_stage_report": ([vp, i64, P(i64)], C.c_int),
+        "ffx_host_xfer_stats": ([P(C.c_uint64), P(C.c_uint64)], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
@@ -281,6 +279,14 @@ def stage_report() -> dict:
     buf = C.create_string_buffer(max(1, need.value))
     _check(lib().ffx_host_stage_report(buf, need.value, C.byref(need)))
     return {k: float(v) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
+
+
+def xfer_stats() -> dict:
+    """Transfers between ordinary host memory and the device that libffx staged through its own page-locked blocks since the
+    process began (csrc/host_xfer.h): {"transfers": n, "bytes": n}."""
+    n, b = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().ffx_host_xfer_stats(C.byref(n), C.byref(b)))
+    return {"transfers": int(n.value), "bytes": int(b.value)}
 
 
 def usable_cores() -> int:

@@ -306,7 +306,8 @@ int ffx_sharded_set_pairs_held(ffx_sharded* s, const int64_t* pair_off, int64_t 
  * on rank own_holder[p]; own_sparse may be NULL.  Collective, and may be called while the previous batch runs (three
  * batches rotate: staged, running, merging); ffx_sharded_run then runs the batch staged last.  Every rank returns the
  * same status: FFX_NOT_FOUND when any rank's candidate names an ordinal without rows (*bad_pair is set on the rank that
- * owns it: a position in ITS list).  Per-rank host->device bytes are proportional to the block, not to the batch. */
+ * owns it: a position in ITS list).  Per-rank host->device bytes are proportional to the block, not to the batch.
+ * Every own_* array has been read when the call returns: the caller may refill it for the next batch at once. */
 int ffx_sharded_stage_owned(ffx_sharded* s, const int64_t* q_bounds, const float* own_queries, const int64_t* own_pair_off,
                             const int32_t* own_pair_ids, const int32_t* own_holder, const float* own_sparse, int mode, int64_t* bad_pair);
 /* Shards whose rows only their holder can name (rows placed by a hash of the document id: every rank interns the ids of its own

@@ -48,6 +48,11 @@ int ffx_plan_set_pairs_device(ffx_plan* plan, const int64_t* dev_pair_off, const
  * runs back to back without waiting in between (n <= 256 and <= the runs so far); waits for the stream */
 int ffx_plan_recent_gather_ms(ffx_plan* plan, int32_t n, float* out_ms);
 
+/* How much of the traffic between caller memory and the device the library staged through its own page-locked blocks
+ * since the process began (csrc/host_xfer.h: ordinary memory above 1 MiB never reaches the runtime, which would page-lock
+ * it on the fly): transfers and bytes.  For tests and tools. */
+int ffx_host_xfer_stats(uint64_t* staged_transfers, uint64_t* staged_bytes);
+
 /* ---- merge: the owner-side half of a row-sharded index --------------------------------------
  * With the index row-sharded by document over several GPUs (one process each), every rank scores
  * the candidates whose documents it holds, and the dense scores of one query arrive at the

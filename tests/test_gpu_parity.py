@@ -1315,6 +1315,52 @@ def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
     idx.close()
 
 
+def test_ordinary_memory_travels_through_the_librarys_own_blocks(monkeypatch):
+    """csrc/host_xfer.h: arrays in ordinary memory above 1 MiB -- index rows, candidate lists, first-stage scores, result
+    buffers, one slice or many, one staging thread or several -- are cut into pieces that go through page-locked blocks of
+    the library (ffx_host_xfer_stats counts them), never to the runtime, which would page-lock the caller's pages on the fly;
+    page-locked buffers are handed over as they are (the counters stand still).  Same bytes either way, against the oracle."""
+    d, n_docs = 768, 5000
+    rng = np.random.default_rng(77)
+    vectors = synth.rows(31, 0.05, 0, n_docs, d)  # 15 MB: four pieces, two staging threads
+    before = native.xfer_stats()
+    idx = native.DeviceIndex(n_docs, d)
+    idx.upload(vectors, 0)
+    after = native.xfer_stats()
+    assert after["transfers"] == before["transfers"] + 1 and after["bytes"] - before["bytes"] == vectors.nbytes
+    idx.set_doc_rows(np.arange(n_docs + 1), np.arange(n_docs))
+    idx.set_psg_rows(np.arange(n_docs))
+    back = idx.gather(np.arange(n_docs)) if hasattr(idx, "gather") else None
+    if back is not None:
+        assert np.array_equal(back, vectors)
+    n_q, k = 40, 20_000  # 800 k candidates: 3.2 MB per array (nothing here takes the single-submission path)
+    queries = synth.rows(32, 0.05, 0, n_q, d)
+    pair_off = np.arange(n_q + 1, dtype=np.int64) * k
+    pair_ids = rng.integers(0, n_docs, size=n_q * k).astype(np.int32)
+    sparse = rng.random(n_q * k, dtype=np.float32) * 10
+    want_ff, want_in = fo.score(vectors, np.arange(n_docs + 1), np.arange(n_docs), np.arange(n_docs), queries, pair_off, pair_ids, 2, sparse, 0.2)
+    want_order = fo.order(want_in, pair_off)
+    for variant in ("no_small_path", "no_small_path,score_slice_pairs=300000", "no_small_path,score_slice_pairs=300000,score_blocking_out"):
+        monkeypatch.setenv("FFX_DEBUG_VARIANT", variant)
+        at = native.xfer_stats()
+        ff, interp, order, _ = native.score(idx, queries, pair_off, pair_ids, 2, sparse, 0.2, sort=True)
+        moved = native.xfer_stats()
+        assert np.array_equal(bits(ff), bits(want_ff)) and np.array_equal(bits(interp), bits(want_in)), variant
+        assert np.array_equal(order.astype(np.int64), want_order), variant
+        # candidate ordinals and first-stage scores went up through the blocks, slice by slice (a slice's arrays of at
+        # most 1 MiB -- the short slices a call begins and ends with -- go to the runtime, which copies those itself)
+        share = 0.9 if variant == "no_small_path" else 0.3
+        assert moved["bytes"] - at["bytes"] >= share * (pair_ids.nbytes + sparse.nbytes), (variant, at, moved)
+    # page-locked buffers both ways: nothing is staged
+    out = tuple(native.pinned_empty(n_q * k, t) for t in (np.float32, np.float32, np.int32))
+    with native.pinned(queries, pair_ids, sparse):
+        at = native.xfer_stats()
+        ff2, in2, or2, _ = native.score(idx, queries, pair_off, pair_ids, 2, sparse, 0.2, sort=True, out=out)
+        assert native.xfer_stats() == at
+    assert np.array_equal(bits(ff2), bits(want_ff)) and np.array_equal(bits(in2), bits(want_in)) and np.array_equal(or2.astype(np.int64), want_order)
+    idx.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float16, np.uint8])
 def test_upload_rows_gathers_from_chunk_maps(monkeypatch, dtype):
     """ffx_index_upload_rows: stored rows scattered over equally sized chunks land in consecutive

@@ -151,12 +151,10 @@ def test_header_is_plain_c(tmp_path):
     assert subprocess.run([str(exe)]).returncode == 0
 
 
-def test_loading_the_library_keeps_the_runtime_from_page_locking_heap_memory():
-    """libffx sets GPU_PINNED_MIN_XFER_SIZE=32 (MiB) when it is loaded -- the HIP runtime then stages transfers from or into
-    ordinary memory of up to 32 MiB (all that malloc ever serves from the heap) instead of page-locking the caller's pages on
-    the fly, the path the rare device fault of DESIGN.md section 10 came from -- unless the process has set the variable
-    itself or asks for the runtime's default (FFX_KEEP_RUNTIME_PINNING=1).  Checked in child processes (the variable is
-    decided when the library is loaded): through the Python binding, and through the C constructor alone (ctypes.CDLL)."""
+def test_loading_the_library_changes_no_setting_of_the_runtime():
+    """Rounds 3 - 4 set GPU_PINNED_MIN_XFER_SIZE from a library constructor and from the binding.  A library must not
+    reconfigure the runtime of its host process: loading libffx -- through the binding or through dlopen alone -- leaves the
+    variable as the process had it (unset stays unset).  Checked in child processes."""
     import subprocess
     import sys
     from pathlib import Path
@@ -165,14 +163,35 @@ def test_loading_the_library_keeps_the_runtime_from_page_locking_heap_memory():
     lib = root / "fast-forward-indexes_amd" / "fast_forward_amd" / "libffx.so"
     via_binding = ("import os, sys; sys.path.insert(0, %r); from fast_forward_amd import native; native.lib(); "
                    "print(os.environ.get('GPU_PINNED_MIN_XFER_SIZE'))" % str(root / "fast-forward-indexes_amd"))
-    via_constructor = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL('libc.so.6'); libc.getenv.restype = ctypes.c_char_p; "
-                       "print((libc.getenv(b'GPU_PINNED_MIN_XFER_SIZE') or b'None').decode())" % str(lib))
-    base = {k: v for k, v in os.environ.items() if k not in ("GPU_PINNED_MIN_XFER_SIZE", "FFX_KEEP_RUNTIME_PINNING")}
-    for code in (via_binding, via_constructor):
-        for extra, want in (({}, "32"), ({"GPU_PINNED_MIN_XFER_SIZE": "7"}, "7"), ({"FFX_KEEP_RUNTIME_PINNING": "1"}, "None")):
+    via_dlopen = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL('libc.so.6'); libc.getenv.restype = ctypes.c_char_p; "
+                  "print((libc.getenv(b'GPU_PINNED_MIN_XFER_SIZE') or b'None').decode())" % str(lib))
+    base = {k: v for k, v in os.environ.items() if k != "GPU_PINNED_MIN_XFER_SIZE"}
+    for code in (via_binding, via_dlopen):
+        for extra, want in (({}, "None"), ({"GPU_PINNED_MIN_XFER_SIZE": "7"}, "7")):
             out = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=120)
             assert out.returncode == 0, out.stderr[-2000:]
             assert out.stdout.strip().splitlines()[-1] == want, (code[:40], extra, out.stdout)
+
+
+def test_caller_memory_reaches_the_runtime_only_through_host_xfer():
+    """What replaces the setting: every copy between host memory and the device in ffx.hip / comm.hip goes through
+    ffx_h2d / ffx_d2h (csrc/host_xfer.h: ordinary memory above 1 MiB is staged through page-locked blocks of the library), or
+    names a page-locked block of the library itself.  A raw hipMemcpy of either direction anywhere else fails this test --
+    the lines below are the known page-locked ones, by what they copy."""
+    import re
+
+    csrc = ROOT / "fast-forward-indexes_amd" / "csrc"
+    page_locked = ("(dev, host, bytes,", "(host + kSmall,", "(h_small,", "(h_local_off,", "(h_got,", "(8 bytes:", ", idx->stage[s],", ", idx->pull_list_host,",
+                   ", s_rows,", "(s_out,", "(b_ff,", "(b_in,", "(b_or,", "(pl->out_stage[lane]", "hipMemcpyDeviceToHost, os)")
+    raw = re.compile(r"hipMemcpy(Async)?\(.*hipMemcpy(HostToDevice|DeviceToHost)")
+    loose = []
+    for name in ("ffx.hip", "comm.hip", "host_io.cpp", "run_file.cpp"):
+        for n, line in enumerate((csrc / name).read_text().splitlines(), 1):
+            if raw.search(line) and not line.lstrip().startswith("//") and not any(word in line for word in page_locked):
+                loose.append(f"{name}:{n}: {line.strip()}")
+    assert not loose, "\n".join(loose)
+    text = (csrc / "ffx.hip").read_text()
+    assert "setenv(" not in text and "setenv(" not in (csrc / "comm.hip").read_text()
 
 
 def test_helpers_around_page_locked_memory_degrade_quietly_without_a_device():
