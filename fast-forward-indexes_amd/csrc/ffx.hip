@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <future>
 #include <cstdarg>
 #include <cstdio>
@@ -114,7 +115,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 //   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
 //   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N   where the per-query sort switches form
 //   sort_interp_apart      the interpolation (and the owner-side scatter) as launches of their own instead of inside the block sort
-//   score_slice_pairs=N, score_ramp_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N, count_always
+//   score_plans=N, score_slice_pairs=N, score_ramp_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N, count_always
 //                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py)
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
 // (FFX_SCORE_TRACE=1 -- a timeline on stderr -- and the operational settings FFX_COMM_TIMEOUT_S, FFX_RDZV_DIR,
@@ -260,7 +261,8 @@ struct ffx_index {
   bool psgs_identity = false;  // passage ordinal o is row o
   bool docs_nonempty = false;  // every document has at least one row
   // the plans ffx_score rotates through (two; three when results leave asynchronously); created on first use, freed with the index
-  struct ffx_plan* score_plans[3] = {nullptr, nullptr, nullptr};
+  static constexpr int kScorePlans = 5;
+  struct ffx_plan* score_plans[kScorePlans] = {};
   // page-locked staging of ffx_index_upload_rows: two blocks, filled by host threads while the
   // other one is in flight to the device
   void* stage[2] = {nullptr, nullptr};
@@ -279,7 +281,7 @@ struct ffx_index {
   // copy of slice c is not queued behind the scoring kernels of slice c+1), one event per plan
   hipStream_t out_stream = nullptr;
   hipStream_t score_stream = nullptr;  // ... and every slice's kernels run on this one, in order (see ffx_score)
-  hipEvent_t out_done[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t out_done[kScorePlans] = {};
   // FFX_FLAG_KEEP_DENSE: the dense scores (first-stage order) and the carried words of the last such ffx_score_ranked call,
   // for ffx_rank_kept (Ranking.interpolate on an Index.__call__ result: the interpolation and the ordering, no gather)
   void* gather_stage = nullptr;  // ffx_index_gather's page-locked block (rows never go straight into the caller's memory)
@@ -351,9 +353,8 @@ struct ffx_plan {
   // results of a slice of ffx_score on their way into ORDINARY memory of the caller (the helper thread of that slice): two
   // page-locked blocks and a stream of the plan's own, see staged_d2h
   static constexpr size_t kOutStageBytes = 4 << 20;
-  static constexpr int kOutLanes = 5;  // one per result array of a slice (dense, interpolated, order, ranked, carried): they leave side by side
+  static constexpr int kOutLanes = 10;  // two per result array of a slice (dense, interpolated, order, ranked, carried): they leave side by side, in halves
   char* out_stage[kOutLanes][2] = {};
-  hipStream_t out_stage_stream[kOutLanes] = {};
   hipEvent_t out_stage_ev[kOutLanes][2] = {};
   char* hstage = nullptr;
   size_t hstage_used = 0;
@@ -1084,7 +1085,6 @@ int ffx_plan_destroy(ffx_plan* pl) {
       if (pl->out_stage[l][i]) (void)hipHostFree(pl->out_stage[l][i]);
       if (pl->out_stage_ev[l][i]) (void)hipEventDestroy(pl->out_stage_ev[l][i]);
     }
-    if (pl->out_stage_stream[l]) (void)hipStreamDestroy(pl->out_stage_stream[l]);
   }
   if (pl->hstage) (void)hipHostFree(pl->hstage);
   delete pl;
@@ -2812,18 +2812,16 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
 static int staged_d2h(ffx_plan* pl, int lane, void* dst, const void* src_dev, size_t bytes) {
   if (bytes == 0) return FFX_OK;
   FFX_HIP(hipSetDevice(pl->device));
-  if (!pl->out_stage_stream[lane]) {
-    // (highest priority, as the result stream of the page-locked form: a copy that queues behind the next slices' scoring
-    // kernels leaves when they are done -- measured: 24.6 ms for the headline batch with ordinary result buffers at normal priority)
-    int least = 0, greatest = 0;
-    FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    FFX_HIP(hipStreamCreateWithPriority(&pl->out_stage_stream[lane], hipStreamNonBlocking, greatest));
+  if (!pl->out_stage[lane][0]) {
     for (int i = 0; i < 2; ++i) {
-      FFX_HIP(hipHostMalloc(reinterpret_cast<void**>(&pl->out_stage[lane][i]), ffx_plan::kOutStageBytes, hipHostMallocDefault));
       FFX_HIP(hipEventCreateWithFlags(&pl->out_stage_ev[lane][i], hipEventDisableTiming));
+      FFX_HIP(hipHostMalloc(reinterpret_cast<void**>(&pl->out_stage[lane][i]), ffx_plan::kOutStageBytes, hipHostMallocDefault));
     }
   }
-  hipStream_t st = pl->out_stage_stream[lane];
+  // every lane of every plan queues its pieces on the index's ONE result stream (highest priority: a copy that queues behind the
+  // next slices' scoring kernels leaves when they are done -- 24.6 ms for the headline batch at normal priority).  A stream per
+  // lane (round 4) meant up to fifteen streams on the device's four hardware queues: some shared a queue with the kernel stream.
+  hipStream_t st = pl->idx->out_stream;
   const size_t piece = ffx_plan::kOutStageBytes;
   const size_t n = (bytes + piece - 1) / piece;
   auto issue = [&](size_t k) -> int {
@@ -2939,8 +2937,13 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   // while the first slice is uploaded and the caller idles while the last one's results come back
   int64_t ramp_base = ffx_debug_variant("score_no_ramp", nullptr) ? per_slice : std::max<int64_t>(per_slice / 8, 1);
   if (long long v = 0; ffx_debug_variant("score_ramp_pairs", &v)) ramp_base = std::max<int64_t>(1, std::min<int64_t>((int64_t)v, per_slice));  // A/B hook: tools/slice_sweep.py
+  long long growth_pct = 200;  // how fast the first slices grow (A/B hook)
+  (void)ffx_debug_variant("score_ramp_growth_pct", &growth_pct);
+  growth_pct = std::max<long long>(110, std::min<long long>(growth_pct, 400));
   auto slice_target = [&](size_t i, int64_t first_pair) {
-    const int64_t up = i < 8 ? ramp_base << i : per_slice;
+    double grown = (double)ramp_base;
+    for (size_t j = 0; j < i && grown < (double)per_slice; ++j) grown *= (double)growth_pct / 100.0;
+    const int64_t up = (int64_t)std::min<double>(grown, (double)per_slice);
     const int64_t down = std::max<int64_t>(ramp_base, (P - first_pair) / 2);
     return std::min(per_slice, std::min(up, down));
   };
@@ -2972,25 +2975,29 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
     else
       (void)hipGetLastError();
   }
-  if (async_out && !idx->out_stream) {
+  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order || ranked) && !ffx_debug_variant("score_blocking_out", nullptr);
+  if ((async_out || threaded_out) && !idx->out_stream) {
     int least = 0, greatest = 0;
     FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
     for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  const bool threaded_out = n_slices > 1 && !async_out && (out_ff || out_interp || out_order || ranked) && !ffx_debug_variant("score_blocking_out", nullptr);
-  const int n_plans = n_slices > 1 ? (async_out || threaded_out ? 3 : 2) : 1;
+  // (ordinary result buffers: FOUR plans (three and five were 0.2 - 0.4 ms slower).  A slice's results leave at the link's pace -- 2 ms for a full slice -- and the short
+  // slices a call ends with are scored faster than that: with three plans the third-to-last slice waited for the plan of a full
+  // slice whose results were still leaving, and the device idled meanwhile: 1 - 2 ms of the headline batch)
+  int n_plans = n_slices > 1 ? (threaded_out ? 4 : async_out ? 3 : 2) : 1;
+  if (long long v = 0; n_plans > 2 && ffx_debug_variant("score_plans", &v)) n_plans = (int)std::max<long long>(3, std::min<long long>(v, ffx_index::kScorePlans));
   for (int i = 0; i < n_plans; ++i)
     if (!idx->score_plans[i]) FFX_TRY(plan_create(idx, &idx->score_plans[i], i == 0));
   if (n_slices > 1 && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
   // where a plan's uploads go; with blocking result copies (two plans alternate, each complete on its stream)
   // the second plan lives on the kernel stream
-  hipStream_t home[3];
-  for (int i = 0; i < 3; ++i) home[i] = (i == 1 && !async_out && !threaded_out) ? idx->score_stream : idx->score_plans[0]->own_stream;
+  hipStream_t home[ffx_index::kScorePlans];
+  for (int i = 0; i < ffx_index::kScorePlans; ++i) home[i] = (i == 1 && !async_out && !threaded_out) ? idx->score_stream : idx->score_plans[0]->own_stream;
   struct LentStreams {  // plans 1 and 2 own no stream: they hold none between calls
     ffx_index* idx;
     ~LentStreams() {
-      for (int i = 1; i < 3; ++i)
+      for (int i = 1; i < ffx_index::kScorePlans; ++i)
         if (idx->score_plans[i]) idx->score_plans[i]->stream = nullptr;
     }
   } lent{idx};
@@ -3027,6 +3034,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   const bool trace = getenv("FFX_SCORE_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+  const std::function<double()> us_fn = us;
   auto send_out = [&](int c) -> int {  // queue slice c's results behind its kernels
     ffx_plan* pl = idx->score_plans[c % n_plans];
     const int64_t p0 = pair_off[cut[c]];
@@ -3053,7 +3061,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
     int rc = FFX_OK;
     std::string error;
   };
-  std::future<FetchResult> fetching[3];
+  std::future<FetchResult> fetching[ffx_index::kScorePlans];
   auto fetch_on_thread = [&](int c) -> FetchResult {
     FetchResult r;
     ffx_plan* pl = idx->score_plans[c % n_plans];
@@ -3061,25 +3069,39 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
     const size_t bytes = (size_t)pl->n_pairs * sizeof(float);
     auto body = [&]() -> int {
       FFX_HIP(hipSetDevice(idx->device));
+      const double w0 = us();
       FFX_HIP(hipEventSynchronize(pl->ev[4]));
+      const double w1 = us();
+      struct Said {
+        bool on; int c; double w0, w1; const std::function<double()>& now;
+        ~Said() { if (on) fprintf(stderr, "ffx_score results of slice %d: kernels awaited %.0f .. %.0f, copied out by %.0f\n", c, w0, w1, now()); }
+      } said{trace, c, w0, w1, us_fn};
       if (bytes) {
         // every wanted array on a thread of its own (the last one on this one): a thread's memcpy out of the page-locked
         // blocks is what bounds a lane
         struct Job {
           int lane;
-          void* dst;
-          const void* src;
+          char* dst;
+          const char* src;
+          size_t len;
         };
         std::vector<Job> jobs;
-        if (out_ff) jobs.push_back({0, out_ff + p0, pl->ff.p});
-        if (out_interp) jobs.push_back({1, out_interp + p0, pl->interp.p});
-        if (out_order) jobs.push_back({2, out_order + p0, pl->order.p});
-        if (out_ranked) jobs.push_back({3, out_ranked + p0, pl->ranked.p});
-        if (out_carry) jobs.push_back({4, out_carry + p0, pl->carry_ranked.p});
+        // a large array leaves in two halves, a thread each (one thread empties the blocks at ~10 GB/s; three slices' results
+        // are on their way at a time, and the slowest decides when its plan is free for the slice three further on)
+        const size_t half = bytes >= (size_t(8) << 20) ? ((bytes / 2 + ffx_plan::kOutStageBytes - 1) / ffx_plan::kOutStageBytes) * ffx_plan::kOutStageBytes : bytes;
+        auto add = [&](int which, void* dst, const void* src) {
+          jobs.push_back({2 * which, static_cast<char*>(dst), static_cast<const char*>(src), half});
+          if (half < bytes) jobs.push_back({2 * which + 1, static_cast<char*>(dst) + half, static_cast<const char*>(src) + half, bytes - half});
+        };
+        if (out_ff) add(0, out_ff + p0, pl->ff.p);
+        if (out_interp) add(1, out_interp + p0, pl->interp.p);
+        if (out_order) add(2, out_order + p0, pl->order.p);
+        if (out_ranked) add(3, out_ranked + p0, pl->ranked.p);
+        if (out_carry) add(4, out_carry + p0, pl->carry_ranked.p);
         std::vector<std::future<FetchResult>> side;
-        auto one = [pl, bytes](Job j) {
+        auto one = [pl](Job j) {
           FetchResult fr;
-          fr.rc = staged_d2h(pl, j.lane, j.dst, j.src, bytes);
+          fr.rc = staged_d2h(pl, j.lane, j.dst, j.src, j.len);
           if (fr.rc != FFX_OK) fr.error = g_last_error;
           return fr;
         };
@@ -3095,7 +3117,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
             }
           }
         }
-        int rc_all = jobs.empty() ? FFX_OK : staged_d2h(pl, jobs.back().lane, jobs.back().dst, jobs.back().src, bytes);
+        int rc_all = jobs.empty() ? FFX_OK : staged_d2h(pl, jobs.back().lane, jobs.back().dst, jobs.back().src, jobs.back().len);
         std::string err_all = rc_all != FFX_OK ? g_last_error : std::string();
         for (auto& f : side) {
           const FetchResult fr = f.get();
@@ -3254,7 +3276,7 @@ int ffx_index_prepare_score(ffx_index* idx, int64_t n_queries, int64_t n_pairs, 
   const bool sliced = n_pairs > per_slice + per_query;
   const int64_t Ps = sliced ? per_slice + 2 * per_query : n_pairs;
   const int64_t Qs = std::min<int64_t>(n_queries, Ps / std::max<int64_t>(per_query, 1) + 2);
-  const int n_plans = sliced ? 3 : 1;
+  const int n_plans = sliced ? (page_locked_buffers ? 3 : 4) : 1;
   if (sliced && page_locked_buffers && !idx->out_stream) {
     int least = 0, greatest = 0;
     FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));

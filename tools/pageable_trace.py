@@ -41,5 +41,15 @@ for _ in range(5):
     run()
     ts.append(time.perf_counter() - t0)
 print(json.dumps({"ordinary": which, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}))
+for plans in ("score_plans=3", "score_plans=4", "score_plans=5", "score_ramp_growth_pct=150", "score_ramp_growth_pct=150,score_ramp_pairs=400000", "score_ramp_growth_pct=170", "score_ramp_growth_pct=130,score_ramp_pairs=400000"):
+    os.environ["FFX_DEBUG_VARIANT"] = plans
+    run()
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps({"variant": plans, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}))
+os.environ.pop("FFX_DEBUG_VARIANT")
 os.environ["FFX_SCORE_TRACE"] = "1"
 run()

@@ -44,6 +44,8 @@ def read(d):
         "first_kernel_to_last_kernel_end_ms": (max(e[1] for e in window) - window[0][0]) / 1e6, "last_kernel_to_last_copy_ms": (c1 - max(e[1] for e in window)) / 1e6,
         "kernel_busy_ms": busy / 1e6, "kernel_ms_by_name": {k: v / 1e6 for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:8]},
         "largest_gaps_us": [x / 1e3 for x in gaps[:12]], "sum_positive_gaps_ms": sum(x for x in gaps if x > 0) / 1e6,
+        "gather_dot_start_end_ms_since_first_copy": [[round((ev[i][0] - c0) / 1e6, 3), round((ev[i][1] - c0) / 1e6, 3)] for i in last],
+        "copies": len(copies), "copy_busy_ms_by_direction": {d: sum(c[1] - c[0] for c in copies if c[2] == d) / 1e6 for d in sorted({c[2] for c in copies})},
     }, indent=1))
 
 
@@ -68,6 +70,9 @@ p_q = native.pinned_empty(queries.shape, np.float32)
 p_ids, p_sp = native.pinned_empty(n, np.int32), native.pinned_empty(n, np.float32)
 p_q[...], p_ids[...], p_sp[...] = queries, ids, sparse
 outs = (native.pinned_empty(n, np.float32), native.pinned_empty(n, np.float32), native.pinned_empty(n, np.int32))
+if len(sys.argv) > 1 and sys.argv[1] == "ordinary":  # ordinary memory both ways (staged by the library: csrc/host_xfer.h, staged_d2h)
+    p_q, p_ids, p_sp = queries, ids, sparse
+    outs = (np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.int32))
 ts = []
 for _ in range(4):
     time.sleep(0.02)

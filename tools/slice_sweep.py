@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Region (ii) at the headline size for several (slice, ramp) sizes of ffx_score's pipeline (FFX_DEBUG_VARIANT=score_slice_pairs=N,
-score_ramp_pairs=N): page-locked buffers, best of 5 calls each, the HBM-resident step beside it."""
+score_ramp_pairs=N): page-locked buffers (argv[1] = "ordinary": ordinary memory both ways), best of 5 calls each, the
+HBM-resident step beside it."""
 import json
 import os
 import sys
@@ -29,6 +30,9 @@ p_q = native.pinned_empty(queries.shape, np.float32)
 p_ids, p_sp = native.pinned_empty(n, np.int32), native.pinned_empty(n, np.float32)
 p_q[...], p_ids[...], p_sp[...] = queries, ids, sparse
 outs = (native.pinned_empty(n, np.float32), native.pinned_empty(n, np.float32), native.pinned_empty(n, np.int32))
+if len(sys.argv) > 1 and sys.argv[1] == "ordinary":
+    p_q, p_ids, p_sp = queries, ids, sparse
+    outs = (np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.int32))
 run = lambda: native.score(idx, p_q, pair_off, p_ids, 2, p_sp, 0.1, exact_sum=True, sort=True, out=outs)  # noqa: E731
 plan = native.Plan(idx)
 plan.set_queries(queries)
@@ -43,7 +47,8 @@ plan.sync()
 out = {"resident_step_ms": (time.perf_counter() - t0) / 5 * 1e3}
 want = None
 for slice_pairs, ramp in ((0, 0), (4 << 20, 256 << 10), (6 << 20, 512 << 10), (8 << 20, 512 << 10), (8 << 20, 256 << 10), (12 << 20, 512 << 10),
-                          (16 << 20, 512 << 10), (6 << 20, 768 << 10), (3 << 20, 384 << 10)):
+                          (16 << 20, 512 << 10), (6 << 20, 768 << 10), (3 << 20, 384 << 10), (6 << 20, 128 << 10), (4 << 20, 128 << 10), (3 << 20, 128 << 10),
+                          (6 << 20, 384 << 10), (5 << 20, 256 << 10)):
     words = ([f"score_slice_pairs={slice_pairs}"] if slice_pairs else []) + ([f"score_ramp_pairs={ramp}"] if ramp else [])
     if words:
         os.environ["FFX_DEBUG_VARIANT"] = ",".join(words)
