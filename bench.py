@@ -221,6 +221,15 @@ def cpu_baseline(args, doc_off, n_docs, scale, q_first: int = 0, batch_seed: int
         t_c += time.perf_counter() - t0
         passes_c += 1
     assert np.array_equal(ff.view(np.uint32), ff_c.view(np.uint32))
+    # ... and the same sample the way the reference's users run it: frames of string ids, a dictionary look-up per distinct id,
+    # merges + group-by around the three NumPy lines, an outer merge and two sorts (SURVEY 8(d)'s "pandas-faithful variant")
+    t_pd, passes_pd, pd_steps = 0.0, 0, {}
+    while t_pd < args.cpu_seconds / 4 and passes_pd < 1000:
+        ff_p, interp_p, pd_steps = fo.pandas_port_score(vecs, sub_off, sub_rows, sub_rows, queries, pair_off, inv.astype(np.int32), mode, sparse, args.alpha,
+                                                        batch_queries=16)
+        t_pd += pd_steps["total_s"]
+        passes_pd += 1
+    assert np.array_equal(ff_p.view(np.uint32), ff.view(np.uint32)) and np.array_equal(interp_p.view(np.uint32), interp.view(np.uint32))
     threads = int(os.environ["OMP_NUM_THREADS"])
     out = {
         "value": nq * passes / t_np, "unit": "queries/s", "cores": 1, "kind": "port",
@@ -231,6 +240,11 @@ def cpu_baseline(args, doc_off, n_docs, scale, q_first: int = 0, batch_seed: int
         "seconds": t_np, "passes": passes,
         "omp_c_port": {"value": nq * passes_c / t_c, "unit": "queries/s", "cores": threads, "seconds": t_c, "passes": passes_c,
                        "note": "oracle/ffx_oracle.c (scalar, NumPy summation order), OpenMP over candidates"},
+        "pandas_port": {"value": nq * passes_pd / t_pd, "unit": "queries/s", "cores": 1, "seconds": t_pd, "passes": passes_pd,
+                        "steps_of_last_pass_s": {k: round(v, 4) for k, v in pd_steps.items()},
+                        "note": "oracle/ffx_oracle.py pandas_port_score: index(first) then first.interpolate(dense, alpha) through frames of string ids "
+                                "(index/base.py:389-469 with batch_size = 16 queries, :279-314, index/util.py:12-42, ranking.py:67-121, :293-326), same sample, "
+                                "same bits; the frames and id dictionaries exist before the clock starts"},
     }
     return out, (ids, sparse, interp)
 
@@ -316,6 +330,16 @@ def bench_sharded(args, rank: int, world: int):
         os.dup2(keep_stdout, 1)
         os.close(keep_stdout)
     local_rank = comm.device
+    # a second, GPU-less channel over shared memory that the ranks only use to tell each other how their fresh-batch section
+    # went before the closing collective (a rank that failed there must not leave its peers waiting in an all-reduce)
+    args.votes = None
+    if world > 1:
+        from fast_forward_amd.sharded import _rendezvous_key
+
+        try:
+            args.votes = connect("host", rank=rank, world=world, device=-1, key=_rendezvous_key() + "votes", timeout=600.0)
+        except (native.FFXError, TimeoutError, OSError) as e:
+            print(f"rank {rank}: no side channel for the closing vote ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
     return _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, query_partition, ShardedScorer)
 
 
@@ -513,6 +537,16 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
         fresh_parity = check(interp, scorer.q_lo, fresh["last_batch_seed"])
         fresh["line"]["fresh_batch_parity_on_cpu_sample"] = fresh_parity
     failed = parity == "MISMATCH" or fresh_parity == "MISMATCH"
+    # every rank learns whether ANY rank's fresh-batch section failed (over the side channel: the job's own communicator may
+    # have a call of that section still inside it): then no rank enters the closing collective, and every rank exits 5
+    fresh_failed_somewhere = fresh_failed is not None
+    votes = getattr(args, "votes", None)
+    if votes is not None:
+        try:
+            fresh_failed_somewhere = bool(votes.allgather_array(np.array([1.0 if fresh_failed is not None else 0.0])).max() > 0)
+        except (native.FFXError, TimeoutError, OSError) as e:
+            print(f"rank {rank}: the closing vote failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            fresh_failed_somewhere = True
     if lead:
         slowest = max(per_rank, key=lambda t: t["ms_gather_dot"])
         achieved = slowest["n_rows"] * row_bytes / (slowest["ms_gather_dot"] * 1e-3) / 1e9
@@ -587,14 +621,20 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                 result["cpu_baseline"] = base
             result["parity_on_cpu_sample"] = parity
         print(json.dumps(result), flush=True)
-    if fresh_failed is not None:
-        # a call of that section may still be inside the library on its thread: no further collective, no teardown that waits for it
+    if fresh_failed_somewhere:
+        # a call of that section may still be inside the library on its thread: no further collective, no teardown that waits
+        # for it.  The line (printed above, with fresh_batch_error) carries the replayed batch only; the status says so: 4 =
+        # scores disagree with the oracle, 5 = the fresh-batch section failed or timed out on some rank
+        if fresh_failed is None:
+            print(f"rank {rank}: another rank's fresh-batch section failed; leaving without the closing collective", file=sys.stderr, flush=True)
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(4 if failed else 0)
+        os._exit(4 if failed else 5)
     failed = bool(comm.allreduce([1.0 if failed else 0.0], native.OP_MAX)[0])
     scorer.close()
     comm.close()
+    if votes is not None:
+        votes.close()
     if failed:
         sys.exit("sharded GPU scores disagree with the CPU oracle on the sampled queries")
 

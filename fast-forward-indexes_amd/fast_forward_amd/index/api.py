@@ -41,6 +41,18 @@ class Mode(Enum):
     AVEP = 4
 
 
+def _drop_kept_scores(index_ref, token: int) -> None:
+    """Finaliser of a ranking that came out of ``Index.__call__``: if the index still keeps the dense scores of that very call
+    (nobody has displaced them), release them -- nothing else could ask for them (``Ranking.interpolate`` needs that ranking)."""
+    index = index_ref()
+    try:
+        if index is not None and getattr(index, "_store", None) is not None and index._kept_token() == token:
+            from fast_forward_amd import native
+
+            native.drop_kept(index._store)
+    except Exception:  # noqa: BLE001  (interpreter shutdown, a closed index: nothing left to release)
+        pass
+
 def _in_final_order(q_order: Sequence[str]) -> bool:
     """Query ids strictly descending: the order a ``Ranking`` the constructor sorted has
     (ranking.py:115-117).  A user-built ``Ranking(..., is_sorted=True)`` need not be."""
@@ -419,7 +431,10 @@ class Index(abc.ABC):
                 LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
                 src = kept if run.perm is None else run.perm[kept]
                 out._source_rows = (weakref.ref(ranking), src)
-                out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None), self._kept_token() if keeps else 0)
+                token = self._kept_token() if keeps else 0
+                out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None), token)
+                if token:  # the kept scores (8 bytes per candidate of HBM) go when the only ranking that can use them has gone
+                    weakref.finalize(out, _drop_kept_scores, weakref.ref(self), token)
                 return out
             for qa, qb in run.batches(batch_size):
                 pa, pb = int(off[qa]), int(off[qb])

@@ -340,6 +340,10 @@ class InMemoryIndex(Index):
             self._store = None
         self._out_cache = None
         self._n = 0
+        try:  # idle page-locked result blocks (up to FFX_RESULT_POOL_BYTES of host memory) go with the index that filled them
+            native.drain_result_pool(wait=False)
+        except Exception:  # noqa: BLE001
+            pass
 
     def __del__(self) -> None:
         try:

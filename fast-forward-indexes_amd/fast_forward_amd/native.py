@@ -673,6 +673,11 @@ def pinned_empty(shape, dtype) -> np.ndarray:
 # 4 GiB) of idle blocks are kept; beyond that a dying block is released.
 _POOL: dict = {}
 _POOL_IDLE = [0]
+# the bookkeeping is touched by the caller's thread, by reserve_pooled's helper thread and by finalisers (which may run inside
+# any of them, hence re-entrant)
+import threading as _threading  # noqa: E402
+
+_POOL_LOCK = _threading.RLock()
 
 
 def _pool_limit() -> int:
@@ -700,10 +705,11 @@ def _return_pooled(self) -> None:
         return
     cap = C.sizeof(self)
     try:
-        if _POOL_IDLE[0] + cap <= _pool_limit():
-            _POOL.setdefault(cap, []).append(addr)
-            _POOL_IDLE[0] += cap
-            return
+        with _POOL_LOCK:
+            if _POOL_IDLE[0] + cap <= _pool_limit():
+                _POOL.setdefault(cap, []).append(addr)
+                _POOL_IDLE[0] += cap
+                return
     except Exception:  # interpreter shutdown: the module's globals may be gone
         pass
     _lib.ffx_host_free(C.c_void_p(addr))
@@ -715,11 +721,13 @@ def pooled_empty(n: int, dtype) -> np.ndarray:
     dtype = np.dtype(dtype)
     n = int(n)
     cap = _pool_class(max(1, n * dtype.itemsize))
-    free = _POOL.get(cap)
-    if free:
-        addr = free.pop()
-        _POOL_IDLE[0] -= cap
-    else:
+    addr = None
+    with _POOL_LOCK:
+        free = _POOL.get(cap)
+        if free:
+            addr = free.pop()
+            _POOL_IDLE[0] -= cap
+    if addr is None:
         p = C.c_void_p()
         _check(lib().ffx_host_alloc(cap, C.byref(p)))
         addr = p.value
@@ -748,7 +756,8 @@ def reserve_pooled(requests, first=None) -> "object":
     for n, dtype in requests:
         cap = _pool_class(max(1, int(n) * np.dtype(dtype).itemsize))
         need[cap] = need.get(cap, 0) + 1
-    todo = [cap for cap, k in need.items() for _ in range(max(0, k - len(_POOL.get(cap, ()))))]
+    with _POOL_LOCK:
+        todo = [cap for cap, k in need.items() for _ in range(max(0, k - len(_POOL.get(cap, ()))))]
 
     def work():
         try:
@@ -759,8 +768,9 @@ def reserve_pooled(requests, first=None) -> "object":
         for cap in todo:
             p = C.c_void_p()
             if _lib.ffx_host_alloc(cap, C.byref(p)) == OK:
-                _POOL.setdefault(cap, []).append(p.value)
-                _POOL_IDLE[0] += cap
+                with _POOL_LOCK:
+                    _POOL.setdefault(cap, []).append(p.value)
+                    _POOL_IDLE[0] += cap
 
     t = threading.Thread(target=work, daemon=True)
     _RESERVING[:] = [x for x in _RESERVING if x.is_alive()] + [t]
@@ -768,17 +778,26 @@ def reserve_pooled(requests, first=None) -> "object":
     return t
 
 
-def drain_result_pool() -> int:
-    """Release every idle block of the result pool; returns the bytes freed."""
-    for t in list(_RESERVING):  # nobody adds a block behind this call's back
-        t.join()
-    _RESERVING.clear()
+def drain_result_pool(wait: bool = True) -> int:
+    """Release every idle block of the result pool; returns the bytes freed.  ``wait=False`` (an index being closed, possibly
+    from a finaliser): the helper threads of ``reserve_pooled`` are not joined -- a block one of them adds afterwards stays
+    for the next call."""
+    if _lib is None:
+        return 0
+    if wait:
+        for t in list(_RESERVING):  # nobody adds a block behind this call's back
+            t.join()
+        _RESERVING.clear()
     freed = 0
-    for cap, blocks in list(_POOL.items()):
-        while blocks:
-            lib().ffx_host_free(C.c_void_p(blocks.pop()))
+    with _POOL_LOCK:
+        taken = [(cap, blocks[:]) for cap, blocks in _POOL.items()]
+        for blocks in _POOL.values():
+            del blocks[:]
+        _POOL_IDLE[0] = 0
+    for cap, blocks in taken:
+        for addr in blocks:
+            _lib.ffx_host_free(C.c_void_p(addr))
             freed += cap
-    _POOL_IDLE[0] = 0
     return freed
 
 

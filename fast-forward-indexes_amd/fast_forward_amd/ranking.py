@@ -784,10 +784,12 @@ class Ranking:
             native.lib()
         except (ImportError, OSError):
             return None
-        # A large run whose dense scores came from an index that is still there, unchanged: the device interpolates with THIS
-        # alpha and orders -- from the dense scores it kept in HBM when it made them (Index._interpolate_kept), or, once
-        # another call has displaced those, by doing the whole of it again (Index.rerank) -- faster than the host orders
-        # 35 M scores; same bits either way, pinned by test_rerank_equals_call_then_interpolate.
+        # A large run whose dense scores are still in HBM where the index left them when it made them (the token names that
+        # very call): the device interpolates with THIS alpha and orders (Index._interpolate_kept) -- faster than the host
+        # orders 35 M scores; same bits, pinned by test_rerank_equals_call_then_interpolate.  Once another call has displaced
+        # them (or the call was batched and kept nothing), the host path below combines `other`'s OWN scores: interpolate is
+        # arithmetic on the two rankings (ranking.py:293-326) -- it never encodes a query or scores a candidate again, so an
+        # index whose encoder, summation or contents changed in between cannot change what it returns.
         origin = getattr(other, "_origin", None)
         index = origin[0]() if origin is not None else None
         if (index is not None and isinstance(alpha, (int, float)) and len(mine) >= (1 << 20) and self.has_queries and origin[1] == index.mode
@@ -795,7 +797,6 @@ class Ranking:
             token = origin[3] if len(origin) > 3 else 0
             if token and index._kept_token() == token:  # the dense scores of that very call are still in HBM: no second gather
                 return index._interpolate_kept(self, token, alpha)
-            return index.rerank(self, alpha)
         if isinstance(alpha, (int, float)) and len(mine) >= (1 << 18) and link[1].dtype == np.int32:
             # one threaded pass: scatter back + `alpha * mine + (1 - alpha) * dense` in float32, as below
             score, any_nan = native.host_interpolate(mine, other._scores(), link[1], alpha)

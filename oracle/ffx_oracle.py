@@ -10,6 +10,8 @@ Two restatements live here, both pinned against the reference by ``tests/golden`
 * ``numpy_port_*``: the same three NumPy operations the reference executes at
   ``src/fast_forward/index/base.py:301-303`` (gather, gather, ``np.sum(q*d, axis=1)``),
   used as the "reference-equivalent CPU path" that ``bench.py`` times beside the GPU.
+* ``pandas_port_score``: the same path through frames of string ids, merges and a group-by, as a user of the
+  reference experiences it (timed beside the NumPy port; checked against it and against the golden fixtures).
 """
 
 from __future__ import annotations
@@ -220,6 +222,113 @@ def numpy_port_score(vectors, doc_off, doc_rows, psg_row, queries, pair_off, pai
         # ranking.py:319 with a Python-float alpha on float32 columns
         interp = alpha * np.asarray(sparse, dtype=np.float32) + (1 - alpha) * ff
     return ff, interp
+
+
+# --------------------------------------------------------------------------------------
+# The path as a user of the reference experiences it: frames of STRING ids, a Python look-up per distinct id,
+# pandas merges and a group-by around the three NumPy lines, an outer merge for the interpolation and a sort of
+# strings + floats for every Ranking made ("a pandas-faithful variant").  bench.py times it
+# beside ``numpy_port_score`` on the same sample; tests check that it gives the same scores.
+# --------------------------------------------------------------------------------------
+def pandas_port_score(vectors, doc_off, doc_rows, psg_row, queries, pair_off, pair_ids, mode: int, sparse, alpha: float,
+                      batch_queries: int | None = None):
+    """``index(first)`` then ``first.interpolate(dense, alpha)`` through pandas, restating (not importing) what
+    ``Index.__call__`` (index/base.py:389-469), ``_compute_scores`` (:279-314), ``get_indices`` (index/util.py:12-42),
+    ``Ranking.__init__`` (ranking.py:67-121) and ``Ranking.interpolate`` (:293-326) do, operation by operation.
+    Candidate ``c`` of the index is named ``"D<c>"`` (``"P<c>"`` in PASSAGE mode), query ``q`` ``"q<q>"``.
+
+    Returns ``(ff, interp, seconds)``: dense and interpolated scores per candidate in the CSR order of the input, and a
+    dict of the time spent per step.  The frames of strings and the id dictionaries are built before the clock starts
+    (the reference holds them already: the run is a ``Ranking``, the dictionaries are the index)."""
+    import time
+
+    import pandas as pd
+
+    pair_off = np.asarray(pair_off, dtype=np.int64)
+    pair_ids = np.asarray(pair_ids, dtype=np.int64)
+    doc_off = np.asarray(doc_off, dtype=np.int64)
+    doc_rows = np.asarray(doc_rows, dtype=np.int64)
+    psg_row = np.asarray(psg_row, dtype=np.int64)
+    n_q = pair_off.shape[0] - 1
+    lens = np.diff(pair_off)
+    prefix = "P" if mode == MODE_PASSAGE else "D"
+    # ---- what exists before the call (untimed) -----------------------------------------------------------------------
+    touched = np.unique(pair_ids)
+    if mode == MODE_PASSAGE:
+        psg_to_row = {f"P{c}": int(psg_row[c]) for c in touched}
+        doc_to_rows: dict = {}
+    else:
+        doc_to_rows = {f"D{c}": [int(r) for r in doc_rows[doc_off[c]:doc_off[c + 1]]] for c in touched}
+        psg_to_row = {}
+    q_names = np.array([f"q{q:07d}" for q in range(n_q)], dtype=object)
+    first = pd.DataFrame({"q_id": np.repeat(q_names, lens), "id": np.array([f"{prefix}{c}" for c in pair_ids], dtype=object),
+                          "score": np.asarray(sparse, dtype=np.float32), "query": np.repeat(q_names, lens)})
+    position = pd.Series(np.arange(len(first)), index=pd.MultiIndex.from_arrays([first["q_id"], first["id"]]))
+    first = first.sort_values(by=["q_id", "score"], ascending=False).reset_index(drop=True)  # a Ranking holds its frame sorted
+    sec = {}
+    clock = time.perf_counter
+
+    def get_indices(ids):  # index/util.py:12-42, one dictionary look-up (or two) per distinct id
+        rows, names = [], []
+        for name in ids:
+            if mode == MODE_PASSAGE:
+                found = [psg_to_row[name]] if name in psg_to_row else []
+            else:
+                found = doc_to_rows.get(name, [])
+                if mode == MODE_FIRSTP:
+                    found = found[:1]
+            if not found:
+                raise IndexError(f"ID {name} not found in the index.")
+            rows.extend(found)
+            names.extend([name] * len(found))
+        return rows, names
+
+    def compute_scores(data, query_vectors):  # index/base.py:279-314
+        rows, names = get_indices(data["id"].unique())
+        got = vectors[rows]
+        by_id = pd.DataFrame(names, columns=["id"])
+        by_id["id_idx"] = by_id.index
+        merged = by_id.merge(data[["id", "q_no"]], how="left", on="id")
+        q_reps = query_vectors[merged["q_no"].tolist()]
+        d_reps = got[merged["id_idx"].tolist()]
+        merged["ff_score"] = np.sum(q_reps * d_reps, axis=1)
+        op = "max" if mode == MODE_MAXP else "mean" if mode == MODE_AVEP else "first"
+        return data.merge(merged.groupby(["id", "q_no"], as_index=False).aggregate(op), on=["id", "q_no"])
+
+    # ---- Index.__call__ (index/base.py:418-469) ------------------------------------------------------------------------
+    t0 = clock()
+    numbered = first[["q_id", "query"]].drop_duplicates().reset_index(drop=True)
+    numbered["q_no"] = numbered.index
+    frame = first.merge(numbered, on=["q_id", "query"], suffixes=[None, "_"])
+    q_vectors = np.asarray(queries, dtype=np.float32)[[int(name[1:]) for name in numbered["query"]]]  # (the encoder: a table look-up)
+    sec["queries_numbered_s"] = clock() - t0
+    t0 = clock()
+    if batch_queries is None:
+        result = compute_scores(frame, q_vectors)
+    else:
+        parts = [compute_scores(frame.loc[frame["q_no"].isin(range(a, a + batch_queries))], q_vectors) for a in range(0, len(numbered), batch_queries)]
+        result = pd.concat(parts)
+    sec["compute_scores_s"] = clock() - t0
+    t0 = clock()
+    result["score"] = result["ff_score"]
+    dense = result[["q_id", "id", "score", "query"]].dropna().astype({"score": np.float32})
+    dense = dense.sort_values(by=["q_id", "score"], ascending=False).reset_index(drop=True)  # Ranking.__init__ (ranking.py:103-117)
+    sec["dense_ranking_made_s"] = clock() - t0
+    # ---- Ranking.interpolate (ranking.py:293-326) ----------------------------------------------------------------------
+    t0 = clock()
+    both = first.merge(dense, on=["q_id", "id"], suffixes=(None, "_other"), how="outer").fillna(0)
+    both["score"] = alpha * both["score"] + (1 - alpha) * both["score_other"]
+    final = both[["q_id", "id", "score", "query"]].astype({"score": np.float32})
+    final = final.sort_values(by=["q_id", "score"], ascending=False).reset_index(drop=True)
+    sec["interpolated_ranking_made_s"] = clock() - t0
+    sec["total_s"] = sum(sec.values())
+    # ---- back to CSR order, for the checks (untimed) --------------------------------------------------------------------
+    n = len(first)
+    ff = np.empty(n, dtype=np.float32)
+    interp = np.empty(n, dtype=np.float32)
+    ff[position.loc[pd.MultiIndex.from_arrays([dense["q_id"], dense["id"]])].to_numpy()] = dense["score"].to_numpy()
+    interp[position.loc[pd.MultiIndex.from_arrays([final["q_id"], final["id"]])].to_numpy()] = final["score"].to_numpy()
+    return ff, interp, sec
 
 
 # --------------------------------------------------------------------------------------

@@ -741,7 +741,8 @@ def test_interpolate_after_call_starts_from_the_dense_scores_the_device_kept():
     index/base.py:389-469) -- does not score twice: ``index(first)`` leaves its dense scores (and the ranking's id codes)
     in HBM (FFX_FLAG_KEEP_DENSE) and the interpolate is the interpolation + ordering on the device alone (ffx_rank_kept).
     Same Ranking as ``index.rerank`` for every alpha; MaxP over documents of 1 - 3 passages (the kept scores are the
-    aggregated ones); once another call has displaced the kept scores the interpolate scores again -- same result."""
+    aggregated ones); once another call has displaced the kept scores the interpolate combines the dense ranking's own scores on
+    the host -- same result, and nothing is encoded or scored again."""
     from fast_forward_amd import native
 
     rng = np.random.default_rng(11)
@@ -783,9 +784,16 @@ def test_interpolate_after_call_starts_from_the_dense_scores_the_device_kept():
     assert index._kept_token() not in (0, token)
     with pytest.raises(native.FFXError):
         native.rank_kept(index._store, token, off, None, 0.0)
-    index.last_timings = None
-    assert first.interpolate(dense, 0.2) == index.rerank(first, 0.2) and "ids_to_ordinals_s" in index.last_timings  # scored again
+    # the kept scores are gone: interpolate is arithmetic on the two rankings (ranking.py:293-326) -- `dense`'s OWN scores, combined
+    # and ordered on the host; no query is encoded and no candidate scored again, whatever has happened to the index since
     assert second.interpolate(dense_second, 0.2) == index.rerank(second, 0.2)
+    want = index.rerank(first, 0.2)
+    encoded = []
+    index.query_encoder = LambdaEncoder(lambda t: encoded.append(t) or qv[int(t)] * 0)  # (an encoder that would give other scores)
+    index.last_timings = None
+    got = first.interpolate(dense, 0.2)
+    assert not encoded and index.last_timings is None
+    assert got == want and np.array_equal(bits(got._coded["score"]), bits(want._coded["score"])) and np.array_equal(got._coded["id_codes"], want._coded["id_codes"])
     index.close()
 
 

@@ -37,6 +37,24 @@ def test_numpy_port_matches_c_oracle(name):
         assert np.array_equal(bits(ai), bits(bi))
 
 
+@pytest.mark.parametrize("name", SCORING_CASES)
+def test_pandas_port_matches_c_oracle(name):
+    """The pandas-faithful restatement (frames of string ids, merges, group-by, outer merge; what bench.py's cpu_baseline times
+    beside the NumPy port) gives the bits of the C oracle -- and so of the reference-run fixtures -- in every mode, whole run
+    and in batches of queries (index/base.py:445-459)."""
+    case = load_scoring_case(name)
+    for mode in case.modes():
+        pair_off, pair_ids, sparse, _ = case.pairs(mode)
+        if any(len(set(pair_ids[a:b].tolist())) != b - a for a, b in zip(pair_off[:-1], pair_off[1:])):
+            continue  # (a frame cannot hold a candidate twice under one query)
+        a, ai = fo.score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids, MODE_NO[mode], sparse, 0.1)
+        for batch in (None, 3):
+            b, bi, steps = fo.pandas_port_score(case.vectors, case.doc_off, case.doc_rows, case.psg_row, case.queries, pair_off, pair_ids, MODE_NO[mode],
+                                                sparse, 0.1, batch_queries=batch)
+            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(ai), bits(bi)), (name, mode, batch)
+            assert steps["total_s"] > 0
+
+
 @pytest.mark.parametrize("name", ["config1", "d768", "s2_sub"])
 def test_interpolation_and_order(name):
     case = load_scoring_case(name)
