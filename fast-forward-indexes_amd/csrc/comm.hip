@@ -791,7 +791,7 @@ static int comm_route_lane(ffx_comm* c) {
   if (c->route_stream || c->device < 0) return FFX_OK;
   C_HIP(hipSetDevice(c->device));
   hipStream_t st = nullptr;
-  if (ffx_debug_variant("route_high_priority", nullptr)) {
+  if (ffx_experiment("route_high_priority", nullptr)) {
     int least = 0, greatest = 0;
     C_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     C_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
@@ -2126,7 +2126,7 @@ static int sharded_merge_pending(ffx_sharded* s) {
   // a small merge hides inside the next gather_dot; a large one (tens of millions of candidates: one or two ranks) takes
   // slots from it for its whole length and is better paid for once, in line (measured: DESIGN.md section 7)
   const bool small = sl.own[3] <= (int64_t)(6 << 20);  // (4.4 M owned candidates: hidden, 2.26 -> 2.12 ms; 8.7 M: the fresh step loses 5 %; 34.9 M: 7 %)
-  if (ffx_debug_variant("merge_on_results", nullptr) || (small && !ffx_debug_variant("merge_on_compute", nullptr))) {
+  if (ffx_experiment("merge_on_results", nullptr) || (small && !ffx_experiment("merge_on_compute", nullptr))) {
     C_TRY(sharded_io_streams(s));
     ms = s->out;
   }

@@ -94,6 +94,14 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+extern "C" int ffx_build_has_experiments(void) {
+#ifdef FFX_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 // shared with host_io.cpp
 int ffx_fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -106,18 +114,21 @@ int ffx_fail(int code, const char* fmt, ...) {
 }
 
 // FFX_DEBUG_VARIANT -- the ONE environment knob for A/B switches (tests, tools/*.py; never needed in production).
-// A comma-separated list of words, `name` or `name=N`:
+// A comma-separated list of words, `name` or `name=N`.  In every build (a choice between two paths that both ship):
 //   no_small_path          ffx_score never takes the single-submission path of small batches
 //   route_host             the sharded scorer routes a batch on the host even for document-range shards
 //   pq_no_fuse, pq_no_adc, pq_sort_apart  product-quantized rows: unfused exact ADC / decode-then-dot instead of exact ADC / the ordering as a launch of its own
-//   generic_staged, generic_plain   the round-1 generic exact kernels instead of the any-d / segment kernels
-//   anyd_u=N               loads in flight per wave of the any-d kernel (2, 4, 8)
-//   gather=N               an experimental gather_dot instantiation by variant number (tools/kernel_ab.py)
-//   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N   where the per-query sort switches form
-//   sort_interp_apart      the interpolation (and the owner-side scatter) as launches of their own instead of inside the block sort
-//   score_plans=N, score_slice_pairs=N, score_ramp_pairs=N, score_no_ramp, score_no_out_stream, score_out_priority_low, score_blocking_out, pull_grid=N, count_always
-//                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py)
+//   score_slice_pairs=N, score_blocking_out   where ffx_score cuts a batch into slices; results fetched by the calling thread
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
+//   rehearsal_paced[=GB/s] the rehearsal transport's stand-in exchange paced like a link (bench.py --rehearsal-exchange)
+// Only in the experiments build (make EXPERIMENTS=1; ffx_experiment in ffx_internal.h -- tuning hooks that lost their A/B):
+//   gather=N               a gather_dot instantiation by variant number (tools/kernel_ab.py): 8xx strided small rows, 9xx d = 768 forms,
+//                          921 - 924 the persistent grid, 925 workgroups of two waves
+//   generic_staged, generic_plain, anyd_u=N   the round-1 generic exact kernels instead of the any-d / segment kernels; loads in flight of the any-d kernel
+//   sort_device_wide_from=N, sort_block_from=N, sort_block_to=N, sort_interp_apart   where the per-query sort switches form; the interpolation as a launch of its own
+//   score_plans=N, score_ramp_pairs=N, score_ramp_growth_pct=N, score_no_ramp, score_no_out_stream, score_out_priority_low, pull_grid=N, count_always
+//                          the slicing of ffx_score's host-to-host pipeline (tools/score_trace.py, slice_sweep.py)
+//   route_high_priority, merge_on_results, merge_on_compute   stream placement of the sharded scorer's routing and merge
 // (FFX_SCORE_TRACE=1 -- a timeline on stderr -- and the operational settings FFX_COMM_TIMEOUT_S, FFX_RDZV_DIR,
 // FFX_RDZV_KEY, FFX_READ_THREADS are not variants and keep their own names.)
 // True if `name` is in the list; *value (if given) receives N, or stays untouched for a bare word.
@@ -768,7 +779,7 @@ int ffx_index_pull_rows_async(ffx_index* idx, const void* const* chunks, int64_t
   // outstanding reads fill the queues every kernel's loads go through (tools/probes/host_pull_probe.hip: an HBM-bound
   // kernel beside a pull of 16 / 64 / 256 workgroups runs 1.6 / 5.5 / 8 x longer)
   int64_t grid_cap = 64;
-  if (long long v = 0; ffx_debug_variant("pull_grid", &v)) grid_cap = std::max<long long>(1, v);
+  if (long long v = 0; ffx_experiment("pull_grid", &v)) grid_cap = std::max<long long>(1, v);
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid_cap, (waves + 3) / 4));
   const char* const* table = idx->pull_chunks.as<const char*>();
   char* dst = static_cast<char*>(idx->row_ptr(dst_row));
@@ -1206,7 +1217,7 @@ static int set_pairs_check_launch(ffx_plan* pl) {
   // list has one entry per candidate.  (The count + scan of a 4 M-pair slice took 0.12 ms beside the scoring kernels of
   // the slice before: a tenth of ffx_score's device time went there.)
   pl->check_one_each = (mode == FFX_MODE_PASSAGE ? ix->psgs_identity : ix->docs_nonempty && (mode == FFX_MODE_FIRSTP || ix->max_doc_rows <= 1)) &&
-                       !ffx_debug_variant("count_always", nullptr);
+                       !ffx_experiment("count_always", nullptr);
   if (pl->check_one_each) {
     if (P > 0) {
       ffx::check_range_kernel<<<blocks_for(P, 256), 256, 0, pl->stream>>>(pl->pair_ids.as<int32_t>(), P, (int32_t)(mode == FFX_MODE_PASSAGE ? ix->n_psgs : ix->n_docs),
@@ -1544,9 +1555,10 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     ffx::gather_dot_exact_kernel<T, LEAVES, NPER, U><<<blocks_for(R, 4 * TILE_), 256, 0, st>>>(V, Q, desc, rs, R); \
     pl->variant = ID + HALF;                                                                      \
   } while (0)
-  // tuning hook (tools/kernel_ab.py): FFX_DEBUG_VARIANT=gather=N selects an experimental d=768 instantiation
+#ifdef FFX_EXPERIMENTS
+  // tuning hook (tools/kernel_ab.py; experiments build only): FFX_DEBUG_VARIANT=gather=N selects an experimental d=768 instantiation
   long long exp_value = 0;
-  const int exp_variant = ffx_debug_variant("gather", &exp_value) ? (int)exp_value : 0;  // tuning hook (tools/kernel_ab.py)
+  const int exp_variant = ffx_experiment("gather", &exp_value) ? (int)exp_value : 0;  // tuning hook (tools/kernel_ab.py)
   if (exp_variant >= 800 && exp_variant < 900) {  // the strided-load form of the small-row dims, for A/B
     switch (d) {
       case 512: FFX_EXACT(4, 16, 2, 803); break;
@@ -1595,6 +1607,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     FFX_HIP(hipGetLastError());
     return FFX_OK;
   }
+#endif  // FFX_EXPERIMENTS
   // d = 768 / 1024 (8 leaves): full-line non-temporal loads + LDS transpose (16.0 ms vs 17.7 ms for
   // the strided form at 8.8M x 768 fp32, k=5000: tools/kernel_ab.py, profiles/r01/kernel_ab_2.log)
   if (exact) {
@@ -1648,8 +1661,8 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     else FFX_ANYD_LG(8, U_SEL, TAILS_, COL0, LS, NL, CS, OUT);                 \
   } while (0)
         long long u_value = 0;  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
-        const bool u_env = ffx_debug_variant("anyd_u", &u_value);
-        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !ffx_debug_variant("generic_staged", nullptr)) {
+        const bool u_env = ffx_experiment("anyd_u", &u_value);
+        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !ffx_experiment("generic_staged", nullptr)) {
           const int* LS = pl->leaf_start.as<int>();
           const int* CS = pl->combine_steps.as<int>();
           const int nl = pl->n_leaves;
@@ -1665,7 +1678,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         // any-d kernel (one launch per segment over all rows: a segment is >= 2 KB of consecutive bytes of a row),
         // and combine_tree_kernel adds the segment sums in the order of the recursion.  Bit-identical to NumPy; the
         // staged generic kernel it replaces walked every row out of LDS with one wave (1 - 3.5 TB/s).
-        if (!pl->ov_dim && !pl->segments.empty() && !ffx_debug_variant("generic_staged", nullptr)) {
+        if (!pl->ov_dim && !pl->segments.empty() && !ffx_experiment("generic_staged", nullptr)) {
           const int G = (int)pl->segments.size();
           FFX_TRY(pl->rs_v.ensure((size_t)G * (size_t)R * sizeof(float)));
           const int* tab = pl->seg_tables.as<int>();
@@ -1692,7 +1705,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         while (RP > 1 && (size_t)RP * (2 * dp + lp) * sizeof(float) > (12 << 10)) RP /= 2;  // keep 4 waves per block
         const size_t per_wave = (size_t)RP * (2 * dp + lp) * sizeof(float);
         const int waves = (int)std::min<size_t>(4, (48 << 10) / per_wave);
-        if (waves >= 1 && !ffx_debug_variant("generic_plain", nullptr)) {
+        if (waves >= 1 && !ffx_experiment("generic_plain", nullptr)) {
           const int rows_per_wave = 8 * RP;
           ffx::gather_dot_exact_generic_staged_kernel<T><<<blocks_for(R, waves * rows_per_wave), 64 * waves, per_wave * waves, st>>>(
               V, Q, desc, rs, R, d, pl->leaf_start.as<int>(), pl->n_leaves, pl->combine_steps.as<int>(), dp, lp, rows_per_wave, RP);
@@ -1911,9 +1924,9 @@ static int64_t longest_segment(const int64_t* off, int64_t n) {
 // which form the ordering of a batch takes: one workgroup per query, in LDS (the form that can make its keys itself)?
 static bool sort_in_blocks(int64_t max_len, int64_t n_queries) {
   int64_t device_wide_from = 16 << 10, block_from = 129, block_to = 8192;
-  if (long long v = 0; ffx_debug_variant("sort_device_wide_from", &v)) device_wide_from = (int64_t)v;
-  if (long long v = 0; ffx_debug_variant("sort_block_from", &v)) block_from = (int64_t)v;
-  if (long long v = 0; ffx_debug_variant("sort_block_to", &v)) block_to = (int64_t)v;
+  if (long long v = 0; ffx_experiment("sort_device_wide_from", &v)) device_wide_from = (int64_t)v;
+  if (long long v = 0; ffx_experiment("sort_block_from", &v)) block_from = (int64_t)v;
+  if (long long v = 0; ffx_experiment("sort_block_to", &v)) block_to = (int64_t)v;
   return max_len <= device_wide_from && max_len >= block_from && max_len <= std::min<int64_t>(block_to, 8192) && n_queries > 0;
 }
 
@@ -1925,7 +1938,7 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
   FFX_TRY(order.ensure(pb * sizeof(int32_t)));
   FFX_TRY(iota.ensure(pb * sizeof(int32_t)));
   int64_t device_wide_from = 16 << 10;
-  if (long long v = 0; ffx_debug_variant("sort_device_wide_from", &v)) device_wide_from = (int64_t)v;  // A/B hook
+  if (long long v = 0; ffx_experiment("sort_device_wide_from", &v)) device_wide_from = (int64_t)v;  // A/B hook
   if (max_len > device_wide_from) {
     // words in / words out share `sorted_keys` (2 x 8 bytes per pair)
     FFX_TRY(sorted_keys.ensure(2 * pb * sizeof(unsigned long long)));
@@ -1948,8 +1961,8 @@ static int launch_segmented_sort(const float* keys, int64_t P, const int64_t* of
   // query (k = 100: 0.115 vs 0.179, k = 10: 0.77 vs 1.63) where it packs many queries into a workgroup.
   // FFX_DEBUG_VARIANT=sort_block_from=N / sort_block_to=N move the window (A/B hook)
   int64_t block_from = 129, block_to = 8192;
-  if (long long v = 0; ffx_debug_variant("sort_block_from", &v)) block_from = (int64_t)v;
-  if (long long v = 0; ffx_debug_variant("sort_block_to", &v)) block_to = (int64_t)v;
+  if (long long v = 0; ffx_experiment("sort_block_from", &v)) block_from = (int64_t)v;
+  if (long long v = 0; ffx_experiment("sort_block_to", &v)) block_to = (int64_t)v;
   if (max_len >= block_from && max_len <= std::min<int64_t>(block_to, 8192) && n_queries > 0) {
     const unsigned nq = (unsigned)n_queries;
     ffx::SortKeys sk;
@@ -2044,7 +2057,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   const float b = (float)(1.0 - alpha);
   const int64_t longest_query = (do_sort && P > 0) ? longest_segment(pl->host_pair_off.data(), pl->n_queries) : 0;
   const bool interp_in_sort = single && pl->have_sparse && do_sort && P > 0 && !pq_fused && sort_in_blocks(longest_query, pl->n_queries) &&
-                              !ffx_debug_variant("sort_interp_apart", nullptr);
+                              !ffx_experiment("sort_interp_apart", nullptr);
   if (P > 0 && !pq_fused) {
     if (!single) {
       ffx::reduce_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
@@ -2489,7 +2502,7 @@ int ffx_merge_run(ffx_merge* m, const float* recv_dev, double alpha, uint32_t fl
   if (P > 0) {
     // queries that are ordered a workgroup each: the scatter out of the receive buffer and the interpolation are made by the
     // sort kernel while it loads its keys -- the owner-side half of a step is ONE launch
-    const bool in_sort = do_sort && sort_in_blocks(m->max_len, m->n_queries) && !ffx_debug_variant("sort_interp_apart", nullptr);
+    const bool in_sort = do_sort && sort_in_blocks(m->max_len, m->n_queries) && !ffx_experiment("sort_interp_apart", nullptr);
     if (!in_sort) {
       ffx::merge_kernel<<<blocks_for(P, 256), 256, 0, st>>>(recv_dev, m->slot.as<int32_t>(),
                                                            m->have_sparse ? m->sparse.as<float>() : nullptr, P, (float)alpha,
@@ -2935,10 +2948,10 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   if (long long v = 0; ffx_debug_variant("score_slice_pairs", &v)) per_slice = std::max<int64_t>(1, (int64_t)v);
   // ... and the first and last slices are smaller (an eighth of a slice, doubling / halving): the device idles
   // while the first slice is uploaded and the caller idles while the last one's results come back
-  int64_t ramp_base = ffx_debug_variant("score_no_ramp", nullptr) ? per_slice : std::max<int64_t>(per_slice / 8, 1);
-  if (long long v = 0; ffx_debug_variant("score_ramp_pairs", &v)) ramp_base = std::max<int64_t>(1, std::min<int64_t>((int64_t)v, per_slice));  // A/B hook: tools/slice_sweep.py
+  int64_t ramp_base = ffx_experiment("score_no_ramp", nullptr) ? per_slice : std::max<int64_t>(per_slice / 8, 1);
+  if (long long v = 0; ffx_experiment("score_ramp_pairs", &v)) ramp_base = std::max<int64_t>(1, std::min<int64_t>((int64_t)v, per_slice));  // A/B hook: tools/slice_sweep.py
   long long growth_pct = 200;  // how fast the first slices grow (A/B hook)
-  (void)ffx_debug_variant("score_ramp_growth_pct", &growth_pct);
+  (void)ffx_experiment("score_ramp_growth_pct", &growth_pct);
   growth_pct = std::max<long long>(110, std::min<long long>(growth_pct, 400));
   auto slice_target = [&](size_t i, int64_t first_pair) {
     double grown = (double)ramp_base;
@@ -2967,7 +2980,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   // kernel stream the upload queued behind a slice's kernels (3.9 ms instead of 0.9 ms for set_pairs: 20.9 ms
   // instead of 18.4 ms for the headline batch, depending on which other streams the process had created).
   bool async_out = false;
-  if (n_slices > 1 && !ffx_debug_variant("score_no_out_stream", nullptr)) {
+  if (n_slices > 1 && !ffx_experiment("score_no_out_stream", nullptr)) {
     const void* any = out_ff ? (const void*)out_ff : out_interp ? (const void*)out_interp : out_order ? (const void*)out_order : out_ranked ? (const void*)out_ranked : (const void*)out_carry;
     hipPointerAttribute_t attr;
     if (any && hipPointerGetAttributes(&attr, any) == hipSuccess && attr.type == hipMemoryTypeHost)
@@ -2979,14 +2992,14 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
   if ((async_out || threaded_out) && !idx->out_stream) {
     int least = 0, greatest = 0;
     FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
+    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_experiment("score_out_priority_low", nullptr) ? least : greatest));
     for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   // (ordinary result buffers: FOUR plans (three and five were 0.2 - 0.4 ms slower).  A slice's results leave at the link's pace -- 2 ms for a full slice -- and the short
   // slices a call ends with are scored faster than that: with three plans the third-to-last slice waited for the plan of a full
   // slice whose results were still leaving, and the device idled meanwhile: 1 - 2 ms of the headline batch)
   int n_plans = n_slices > 1 ? (threaded_out ? 4 : async_out ? 3 : 2) : 1;
-  if (long long v = 0; n_plans > 2 && ffx_debug_variant("score_plans", &v)) n_plans = (int)std::max<long long>(3, std::min<long long>(v, ffx_index::kScorePlans));
+  if (long long v = 0; n_plans > 2 && ffx_experiment("score_plans", &v)) n_plans = (int)std::max<long long>(3, std::min<long long>(v, ffx_index::kScorePlans));
   for (int i = 0; i < n_plans; ++i)
     if (!idx->score_plans[i]) FFX_TRY(plan_create(idx, &idx->score_plans[i], i == 0));
   if (n_slices > 1 && !idx->score_stream) FFX_HIP(hipStreamCreateWithFlags(&idx->score_stream, hipStreamNonBlocking));
@@ -3280,7 +3293,7 @@ int ffx_index_prepare_score(ffx_index* idx, int64_t n_queries, int64_t n_pairs, 
   if (sliced && page_locked_buffers && !idx->out_stream) {
     int least = 0, greatest = 0;
     FFX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_debug_variant("score_out_priority_low", nullptr) ? least : greatest));
+    FFX_HIP(hipStreamCreateWithPriority(&idx->out_stream, hipStreamNonBlocking, ffx_experiment("score_out_priority_low", nullptr) ? least : greatest));
     for (auto& e : idx->out_done) FFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   for (int i = 0; i < n_plans; ++i)

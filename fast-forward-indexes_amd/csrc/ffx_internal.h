@@ -14,6 +14,16 @@
 
 int ffx_fail(int code, const char* fmt, ...);
 bool ffx_debug_variant(const char* name, long long* value);  // the FFX_DEBUG_VARIANT list of A/B switches (ffx.hip)
+// The switches of FFX_DEBUG_VARIANT come in two kinds.  ffx_debug_variant: a choice between two paths that BOTH ship (the
+// dispatcher reaches either under some input), kept so that tests can compare them on one input.  ffx_experiment: tuning
+// hooks -- kernels and schedules that lost their A/B and that no input reaches (tools/kernel_ab.py, slice_sweep.py,
+// sort_ab.py, dims_bench.py) -- compiled only into the experiments build (make EXPERIMENTS=1 -> libffx_experiments.so,
+// loaded with FFX_LIBRARY=...); in the default build the switch is a constant `false` and the code behind it is not there.
+#ifdef FFX_EXPERIMENTS
+inline bool ffx_experiment(const char* name, long long* value) { return ffx_debug_variant(name, value); }
+#else
+inline bool ffx_experiment(const char*, long long*) { return false; }
+#endif
 
 // Room in the plan for n_queries + 1 offsets and n_pairs ordinals; the caller fills both device buffers on any stream.
 // (Buffers may be re-allocated here: call it while nothing of the plan is in flight.)

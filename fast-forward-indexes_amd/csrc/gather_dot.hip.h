@@ -277,6 +277,7 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   }
 }
 
+#ifdef FFX_EXPERIMENTS
 // ---- experiment (FFX_DEBUG_VARIANT=gather=921 / 922 / 923, tools/kernel_ab.py): the same kernel as a PERSISTENT grid --------
 // gridDim.x workgroups stay for the whole launch and every wave walks tiles of the row list: CHUNKED = false: tile w, w + W,
 // w + 2 W ... (W waves in all); CHUNKED = true: a contiguous share of the tiles (consecutive rows: the query vector stays in
@@ -363,6 +364,8 @@ gather_dot_exact_lds_persistent_kernel(const T* __restrict__ vectors, const floa
     }
   }
 }
+
+#endif  // FFX_EXPERIMENTS
 
 // ---- the same for smaller rows: d = 8*LEAVES*NPER with LEAVES in {1,2,4}, NPER % 4 == 0 ----------
 // (d = 512, 384, 256, 128, 64, ...).  NumPy's tree for such a row has 8*LEAVES partial sums, so

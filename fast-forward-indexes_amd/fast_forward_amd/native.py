@@ -12,7 +12,11 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "libffx.so"
+import os as _os  # noqa: E402
+
+# FFX_LIBRARY: another build of the same sources (tools/kernel_ab.py & co. name libffx_experiments.so, `make EXPERIMENTS=1`,
+# which carries the tuning hooks and the kernels only they reach; the default library has neither)
+LIB_PATH = Path(_os.environ["FFX_LIBRARY"]).resolve() if _os.environ.get("FFX_LIBRARY") else Path(__file__).resolve().parent / "libffx.so"
 
 OK, BAD_ARG, OOM, HIP_ERROR, RCCL_ERROR, NOT_FOUND, NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 FLAG_EXACT_SUM, FLAG_SORT, FLAG_SORT_FF, FLAG_ES_BOUND_F32, FLAG_KEEP_DENSE = 1, 2, 4, 8, 16
@@ -39,7 +43,7 @@ SYMBOLS = (
 # ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
 PRIVATE_SYMBOLS = (
     "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
-    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats",
+    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats", "ffx_build_has_experiments",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_strings_code_offsets32", "ffx_strings_code_fixed", "ffx_host_repeated_in_groups", "ffx_buffer_free",
@@ -211,6 +215,7 @@ def lib() -> C.CDLL:
         "ffx_run_names": ([vp, P(vp), P(i64), P(i64)], C.c_int),
         "ffx_host_stage_report": ([vp, i64, P(i64)], C.c_int),
         "ffx_host_xfer_stats": ([P(C.c_uint64), P(C.c_uint64)], C.c_int),
+        "ffx_build_has_experiments": ([], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
@@ -279,6 +284,11 @@ def stage_report() -> dict:
     buf = C.create_string_buffer(max(1, need.value))
     _check(lib().ffx_host_stage_report(buf, need.value, C.byref(need)))
     return {k: float(v) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
+
+
+def has_experiments() -> bool:
+    """True for the experiments build (``make EXPERIMENTS=1``): the tuning hooks of FFX_DEBUG_VARIANT are compiled in."""
+    return bool(lib().ffx_build_has_experiments())
 
 
 def xfer_stats() -> dict:

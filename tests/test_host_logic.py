@@ -173,6 +173,22 @@ def test_loading_the_library_changes_no_setting_of_the_runtime():
             assert out.stdout.strip().splitlines()[-1] == want, (code[:40], extra, out.stdout)
 
 
+def test_the_default_library_ships_no_tuning_hooks():
+    """`make` builds what the dispatcher can reach; the tuning hooks of FFX_DEBUG_VARIANT (ffx_experiment) and the kernels only
+    they select (gather=N: strided, persistent, two-wave forms) are compiled with `make EXPERIMENTS=1` into a library of their
+    own.  The default library says so, and the sources keep every such hook behind ffx_experiment."""
+    from fast_forward_amd import native
+
+    if not os.environ.get("FFX_LIBRARY"):
+        assert native.has_experiments() is False
+    csrc = ROOT / "fast-forward-indexes_amd" / "csrc"
+    text = (csrc / "ffx.hip").read_text() + (csrc / "comm.hip").read_text()
+    for hook in ("gather", "anyd_u", "generic_staged", "generic_plain", "sort_block_from", "score_plans", "score_no_ramp", "merge_on_results"):
+        assert f'ffx_debug_variant("{hook}"' not in text and f'ffx_experiment("{hook}"' in text, hook
+    header = (csrc / "gather_dot.hip.h").read_text()
+    assert header.index("#ifdef FFX_EXPERIMENTS") < header.index("gather_dot_exact_lds_persistent_kernel(")
+
+
 def test_caller_memory_reaches_the_runtime_only_through_host_xfer():
     """What replaces the setting: every copy between host memory and the device in ffx.hip / comm.hip goes through
     ffx_h2d / ffx_d2h (csrc/host_xfer.h: ordinary memory above 1 MiB is staged through page-locked blocks of the library), or

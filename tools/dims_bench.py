@@ -11,6 +11,10 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "fast-forward-indexes_amd"))
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+import _experiments  # noqa: E402
+
+_experiments.use()  # the switches this tool flips exist in the experiments build only
 from fast_forward_amd import native, synth  # noqa: E402
 import bench as B  # noqa: E402
 
