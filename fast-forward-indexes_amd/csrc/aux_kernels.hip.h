@@ -169,6 +169,24 @@ expand_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, int mode,
   }
 }
 
+// For the gather_dot kernels that derive their rows themselves (gather_dot.hip.h, Derive; documents of several passages,
+// MAXP / AVEP): per candidate where its document's rows begin in doc_rows, per TILE of the row list the candidate its first row
+// belongs to and that candidate's query.  4 bytes per candidate and 8 per tile; made once per candidate list.
+__global__ void __launch_bounds__(256)
+tile_index_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, const int64_t* __restrict__ pair_off, int n_queries,
+                  double queries_per_pair, const int32_t* __restrict__ doc_off, const int32_t* __restrict__ seg_off, int tile,
+                  int32_t* __restrict__ pair_first, int2* __restrict__ tile_tab) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int32_t s = seg_off[p], e = seg_off[p + 1];
+  pair_first[p] = doc_off[pair_ids[p]];
+  int64_t t = ((int64_t)s + tile - 1) / tile;
+  if (t * tile < e) {
+    const int q = query_of_pair(pair_off, n_queries, p, queries_per_pair);
+    for (; t * tile < e; ++t) tile_tab[t] = make_int2((int)p, q);
+  }
+}
+
 // single-row candidates (FIRSTP, PASSAGE, or every document has one passage): no scan needed.
 // row_of[o] is the one row of ordinal o (first row of the document / row of the passage);
 // row_of == nullptr means ordinal == row (ids were added one per row, in order).

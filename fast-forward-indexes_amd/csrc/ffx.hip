@@ -118,6 +118,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 //   no_small_path          ffx_score never takes the single-submission path of small batches
 //   route_host             the sharded scorer routes a batch on the host even for document-range shards
 //   pq_no_fuse, pq_no_adc, pq_sort_apart  product-quantized rows: unfused exact ADC / decode-then-dot instead of exact ADC / the ordering as a launch of its own
+//   no_derive              documents of several passages: the row list written by an expand kernel instead of rows derived by gather_dot
 //   score_slice_pairs=N, score_blocking_out   where ffx_score cuts a batch into slices; results fetched by the calling thread
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
 //   rehearsal_paced[=GB/s] the rehearsal transport's stand-in exchange paced like a link (bench.py --rehearsal-exchange)
@@ -269,6 +270,7 @@ struct ffx_index {
   int64_t n_docs = 0, n_doc_rows = 0, n_psgs = 0;
   int64_t max_doc_rows = 1;  // rows of the longest document: bounds what a candidate can contribute
   bool docs_identity = false;  // document ordinal o owns exactly row o
+  bool doc_rows_identity = false;  // doc_rows[i] == i: documents were added whole and in order (position in doc_rows == row)
   bool psgs_identity = false;  // passage ordinal o is row o
   bool docs_nonempty = false;  // every document has at least one row
   // the plans ffx_score rotates through (two; three when results leave asynchronously); created on first use, freed with the index
@@ -325,6 +327,9 @@ struct ffx_plan {
   DevBuf ff, interp, order;
   // the run in final order (ffx_score_ranked): the sort key and a carried word per candidate, permuted by `order`
   DevBuf carry, ranked, carry_ranked;
+  // documents of several passages scored without a row list (gather_dot.hip.h, Derive): made on the first run of a candidate list
+  DevBuf pair_first, tile_tab;
+  bool derive_valid = false, use_derive = false;
   bool want_ranked = false, have_carry = false;
   bool dense_given = false;  // the next run starts from dense scores already in `ff` (ffx_rank_kept): no expand, no gather
   int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
@@ -386,6 +391,8 @@ struct ffx_plan {
   }
   bool hstage_failed = false;
 };
+
+static bool derive_applies(const ffx_plan* pl);  // (defined beside the gather_dot dispatcher)
 
 namespace {
 // host -> device on the plan's stream; small sources go through the page-locked block (the
@@ -953,6 +960,8 @@ int ffx_index_set_doc_rows(ffx_index* idx, const int64_t* doc_off, int64_t n_doc
   idx->max_doc_rows = 1;
   for (int64_t i = 0; i < n_docs; ++i) idx->max_doc_rows = std::max(idx->max_doc_rows, doc_off[i + 1] - doc_off[i]);
   idx->docs_identity = identity && n_docs > 0;
+  idx->doc_rows_identity = n_doc_rows > 0;
+  for (int64_t i = 0; i < n_doc_rows && idx->doc_rows_identity; ++i) idx->doc_rows_identity = doc_rows[i] == i;
   idx->docs_nonempty = n_docs > 0;
   for (int64_t i = 0; i < n_docs && idx->docs_nonempty; ++i) idx->docs_nonempty = doc_off[i + 1] > doc_off[i];
   return FFX_OK;
@@ -1252,6 +1261,7 @@ static int set_pairs_check_complete(ffx_plan* pl, int64_t* bad_pair) {
     pl->n_rows = P;
     FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)P, 1) * sizeof(int2)));
     pl->have_pairs = true;
+    pl->derive_valid = false;
     pl->lazy_pairs = false;
     return FFX_OK;
   }
@@ -1274,9 +1284,10 @@ static int set_pairs_check_complete(ffx_plan* pl, int64_t* bad_pair) {
   if (total < 0) return fail(FFX_BAD_ARG, "more than 2^31-1 gathered rows in one batch: split the queries");
   pl->n_rows = total;
   const size_t rb = std::max<size_t>((size_t)total, 1);
-  FFX_TRY(pl->desc.ensure(rb * sizeof(int2)));
+  if (!derive_applies(pl)) FFX_TRY(pl->desc.ensure(rb * sizeof(int2)));  // (else on the run that needs it: 8 bytes per gathered row)
   if (pl->n_rows != pl->n_pairs) FFX_TRY(pl->rs.ensure(rb * sizeof(float)));
   pl->have_pairs = true;
+  pl->derive_valid = false;
   pl->lazy_pairs = false;
   return FFX_OK;
 }
@@ -1352,7 +1363,7 @@ int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src) {
     FFX_TRY(dst->interp.ensure(pb * sizeof(float)));
   }
   const size_t rb = std::max<size_t>((size_t)src->n_rows, 1);
-  FFX_TRY(dst->desc.ensure(rb * sizeof(int2)));
+  if (src->desc.p) FFX_TRY(dst->desc.ensure(rb * sizeof(int2)));
   if (src->n_rows != P) FFX_TRY(dst->rs.ensure(rb * sizeof(float)));
   hipStream_t st = dst->stream;
   FFX_HIP(hipStreamSynchronize(src->stream));
@@ -1372,6 +1383,7 @@ int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src) {
   dst->host_pair_off = src->host_pair_off;
   dst->order_base = src->order_base;
   dst->have_pairs = true;
+  dst->derive_valid = false;
   return FFX_OK;
 }
 
@@ -1501,6 +1513,26 @@ int ffx_plan_queries_room(ffx_plan* pl, int64_t n_queries, float** d_queries) {
   return FFX_OK;
 }
 
+// what a row-deriving gather_dot reads instead of a row list (gather_dot.hip.h, Derive)
+static ffx::Derive plan_derive(const ffx_plan* pl) {
+  const ffx_index* ix = pl->idx;
+  ffx::Derive dv;
+  dv.tile_tab = pl->tile_tab.as<int2>();
+  dv.seg_off = pl->seg_off.as<int32_t>();
+  dv.pair_first = pl->pair_first.as<int32_t>();
+  dv.doc_rows = ix->doc_rows_identity ? nullptr : ix->doc_rows.as<int32_t>();
+  dv.pair_off = pl->pair_off.as<int64_t>();
+  dv.n_pairs = (int)pl->n_pairs;
+  return dv;
+}
+
+// rows of this storage type and length, in this mode, have a row-deriving kernel (exact summation only)
+static bool derive_applies(const ffx_plan* pl) {
+  const ffx_index* ix = pl->idx;
+  return (ix->dtype == FFX_DTYPE_F32 || ix->dtype == FFX_DTYPE_F16) && (ix->qdim == 768 || ix->qdim == 1024) && !pl->ov_dim &&
+         (pl->mode == FFX_MODE_MAXP || pl->mode == FFX_MODE_AVEP) && !ffx_debug_variant("no_derive", nullptr);
+}
+
 // pick and launch the gather_dot instantiation for rows of type T (float / _Float16); the
 // variant id lands in ffx_stats.kernel_variant (+1000 for half rows)
 template <typename T>
@@ -1581,7 +1613,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       FFX_EXP_EXACT(907, 4, 8, false);
 #undef FFX_EXP_EXACT
 #define FFX_EXP_LDS(ID, U, TILE, NT) \
-  case ID: ffx::gather_dot_exact_lds_kernel<T, 3, U, TILE, NT><<<blocks_for(waves, 4 * TILE), 256, 0, st>>>(V, Q, desc, rs, R); break
+  case ID: ffx::gather_dot_exact_lds_kernel<T, 3, U, TILE, NT><<<blocks_for(waves, 4 * TILE), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break
       FFX_EXP_LDS(911, 4, 16, true);
       FFX_EXP_LDS(912, 2, 8, true);
       FFX_EXP_LDS(913, 4, 8, true);
@@ -1595,7 +1627,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       case 922: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 923: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, false><<<256 * 12, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 924: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 16, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 925: ffx::gather_dot_exact_lds_kernel<T, 3, 4, 8, true><<<blocks_for(waves, 2 * 8), 128, 0, st>>>(V, Q, desc, rs, R); break;  // workgroups of two waves
+      case 925: ffx::gather_dot_exact_lds_kernel<T, 3, 4, 8, true><<<blocks_for(waves, 2 * 8), 128, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;  // workgroups of two waves
       case 951: ffx::gather_dot_fast_kernel<T, 3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 953: ffx::gather_dot_fast_kernel<T, 3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
@@ -1613,12 +1645,18 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   if (exact) {
     switch (d) {
       case 768:
-        ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R);
-        pl->variant = 111 + HALF;
+        if (pl->use_derive)  // no row list: the waves work their rows out of the candidate lists (311 / 1311)
+          ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+        else
+          ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
+        pl->variant = (pl->use_derive ? 311 : 111) + HALF;
         break;
       case 1024:
-        ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R);
-        pl->variant = 112 + HALF;
+        if (pl->use_derive)
+          ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+        else
+          ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
+        pl->variant = (pl->use_derive ? 312 : 112) + HALF;
         break;
 #define FFX_MULTI(LEAVES, NPER, U, TILE, ID)                                                                     \
   do {                                                                                                           \
@@ -2005,6 +2043,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
   const bool exact = (flags & FFX_FLAG_EXACT_SUM) != 0;
   pl->ran = false;
+  pl->use_derive = false;
   FFX_HIP(hipEventRecord(pl->ev[0], st));
   // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
   const bool pq_fused = !given && single && P > 0 && !ffx_debug_variant("pq_no_fuse", nullptr) && pq_exact_adc_applies(pl);
@@ -2029,7 +2068,22 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
                                                            : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
       ffx::expand_single_kernel<<<blocks_for((P + 3) / 4, 256), 256, 0, st>>>(
           pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of, ix->capacity, pl->desc.as<int2>());
+    } else if (exact && derive_applies(pl)) {
+      // no row list: the scoring kernel derives its rows from the candidate lists, the row offsets (the scan of set_pairs is
+      // still there) and two small tables made on the first run of a candidate list (4 B per candidate, 8 B per tile)
+      pl->use_derive = true;
+      if (!pl->derive_valid) {
+        const int tile = ix->dtype == FFX_DTYPE_F16 ? 16 : 8;  // (TL of launch_gather_dot_t)
+        FFX_TRY(launch_count_scan(pl));
+        FFX_TRY(pl->pair_first.ensure((size_t)P * sizeof(int32_t)));
+        FFX_TRY(pl->tile_tab.ensure(((size_t)R / tile + 2) * sizeof(int2)));
+        ffx::tile_index_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp,
+                                                                  ix->doc_off.as<int32_t>(), pl->seg_off.as<int32_t>(), tile, pl->pair_first.as<int32_t>(),
+                                                                  pl->tile_tab.as<int2>());
+        pl->derive_valid = true;
+      }
     } else {
+      FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)R, 1) * sizeof(int2)));  // (not made by set_pairs where rows can be derived)
       FFX_TRY(launch_count_scan(pl));
       ffx::expand_kernel<<<blocks_for(P, 256), 256, 0, st>>>(
           pl->pair_ids.as<int32_t>(), P, pl->mode, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp,
@@ -2221,6 +2275,7 @@ int ffx_plan_early_stopping(ffx_plan* pl, int32_t cutoff, double alpha, const in
     FFX_TRY(ch->desc.ensure(rb * sizeof(int2)));
     if (ch->n_rows != ch->n_pairs) FFX_TRY(ch->rs.ensure(rb * sizeof(float)));
     ch->have_pairs = true;
+    ch->derive_valid = false;
     FFX_TRY(ffx_plan_run(ch, alpha, flags & FFX_FLAG_EXACT_SUM));
     ffx::es_scatter_kernel<<<blocks_for(n_sub, 256), 256, 0, st>>>(ch->ff.as<float>(), ch->interp.as<float>(), pl->es_pos.as<int32_t>(), n_sub,
                                                                   pl->ff.as<float>(), pl->interp.as<float>());
@@ -2786,6 +2841,7 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
       idx->n_psgs, idx->capacity, pl->small_flag.as<unsigned long long>());
   FFX_HIP(hipGetLastError());
   pl->have_pairs = true;
+  pl->derive_valid = false;
   if (const int rc = ffx_plan_run(pl, alpha, flags)) {
     pl->have_pairs = false;
     const std::string keep = g_last_error;
@@ -2885,6 +2941,7 @@ static int plan_set_given(ffx_plan* pl, const int64_t* off, int64_t n_queries, c
   }
   FFX_HIP(hipStreamSynchronize(pl->stream));  // (as ffx_plan_set_pairs: the run goes to another stream)
   pl->have_pairs = true;
+  pl->derive_valid = false;
   pl->dense_given = true;
   return FFX_OK;
 }

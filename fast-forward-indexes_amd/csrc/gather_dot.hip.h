@@ -201,10 +201,26 @@ gather_dot_exact_kernel(const T* __restrict__ vectors, const float* __restrict__
 // LL+8 floats in LDS so that the 32 lanes of a ds_read_b32 group hit 32 different banks
 // ((LL+8)*l + j mod 32 = 8*l + j for LL a multiple of 32).  LDS operations of one wave execute in
 // order, so the read-after-write and the next row's write-after-read need no s_barrier.
-template <typename T, int NCH, int U, int TILE, bool NT>
+// DERIVE (documents of several passages, Mode.MAXP / AVEP): there is no row list.  The wave works out the rows of its tile
+// itself (get_indices, index/util.py:29-41 + the left merge of index/base.py:296-298, for TILE rows at a time): `tile_tab`
+// names the candidate its first row belongs to and that candidate's query; TILE + 1 lanes read the row offsets of that
+// candidate and the TILE after it (every candidate has at least one row, so the tile's rows lie among them), every lane finds
+// its row's candidate by comparing against those offsets, and the row is that candidate's first row (`pair_first`: where the
+// document's rows begin in doc_rows) plus the distance -- 4 bytes per candidate and 8 per tile instead of 8 per row written by
+// an expand kernel and read back here (1.26 GB each way at 157 M rows).
+struct Derive {
+  const int2* tile_tab = nullptr;       // per tile: {candidate of the tile's first row, query of that candidate}
+  const int32_t* seg_off = nullptr;     // [n_pairs + 1] first row of every candidate in the (virtual) row list
+  const int32_t* pair_first = nullptr;  // [n_pairs] position in doc_rows of every candidate's first row
+  const int32_t* doc_rows = nullptr;    // nullptr: position == row (documents added whole, in order)
+  const int64_t* pair_off = nullptr;    // [n_queries + 1]
+  int n_pairs = 0;
+};
+
+template <typename T, int NCH, int U, int TILE, bool NT, bool DERIVE = false>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
-                            const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+                            const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, const Derive dv) {
   constexpr int D = 256 * NCH;
   constexpr int LL = D / 8;        // leaf length (96 or 128)
   constexpr int NPER = LL / 8;     // adds per accumulator
@@ -220,7 +236,28 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   if (base >= n_rows) return;
   const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
   const int my_t = lane < n_here ? lane : n_here - 1;
-  const int2 my = desc[base + my_t];
+  int2 my;
+  if constexpr (DERIVE) {
+    const int2 first = dv.tile_tab[wave];  // (uniform: one scalar load)
+    const int p_mine = first.x + lane;
+    const int so = lane <= TILE ? dv.seg_off[p_mine < dv.n_pairs ? p_mine : dv.n_pairs] : 0x7fffffff;
+    const int pf = dv.pair_first[p_mine < dv.n_pairs ? p_mine : dv.n_pairs - 1];
+    long next_q = dv.pair_off[first.y + 1];
+    const int r = (int)base + my_t;
+    int j = 0;  // how many of the TILE candidates after the first begin at or before my row
+#pragma unroll
+    for (int l = 1; l <= TILE; ++l) j += __builtin_amdgcn_readlane(so, l) <= r ? 1 : 0;
+    int rid = __shfl(pf, j) + (r - __shfl(so, j));
+    if (dv.doc_rows) rid = dv.doc_rows[rid];
+    int qn = first.y;
+    while (first.x + j >= next_q) {  // my candidate lies in a later query (queries without candidates are stepped over)
+      ++qn;
+      next_q = dv.pair_off[qn + 1];
+    }
+    my = make_int2(rid, qn);
+  } else {
+    my = desc[base + my_t];
+  }
 
   float* buf = tile[wave_in_block];
   // where this lane's NCH float4 of products go, and where its NPER summands come from

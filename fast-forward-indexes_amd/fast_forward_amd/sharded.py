@@ -371,7 +371,7 @@ def _owner_of(doc_id: str | None, psg_id: str | None, world: int) -> int:
 
 class _ShardedIndex:
     """What the sharded index classes share: the ``Index`` surface over SPMD ranks.  Subclasses say
-    who holds each candidate (``_holders``) and own the shard."""
+    who holds each candidate (``_code_routing``) and own the shard."""
 
     comm = None
     local = None  # the object carrying mode / query encoder (an Index)
@@ -469,18 +469,6 @@ class _ShardedIndex:
         bad = np.flatnonzero(routing["holder_c"][codes] < 0)
         raise IndexError(f"ID {names[codes[int(bad[0])]]} not found in the index.")
 
-    def _holders(self, ranking, perm, missing_ok: bool = False) -> tuple[np.ndarray, np.ndarray]:
-        """(holder rank, ordinal on that rank) of every candidate, rows grouped by query.  ``IndexError`` on EVERY rank
-        for an id no rank holds, naming the first one in row order -- or, with ``missing_ok`` (early stopping: an unknown
-        id only matters if it is reached), holder -1 for such rows."""
-        routing = self._code_routing(ranking)
-        if "rows" not in routing:
-            routing["rows"] = (routing["holder_c"][routing["codes"]], routing["ordinal_c"][routing["codes"]])
-        holder, local_ids = routing["rows"]
-        if not missing_ok and routing["missing"]:
-            self._raise_first_missing(routing)
-        return (holder, local_ids) if perm is None else (holder[perm], local_ids[perm])
-
     def _streams_rows(self) -> bool:
         """True when this rank's rows are not resident and every call streams them from the file (``ShardedOnDiskIndex``)."""
         return False
@@ -501,10 +489,10 @@ class _ShardedIndex:
         """The query vectors as the resident scorer wants them (an OPQ shard: rotated once, see InMemoryIndex)."""
         return query_vectors
 
-    def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode) -> np.ndarray | None:
-        """Dense scores of this rank's candidates computed outside ``ffx_sharded`` (a shard that is
-        streamed from its file instead of resident), or None when the resident scorer does it."""
-        return None
+    def _score_held(self, query_vectors, local_off, ordinals) -> np.ndarray:
+        """Dense scores of candidates THIS rank holds (a CSR over all queries of the batch, ordinals of this rank), by the
+        rank's own 1-GPU path: the resident shard, or -- a shard that stays in its file -- the streaming path."""
+        return self.local._score_pairs(query_vectors, local_off, ordinals, self.local.mode)[0]
 
     def _rank(self, ranking, alpha: float | None, name, gather: bool):
         """Score, exchange, finish the owned queries; the ``Ranking`` of this rank's queries (or of all).  The same one
@@ -533,22 +521,28 @@ class _ShardedIndex:
             rows = slice(lo, hi) if run.perm is None else run.perm[lo:hi]  # this block's rows of the ranking
             own_codes = np.ascontiguousarray(run.codes[rows], dtype=np.int32)
             own_sparse = np.ascontiguousarray(ranking._scores()[rows], dtype=np.float32) if alpha is not None else None
-            own_q = self._scorer_queries(run.query_vectors[q_lo:q_hi]) if q_hi > q_lo else np.zeros((0, scorer.shard.query_dim), dtype=np.float32)
+            # (an OPQ shard rotates the queries: ALL of them in one product, then the block -- a matrix product's rounding depends on
+            # its shape, and the block of one query must get the bits the one-GPU index gets for that query)
+            own_q = (np.ascontiguousarray(self._scorer_queries(run.query_vectors)[q_lo:q_hi]) if q_hi > q_lo
+                     else np.zeros((0, scorer.shard.query_dim), dtype=np.float32))
             ff, interp, order = scorer.score_owned(qb, own_q, pair_off[q_lo:q_hi + 1] - lo, own_codes, own_sparse, mode, 0.0 if alpha is None else alpha,
                                                    exact_sum=self.exact_sum, sort=True, own_holder=routing["holder_c"][own_codes])
         else:
-            # the shard is streamed from its file: local scores by the 1-GPU streaming path, the same exchange on host
-            # buffers, then the owner-side epilogue (ffx_aggregate, 1-row segments)
-            sparse = np.ascontiguousarray(run.grouped(ranking._scores()), dtype=np.float32)
-            holder, local_ids = self._holders(ranking, run.perm)
-            streamed = self._local_scores(run.query_vectors, pair_off, holder, local_ids, mode)
-            r = native.route(pair_off, local_ids, self.comm.rank, self.comm.world, holder=holder)
-            recv = self.comm.exchange_host(streamed, r["send_counts"], r["recv_counts"])
-            dense = recv[r["recv_slot"]]
-            q_lo, q_hi = r["q_lo"], r["q_hi"]
-            lo, hi = r["own_first_pair"], r["own_first_pair"] + r["own_pairs"]
+            # the shard is streamed from its file: the same owner-side routing on host buffers -- this rank takes in the block
+            # of the queries it owns, the holders get the id codes of what they hold (and score them by the 1-GPU streaming
+            # path), the scores come back; then the owner-side epilogue (ffx_aggregate, 1-row segments)
+            routing = self._code_routing(ranking)
+            if routing["missing"]:
+                self._raise_first_missing(routing)
+            qb = native.query_partition(run.n_q, self.comm.world)
+            q_lo, q_hi = int(qb[self.comm.rank]), int(qb[self.comm.rank + 1])
+            lo, hi = int(pair_off[q_lo]), int(pair_off[q_hi])
+            rows = slice(lo, hi) if run.perm is None else run.perm[lo:hi]  # this block's rows of the ranking
+            own_codes = np.ascontiguousarray(run.codes[rows], dtype=np.int32)
+            dense = self._owner_routed_dense(run.query_vectors, qb, pair_off[q_lo:q_hi + 1] - lo, own_codes, routing)
             if hi > lo:
-                ff, interp, order = native.aggregate(dense, np.arange(hi - lo + 1, dtype=np.int64), 1, sparse[lo:hi] if alpha is not None else None,
+                own_sparse = np.ascontiguousarray(ranking._scores()[rows], dtype=np.float32) if alpha is not None else None
+                ff, interp, order = native.aggregate(dense, np.arange(hi - lo + 1, dtype=np.int64), 1, own_sparse,
                                                      0.0 if alpha is None else alpha, pair_off[q_lo:q_hi + 1] - lo, sort=True, device=self.comm.device)
             else:
                 ff, interp, order = dense, (dense if alpha is not None else None), np.zeros(0, dtype=np.int32)
@@ -567,66 +561,136 @@ class _ShardedIndex:
         full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(self.comm.world)])
         return run.result(name, full_k, full_s, pair_off)[0]
 
-    def _dense_everywhere(self, query_vectors, pair_off, holder, local_ids) -> np.ndarray:
-        """Dense scores of EVERY candidate of a CSR, on every rank (collective): the sharded step -- local scores, exchange
-        to the owners -- and one all-gather of the owners' blocks, which stand in query order."""
-        from fast_forward_amd import native
+    def _owner_routed_dense(self, query_vectors, q_bounds, own_off, own_codes, routing, error: "str | None" = None) -> np.ndarray:
+        """Dense scores of the candidates of the queries THIS rank owns (collective; the host-buffer form of
+        ``ffx_sharded_stage_owned`` + run, for shards that are streamed and for the steps of early stopping).
 
-        mode = self.local.mode.value
-        streamed = self._local_scores(query_vectors, pair_off, holder, local_ids, mode)
-        if streamed is None:
-            scorer = self._sharded()
-            scorer.set_queries(self._scorer_queries(query_vectors))
-            scorer.set_pairs(pair_off, local_ids, None, mode, holder=holder)
-            scorer.run(0.0, exact_sum=self.exact_sum, sort=False)
-            mine = scorer.fetch(order=False)[0]
-            n_own = scorer.own_pairs
+        ``own_off`` / ``own_codes``: CSR over this rank's block ``q_bounds[rank] .. q_bounds[rank + 1]`` of the batch's queries,
+        candidates as the ranking's id codes (every rank numbers a ranking's ids alike; ``routing`` names each code's holder
+        and its ordinal there).  A rank takes in its own block and what the owners send it -- the codes of the candidates
+        it holds, with their per-query counts -- never the batch: per-rank intake is proportional to 1 / world
+        (``last_intake`` says what it was).  Every holder scores what it received with its own 1-GPU path (resident or
+        streamed) and returns the scores to the owners, which put them back in candidate order.
+
+        ``error``: a message this rank wants EVERY rank to raise as ``IndexError`` at this step instead (an unknown id
+        reached by one owner's early-stopping loop must not leave the others waiting in the exchange)."""
+        comm, world, me = self.comm, self.comm.world, self.comm.rank
+        q_bounds = np.asarray(q_bounds, dtype=np.int64)
+        own_off = np.asarray(own_off, dtype=np.int64)
+        n_own_q, n_own = own_off.shape[0] - 1, int(own_off[-1])
+        assert n_own_q == int(q_bounds[me + 1] - q_bounds[me])
+        own_codes = np.ascontiguousarray(own_codes, dtype=np.int32)
+        holder = routing["holder_c"][own_codes] if n_own else np.zeros(0, dtype=np.int32)
+        if error is None and n_own and int(holder.min()) < 0:
+            error = f"ID {routing['names'][own_codes[int(np.flatnonzero(holder < 0)[0])]]} not found in the index."
+        message = (error or "").encode()[:400]
+        counts = np.bincount(holder, minlength=world).astype(np.int64) if error is None else np.zeros(world, dtype=np.int64)
+        header = comm.allgather_array(np.concatenate([[len(message)], counts]).astype(np.int64))  # (world, 1 + world)
+        if header[:, 0].any():
+            said = comm.allgather_bytes(message.ljust(400, b"\0"))
+            raise IndexError(next(m.rstrip(b"\0").decode(errors="replace") for m, n in zip(said, header[:, 0]) if n))
+        # to every holder: how many of each of my queries' candidates it holds, then their codes (in my candidate order)
+        by_holder = np.argsort(holder, kind="stable")
+        q_of = np.repeat(np.arange(n_own_q, dtype=np.int64), np.diff(own_off))
+        per_query = (np.bincount(holder.astype(np.int64) * n_own_q + q_of, minlength=world * n_own_q).astype(np.int32).reshape(world, n_own_q)
+                     if n_own_q else np.zeros((world, 0), dtype=np.int32))
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        grouped = own_codes[by_holder]
+        send = np.concatenate([part for t in range(world) for part in (per_query[t], grouped[starts[t]:starts[t + 1]])]).astype(np.int32, copy=False)
+        q_per_rank = np.diff(q_bounds)
+        held_from = header[:, 1 + me]  # candidates rank r sends me
+        got = comm.exchange_host(send.view(np.float32), n_own_q + counts, q_per_rank + held_from).view(np.int32)
+        # what arrived, owner after owner = query after query: the CSR of the candidates this rank holds, as ordinals
+        at, local_counts, held_codes = 0, [], []
+        for r in range(world):
+            local_counts.append(got[at:at + int(q_per_rank[r])])
+            at += int(q_per_rank[r])
+            held_codes.append(got[at:at + int(held_from[r])])
+            at += int(held_from[r])
+        local_off = np.zeros(int(q_bounds[-1]) + 1, dtype=np.int64)
+        np.cumsum(np.concatenate(local_counts), out=local_off[1:])
+        held_codes = np.concatenate(held_codes)
+        self.last_intake = {"own_pairs": n_own, "held_pairs": int(held_codes.shape[0]), "batch_pairs": int(header[:, 1:].sum()),
+                            "bytes": int(own_off.nbytes + own_codes.nbytes + got.nbytes)}
+        if held_codes.shape[0]:
+            ordinals = np.ascontiguousarray(routing["ordinal_c"][held_codes], dtype=np.int32)
+            scores = np.ascontiguousarray(self._score_held(query_vectors, local_off, ordinals), dtype=np.float32)
         else:
-            r = native.route(pair_off, local_ids, self.comm.rank, self.comm.world, holder=holder)
-            mine = self.comm.exchange_host(streamed, r["send_counts"], r["recv_counts"])[r["recv_slot"]]
-            n_own = r["own_pairs"]
-        mine = np.ascontiguousarray(mine[:n_own], dtype=np.float32)
-        sizes = self.comm.allgather_array(np.array([n_own], dtype=np.int64))[:, 0]
-        pad = np.zeros(max(1, int(sizes.max())), dtype=np.float32)
-        pad[:n_own] = mine
-        blocks = self.comm.allgather_array(pad)
-        return np.concatenate([blocks[r, :int(sizes[r])] for r in range(self.comm.world)])
+            scores = np.zeros(0, dtype=np.float32)
+        back = comm.exchange_host(scores, held_from, counts)  # owner r's candidates stand together (its queries do), in its order
+        dense = np.empty(n_own, dtype=np.float32)
+        dense[by_holder] = back
+        return dense
 
     def _early_stopping(self, ranking, cutoff: int, alpha: float, depths, gather: bool):
-        """``Index._early_stopping`` (base.py:316-387) over the shards: the reference's loop over depth intervals, as
-        stated in ``Index._early_stopping_kept``, where scoring an interval is one sharded step whose dense scores every
-        rank receives -- so every rank takes the same decisions on the same numbers and no further message is needed.
-        Returns the ranking of the candidates that were scored (of all queries on every rank; ``gather=False`` keeps this
-        rank's owned queries)."""
+        """``Index._early_stopping`` (base.py:316-387) over the shards.  The reference's decisions are per query, so every
+        rank runs the loop over depth intervals (``Index._early_stopping_kept``) for the queries it OWNS, and scoring an
+        interval is one owner-routed step (``_owner_routed_dense``): a rank takes in its block and what it holds of the
+        others', never the batch.  Every rank joins the same number of steps -- one per depth at or beyond the cutoff; a
+        rank whose queries are done joins the rest with empty lists -- and an unknown id that one owner's loop reaches is
+        raised on every rank at that step.  Returns the ranking of the candidates that were scored: of this rank's owned
+        queries, or (``gather``) of all queries on every rank."""
         from fast_forward_amd import native
         from fast_forward_amd.index.api import Index, _Run
 
         run = _Run(self.local, ranking)
         off = run.pair_off
-        holder, local_ids = self._holders(ranking, run.perm, missing_ok=True)
-        sparse, codes_g = run.grouped(ranking._scores()), run.grouped(run.codes)
-        me = self
+        routing = self._code_routing(ranking)
+        world, me = self.comm.world, self.comm.rank
+        qb = native.query_partition(run.n_q, world)
+        q_lo, q_hi = int(qb[me]), int(qb[me + 1])
+        lo, hi = int(off[q_lo]), int(off[q_hi])
+        rows_of_block = slice(lo, hi) if run.perm is None else run.perm[lo:hi]
+        own_codes = np.ascontiguousarray(run.codes[rows_of_block], dtype=np.int32)
+        own_sparse = np.ascontiguousarray(ranking._scores()[rows_of_block])
+        own_off = off[q_lo:q_hi + 1] - lo
+        steps = sum(1 for b in depths if b >= cutoff)  # the most intervals any rank's loop can score
+        taken = [0]
+        outer = self
 
         class Scored:  # what Index._early_stopping_kept needs of an index
             mode = self.local.mode
 
             def _es_bound_f32(self):
-                return me.local._es_bound_f32()
+                return outer.local._es_bound_f32()
 
             def _score_pairs(self, query_vectors, part_off, positions, mode):
-                return me._dense_everywhere(query_vectors, part_off, holder[positions], local_ids[positions]), None, None
+                taken[0] += 1
+                return outer._owner_routed_dense(run.query_vectors, qb, part_off, own_codes[positions], routing), None, None
 
-        positions = np.where(holder >= 0, np.arange(holder.shape[0], dtype=np.int64), -1)  # -1: no rank holds the id (an error if reached)
-        rows, scores = Index._early_stopping_kept(Scored(), lambda p: run.names[codes_g[p]], sparse, off, run.query_vectors, cutoff, alpha, depths, positions)
+        known = routing["holder_c"][own_codes] >= 0 if hi > lo else np.zeros(0, dtype=bool)
+        positions = np.where(known, np.arange(hi - lo, dtype=np.int64), -1)  # -1: no rank holds the id (an error if reached)
+        failure, rows, scores = None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float32)
+        try:
+            rows, scores = Index._early_stopping_kept(Scored(), lambda p: run.names[own_codes[p]], own_sparse, own_off, run.query_vectors[q_lo:q_hi], cutoff,
+                                                      alpha, depths, positions)
+        except IndexError as e:
+            if taken[0] >= steps or "not found in the index" not in str(e):
+                raise
+            failure = str(e)  # reached here, between two steps: the next step tells every rank
+        empty_off = np.zeros(q_hi - q_lo + 1, dtype=np.int64)
+        while taken[0] < steps:  # this rank's queries are done (or it has something to say): the others' steps still need it
+            taken[0] += 1
+            self._owner_routed_dense(run.query_vectors, qb, empty_off, np.zeros(0, dtype=np.int32), routing, error=failure)
         rows, scores = rows.astype(np.int32), np.ascontiguousarray(scores, dtype=np.float32)
-        kept_off = np.searchsorted(rows, off).astype(np.int64)
+        kept_off = np.searchsorted(rows, own_off).astype(np.int64)
         order = native.host_order(scores, kept_off)
-        out = run.result("fast-forward", native.take32(rows, order), native.take32(scores, order), kept_off)[0]
-        if gather:
-            return out
-        q_lo, q_hi = native.query_partition(off.shape[0] - 1, self.comm.world)[self.comm.rank:self.comm.rank + 2]
-        lo, hi = int(kept_off[q_lo]), int(kept_off[q_hi])
-        return run.result("fast-forward", native.take32(rows, order)[lo:hi], native.take32(scores, order)[lo:hi], kept_off[q_lo:q_hi + 1] - lo, q_range=(int(q_lo), int(q_hi)))[0]
+        kept, kept_scores = native.take32(rows, order) + np.int32(lo), native.take32(scores, order)
+        if not gather:
+            return run.result("fast-forward", kept, kept_scores, kept_off, q_range=(q_lo, q_hi))[0]
+        # every rank's block, in rank order = query order (queries are owned in contiguous blocks)
+        sizes = self.comm.allgather_array(np.array([kept.shape[0]], dtype=np.int64))[:, 0]
+        most_q = int(np.diff(qb).max())
+        counts_all = self.comm.allgather_array(np.pad(np.diff(kept_off), (0, most_q - (q_hi - q_lo))).astype(np.int64))
+        room = max(1, int(sizes.max()))
+        pad_k, pad_s = np.zeros(room, dtype=np.int32), np.zeros(room, dtype=np.float32)
+        pad_k[:kept.shape[0]], pad_s[:kept.shape[0]] = kept, kept_scores
+        all_k, all_s = self.comm.allgather_array(pad_k), self.comm.allgather_array(pad_s)
+        full_k = np.concatenate([all_k[r, :int(sizes[r])] for r in range(world)])
+        full_s = np.concatenate([all_s[r, :int(sizes[r])] for r in range(world)])
+        full_off = np.zeros(run.n_q + 1, dtype=np.int64)
+        np.cumsum(np.concatenate([counts_all[r, :int(qb[r + 1] - qb[r])] for r in range(world)]), out=full_off[1:])
+        return run.result("fast-forward", full_k, full_s, full_off)[0]
 
     def __call__(self, ranking, early_stopping: int | None = None, early_stopping_alpha: float | None = None,
                  early_stopping_depths=None, batch_size: int | None = None, gather: bool = False):
@@ -841,19 +905,13 @@ class ShardedOnDiskIndex(_ShardedIndex):
     def _streams_rows(self) -> bool:
         return not self.resident
 
-    def _local_scores(self, query_vectors, pair_off, holder, local_ids, mode):
-        if self.resident:
-            return None
-        mine = np.flatnonzero(holder == self.rank)
-        n_q = pair_off.shape[0] - 1
-        pair_q = np.repeat(np.arange(n_q, dtype=np.int64), np.diff(pair_off))
-        local_off = np.zeros(n_q + 1, dtype=np.int64)
-        np.cumsum(np.bincount(pair_q[mine], minlength=n_q), out=local_off[1:])
-        if mine.size == 0:
-            return np.zeros(0, dtype=np.float32)
-        # the shard view numbers its documents / passages itself: the 1-GPU streaming path takes it from there
-        ff, _, _ = self.local._score_pairs(query_vectors, local_off, np.ascontiguousarray(local_ids[mine], dtype=np.int32), self.local.mode)
-        return ff
+    def _score_held(self, query_vectors, local_off, ordinals) -> np.ndarray:
+        if not self.resident:  # the shard view numbers its documents / passages itself: the 1-GPU streaming path takes it from there
+            return self.local._score_pairs(query_vectors, local_off, ordinals, self.local.mode)[0]
+        from fast_forward_amd import native
+
+        return native.score(self._store, self._scorer_queries(query_vectors), local_off, ordinals, self.local.mode.value, None, 0.0,
+                            exact_sum=self.exact_sum)[0]
 
     def close(self) -> None:
         if self._scorer is not None:

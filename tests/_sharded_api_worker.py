@@ -71,6 +71,11 @@ for mode in ("MAXP", "PASSAGE", "AVEP"):
         assert idx(first, early_stopping=cutoff, early_stopping_alpha=es_alpha, early_stopping_depths=depths, gather=True) == want
         mine = idx(first, early_stopping=cutoff, early_stopping_alpha=es_alpha, early_stopping_depths=depths)
         assert 0 < len(mine.q_ids) < len(want.q_ids) and all(mine[q] == want[q] for q in mine.q_ids)
+        # every depth interval was an owner-routed step: the rank took in candidates of the queries it owns and what it holds of
+        # the others' (the last step's figures: at most its share of the batch, never the batch)
+        it = idx.last_intake
+        assert it["own_pairs"] <= n_own_p and it["held_pairs"] < len(names) and it["batch_pairs"] <= len(names), it
+        assert it["bytes"] == (n_own_q + 1) * 8 + it["own_pairs"] * 4 + (len(case.q_names) + it["held_pairs"]) * 4, it
     tail = Ranking.from_run({"q000": {names[0]: 9.0, names[1]: 8.0, "missing-id": 0.5}}, queries={"q000": "0"})
     assert idx(tail, early_stopping=1, early_stopping_alpha=1.0, early_stopping_depths=(2, 3), gather=True) == \
         one(tail, early_stopping=1, early_stopping_alpha=1.0, early_stopping_depths=(2, 3))

@@ -51,6 +51,17 @@ for resident in (True, False):
         for q in own.q_ids:
             assert own[q] == want[q]
             checked += len(own[q])
+        if not resident:
+            # a streamed shard is owner-routed too: what the rank took in is ITS block of the batch (the candidates of the
+            # queries it owns, as id codes) and what the owners sent it (per-query counts + the codes of what it holds),
+            # never the batch -- per-rank intake ~ 2 / world of it
+            it, routing = sharded.last_intake, sharded._code_routing(first)
+            own_pairs = sum(len(own[q]) for q in own.q_ids)
+            held_pairs = int((routing["holder_c"][routing["codes"]] == rank).sum())
+            batch_pairs = sum(len(v) for v in run.values())
+            assert it == {"own_pairs": own_pairs, "held_pairs": held_pairs, "batch_pairs": batch_pairs,
+                          "bytes": (len(own.q_ids) + 1) * 8 + own_pairs * 4 + (5 + held_pairs) * 4}, (it, own_pairs, held_pairs)
+            assert own_pairs < batch_pairs and held_pairs < batch_pairs
     sharded.mode = mem.mode = Mode.PASSAGE
     assert sharded(first_psg, gather=True) == mem(first_psg), (resident, "PASSAGE")
     assert sharded.rerank(first_psg, 0.7, gather=True) == mem.rerank(first_psg, 0.7)

@@ -396,6 +396,71 @@ def test_many_passages_per_document():
 
 
 @pytest.mark.parametrize("store", [np.float32, np.float16])
+@pytest.mark.parametrize("d", [768, 1024])
+@pytest.mark.parametrize("contiguous", [True, False])
+def test_rows_derived_inside_gather_dot_for_documents_of_several_passages(monkeypatch, d, store, contiguous):
+    """MAXP / AVEP over documents of 1 - 9 (one of 70) passages at d = 768 / 1024: no row list is written -- the waves of
+    gather_dot work the rows of their tile out of the candidate lists, the row offsets and two small tables (kernel variants
+    311 / 312, +1000 for half rows; get_indices, index/util.py:29-41 + the merge of index/base.py:296-298).  Same bits as the
+    oracle and as the row-list form (FFX_DEBUG_VARIANT=no_derive -> variants 111 / 112) -- documents whose rows are scattered
+    over the index or contiguous, queries without candidates at the start, in the middle and at the end, lists of one candidate,
+    a last tile that is not full; a plan that is run again, and with other candidate lists."""
+    rng = np.random.default_rng(d + (1 if contiguous else 0))
+    n_docs = 600
+    per_doc = rng.integers(1, 10, size=n_docs)
+    per_doc[11] = 70
+    n = int(per_doc.sum())
+    doc_of_row = np.repeat(np.arange(n_docs), per_doc)
+    if not contiguous:
+        doc_of_row = rng.permutation(doc_of_row)
+    doc_rows = np.argsort(doc_of_row, kind="stable").astype(np.int32)
+    doc_off = np.concatenate([[0], np.cumsum(np.bincount(doc_of_row, minlength=n_docs))])
+    vectors = synth.rows(5, 0.05, 0, n, d).astype(store)
+    as_f32 = vectors.astype(np.float32)
+    lens = [0, 200, 1, 0, 0, 333, 57, 600, 0]
+    queries = synth.rows(6, 0.05, 0, len(lens), d)
+    idx = native.DeviceIndex(n, d, dtype=store)
+    idx.upload(vectors, 0)
+    idx.set_doc_rows(doc_off, doc_rows)
+    idx.set_psg_rows(np.arange(n))
+    plan = native.Plan(idx)
+    plan.set_queries(queries)
+    half = 1000 if store == np.float16 else 0
+    for trial in range(2):
+        pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pair_ids = np.concatenate([rng.choice(n_docs, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+        sparse = rng.random(len(pair_ids), dtype=np.float32) * 10
+        for mode in (2, 4):
+            want, want_i = fo.score(as_f32, doc_off, doc_rows, np.arange(n), queries, pair_off, pair_ids, mode, sparse, 0.3)
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+            plan.set_pairs(pair_off, pair_ids, sparse, mode)
+            for _ in range(2):  # (the second run starts from the tables the first one made)
+                plan.run(0.3, exact_sum=True, sort=True)
+                ff, interp, order = plan.fetch(interp=True, order=True)
+                assert plan.stats()["kernel_variant"] == (311 if d == 768 else 312) + half
+                assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i)), (mode, trial)
+                assert np.array_equal(order.astype(np.int64), fo.order(want_i, pair_off))
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_derive")
+            plan.run(0.3, exact_sum=True, sort=True)
+            ff2, interp2, _ = plan.fetch(interp=True)
+            assert plan.stats()["kernel_variant"] == (111 if d == 768 else 112) + half
+            assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp))
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+            # the fast summation order has no row-deriving kernel: the row list is made when such a run asks for it
+            plan.run(0.3, exact_sum=False)
+            ff3, _, _ = plan.fetch()
+            assert np.abs(ff3 - want).max() <= FAST_TOL * 10
+            # ... and through ffx_score, slices of whole queries
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_small_path,score_slice_pairs=250")
+            ff4, interp4, order4, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.3, sort=True)
+            assert st["kernel_variant"] == (311 if d == 768 else 312) + half
+            assert np.array_equal(bits(ff4), bits(want)) and np.array_equal(bits(interp4), bits(want_i)) and np.array_equal(order4, order)
+        lens = lens[::-1]
+    plan.close()
+    idx.close()
+
+
+@pytest.mark.parametrize("store", [np.float32, np.float16])
 @pytest.mark.parametrize("d", [64, 128, 256, 384, 512, 768, 1024, 8, 24, 1000, 4100,
                                1536, 2048, 3072, 4096, 6144, 8192])  # second line: S x (768 | 1024), scored as S short rows
 def test_every_kernel_variant_exact(d, store):
@@ -569,8 +634,11 @@ def test_sharded_scorer_single_rank_nccl():
     assert "sharded 1-rank ok" in out.stdout
 
 
+# (world 5: the most ranks one GPU box lets share its card -- its process guard allows six processes on the GPU at a time, and
+# this pytest process is one of them; the eight-rank rendezvous, piece tables and owner routing run without a device in
+# tests/test_sharded_native.py)
 @pytest.mark.parametrize("world,sharding,spelling", [(2, "rows", "--transport host"), (3, "rows", "--transport host"), (2, "queries", "--transport host"),
-                                                     (2, "rows", "--dist-backend gloo")])
+                                                     (2, "rows", "--dist-backend gloo"), (5, "rows", "--transport host")])
 def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding, spelling):
     """`python bench.py --gpus N` exactly as the driver starts it (no outer launcher: bench.py starts
     its own ranks): rows sharded by document, two plans alternating between a compute and a
@@ -724,7 +792,7 @@ def test_device_routing_equals_host_routing(monkeypatch):
     shard.close()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
 def test_owner_routed_fresh_batches_with_ranks_sharing_the_gpu(world):
     """ffx_sharded_stage_owned / ffx_sharded_score: every rank is handed only the queries it owns, finds the holders on the
     device and sends them the ordinals in a first all-to-all; results equal the single-GPU scorer over the whole index bit for

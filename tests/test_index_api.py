@@ -568,9 +568,9 @@ def test_pyterrier_transformers():
     assert "FFScore(" in repr(FFScore(idx))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_sharded_index_api_matches_reference_frames(world):
-    """ShardedInMemoryIndex with 2 and 3 ranks (sharing this GPU, exchange through libffx's
+    """ShardedInMemoryIndex with 2, 3 and 5 ranks (sharing this GPU; five is what the box's process guard leaves room for, exchange through libffx's
     shared-memory transport): gathered dense frames and per-owner interpolated frames equal the
     reference's."""
     from pathlib import Path
