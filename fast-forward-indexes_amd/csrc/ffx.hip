@@ -1526,6 +1526,13 @@ static ffx::Derive plan_derive(const ffx_plan* pl) {
   return dv;
 }
 
+// rows per tile of the row-deriving kernels (TL of launch_gather_dot_t; the tile table is made for it)
+static int derive_tile(const ffx_plan* pl) {
+  long long v = 0;
+  if (ffx_experiment("derive_tile", &v) && (v == 8 || v == 16 || v == 32)) return (int)v;
+  return pl->idx->dtype == FFX_DTYPE_F16 ? 16 : 8;
+}
+
 // rows of this storage type and length, in this mode, have a row-deriving kernel (exact summation only)
 static bool derive_applies(const ffx_plan* pl) {
   const ffx_index* ix = pl->idx;
@@ -1645,9 +1652,18 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   if (exact) {
     switch (d) {
       case 768:
-        if (pl->use_derive)  // no row list: the waves work their rows out of the candidate lists (311 / 1311)
+        if (pl->use_derive) {  // no row list: the waves work their rows out of the candidate lists (311 / 1311)
+#ifdef FFX_EXPERIMENTS
+          if (derive_tile(pl) == 16 && TL != 16) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 16, true, true><<<blocks_for(R, 4 * 16), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (derive_tile(pl) == 32) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 32, true, true><<<blocks_for(R, 4 * 32), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (derive_tile(pl) == 8 && TL != 8) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 8, true, true><<<blocks_for(R, 4 * 8), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else
+#endif
           ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
-        else
+        } else
           ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
         pl->variant = (pl->use_derive ? 311 : 111) + HALF;
         break;
@@ -2073,7 +2089,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
       // still there) and two small tables made on the first run of a candidate list (4 B per candidate, 8 B per tile)
       pl->use_derive = true;
       if (!pl->derive_valid) {
-        const int tile = ix->dtype == FFX_DTYPE_F16 ? 16 : 8;  // (TL of launch_gather_dot_t)
+        const int tile = derive_tile(pl);
         FFX_TRY(launch_count_scan(pl));
         FFX_TRY(pl->pair_first.ensure((size_t)P * sizeof(int32_t)));
         FFX_TRY(pl->tile_tab.ensure(((size_t)R / tile + 2) * sizeof(int2)));
