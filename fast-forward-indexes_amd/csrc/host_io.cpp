@@ -188,6 +188,7 @@ int ffx_ids_intern_packed(ffx_ids* t, const char* data, int64_t n_bytes, char se
   if (seps != n - 1) return ffx_fail(FFX_BAD_ARG, "the buffer does not hold exactly %lld separated strings", (long long)n);
   if (t->size() + n >= INT32_MAX - 1) return ffx_fail(FFX_BAD_ARG, "too many distinct ids for int32 ordinals");
   try {
+    t->expect(n, n_bytes);
     const char* p = data;
     const char* end = data + n_bytes;
     for (int64_t i = 0; i < n; ++i) {
