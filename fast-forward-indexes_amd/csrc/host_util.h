@@ -18,11 +18,6 @@
 #include <thread>
 #include <vector>
 
-#include <sys/mman.h>
-
-#include <cstdlib>
-#include <new>
-
 #include "../../include/ffx.h"
 #include "../../include/ffx_private.h"
 
@@ -158,39 +153,10 @@ struct StageClock {
 // insertion-ordered interning table: ordinal = order of first insertion.  Open addressing; a slot holds the ordinal + 1
 // (0: empty) under the upper half of the string's hash, so that a probe that meets another string's slot goes on without
 // touching that string.
-// Storage of the large tables below (hundreds of MB looked up at random: a hash slot, an offset pair, the bytes of a string --
-// three dependent misses per look-up): allocations of 4 MiB or more are 2 MiB-aligned and marked for transparent huge pages
-// (where the system grants them on madvise), so that a look-up misses the cache three times but not the TLB three times as
-// well -- a page walk over 4 KB pages of a 250 MB table is itself two or three memory accesses.
-template <class T>
-struct HugeAlloc {
-  using value_type = T;
-  HugeAlloc() = default;
-  template <class U>
-  HugeAlloc(const HugeAlloc<U>&) {}
-  T* allocate(size_t n) {
-    const size_t bytes = n * sizeof(T), two = size_t(2) << 20;
-    void* p = nullptr;
-    if (bytes >= 2 * two) {
-      const size_t room = (bytes + two - 1) / two * two;
-      if (posix_memalign(&p, two, room) != 0) throw std::bad_alloc();
-      (void)madvise(p, room, MADV_HUGEPAGE);
-    } else if (!(p = malloc(bytes ? bytes : 1))) {
-      throw std::bad_alloc();
-    }
-    return static_cast<T*>(p);
-  }
-  void deallocate(T* p, size_t) { free(p); }
-  template <class U>
-  bool operator==(const HugeAlloc<U>&) const { return true; }
-  template <class U>
-  bool operator!=(const HugeAlloc<U>&) const { return false; }
-};
-
 struct ffx_ids {
-  std::vector<char, HugeAlloc<char>> arena;
-  std::vector<uint64_t, HugeAlloc<uint64_t>> off;   // off[i]..off[i+1] = bytes of string i
-  std::vector<uint64_t, HugeAlloc<uint64_t>> slots;  // (hash >> 32) << 32 | ordinal + 1
+  std::vector<char> arena;
+  std::vector<uint64_t> off;   // off[i]..off[i+1] = bytes of string i
+  std::vector<uint64_t> slots;  // (hash >> 32) << 32 | ordinal + 1  (huge pages for these arrays: tried twice on the box's host, no gain)
   size_t mask = 0;
 
   ffx_ids() { off.push_back(0); rehash(1024); }
