@@ -1250,7 +1250,7 @@ def bench_single(args):
         "dtype": compute_dtype(args), "data": "synthetic",
         "value_region": "(i): inputs and outputs resident in HBM when the timed region starts, per-query ordering included.  The round brief's measurement "
                         "section fixes this (\"`value` is whole-job throughput with inputs already resident in HBM when the timed region starts (if the boundary "
-                        "hands over host buffers, note the PCIe-inclusive rate in DESIGN.md -- it is never `value`)\": quoted in DESIGN.md section 8); SURVEY 8(d) "
+                        "hands over host buffers, note the PCIe-inclusive rate in DESIGN.md -- it is never `value`)\": quoted in DESIGN.md section 7); SURVEY 8(d) "
                         "names region (ii), host buffers -> host buffers through ffx_score, as its headline: that rate is `value_host_to_host` right below, "
                         "and (iii), through Index.rerank / Index.__call__ + Ranking.interpolate, is in `regions`",
         "config": {

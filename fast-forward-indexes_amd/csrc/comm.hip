@@ -2124,7 +2124,7 @@ static int sharded_merge_pending(ffx_sharded* s) {
   ffx_sharded::Slot& sl = s->slot[i];
   hipStream_t ms = s->compute;
   // a small merge hides inside the next gather_dot; a large one (tens of millions of candidates: one or two ranks) takes
-  // slots from it for its whole length and is better paid for once, in line (measured: DESIGN.md section 7)
+  // slots from it for its whole length and is better paid for once, in line (measured: HISTORY.md section 7)
   const bool small = sl.own[3] <= (int64_t)(6 << 20);  // (4.4 M owned candidates: hidden, 2.26 -> 2.12 ms; 8.7 M: the fresh step loses 5 %; 34.9 M: 7 %)
   if (ffx_experiment("merge_on_results", nullptr) || (small && !ffx_experiment("merge_on_compute", nullptr))) {
     C_TRY(sharded_io_streams(s));

@@ -52,7 +52,7 @@ static bool ffx_trace_host() {
 
 // FFX_ABORT_BACKTRACE=1 (a diagnostic, off by default): when something below this library -- the HIP runtime, the driver's
 // user-mode part -- ends the process with abort(), the native call stack of the aborting thread goes to stderr first (Python's
-// faulthandler shows the Python frames only).  For the rare SIGABRT inside hipMemcpy of DESIGN.md section 10 / tools/abort_hunt.sh.
+// faulthandler shows the Python frames only).  For the rare SIGABRT inside hipMemcpy of HISTORY.md section 10 / tools/abort_hunt.sh.
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
@@ -1541,7 +1541,7 @@ static bool derive_applies(const ffx_plan* pl) {
 }
 
 // pick and launch the gather_dot instantiation for rows of type T (float / _Float16); the
-// variant id lands in ffx_stats.kernel_variant (+1000 for half rows; DESIGN.md table)
+// variant id lands in ffx_stats.kernel_variant (+1000 for half rows; DESIGN.md section 5)
 template <typename T>
 static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   const ffx_index* ix = pl->idx;
@@ -3008,7 +3008,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
     if (rc_small != FFX_OK || handled) return rc_small;
   }
   // slices cut at query boundaries: ~4M pairs (a ~2 ms device pass at 768-d fp32) when the caller's
-  // buffers are page-locked, ~6M when they are ordinary memory (measured: tools/score_trace.py)
+  // buffers are page-locked, ~6M when they are ordinary memory (measured: tools/score_trace.py, HISTORY.md section 8; ordinary buffers: MEASUREMENTS.md section 2)
   int64_t per_slice = 6 << 20;
   {
     hipPointerAttribute_t attr;

@@ -24,7 +24,7 @@
 //   fast   coalesced loads, FMA chain, butterfly.  |error| ~ d * 2^-24 * |q||v|.
 //
 // Roofline: HBM.  Per row the kernel must move d*sizeof(T) B of row data + 8 B of descriptor in
-// and 4 B out; 2*d flop.  <= 1 flop/B, so MFMA is irrelevant (DESIGN.md).
+// and 4 B out; 2*d flop.  <= 1 flop/B, so MFMA is irrelevant (DESIGN.md section 5).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -570,7 +570,7 @@ class OnDiskIndex(Index):
         n_rows_gathered = int(slot_row.shape[0])
         store_dtype = np.dtype(self._meta["dtype"])
         if host_decode or store_dtype not in (np.dtype(np.float16), np.dtype(np.uint8)):
-            store_dtype = np.dtype(np.float32)  # float64 files of the reference are scored in fp32 (DESIGN.md divergence 1)
+            store_dtype = np.dtype(np.float32)  # float64 files of the reference are scored in fp32 (divergences)
         store_dim = dim_q if host_decode else self._meta["dim"]
         per_window = max(1, self._window_bytes // max(1, store_dim * store_dtype.itemsize))
         n_win = -(-uniq.shape[0] // per_window)

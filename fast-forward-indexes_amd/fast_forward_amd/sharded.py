@@ -369,6 +369,10 @@ def _owner_of(doc_id: str | None, psg_id: str | None, world: int) -> int:
     return zlib.crc32(key.encode()) % world
 
 
+class _AgreedIndexError(IndexError):
+    """An ``IndexError`` every rank raises at the same collective step (one of them found the id missing and said so)."""
+
+
 class _ShardedIndex:
     """What the sharded index classes share: the ``Index`` surface over SPMD ranks.  Subclasses say
     who holds each candidate (``_code_routing``) and own the shard."""
@@ -588,7 +592,7 @@ class _ShardedIndex:
         header = comm.allgather_array(np.concatenate([[len(message)], counts]).astype(np.int64))  # (world, 1 + world)
         if header[:, 0].any():
             said = comm.allgather_bytes(message.ljust(400, b"\0"))
-            raise IndexError(next(m.rstrip(b"\0").decode(errors="replace") for m, n in zip(said, header[:, 0]) if n))
+            raise _AgreedIndexError(next(m.rstrip(b"\0").decode(errors="replace") for m, n in zip(said, header[:, 0]) if n))
         # to every holder: how many of each of my queries' candidates it holds, then their codes (in my candidate order)
         by_holder = np.argsort(holder, kind="stable")
         q_of = np.repeat(np.arange(n_own_q, dtype=np.int64), np.diff(own_off))
@@ -664,10 +668,12 @@ class _ShardedIndex:
         try:
             rows, scores = Index._early_stopping_kept(Scored(), lambda p: run.names[own_codes[p]], own_sparse, own_off, run.query_vectors[q_lo:q_hi], cutoff,
                                                       alpha, depths, positions)
+        except _AgreedIndexError:
+            raise  # (every rank is raising this at the same step)
         except IndexError as e:
-            if taken[0] >= steps or "not found in the index" not in str(e):
+            if taken[0] >= steps:
                 raise
-            failure = str(e)  # reached here, between two steps: the next step tells every rank
+            failure = str(e)  # reached HERE, between two steps: the next step tells every rank, and every rank raises there
         empty_off = np.zeros(q_hi - q_lo + 1, dtype=np.int64)
         while taken[0] < steps:  # this rank's queries are done (or it has something to say): the others' steps still need it
             taken[0] += 1

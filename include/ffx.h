@@ -98,7 +98,7 @@ typedef struct ffx_stats {
   float ms_reduce;           /* segment max/first/mean + interpolation                        */
   float ms_sort;             /* per-query ordering (0 unless FFX_FLAG_SORT)                   */
   float ms_total;            /* first launch to last completion of ffx_plan_run               */
-  int32_t kernel_variant;    /* which gather_dot instantiation ran            */
+  int32_t kernel_variant;    /* which gather_dot instantiation ran      */
   int32_t reserved;
 } ffx_stats;
 
@@ -321,7 +321,7 @@ int ffx_sharded_set_code_table(ffx_sharded* s, const int32_t* ordinal_of_code, i
  * rank uploads Q * dim * 4 bytes over its own link; nothing is exchanged), then ffx_sharded_stage_owned with own_queries =
  * NULL.  Asynchronous (the vectors must stay put until the stage call returns).  Which of the two is cheaper depends on the
  * node: the all-gather keeps the intake per rank proportional to its block but runs as a copy kernel beside gather_dot,
- * the replicated upload costs PCIe time only (DESIGN.md section 7 has both measured). */
+ * the replicated upload costs PCIe time only (MEASUREMENTS.md section 4 has both measured). */
 int ffx_sharded_stage_queries(ffx_sharded* s, const float* all_queries, int64_t n_queries);
 int ffx_sharded_run(ffx_sharded* s, double alpha, uint32_t flags); /* asynchronous */
 /* the results of the batch merged last -- after ffx_sharded_run that is the batch BEFORE the one it ran -- copied out on a

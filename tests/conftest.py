@@ -15,7 +15,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # if anything below libffx ends the process with abort(), the log should show the NATIVE call stack of the aborting thread, not
 # only Python's (libffx installs the handler when it is loaded).  That -- with pytest.ini's Python-level capture, which lets the
 # runtime's own last words through -- is how the rare abort of rounds 3 - 4 was traced to the HIP runtime's on-the-fly
-# page-locking of heap memory; libffx keeps heap memory off that path since, and the handler stays armed
+# page-locking of heap memory (HISTORY.md section 10); libffx hands the runtime no ordinary memory since (csrc/host_xfer.h), and the handler stays armed
 os.environ.setdefault("FFX_ABORT_BACKTRACE", "1")
 
 
@@ -70,7 +70,7 @@ def _release_device_objects_between_tests(request):
     whenever the interpreter gets to it in the middle of a later test: the device-side resources of ~200 tests (streams,
     events, page-locked blocks) then never pile up, and what a test sees does not depend on the garbage of its
     predecessors.  (Not what the rare SIGABRT of rounds 3 - 4 was about -- that was the runtime page-locking heap memory on the
-    fly, DESIGN.md section 10 -- but a suite whose tests do not see each other's leftovers is worth having anyway.)"""
+    fly, HISTORY.md section 10 -- but a suite whose tests do not see each other's leftovers is worth having anyway.)"""
     yield
     if "gpu" in request.keywords and not os.environ.get("FFX_TEST_KEEP_GARBAGE"):  # (tools/abort_hunt.sh runs the suite without this)
         import gc

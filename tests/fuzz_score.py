@@ -5,7 +5,7 @@ row lengths and stores, random slice sizes of ffx_score, sort on and off.  Not c
 seed of any failure.  Last runs of round 1: 300 + 1000 configurations (seeds 0 and 1), all bit-exact;
 round 2 (any-d kernel, in-LDS sort): 600 + 600 configurations (seeds 2 and 3), all bit-exact; round 2 later
 (ffx_score's single-submission path for small single-row batches; slices through three plans with asynchronous
-copies into page-locked results or helper threads into ordinary ones): seeds 4 and 5; round 3 (segments
+copies into page-locked results or helper threads into ordinary ones): seeds 4 and 5, see HISTORY.md; round 3 (segments
 for long rows, uploads of all slices on one stream): 600 + 600 configurations (seeds 8 and 9), all bit-exact."""
 import argparse
 import os

@@ -41,6 +41,18 @@ def test_sharded_path_over_native_host_transport(world):
     assert "checked bit-exact" in outs[0][0]
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_owner_routed_host_path_and_sharded_early_stopping_without_a_gpu(world):
+    """``sharded._owner_routed_dense`` (streamed shards, the steps of early stopping) and ``_ShardedIndex._early_stopping`` with 2, 3
+    and EIGHT ranks over the shared-memory transport, the CPU oracle standing in for each rank's device
+    (tests/_owner_routed_cpu_worker.py): every rank's block of dense scores bit-equal to the one-process index's, per-rank intake =
+    its own block + what it holds, early stopping equal to the one-process loop for four (cutoff, depths) settings in three modes, and
+    an id nobody holds raised on every rank at the same collective step whichever rank's loop reaches it."""
+    codes, outs = run_ranks(world, ROOT / "tests" / "_owner_routed_cpu_worker.py", timeout=600)
+    assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    assert f"world={world}:" in outs[0][0] and "checked bit-exact" in outs[0][0]
+
+
 def test_ranks_started_by_torchrun_find_each_other():
     """The other way N ranks get started (`python -m torch.distributed.run ...`): no FFX_RDZV_KEY; the ranks
     derive the job's name from the launcher's port, run id and their common parent process."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""cProfile of Index.__call__ / rerank on a pandas Ranking (region iii of DESIGN.md section 8)."""
+"""cProfile of Index.__call__ / rerank on a pandas Ranking (region iii: DESIGN.md section 7)."""
 import cProfile
 import pstats
 import sys
