@@ -462,15 +462,11 @@ class Index(abc.ABC):
         out, src = run.result("fast-forward", kept, scores, kept_off)
         LOGGER.info("computed scores in %s seconds", perf_counter() - t0)
         if early_stopping is None:
-            # row i of the result is row src[i] of `ranking`: ranking.interpolate(result, alpha) needs no join.  When `src`
-            # still looks into the index's re-used result block, the result borrows it until the index needs the block
-            # again (InMemoryIndex._result_buffers then gives it its own copy): the interpolate that usually follows at once
-            # reads it in place
-            borrowed = src.base is not None and getattr(self, "_result_buffers", None) is not None and src is kept
-            out._source_rows = (weakref.ref(ranking), src if (borrowed or src.base is None) else np.array(src, dtype=np.int32))
-            if borrowed:
-                self._order_borrower = weakref.ref(out)
-            out._origin = (weakref.ref(self), self.mode, getattr(getattr(self, "_ids", None), "version", None))
+            # row i of the result is row src[i] of `ranking`: ranking.interpolate(result, alpha) needs no join.  The result owns
+            # that array (a view into the index's re-used result block is copied: round 4 let the result borrow the block
+            # until the index needed it again -- one more piece of state between two objects for 4 bytes per row saved on a
+            # route that large runs do not take: from 256 K candidates on the device applies the ordering, above)
+            out._source_rows = (weakref.ref(ranking), src if src.base is None else np.array(src, dtype=np.int32))
         return out
 
     _RANKED_FROM = 1 << 18  # candidates from which the device applies the ordering itself (ffx_score_ranked)

@@ -209,13 +209,6 @@ class InMemoryIndex(Index):
         Only the ``wanted`` ones are made (page-locking 157 MB takes ~40 ms); the others come back as None.
         Only for callers that consume the results before the next call (the coded paths of ``__call__`` /
         ``rerank`` gather out of them at once)."""
-        # a ranking handed out by the previous call may still look into the block (Index.__call__ leaves the device's
-        # order there for the interpolate that usually follows at once): give it its own copy before the block is re-used
-        holder = getattr(self, "_order_borrower", None)
-        holder = holder() if holder is not None else None
-        if holder is not None and getattr(holder, "_source_rows", None) is not None and holder._source_rows[1].base is not None:
-            holder._source_rows = (holder._source_rows[0], holder._source_rows[1].copy())
-        self._order_borrower = None
         have = getattr(self, "_out_cache", None)
         if have is None:
             have = self._out_cache = [None, None, None]

@@ -1401,6 +1401,13 @@ def test_ordinary_memory_travels_through_the_librarys_own_blocks(monkeypatch):
     back = idx.gather(np.arange(n_docs)) if hasattr(idx, "gather") else None
     if back is not None:
         assert np.array_equal(back, vectors)
+    # sizes around the 4 MiB pieces: a last piece of a few bytes, an odd number of pieces on one thread, pieces dealt to two threads
+    for n_rows in (1366, 1367, 2733, 5500):
+        rows = synth.rows(40 + n_rows, 0.05, 0, n_rows, d)
+        odd = native.DeviceIndex(n_rows, d)
+        odd.upload(rows, 0)
+        assert np.array_equal(odd.gather(np.arange(n_rows)), rows), n_rows
+        odd.close()
     n_q, k = 40, 20_000  # 800 k candidates: 3.2 MB per array (nothing here takes the single-submission path)
     queries = synth.rows(32, 0.05, 0, n_q, d)
     pair_off = np.arange(n_q + 1, dtype=np.int64) * k
