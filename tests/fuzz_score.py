@@ -6,7 +6,8 @@ seed of any failure.  Last runs of round 1: 300 + 1000 configurations (seeds 0 a
 round 2 (any-d kernel, in-LDS sort): 600 + 600 configurations (seeds 2 and 3), all bit-exact; round 2 later
 (ffx_score's single-submission path for small single-row batches; slices through three plans with asynchronous
 copies into page-locked results or helper threads into ordinary ones): seeds 4 and 5, see HISTORY.md; round 3 (segments
-for long rows, uploads of all slices on one stream): 600 + 600 configurations (seeds 8 and 9), all bit-exact."""
+for long rows, uploads of all slices on one stream): 600 + 600 configurations (seeds 8 and 9), all bit-exact; round 5 (staged
+transfers of ordinary memory, four plans, rows derived inside gather_dot; one configuration in eight LARGE): seeds 10 and 11."""
 import argparse
 import os
 import sys
@@ -30,25 +31,29 @@ DIMS = [8, 24, 64, 100, 128, 256, 300, 384, 512, 768, 1024, 1536, 2048,
 for rnd in range(args.rounds):
     seed = args.seed * 100_000 + rnd
     rng = np.random.default_rng(seed)
-    d = int(rng.choice(DIMS))
+    # one configuration in eight is LARGE (round 5): candidate arrays of 1.5 - 5 MB in ordinary or page-locked memory, cut into
+    # several slices -- the staged transfers of csrc/host_xfer.h, the four rotating plans and the result arrays leaving in halves
+    large = rng.random() < 0.125
+    d = int(rng.choice([64, 128, 768, 1024] if large else DIMS))
     store = np.float16 if rng.random() < 0.3 else np.float32
-    n_docs = int(rng.integers(1, 400))
-    per_doc = rng.integers(1, 6, size=n_docs) if rng.random() < 0.7 else np.ones(n_docs, dtype=np.int64)  # single-row documents: the small path
+    n_docs = int(rng.integers(40_000, 80_000) if d > 128 else rng.integers(60_000, 120_000)) if large else int(rng.integers(1, 400))
+    per_doc = rng.integers(1, 3 if large else 6, size=n_docs) if rng.random() < 0.7 else np.ones(n_docs, dtype=np.int64)  # single-row documents: the small path
     doc_off = np.concatenate([[0], np.cumsum(per_doc)]).astype(np.int64)
     n = int(doc_off[-1])
     doc_rows = rng.permutation(n).astype(np.int32)
     psg_row = rng.permutation(n).astype(np.int32)
     vectors = synth.rows(seed, 0.2, 0, n, d).astype(store)
-    n_q = int(rng.integers(1, 12))
+    n_q = int(rng.integers(6, 14)) if large else int(rng.integers(1, 12))
     queries = synth.rows(seed + 1, 0.2, 0, n_q, d)
     mode = int(rng.integers(1, 5))
     pool = n if mode == 1 else n_docs
-    lens = [int(rng.integers(0, min(pool, 300 if rng.random() < 0.8 else 3000) + 1)) for _ in range(n_q)]
+    lens = ([int(rng.integers(pool // 2, pool + 1)) for _ in range(n_q)] if large else
+            [int(rng.integers(0, min(pool, 300 if rng.random() < 0.8 else 3000) + 1)) for _ in range(n_q)])
     pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     pair_ids = np.concatenate([rng.choice(pool, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
     sparse = (rng.integers(0, 5, size=len(pair_ids)) if rng.random() < 0.5 else rng.random(len(pair_ids)) * 10).astype(np.float32)
     alpha = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
-    variant = [f"score_slice_pairs={int(rng.choice([1, 7, 100, 10**9]))}"]
+    variant = [f"score_slice_pairs={int(rng.choice([70_000, 300_000, 10**9] if large else [1, 7, 100, 10**9]))}"]
     if rng.random() < 0.5:
         variant.append("no_small_path")
     os.environ["FFX_DEBUG_VARIANT"] = ",".join(variant)
