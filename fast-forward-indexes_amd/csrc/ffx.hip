@@ -1205,8 +1205,16 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   pl->hstage_used = 0;
   FFX_TRY(plan_h2d(pl, pl->pair_off.p, pair_off, (size_t)(n_queries + 1) * sizeof(int64_t)));
   if (P > 0) {
-    FFX_TRY(plan_h2d(pl, pl->pair_ids.p, pair_ids, (size_t)P * sizeof(int32_t)));
-    if (sparse) FFX_TRY(plan_h2d(pl, pl->sparse.p, sparse, (size_t)P * sizeof(float)));
+    const size_t pbytes = (size_t)P * sizeof(int32_t);
+    if (sparse && pbytes > (1u << 20)) {  // both arrays above the small-copy block: staged together (one round of threads)
+      void* dsts[2] = {pl->pair_ids.p, pl->sparse.p};
+      const void* srcs[2] = {pair_ids, sparse};
+      const size_t sizes[2] = {pbytes, pbytes};
+      FFX_TRY(ffx_h2d_many(pl->device, 2, dsts, srcs, sizes, pl->stream));
+    } else {
+      FFX_TRY(plan_h2d(pl, pl->pair_ids.p, pair_ids, pbytes));
+      if (sparse) FFX_TRY(plan_h2d(pl, pl->sparse.p, sparse, pbytes));
+    }
   }
   return finish_set_pairs(pl, bad_pair);
 }

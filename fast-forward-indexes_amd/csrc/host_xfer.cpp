@@ -128,42 +128,65 @@ bool ffx_runtime_owns(const void* p) {
   return false;
 }
 
-int ffx_h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t stream) {
-  if (bytes == 0) return FFX_OK;
-  if (!dst || !src) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: null pointer");
-  if (bytes <= kDirectBytes || ffx_runtime_owns(src)) {
-    X_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-    return FFX_OK;
+int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* srcs, const size_t* sizes, hipStream_t stream) {
+  // the parts that go to the runtime as they are (small, or page-locked by the caller), in order; the others are staged TOGETHER:
+  // their pieces form one list that the lanes' threads share, so that several arrays of one batch (candidate ordinals and
+  // first-stage scores of a slice) cost one round of threads and one piece's worth of filling before the wire is busy, not one each
+  struct Piece {
+    char* dst;
+    const char* src;
+    size_t len;
+  };
+  std::vector<Piece> pieces;
+  size_t staged_bytes = 0;
+  int staged_parts = 0;
+  for (int i = 0; i < n_parts; ++i) {
+    const size_t bytes = sizes[i];
+    if (bytes == 0) continue;
+    if (!dsts[i] || !srcs[i]) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: null pointer");
+    if (bytes <= kDirectBytes || ffx_runtime_owns(srcs[i])) {
+      X_HIP(hipMemcpyAsync(dsts[i], srcs[i], bytes, hipMemcpyHostToDevice, stream));
+      continue;
+    }
+    for (size_t at = 0; at < bytes; at += kPiece)
+      pieces.push_back({static_cast<char*>(dsts[i]) + at, static_cast<const char*>(srcs[i]) + at, std::min(kPiece, bytes - at)});
+    staged_bytes += bytes;
+    ++staged_parts;
   }
+  if (pieces.empty()) return FFX_OK;
   DeviceWays* dw = ways_of(device);
   if (!dw) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: device %d", device);
   Way& w = dw->in;
   std::lock_guard<std::mutex> lock(w.mu);
   X_HIP(hipSetDevice(device));
-  const int T = lanes_for(bytes);
+  const int T = lanes_for(staged_bytes);
   for (int t = 0; t < T; ++t) {
     const int rc = w.lanes[t].make();
     if (rc != FFX_OK) return rc;
   }
-  const size_t n = (bytes + kPiece - 1) / kPiece;
+  const size_t n = pieces.size();
   const int rc = on_threads(T, [&](int t) -> int {
     Lane& ln = w.lanes[t];
     if (t > 0) X_HIP(hipSetDevice(device));
     int b = 0;
     for (size_t k = (size_t)t; k < n; k += (size_t)T, b ^= 1) {
-      const size_t at = k * kPiece, len = std::min(kPiece, bytes - at);
+      const Piece& pc = pieces[k];
       if (ln.busy[b]) X_HIP(hipEventSynchronize(ln.ev[b]));
-      memcpy(ln.block[b], static_cast<const char*>(src) + at, len);
-      X_HIP(hipMemcpyAsync(static_cast<char*>(dst) + at, ln.block[b], len, hipMemcpyHostToDevice, stream));
+      memcpy(ln.block[b], pc.src, pc.len);
+      X_HIP(hipMemcpyAsync(pc.dst, ln.block[b], pc.len, hipMemcpyHostToDevice, stream));
       X_HIP(hipEventRecord(ln.ev[b], stream));
       ln.busy[b] = true;
     }
     return FFX_OK;
   });
   if (rc != FFX_OK) return rc;
-  g_staged_transfers.fetch_add(1, std::memory_order_relaxed);
-  g_staged_bytes.fetch_add(bytes, std::memory_order_relaxed);
+  g_staged_transfers.fetch_add((unsigned long long)staged_parts, std::memory_order_relaxed);
+  g_staged_bytes.fetch_add(staged_bytes, std::memory_order_relaxed);
   return FFX_OK;
+}
+
+int ffx_h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  return ffx_h2d_many(device, 1, &dst, &src, &bytes, stream);
 }
 
 int ffx_d2h(int device, void* dst, const void* src, size_t bytes, hipStream_t stream) {

@@ -23,6 +23,8 @@
 bool ffx_runtime_owns(const void* p);
 int ffx_h2d(int device, void* dst, const void* src, size_t bytes, hipStream_t stream);
 int ffx_d2h(int device, void* dst, const void* src, size_t bytes, hipStream_t stream);
+// several arrays of one batch at once: their staged pieces share one round of threads (same guarantees as ffx_h2d for each)
+int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* srcs, const size_t* sizes, hipStream_t stream);
 // the blocking forms (what hipMemcpy on the null stream was): done on return
 int ffx_h2d_now(int device, void* dst, const void* src, size_t bytes);
 int ffx_d2h_now(int device, void* dst, const void* src, size_t bytes);
