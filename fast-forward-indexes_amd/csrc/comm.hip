@@ -848,8 +848,14 @@ static int comm_alltoallv(ffx_comm* c, int lane, const Piece* pc, hipStream_t st
         C_NCCL(r->GroupStart());
         grouped = true;
       }
-      if (pc[p].n_send > 0) C_NCCL(r->Send(pc[p].send, (size_t)pc[p].n_send, ncclInt32, p, nc, st));
-      if (pc[p].n_recv > 0) C_NCCL(r->Recv(pc[p].recv, (size_t)pc[p].n_recv, ncclInt32, p, nc, st));
+      // (an error inside the group still closes it: a group left open would swallow the next collective of this thread)
+      ncclResult_t nr = ncclSuccess;
+      if (pc[p].n_send > 0) nr = r->Send(pc[p].send, (size_t)pc[p].n_send, ncclInt32, p, nc, st);
+      if (nr == ncclSuccess && pc[p].n_recv > 0) nr = r->Recv(pc[p].recv, (size_t)pc[p].n_recv, ncclInt32, p, nc, st);
+      if (nr != ncclSuccess) {
+        (void)r->GroupEnd();
+        return ffx_fail(FFX_RCCL_ERROR, "ncclSend / ncclRecv with rank %d: %s", p, r->GetErrorString(nr));
+      }
     }
   }
   if (grouped) C_NCCL(r->GroupEnd());
