@@ -291,3 +291,8 @@ extern "C" int ffx_host_xfer_stats(uint64_t* staged_transfers, uint64_t* staged_
   if (staged_bytes) *staged_bytes = b;
   return FFX_OK;
 }
+
+extern "C" int ffx_host_xfer_release(void) {
+  ffx_xfer_release();
+  return FFX_OK;
+}

@@ -43,7 +43,7 @@ SYMBOLS = (
 # ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
 PRIVATE_SYMBOLS = (
     "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
-    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats", "ffx_build_has_experiments",
+    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats", "ffx_host_xfer_release", "ffx_build_has_experiments",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_strings_code_offsets32", "ffx_strings_code_fixed", "ffx_host_repeated_in_groups", "ffx_buffer_free",
@@ -216,6 +216,7 @@ def lib() -> C.CDLL:
         "ffx_host_stage_report": ([vp, i64, P(i64)], C.c_int),
         "ffx_host_xfer_stats": ([P(C.c_uint64), P(C.c_uint64)], C.c_int),
         "ffx_build_has_experiments": ([], C.c_int),
+        "ffx_host_xfer_release": ([], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
         "ffx_score": ([vp, vp, i64, vp, vp, vp, C.c_int, C.c_double, C.c_uint32, vp, vp, vp, P(i64), P(Stats)], C.c_int),
@@ -297,6 +298,11 @@ def xfer_stats() -> dict:
     n, b = C.c_uint64(0), C.c_uint64(0)
     _check(lib().ffx_host_xfer_stats(C.byref(n), C.byref(b)))
     return {"transfers": int(n.value), "bytes": int(b.value)}
+
+
+def xfer_release() -> None:
+    """Release the library's page-locked staging blocks (they come back on the next staged transfer)."""
+    _check(lib().ffx_host_xfer_release())
 
 
 def usable_cores() -> int:

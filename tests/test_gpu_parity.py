@@ -1426,6 +1426,10 @@ def test_ordinary_memory_travels_through_the_librarys_own_blocks(monkeypatch):
         # most 1 MiB -- the short slices a call begins and ends with -- go to the runtime, which copies those itself)
         share = 0.9 if variant == "no_small_path" else 0.3
         assert moved["bytes"] - at["bytes"] >= share * (pair_ids.nbytes + sparse.nbytes), (variant, at, moved)
+    # the staging blocks can be given back; they return with the next staged transfer
+    native.xfer_release()
+    ff, interp, order, _ = native.score(idx, queries, pair_off, pair_ids, 2, sparse, 0.2, sort=True)
+    assert np.array_equal(bits(ff), bits(want_ff)) and np.array_equal(order.astype(np.int64), want_order)
     # page-locked buffers both ways: nothing is staged
     out = tuple(native.pinned_empty(n_q * k, t) for t in (np.float32, np.float32, np.int32))
     with native.pinned(queries, pair_ids, sparse):
