@@ -1176,13 +1176,16 @@ def code_u64(address: int, n: int, threads: int = 0) -> tuple[np.ndarray, np.nda
     return codes, first[:n_distinct.value].copy()
 
 
-def code_object_column(col: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, np.ndarray, tuple[bytes, int] | None] | None":
+def code_object_column(col: np.ndarray, threads: int = 0, names_as_objects: bool = True) -> "tuple[np.ndarray, np.ndarray | None, tuple[bytes, int] | None] | None":
     """(int32 code of every element, the distinct strings by code, those strings once more as one ``'\n'``-joined
     UTF-8 buffer with their number -- or None if one of them holds a newline) of an object array of Python
     strings; None when some element is not a ``str``.  The array holds POINTERS: they are numbered first
     (rows that share an object share a code at once, no string is looked at), then only the distinct objects are
     read as strings and numbered by value (``ffx_strings_code``) -- a run of 34.9 M rows names 8.7 M documents
-    and 7 k queries, and pandas' own hash of 34.9 M Python strings is what the constructor used to wait for."""
+    and 7 k queries, and pandas' own hash of 34.9 M Python strings is what the constructor used to wait for.
+    ``names_as_objects=False``: where the joined buffer can stand for the name table, the object array of the distinct strings
+    is not made (None comes back in its place): scattering 8.7 M string objects into it is a quarter of a second nobody
+    needs while the names are only ever looked up, written or compared as bytes."""
     if col.dtype != object or col.ndim != 1 or not col.flags["C_CONTIGUOUS"] or col.itemsize != 8:
         return None
     n = col.shape[0]
@@ -1198,9 +1201,12 @@ def code_object_column(col: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, 
             return None
         codes, blob = got
         n_names = int(codes.max()) + 1
+        packed = (blob, n_names) if (blob.count(b"\n") == n_names - 1 and b"\0" not in blob) else None
+        if packed is not None and not names_as_objects:
+            return codes, None, packed
         names = np.empty(n_names, dtype=object)
         names[codes] = col
-        return codes, names, ((blob, n_names) if (blob.count(b"\n") == n_names - 1 and b"\0" not in blob) else None)
+        return codes, names, packed
     distinct = col[first]
     if distinct.shape[0] < 4096:  # few objects: joined in Python, numbered by the same coder (one numbering rule for any size)
         items = distinct.tolist()
@@ -1220,10 +1226,13 @@ def code_object_column(col: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, 
         if got is None:
             return None
         of_object, blob = got
-        names = np.empty(int(of_object.max()) + 1, dtype=object)
+        n_names = int(of_object.max()) + 1
+        if not names_as_objects and blob.count(b"\n") == n_names - 1 and b"\0" not in blob:
+            return take32(of_object, by_object), None, (blob, n_names)
+        names = np.empty(n_names, dtype=object)
         names[of_object] = distinct  # the strings themselves: any object of a value stands for it
     packed = (blob, len(names)) if (blob.count(b"\n") == len(names) - 1 and b"\0" not in blob) else None
-    return take32(of_object, by_object), names, packed
+    return take32(of_object, by_object), (None if (packed is not None and not names_as_objects) else names), packed
 
 
 def _code_distinct_objects(distinct: np.ndarray, threads: int = 0) -> "tuple[np.ndarray, bytes] | None":

@@ -174,10 +174,10 @@ def _coded_text_column(native, col) -> "tuple[np.ndarray, object] | None":
         if col.dtype == object:
             if col.ndim != 1:
                 return None
-            got = native.code_object_column(np.ascontiguousarray(col))
+            got = native.code_object_column(np.ascontiguousarray(col), names_as_objects=False)
             if got is None:
                 return None
-            codes, names, packed = got
+            codes, names, packed = got  # (names is None where the joined buffer stands for the table: strings on demand)
             return codes, (names if packed is None else Names(packed[0], packed[1], objects=names))
         return native.code_fixed_strings(col) if col.dtype.kind in "SU" else None
     try:

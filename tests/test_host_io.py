@@ -470,3 +470,7 @@ def test_object_column_numbering_depends_on_the_strings_only(n_values):
     odd = col.copy()
     odd[5] = "two\nlines"
     assert native.code_object_column(odd)[2] is None
+    # without the object array of the names: the same codes and buffer, None where the buffer stands for the table
+    codes3, names3, packed3 = native.code_object_column(col, names_as_objects=False)
+    assert names3 is None and packed3 == packed and np.array_equal(codes3, codes)
+    assert native.code_object_column(odd, names_as_objects=False)[1] is not None  # (no buffer can stand for these names)
