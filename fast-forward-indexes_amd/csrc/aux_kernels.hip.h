@@ -187,6 +187,25 @@ tile_index_kernel(const int32_t* __restrict__ pair_ids, int64_t n_pairs, const i
   }
 }
 
+#ifdef FFX_EXPERIMENTS
+// FFX_DEBUG_VARIANT=doc_major (ffx_plan_run): the row list in row order and back
+__global__ void __launch_bounds__(256) dm_prepare_kernel(const int2* __restrict__ desc, int64_t n, uint32_t* __restrict__ keys, int32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    keys[i] = (uint32_t)desc[i].x;
+    idx[i] = (int32_t)i;
+  }
+}
+__global__ void __launch_bounds__(256) dm_gather_kernel(const int2* __restrict__ desc, const int32_t* __restrict__ perm, int64_t n, int2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = desc[perm[i]];
+}
+__global__ void __launch_bounds__(256) dm_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, int64_t n, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[perm[i]] = src[i];
+}
+#endif
+
 // single-row candidates (FIRSTP, PASSAGE, or every document has one passage): no scan needed.
 // row_of[o] is the one row of ordinal o (first row of the document / row of the passage);
 // row_of == nullptr means ordinal == row (ids were added one per row, in order).

@@ -220,10 +220,11 @@ void numpy_leaf_plan(int start, int n, std::vector<int>& bounds) {
 // has <= 8 leaves (its sub-tree then is what gather_dot_exact_anyd_kernel sums); `steps` replays the recursion above
 // the pieces ("sum[a] += sum[b]" over segment numbers, the total ending in segment 0).  Returns the number of the
 // segment that holds the sum of [start, start + n).
+int g_max_piece_leaves = 8;  // (experiments: smaller pieces, see plan_create)
 int long_row_plan(int start, int n, std::vector<std::pair<int, int>>& pieces, std::vector<int>& steps) {
   std::vector<int> bounds;
   numpy_leaf_plan(0, n, bounds);
-  if (bounds.size() <= 8) {
+  if ((int)bounds.size() <= g_max_piece_leaves) {
     pieces.emplace_back(start, n);
     return (int)pieces.size() - 1;
   }
@@ -330,6 +331,8 @@ struct ffx_plan {
   // documents of several passages scored without a row list (gather_dot.hip.h, Derive): made on the first run of a candidate list
   DevBuf pair_first, tile_tab;
   bool derive_valid = false, use_derive = false;
+  bool forced_pieces = false;  // (experiments: seg_leaves=N)
+  DevBuf dm_keys, dm_keys2, dm_perm, dm_perm2, dm_desc, dm_rs, dm_tmp;  // (experiments: doc_major)
   bool want_ranked = false, have_carry = false;
   bool dense_given = false;  // the next run starts from dense scores already in `ff` (ffx_rank_kept): no expand, no gather
   int64_t n_queries = 0, n_pairs = 0, n_rows = 0;
@@ -1028,11 +1031,18 @@ static int plan_create(ffx_index* idx, ffx_plan** out, bool with_stream) {
     if (rc == FFX_OK && ffx_h2d_now(pl->device, pl->combine_steps.p, steps.data(), steps.size() * sizeof(int)) != FFX_OK)
       rc = fail(FFX_HIP_ERROR, "combine plan upload failed");
   }
-  if (rc == FFX_OK && pl->n_leaves > 8 && idx->dtype != FFX_DTYPE_PQ8) {
+  // (experiments build, FFX_DEBUG_VARIANT=seg_leaves=N: ANY row is cut into pieces of at most N leaves of NumPy's tree and scored
+  // piece by piece -- d = 768 with N = 1: eight passes over 96-element slices, every pass's query slices 2.7 MB in all)
+  long long seg_leaves = 0;
+  const bool forced_pieces = ffx_experiment("seg_leaves", &seg_leaves) && seg_leaves >= 1 && seg_leaves < 8 && pl->n_leaves > seg_leaves;
+  if (rc == FFX_OK && (pl->n_leaves > 8 || forced_pieces) && idx->dtype != FFX_DTYPE_PQ8) {
     // more than 8 leaves: segments of <= 8 leaves, each with its own leaf table and combine steps
     std::vector<std::pair<int, int>> pieces;
     std::vector<int> above, tables;
+    g_max_piece_leaves = forced_pieces ? (int)seg_leaves : 8;
     long_row_plan(0, idx->qdim, pieces, above);
+    g_max_piece_leaves = 8;
+    pl->forced_pieces = forced_pieces;
     bool ok = pieces.size() <= 64;
     for (const auto& [col0, len] : pieces) {
       ffx_plan::Segment sg{};
@@ -1658,7 +1668,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   // d = 768 / 1024 (8 leaves): full-line non-temporal loads + LDS transpose (16.0 ms vs 17.7 ms for
   // the strided form at 8.8M x 768 fp32, k=5000: tools/kernel_ab.py, profiles/r01/kernel_ab_2.log)
   if (exact) {
-    switch (d) {
+    switch (pl->forced_pieces && !pl->segments.empty() ? -1 : d) {
       case 768:
         if (pl->use_derive) {  // no row list: the waves work their rows out of the candidate lists (311 / 1311)
 #ifdef FFX_EXPERIMENTS
@@ -1724,7 +1734,7 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
   } while (0)
         long long u_value = 0;  // A/B hook (tools/dims_bench.py): passes of loads in flight per wave
         const bool u_env = ffx_experiment("anyd_u", &u_value);
-        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !ffx_experiment("generic_staged", nullptr)) {
+        if (pl->n_leaves <= 8 && d >= 8 && pl->anyd_ok && !pl->forced_pieces && !ffx_experiment("generic_staged", nullptr)) {
           const int* LS = pl->leaf_start.as<int>();
           const int* CS = pl->combine_steps.as<int>();
           const int nl = pl->n_leaves;
@@ -2116,6 +2126,27 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
     }
     FFX_HIP(hipGetLastError());
   }
+#ifdef FFX_EXPERIMENTS
+  // FFX_DEBUG_VARIANT=doc_major: the row list is put in ROW order before gather_dot (a stable radix sort of the rows by index row:
+  // candidates of different queries that name the same row stand next to each other, so the row is fetched from HBM once and
+  // found in the cache by the others) and the row scores are put back afterwards.  The sort is inside the step's first stage,
+  // the way back inside its third: ms_gather_dot is the kernel(s) alone.
+  const bool doc_major = single && P > 0 && !pq_fused && !given && ffx_experiment("doc_major", nullptr);
+  if (doc_major) {
+    const size_t nb = (size_t)P * 4;
+    for (DevBuf* b : {&pl->dm_keys, &pl->dm_keys2, &pl->dm_perm, &pl->dm_perm2, &pl->dm_rs}) FFX_TRY(b->ensure(nb));
+    FFX_TRY(pl->dm_desc.ensure((size_t)P * sizeof(int2)));
+    ffx::dm_prepare_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->desc.as<int2>(), P, pl->dm_keys.as<uint32_t>(), pl->dm_perm.as<int32_t>());
+    size_t tmp = 0;
+    FFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp, pl->dm_keys.as<uint32_t>(), pl->dm_keys2.as<uint32_t>(), pl->dm_perm.as<int32_t>(),
+                                      pl->dm_perm2.as<int32_t>(), (size_t)P, 0, 32, st));
+    FFX_TRY(pl->dm_tmp.ensure(std::max<size_t>(tmp, 16)));
+    FFX_HIP(rocprim::radix_sort_pairs(pl->dm_tmp.p, tmp, pl->dm_keys.as<uint32_t>(), pl->dm_keys2.as<uint32_t>(), pl->dm_perm.as<int32_t>(),
+                                      pl->dm_perm2.as<int32_t>(), (size_t)P, 0, 32, st));
+    ffx::dm_gather_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->desc.as<int2>(), pl->dm_perm2.as<int32_t>(), P, pl->dm_desc.as<int2>());
+    FFX_HIP(hipGetLastError());
+  }
+#endif
   if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[1], st));
   hipEvent_t* recent = pl->recent[pl->n_runs % ffx_plan::kRecent];
   if (!recent[0]) {
@@ -2125,8 +2156,23 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (!pq_fused) FFX_HIP(hipEventRecord(recent[0], st));
   // 2. gather + inner product (the hot kernel)
   float* rs = single ? pl->ff.as<float>() : pl->rs.as<float>();
+#ifdef FFX_EXPERIMENTS
+  if (doc_major) {
+    std::swap(pl->desc, pl->dm_desc);
+    const int rc_dm = launch_gather_dot(pl, exact, pl->dm_rs.as<float>());
+    std::swap(pl->desc, pl->dm_desc);
+    FFX_TRY(rc_dm);
+    FFX_HIP(hipEventRecord(pl->ev[2], st));
+    ffx::dm_scatter_kernel<<<blocks_for(P, 256), 256, 0, st>>>(pl->dm_rs.as<float>(), pl->dm_perm2.as<int32_t>(), P, rs);
+    FFX_HIP(hipGetLastError());
+  } else
+#endif
   if (R > 0 && !pq_fused && !given) FFX_TRY(launch_gather_dot(pl, exact, rs));
+#ifdef FFX_EXPERIMENTS
+  if (!pq_fused && !doc_major) FFX_HIP(hipEventRecord(pl->ev[2], st));
+#else
   if (!pq_fused) FFX_HIP(hipEventRecord(pl->ev[2], st));
+#endif
   if (!pq_fused) FFX_HIP(hipEventRecord(recent[1], st));
   // 3. segment aggregation + interpolation.  One row per candidate, first-stage scores, queries that are ordered a workgroup
   // each: the interpolation is made by the sort kernel while it loads its keys (one launch and its gap less per run; what
