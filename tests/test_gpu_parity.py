@@ -845,6 +845,15 @@ def test_single_rank_rccl_bench_leg_matches_the_plain_leg():
         assert vals[name]["parity_on_cpu_sample"] == "bit-exact"
     assert vals["sharded"]["rccl_ranks"] == 1
     assert vals["sharded"]["value"] > 0.9 * vals["plain"]["value"], (vals["sharded"]["value"], vals["plain"]["value"])
+    # documents of several passages: the sharded scorer's plans derive their rows inside gather_dot too (variant 311), replayed
+    # and fresh batches bit-exact against the oracle
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--layout", "multi", "--force-sharded", "--rows", "1000000", "--queries", "300",
+                          "--k", "1500", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "8", "--cpu-seconds", "0.2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    multi = json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{")))
+    assert multi["parity_on_cpu_sample"] == "bit-exact" and multi["fresh_batch_parity_on_cpu_sample"] == "bit-exact"
+    assert "variant 311" in multi["roofline"]["kernel"], multi["roofline"]["kernel"]
 
 
 def test_bench_measures_hbm_traffic_with_pmc_passes_of_its_own():
