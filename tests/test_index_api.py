@@ -797,6 +797,37 @@ def test_interpolate_after_call_starts_from_the_dense_scores_the_device_kept():
     index.close()
 
 
+def test_early_stopping_over_documents_of_several_passages_at_768():
+    """Early stopping where every interval's scoring derives its rows inside gather_dot (d = 768, documents of 1 - 4 passages, MaxP and
+    AveP; the interval's candidate lists change every time, so do the tile tables): the device loop equals the NumPy statement of the
+    reference's loop (``Index._early_stopping_kept``, base.py:316-387, which scores every interval through ``_score_pairs``)."""
+    from fast_forward_amd.index.api import Index as BaseIndex
+
+    rng = np.random.default_rng(21)
+    n_docs, d, n_q, k = 3000, 768, 12, 700
+    per_doc = rng.integers(1, 5, size=n_docs)
+    doc_of_row = np.repeat(np.arange(n_docs), per_doc)
+    qv = (rng.standard_normal((n_q, d)) * 0.05).astype(np.float32)
+    frame = pd.DataFrame({"q_id": np.repeat([f"q{i:02d}" for i in range(n_q)], k),
+                          "id": np.concatenate([[f"D{x}" for x in rng.choice(n_docs, size=k, replace=False)] for _ in range(n_q)]),
+                          "score": -np.sort(-(rng.random((n_q, k)) * 3).astype(np.float32), axis=1).reshape(-1)})
+    first = Ranking(frame, queries={f"q{i:02d}": str(i) for i in range(n_q)})
+    for mode in (Mode.MAXP, Mode.AVEP):
+        idx = InMemoryIndex(LambdaEncoder(lambda t: qv[int(t)]), mode=mode)
+        idx.add((rng.standard_normal((len(doc_of_row), d)) * 0.05).astype(np.float32), doc_ids=[f"D{x}" for x in doc_of_row])
+        for cutoff, alpha, depths in ((10, 0.3, (10, 100, 700)), (3, 0.1, (5, 50, 200, 700))):
+            got = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+            device_loop = InMemoryIndex._early_stopping_kept
+            try:
+                InMemoryIndex._early_stopping_kept = BaseIndex._early_stopping_kept  # the NumPy statement, intervals scored by the device
+                want = idx(first, early_stopping=cutoff, early_stopping_alpha=alpha, early_stopping_depths=depths)
+            finally:
+                InMemoryIndex._early_stopping_kept = device_loop
+            assert got == want and 0 < len(got._df) < len(frame), (mode, cutoff)
+            assert idx.last_stats["kernel_variant"] in (311, 111), idx.last_stats  # (111: an interval whose candidates all have one row)
+        idx.close()
+
+
 def test_early_stopping_on_a_large_run_edge_cases():
     """The coded early-stopping route (>= 4096 rows: id codes in, only the scored candidates back, a coded Ranking out)
     on the edges: depths all below the cutoff (nothing is scored: an empty ranking), an unknown id that IS reached
