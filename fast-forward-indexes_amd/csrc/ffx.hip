@@ -118,7 +118,7 @@ int ffx_fail(int code, const char* fmt, ...) {
 //   no_small_path          ffx_score never takes the single-submission path of small batches
 //   route_host             the sharded scorer routes a batch on the host even for document-range shards
 //   pq_no_fuse, pq_no_adc, pq_sort_apart  product-quantized rows: unfused exact ADC / decode-then-dot instead of exact ADC / the ordering as a launch of its own
-//   no_derive              documents of several passages: the row list written by an expand kernel instead of rows derived by gather_dot
+//   no_derive              d = 768 / 1024: the row list written by an expand kernel instead of rows derived inside gather_dot
 //   score_slice_pairs=N, score_blocking_out   where ffx_score cuts a batch into slices; results fetched by the calling thread
 //   stage_bytes=N          size of a page-locked staging block of ffx_index_upload_rows
 //   rehearsal_paced[=GB/s] the rehearsal transport's stand-in exchange paced like a link (bench.py --rehearsal-exchange)
@@ -330,7 +330,7 @@ struct ffx_plan {
   DevBuf carry, ranked, carry_ranked;
   // documents of several passages scored without a row list (gather_dot.hip.h, Derive): made on the first run of a candidate list
   DevBuf pair_first, tile_tab;
-  bool derive_valid = false, use_derive = false;
+  bool derive_valid = false, use_derive = false, use_derive1 = false;
   bool forced_pieces = false;  // (experiments: seg_leaves=N)
   DevBuf dm_keys, dm_keys2, dm_perm, dm_perm2, dm_desc, dm_rs, dm_tmp;  // (experiments: doc_major)
   bool want_ranked = false, have_carry = false;
@@ -395,7 +395,8 @@ struct ffx_plan {
   bool hstage_failed = false;
 };
 
-static bool derive_applies(const ffx_plan* pl);  // (defined beside the gather_dot dispatcher)
+static bool derive_applies(const ffx_plan* pl);  // (both defined beside the gather_dot dispatcher)
+static bool derive_kernel_exists(const ffx_plan* pl);
 
 namespace {
 // host -> device on the plan's stream; small sources go through the page-locked block (the
@@ -1277,7 +1278,7 @@ static int set_pairs_check_complete(ffx_plan* pl, int64_t* bad_pair) {
   }
   if (pl->check_one_each) {
     pl->n_rows = P;
-    FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)P, 1) * sizeof(int2)));
+    if (!derive_kernel_exists(pl)) FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)P, 1) * sizeof(int2)));  // (else: on the run that needs a row list)
     pl->have_pairs = true;
     pl->derive_valid = false;
     pl->lazy_pairs = false;
@@ -1541,6 +1542,12 @@ static ffx::Derive plan_derive(const ffx_plan* pl) {
   dv.doc_rows = ix->doc_rows_identity ? nullptr : ix->doc_rows.as<int32_t>();
   dv.pair_off = pl->pair_off.as<int64_t>();
   dv.n_pairs = (int)pl->n_pairs;
+  dv.pair_ids = pl->pair_ids.as<int32_t>();
+  dv.row_of = pl->mode == FFX_MODE_PASSAGE ? (ix->psgs_identity ? nullptr : ix->psg_row.as<int32_t>())
+                                           : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
+  dv.n_queries = (int)pl->n_queries;
+  dv.n_index_rows = (int)std::min<int64_t>(ix->capacity, INT32_MAX);
+  dv.queries_per_pair = pl->n_pairs > 0 ? (double)pl->n_queries / (double)pl->n_pairs : 0.0;
   return dv;
 }
 
@@ -1552,10 +1559,13 @@ static int derive_tile(const ffx_plan* pl) {
 }
 
 // rows of this storage type and length, in this mode, have a row-deriving kernel (exact summation only)
-static bool derive_applies(const ffx_plan* pl) {
+static bool derive_kernel_exists(const ffx_plan* pl) {
   const ffx_index* ix = pl->idx;
   return (ix->dtype == FFX_DTYPE_F32 || ix->dtype == FFX_DTYPE_F16) && (ix->qdim == 768 || ix->qdim == 1024) && !pl->ov_dim &&
-         (pl->mode == FFX_MODE_MAXP || pl->mode == FFX_MODE_AVEP) && !ffx_debug_variant("no_derive", nullptr);
+         !ffx_debug_variant("no_derive", nullptr);
+}
+static bool derive_applies(const ffx_plan* pl) {  // (candidates of several rows)
+  return derive_kernel_exists(pl) && (pl->mode == FFX_MODE_MAXP || pl->mode == FFX_MODE_AVEP);
 }
 
 // pick and launch the gather_dot instantiation for rows of type T (float / _Float16); the
@@ -1673,24 +1683,28 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
         if (pl->use_derive) {  // no row list: the waves work their rows out of the candidate lists (311 / 1311)
 #ifdef FFX_EXPERIMENTS
           if (derive_tile(pl) == 16 && TL != 16) {
-            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 16, true, true><<<blocks_for(R, 4 * 16), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 16, true, 1><<<blocks_for(R, 4 * 16), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
           } else if (derive_tile(pl) == 32) {
-            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 32, true, true><<<blocks_for(R, 4 * 32), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 32, true, 1><<<blocks_for(R, 4 * 32), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
           } else if (derive_tile(pl) == 8 && TL != 8) {
-            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 8, true, true><<<blocks_for(R, 4 * 8), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 8, true, 1><<<blocks_for(R, 4 * 8), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
           } else
 #endif
-          ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, 1><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+        } else if (pl->use_derive1) {  // one row per candidate, no row list either (411 / 1411)
+          ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, 2><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
         } else
           ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
-        pl->variant = (pl->use_derive ? 311 : 111) + HALF;
+        pl->variant = (pl->use_derive ? 311 : pl->use_derive1 ? 411 : 111) + HALF;
         break;
       case 1024:
         if (pl->use_derive)
-          ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true, 1><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+        else if (pl->use_derive1)
+          ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true, 2><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
         else
           ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
-        pl->variant = (pl->use_derive ? 312 : 112) + HALF;
+        pl->variant = (pl->use_derive ? 312 : pl->use_derive1 ? 412 : 112) + HALF;
         break;
 #define FFX_MULTI(LEAVES, NPER, U, TILE, ID)                                                                     \
   do {                                                                                                           \
@@ -2077,7 +2091,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   const bool do_sort = (flags & FFX_FLAG_SORT) != 0;
   const bool exact = (flags & FFX_FLAG_EXACT_SUM) != 0;
   pl->ran = false;
-  pl->use_derive = false;
+  pl->use_derive = pl->use_derive1 = false;
   FFX_HIP(hipEventRecord(pl->ev[0], st));
   // product-quantized rows, one row per candidate, exact ADC: the three stages below are one kernel
   const bool pq_fused = !given && single && P > 0 && !ffx_debug_variant("pq_no_fuse", nullptr) && pq_exact_adc_applies(pl);
@@ -2097,7 +2111,10 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (P > 0 && !pq_fused && !given) {
     // 1. candidates -> row list
     const double qpp = (double)pl->n_queries / (double)P;
-    if (single) {
+    if (single && exact && derive_kernel_exists(pl) && ix->capacity <= INT32_MAX && !pl->forced_pieces && !ffx_experiment("doc_major", nullptr)) {
+      pl->use_derive1 = true;  // candidate -> row inside gather_dot: no launch here, no row list
+    } else if (single) {
+      FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)P, 1) * sizeof(int2)));
       const int32_t* row_of = pl->mode == FFX_MODE_PASSAGE ? (ix->psgs_identity ? nullptr : ix->psg_row.as<int32_t>())
                                                            : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
       ffx::expand_single_kernel<<<blocks_for((P + 3) / 4, 256), 256, 0, st>>>(

@@ -208,6 +208,10 @@ gather_dot_exact_kernel(const T* __restrict__ vectors, const float* __restrict__
 // its row's candidate by comparing against those offsets, and the row is that candidate's first row (`pair_first`: where the
 // document's rows begin in doc_rows) plus the distance -- 4 bytes per candidate and 8 per tile instead of 8 per row written by
 // an expand kernel and read back here (1.26 GB each way at 157 M rows).
+// DERIVE = 2 (one row per candidate: PASSAGE, FIRSTP, documents of one passage): row t of the tile IS candidate base + t -- its
+// row is `row_of[ordinal]` (or the ordinal itself when ordinals are rows), its query the one whose candidate list holds that
+// position (the proportional guess of query_of_pair for the tile's first candidate, stepped forward per lane).  No expand launch
+// and no row list here either: the kernel reads 4 bytes per candidate where it read 8.
 struct Derive {
   const int2* tile_tab = nullptr;       // per tile: {candidate of the tile's first row, query of that candidate}
   const int32_t* seg_off = nullptr;     // [n_pairs + 1] first row of every candidate in the (virtual) row list
@@ -215,9 +219,15 @@ struct Derive {
   const int32_t* doc_rows = nullptr;    // nullptr: position == row (documents added whole, in order)
   const int64_t* pair_off = nullptr;    // [n_queries + 1]
   int n_pairs = 0;
+  // DERIVE = 2
+  const int32_t* pair_ids = nullptr;  // [n_pairs] ordinals
+  const int32_t* row_of = nullptr;    // ordinal -> row; nullptr: ordinal == row
+  int n_queries = 0;
+  int n_index_rows = 0;
+  double queries_per_pair = 0.0;
 };
 
-template <typename T, int NCH, int U, int TILE, bool NT, bool DERIVE = false>
+template <typename T, int NCH, int U, int TILE, bool NT, int DERIVE = 0>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
                             const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, const Derive dv) {
@@ -237,7 +247,31 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
   const int my_t = lane < n_here ? lane : n_here - 1;
   int2 my;
-  if constexpr (DERIVE) {
+  if constexpr (DERIVE == 2) {
+    const long p = base + my_t;
+    const int o = dv.pair_ids[p];
+    int rid = dv.row_of ? dv.row_of[o] : o;
+    // (validated ordinals always give a row of the store; the clamp is for ffx_score's single-submission path, where the verdict
+    // on a bad ordinal is read back only after the kernels behind this one have run)
+    rid = (unsigned)rid < (unsigned)dv.n_index_rows ? rid : 0;
+    // the query of the tile's first candidate (uniform), then forward: a tile rarely crosses a query boundary
+    int qn = (int)((double)base * dv.queries_per_pair);
+    qn = qn < 0 ? 0 : (qn > dv.n_queries - 1 ? dv.n_queries - 1 : qn);
+    if (!(dv.pair_off[qn] <= base && base < dv.pair_off[qn + 1])) {
+      int lo = 0, hi = dv.n_queries;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (dv.pair_off[mid] <= base) lo = mid; else hi = mid;
+      }
+      qn = lo;
+    }
+    long next_q = dv.pair_off[qn + 1];
+    while (p >= next_q) {
+      ++qn;
+      next_q = dv.pair_off[qn + 1];
+    }
+    my = make_int2(rid, qn);
+  } else if constexpr (DERIVE == 1) {
     const int2 first = dv.tile_tab[wave];  // (uniform: one scalar load)
     const int p_mine = first.x + lane;
     const int so = lane <= TILE ? dv.seg_off[p_mine < dv.n_pairs ? p_mine : dv.n_pairs] : 0x7fffffff;

@@ -399,9 +399,10 @@ def test_many_passages_per_document():
 @pytest.mark.parametrize("d", [768, 1024])
 @pytest.mark.parametrize("contiguous", [True, False])
 def test_rows_derived_inside_gather_dot_for_documents_of_several_passages(monkeypatch, d, store, contiguous):
-    """MAXP / AVEP over documents of 1 - 9 (one of 70) passages at d = 768 / 1024: no row list is written -- the waves of
+    """At d = 768 / 1024 no row list is written.  MAXP / AVEP over documents of 1 - 9 (one of 70) passages: the waves of
     gather_dot work the rows of their tile out of the candidate lists, the row offsets and two small tables (kernel variants
-    311 / 312, +1000 for half rows; get_indices, index/util.py:29-41 + the merge of index/base.py:296-298).  Same bits as the
+    311 / 312, +1000 for half rows; get_indices, index/util.py:29-41 + the merge of index/base.py:296-298); FIRSTP / PASSAGE: a
+    candidate's one row is looked up inside the kernel (411 / 412).  Same bits as the
     oracle and as the row-list form (FFX_DEBUG_VARIANT=no_derive -> variants 111 / 112) -- documents whose rows are scattered
     over the index or contiguous, queries without candidates at the start, in the middle and at the end, lists of one candidate,
     a last tile that is not full; a plan that is run again, and with other candidate lists."""
@@ -455,6 +456,33 @@ def test_rows_derived_inside_gather_dot_for_documents_of_several_passages(monkey
             ff4, interp4, order4, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.3, sort=True)
             assert st["kernel_variant"] == (311 if d == 768 else 312) + half
             assert np.array_equal(bits(ff4), bits(want)) and np.array_equal(bits(interp4), bits(want_i)) and np.array_equal(order4, order)
+        # one row per candidate (FIRSTP, PASSAGE with passages that are NOT their own rows): the row is looked up inside gather_dot
+        # as well (variants 411 / 412): no expand launch, no row list; the row-list form (no_derive) gives the same bits
+        psg_row = rng.permutation(n).astype(np.int32)
+        idx.set_psg_rows(psg_row)
+        for mode, pool in ((3, n_docs), (1, n)):
+            ids1 = np.concatenate([rng.choice(pool, size=k, replace=False) for k in lens] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+            want, want_i = fo.score(as_f32, doc_off, doc_rows, psg_row, queries, pair_off, ids1, mode, sparse, 0.3)
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+            plan.set_pairs(pair_off, ids1, sparse, mode)
+            plan.run(0.3, exact_sum=True, sort=True)
+            ff, interp, order = plan.fetch(interp=True, order=True)
+            assert plan.stats()["kernel_variant"] == (411 if d == 768 else 412) + half
+            assert np.array_equal(bits(ff), bits(want)) and np.array_equal(bits(interp), bits(want_i)), (mode, trial)
+            assert np.array_equal(order.astype(np.int64), fo.order(want_i, pair_off))
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_derive")
+            plan.run(0.3, exact_sum=True, sort=True)
+            ff2, interp2, _ = plan.fetch(interp=True)
+            assert plan.stats()["kernel_variant"] == (111 if d == 768 else 112) + half
+            assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp))
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_small_path,score_slice_pairs=250")
+            ff4, interp4, order4, st = native.score(idx, queries, pair_off, ids1, mode, sparse, 0.3, sort=True)
+            assert st["kernel_variant"] == (411 if d == 768 else 412) + half
+            assert np.array_equal(bits(ff4), bits(want)) and np.array_equal(bits(interp4), bits(want_i)) and np.array_equal(order4, order)
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+            ff5, interp5, order5, st = native.score(idx, queries, pair_off, ids1, mode, sparse, 0.3, sort=True)  # (small batch: one submission)
+            assert np.array_equal(bits(ff5), bits(want)) and np.array_equal(bits(interp5), bits(want_i)) and np.array_equal(order5, order)
+        idx.set_psg_rows(np.arange(n))
         lens = lens[::-1]
     plan.close()
     idx.close()
@@ -1012,7 +1040,7 @@ def test_baseline_config_full_size_properties():
     plan.run(0.1, exact_sum=True, sort=True)
     ff, interp, order = plan.fetch(interp=True, order=True)
     st = plan.stats()
-    assert st["n_rows"] == nq * k and st["kernel_variant"] == 111
+    assert st["n_rows"] == nq * k and st["kernel_variant"] == 411  # (one row per candidate, found inside gather_dot: no row list)
     # order: permutation of each query's positions, scores non-increasing
     o2 = order.reshape(nq, k).astype(np.int64)
     assert np.array_equal(np.sort(o2, axis=1), pair_off[:-1, None] + np.arange(k)[None, :])
