@@ -1692,6 +1692,24 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
 #endif
           ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, 1><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
         } else if (pl->use_derive1) {  // one row per candidate, no row list either (411 / 1411)
+#ifdef FFX_EXPERIMENTS
+          long long tv = 0, uv = 0;
+          (void)ffx_experiment("derive_tile", &tv);
+          (void)ffx_experiment("derive_u", &uv);
+          if (tv == 16 && uv == 0) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 16, true, 2><<<blocks_for(R, 4 * 16), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (tv == 32) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, UL, 32, true, 2><<<blocks_for(R, 4 * 32), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (tv == 16 && uv == 8) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, 8, 16, true, 2><<<blocks_for(R, 4 * 16), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (tv == 8 && uv == 8) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, 8, 8, true, 2><<<blocks_for(R, 4 * 8), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (tv == 8 && uv == 2) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, 2, 8, true, 2><<<blocks_for(R, 4 * 8), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else if (tv == 4) {
+            ffx::gather_dot_exact_lds_kernel<T, 3, 4, 4, true, 2><<<blocks_for(R, 4 * 4), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
+          } else
+#endif
           ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true, 2><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));
         } else
           ffx::gather_dot_exact_lds_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
