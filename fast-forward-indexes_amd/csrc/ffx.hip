@@ -331,6 +331,12 @@ struct ffx_plan {
   // documents of several passages scored without a row list (gather_dot.hip.h, Derive): made on the first run of a candidate list
   DevBuf pair_first, tile_tab;
   bool derive_valid = false, use_derive = false, use_derive1 = false;
+  // for the one-row derive: the query of every 1024th candidate (made on the host from the offsets it validates anyway and
+  // uploaded with them), so that a wave finds its tile's query in a step or two however ragged the lists are
+  static constexpr int64_t kHintBlock = 1024;
+  DevBuf q_hint;
+  std::vector<int32_t> host_hint;
+  bool q_hint_valid = false;
   bool forced_pieces = false;  // (experiments: seg_leaves=N)
   DevBuf dm_keys, dm_keys2, dm_perm, dm_perm2, dm_desc, dm_rs, dm_tmp;  // (experiments: doc_major)
   bool want_ranked = false, have_carry = false;
@@ -1235,10 +1241,31 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
 // on the stream (the sharded scorer's staging) waits once for everything: launch (asynchronous; the verdict and, where
 // candidates may contribute several rows, the row count travel into page-locked memory) and complete (after the stream
 // has been synchronised).
+static int upload_query_hint(ffx_plan* pl) {
+  const int64_t P = pl->n_pairs, Q = pl->n_queries;
+  pl->q_hint_valid = false;
+  if (P <= 0 || Q <= 0 || !derive_kernel_exists(pl) || (int64_t)pl->host_pair_off.size() != Q + 1) return FFX_OK;
+  const int64_t nb = (P + ffx_plan::kHintBlock - 1) / ffx_plan::kHintBlock;
+  pl->host_hint.resize((size_t)nb + 1);
+  const int64_t* off = pl->host_pair_off.data();
+  int64_t q = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t p = b * ffx_plan::kHintBlock;  // (p < P = off[Q]: the walk ends at a query that has candidates)
+    while (off[q + 1] <= p) ++q;
+    pl->host_hint[(size_t)b] = (int32_t)q;
+  }
+  pl->host_hint[(size_t)nb] = (int32_t)(Q - 1);
+  FFX_TRY(pl->q_hint.ensure(((size_t)nb + 1) * sizeof(int32_t)));
+  FFX_TRY(plan_h2d(pl, pl->q_hint.p, pl->host_hint.data(), ((size_t)nb + 1) * sizeof(int32_t)));
+  pl->q_hint_valid = true;
+  return FFX_OK;
+}
+
 static int set_pairs_check_launch(ffx_plan* pl) {
   ffx_index* ix = pl->idx;
   const int64_t P = pl->n_pairs;
   const int mode = pl->mode;
+  FFX_TRY(upload_query_hint(pl));
   FFX_HIP(hipMemsetAsync(pl->flags.p, 0xFF, sizeof(unsigned long long), pl->stream));
   // Where every valid ordinal names exactly one row (passages that are their own rows; FirstP, or documents of one row
   // each, when no document is empty) there is nothing to count or scan: the ordinals are range-checked and the row
@@ -1369,6 +1396,7 @@ int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src) {
   FFX_HIP(hipSetDevice(dst->device));
   const int64_t Q = src->n_queries, P = src->n_pairs;
   dst->have_pairs = false;
+  dst->q_hint_valid = false;
   dst->lazy_pairs = false;
   dst->ran = false;
   const size_t pb = std::max<size_t>((size_t)P, 1);
@@ -1548,6 +1576,7 @@ static ffx::Derive plan_derive(const ffx_plan* pl) {
   dv.n_queries = (int)pl->n_queries;
   dv.n_index_rows = (int)std::min<int64_t>(ix->capacity, INT32_MAX);
   dv.queries_per_pair = pl->n_pairs > 0 ? (double)pl->n_queries / (double)pl->n_pairs : 0.0;
+  dv.q_hint = pl->q_hint_valid ? pl->q_hint.as<int32_t>() : nullptr;
   return dv;
 }
 
@@ -2360,6 +2389,7 @@ int ffx_plan_early_stopping(ffx_plan* pl, int32_t cutoff, double alpha, const in
     ch->mode = pl->mode;
     ch->have_sparse = true;
     ch->have_pairs = false;
+    ch->q_hint_valid = false;  // (the interval's lists are made on the device: the kernel falls back to its own search)
     // get_indices for the interval only: an unknown id is an IndexError when (and only when) it is reached
     FFX_HIP(hipMemsetAsync(ch->flags.p, 0xFF, sizeof(unsigned long long), st));
     FFX_TRY(launch_count_scan(ch));

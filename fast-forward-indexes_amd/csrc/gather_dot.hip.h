@@ -225,6 +225,7 @@ struct Derive {
   int n_queries = 0;
   int n_index_rows = 0;
   double queries_per_pair = 0.0;
+  const int32_t* q_hint = nullptr;    // query of candidate 0, 1024, 2048, ... and (last entry) the last query; nullptr: not given
 };
 
 template <typename T, int NCH, int U, int TILE, bool NT, int DERIVE = 0>
@@ -254,16 +255,29 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
     // (validated ordinals always give a row of the store; the clamp is for ffx_score's single-submission path, where the verdict
     // on a bad ordinal is read back only after the kernels behind this one have run)
     rid = (unsigned)rid < (unsigned)dv.n_index_rows ? rid : 0;
-    // the query of the tile's first candidate (uniform), then forward: a tile rarely crosses a query boundary
-    int qn = (int)((double)base * dv.queries_per_pair);
-    qn = qn < 0 ? 0 : (qn > dv.n_queries - 1 ? dv.n_queries - 1 : qn);
-    if (!(dv.pair_off[qn] <= base && base < dv.pair_off[qn + 1])) {
-      int lo = 0, hi = dv.n_queries;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (dv.pair_off[mid] <= base) lo = mid; else hi = mid;
+    // the query of the tile's first candidate (uniform), then forward: a tile rarely crosses a query boundary.  With the host's
+    // hint (the query of every 1024th candidate) the search runs between two neighbouring entries: no step at all where
+    // queries are longer than 1024 candidates, however ragged the lists; without it (lists made on the device) the
+    // proportional guess, then a search over all queries
+    int qn;
+    if (dv.q_hint) {
+      int lo = dv.q_hint[base >> 10], hi = dv.q_hint[(base >> 10) + 1];
+      while (lo < hi) {  // the last query that begins at or before `base`
+        const int mid = (lo + hi + 1) >> 1;
+        if (dv.pair_off[mid] <= base) lo = mid; else hi = mid - 1;
       }
       qn = lo;
+    } else {
+      qn = (int)((double)base * dv.queries_per_pair);
+      qn = qn < 0 ? 0 : (qn > dv.n_queries - 1 ? dv.n_queries - 1 : qn);
+      if (!(dv.pair_off[qn] <= base && base < dv.pair_off[qn + 1])) {
+        int lo = 0, hi = dv.n_queries;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (dv.pair_off[mid] <= base) lo = mid; else hi = mid;
+        }
+        qn = lo;
+      }
     }
     long next_q = dv.pair_off[qn + 1];
     while (p >= next_q) {

@@ -27,6 +27,15 @@ idx.set_doc_rows(np.arange(rows + 1, dtype=np.int64), np.arange(rows, dtype=np.i
 idx.set_psg_rows(np.arange(rows, dtype=np.int32))
 ids, sparse = B.candidates(rows, nq, k, 2024)
 pair_off = np.arange(nq + 1, dtype=np.int64) * k
+if len(sys.argv) > 1 and sys.argv[1] == "ragged":
+    # the same candidates cut into queries of 1 .. 2 k candidates (a first stage that returns what it finds): the proportional
+    # guess for a tile's query is off by hundreds of queries in the middle of the batch
+    rng = np.random.default_rng(5)
+    lens = rng.integers(1, 2 * k, size=nq)
+    lens = (lens * (len(ids) / lens.sum())).astype(np.int64)
+    lens[-1] += len(ids) - lens.sum()
+    assert lens.min() >= 0
+    pair_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
 queries = synth.rows(2027, scale, 0, nq, d)
 plan = native.Plan(idx)
 plan.set_queries(queries)
