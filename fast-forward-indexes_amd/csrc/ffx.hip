@@ -1209,6 +1209,7 @@ int ffx_plan_set_pairs(ffx_plan* pl, const int64_t* pair_off, int64_t n_queries,
   pl->mode = mode;
   pl->have_sparse = sparse != nullptr;
   pl->host_pair_off.assign(pair_off, pair_off + n_queries + 1);
+  pl->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   const size_t pb = std::max<size_t>((size_t)P, 1);
   FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
   FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
@@ -1374,6 +1375,7 @@ int ffx_plan_set_pairs_device(ffx_plan* pl, const int64_t* dev_pair_off, const i
   pl->mode = mode;
   pl->have_sparse = false;
   pl->host_pair_off.assign(host_pair_off, host_pair_off + n_queries + 1);
+  pl->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   const size_t pb = std::max<size_t>((size_t)P, 1);
   FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
   FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
@@ -1428,6 +1430,7 @@ int ffx_plan_copy_pairs(ffx_plan* dst, const ffx_plan* src) {
   dst->mode = src->mode;
   dst->have_sparse = src->have_sparse;
   dst->host_pair_off = src->host_pair_off;
+  dst->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   dst->order_base = src->order_base;
   dst->have_pairs = true;
   dst->derive_valid = false;
@@ -1459,6 +1462,7 @@ int ffx_plan_set_pairs_lazy(ffx_plan* pl, const int64_t* pair_off, int64_t n_que
   pl->mode = mode;
   pl->have_sparse = true;
   pl->host_pair_off.assign(pair_off, pair_off + n_queries + 1);
+  pl->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   const size_t pb = std::max<size_t>((size_t)P, 1);
   FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
   FFX_TRY(pl->pair_ids.ensure(pb * sizeof(int32_t)));
@@ -1518,6 +1522,7 @@ int ffx_plan_adopt_check(ffx_plan* pl, const int64_t* host_pair_off, hipStream_t
   pl->adopt_empty_index = (pl->mode == FFX_MODE_PASSAGE ? ix->n_psgs == 0 : ix->n_docs == 0) && pl->n_pairs > 0;
   FFX_HIP(hipSetDevice(pl->device));
   pl->host_pair_off.assign(host_pair_off, host_pair_off + pl->n_queries + 1);
+  pl->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   pl->hstage_used = 0;
   hipStream_t keep = pl->stream;
   pl->stream = stream;  // the validation belongs to the caller's stream, not to the one the plan scores on
@@ -2959,6 +2964,7 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
   pl->have_sparse = sparse != nullptr;
   pl->order_base = 0;
   pl->host_pair_off.assign(pair_off, pair_off + n_queries + 1);
+  pl->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   // page-locked memory is mapped into the device's address space: the kernels read and write the block itself
   if (!pl->small_flag.p) {
     FFX_TRY(pl->small_flag.ensure(sizeof(unsigned long long)));
@@ -3059,6 +3065,7 @@ static int plan_set_given(ffx_plan* pl, const int64_t* off, int64_t n_queries, c
   pl->n_pairs = pl->n_rows = P;
   pl->have_sparse = sparse != nullptr;
   pl->host_pair_off.assign(off, off + n_queries + 1);
+  pl->q_hint_valid = false;  // (the hint goes with the offsets it was made from: upload_query_hint makes a new one)
   const size_t pb = std::max<size_t>((size_t)P, 1) * 4;
   FFX_TRY(pl->pair_off.ensure((size_t)(n_queries + 1) * sizeof(int64_t)));
   FFX_TRY(pl->ff.ensure(pb));
