@@ -1593,13 +1593,14 @@ static int derive_tile(const ffx_plan* pl) {
 }
 
 // rows of this storage type and length, in this mode, have a row-deriving kernel (exact summation only)
-static bool derive_kernel_exists(const ffx_plan* pl) {
+static bool derive_kernel_exists(const ffx_plan* pl) {  // (one row per candidate: 411 - 417)
   const ffx_index* ix = pl->idx;
-  return (ix->dtype == FFX_DTYPE_F32 || ix->dtype == FFX_DTYPE_F16) && (ix->qdim == 768 || ix->qdim == 1024) && !pl->ov_dim &&
-         !ffx_debug_variant("no_derive", nullptr);
+  const int d = ix->qdim;
+  return (ix->dtype == FFX_DTYPE_F32 || ix->dtype == FFX_DTYPE_F16) && !pl->ov_dim && !ffx_debug_variant("no_derive", nullptr) &&
+         (d == 768 || d == 1024 || d == 512 || d == 384 || d == 256 || d == 128 || d == 64);
 }
-static bool derive_applies(const ffx_plan* pl) {  // (candidates of several rows)
-  return derive_kernel_exists(pl) && (pl->mode == FFX_MODE_MAXP || pl->mode == FFX_MODE_AVEP);
+static bool derive_applies(const ffx_plan* pl) {  // (candidates of several rows: 311 / 312)
+  return derive_kernel_exists(pl) && (pl->idx->qdim == 768 || pl->idx->qdim == 1024) && (pl->mode == FFX_MODE_MAXP || pl->mode == FFX_MODE_AVEP);
 }
 
 // pick and launch the gather_dot instantiation for rows of type T (float / _Float16); the
@@ -1758,11 +1759,15 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
           ffx::gather_dot_exact_lds_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});
         pl->variant = (pl->use_derive ? 312 : pl->use_derive1 ? 412 : 112) + HALF;
         break;
-#define FFX_MULTI(LEAVES, NPER, U, TILE, ID)                                                                     \
-  do {                                                                                                           \
-    ffx::gather_dot_exact_lds_multi_kernel<T, LEAVES, NPER, U, TILE, true><<<blocks_for(R, 4 * TILE), 256, 0, st>>>( \
-        V, Q, desc, rs, R);                                                                                      \
-    pl->variant = ID + HALF;                                                                                     \
+#define FFX_MULTI(LEAVES, NPER, U, TILE, ID)                                                                        \
+  do {                                                                                                              \
+    if (pl->use_derive1)                                                                                            \
+      ffx::gather_dot_exact_lds_multi_kernel<T, LEAVES, NPER, U, TILE, true, 2><<<blocks_for(R, 4 * TILE), 256, 0, st>>>( \
+          V, Q, nullptr, rs, R, plan_derive(pl));                                                                   \
+    else                                                                                                            \
+      ffx::gather_dot_exact_lds_multi_kernel<T, LEAVES, NPER, U, TILE, true><<<blocks_for(R, 4 * TILE), 256, 0, st>>>( \
+          V, Q, desc, rs, R, ffx::Derive{});                                                                        \
+    pl->variant = ID + (pl->use_derive1 ? 300 : 0) + HALF;                                                          \
   } while (0)
       // smaller rows: several rows share a wave, same full-line nt loads + LDS transpose
       case 512: FFX_MULTI(4, 16, 2, 16, 113); break;
@@ -2163,7 +2168,8 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (P > 0 && !pq_fused && !given) {
     // 1. candidates -> row list
     const double qpp = (double)pl->n_queries / (double)P;
-    if (single && exact && derive_kernel_exists(pl) && ix->capacity <= INT32_MAX && !pl->forced_pieces && !ffx_experiment("doc_major", nullptr)) {
+    if (single && exact && derive_kernel_exists(pl) && ix->capacity <= INT32_MAX && !pl->forced_pieces && !ffx_experiment("doc_major", nullptr) &&
+        !ffx_experiment("gather", nullptr)) {
       pl->use_derive1 = true;  // candidate -> row inside gather_dot: no launch here, no row list
     } else if (single) {
       FFX_TRY(pl->desc.ensure(std::max<size_t>((size_t)P, 1) * sizeof(int2)));

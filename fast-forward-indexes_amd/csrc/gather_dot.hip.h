@@ -228,6 +228,46 @@ struct Derive {
   const int32_t* q_hint = nullptr;    // query of candidate 0, 1024, 2048, ... and (last entry) the last query; nullptr: not given
 };
 
+// {row, query} of candidate base + my_t when every candidate has one row (DERIVE = 2)
+__device__ __forceinline__ int2 derive_one_row(const Derive& dv, long base, int my_t) {
+  const long p = base + my_t;
+  const int o = dv.pair_ids[p];
+  int rid = dv.row_of ? dv.row_of[o] : o;
+  // (validated ordinals always give a row of the store; the clamp is for ffx_score's single-submission path, where the verdict
+  // on a bad ordinal is read back only after the kernels behind this one have run)
+  rid = (unsigned)rid < (unsigned)dv.n_index_rows ? rid : 0;
+  // the query of the tile's first candidate (uniform), then forward: a tile rarely crosses a query boundary.  With the host's
+  // hint (the query of every 1024th candidate) the search runs between two neighbouring entries: no step at all where
+  // queries are longer than 1024 candidates, however ragged the lists; without it (lists made on the device) the
+  // proportional guess, then a search over all queries
+  int qn;
+  if (dv.q_hint) {
+    int lo = dv.q_hint[base >> 10], hi = dv.q_hint[(base >> 10) + 1];
+    while (lo < hi) {  // the last query that begins at or before `base`
+      const int mid = (lo + hi + 1) >> 1;
+      if (dv.pair_off[mid] <= base) lo = mid; else hi = mid - 1;
+    }
+    qn = lo;
+  } else {
+    qn = (int)((double)base * dv.queries_per_pair);
+    qn = qn < 0 ? 0 : (qn > dv.n_queries - 1 ? dv.n_queries - 1 : qn);
+    if (!(dv.pair_off[qn] <= base && base < dv.pair_off[qn + 1])) {
+      int lo = 0, hi = dv.n_queries;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (dv.pair_off[mid] <= base) lo = mid; else hi = mid;
+      }
+      qn = lo;
+    }
+  }
+  long next_q = dv.pair_off[qn + 1];
+  while (p >= next_q) {
+    ++qn;
+    next_q = dv.pair_off[qn + 1];
+  }
+  return make_int2(rid, qn);
+}
+
 template <typename T, int NCH, int U, int TILE, bool NT, int DERIVE = 0>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
@@ -249,42 +289,7 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   const int my_t = lane < n_here ? lane : n_here - 1;
   int2 my;
   if constexpr (DERIVE == 2) {
-    const long p = base + my_t;
-    const int o = dv.pair_ids[p];
-    int rid = dv.row_of ? dv.row_of[o] : o;
-    // (validated ordinals always give a row of the store; the clamp is for ffx_score's single-submission path, where the verdict
-    // on a bad ordinal is read back only after the kernels behind this one have run)
-    rid = (unsigned)rid < (unsigned)dv.n_index_rows ? rid : 0;
-    // the query of the tile's first candidate (uniform), then forward: a tile rarely crosses a query boundary.  With the host's
-    // hint (the query of every 1024th candidate) the search runs between two neighbouring entries: no step at all where
-    // queries are longer than 1024 candidates, however ragged the lists; without it (lists made on the device) the
-    // proportional guess, then a search over all queries
-    int qn;
-    if (dv.q_hint) {
-      int lo = dv.q_hint[base >> 10], hi = dv.q_hint[(base >> 10) + 1];
-      while (lo < hi) {  // the last query that begins at or before `base`
-        const int mid = (lo + hi + 1) >> 1;
-        if (dv.pair_off[mid] <= base) lo = mid; else hi = mid - 1;
-      }
-      qn = lo;
-    } else {
-      qn = (int)((double)base * dv.queries_per_pair);
-      qn = qn < 0 ? 0 : (qn > dv.n_queries - 1 ? dv.n_queries - 1 : qn);
-      if (!(dv.pair_off[qn] <= base && base < dv.pair_off[qn + 1])) {
-        int lo = 0, hi = dv.n_queries;
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (dv.pair_off[mid] <= base) lo = mid; else hi = mid;
-        }
-        qn = lo;
-      }
-    }
-    long next_q = dv.pair_off[qn + 1];
-    while (p >= next_q) {
-      ++qn;
-      next_q = dv.pair_off[qn + 1];
-    }
-    my = make_int2(rid, qn);
+    my = derive_one_row(dv, base, my_t);
   } else if constexpr (DERIVE == 1) {
     const int2 first = dv.tile_tab[wave];  // (uniform: one scalar load)
     const int p_mine = first.x + lane;
@@ -459,10 +464,10 @@ gather_dot_exact_lds_persistent_kernel(const T* __restrict__ vectors, const floa
 // in row e / D at offset e % D, leaf e / LL -- so the LDS transpose is the 8-leaf one above, the
 // only differences being per-lane row/query addresses and a shorter butterfly (a row's partial
 // sums occupy 8*LEAVES adjacent lanes; lane 8*LEAVES*s ends with the score of the pass's row s).
-template <typename T, int LEAVES, int NPER, int U, int TILE, bool NT>
+template <typename T, int LEAVES, int NPER, int U, int TILE, bool NT, int DERIVE = 0>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_lds_multi_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
-                                  const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+                                  const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, const Derive dv) {
   constexpr int LPR = 8 * LEAVES;     // lanes per row in the summation phase
   constexpr int RPP = 64 / LPR;       // rows per pass
   constexpr int D = LPR * NPER;
@@ -481,7 +486,7 @@ gather_dot_exact_lds_multi_kernel(const T* __restrict__ vectors, const float* __
   if (base >= n_rows) return;
   const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
   const int my_t = lane < n_here ? lane : n_here - 1;
-  const int2 my = desc[base + my_t];
+  const int2 my = DERIVE == 2 ? derive_one_row(dv, base, my_t) : desc[base + my_t];
 
   float* buf = tile[wave_in_block];
   int woff[NCH], slot[NCH], roff[NCH];

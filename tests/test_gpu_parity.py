@@ -508,6 +508,15 @@ def test_every_kernel_variant_exact(d, store):
     want, _ = fo.score(vectors, np.arange(n + 1), np.arange(n), np.arange(n), queries, pair_off, pair_ids, 2)
     assert np.array_equal(bits(ff), bits(want)), f"d={d} variant {st['kernel_variant']}"
     assert (st["kernel_variant"] % 10000 >= 1000) == (store == np.float16)
+    rows_found_in_kernel = {768: 411, 1024: 412, 512: 413, 384: 414, 256: 415, 128: 416, 64: 417}
+    if d in rows_found_in_kernel:  # one row per candidate: no row list; the row-list form (no_derive) gives the same bits
+        assert st["kernel_variant"] % 1000 == rows_found_in_kernel[d]
+        os.environ["FFX_DEBUG_VARIANT"] = "no_derive"
+        try:
+            ff_list, _, _, st_list = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=True)
+        finally:
+            del os.environ["FFX_DEBUG_VARIANT"]
+        assert st_list["kernel_variant"] % 1000 == rows_found_in_kernel[d] - 300 and np.array_equal(bits(ff_list), bits(ff))
     if d in (1536, 2048, 3072, 4096, 6144, 8192):  # S * 10000 + the variant of the short-row kernel
         base = 768 if d % 768 == 0 else 1024
         assert st["kernel_variant"] // 10000 == d // base and st["kernel_variant"] % 1000 == (111 if base == 768 else 112)
