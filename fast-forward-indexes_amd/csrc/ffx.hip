@@ -333,7 +333,7 @@ struct ffx_plan {
   bool derive_valid = false, use_derive = false, use_derive1 = false;
   // for the one-row derive: the query of every 1024th candidate (made on the host from the offsets it validates anyway and
   // uploaded with them), so that a wave finds its tile's query in a step or two however ragged the lists are
-  static constexpr int64_t kHintBlock = 1024;
+  static constexpr int64_t kHintBlock = int64_t(1) << ffx::kQueryHintShift;
   DevBuf q_hint;
   std::vector<int32_t> host_hint;
   bool q_hint_valid = false;

@@ -210,8 +210,10 @@ gather_dot_exact_kernel(const T* __restrict__ vectors, const float* __restrict__
 // an expand kernel and read back here (1.26 GB each way at 157 M rows).
 // DERIVE = 2 (one row per candidate: PASSAGE, FIRSTP, documents of one passage): row t of the tile IS candidate base + t -- its
 // row is `row_of[ordinal]` (or the ordinal itself when ordinals are rows), its query the one whose candidate list holds that
-// position (the proportional guess of query_of_pair for the tile's first candidate, stepped forward per lane).  No expand launch
-// and no row list here either: the kernel reads 4 bytes per candidate where it read 8.
+// position (found from the host's hint -- the query of every (1 << kQueryHintShift)-th candidate -- or, without one, from a
+// proportional guess; then stepped forward per lane).  No expand launch and no row list here either: the kernel reads 4 bytes
+// per candidate where it read 8.
+constexpr int kQueryHintShift = 10;  // the hint names the query of candidates 0, 1024, 2048, ... (ffx_plan::kHintBlock in ffx.hip)
 struct Derive {
   const int2* tile_tab = nullptr;       // per tile: {candidate of the tile's first row, query of that candidate}
   const int32_t* seg_off = nullptr;     // [n_pairs + 1] first row of every candidate in the (virtual) row list
@@ -242,7 +244,7 @@ __device__ __forceinline__ int2 derive_one_row(const Derive& dv, long base, int 
   // proportional guess, then a search over all queries
   int qn;
   if (dv.q_hint) {
-    int lo = dv.q_hint[base >> 10], hi = dv.q_hint[(base >> 10) + 1];
+    int lo = dv.q_hint[base >> kQueryHintShift], hi = dv.q_hint[(base >> kQueryHintShift) + 1];
     while (lo < hi) {  // the last query that begins at or before `base`
       const int mid = (lo + hi + 1) >> 1;
       if (dv.pair_off[mid] <= base) lo = mid; else hi = mid - 1;
