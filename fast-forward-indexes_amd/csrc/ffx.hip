@@ -1592,14 +1592,15 @@ static int derive_tile(const ffx_plan* pl) {
   return pl->idx->dtype == FFX_DTYPE_F16 ? 16 : 8;
 }
 
-// rows of this storage type and length, in this mode, have a row-deriving kernel (exact summation only)
-static bool derive_kernel_exists(const ffx_plan* pl) {  // (one row per candidate: 411 - 417)
+// rows of this storage type and length, in this mode, have a row-deriving kernel (either summation order: the fast order
+// of d = 384 / 128 / 64 is served by the exact kernels)
+static bool derive_kernel_exists(const ffx_plan* pl) {  // (one row per candidate: 411 - 417, 611 - 614)
   const ffx_index* ix = pl->idx;
   const int d = ix->qdim;
   return (ix->dtype == FFX_DTYPE_F32 || ix->dtype == FFX_DTYPE_F16) && !pl->ov_dim && !ffx_debug_variant("no_derive", nullptr) &&
          (d == 768 || d == 1024 || d == 512 || d == 384 || d == 256 || d == 128 || d == 64);
 }
-static bool derive_applies(const ffx_plan* pl) {  // (candidates of several rows: 311 / 312)
+static bool derive_applies(const ffx_plan* pl) {  // (candidates of several rows: 311 / 312, 511 / 512)
   return derive_kernel_exists(pl) && (pl->idx->qdim == 768 || pl->idx->qdim == 1024) && (pl->mode == FFX_MODE_MAXP || pl->mode == FFX_MODE_AVEP);
 }
 
@@ -1698,11 +1699,11 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
       case 923: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 8, true, false><<<256 * 12, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 924: ffx::gather_dot_exact_lds_persistent_kernel<T, 3, 4, 16, true, true><<<256 * 6, 256, 0, st>>>(V, Q, desc, rs, R); break;
       case 925: ffx::gather_dot_exact_lds_kernel<T, 3, 4, 8, true><<<blocks_for(waves, 2 * 8), 128, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;  // workgroups of two waves
-      case 951: ffx::gather_dot_fast_kernel<T, 3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 953: ffx::gather_dot_fast_kernel<T, 3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 958: ffx::gather_dot_fast_kernel<T, 3, 8, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R); break;
-      case 959: ffx::gather_dot_fast_kernel<T, 3, 16, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R); break;
+      case 951: ffx::gather_dot_fast_kernel<T, 3, 4, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;
+      case 953: ffx::gather_dot_fast_kernel<T, 3, 8, 32, true><<<blocks_for(R, 128), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;
+      case 955: ffx::gather_dot_fast_kernel<T, 3, 4, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;
+      case 958: ffx::gather_dot_fast_kernel<T, 3, 8, 8, true><<<blocks_for(R, 32), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;
+      case 959: ffx::gather_dot_fast_kernel<T, 3, 16, 16, true><<<blocks_for(R, 64), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{}); break;
       default: return fail(FFX_BAD_ARG, "unknown gather variant %d (FFX_DEBUG_VARIANT)", exp_variant);
     }
     pl->variant = exp_variant;
@@ -1862,10 +1863,25 @@ static int launch_gather_dot_t(ffx_plan* pl, bool exact, float* rs) {
     }
   } else {
     switch (d) {
-      case 768: ffx::gather_dot_fast_kernel<T, 3, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 211 + HALF; break;
-      case 1024: ffx::gather_dot_fast_kernel<T, 4, UL / 2, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 212 + HALF; break;
-      case 512: ffx::gather_dot_fast_kernel<T, 2, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 213 + HALF; break;
-      case 256: ffx::gather_dot_fast_kernel<T, 1, UL, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R); pl->variant = 214 + HALF; break;
+      // row list: 211 - 214; rows derived in the kernel, as in the exact kernels: several per candidate 511 / 512, one 611 - 614
+#define FFX_FAST(NCH, U, ID)                                                                                                            \
+  do {                                                                                                                                  \
+    if (pl->use_derive) {                                                                                                               \
+      ffx::gather_dot_fast_kernel<T, NCH, U, TL, true, 1><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));  \
+      pl->variant = ID + 300 + HALF;                                                                                                    \
+    } else if (pl->use_derive1) {                                                                                                       \
+      ffx::gather_dot_fast_kernel<T, NCH, U, TL, true, 2><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, nullptr, rs, R, plan_derive(pl));  \
+      pl->variant = ID + 400 + HALF;                                                                                                    \
+    } else {                                                                                                                            \
+      ffx::gather_dot_fast_kernel<T, NCH, U, TL, true><<<blocks_for(R, 4 * TL), 256, 0, st>>>(V, Q, desc, rs, R, ffx::Derive{});         \
+      pl->variant = ID + HALF;                                                                                                          \
+    }                                                                                                                                   \
+  } while (0)
+      case 768: FFX_FAST(3, UL, 211); break;
+      case 1024: FFX_FAST(4, UL / 2, 212); break;
+      case 512: FFX_FAST(2, UL, 213); break;  // (use_derive is never set here: derive_applies)
+      case 256: FFX_FAST(1, UL, 214); break;
+#undef FFX_FAST
       default:
         // dims with a multi-row exact kernel but no FMA specialisation: the exact kernel is HBM-bound
         // too (and 1.3-2.8x faster than the one-row-per-wave generic kernel), so "fast" uses it
@@ -2168,7 +2184,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
   if (P > 0 && !pq_fused && !given) {
     // 1. candidates -> row list
     const double qpp = (double)pl->n_queries / (double)P;
-    if (single && exact && derive_kernel_exists(pl) && ix->capacity <= INT32_MAX && !pl->forced_pieces && !ffx_experiment("doc_major", nullptr) &&
+    if (single && derive_kernel_exists(pl) && ix->capacity <= INT32_MAX && !pl->forced_pieces && !ffx_experiment("doc_major", nullptr) &&
         !ffx_experiment("gather", nullptr)) {
       pl->use_derive1 = true;  // candidate -> row inside gather_dot: no launch here, no row list
     } else if (single) {
@@ -2177,7 +2193,7 @@ int ffx_plan_run(ffx_plan* pl, double alpha, uint32_t flags) {
                                                            : (ix->docs_identity ? nullptr : ix->doc_first.as<int32_t>());
       ffx::expand_single_kernel<<<blocks_for((P + 3) / 4, 256), 256, 0, st>>>(
           pl->pair_ids.as<int32_t>(), P, pl->pair_off.as<int64_t>(), (int)pl->n_queries, qpp, row_of, ix->capacity, pl->desc.as<int2>());
-    } else if (exact && derive_applies(pl)) {
+    } else if (derive_applies(pl)) {
       // no row list: the scoring kernel derives its rows from the candidate lists, the row offsets (the scan of set_pairs is
       // still there) and two small tables made on the first run of a candidate list (4 B per candidate, 8 B per tile)
       pl->use_derive = true;

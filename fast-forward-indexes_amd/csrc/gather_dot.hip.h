@@ -270,6 +270,36 @@ __device__ __forceinline__ int2 derive_one_row(const Derive& dv, long base, int 
   return make_int2(rid, qn);
 }
 
+// {row, query} of row base + my_t of a wave's tile: read from the row list (DERIVE = 0) or worked out here (see above);
+// `wave` = the tile's number (DERIVE = 1: tile_tab was made for tiles of TILE rows)
+template <int DERIVE, int TILE>
+__device__ __forceinline__ int2 tile_row(const int2* __restrict__ desc, const Derive& dv, int wave, long base, int my_t, int lane) {
+  if constexpr (DERIVE == 2) {
+    return derive_one_row(dv, base, my_t);
+  } else if constexpr (DERIVE == 1) {
+    static_assert(TILE < 64, "TILE + 1 lanes read the row offsets");
+    const int2 first = dv.tile_tab[wave];  // (uniform: one scalar load)
+    const int p_mine = first.x + lane;
+    const int so = lane <= TILE ? dv.seg_off[p_mine < dv.n_pairs ? p_mine : dv.n_pairs] : 0x7fffffff;
+    const int pf = dv.pair_first[p_mine < dv.n_pairs ? p_mine : dv.n_pairs - 1];
+    long next_q = dv.pair_off[first.y + 1];
+    const int r = (int)base + my_t;
+    int j = 0;  // how many of the TILE candidates after the first begin at or before my row
+#pragma unroll
+    for (int l = 1; l <= TILE; ++l) j += __builtin_amdgcn_readlane(so, l) <= r ? 1 : 0;
+    int rid = __shfl(pf, j) + (r - __shfl(so, j));
+    if (dv.doc_rows) rid = dv.doc_rows[rid];
+    int qn = first.y;
+    while (first.x + j >= next_q) {  // my candidate lies in a later query (queries without candidates are stepped over)
+      ++qn;
+      next_q = dv.pair_off[qn + 1];
+    }
+    return make_int2(rid, qn);
+  } else {
+    return desc[base + my_t];
+  }
+}
+
 template <typename T, int NCH, int U, int TILE, bool NT, int DERIVE = 0>
 __global__ void __launch_bounds__(256)
 gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
@@ -289,30 +319,7 @@ gather_dot_exact_lds_kernel(const T* __restrict__ vectors, const float* __restri
   if (base >= n_rows) return;
   const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
   const int my_t = lane < n_here ? lane : n_here - 1;
-  int2 my;
-  if constexpr (DERIVE == 2) {
-    my = derive_one_row(dv, base, my_t);
-  } else if constexpr (DERIVE == 1) {
-    const int2 first = dv.tile_tab[wave];  // (uniform: one scalar load)
-    const int p_mine = first.x + lane;
-    const int so = lane <= TILE ? dv.seg_off[p_mine < dv.n_pairs ? p_mine : dv.n_pairs] : 0x7fffffff;
-    const int pf = dv.pair_first[p_mine < dv.n_pairs ? p_mine : dv.n_pairs - 1];
-    long next_q = dv.pair_off[first.y + 1];
-    const int r = (int)base + my_t;
-    int j = 0;  // how many of the TILE candidates after the first begin at or before my row
-#pragma unroll
-    for (int l = 1; l <= TILE; ++l) j += __builtin_amdgcn_readlane(so, l) <= r ? 1 : 0;
-    int rid = __shfl(pf, j) + (r - __shfl(so, j));
-    if (dv.doc_rows) rid = dv.doc_rows[rid];
-    int qn = first.y;
-    while (first.x + j >= next_q) {  // my candidate lies in a later query (queries without candidates are stepped over)
-      ++qn;
-      next_q = dv.pair_off[qn + 1];
-    }
-    my = make_int2(rid, qn);
-  } else {
-    my = desc[base + my_t];
-  }
+  const int2 my = tile_row<DERIVE, TILE>(desc, dv, wave, base, my_t, lane);
 
   float* buf = tile[wave_in_block];
   // where this lane's NCH float4 of products go, and where its NPER summands come from
@@ -488,7 +495,8 @@ gather_dot_exact_lds_multi_kernel(const T* __restrict__ vectors, const float* __
   if (base >= n_rows) return;
   const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
   const int my_t = lane < n_here ? lane : n_here - 1;
-  const int2 my = DERIVE == 2 ? derive_one_row(dv, base, my_t) : desc[base + my_t];
+  static_assert(DERIVE != 1, "several rows per candidate: the 8-leaf kernels only");
+  const int2 my = tile_row<DERIVE, TILE>(desc, dv, wave, base, my_t, lane);
 
   float* buf = tile[wave_in_block];
   int woff[NCH], slot[NCH], roff[NCH];
@@ -551,10 +559,11 @@ gather_dot_exact_lds_multi_kernel(const T* __restrict__ vectors, const float* __
 }
 
 // ---- fast kernel, d = 256*NCH: lane holds NCH float4 per row (16-B coalesced loads) --------
-template <typename T, int NCH, int U, int TILE = 16, bool NT = false>
+// DERIVE: as in gather_dot_exact_lds_kernel (no row list; 1 = several rows per candidate, 2 = one)
+template <typename T, int NCH, int U, int TILE = 16, bool NT = false, int DERIVE = 0>
 __global__ void __launch_bounds__(256)
 gather_dot_fast_kernel(const T* __restrict__ vectors, const float* __restrict__ queries,
-                       const int2* __restrict__ desc, float* __restrict__ rs, int n_rows) {
+                       const int2* __restrict__ desc, float* __restrict__ rs, int n_rows, const Derive dv) {
   constexpr int D = 256 * NCH;
   static_assert(TILE % U == 0, "TILE must be a multiple of U");
   const int lane = threadIdx.x & 63;
@@ -564,7 +573,7 @@ gather_dot_fast_kernel(const T* __restrict__ vectors, const float* __restrict__ 
   if (base >= n_rows) return;
   const int n_here = (n_rows - base) < TILE ? (int)(n_rows - base) : TILE;
   const int my_t = lane < n_here ? lane : n_here - 1;
-  const int2 my = desc[base + my_t];
+  const int2 my = tile_row<DERIVE, TILE>(desc, dv, wave, base, my_t, lane);
 
   float4 q[NCH];
   int cur_q = -1;

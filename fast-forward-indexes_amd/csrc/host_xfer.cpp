@@ -13,6 +13,7 @@
 
 #include "../../include/ffx.h"
 #include "../../include/ffx_private.h"
+#include "ffx_internal.h"
 
 int ffx_fail(int code, const char* fmt, ...);  // ffx.hip
 extern thread_local std::string g_last_error;
@@ -23,7 +24,8 @@ constexpr size_t kDirectBytes = size_t(1) << 20;  // at or below: the runtime co
 // (1 MiB pieces were tried -- less to fill before the wire is busy, less to drain at the end: the calls into the runtime, two per
 // piece from four threads onto one stream, then cost more than the shorter fill saved: 1.9 instead of 1.4 ms for a 50 MB upload)
 constexpr size_t kPiece = size_t(4) << 20;
-constexpr int kLanes = 4;       // host threads (and copy streams) a large transfer is spread over
+constexpr int kLanes = 4;       // host threads a large transfer is spread over
+constexpr int kLaneRoom = 8;    // (the experiments build can try more: xfer_lanes=N)
 constexpr int kMaxDevices = 64;
 
 #define X_HIP(expr)                                                                                              \
@@ -64,7 +66,7 @@ struct Lane {
 // waits behind its kernels (measured: 3.2 ms instead of 0.1 ms for a 4 MB upload next to the scoring kernels).
 struct Way {
   std::mutex mu;
-  Lane lanes[kLanes];
+  Lane lanes[kLaneRoom];
 };
 
 struct DeviceWays {
@@ -86,7 +88,9 @@ std::atomic<unsigned long long> g_staged_transfers{0}, g_staged_bytes{0};
 int lanes_for(size_t bytes) {
   const size_t pieces = (bytes + kPiece - 1) / kPiece;
   // a thread per 8 MiB at least: starting one costs what copying ~1 MiB does
-  return (int)std::max<size_t>(1, std::min<size_t>(kLanes, pieces / 2));
+  size_t most = kLanes;
+  if (long long v = 0; ffx_experiment("xfer_lanes", &v) && v >= 1 && v <= kLaneRoom) most = (size_t)v;
+  return (int)std::max<size_t>(1, std::min<size_t>(most, pieces / 2));
 }
 
 template <class Body>
@@ -179,7 +183,13 @@ int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* 
     }
     return FFX_OK;
   });
-  if (rc != FFX_OK) return rc;
+  if (rc != FFX_OK) {
+    // some pieces may be on their way out of the blocks with no event behind them (a failed record): wait them out here, so
+    // that the blocks are free for the next transfer whatever the flags say
+    (void)hipStreamSynchronize(stream);
+    for (int t = 0; t < T; ++t) w.lanes[t].busy[0] = w.lanes[t].busy[1] = false;
+    return rc;
+  }
   g_staged_transfers.fetch_add((unsigned long long)staged_parts, std::memory_order_relaxed);
   g_staged_bytes.fetch_add(staged_bytes, std::memory_order_relaxed);
   return FFX_OK;

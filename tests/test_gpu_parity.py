@@ -447,10 +447,17 @@ def test_rows_derived_inside_gather_dot_for_documents_of_several_passages(monkey
             assert plan.stats()["kernel_variant"] == (111 if d == 768 else 112) + half
             assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp))
             monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
-            # the fast summation order has no row-deriving kernel: the row list is made when such a run asks for it
+            # the fast summation order derives its rows too (511 / 512): within tolerance of the oracle, and the bits of its own
+            # row-list form (211 / 212: the row list is made on the run that asks for it)
             plan.run(0.3, exact_sum=False)
             ff3, _, _ = plan.fetch()
+            assert plan.stats()["kernel_variant"] == (511 if d == 768 else 512) + half
             assert np.abs(ff3 - want).max() <= FAST_TOL * 10
+            monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_derive")
+            plan.run(0.3, exact_sum=False)
+            ff3_list, _, _ = plan.fetch()
+            assert plan.stats()["kernel_variant"] == (211 if d == 768 else 212) + half and np.array_equal(bits(ff3_list), bits(ff3))
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
             # ... and through ffx_score, slices of whole queries
             monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_small_path,score_slice_pairs=250")
             ff4, interp4, order4, st = native.score(idx, queries, pair_off, pair_ids, mode, sparse, 0.3, sort=True)
@@ -475,6 +482,14 @@ def test_rows_derived_inside_gather_dot_for_documents_of_several_passages(monkey
             ff2, interp2, _ = plan.fetch(interp=True)
             assert plan.stats()["kernel_variant"] == (111 if d == 768 else 112) + half
             assert np.array_equal(bits(ff2), bits(ff)) and np.array_equal(bits(interp2), bits(interp))
+            plan.run(0.3, exact_sum=False)  # (the fast order from the row list: 211 / 212 ...)
+            fast_list, _, _ = plan.fetch()
+            assert plan.stats()["kernel_variant"] == (211 if d == 768 else 212) + half
+            monkeypatch.delenv("FFX_DEBUG_VARIANT", raising=False)
+            plan.run(0.3, exact_sum=False)  # (... and with the row looked up in the kernel: 611 / 612, same bits)
+            fast, _, _ = plan.fetch()
+            assert plan.stats()["kernel_variant"] == (611 if d == 768 else 612) + half and np.array_equal(bits(fast), bits(fast_list))
+            assert np.abs(fast - want).max() <= FAST_TOL * 10
             monkeypatch.setenv("FFX_DEBUG_VARIANT", "no_small_path,score_slice_pairs=250")
             ff4, interp4, order4, st = native.score(idx, queries, pair_off, ids1, mode, sparse, 0.3, sort=True)
             assert st["kernel_variant"] == (411 if d == 768 else 412) + half
@@ -525,6 +540,16 @@ def test_every_kernel_variant_exact(d, store):
     assert np.array_equal(bits(ff), bits(ref))
     ff_fast, _, _, st = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=False)
     assert np.abs(ff_fast - want).max() <= FAST_TOL * max(1.0, float(np.abs(want).max())), f"d={d} variant {st['kernel_variant']}"
+    fast_rows_found_in_kernel = {768: 611, 1024: 612, 512: 613, 256: 614, 384: 414, 128: 416, 64: 417}  # (384 / 128 / 64: the exact kernels serve)
+    if d in fast_rows_found_in_kernel:
+        assert st["kernel_variant"] % 1000 == fast_rows_found_in_kernel[d]
+        os.environ["FFX_DEBUG_VARIANT"] = "no_derive"
+        try:
+            fast_list, _, _, st_list = native.score(idx, queries, pair_off, pair_ids, 2, exact_sum=False)
+        finally:
+            del os.environ["FFX_DEBUG_VARIANT"]
+        assert st_list["kernel_variant"] % 1000 == fast_rows_found_in_kernel[d] - (400 if d in (768, 1024, 512, 256) else 300)
+        assert np.array_equal(bits(fast_list), bits(ff_fast))
     idx.close()
 
 

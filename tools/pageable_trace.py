@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """ffx_score at the headline size with ORDINARY (not page-locked) buffers both ways, written before: best of 5 calls and the
-host-side timeline of one (FFX_SCORE_TRACE=1).  argv[1]: 'in' = only the inputs ordinary, 'out' = only the outputs, default both."""
+host-side timeline of one (FFX_SCORE_TRACE=1).  argv[1]: 'in' = only the inputs ordinary, 'out' = only the outputs, 'both'; argv[2:]: the
+FFX_DEBUG_VARIANT settings to time one after the other (experiments build)."""
 import json
 import os
 import sys
@@ -45,7 +46,9 @@ for _ in range(5):
     run()
     ts.append(time.perf_counter() - t0)
 print(json.dumps({"ordinary": which, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}))
-for plans in ("score_plans=3", "score_plans=4", "score_plans=5", "score_ramp_growth_pct=150", "score_ramp_growth_pct=150,score_ramp_pairs=400000", "score_ramp_growth_pct=170", "score_ramp_growth_pct=130,score_ramp_pairs=400000"):
+VARIANTS = sys.argv[2:] or ["score_plans=3", "score_plans=4", "score_plans=5", "score_ramp_growth_pct=150", "score_ramp_growth_pct=150,score_ramp_pairs=400000",
+                            "score_ramp_growth_pct=170", "score_ramp_growth_pct=130,score_ramp_pairs=400000"]
+for plans in VARIANTS:  # (argv[2:]: the switches to try instead, e.g. xfer_lanes=2 xfer_lanes=4 xfer_lanes=6 xfer_lanes=8)
     os.environ["FFX_DEBUG_VARIANT"] = plans
     run()
     ts = []
