@@ -85,9 +85,17 @@ DeviceWays* ways_of(int device) {
 
 std::atomic<unsigned long long> g_staged_transfers{0}, g_staged_bytes{0};
 
-int lanes_for(size_t bytes) {
-  const size_t pieces = (bytes + kPiece - 1) / kPiece;
-  // a thread per 8 MiB at least: starting one costs what copying ~1 MiB does
+// the piece size of a staged transfer.  Cutting small transfers finer (the first slices of an ffx_score call are 6 - 25 MB) so that
+// the wire has something to do sooner was tried: 1 MiB pieces below 12 MB, 2 MiB below 32 MB gave 18.6 ms against 18.45 for the
+// headline call with ordinary buffers -- the calls into the runtime cost what the earlier start saves (profiles/r05/xfer_piece_sweep.txt)
+size_t piece_for(size_t) {
+  if (long long v = 0; ffx_experiment("xfer_piece_kb", &v) && v >= 64 && (size_t)v * 1024 <= kPiece) return (size_t)v * 1024;
+  return kPiece;
+}
+
+int lanes_for(size_t bytes, size_t piece) {
+  const size_t pieces = (bytes + piece - 1) / piece;
+  // two pieces per thread at least: starting one costs what copying ~1 MiB does
   size_t most = kLanes;
   if (long long v = 0; ffx_experiment("xfer_lanes", &v) && v >= 1 && v <= kLaneRoom) most = (size_t)v;
   return (int)std::max<size_t>(1, std::min<size_t>(most, pieces / 2));
@@ -142,8 +150,8 @@ int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* 
     size_t len;
   };
   std::vector<Piece> pieces;
+  std::vector<int> staged;  // the parts that travel through the blocks
   size_t staged_bytes = 0;
-  int staged_parts = 0;
   for (int i = 0; i < n_parts; ++i) {
     const size_t bytes = sizes[i];
     if (bytes == 0) continue;
@@ -152,18 +160,21 @@ int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* 
       X_HIP(hipMemcpyAsync(dsts[i], srcs[i], bytes, hipMemcpyHostToDevice, stream));
       continue;
     }
-    for (size_t at = 0; at < bytes; at += kPiece)
-      pieces.push_back({static_cast<char*>(dsts[i]) + at, static_cast<const char*>(srcs[i]) + at, std::min(kPiece, bytes - at)});
+    staged.push_back(i);
     staged_bytes += bytes;
-    ++staged_parts;
   }
-  if (pieces.empty()) return FFX_OK;
+  if (staged.empty()) return FFX_OK;
+  const size_t piece = piece_for(staged_bytes);
+  for (int i : staged)
+    for (size_t at = 0; at < sizes[i]; at += piece)
+      pieces.push_back({static_cast<char*>(dsts[i]) + at, static_cast<const char*>(srcs[i]) + at, std::min(piece, sizes[i] - at)});
+  const int staged_parts = (int)staged.size();
   DeviceWays* dw = ways_of(device);
   if (!dw) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: device %d", device);
   Way& w = dw->in;
   std::lock_guard<std::mutex> lock(w.mu);
   X_HIP(hipSetDevice(device));
-  const int T = lanes_for(staged_bytes);
+  const int T = lanes_for(staged_bytes, piece);
   for (int t = 0; t < T; ++t) {
     const int rc = w.lanes[t].make();
     if (rc != FFX_OK) return rc;
@@ -211,7 +222,7 @@ int ffx_d2h(int device, void* dst, const void* src, size_t bytes, hipStream_t st
   Way& w = dw->out;
   std::lock_guard<std::mutex> lock(w.mu);
   X_HIP(hipSetDevice(device));
-  const int T = lanes_for(bytes);
+  const int T = lanes_for(bytes, kPiece);
   for (int t = 0; t < T; ++t) {
     const int rc = w.lanes[t].make();
     if (rc != FFX_OK) return rc;

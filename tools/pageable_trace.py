@@ -48,15 +48,27 @@ for _ in range(5):
 print(json.dumps({"ordinary": which, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}))
 VARIANTS = sys.argv[2:] or ["score_plans=3", "score_plans=4", "score_plans=5", "score_ramp_growth_pct=150", "score_ramp_growth_pct=150,score_ramp_pairs=400000",
                             "score_ramp_growth_pct=170", "score_ramp_growth_pct=130,score_ramp_pairs=400000"]
-for plans in VARIANTS:  # (argv[2:]: the switches to try instead, e.g. xfer_lanes=2 xfer_lanes=4 xfer_lanes=6 xfer_lanes=8)
-    os.environ["FFX_DEBUG_VARIANT"] = plans
+for plans in VARIANTS:  # (argv[2:]: the switches to try instead, e.g. xfer_lanes=2 xfer_lanes=4; "none" = no switch; "trace:<switches>" = one traced call)
+    traced = plans.startswith("trace:")
+    setting = plans[6:] if traced else plans
+    if setting in ("", "none"):
+        os.environ.pop("FFX_DEBUG_VARIANT", None)
+    else:
+        os.environ["FFX_DEBUG_VARIANT"] = setting
     run()
+    if traced:
+        print(f"--- timeline with {setting or 'none'}", flush=True)
+        os.environ["FFX_SCORE_TRACE"] = "1"
+        run()
+        os.environ.pop("FFX_SCORE_TRACE")
+        continue
     ts = []
     for _ in range(7):
         t0 = time.perf_counter()
         run()
         ts.append(time.perf_counter() - t0)
-    print(json.dumps({"variant": plans, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}))
-os.environ.pop("FFX_DEBUG_VARIANT")
-os.environ["FFX_SCORE_TRACE"] = "1"
-run()
+    print(json.dumps({"variant": plans, "best_ms": min(ts) * 1e3, "median_ms": float(np.median(ts)) * 1e3}), flush=True)
+os.environ.pop("FFX_DEBUG_VARIANT", None)
+if len(sys.argv) <= 2:
+    os.environ["FFX_SCORE_TRACE"] = "1"
+    run()
