@@ -377,7 +377,7 @@ struct ffx_plan {
   static constexpr size_t kStageBytes = 4 << 20;
   // results of a slice of ffx_score on their way into ORDINARY memory of the caller (the helper thread of that slice): two
   // page-locked blocks and a stream of the plan's own, see staged_d2h
-  static constexpr size_t kOutStageBytes = 4 << 20;
+  static constexpr size_t kOutStageBytes = 8 << 20;  // (a copy command costs the wire ~20 us whatever its size: 4 MiB pieces leave at 45 GB/s, 8 MiB at 51)
   static constexpr int kOutLanes = 10;  // two per result array of a slice (dense, interpolated, order, ranked, carried): they leave side by side, in halves
   char* out_stage[kOutLanes][2] = {};
   hipEvent_t out_stage_ev[kOutLanes][2] = {};
@@ -3037,8 +3037,8 @@ static int score_small(ffx_index* idx, const float* host_queries, int64_t n_quer
 
 // Device memory into ORDINARY host memory without handing that memory to the runtime (which would either page-lock it on
 // the fly -- the path this library keeps heap memory off, see the constructor at the top -- or stage it on the null stream, one
-// copy at a time for the whole process, at 17 GB/s): 4 MiB pieces go into two page-locked blocks of the plan on a copy stream
-// of the plan's own, and while piece k+1 is on its way the calling thread copies piece k out (a thread's memcpy: ~10 GB/s).
+// copy at a time for the whole process, at 17 GB/s): 8 MiB pieces go into two page-locked blocks of the plan on the index's
+// result stream, and while piece k+1 is on its way the calling thread copies piece k out.
 // `lane`: which pair of blocks and stream -- the result arrays of a slice leave side by side, a thread each (fetch_on_thread),
 // and up to three slices at a time on three plans: enough for ffx_score's results to leave as fast as they are made.
 static int staged_d2h(ffx_plan* pl, int lane, void* dst, const void* src_dev, size_t bytes) {
@@ -3054,7 +3054,8 @@ static int staged_d2h(ffx_plan* pl, int lane, void* dst, const void* src_dev, si
   // next slices' scoring kernels leaves when they are done -- 24.6 ms for the headline batch at normal priority).  A stream per
   // lane (round 4) meant up to fifteen streams on the device's four hardware queues: some shared a queue with the kernel stream.
   hipStream_t st = pl->idx->out_stream;
-  const size_t piece = ffx_plan::kOutStageBytes;
+  size_t piece = ffx_plan::kOutStageBytes;
+  if (long long v = 0; ffx_experiment("out_piece_kb", &v) && v >= 64 && (size_t)v * 1024 <= ffx_plan::kOutStageBytes) piece = (size_t)v * 1024;  // A/B
   const size_t n = (bytes + piece - 1) / piece;
   auto issue = [&](size_t k) -> int {
     const size_t at = k * piece, len = std::min(piece, bytes - at);
@@ -3322,7 +3323,7 @@ static int score_impl(ffx_index* idx, const float* host_queries, int64_t n_queri
         std::vector<Job> jobs;
         // a large array leaves in two halves, a thread each (one thread empties the blocks at ~10 GB/s; three slices' results
         // are on their way at a time, and the slowest decides when its plan is free for the slice three further on)
-        const size_t half = bytes >= (size_t(8) << 20) ? ((bytes / 2 + ffx_plan::kOutStageBytes - 1) / ffx_plan::kOutStageBytes) * ffx_plan::kOutStageBytes : bytes;
+        const size_t half = bytes >= (size_t(8) << 20) ? ((bytes / 2 + 4095) & ~size_t(4095)) : bytes;
         auto add = [&](int which, void* dst, const void* src) {
           jobs.push_back({2 * which, static_cast<char*>(dst), static_cast<const char*>(src), half});
           if (half < bytes) jobs.push_back({2 * which + 1, static_cast<char*>(dst) + half, static_cast<const char*>(src) + half, bytes - half});

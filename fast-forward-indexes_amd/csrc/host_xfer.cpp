@@ -21,9 +21,13 @@ extern thread_local std::string g_last_error;
 namespace {
 
 constexpr size_t kDirectBytes = size_t(1) << 20;  // at or below: the runtime copies through its own staging, it pins nothing
-// (1 MiB pieces were tried -- less to fill before the wire is busy, less to drain at the end: the calls into the runtime, two per
-// piece from four threads onto one stream, then cost more than the shorter fill saved: 1.9 instead of 1.4 ms for a 50 MB upload)
-constexpr size_t kPiece = size_t(4) << 20;
+// A copy command costs the wire ~15 us (+ ~5 us for the event behind it) whatever its size: page-locked memory cut into 4 MiB
+// commands moves at 45.6 GB/s, 8 MiB 50.7, 16 MiB 53.4, uncut 57 (tools/probes/staged_xfer_probe.cpp) -- and a piece must be
+// filled by a host thread before the wire can have it (4 MiB: 0.13 ms).  So pieces are GRADED: an upload begins with 1 MiB
+// pieces (the wire is busy after 35 us) and grows to whole blocks; a download ends with small ones (the last piece's way out
+// of its block is all that is not overlapped).  A fixed 4 MiB was the first form (45 GB/s at best; 1 MiB throughout: 30).
+constexpr size_t kMiB = size_t(1) << 20;
+constexpr size_t kBlock = 8 * kMiB;  // a lane's page-locked block = the largest piece
 constexpr int kLanes = 4;       // host threads a large transfer is spread over
 constexpr int kLaneRoom = 8;    // (the experiments build can try more: xfer_lanes=N)
 constexpr int kMaxDevices = 64;
@@ -44,7 +48,7 @@ struct Lane {
     if (block[0]) return FFX_OK;
     for (int b = 0; b < 2; ++b) {
       X_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
-      X_HIP(hipHostMalloc(reinterpret_cast<void**>(&block[b]), kPiece, hipHostMallocDefault));
+      X_HIP(hipHostMalloc(reinterpret_cast<void**>(&block[b]), kBlock, hipHostMallocDefault));
     }
     return FFX_OK;
   }
@@ -85,20 +89,47 @@ DeviceWays* ways_of(int device) {
 
 std::atomic<unsigned long long> g_staged_transfers{0}, g_staged_bytes{0};
 
-// the piece size of a staged transfer.  Cutting small transfers finer (the first slices of an ffx_score call are 6 - 25 MB) so that
-// the wire has something to do sooner was tried: 1 MiB pieces below 12 MB, 2 MiB below 32 MB gave 18.6 ms against 18.45 for the
-// headline call with ordinary buffers -- the calls into the runtime cost what the earlier start saves (profiles/r05/xfer_piece_sweep.txt)
-size_t piece_for(size_t) {
-  if (long long v = 0; ffx_experiment("xfer_piece_kb", &v) && v >= 64 && (size_t)v * 1024 <= kPiece) return (size_t)v * 1024;
-  return kPiece;
+// length of piece k of a transfer counted from the graded end (uploads: its beginning, downloads: its end)
+size_t graded_piece(size_t k) {
+  if (long long v = 0; ffx_experiment("xfer_piece_kb", &v) && v >= 64 && (size_t)v * 1024 <= kBlock) return (size_t)v * 1024;  // a fixed size, for A/B
+  return k < 2 ? kMiB : k < 4 ? 2 * kMiB : k < 6 ? 4 * kMiB : kBlock;
 }
 
-int lanes_for(size_t bytes, size_t piece) {
-  const size_t pieces = (bytes + piece - 1) / piece;
+struct Piece {
+  size_t part;  // which array of the call
+  size_t at, len;
+};
+
+// the pieces of arrays of `sizes` bytes (those listed in `parts`), in the order they are to travel
+std::vector<Piece> cut_graded(const std::vector<size_t>& parts, const size_t* sizes, bool small_first) {
+  std::vector<Piece> pieces;
+  size_t k = 0;
+  if (small_first) {
+    for (size_t i : parts)
+      for (size_t at = 0; at < sizes[i]; ++k) {
+        const size_t len = std::min(graded_piece(k), sizes[i] - at);
+        pieces.push_back({i, at, len});
+        at += len;
+      }
+  } else {  // the same cut made from the end, then turned round
+    for (size_t r = parts.size(); r-- > 0;) {
+      const size_t i = parts[r];
+      for (size_t end = sizes[i]; end > 0; ++k) {
+        const size_t len = std::min(graded_piece(k), end);
+        pieces.push_back({i, end - len, len});
+        end -= len;
+      }
+    }
+    std::reverse(pieces.begin(), pieces.end());
+  }
+  return pieces;
+}
+
+int lanes_for(size_t n_pieces) {
   // two pieces per thread at least: starting one costs what copying ~1 MiB does
   size_t most = kLanes;
   if (long long v = 0; ffx_experiment("xfer_lanes", &v) && v >= 1 && v <= kLaneRoom) most = (size_t)v;
-  return (int)std::max<size_t>(1, std::min<size_t>(most, pieces / 2));
+  return (int)std::max<size_t>(1, std::min<size_t>(most, n_pieces / 2));
 }
 
 template <class Body>
@@ -143,14 +174,8 @@ bool ffx_runtime_owns(const void* p) {
 int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* srcs, const size_t* sizes, hipStream_t stream) {
   // the parts that go to the runtime as they are (small, or page-locked by the caller), in order; the others are staged TOGETHER:
   // their pieces form one list that the lanes' threads share, so that several arrays of one batch (candidate ordinals and
-  // first-stage scores of a slice) cost one round of threads and one piece's worth of filling before the wire is busy, not one each
-  struct Piece {
-    char* dst;
-    const char* src;
-    size_t len;
-  };
-  std::vector<Piece> pieces;
-  std::vector<int> staged;  // the parts that travel through the blocks
+  // first-stage scores of a slice) cost one round of threads and one small piece's worth of filling before the wire is busy
+  std::vector<size_t> staged;  // the parts that travel through the blocks
   size_t staged_bytes = 0;
   for (int i = 0; i < n_parts; ++i) {
     const size_t bytes = sizes[i];
@@ -160,35 +185,31 @@ int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* 
       X_HIP(hipMemcpyAsync(dsts[i], srcs[i], bytes, hipMemcpyHostToDevice, stream));
       continue;
     }
-    staged.push_back(i);
+    staged.push_back((size_t)i);
     staged_bytes += bytes;
   }
   if (staged.empty()) return FFX_OK;
-  const size_t piece = piece_for(staged_bytes);
-  for (int i : staged)
-    for (size_t at = 0; at < sizes[i]; at += piece)
-      pieces.push_back({static_cast<char*>(dsts[i]) + at, static_cast<const char*>(srcs[i]) + at, std::min(piece, sizes[i] - at)});
-  const int staged_parts = (int)staged.size();
+  const std::vector<Piece> pieces = cut_graded(staged, sizes, /*small_first=*/true);
   DeviceWays* dw = ways_of(device);
   if (!dw) return ffx_fail(FFX_BAD_ARG, "ffx_h2d: device %d", device);
   Way& w = dw->in;
   std::lock_guard<std::mutex> lock(w.mu);
   X_HIP(hipSetDevice(device));
-  const int T = lanes_for(staged_bytes, piece);
+  const int T = lanes_for(pieces.size());
   for (int t = 0; t < T; ++t) {
     const int rc = w.lanes[t].make();
     if (rc != FFX_OK) return rc;
   }
-  const size_t n = pieces.size();
+  std::atomic<size_t> next{0};  // the threads take the pieces as they come free: the first ones go to whoever is up first
   const int rc = on_threads(T, [&](int t) -> int {
     Lane& ln = w.lanes[t];
     if (t > 0) X_HIP(hipSetDevice(device));
     int b = 0;
-    for (size_t k = (size_t)t; k < n; k += (size_t)T, b ^= 1) {
+    for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < pieces.size(); b ^= 1) {
       const Piece& pc = pieces[k];
       if (ln.busy[b]) X_HIP(hipEventSynchronize(ln.ev[b]));
-      memcpy(ln.block[b], pc.src, pc.len);
-      X_HIP(hipMemcpyAsync(pc.dst, ln.block[b], pc.len, hipMemcpyHostToDevice, stream));
+      memcpy(ln.block[b], static_cast<const char*>(srcs[pc.part]) + pc.at, pc.len);
+      X_HIP(hipMemcpyAsync(static_cast<char*>(dsts[pc.part]) + pc.at, ln.block[b], pc.len, hipMemcpyHostToDevice, stream));
       X_HIP(hipEventRecord(ln.ev[b], stream));
       ln.busy[b] = true;
     }
@@ -201,7 +222,7 @@ int ffx_h2d_many(int device, int n_parts, void* const* dsts, const void* const* 
     for (int t = 0; t < T; ++t) w.lanes[t].busy[0] = w.lanes[t].busy[1] = false;
     return rc;
   }
-  g_staged_transfers.fetch_add((unsigned long long)staged_parts, std::memory_order_relaxed);
+  g_staged_transfers.fetch_add((unsigned long long)staged.size(), std::memory_order_relaxed);
   g_staged_bytes.fetch_add(staged_bytes, std::memory_order_relaxed);
   return FFX_OK;
 }
@@ -222,37 +243,42 @@ int ffx_d2h(int device, void* dst, const void* src, size_t bytes, hipStream_t st
   Way& w = dw->out;
   std::lock_guard<std::mutex> lock(w.mu);
   X_HIP(hipSetDevice(device));
-  const int T = lanes_for(bytes, kPiece);
+  const std::vector<Piece> pieces = cut_graded({0}, &bytes, /*small_first=*/false);
+  const size_t n = pieces.size();
+  const int T = lanes_for(n);
   for (int t = 0; t < T; ++t) {
     const int rc = w.lanes[t].make();
     if (rc != FFX_OK) return rc;
   }
-  const size_t n = (bytes + kPiece - 1) / kPiece;
+  std::atomic<size_t> next{0};
   const int rc = on_threads(T, [&](int t) -> int {
     Lane& ln = w.lanes[t];
     if (t > 0) X_HIP(hipSetDevice(device));
     auto issue = [&](size_t k, int b) -> int {
-      const size_t at = k * kPiece, len = std::min(kPiece, bytes - at);
-      X_HIP(hipMemcpyAsync(ln.block[b], static_cast<const char*>(src) + at, len, hipMemcpyDeviceToHost, stream));
+      X_HIP(hipMemcpyAsync(ln.block[b], static_cast<const char*>(src) + pieces[k].at, pieces[k].len, hipMemcpyDeviceToHost, stream));
       X_HIP(hipEventRecord(ln.ev[b], stream));
       ln.busy[b] = true;
       return FFX_OK;
     };
     // (the blocks of an out-lane are empty between transfers: every piece is copied out before the transfer returns)
-    if ((size_t)t < n) {
-      const int rc0 = issue((size_t)t, 0);
+    // a thread has one piece landing in one block while it empties the other
+    size_t cur = next.fetch_add(1, std::memory_order_relaxed);
+    int b = 0;
+    if (cur < n) {
+      const int rc0 = issue(cur, b);
       if (rc0 != FFX_OK) return rc0;
     }
-    int b = 0;
-    for (size_t k = (size_t)t; k < n; k += (size_t)T, b ^= 1) {
-      if (k + (size_t)T < n) {
-        const int rc1 = issue(k + (size_t)T, b ^ 1);
+    while (cur < n) {
+      const size_t nxt = next.fetch_add(1, std::memory_order_relaxed);
+      if (nxt < n) {
+        const int rc1 = issue(nxt, b ^ 1);
         if (rc1 != FFX_OK) return rc1;
       }
       X_HIP(hipEventSynchronize(ln.ev[b]));
       ln.busy[b] = false;
-      const size_t at = k * kPiece, len = std::min(kPiece, bytes - at);
-      memcpy(static_cast<char*>(dst) + at, ln.block[b], len);
+      memcpy(static_cast<char*>(dst) + pieces[cur].at, ln.block[b], pieces[cur].len);
+      cur = nxt;
+      b ^= 1;
     }
     return FFX_OK;
   });

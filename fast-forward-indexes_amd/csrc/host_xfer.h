@@ -1,7 +1,7 @@
 // host_xfer.h -- how bytes move between the CALLER'S host memory and the device (shared by ffx.hip and comm.hip).
 //
 // A transfer of more than 1 MiB from or into ordinary (pageable) memory makes the HIP runtime page-lock the caller's pages
-// on the fly and release them afterwards.  This library never lets it: such a transfer is cut into 4 MiB pieces that travel
+// on the fly and release them afterwards.  This library never lets it: such a transfer is cut into pieces of 1 - 8 MiB that travel
 // through page-locked blocks the library owns, filled (or emptied) by a few host threads while the pieces before them are on
 // the wire; the pieces are queued on the caller's stream (no stream is created here).  Memory the caller page-locked itself (ffx_host_alloc,
 // ffx_host_register, hipHostMalloc) and transfers of at most 1 MiB (the runtime stages those through its own blocks, it

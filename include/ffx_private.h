@@ -52,7 +52,7 @@ int ffx_plan_recent_gather_ms(ffx_plan* plan, int32_t n, float* out_ms);
  * since the process began (csrc/host_xfer.h: ordinary memory above 1 MiB never reaches the runtime, which would page-lock
  * it on the fly): transfers and bytes.  For tests and tools. */
 int ffx_host_xfer_stats(uint64_t* staged_transfers, uint64_t* staged_bytes);
-/* release the page-locked staging blocks of every device (up to 64 MiB per device and direction; they come back on the next
+/* release the page-locked staging blocks of every device (up to 64 MiB per device and direction (four lanes of two 8 MiB blocks); they come back on the next
  * staged transfer): for a host program that is done with the GPU for a while */
 int ffx_host_xfer_release(void);
 /* 1 for the experiments build (make EXPERIMENTS=1: the tuning hooks of FFX_DEBUG_VARIANT and the kernels only they reach), 0

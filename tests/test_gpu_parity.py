@@ -1472,8 +1472,8 @@ def test_ordinary_memory_travels_through_the_librarys_own_blocks(monkeypatch):
     back = idx.gather(np.arange(n_docs)) if hasattr(idx, "gather") else None
     if back is not None:
         assert np.array_equal(back, vectors)
-    # sizes around the 4 MiB pieces: a last piece of a few bytes, an odd number of pieces on one thread, pieces dealt to two threads
-    for n_rows in (1366, 1367, 2733, 5500):
+    # sizes around the pieces (1, 1, 2, 2, 4, 4, 8, 8 ... MiB from the graded end): a last piece of a few bytes, an odd number of pieces on one thread, pieces dealt to two threads
+    for n_rows in (342, 683, 1366, 1367, 2733, 5500, 11000):
         rows = synth.rows(40 + n_rows, 0.05, 0, n_rows, d)
         odd = native.DeviceIndex(n_rows, d)
         odd.upload(rows, 0)

@@ -418,7 +418,7 @@ def test_fast_sum_mode_within_tolerance():
     want = case.expected("MAXP_ff")
     err = max(abs(s - want[(q, i)]) for q, i, s in zip(got["q_id"], got["id"], got["score"]))
     assert 0 < err <= 1e-4 * max(1.0, max(abs(v) for v in want.values()))  # 1e-4: BASELINE.json north_star
-    assert idx.last_stats["kernel_variant"] // 100 == 2
+    assert idx.last_stats["kernel_variant"] // 100 in (2, 5, 6)  # gather_dot_fast_kernel: from a row list, or rows derived in the kernel
 
 
 # ---- quantized indexes (reference tests/test_index.py:389-399 + golden frames) ------------------------
