@@ -1,7 +1,8 @@
 """One rank of the ShardedOnDiskIndex test (BASELINE config 5 at fixture size): N ranks share ONE GPU
 and open the same index files -- an HDF5 file written by real HDF5 replaying the reference's calls,
 and this build's own container with documents whose rows are NOT contiguous -- resident shards
-and streamed shards; launched by tests/test_ondisk.py as N plain processes."""
+and streamed shards; launched by tests/test_ondisk.py as N plain processes (or fewer, several ranks a process, a thread
+each: FFX_RANKS_HERE)."""
 
 import sys
 from pathlib import Path
@@ -13,163 +14,192 @@ for p in (ROOT / "fast-forward-indexes_amd", ROOT / "oracle", ROOT / "tests"):
     sys.path.insert(0, str(p))
 
 from _cases import MODE_NO, load_scoring_case  # noqa: E402
-from fast_forward_amd import Ranking  # noqa: E402
+from fast_forward_amd import Ranking, native  # noqa: E402
 from fast_forward_amd.encoder import LambdaEncoder  # noqa: E402
 from fast_forward_amd.index import InMemoryIndex, Mode, OnDiskIndex  # noqa: E402
 from fast_forward_amd.sharded import ShardedOnDiskIndex, connect  # noqa: E402
 
 H5 = ROOT / "tests" / "golden" / "h5"
 work = Path(sys.argv[1])
-comm = connect("host")
-rank, world = comm.rank, comm.world
-checked = 0
 
-# ---- 1. the reference's HDF5 layout (float64 rows, several chunks): every rank maps the file -------------
-rng = np.random.default_rng(0)
-qv = rng.standard_normal((5, 32)).astype(np.float32)
-enc = LambdaEncoder(lambda t: qv[int(t)])
-disk = OnDiskIndex.load(H5 / "big_f64.h5", enc)
-rows = disk._read_rows(np.arange(1400))
-mem = InMemoryIndex(enc)
-mem.add(rows, doc_ids=[f"D{i // 2}" for i in range(1400)], psg_ids=[f"P{i}" for i in range(1400)])
-run = {f"q{q}": {f"D{d}": float(rng.random()) for d in rng.choice(700, size=150 + 10 * q, replace=False)} for q in range(5)}
-first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(5)})
-psg_run = {f"q{q}": {f"P{p}": float(rng.random()) for p in rng.choice(1400, size=90, replace=False)} for q in range(5)}
-first_psg = Ranking.from_run(psg_run, queries={f"q{q}": str(q) for q in range(5)})
-for resident in (True, False):
-    sharded = ShardedOnDiskIndex(H5 / "big_f64.h5", comm, enc, resident=resident, window_bytes=20_000)
-    assert sharded.resident == resident and len(sharded) == 1400
-    assert sharded.rows_per_rank.sum() == 1400 and sharded.rows_per_rank.min() > 0
-    for mode in (Mode.MAXP, Mode.FIRSTP, Mode.AVEP):
-        sharded.mode = mem.mode = mode
-        assert sharded(first, gather=True) == mem(first), (resident, mode)
-        es = dict(early_stopping=4, early_stopping_alpha=0.3, early_stopping_depths=(4, 20, 200))  # over shards, resident and streamed
-        assert sharded(first, gather=True, **es) == mem(first, **es), (resident, mode, "early stopping")
-        own = sharded.rerank(first, 0.3)
-        want = mem.rerank(first, 0.3)
-        assert 0 < len(own.q_ids) < 5
-        for q in own.q_ids:
-            assert own[q] == want[q]
-            checked += len(own[q])
-        if not resident:
-            # a streamed shard is owner-routed too: what the rank took in is ITS block of the batch (the candidates of the
-            # queries it owns, as id codes) and what the owners sent it (per-query counts + the codes of what it holds),
-            # never the batch -- per-rank intake ~ 2 / world of it
-            it, routing = sharded.last_intake, sharded._code_routing(first)
-            own_pairs = sum(len(own[q]) for q in own.q_ids)
-            held_pairs = int((routing["holder_c"][routing["codes"]] == rank).sum())
-            batch_pairs = sum(len(v) for v in run.values())
-            assert it == {"own_pairs": own_pairs, "held_pairs": held_pairs, "batch_pairs": batch_pairs,
-                          "bytes": (len(own.q_ids) + 1) * 8 + own_pairs * 4 + (5 + held_pairs) * 4}, (it, own_pairs, held_pairs)
-            assert own_pairs < batch_pairs and held_pairs < batch_pairs
-    sharded.mode = mem.mode = Mode.PASSAGE
-    assert sharded(first_psg, gather=True) == mem(first_psg), (resident, "PASSAGE")
-    assert sharded.rerank(first_psg, 0.7, gather=True) == mem.rerank(first_psg, 0.7)
-    try:
-        sharded(Ranking.from_run({"q0": {"P1": 1.0, "nowhere": 2.0}}, queries={"q0": "0"}))
-    except IndexError as e:
-        assert "nowhere" in str(e)
-    else:
-        raise AssertionError("unknown id accepted")
+def main(rank=None, world=None):
+    comm = connect("host", rank=rank, world=world)
+    rank, world = comm.rank, comm.world
+    checked = 0
+
+    # ---- 1. the reference's HDF5 layout (float64 rows, several chunks): every rank maps the file -------------
+    rng = np.random.default_rng(0)
+    qv = rng.standard_normal((5, 32)).astype(np.float32)
+    enc = LambdaEncoder(lambda t: qv[int(t)])
+    disk = OnDiskIndex.load(H5 / "big_f64.h5", enc)
+    rows = disk._read_rows(np.arange(1400))
+    mem = InMemoryIndex(enc)
+    mem.add(rows, doc_ids=[f"D{i // 2}" for i in range(1400)], psg_ids=[f"P{i}" for i in range(1400)])
+    run = {f"q{q}": {f"D{d}": float(rng.random()) for d in rng.choice(700, size=150 + 10 * q, replace=False)} for q in range(5)}
+    first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(5)})
+    psg_run = {f"q{q}": {f"P{p}": float(rng.random()) for p in rng.choice(1400, size=90, replace=False)} for q in range(5)}
+    first_psg = Ranking.from_run(psg_run, queries={f"q{q}": str(q) for q in range(5)})
+    for resident in (True, False):
+        sharded = ShardedOnDiskIndex(H5 / "big_f64.h5", comm, enc, resident=resident, window_bytes=20_000)
+        assert sharded.resident == resident and len(sharded) == 1400
+        assert sharded.rows_per_rank.sum() == 1400 and sharded.rows_per_rank.min() > 0
+        for mode in (Mode.MAXP, Mode.FIRSTP, Mode.AVEP):
+            sharded.mode = mem.mode = mode
+            assert sharded(first, gather=True) == mem(first), (resident, mode)
+            es = dict(early_stopping=4, early_stopping_alpha=0.3, early_stopping_depths=(4, 20, 200))  # over shards, resident and streamed
+            assert sharded(first, gather=True, **es) == mem(first, **es), (resident, mode, "early stopping")
+            own = sharded.rerank(first, 0.3)
+            want = mem.rerank(first, 0.3)
+            assert len(own.q_ids) == int(np.diff(native.query_partition(5, world))[rank]) < 5  # (with more ranks than queries some rank owns none)
+            for q in own.q_ids:
+                assert own[q] == want[q]
+                checked += len(own[q])
+            if not resident:
+                # a streamed shard is owner-routed too: what the rank took in is ITS block of the batch (the candidates of the
+                # queries it owns, as id codes) and what the owners sent it (per-query counts + the codes of what it holds),
+                # never the batch -- per-rank intake ~ 2 / world of it
+                it, routing = sharded.last_intake, sharded._code_routing(first)
+                own_pairs = sum(len(own[q]) for q in own.q_ids)
+                held_pairs = int((routing["holder_c"][routing["codes"]] == rank).sum())
+                batch_pairs = sum(len(v) for v in run.values())
+                assert it == {"own_pairs": own_pairs, "held_pairs": held_pairs, "batch_pairs": batch_pairs,
+                              "bytes": (len(own.q_ids) + 1) * 8 + own_pairs * 4 + (5 + held_pairs) * 4}, (it, own_pairs, held_pairs)
+                assert own_pairs < batch_pairs and held_pairs < batch_pairs
+        sharded.mode = mem.mode = Mode.PASSAGE
+        assert sharded(first_psg, gather=True) == mem(first_psg), (resident, "PASSAGE")
+        assert sharded.rerank(first_psg, 0.7, gather=True) == mem.rerank(first_psg, 0.7)
+        try:
+            sharded(Ranking.from_run({"q0": {"P1": 1.0, "nowhere": 2.0}}, queries={"q0": "0"}))
+        except IndexError as e:
+            assert "nowhere" in str(e)
+        else:
+            raise AssertionError("unknown id accepted")
+        sharded.close()
+    mem.close()
+
+    # ---- 1b. a quantized HDF5 file (NanoPQ codes + codewords stored by the reference's layout): shards hold codes ------
+    rng2 = np.random.default_rng(5)
+    qv2 = rng2.standard_normal((2, 24)).astype(np.float32)
+    enc2 = LambdaEncoder(lambda t: qv2[int(t)])
+    single = OnDiskIndex.load(H5 / "quantized.h5", enc2)
+    n_q = len(single)
+    pq_run = Ranking.from_run({"a": {f"q{i}": float(i) for i in range(n_q)}, "b": {"q5": 2.0, "q1": 0.5, "q7": 0.1}}, queries={"a": "0", "b": "1"})
+    want_pq, want_pq_i = single(pq_run), single.rerank(pq_run, 0.4)
+    for resident in (True, False):
+        sharded = ShardedOnDiskIndex(H5 / "quantized.h5", comm, enc2, resident=resident)
+        if resident:
+            assert sharded._store.dtype == np.uint8 and sharded._store.codebook_shape is not None  # codes + codebook in HBM
+        assert sharded(pq_run, gather=True) == want_pq and sharded.rerank(pq_run, 0.4, gather=True) == want_pq_i, resident
+        checked += len(pq_run._df)
+        sharded.close()
+
+    # ---- 2. this build's container; documents re-opened by later add() calls (rows not contiguous), rows
+    #         with only a passage id, fp16 storage -------------------------------------------------------------
+    case = load_scoring_case("d768_f16")
+    qvecs = case.queries
+    enc = LambdaEncoder(lambda t: qvecs[int(t)])
+    path = work / "shared.ffx"
+    n = len(case.vectors)
+    perm = np.random.default_rng(3).permutation(n)  # insertion order scrambled: a document's rows are scattered over the file
+    doc_names = [case.doc_names[i] if i % 7 else None for i in perm]   # every 7th row has no document id
+    psg_names = [case.psg_names[i] for i in perm]
+    if rank == 0:
+        w = OnDiskIndex(path, enc, mode=Mode.MAXP, chunk_size=64, overwrite=True)
+        third = n // 3
+        for lo, hi in ((0, third), (third, 2 * third), (2 * third, n)):
+            w.add(case.vectors[perm[lo:hi]], doc_ids=doc_names[lo:hi], psg_ids=psg_names[lo:hi])
+        del w
+    comm.barrier()
+    mem = InMemoryIndex(enc)
+    mem.add(case.vectors[perm], doc_ids=doc_names, psg_ids=psg_names)
+    docs = sorted({d for d in doc_names if d})
+    rng = np.random.default_rng(9)
+    run = {f"q{q}": {d: float(rng.random() * 20) for d in rng.choice(docs, size=30, replace=False)} for q in range(len(case.q_names))}
+    first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(len(case.q_names))})
+    psg_run = {f"q{q}": {p: float(rng.random()) for p in rng.choice(psg_names, size=40, replace=False)} for q in range(len(case.q_names))}
+    first_psg = Ranking.from_run(psg_run, queries={f"q{q}": str(q) for q in range(len(case.q_names))})
+    for resident in (True, False):
+        sharded = ShardedOnDiskIndex(path, comm, enc, resident=resident, window_bytes=60_000)
+        assert sharded._store is None or sharded._store.dtype == np.float16
+        for mode in ("MAXP", "AVEP", "FIRSTP"):
+            sharded.mode = mem.mode = Mode(MODE_NO[mode])
+            assert sharded(first, gather=True) == mem(first), (resident, mode)
+            assert sharded.rerank(first, 0.1, gather=True) == mem.rerank(first, 0.1), (resident, mode)
+        sharded.mode = mem.mode = Mode.PASSAGE
+        assert sharded(first_psg, gather=True) == mem(first_psg)
+        checked += len(first_psg._df)
+        sharded.close()
+    mem.close()
+
+    # ---- 2b. an OPQ-quantized container: codes in the shards, the queries rotated once on every rank ------------------
+    from fast_forward_amd.quantizer import NanoOPQ  # noqa: E402
+
+    opq_path = work / "opq.ffx"
+    x32 = case.vectors.astype(np.float32)
+    if rank == 0:
+        opq = NanoOPQ(8, 16)
+        opq.fit(x32, pq_iter=2, rotation_iter=2)
+        w = OnDiskIndex(opq_path, enc, quantizer=opq, mode=Mode.MAXP, chunk_size=64, overwrite=True)
+        w.add(x32, doc_ids=case.doc_names, psg_ids=case.psg_names)
+        del w
+    comm.barrier()
+    opq_single = OnDiskIndex.load(opq_path, enc).to_memory()
+    opq_docs = sorted(set(case.doc_names))
+    opq_run = Ranking.from_run({f"q{q}": {d: float(rng.random() * 20) for d in rng.choice(opq_docs, size=25, replace=False)} for q in range(len(case.q_names))},
+                               queries={f"q{q}": str(q) for q in range(len(case.q_names))})
+    for resident in (True, False):
+        sharded = ShardedOnDiskIndex(opq_path, comm, enc, resident=resident, window_bytes=300)
+        assert sharded(opq_run, gather=True) == opq_single(opq_run), resident
+        assert sharded.rerank(opq_run, 0.2, gather=True) == opq_single.rerank(opq_run, 0.2), resident
+        checked += len(opq_run._df)
+        sharded.close()
+    opq_single.close()
+
+    # ---- 3. fewer documents than ranks: some rank's document range is empty; it takes part with empty candidate lists
+    #         (the constructor's "no rows here" is the same decision on every rank, nobody raises between two collectives)
+    tiny = work / "tiny.ffx"
+    if rank == 0:
+        w = OnDiskIndex(tiny, enc, mode=Mode.MAXP, chunk_size=8, overwrite=True)
+        w.add(case.vectors[:3].astype(np.float32), doc_ids=["only"] * 3, psg_ids=["t0", "t1", "t2"])
+        del w
+    comm.barrier()
+    mem = InMemoryIndex(enc)
+    mem.add(case.vectors[:3].astype(np.float32), doc_ids=["only"] * 3, psg_ids=["t0", "t1", "t2"])
+    one = Ranking.from_run({"q0": {"only": 1.5}, "q1": {"only": 0.5}}, queries={"q0": "0", "q1": "1"})
+    sharded = ShardedOnDiskIndex(tiny, comm, enc, resident=True)
+    assert sharded.rows_per_rank.min() == 0 and sharded.rows_per_rank.sum() == 3
+    assert sharded(one, gather=True) == mem(one) and sharded.rerank(one, 0.5, gather=True) == mem.rerank(one, 0.5)
+    checked += 2
     sharded.close()
-mem.close()
+    total = int(comm.allreduce([checked])[0])
+    assert "torch" not in sys.modules
+    if rank == 0:
+        print(f"sharded on-disk world={world}: {total} rows checked bit for bit against the in-memory index")
+    comm.close()
 
-# ---- 1b. a quantized HDF5 file (NanoPQ codes + codewords stored by the reference's layout): shards hold codes ------
-rng2 = np.random.default_rng(5)
-qv2 = rng2.standard_normal((2, 24)).astype(np.float32)
-enc2 = LambdaEncoder(lambda t: qv2[int(t)])
-single = OnDiskIndex.load(H5 / "quantized.h5", enc2)
-n_q = len(single)
-pq_run = Ranking.from_run({"a": {f"q{i}": float(i) for i in range(n_q)}, "b": {"q5": 2.0, "q1": 0.5, "q7": 0.1}}, queries={"a": "0", "b": "1"})
-want_pq, want_pq_i = single(pq_run), single.rerank(pq_run, 0.4)
-for resident in (True, False):
-    sharded = ShardedOnDiskIndex(H5 / "quantized.h5", comm, enc2, resident=resident)
-    if resident:
-        assert sharded._store.dtype == np.uint8 and sharded._store.codebook_shape is not None  # codes + codebook in HBM
-    assert sharded(pq_run, gather=True) == want_pq and sharded.rerank(pq_run, 0.4, gather=True) == want_pq_i, resident
-    checked += len(pq_run._df)
-    sharded.close()
 
-# ---- 2. this build's container; documents re-opened by later add() calls (rows not contiguous), rows
-#         with only a passage id, fp16 storage -------------------------------------------------------------
-case = load_scoring_case("d768_f16")
-qvecs = case.queries
-enc = LambdaEncoder(lambda t: qvecs[int(t)])
-path = work / "shared.ffx"
-n = len(case.vectors)
-perm = np.random.default_rng(3).permutation(n)  # insertion order scrambled: a document's rows are scattered over the file
-doc_names = [case.doc_names[i] if i % 7 else None for i in perm]   # every 7th row has no document id
-psg_names = [case.psg_names[i] for i in perm]
-if rank == 0:
-    w = OnDiskIndex(path, enc, mode=Mode.MAXP, chunk_size=64, overwrite=True)
-    third = n // 3
-    for lo, hi in ((0, third), (third, 2 * third), (2 * third, n)):
-        w.add(case.vectors[perm[lo:hi]], doc_ids=doc_names[lo:hi], psg_ids=psg_names[lo:hi])
-    del w
-comm.barrier()
-mem = InMemoryIndex(enc)
-mem.add(case.vectors[perm], doc_ids=doc_names, psg_ids=psg_names)
-docs = sorted({d for d in doc_names if d})
-rng = np.random.default_rng(9)
-run = {f"q{q}": {d: float(rng.random() * 20) for d in rng.choice(docs, size=30, replace=False)} for q in range(len(case.q_names))}
-first = Ranking.from_run(run, queries={f"q{q}": str(q) for q in range(len(case.q_names))})
-psg_run = {f"q{q}": {p: float(rng.random()) for p in rng.choice(psg_names, size=40, replace=False)} for q in range(len(case.q_names))}
-first_psg = Ranking.from_run(psg_run, queries={f"q{q}": str(q) for q in range(len(case.q_names))})
-for resident in (True, False):
-    sharded = ShardedOnDiskIndex(path, comm, enc, resident=resident, window_bytes=60_000)
-    assert sharded._store is None or sharded._store.dtype == np.float16
-    for mode in ("MAXP", "AVEP", "FIRSTP"):
-        sharded.mode = mem.mode = Mode(MODE_NO[mode])
-        assert sharded(first, gather=True) == mem(first), (resident, mode)
-        assert sharded.rerank(first, 0.1, gather=True) == mem.rerank(first, 0.1), (resident, mode)
-    sharded.mode = mem.mode = Mode.PASSAGE
-    assert sharded(first_psg, gather=True) == mem(first_psg)
-    checked += len(first_psg._df)
-    sharded.close()
-mem.close()
+if __name__ == "__main__":
+    import os
 
-# ---- 2b. an OPQ-quantized container: codes in the shards, the queries rotated once on every rank ------------------
-from fast_forward_amd.quantizer import NanoOPQ  # noqa: E402
+    here = os.environ.get("FFX_RANKS_HERE")
+    if not here:
+        main()
+    else:  # several ranks in this process, a thread each (tests/_sharded_owned_worker.py says why)
+        import threading
+        import traceback
 
-opq_path = work / "opq.ffx"
-x32 = case.vectors.astype(np.float32)
-if rank == 0:
-    opq = NanoOPQ(8, 16)
-    opq.fit(x32, pq_iter=2, rotation_iter=2)
-    w = OnDiskIndex(opq_path, enc, quantizer=opq, mode=Mode.MAXP, chunk_size=64, overwrite=True)
-    w.add(x32, doc_ids=case.doc_names, psg_ids=case.psg_names)
-    del w
-comm.barrier()
-opq_single = OnDiskIndex.load(opq_path, enc).to_memory()
-opq_docs = sorted(set(case.doc_names))
-opq_run = Ranking.from_run({f"q{q}": {d: float(rng.random() * 20) for d in rng.choice(opq_docs, size=25, replace=False)} for q in range(len(case.q_names))},
-                           queries={f"q{q}": str(q) for q in range(len(case.q_names))})
-for resident in (True, False):
-    sharded = ShardedOnDiskIndex(opq_path, comm, enc, resident=resident, window_bytes=300)
-    assert sharded(opq_run, gather=True) == opq_single(opq_run), resident
-    assert sharded.rerank(opq_run, 0.2, gather=True) == opq_single.rerank(opq_run, 0.2), resident
-    checked += len(opq_run._df)
-    sharded.close()
-opq_single.close()
+        failed = []
 
-# ---- 3. fewer documents than ranks: some rank's document range is empty; it takes part with empty candidate lists
-#         (the constructor's "no rows here" is the same decision on every rank, nobody raises between two collectives)
-tiny = work / "tiny.ffx"
-if rank == 0:
-    w = OnDiskIndex(tiny, enc, mode=Mode.MAXP, chunk_size=8, overwrite=True)
-    w.add(case.vectors[:3].astype(np.float32), doc_ids=["only"] * 3, psg_ids=["t0", "t1", "t2"])
-    del w
-comm.barrier()
-mem = InMemoryIndex(enc)
-mem.add(case.vectors[:3].astype(np.float32), doc_ids=["only"] * 3, psg_ids=["t0", "t1", "t2"])
-one = Ranking.from_run({"q0": {"only": 1.5}, "q1": {"only": 0.5}}, queries={"q0": "0", "q1": "1"})
-sharded = ShardedOnDiskIndex(tiny, comm, enc, resident=True)
-assert sharded.rows_per_rank.min() == 0 and sharded.rows_per_rank.sum() == 3
-assert sharded(one, gather=True) == mem(one) and sharded.rerank(one, 0.5, gather=True) == mem.rerank(one, 0.5)
-checked += 2
-sharded.close()
-total = int(comm.allreduce([checked])[0])
-assert "torch" not in sys.modules
-if rank == 0:
-    print(f"sharded on-disk world={world}: {total} rows checked bit for bit against the in-memory index")
-comm.close()
+        def one_rank(r):
+            try:
+                main(r, int(os.environ["WORLD_SIZE"]))
+            except BaseException:  # noqa: BLE001
+                failed.append(r)
+                traceback.print_exc()
+
+        threads = [threading.Thread(target=one_rank, args=(int(r),)) for r in here.split(",")]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        sys.exit(1 if failed else 0)

@@ -696,8 +696,10 @@ def test_sharded_scorer_single_rank_nccl():
     assert "sharded 1-rank ok" in out.stdout
 
 
-# (world 5: the most ranks one GPU box lets share its card -- its process guard allows six processes on the GPU at a time, and
-# this pytest process is one of them; the eight-rank rendezvous, piece tables and owner routing run without a device in
+# (world 5: the most PROCESSES one GPU box lets share its card -- its process guard allows six on the GPU at a time, and this
+# pytest process is one of them.  bench.py is one rank per process, so five it is here; the eight-rank rendezvous, piece
+# tables and owner routing run against this device with two ranks per process in
+# test_owner_routed_fresh_batches_with_ranks_sharing_the_gpu[8], test_index_api.py and test_ondisk.py, and without a device in
 # tests/test_sharded_native.py)
 @pytest.mark.parametrize("world,sharding,spelling", [(2, "rows", "--transport host"), (3, "rows", "--transport host"), (2, "queries", "--transport host"),
                                                      (2, "rows", "--dist-backend gloo"), (5, "rows", "--transport host")])
@@ -854,7 +856,7 @@ def test_device_routing_equals_host_routing(monkeypatch):
     shard.close()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
 def test_owner_routed_fresh_batches_with_ranks_sharing_the_gpu(world):
     """ffx_sharded_stage_owned / ffx_sharded_score: every rank is handed only the queries it owns, finds the holders on the
     device and sends them the ordinals in a first all-to-all; results equal the single-GPU scorer over the whole index bit for
@@ -864,8 +866,10 @@ def test_owner_routed_fresh_batches_with_ranks_sharing_the_gpu(world):
 
     from test_sharded_native import run_ranks
 
-    codes, outs = run_ranks(world, Path(__file__).resolve().parent / "_sharded_owned_worker.py", timeout=600)
-    assert codes == [0] * world, "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    # (the box admits six processes to its GPU, this one included: eight ranks are four processes of two ranks, a thread each)
+    per_process = 2 if world > 5 else 1
+    codes, outs = run_ranks(world, Path(__file__).resolve().parent / "_sharded_owned_worker.py", timeout=600, ranks_per_process=per_process)
+    assert codes == [0] * len(codes) and len(codes) == -(-world // per_process), "\n".join(o[0][-1500:] + o[1][-3000:] for o in outs)
     assert f"owner-routed world={world}:" in outs[0][0] and "checked bit-exact" in outs[0][0]
 
 

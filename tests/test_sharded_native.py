@@ -16,12 +16,17 @@ from fast_forward_amd.sharded import assemble_local, doc_partition, query_partit
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def run_ranks(world: int, script: Path, *args, timeout: int = 600, extra_env=None):
+def run_ranks(world: int, script: Path, *args, timeout: int = 600, extra_env=None, ranks_per_process: int = 1):
+    """Start the ranks of one job and wait for them: (exit codes, (stdout, stderr)) per PROCESS.  ``ranks_per_process`` > 1: a
+    process hosts that many consecutive ranks, a thread each (FFX_RANKS_HERE names them; a worker that supports it starts the
+    threads itself) -- how eight ranks share one GPU on a box that admits six processes to it."""
     key = f"test_{os.getpid()}_{uuid.uuid4().hex[:10]}"
     procs = []
-    for r in range(world):
+    for r in range(0, world, ranks_per_process):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), FFX_RDZV_KEY=key, OMP_NUM_THREADS="2",
                    FFX_COMM_TIMEOUT_S="60", **(extra_env or {}))
+        if ranks_per_process > 1:
+            env["FFX_RANKS_HERE"] = ",".join(str(x) for x in range(r, min(world, r + ranks_per_process)))
         procs.append(subprocess.Popen([sys.executable, str(script), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
