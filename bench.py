@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--sort", dest="sort", action="store_true", default=True,
                     help="order every query's candidates on the device as part of the step (default)")
     ap.add_argument("--no-sort", dest="sort", action="store_false", help="leave the ordering out of the step")
+    ap.add_argument("--placement-tries", type=int, default=3,
+                    help="ffx_index_reseat after the index is filled (what InMemoryIndex.consolidate() does): the rows move into the fastest of "
+                         "up to this many further allocations; 0: the allocation stays where hipMalloc put it")
     ap.add_argument("--no-regions", dest="regions", action="store_false", default=True,
                     help="skip the side measurements (host-to-host, Index API, stream ceiling) of the 1-GPU line")
     ap.add_argument("--api-queries", type=int, default=6980, help="queries of the Index-API region (iii); 0: skip")
@@ -435,6 +438,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
         sys.exit("--store pq is a single-GPU leg")
     shard = native.DeviceIndex(max(n_local, 1), args.dim, device=local_rank, dtype=store)
     shard.fill_synthetic(args.seed, scale, 0, n_local, first_global_row=r_lo)
+    placement = shard.reseat(args.placement_tries)
     shard.set_doc_rows(doc_off[d_lo:d_hi + 1] - r_lo, np.arange(n_local, dtype=np.int32))
     shard.set_psg_rows(np.arange(n_local, dtype=np.int32))
     ids, sparse = candidates(n_docs, args.queries, args.k, args.seed)
@@ -574,6 +578,7 @@ def _bench_sharded_body(args, rank, world, comm, local_rank, doc_partition, quer
                 "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": int(pair_off[-1]), "store": args.store,
                 "sharding": f"rows by document, {world} ranks; queries owned in {world} contiguous blocks",
                 "rows_per_rank": [int(doc_off[doc_bounds[r + 1]] - doc_off[doc_bounds[r]]) for r in range(world)],
+                "placement": placement,  # (rank 0's shard: ffx_index_reseat at set-up, see the 1-GPU line)
             },
             "roofline": {
                 "bound": "hbm", "kernel": f"gather_dot (variant {int(slowest['kernel_variant'])}), slowest rank of one step",
@@ -763,6 +768,7 @@ def bench_replicas(args, comm):
     store = np.float16 if args.store == "f16" else np.float32
     index = native.DeviceIndex(args.rows, args.dim, device=local_rank, dtype=store)
     index.fill_synthetic(args.seed, scale, 0, args.rows)
+    placement = index.reseat(args.placement_tries)
     index.set_doc_rows(doc_off, np.arange(args.rows, dtype=np.int32))
     index.set_psg_rows(np.arange(args.rows, dtype=np.int32))
     bounds = query_partition(args.queries, world)
@@ -804,7 +810,7 @@ def bench_replicas(args, comm):
                             f"sum={args.sum}; no exchange (comparison point of the row-sharded layout)",
                 "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
                 "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": args.queries * args.k, "store": args.store,
-                "sharding": f"queries: {world} replicas, contiguous query blocks",
+                "sharding": f"queries: {world} replicas, contiguous query blocks", "placement": placement,
             },
             "roofline": {
                 "bound": "hbm", "kernel": f"gather_dot (variant {int(slowest['kernel_variant'])}), slowest rank of the last step",
@@ -1211,6 +1217,7 @@ def bench_single(args):
     if args.store == "pq":  # synthetic codebook [M][Ks][Ds] and uniform random codes
         index.set_codebook(synth.rows(args.seed + 9, scale, 0, pq_m * pq_ks, args.dim // pq_m).reshape(pq_m, pq_ks, -1))
     index.fill_synthetic(args.seed, scale, 0, args.rows)
+    placement = index.reseat(args.placement_tries)  # (index set-up, like the fill: not in the timed region)
     index.set_doc_rows(doc_off, np.arange(args.rows, dtype=np.int32))
     index.set_psg_rows(np.arange(args.rows, dtype=np.int32))
     ids, sparse = candidates(n_docs, args.queries, args.k, args.seed)
@@ -1261,6 +1268,9 @@ def bench_single(args):
             "rows": args.rows, "dim": args.dim, "queries": args.queries, "k": args.k, "mode": args.mode,
             "layout": args.layout, "sum": args.sum, "sort": bool(args.sort), "pairs": st["n_pairs"], "gathered_rows": st["n_rows"],
             "sharding": "none (1 GPU)", "index_bytes": args.rows * (pq_m if args.store == "pq" else args.dim * np.dtype(store).itemsize), "store": args.store,
+            # where the rows lie: the index was moved into the fastest of `candidates` allocations when it was set up (ffx_index_reseat =
+            # InMemoryIndex.consolidate(); probe_ms: a 2 M-row random gather over each; chosen 0 = the one hipMalloc gave first)
+            "placement": placement,
         },
         "roofline": {
             "bound": "hbm", "kernel": f"gather_dot (variant {st['kernel_variant']})",

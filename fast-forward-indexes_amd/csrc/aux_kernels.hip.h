@@ -731,4 +731,46 @@ combine_segments_kernel(const float* __restrict__ rs_v, int n_rows, int S, int B
   rs[r] = v[0];
 }
 
+// ---- placement probe (ffx_index_reseat) -------------------------------------------------------------------------------------
+// Whole rows read at random, the way gather_dot reads them: a wave takes 8 rows, 4 at a time, every row in 16-byte coalesced
+// non-temporal loads (each 128-B line requested once).  No arithmetic worth the name: the kernel is there to be timed -- a random
+// gather over an allocation runs 3 - 6 % faster or slower with the physical memory the allocation was handed.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+placement_probe_kernel(const u32x4* __restrict__ base, long n_rows, int row_vec, long n_probe, unsigned long long seed, unsigned* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long first = wave * 8;
+  if (first >= n_probe) return;
+  unsigned acc = 0;
+#pragma unroll 1
+  for (int b = 0; b < 8; b += 4) {
+    const u32x4* row[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      unsigned long long h = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(first + b + u + 1);  // splitmix64
+      h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+      h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+      h ^= h >> 31;
+      row[u] = base + (long)(h % (unsigned long long)n_rows) * row_vec;
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < row_vec; c0 += 256) {  // (a 3072-byte row: one round of 3 loads per row, 12 in flight)
+      u32x4 v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = c0 + 64 * j + lane;
+          v[u][j] = c < row_vec ? __builtin_nontemporal_load(row[u] + c) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc ^= v[u][j].x ^ v[u][j].y ^ v[u][j].z ^ v[u][j].w;
+    }
+  }
+  sink[(wave * 64 + lane) & 65535] = acc;  // (what keeps the loads)
+}
+
 }  // namespace ffx

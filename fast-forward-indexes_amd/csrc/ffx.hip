@@ -600,6 +600,106 @@ int ffx_index_device_ptr(const ffx_index* idx, void** ptr) {
   return FFX_OK;
 }
 
+// the placement probe over one block of the index's size: time of a random gather of whole rows (best of three, after one uncounted launch)
+static int probe_placement(const ffx_index* idx, const void* block, unsigned* sink, hipEvent_t* ev, float* out_ms) {
+  const size_t row_bytes = (size_t)idx->dim * idx->elem;
+  const size_t bytes = std::max<size_t>((size_t)idx->capacity * row_bytes, 256);
+  // rows as the scoring kernels read them (16-byte loads); rows that are no multiple of 16 bytes (PQ codes): 128-byte lines
+  const bool whole = row_bytes >= 16 && row_bytes % 16 == 0;
+  const int row_vec = whole ? (int)(row_bytes / 16) : 8;
+  const long n_rows = whole ? (long)idx->capacity : (long)(bytes / 128);
+  if (n_rows < 1) return fail(FFX_BAD_ARG, "an empty index has no placement to probe");
+  long n_probe = (long)std::min<size_t>(size_t(1) << 21, (size_t(8) << 30) / ((size_t)row_vec * 16));
+  n_probe = std::max<long>(8, n_probe / 8 * 8);
+  float best = 0.f;
+  for (int rep_no = 0; rep_no < 4; ++rep_no) {  // (the first launch fills the upper levels of the translation caches and is not counted)
+    FFX_HIP(hipEventRecord(ev[0], nullptr));
+    ffx::placement_probe_kernel<<<blocks_for(n_probe, 32), 256, 0, nullptr>>>(static_cast<const ffx::u32x4*>(block), n_rows, row_vec, n_probe,
+                                                                             0x5eedull + rep_no, sink);
+    FFX_HIP(hipEventRecord(ev[1], nullptr));
+    FFX_HIP(hipEventSynchronize(ev[1]));
+    float ms = 0.f;
+    FFX_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    if (rep_no == 1 || (rep_no > 1 && ms < best)) best = ms;
+  }
+  *out_ms = best;
+  return FFX_OK;
+}
+
+// ffx_private.h: the probe alone, over the block the index has (tools/placement_probe.py compares it with the scoring kernel)
+int ffx_index_probe_placement(ffx_index* idx, float* ms) {
+  if (!idx || !ms) return fail(FFX_BAD_ARG, "NULL argument");
+  FFX_HIP(hipSetDevice(idx->device));
+  FFX_HIP(hipDeviceSynchronize());
+  DevBuf sink;
+  FFX_TRY(sink.ensure(65536 * sizeof(unsigned)));
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  FFX_HIP(hipEventCreate(&ev[0]));
+  hipError_t e = hipEventCreate(&ev[1]);
+  int rc = e == hipSuccess ? probe_placement(idx, idx->vectors, sink.as<unsigned>(), ev, ms) : fail(FFX_HIP_ERROR, "hipEventCreate: %s", hipGetErrorString(e));
+  for (int i = 0; i < 2; ++i)
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+  return rc;
+}
+
+// ffx.h: the rows move into the fastest of a few allocations.  How fast a random gather over 27 GB runs belongs to the
+// ALLOCATION: eight copies of the headline index side by side in one process score the same batch in 15.95 .. 16.92 ms, each
+// within 0.3 % of its own figure round after round (tools/placement_probe.py; the translation counters of HISTORY section 5
+// show two regimes of the L1 translation cache).  Nothing the library does at hipMalloc selects the memory it is handed; what
+// it can do is look at a few hands.
+int ffx_index_reseat(ffx_index* idx, int32_t tries, ffx_reseat_report* report) {
+  if (!idx) return fail(FFX_BAD_ARG, "NULL argument");
+  if (tries < 0 || tries > 7) return fail(FFX_BAD_ARG, "tries must be 0 .. 7");
+  FFX_HIP(hipSetDevice(idx->device));
+  const size_t row_bytes = (size_t)idx->dim * idx->elem;
+  const size_t bytes = std::max<size_t>((size_t)idx->capacity * row_bytes, 256);
+  ffx_reseat_report rep{};
+  rep.bytes = (int64_t)bytes;
+  rep.candidates = 1;
+  if (tries == 0 || bytes < (size_t(256) << 20)) {  // (a small index lies within the reach of the translation caches wherever it is)
+    if (report) *report = rep;
+    return FFX_OK;
+  }
+  FFX_HIP(hipDeviceSynchronize());  // nothing of this index may be in flight
+  std::vector<void*> blocks{idx->vectors};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  DevBuf sink;
+  struct Guard {  // whatever happens below: every block but the index's own goes back
+    std::vector<void*>& blocks;
+    ffx_index* idx;
+    hipEvent_t* ev;
+    ~Guard() {
+      for (void* p : blocks)
+        if (p && p != idx->vectors) (void)hipFree(p);
+      for (int i = 0; i < 2; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+  } guard{blocks, idx, ev};
+  for (int t = 0; t < tries; ++t) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();  // memory ran out: the candidates so far are the candidates
+      break;
+    }
+    blocks.push_back(p);
+  }
+  FFX_TRY(sink.ensure(65536 * sizeof(unsigned)));
+  FFX_HIP(hipEventCreate(&ev[0]));
+  FFX_HIP(hipEventCreate(&ev[1]));
+  for (size_t i = 0; i < blocks.size(); ++i) FFX_TRY(probe_placement(idx, blocks[i], sink.as<unsigned>(), ev, &rep.probe_ms[i]));
+  rep.candidates = (int32_t)blocks.size();
+  int chosen = 0;
+  for (int i = 1; i < rep.candidates; ++i)
+    if (rep.probe_ms[i] < rep.probe_ms[chosen]) chosen = i;
+  if (chosen != 0) {
+    FFX_HIP(hipMemcpy(blocks[(size_t)chosen], idx->vectors, bytes, hipMemcpyDeviceToDevice));
+    idx->vectors = blocks[(size_t)chosen];  // (the guard frees what the index does not hold: the block it had, and the losers)
+  }
+  rep.chosen = chosen;
+  if (report) *report = rep;
+  return FFX_OK;
+}
+
 int ffx_index_capacity(const ffx_index* idx, int64_t* rows) {
   if (!idx || !rows) return fail(FFX_BAD_ARG, "NULL argument");
   *rows = idx->capacity;

@@ -27,7 +27,7 @@ BUF_FF, BUF_INTERP, BUF_ORDER, BUF_QUERIES, BUF_PAIR_IDS, BUF_SPARSE = 0, 1, 2, 
 # every symbol include/ffx.h declares: the stable contract (tests check the library exports all of them) ...
 SYMBOLS = (
     "ffx_abi_version", "ffx_last_error", "ffx_device_count", "ffx_device_info", "ffx_index_create", "ffx_index_create_typed", "ffx_index_dtype",
-    "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr",
+    "ffx_index_set_codebook", "ffx_index_query_dim", "ffx_index_destroy", "ffx_index_dim", "ffx_index_capacity", "ffx_index_device_ptr", "ffx_index_reseat",
     "ffx_index_upload", "ffx_index_upload_rows", "ffx_index_copy_rows", "ffx_index_gather", "ffx_index_set_doc_rows", "ffx_index_set_psg_rows",
     "ffx_plan_create", "ffx_plan_destroy", "ffx_plan_set_queries", "ffx_plan_set_queries_device", "ffx_plan_set_pairs", "ffx_plan_run",
     "ffx_plan_set_pairs_lazy", "ffx_plan_early_stopping", "ffx_plan_fetch_scored", "ffx_plan_sync", "ffx_plan_fetch", "ffx_plan_stats",
@@ -43,7 +43,7 @@ SYMBOLS = (
 # ... and include/ffx_private.h: what this Python layer uses on top of it, no stability promise
 PRIVATE_SYMBOLS = (
     "ffx_index_upload_rows_async", "ffx_index_pull_rows_async", "ffx_index_upload_wait", "ffx_index_upload_after", "ffx_index_fill_synthetic",
-    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats", "ffx_host_xfer_release", "ffx_build_has_experiments",
+    "ffx_index_prepare_score", "ffx_host_fill_runs", "ffx_host_xfer_stats", "ffx_host_xfer_release", "ffx_build_has_experiments", "ffx_index_probe_placement",
     "ffx_plan_copy_pairs", "ffx_plan_set_pairs_device", "ffx_plan_recent_gather_ms", "ffx_merge_create", "ffx_merge_destroy", "ffx_merge_set",
     "ffx_merge_set_device", "ffx_merge_run", "ffx_merge_sync", "ffx_merge_fetch", "ffx_merge_device_ptr", "ffx_comm_rehearsal_inbox",
     "ffx_ids_lookup_packed", "ffx_ids_intern_packed", "ffx_ids_blob", "ffx_strings_code", "ffx_strings_code_offsets", "ffx_strings_code_offsets32", "ffx_strings_code_fixed", "ffx_host_repeated_in_groups", "ffx_buffer_free",
@@ -66,6 +66,11 @@ class Stats(C.Structure):
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+class ReseatReport(C.Structure):
+    """``ffx_reseat_report`` (include/ffx.h)."""
+    _fields_ = [("candidates", C.c_int32), ("chosen", C.c_int32), ("probe_ms", C.c_float * 8), ("bytes", C.c_int64)]
 
 
 class ShardStats(C.Structure):
@@ -146,6 +151,7 @@ def lib() -> C.CDLL:
         "ffx_index_dim": ([vp, P(i32)], C.c_int),
         "ffx_index_capacity": ([vp, P(i64)], C.c_int),
         "ffx_index_device_ptr": ([vp, P(vp)], C.c_int),
+        "ffx_index_reseat": ([vp, C.c_int32, P(ReseatReport)], C.c_int),
         "ffx_index_upload": ([vp, vp, i64, i64], C.c_int),
         "ffx_index_upload_rows": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
         "ffx_index_upload_rows_async": ([vp, vp, i64, i64, vp, i64, i64, i32], C.c_int),
@@ -216,6 +222,7 @@ def lib() -> C.CDLL:
         "ffx_host_stage_report": ([vp, i64, P(i64)], C.c_int),
         "ffx_host_xfer_stats": ([P(C.c_uint64), P(C.c_uint64)], C.c_int),
         "ffx_build_has_experiments": ([], C.c_int),
+        "ffx_index_probe_placement": ([vp, P(C.c_float)], C.c_int),
         "ffx_host_xfer_release": ([], C.c_int),
         "ffx_run_save": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, C.c_char_p], C.c_int),
         "ffx_run_save_coded": ([C.c_char_p, C.c_char_p, i64, i64, vp, C.c_char_p, i64, i64, vp, i64, vp, C.c_char_p], C.c_int),
@@ -456,6 +463,21 @@ class DeviceIndex:
         p = C.c_void_p()
         _check(lib().ffx_index_device_ptr(self._h, C.byref(p)))
         return p.value or 0
+
+    def reseat(self, tries: int = 3) -> dict:
+        """``ffx_index_reseat``: the rows move into the fastest of up to ``tries`` further allocations (a random gather over an
+        allocation runs 3 - 6 % faster or slower with the physical memory it was handed).  Transient memory: ``tries`` x the
+        index.  Returns what was measured."""
+        rep = ReseatReport()
+        _check(lib().ffx_index_reseat(self._h, int(tries), C.byref(rep)))
+        return {"candidates": int(rep.candidates), "chosen": int(rep.chosen), "probe_ms": [float(rep.probe_ms[i]) for i in range(rep.candidates)],
+                "bytes": int(rep.bytes)}
+
+    def probe_placement(self) -> float:
+        """Milliseconds of ``ffx_index_reseat``'s probe over the block this index has (a tool's view of what reseat compares)."""
+        ms = C.c_float()
+        _check(lib().ffx_index_probe_placement(self._h, C.byref(ms)))
+        return float(ms.value)
 
     def copy_rows_from(self, src: "DeviceIndex", n_rows: int) -> None:
         _check(lib().ffx_index_copy_rows(self._h, src._h, n_rows))

@@ -207,6 +207,10 @@ int ffx_host_fill_runs(const int64_t* off, int64_t n_runs, int32_t n_threads, in
  * call.  Not while another thread uses the index. */
 int ffx_index_prepare_score(ffx_index* idx, int64_t n_queries, int64_t n_pairs, int32_t has_sparse, int32_t ranked, int32_t page_locked_buffers);
 
+/* the placement probe of ffx_index_reseat alone, over the block the index has: milliseconds of a random gather of whole rows
+ * (tools/placement_probe.py compares its ranking of several indexes with the scoring kernel's) */
+int ffx_index_probe_placement(ffx_index* idx, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1458,6 +1458,59 @@ def test_one_shot_score_is_independent_of_slicing(monkeypatch, slice_pairs):
     idx.close()
 
 
+def test_rows_move_into_the_fastest_of_a_few_allocations():
+    """ffx_index_reseat (``DeviceIndex.reseat``, ``InMemoryIndex.consolidate``): candidates are allocated, timed with a random gather
+    of whole rows, the rows end up in the fastest one and everything scores to the same bits as before; a small index is
+    left where it is; what was measured comes back."""
+    n, d = 90_000, 768  # 276 MB: above the size below which nothing is tried
+    vectors = synth.rows(71, 0.05, 0, n, d)
+    idx = native.DeviceIndex(n, d)
+    idx.upload(vectors, 0)
+    idx.set_doc_rows(np.arange(n + 1), np.arange(n))
+    idx.set_psg_rows(np.arange(n))
+    rng = np.random.default_rng(3)
+    nq, k = 6, 700
+    queries = synth.rows(72, 0.05, 0, nq, d)
+    pair_off = np.arange(nq + 1, dtype=np.int64) * k
+    pair_ids = np.concatenate([rng.choice(n, size=k, replace=False) for _ in range(nq)]).astype(np.int32)
+    sparse = rng.random(nq * k, dtype=np.float32)
+    plan = native.Plan(idx)  # (a plan made BEFORE the move keeps working: the rows' address is read at launch)
+    plan.set_queries(queries)
+    plan.set_pairs(pair_off, pair_ids, sparse, 2)
+    plan.run(0.2, exact_sum=True, sort=True)
+    before = plan.fetch(interp=True, order=True)
+    where = idx.device_ptr()
+    rep = idx.reseat(3)
+    assert rep["candidates"] == 4 and 0 <= rep["chosen"] < 4 and rep["bytes"] == vectors.nbytes
+    assert len(rep["probe_ms"]) == 4 and all(ms > 0 for ms in rep["probe_ms"]) and rep["probe_ms"][rep["chosen"]] == min(rep["probe_ms"])
+    assert (idx.device_ptr() != where) == (rep["chosen"] != 0)
+    plan.run(0.2, exact_sum=True, sort=True)
+    after = plan.fetch(interp=True, order=True)
+    for x, y in zip(before, after):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    want, want_i = fo.score(vectors, np.arange(n + 1), np.arange(n), np.arange(n), queries, pair_off, pair_ids, 2, sparse, 0.2)
+    assert np.array_equal(bits(after[0]), bits(want)) and np.array_equal(bits(after[1]), bits(want_i))
+    pick = rng.choice(n, size=500, replace=False)
+    assert np.array_equal(idx.gather(pick), vectors[pick])
+    assert idx.reseat(0)["candidates"] == 1
+    plan.close()
+    idx.close()
+    small = native.DeviceIndex(1000, 64)
+    assert small.reseat(3) == {"candidates": 1, "chosen": 0, "probe_ms": [0.0], "bytes": 1000 * 64 * 4}
+    with pytest.raises(native.FFXError):
+        small.reseat(8)
+    small.close()
+    # the API: consolidate() is where the reference says "done adding" (index/memory.py:121-131)
+    from fast_forward_amd.encoder import LambdaEncoder
+    from fast_forward_amd.index import InMemoryIndex
+
+    api = InMemoryIndex(LambdaEncoder(lambda t: queries[int(t)]), init_size=n)
+    api.add(vectors, doc_ids=[f"D{i}" for i in range(n)])
+    api.consolidate(placement_tries=2)
+    assert api.last_placement["candidates"] == 3
+    api.close()
+
+
 def test_ordinary_memory_travels_through_the_librarys_own_blocks(monkeypatch):
     """csrc/host_xfer.h: arrays in ordinary memory above 1 MiB -- index rows, candidate lists, first-stage scores, result
     buffers, one slice or many, one staging thread or several -- are cut into pieces that go through page-locked blocks of

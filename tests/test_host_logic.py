@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert declared == set(names), (header, declared ^ set(names))
         found[header] = declared
     assert not (found["ffx.h"] & found["ffx_private.h"])
-    assert len(found["ffx.h"]) <= 85  # the contract stays small: helpers go to the private header
+    assert len(found["ffx.h"]) <= 86  # the contract stays small: helpers go to the private header
     lib = native.lib()
     for name in found["ffx.h"] | found["ffx_private.h"]:
         assert hasattr(lib, name), name
