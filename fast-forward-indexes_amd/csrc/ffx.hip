@@ -609,7 +609,7 @@ static int probe_placement(const ffx_index* idx, const void* block, unsigned* si
   const int row_vec = whole ? (int)(row_bytes / 16) : 8;
   const long n_rows = whole ? (long)idx->capacity : (long)(bytes / 128);
   if (n_rows < 1) return fail(FFX_BAD_ARG, "an empty index has no placement to probe");
-  long n_probe = (long)std::min<size_t>(size_t(1) << 21, (size_t(8) << 30) / ((size_t)row_vec * 16));
+  long n_probe = (long)std::min<size_t>(size_t(1) << 23, (size_t(32) << 30) / ((size_t)row_vec * 16));  // (8 M rows: ~4 ms at 3 KB a row)
   n_probe = std::max<long>(8, n_probe / 8 * 8);
   float best = 0.f;
   for (int rep_no = 0; rep_no < 4; ++rep_no) {  // (the first launch fills the upper levels of the translation caches and is not counted)
