@@ -66,9 +66,10 @@ def parse_args():
     ap.add_argument("--sort", dest="sort", action="store_true", default=True,
                     help="order every query's candidates on the device as part of the step (default)")
     ap.add_argument("--no-sort", dest="sort", action="store_false", help="leave the ordering out of the step")
-    ap.add_argument("--placement-tries", type=int, default=3,
+    ap.add_argument("--placement-tries", type=int, default=-1,
                     help="ffx_index_reseat after the index is filled (what InMemoryIndex.consolidate() does): the rows move into the fastest of "
-                         "up to this many further allocations; 0: the allocation stays where hipMalloc put it")
+                         "up to this many further allocations (-1, the library's default: as many as half of the free memory holds, at most 7); "
+                         "0: the allocation stays where hipMalloc put it")
     ap.add_argument("--no-regions", dest="regions", action="store_false", default=True,
                     help="skip the side measurements (host-to-host, Index API, stream ceiling) of the 1-GPU line")
     ap.add_argument("--api-queries", type=int, default=6980, help="queries of the Index-API region (iii); 0: skip")

@@ -178,15 +178,15 @@ class InMemoryIndex(Index):
             self._host_codes.append(np.array(codes, copy=True))
         self._n += n_new
 
-    def consolidate(self, placement_tries: int = 3) -> None:
+    def consolidate(self, placement_tries: int = -1) -> None:
         """The reference merges its chunks into one array here (index/memory.py:121-131).  The device store is one matrix
         already; what is left of "I am done adding, lay the vectors out for look-ups" is WHERE that matrix lies in HBM:
         ``ffx_index_reseat`` moves it into the fastest of up to ``placement_tries`` further allocations (how fast a random
         gather runs belongs to the allocation: copies of one 27 GB index score the same batch 3 - 6 % apart).  Stores below
-        256 MiB stay where they are; transient memory: ``placement_tries`` x the store, fewer when memory is short;
-        ``last_placement`` says what was measured.  ``placement_tries=0``: nothing happens (the reference's call has no
-        effect on results either)."""
-        if self._store is not None and placement_tries > 0:
+        256 MiB stay where they are; transient memory: ``placement_tries`` x the store (-1, the default: as many as half of the
+        free memory holds, at most 7); ``last_placement`` says what was measured.  ``placement_tries=0``: nothing happens (the
+        reference's call has no effect on results either)."""
+        if self._store is not None and placement_tries != 0:
             self.last_placement = self._store.reseat(placement_tries)
 
     def _sync_ids(self) -> None:

@@ -70,7 +70,8 @@ class Stats(C.Structure):
 
 class ReseatReport(C.Structure):
     """``ffx_reseat_report`` (include/ffx.h)."""
-    _fields_ = [("candidates", C.c_int32), ("chosen", C.c_int32), ("probe_ms", C.c_float * 8), ("bytes", C.c_int64)]
+    _fields_ = [("candidates", C.c_int32), ("chosen", C.c_int32), ("probe_ms", C.c_float * 8), ("bytes", C.c_int64), ("settle_s", C.c_float),
+                ("probe_ms_settled", C.c_float)]
 
 
 class ShardStats(C.Structure):
@@ -464,14 +465,14 @@ class DeviceIndex:
         _check(lib().ffx_index_device_ptr(self._h, C.byref(p)))
         return p.value or 0
 
-    def reseat(self, tries: int = 3) -> dict:
+    def reseat(self, tries: int = -1) -> dict:
         """``ffx_index_reseat``: the rows move into the fastest of up to ``tries`` further allocations (a random gather over an
-        allocation runs 3 - 6 % faster or slower with the physical memory it was handed).  Transient memory: ``tries`` x the
-        index.  Returns what was measured."""
+        allocation runs 3 - 9 % faster or slower with the physical memory it was handed).  ``tries=-1``: as many as half of the
+        free memory holds, at most 7.  Transient memory: ``tries`` x the index.  Returns what was measured."""
         rep = ReseatReport()
         _check(lib().ffx_index_reseat(self._h, int(tries), C.byref(rep)))
         return {"candidates": int(rep.candidates), "chosen": int(rep.chosen), "probe_ms": [float(rep.probe_ms[i]) for i in range(rep.candidates)],
-                "bytes": int(rep.bytes)}
+                "bytes": int(rep.bytes), "settle_s": float(rep.settle_s), "probe_ms_settled": float(rep.probe_ms_settled)}
 
     def probe_placement(self) -> float:
         """Milliseconds of ``ffx_index_reseat``'s probe over the block this index has (a tool's view of what reseat compares)."""
