@@ -410,6 +410,12 @@ class _ShardedIndex:
         """``Index.encode_queries`` (base.py:58-72): every rank encodes the same queries."""
         return self.local.encode_queries(queries)
 
+    def consolidate(self, placement_tries: int = -1) -> None:
+        """``InMemoryIndex.consolidate`` on this rank's shard (not collective: every rank re-seats the rows it holds)."""
+        fn = getattr(self.local, "consolidate", None)
+        if fn is not None:
+            fn(placement_tries)
+
     def _all_ids(self, mine: set) -> set:
         """The union of every rank's id strings (collective; the ids travel once per rank: one buffer of the UTF-8 bytes laid
         back to back plus their lengths -- an id may hold any character, a newline included)."""

@@ -38,6 +38,7 @@ def main(rank=None, world=None):
         pair_q = np.repeat(np.arange(len(case.q_names)), np.diff(pair_off))
         first = Ranking(pd.DataFrame({"q_id": [case.q_names[q] for q in pair_q], "id": names, "score": sparse}),
                         queries={q: str(i) for i, q in enumerate(case.q_names)})
+        idx.consolidate()  # (a shard of this size stays where it is; the call is every rank's own)
         dense = idx(first, gather=True)
         exp = case.expected_order(f"{mode}_ff")
         assert dense._df["q_id"].tolist() == case.z[f"{mode}_ff_q_id"].tolist()
