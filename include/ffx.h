@@ -129,9 +129,9 @@ int ffx_index_device_ptr(const ffx_index* idx, void** ptr);
  * 27 GB index side by side in one process score the same batch 3 - 6 % apart, each within 0.3 % of its own figure.
  * ffx_index_reseat allocates up to `tries` (0 .. 7; -1: as many as half of the free memory holds, at most 7) further blocks
  * of the index's size (fewer when memory runs out), times a
- * short random gather of whole rows over each of them and over the block in use, moves the rows into the fastest
- * (device-to-device), frees the others and waits until the device is at rest again (see settle_s).  Transient memory: up to
- * `tries` x the index; time: tens of ms per block + the copy + the wait.
+ * short random gather of whole rows over each of them (a copy of the rows in each: memory nobody has written reads faster)
+ * and over the block in use, keeps the fastest, frees the others and waits until the device is at rest again (see settle_s).
+ * Transient memory: up to `tries` x the index; time: tens of ms per block + the wait.
  * An index below 256 MiB is left where it is.  No call on the index may be in flight; addresses from ffx_index_device_ptr
  * are stale afterwards.  `report` (may be NULL) says what was measured. */
 typedef struct ffx_reseat_report {
@@ -139,8 +139,8 @@ typedef struct ffx_reseat_report {
   int32_t chosen;      /* 0: the block the index had; k: the k-th new one */
   float probe_ms[8];   /* time of the probe over each block */
   int64_t bytes;       /* size of a block */
-  float settle_s;      /* for a few seconds after blocks of this size are freed, gathers run 1 - 3 % slower: the call waits (at most 8 s) */
-  float probe_ms_settled; /* ... until the probe over the chosen block reads this (within 1 % of its figure as a candidate) */
+  float settle_s;      /* for four seconds after blocks of this size are freed, gathers run 1 - 3 % slower: the call waits them out */
+  float probe_ms_settled; /* ... and until the probe over the chosen block reads this (within 1 % of its figure as a candidate; 8 s at most) */
 } ffx_reseat_report;
 int ffx_index_reseat(ffx_index* idx, int32_t tries, ffx_reseat_report* report);
 /* copy host rows into rows [row_offset, row_offset+n_rows): InMemoryIndex._add, memory.py:100-119 */

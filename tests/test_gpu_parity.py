@@ -1484,7 +1484,7 @@ def test_rows_move_into_the_fastest_of_a_few_allocations():
     assert rep["candidates"] == 4 and 0 <= rep["chosen"] < 4 and rep["bytes"] == vectors.nbytes
     assert len(rep["probe_ms"]) == 4 and all(ms > 0 for ms in rep["probe_ms"]) and rep["probe_ms"][rep["chosen"]] == min(rep["probe_ms"])
     assert (idx.device_ptr() != where) == (rep["chosen"] != 0)
-    assert 0 <= rep["settle_s"] < 10 and rep["probe_ms_settled"] > 0
+    assert 4 <= rep["settle_s"] < 10 and rep["probe_ms_settled"] > 0  # (the slow spell after the losers are freed is waited out)
     plan.run(0.2, exact_sum=True, sort=True)
     after = plan.fetch(interp=True, order=True)
     for x, y in zip(before, after):
@@ -1494,7 +1494,6 @@ def test_rows_move_into_the_fastest_of_a_few_allocations():
     pick = rng.choice(n, size=500, replace=False)
     assert np.array_equal(idx.gather(pick), vectors[pick])
     assert idx.reseat(0)["candidates"] == 1
-    assert idx.reseat()["candidates"] == 8  # (-1: as many as half of the free memory holds, at most 7 -- 276 MB a block on an empty card)
     plan.close()
     idx.close()
     small = native.DeviceIndex(1000, 64)
@@ -1508,8 +1507,8 @@ def test_rows_move_into_the_fastest_of_a_few_allocations():
 
     api = InMemoryIndex(LambdaEncoder(lambda t: queries[int(t)]), init_size=n)
     api.add(vectors, doc_ids=[f"D{i}" for i in range(n)])
-    api.consolidate(placement_tries=2)
-    assert api.last_placement["candidates"] == 3
+    api.consolidate()  # (the default: as many candidates as half of the free memory holds, at most 7 -- 276 MB a block on an empty card)
+    assert api.last_placement["candidates"] == 8 and api.last_placement["settle_s"] >= 4
     api.close()
 
 
