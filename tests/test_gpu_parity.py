@@ -716,7 +716,7 @@ def test_sharded_bench_leg_with_ranks_sharing_the_gpu(world, sharding, spelling)
 
     root = Path(__file__).resolve().parent.parent
     cmd = [sys.executable, str(root / "bench.py"), "--gpus", str(world), *spelling.split(),  # (--dist-backend gloo: round 1's spelling of the same)
-           "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "12",
+           "--placement-tries", "0", "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "12",
            "--cpu-seconds", "0.2", "--sharding", sharding]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -748,7 +748,7 @@ def test_sharded_bench_falls_back_together_when_rccl_cannot_come_up():
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "3",
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--placement-tries", "0", "--rows", "300000", "--queries", "90", "--k", "700", "--steps", "3",
            "--warmup", "1", "--cpu-sample-queries", "12", "--cpu-seconds", "0.2"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["HIP_VISIBLE_DEVICES"] = "0"
@@ -779,7 +779,7 @@ def test_rehearsal_of_one_rank_of_eight_on_one_gpu():
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    cmd = [sys.executable, str(root / "bench.py"), "--as-rank-of", "8", "--as-rank", "5", "--rows", "400000", "--queries", "160", "--k", "900",
+    cmd = [sys.executable, str(root / "bench.py"), "--as-rank-of", "8", "--as-rank", "5", "--placement-tries", "0", "--rows", "400000", "--queries", "160", "--k", "900",
            "--steps", "6", "--warmup", "2", "--cpu-sample-queries", "6", "--cpu-seconds", "0.2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -856,7 +856,7 @@ def test_device_routing_equals_host_routing(monkeypatch):
     shard.close()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])  # (five processes of one rank ran here until eight ranks in four processes did: 28 s the suite can do without)
 def test_owner_routed_fresh_batches_with_ranks_sharing_the_gpu(world):
     """ffx_sharded_stage_owned / ffx_sharded_score: every rank is handed only the queries it owns, finds the holders on the
     device and sends them the ordinals in a first all-to-all; results equal the single-GPU scorer over the whole index bit for
@@ -884,7 +884,7 @@ def test_sharded_bench_leg_also_runs_under_torchrun():
     root = Path(__file__).resolve().parent.parent
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29712", str(root / "bench.py"), "--gpus", "2", "--transport", "host",
-           "--rows", "200000", "--queries", "60", "--k", "500", "--steps", "3", "--warmup", "1", "--cpu-sample-queries", "8", "--cpu-seconds", "0.2"]
+           "--placement-tries", "0", "--rows", "200000", "--queries", "60", "--k", "500", "--steps", "3", "--warmup", "1", "--cpu-sample-queries", "8", "--cpu-seconds", "0.2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     result = json.loads(next(ln for ln in out.stdout.splitlines() if ln.startswith("{")))
@@ -901,7 +901,7 @@ def test_single_rank_rccl_bench_leg_matches_the_plain_leg():
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    common = ["--rows", "2000000", "--queries", "400", "--k", "5000", "--steps", "10", "--warmup", "3", "--cpu-sample-queries", "4",
+    common = ["--placement-tries", "0", "--rows", "2000000", "--queries", "400", "--k", "5000", "--steps", "10", "--warmup", "3", "--cpu-sample-queries", "4",
               "--cpu-seconds", "0.2", "--no-regions", "--no-traffic"]
     vals = {}
     for name, extra in (("plain", []), ("sharded", ["--force-sharded"])):
@@ -913,7 +913,7 @@ def test_single_rank_rccl_bench_leg_matches_the_plain_leg():
     assert vals["sharded"]["value"] > 0.9 * vals["plain"]["value"], (vals["sharded"]["value"], vals["plain"]["value"])
     # documents of several passages: the sharded scorer's plans derive their rows inside gather_dot too (variant 311), replayed
     # and fresh batches bit-exact against the oracle
-    out = subprocess.run([sys.executable, str(root / "bench.py"), "--layout", "multi", "--force-sharded", "--rows", "1000000", "--queries", "300",
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--layout", "multi", "--force-sharded", "--placement-tries", "0", "--rows", "1000000", "--queries", "300",
                           "--k", "1500", "--steps", "4", "--warmup", "1", "--cpu-sample-queries", "8", "--cpu-seconds", "0.2"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -1480,9 +1480,9 @@ def test_rows_move_into_the_fastest_of_a_few_allocations():
     plan.run(0.2, exact_sum=True, sort=True)
     before = plan.fetch(interp=True, order=True)
     where = idx.device_ptr()
-    rep = idx.reseat(3)
-    assert rep["candidates"] == 4 and 0 <= rep["chosen"] < 4 and rep["bytes"] == vectors.nbytes
-    assert len(rep["probe_ms"]) == 4 and all(ms > 0 for ms in rep["probe_ms"]) and rep["probe_ms"][rep["chosen"]] == min(rep["probe_ms"])
+    rep = idx.reseat()  # (the default: as many candidates as half of the free memory holds, at most 7 -- 276 MB a block on an empty card)
+    assert rep["candidates"] == 8 and 0 <= rep["chosen"] < 8 and rep["bytes"] == vectors.nbytes
+    assert len(rep["probe_ms"]) == 8 and all(ms > 0 for ms in rep["probe_ms"]) and rep["probe_ms"][rep["chosen"]] == min(rep["probe_ms"])
     assert (idx.device_ptr() != where) == (rep["chosen"] != 0)
     assert 4 <= rep["settle_s"] < 10 and rep["probe_ms_settled"] > 0  # (the slow spell after the losers are freed is waited out)
     plan.run(0.2, exact_sum=True, sort=True)
@@ -1505,10 +1505,10 @@ def test_rows_move_into_the_fastest_of_a_few_allocations():
     from fast_forward_amd.encoder import LambdaEncoder
     from fast_forward_amd.index import InMemoryIndex
 
-    api = InMemoryIndex(LambdaEncoder(lambda t: queries[int(t)]), init_size=n)
-    api.add(vectors, doc_ids=[f"D{i}" for i in range(n)])
-    api.consolidate()  # (the default: as many candidates as half of the free memory holds, at most 7 -- 276 MB a block on an empty card)
-    assert api.last_placement["candidates"] == 8 and api.last_placement["settle_s"] >= 4
+    api = InMemoryIndex(LambdaEncoder(lambda t: queries[int(t)]), init_size=2000)
+    api.add(vectors[:2000], doc_ids=[f"D{i}" for i in range(2000)])
+    api.consolidate()  # (a store of this size stays where it is: the wiring is what is looked at -- the wait above is not paid twice)
+    assert api.last_placement == {"candidates": 1, "chosen": 0, "probe_ms": [0.0], "bytes": 2000 * d * 4, "settle_s": 0.0, "probe_ms_settled": 0.0}
     api.close()
 
 
