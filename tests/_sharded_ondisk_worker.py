@@ -179,27 +179,6 @@ def main(rank=None, world=None):
 
 
 if __name__ == "__main__":
-    import os
+    import _rank_threads
 
-    here = os.environ.get("FFX_RANKS_HERE")
-    if not here:
-        main()
-    else:  # several ranks in this process, a thread each (tests/_sharded_owned_worker.py says why)
-        import threading
-        import traceback
-
-        failed = []
-
-        def one_rank(r):
-            try:
-                main(r, int(os.environ["WORLD_SIZE"]))
-            except BaseException:  # noqa: BLE001
-                failed.append(r)
-                traceback.print_exc()
-
-        threads = [threading.Thread(target=one_rank, args=(int(r),)) for r in here.split(",")]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        sys.exit(1 if failed else 0)
+    _rank_threads.run(main)

@@ -183,28 +183,6 @@ def main(rank=None, world=None):
 
 
 if __name__ == "__main__":
-    here = os.environ.get("FFX_RANKS_HERE")
-    if not here:
-        main()
-    else:
-        # several ranks in this process, a thread each (every rank has its own communicator handle, indexes and scorer; the calls
-        # that wait for other ranks are C calls, which release the interpreter): eight ranks against one GPU where the box admits
-        # six processes to it
-        import threading
-        import traceback
+    import _rank_threads
 
-        failed = []
-
-        def one(r):
-            try:
-                main(r, int(os.environ["WORLD_SIZE"]))
-            except BaseException:  # noqa: BLE001 (SystemExit too: a rank that gives up must fail the process)
-                failed.append(r)
-                traceback.print_exc()
-
-        threads = [threading.Thread(target=one, args=(int(r),)) for r in here.split(",")]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        sys.exit(1 if failed else 0)
+    _rank_threads.run(main)
