@@ -7,7 +7,8 @@ round 2 (any-d kernel, in-LDS sort): 600 + 600 configurations (seeds 2 and 3), a
 (ffx_score's single-submission path for small single-row batches; slices through three plans with asynchronous
 copies into page-locked results or helper threads into ordinary ones): seeds 4 and 5, see HISTORY.md; round 3 (segments
 for long rows, uploads of all slices on one stream): 600 + 600 configurations (seeds 8 and 9), all bit-exact; round 5 (staged
-transfers of ordinary memory, four plans, rows derived inside gather_dot; one configuration in eight LARGE): seeds 10 and 11."""
+transfers of ordinary memory, four plans, rows derived inside gather_dot; one configuration in eight LARGE): seeds 10 and 11; 12 - 17 after the
+one-row derive, the query hint, the fast-order derive, graded staging and ffx_index_reseat went in (320 configurations each)."""
 import argparse
 import os
 import sys
