@@ -1494,6 +1494,7 @@ def test_rows_move_into_the_fastest_of_a_few_allocations():
     pick = rng.choice(n, size=500, replace=False)
     assert np.array_equal(idx.gather(pick), vectors[pick])
     assert idx.reseat(0)["candidates"] == 1
+    assert 0 < idx.probe_placement() < 100  # (the probe alone, as tools/placement_probe.py uses it: milliseconds)
     plan.close()
     idx.close()
     small = native.DeviceIndex(1000, 64)
